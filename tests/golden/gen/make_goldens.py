@@ -1,0 +1,273 @@
+"""Generates the golden vectors under tests/golden/ by executing the reference's own Python
+source (read from /root/reference, never copied) on top of `tf_numpy_shim`.
+
+Run in the development container only:   python tests/golden/gen/make_goldens.py
+The resulting .npz files hold ONLY data: inputs, parameters, the random tape (raw N(0,1)/U[0,1)
+draws in call order) and the reference's outputs.  See tests/golden/README.md for the list.
+"""
+import os
+import sys
+import importlib.util
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.dirname(HERE)
+REPO = os.path.dirname(os.path.dirname(OUT))
+REF = '/root/reference'
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import tf_numpy_shim as shim  # noqa: E402
+
+FEED = []
+NAMED = shim.install(FEED, REF)
+
+# reference modules (executed verbatim from /root/reference)
+from ext.neuron import utils as nrn_utils  # noqa: E402
+from ext.lab2im import utils as l2i_utils  # noqa: E402
+from ext.lab2im import edit_tensors as l2i_et  # noqa: E402
+from ext.lab2im import layers as l2i_layers  # noqa: E402
+from ext.lab2im import edit_volumes as l2i_ev  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location('ref_l2i_model', os.path.join(REF, 'SynthSR', 'labels_to_image_model.py'))
+ref_l2i_model = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(ref_l2i_model)
+
+from synthsr_amd.nifti import read_nifti  # noqa: E402
+
+T = shim.T
+t = shim.t
+
+
+def tape_to_dict(tape, prefix='tape'):
+    d = {'%s_kinds' % prefix: np.array([k for k, _ in tape.entries])}
+    for i, (_, a) in enumerate(tape.entries):
+        d['%s_%02d' % (prefix, i)] = a
+    return d
+
+
+def load_label_crop(which=1, origin=(60, 70, 60), shape=(32, 32, 32)):
+    lab, aff, _ = read_nifti(os.path.join(REF, 'data', 'labels', 'brain%d_labels.nii.gz' % which))
+    lab = np.round(lab).astype(np.int32)
+    sl = tuple(slice(o, o + s) for o, s in zip(origin, shape))
+    return np.ascontiguousarray(lab[sl])
+
+
+GEN_LABELS = np.load(os.path.join(REF, 'data', 'labels_classes_priors', 'generation_labels.npy'))
+GEN_CLASSES = np.load(os.path.join(REF, 'data', 'labels_classes_priors', 'generation_classes.npy'))
+
+
+def class_stats(rng, names=('t1_hr',)):
+    means, stds = [], []
+    for nm in names:
+        pm = np.load(os.path.join(REF, 'data', 'labels_classes_priors', 'prior_means_%s.npy' % nm))
+        ps = np.load(os.path.join(REF, 'data', 'labels_classes_priors', 'prior_stds_%s.npy' % nm))
+        m = np.clip(rng.normal(pm[0], pm[1]), 0, None)[GEN_CLASSES]
+        s = np.clip(rng.normal(ps[0], ps[1]), 0, None)[GEN_CLASSES]
+        means.append(m)
+        stds.append(s)
+    return (np.stack(means, -1)[None].astype(np.float32), np.stack(stds, -1)[None].astype(np.float32))
+
+
+# ----------------------------------------------------------------------------- unit goldens
+def golden_resampler():
+    """interpn / resize / integrate_vec / combine_non_linear_and_aff_to_shift (ext/neuron/utils.py)"""
+    rng = np.random.default_rng(11)
+    out = {}
+    # resize linear 5^3x3 -> 16^3x3 (same code path as 5->80), and anisotropic 3x4x5 -> 12x10x9
+    small = rng.standard_normal((5, 5, 5, 3)).astype(np.float32)
+    out['rs_small'] = small
+    out['rs_lin_16'] = np.asarray(nrn_utils.resize(t(small), [16 / 5] * 3, [16] * 3, 'linear'))
+    small2 = rng.standard_normal((3, 4, 5, 2)).astype(np.float32)
+    out['rs_small2'] = small2
+    out['rs_lin_aniso'] = np.asarray(nrn_utils.resize(t(small2), [12 / 3, 10 / 4, 9 / 5], [12, 10, 9], 'linear'))
+    # nearest down-resize 12x10x9 -> 8x4x3
+    vol = rng.standard_normal((12, 10, 9, 1)).astype(np.float32)
+    out['rs_vol'] = vol
+    out['rs_near_down'] = np.asarray(nrn_utils.resize(t(vol), [8 / 12, 4 / 10, 3 / 9], [8, 4, 3], 'nearest'))
+    # 1-D known answers quoted in SURVEY H6 / H16
+    ramp = np.arange(5, dtype=np.float32)[:, None, None, None] * np.ones((1, 2, 2, 1), np.float32)
+    out['rs_ramp80'] = np.asarray(nrn_utils.resize(t(ramp), [16., 1., 1.], [80, 2, 2], 'linear'))[:, 0, 0, 0]
+    # integrate_vec (7 steps) on a 16^3 field
+    vel = (3.0 * out['rs_lin_16']).astype(np.float32)
+    out['iv_in'] = vel
+    out['iv_out'] = np.asarray(nrn_utils.integrate_vec(t(vel), method='ss', nb_steps=7))
+    # affine + elastic -> shift -> nearest / linear sampling
+    aff = np.eye(4, dtype=np.float32)
+    aff[:3, :3] += rng.uniform(-.1, .1, (3, 3)).astype(np.float32)
+    aff[:3, 3] = rng.uniform(-2, 2, 3).astype(np.float32)
+    field = out['iv_out']
+    lab = load_label_crop(1, (60, 70, 60), (16, 16, 16)).astype(np.float32)[..., None]
+    shift = nrn_utils.combine_non_linear_and_aff_to_shift([t(field), t(aff)], [16, 16, 16], shift_center=True)
+    out['st_aff'] = aff
+    out['st_field'] = field
+    out['st_labels'] = lab
+    out['st_shift'] = np.asarray(shift)
+    out['st_nearest'] = np.asarray(nrn_utils.transform(t(lab), shift, 'nearest'))
+    img = rng.standard_normal((16, 16, 16, 1)).astype(np.float32)
+    out['st_img'] = img
+    out['st_linear'] = np.asarray(nrn_utils.transform(t(img), shift, 'linear'))
+    ashift = nrn_utils.affine_to_shift(t(aff), [16, 16, 16], shift_center=True)
+    out['st_affine_only_shift'] = np.asarray(ashift)
+    out['st_affine_only_linear'] = np.asarray(nrn_utils.transform(t(img), ashift, 'linear'))
+    np.savez_compressed(os.path.join(OUT, 'resampler.npz'), **out)
+    print('resampler.npz', {k: v.shape for k, v in out.items()})
+
+
+def golden_host_math():
+    """pure-numpy helpers + affine sampling + gaussian kernels"""
+    out = {}
+    # get_shapes cases: (labels_shape, output_shape, atlas_res, target_res, padding_margin, div_by_n)
+    cases = [([160, 160, 160], None, [1., 1., 1.], [1., 1., 1.], None, 32),
+             ([148, 187, 155], None, [1., 1., 1.], [1., 1., 1.], None, 32),
+             ([148, 187, 155], 128, [1., 1., 1.], [1., 1., 1.], None, 32),
+             ([148, 187, 155], [96, 128, 100], [1., 1., 1.], [1., 1., 1.], 8, 32),
+             ([148, 187, 155], 160, [1., 1., 1.], [.7, .7, .7], None, 32),
+             ([192, 192, 192], 192, [1., 1., 1.], [1., 1., 1.], None, None),
+             ([40, 48, 36], 32, [1., 1., 1.], [1., 1., 1.], None, 32)]
+    res = []
+    for c in cases:
+        crop, outs, pad = ref_l2i_model.get_shapes(list(c[0]), c[1], c[2], c[3], c[4], c[5])
+        res.append(list(crop) + list(outs))
+    out['get_shapes_in'] = np.array([[*c[0], -1 if c[1] is None else (c[1] if np.isscalar(c[1]) else -2),
+                                      -1 if c[4] is None else c[4], -1 if c[5] is None else c[5]] for c in cases])
+    out['get_shapes_out'] = np.array(res)
+    # sample_affine_transform with a tape
+    tape = shim.Tape(seed=5)
+    shim.set_tape(tape)
+    Tm = l2i_utils.sample_affine_transform(t(np.array([2], np.int32)), 3, rotation_bounds=15, scaling_bounds=.15,
+                                           shearing_bounds=.02, translation_bounds=5)
+    out['affine_T'] = np.asarray(Tm)
+    out.update(tape_to_dict(tape, 'affine_tape'))
+    # gaussian kernels
+    for name, sig in [('k050', [.5] * 3), ('k042', [.42] * 3), ('khyp', [.63, .63, 2.1])]:
+        out['gk_' + name] = np.asarray(l2i_et.gaussian_kernel(sig, separable=False))[..., 0, 0]
+    tape = shim.Tape(seed=6)
+    shim.set_tape(tape)
+    out['gk_rand'] = np.asarray(l2i_et.gaussian_kernel([.42] * 3, blur_range=1.15, separable=False))[..., 0, 0]
+    out.update(tape_to_dict(tape, 'gk_rand_tape'))
+    # blurring sigma
+    out['sigma_lr'] = l2i_et.blurring_sigma_for_downsampling([1., 1., 1.], [1.5, 1.5, 5.], .42, [1.5, 1.5, 5.])
+    out['sigma_tgt'] = l2i_et.blurring_sigma_for_downsampling([1., 1., 1.], [1., 1., 1.])
+    # mapping lut for a sided label list
+    lab_list = np.array([0, 14, 15, 2, 3, 4, 41, 42, 43])
+    out['swap_lut'] = l2i_utils.get_mapping_lut(lab_list, np.concatenate([lab_list[:3], lab_list[6:], lab_list[3:6]]))
+    out['swap_lut_labels'] = lab_list
+    np.savez_compressed(os.path.join(OUT, 'host_math.npz'), **out)
+    print('host_math.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
+
+
+def golden_layers():
+    """call() bodies of the hot lab2im layers, each with its own tape (ext/lab2im/layers.py)"""
+    out = {}
+    rng = np.random.default_rng(21)
+    lab = load_label_crop(2, (55, 80, 60), (24, 20, 28))[None, ..., None]
+    means, stds = class_stats(rng, ('t1_hr', 't2'))
+    # SampleConditionalGMM, 2 channels
+    tape = shim.Tape(seed=31)
+    shim.set_tape(tape)
+    img = l2i_layers.SampleConditionalGMM(GEN_LABELS)([t(lab), t(means), t(stds)])
+    out['gmm_labels'], out['gmm_means'], out['gmm_stds'], out['gmm_out'] = lab, means, stds, np.asarray(img)
+    out.update(tape_to_dict(tape, 'gmm_tape'))
+    # BiasFieldCorruption on one channel
+    chan = np.asarray(img)[..., :1]
+    tape = shim.Tape(seed=32)
+    shim.set_tape(tape)
+    b = l2i_layers.BiasFieldCorruption(.3, .25, False)(t(chan))
+    out['bias_in'], out['bias_out'] = chan, np.asarray(b)
+    out.update(tape_to_dict(tape, 'bias_tape'))
+    # IntensityAugmentation
+    tape = shim.Tape(seed=33)
+    shim.set_tape(tape)
+    ia = l2i_layers.IntensityAugmentation(clip=300, normalise=True, gamma_std=.5)(t(np.asarray(b)))
+    out['ia_in'], out['ia_out'] = np.asarray(b), np.asarray(ia)
+    out.update(tape_to_dict(tape, 'ia_tape'))
+    # GaussianBlur fixed and randomised
+    g1 = l2i_layers.GaussianBlur(sigma=.5)(t(np.asarray(ia)))
+    out['blur_in'], out['blur_s050'] = np.asarray(ia), np.asarray(g1)
+    tape = shim.Tape(seed=34)
+    shim.set_tape(tape)
+    g2 = l2i_layers.GaussianBlur([.63, .63, 2.1], 1.15)(t(np.asarray(g1)))
+    out['blur_hyp_rand'] = np.asarray(g2)
+    out.update(tape_to_dict(tape, 'blur_tape'))
+    # RandomFlip with sided labels (swap active): list = [neutral(3) | left(3) | right(3)]
+    lab_list = np.array([0, 14, 15, 2, 3, 4, 41, 42, 43])
+    fl_in = lab_list[rng.integers(0, 9, (1, 6, 5, 4, 1))].astype(np.int32)
+    for seed in (35, 39, 43):
+        tape = shim.Tape(seed=seed)
+        shim.set_tape(tape)
+        fo = l2i_layers.RandomFlip(0, True, lab_list, 3)(t(fl_in))
+        out['flip_out_%d' % seed] = np.asarray(fo)
+        out.update(tape_to_dict(tape, 'flip_tape_%d' % seed))
+    out['flip_in'], out['flip_label_list'] = fl_in, lab_list
+    # resample_tensor with downsampling + reliability map (Hyperfine-like 1.5x1.5x5)
+    vol = rng.standard_normal((1, 24, 24, 30, 1)).astype(np.float32)
+    r, m = l2i_et.resample_tensor(t(vol), [24, 24, 30], 'linear', [1.5, 1.5, 5.], [1., 1., 1.], True)
+    out['rt_in'], out['rt_out'], out['rt_map'] = vol, np.asarray(r), np.asarray(m)
+    np.savez_compressed(os.path.join(OUT, 'layers.npz'), **out)
+    print('layers.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
+
+
+def run_graph(name, labels, means, stds, seed, **kw):
+    """whole labels_to_image_model() graph (SynthSR/labels_to_image_model.py:32-266)"""
+    tape = shim.Tape(seed=seed)
+    shim.set_tape(tape)
+    NAMED.clear()
+    FEED[:] = [('labels_input', labels), ('means_input', means), ('std_devs_input', stds)]
+    model = ref_l2i_model.labels_to_image_model(labels_shape=list(labels.shape[1:4]),
+                                                generation_labels=GEN_LABELS,
+                                                n_neutral_labels=len(GEN_LABELS),
+                                                aff=np.eye(4), **kw)
+    image, target = model.outputs
+    out = dict(labels=labels, means=means, stds=stds, image=np.asarray(image), target=np.asarray(target),
+               seg=np.asarray(NAMED['segmentation_target']))
+    out.update(tape_to_dict(tape))
+    for k, v in kw.items():
+        if v is None:
+            continue
+        out['kw_' + k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'image', out['image'].shape, 'target', out['target'].shape, 'tape', len(tape.entries),
+          [(k, a.shape) for k, a in tape.entries])
+
+
+def golden_graphs():
+    rng = np.random.default_rng(41)
+    train_defaults = dict(atlas_res=[1., 1., 1.], target_res=None, output_div_by_n=32, padding_margin=None,
+                          flipping=True, scaling_bounds=.15, rotation_bounds=15, shearing_bounds=.02,
+                          translation_bounds=5, nonlin_std=4., nonlin_shape_factor=.03125 * 4,
+                          simulate_registration_error=True, randomise_res=False, data_res=None, thickness=None,
+                          downsample=True, build_reliability_maps=True, blur_range=1.15, bias_field_std=.3,
+                          bias_shape_factor=.03125 * 4)
+    # (a) config-2 structure at 32^3: 1 channel, training() defaults (shape factors x4 so the small grids are 4^3)
+    lab = load_label_crop(1, (58, 78, 62), (32, 32, 32))[None, ..., None]
+    means, stds = class_stats(rng)
+    for seed in (101, 102, 103):
+        run_graph('graph_c2_s%d' % seed, lab, means, stds, seed, input_channels=[True], output_channel=[0],
+                  output_shape=32, **train_defaults)
+    # (b) random crop: 40x48x36 labels cropped to 32^3
+    lab_b = load_label_crop(3, (50, 70, 60), (40, 48, 36))[None, ..., None]
+    run_graph('graph_crop_s111', lab_b, means, stds, 111, input_channels=[True], output_channel=[0],
+              output_shape=32, **train_defaults)
+    # (c) Hyperfine-like: 3 channels [False, True, True], 1.5x1.5x5, registration error, no reliability maps
+    means3, stds3 = class_stats(rng, ('t1_hr', 't1_lr', 't2'))
+    kw = dict(train_defaults)
+    kw.update(build_reliability_maps=False, data_res=np.array([[1.5, 1.5, 5.], [1.5, 1.5, 5.]]),
+              thickness=np.array([[1.5, 1.5, 5.], [1.5, 1.5, 5.]]))
+    run_graph('graph_hyperfine_s121', lab, means3, stds3, 121, input_channels=[False, True, True],
+              output_channel=[0], output_shape=32, **kw)
+    kw.update(build_reliability_maps=True)
+    run_graph('graph_hyperfine_maps_s122', lab, means3, stds3, 122, input_channels=[False, True, True],
+              output_channel=[0], output_shape=32, **kw)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs']
+    if 'resampler' in which:
+        golden_resampler()
+    if 'host_math' in which:
+        golden_host_math()
+    if 'layers' in which:
+        golden_layers()
+    if 'graphs' in which:
+        golden_graphs()

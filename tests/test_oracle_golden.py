@@ -1,0 +1,169 @@
+"""Pins the oracle (oracle/generator_ref.py) against golden vectors produced by executing the
+reference's own source (tests/golden/gen/make_goldens.py).  CPU only.
+
+Tolerances: integer outputs bit-exact.  float32 outputs: exact (0 ulp) wherever only +,-,*,/ and
+floor/round/clip are involved (resampler); 2e-6 absolute where exp/pow/log are involved."""
+import numpy as np
+import pytest
+from conftest import load_golden, tape_from_golden
+from oracle import generator_ref as R
+
+
+def test_resize_linear_exact():
+    g = load_golden('resampler')
+    np.testing.assert_array_equal(R.resize(g['rs_small'], [16] * 3, 'linear'), g['rs_lin_16'])
+    np.testing.assert_array_equal(R.resize(g['rs_small2'], [12, 10, 9], 'linear'), g['rs_lin_aniso'])
+    ramp = np.arange(5, dtype=np.float32)[:, None, None, None] * np.ones((1, 2, 2, 1), np.float32)
+    r = R.resize(ramp, [80, 2, 2], 'linear')[:, 0, 0, 0]
+    np.testing.assert_array_equal(r, g['rs_ramp80'])
+    # known answer quoted in SURVEY H6: edge clamp makes outputs i >= zoom*(in-1) flat
+    np.testing.assert_array_equal(r[63:67], np.float32([3.9375, 4, 4, 4]))
+
+
+def test_resize_nearest_exact():
+    g = load_golden('resampler')
+    np.testing.assert_array_equal(R.resize(g['rs_vol'], [8, 4, 3], 'nearest'), g['rs_near_down'])
+    # SURVEY H16 known answer: 8 -> 3 picks [0, 3, 5]
+    v = np.arange(8, dtype=np.float32)[:, None, None, None] * np.ones((1, 2, 2, 1), np.float32)
+    np.testing.assert_array_equal(R.resize(v, [3, 2, 2], 'nearest')[:, 0, 0, 0], [0, 3, 5])
+
+
+def test_integrate_vec_exact():
+    g = load_golden('resampler')
+    np.testing.assert_array_equal(R.integrate_vec(g['iv_in'], 7), g['iv_out'])
+
+
+def test_affine_elastic_shift_and_sampling_exact():
+    g = load_golden('resampler')
+    sh = R.affine_elastic_shift(g['st_aff'], g['st_field'], (16, 16, 16))
+    np.testing.assert_array_equal(sh, g['st_shift'])
+    np.testing.assert_array_equal(R.transform(g['st_labels'], sh, 'nearest'), g['st_nearest'])
+    np.testing.assert_array_equal(R.transform(g['st_img'], sh, 'linear'), g['st_linear'])
+    sh2 = R.affine_elastic_shift(g['st_aff'], None, (16, 16, 16))
+    np.testing.assert_array_equal(sh2, g['st_affine_only_shift'])
+    np.testing.assert_array_equal(R.transform(g['st_img'], sh2, 'linear'), g['st_affine_only_linear'])
+
+
+def test_linear_interp_matches_scipy_map_coordinates():
+    """independent cross-check: clamp-then-trilinear == map_coordinates(order=1, mode='nearest')"""
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(0)
+    vol = rng.standard_normal((9, 8, 7)).astype(np.float32)
+    loc = (rng.uniform(-2, 10, (500, 3))).astype(np.float32)
+    a = R.interpn(vol[..., None], loc, 'linear')[:, 0]
+    b = map_coordinates(vol.astype(np.float64), loc.T.astype(np.float64), order=1, mode='nearest')
+    np.testing.assert_allclose(a, b, atol=2e-6)
+
+
+def test_sample_affine_exact():
+    g = load_golden('host_math')
+    tape = tape_from_golden(g, 'affine_tape')
+    for b in range(2):
+        T = R.sample_affine(tape[0][1][b], tape[1][1][b], tape[2][1][b], tape[3][1][b], rotation_bounds=15,
+                            scaling_bounds=.15, shearing_bounds=.02, translation_bounds=5)
+        np.testing.assert_array_equal(T, g['affine_T'][b])
+
+
+def test_gaussian_kernels():
+    g = load_golden('host_math')
+    for name, sig in [('k050', [.5] * 3), ('k042', [.42] * 3), ('khyp', [.63, .63, 2.1])]:
+        k = R.gaussian_kernel(sig)
+        assert k.shape == g['gk_' + name].shape
+        np.testing.assert_allclose(k, g['gk_' + name], atol=1e-7)
+        assert abs(float(k.sum()) - 1) < 1e-6
+    # SURVEY H15 known answers
+    assert abs(R.gaussian_kernel([.5] * 3)[1, 1, 1] - .487417) < 1e-6
+    assert abs(R.gaussian_kernel([.42] * 3)[1, 1, 1] - .716569) < 1e-6
+    assert abs(R.gaussian_kernel([.63, .63, 2.1])[1, 1, 3] - .085199) < 1e-6
+    kr = R.gaussian_kernel([.42] * 3, g['gk_rand_tape_00'], 1.15)
+    np.testing.assert_allclose(kr, g['gk_rand'], atol=1e-7)
+
+
+def test_sigma_and_shapes_and_lut():
+    g = load_golden('host_math')
+    np.testing.assert_allclose(R.blurring_sigma_for_downsampling([1.] * 3, [1.5, 1.5, 5.], .42, [1.5, 1.5, 5.]),
+                               g['sigma_lr'])
+    np.testing.assert_allclose(R.blurring_sigma_for_downsampling([1.] * 3, [1.] * 3), g['sigma_tgt'])
+    cases = [([160, 160, 160], None, [1.] * 3, [1.] * 3, None, 32),
+             ([148, 187, 155], None, [1.] * 3, [1.] * 3, None, 32),
+             ([148, 187, 155], 128, [1.] * 3, [1.] * 3, None, 32),
+             ([148, 187, 155], [96, 128, 100], [1.] * 3, [1.] * 3, 8, 32),
+             ([148, 187, 155], 160, [1.] * 3, [.7] * 3, None, 32),
+             ([192, 192, 192], 192, [1.] * 3, [1.] * 3, None, None),
+             ([40, 48, 36], 32, [1.] * 3, [1.] * 3, None, 32)]
+    for c, ref in zip(cases, g['get_shapes_out']):
+        crop, out = R.get_shapes(*c)
+        assert list(crop) + list(out) == list(ref)
+    np.testing.assert_array_equal(R.swap_lut(g['swap_lut_labels'], 3), g['swap_lut'])
+    assert R.swap_lut(np.arange(5), 5) is None
+
+
+def test_layers(gen_labels):
+    g = load_golden('layers')
+    # GMM: two channels, per-channel LUT
+    out = R.sample_gmm(g['gmm_labels'][0, ..., 0], gen_labels, g['gmm_means'][0], g['gmm_stds'][0],
+                       g['gmm_tape_00'][0])
+    np.testing.assert_array_equal(out, g['gmm_out'][0])
+    # bias field
+    b, applied = R.bias_field(g['bias_in'][0], g['bias_tape_00'].reshape(-1)[0], g['bias_tape_01'],
+                              g['bias_tape_02'][0], .3, .25)
+    np.testing.assert_allclose(b, g['bias_out'][0], rtol=2e-6, atol=1e-4)
+    # intensity augmentation
+    ia = R.intensity_augmentation(g['ia_in'][0], g['ia_tape_00'].reshape(-1)[0])
+    np.testing.assert_allclose(ia, g['ia_out'][0], atol=2e-6)
+    # blur
+    np.testing.assert_allclose(R.gaussian_blur(g['blur_in'][0], [.5] * 3), g['blur_s050'][0], atol=1e-6)
+    np.testing.assert_allclose(R.gaussian_blur(g['blur_s050'][0], [.63, .63, 2.1], g['blur_tape_00'], 1.15),
+                               g['blur_hyp_rand'][0], atol=1e-6)
+    # flip + LUT swap with sided labels
+    lut = R.swap_lut(g['flip_label_list'], 3)
+    seen = set()
+    for seed in (35, 39, 43):
+        (o,), did = R.random_flip([g['flip_in'][0, ..., 0]], g['flip_tape_%d_00' % seed][0, 0], lut)
+        np.testing.assert_array_equal(o, g['flip_out_%d' % seed][0, ..., 0])
+        seen.add(did)
+    assert seen == {True, False}, 'goldens must cover both flip outcomes'
+    # resample_tensor with nearest down / linear up / sparse reliability map
+    r, m = R.resample_tensor(g['rt_in'][0], [24, 24, 30], [1.5, 1.5, 5.], [1., 1., 1.], True)
+    np.testing.assert_array_equal(r, g['rt_out'][0])
+    np.testing.assert_array_equal(m, g['rt_map'][0])
+    # sparse map, sum over an axis = number of acquired slices
+    w = R.reliability_map_1d(192, 38)
+    assert abs(w.sum() - 38) < 1e-9 and w[0] == 1 and w[1] == 0 and abs(w[5] - .947) < 1e-3
+
+
+C2_KW = dict(atlas_res=[1., 1., 1.], target_res=None, output_div_by_n=32, padding_margin=None, flipping=True,
+             scaling_bounds=.15, rotation_bounds=15, shearing_bounds=.02, translation_bounds=5, nonlin_std=4.,
+             nonlin_shape_factor=.125, simulate_registration_error=True, data_res=None, thickness=None,
+             downsample=True, build_reliability_maps=True, blur_range=1.15, bias_field_std=.3,
+             bias_shape_factor=.125)
+
+
+def _run_graph(name, gen_labels, **over):
+    g = load_golden(name)
+    kw = dict(C2_KW)
+    kw.update(over)
+    out = R.labels_to_image(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], tape_from_golden(g), gen_labels,
+                            len(gen_labels), output_shape=32, **kw)
+    return g, out
+
+
+@pytest.mark.parametrize('name', ['graph_c2_s101', 'graph_c2_s102', 'graph_c2_s103', 'graph_crop_s111'])
+def test_whole_graph_config2(name, gen_labels):
+    g, out = _run_graph(name, gen_labels, input_channels=[True], output_channel=[0])
+    np.testing.assert_array_equal(out['seg'], g['seg'][0, ..., 0])  # label indexing: bit-exact
+    np.testing.assert_allclose(out['image'], g['image'][0], atol=5e-6)
+    np.testing.assert_allclose(out['target'], g['target'][0], atol=5e-6)
+    assert np.all(out['image'][..., 1] == 1)  # reliability map of a non-downsampled channel
+
+
+@pytest.mark.parametrize('name,maps', [('graph_hyperfine_s121', False), ('graph_hyperfine_maps_s122', True)])
+def test_whole_graph_hyperfine(name, maps, gen_labels):
+    res = np.array([[1.5, 1.5, 5.], [1.5, 1.5, 5.]])
+    g, out = _run_graph(name, gen_labels, input_channels=[False, True, True], output_channel=[0],
+                        data_res=res, thickness=res, build_reliability_maps=maps)
+    np.testing.assert_array_equal(out['seg'], g['seg'][0, ..., 0])
+    assert out['image'].shape == g['image'][0].shape
+    # registration-error path contains a float32 matrix inverse (third-party, unpinned): looser tolerance
+    np.testing.assert_allclose(out['image'], g['image'][0], atol=2e-4)
+    np.testing.assert_allclose(out['target'], g['target'][0], atol=5e-6)
