@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): training volumes/sec for 160^3 fp32 volumes —
+on-the-fly synthetic brain generator + 5-level 3-D U-Net forward/backward + Keras-Adam, batch 1 per GPU,
+pure data parallel over N GPUs (weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (largest total time inside the timed
+region, measured with HIP events on the launch stream); `cpu_baseline` times the oracle (numpy generator +
+PyTorch-CPU U-Net, "port" — NOT TensorFlow) on a bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, exact f32
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(size=96, threads=None):
+    """oracle generator + U-Net fwd/bwd/Adam for ONE volume of size^3 on the host cores; scaled by voxel count"""
+    import torch
+    from oracle import generator_ref as R
+    from oracle import unet_ref as U
+    from synthsr_amd.synthetic import (synthetic_label_map, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
+                                       PRIOR_STDS_T1_HR)
+    if threads:
+        torch.set_num_threads(threads)
+    cores = torch.get_num_threads()
+    rng = np.random.default_rng(0)
+    labels = synthetic_label_map((size,) * 3, 1)
+    means = np.clip(rng.normal(PRIOR_MEANS_T1_HR[0], PRIOR_MEANS_T1_HR[1]), 0, None)[GENERATION_CLASSES][:, None]
+    stds = np.clip(rng.normal(PRIOR_STDS_T1_HR[0], PRIOR_STDS_T1_HR[1]), 0, None)[GENERATION_CLASSES][:, None]
+    small = R.get_resample_shape([size] * 3, .03125)
+    u = lambda *s: rng.random(s, dtype=np.float32)
+    n = lambda *s: rng.standard_normal(s, dtype=np.float32)
+    tape = [('u', u(3)), ('u', u(6)), ('u', u(3)), ('u', u(3)), ('u', u(1)), ('n', n(*small, 3)), ('u', u(1)),
+            ('n', n(size, size, size, 1)), ('u', u(1)), ('n', n(*small)), ('u', u(1)), ('n', n(1)), ('u', u(3))]
+    # random-init U-Net with the benchmark architecture
+    g = torch.Generator().manual_seed(0)
+    P = {}
+    feats = [24, 48, 96, 192, 384]
+    cin = 2
+
+    def conv(name, ci, co):
+        lim = float(np.sqrt(6.0 / (27 * ci + 27 * co)))
+        P[name + '/kernel'] = ((torch.rand(3, 3, 3, ci, co, generator=g) * 2 - 1) * lim).requires_grad_(True)
+        P[name + '/bias'] = torch.zeros(co, requires_grad=True)
+
+    def bn(name, c):
+        P[name + '/gamma'] = torch.ones(c, requires_grad=True)
+        P[name + '/beta'] = torch.zeros(c, requires_grad=True)
+    c = cin
+    for l in range(5):
+        for k in range(2):
+            conv('unet_conv_downarm_%d_%d' % (l, k), c, feats[l])
+            c = feats[l]
+        bn('unet_bn_down_%d' % l, c)
+    for k in range(4):
+        l = 3 - k
+        ci = feats[l] + c
+        for j in range(2):
+            conv('unet_conv_uparm_%d_%d' % (5 + k, j), ci, feats[l])
+            ci = feats[l]
+        c = feats[l]
+        bn('unet_bn_up_%d' % k, c)
+    P['unet_likelihood/kernel'] = ((torch.rand(24, 1, generator=g) * 2 - 1) * .4).requires_grad_(True)
+    P['unet_likelihood/bias'] = torch.zeros(1, requires_grad=True)
+    t0 = time.time()
+    out = R.labels_to_image(labels, means, stds, tape, GENERATION_LABELS, 19, input_channels=[True],
+                            output_channel=[0], output_shape=size, output_div_by_n=32, scaling_bounds=.15,
+                            rotation_bounds=15, shearing_bounds=.02, translation_bounds=5, nonlin_std=4.,
+                            nonlin_shape_factor=.03125, downsample=True, build_reliability_maps=True, blur_range=1.15,
+                            bias_field_std=.3, bias_shape_factor=.03125)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    pred = U.unet_forward(torch.from_numpy(out['image']), P, 'unet', 5, 2, training=True)
+    loss = U.l1_loss(pred, torch.from_numpy(out['target']))
+    loss.backward()
+    for k, p in P.items():
+        U.adam_keras(p.detach(), p.grad, torch.zeros_like(p), torch.zeros_like(p), 1)
+    t_net = time.time() - t0
+    scale = (size / 160.0) ** 3
+    return {'value': round(scale / (t_gen + t_net), 5), 'unit': 'volumes/s', 'cores': cores, 'kind': 'port',
+            'sample': 'one %d^3 volume (%.1f%% of the voxels of a 160^3 volume) through the oracle: numpy generator '
+                      '%.1fs + PyTorch-CPU U-Net fwd/bwd/Adam %.1fs; volumes/s scaled by voxel count; CPU restatement '
+                      '(PyTorch), not TensorFlow' % (size, 100 * scale, t_gen, t_net)}
+
+
+def conv_flops(kind, shape, cin, cout):
+    return 2.0 * 27 * cin * cout * float(np.prod(shape))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--size', type=int, default=160)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-size', type=int, default=96)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from synthsr_amd import ops
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.training import Trainer
+    from synthsr_amd.unet import unet
+    from synthsr_amd.synthetic import (synthetic_label_pool, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
+                                       PRIOR_STDS_T1_HR)
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node N for --gpus N'
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    S = args.size
+    pool = synthetic_label_pool(8, (S, S, S), 1234)
+    rng = np.random.Generator(np.random.Philox(key=1000 + rank))
+    bg = BrainGenerator(None, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', GENERATION_LABELS,
+                        generation_classes=GENERATION_CLASSES, n_neutral_labels=19, output_shape=S, output_div_by_n=32,
+                        flipping=True, scaling_bounds=.15, rotation_bounds=15, shearing_bounds=.02, translation_bounds=5,
+                        nonlin_std=4., nonlin_shape_factor=.03125, randomise_res=False, downsample=True,
+                        blur_range=1.15, build_reliability_maps=True, bias_field_std=.3, bias_shape_factor=.03125,
+                        label_maps=pool, rng=rng)  # = training() defaults, SynthSR/training.py:57-73
+    bg.labels_to_image_model.seed(0, rank)
+    net = unet(24, bg.model_output_shape, 5, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
+               batch_norm=-1, activation='elu', seed=0)
+    if world > 1:
+        dist.broadcast(net.params, 0)
+        net.repack()
+    tr = Trainer(bg, net, lr=1e-4, distributed=world > 1)
+    tr.make_labels_resident(pool)
+    pick = np.random.default_rng(rank)
+
+    def one_step():
+        return tr.step(label_index=int(pick.integers(len(pool))))
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss = one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    if world > 1:
+        tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        # per-kernel aggregation of the conv launches recorded inside the timed region
+        agg = {}
+        for kind, shape, cin, cout, s, e in prof:
+            key = (kind, shape, cin, cout)
+            a = agg.setdefault(key, [0.0, 0])
+            a[0] += s.elapsed_time(e)
+            a[1] += 1
+        rows = []
+        for (kind, shape, cin, cout), (ms, cnt) in agg.items():
+            fl = conv_flops(kind, shape, cin, cout)
+            rows.append(dict(kernel=kind, shape=list(shape), cin=cin, cout=cout, launches=cnt,
+                             avg_ms=ms / cnt, tflops=fl / (ms / cnt * 1e-3) / 1e12, total_ms=ms))
+        rows.sort(key=lambda r: -r['total_ms'])
+        conv_total = sum(r['total_ms'] for r in rows)
+        dom = rows[0]
+        flops_launch = conv_flops(dom['kernel'], dom['shape'], dom['cin'], dom['cout'])
+        roofline = {'bound': 'mfma', 'kernel': '%s %s Cin=%d Cout=%d' % (dom['kernel'], 'x'.join(map(str, dom['shape'])),
+                                                                          dom['cin'], dom['cout']),
+                    'achieved': round(dom['tflops'], 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                    'flops_per_launch': flops_launch, 'avg_launch_ms': round(dom['avg_ms'], 4),
+                    'all_conv_tflops': round(sum(conv_flops(r['kernel'], r['shape'], r['cin'], r['cout']) * r['launches']
+                                                 for r in rows) / (conv_total * 1e-3) / 1e12, 2),
+                    'conv_ms_per_step': round(conv_total / args.steps, 3)}
+        out = {'metric': 'training volumes/sec (160^3 fp32, 5-level U-Net)', 'value': round(world * args.steps / dt, 4),
+               'unit': 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'configs[1]: brain_generator %d^3 batch=1 (training() defaults) + 5-level 3-D U-Net '
+                                      '(24..384 features, Cin=2) fwd/bwd + Adam, fp32, random-init' % S,
+                          'global_batch': world, 'parallelism': 'dp%d' % world, 'volume': [S, S, S]},
+               'roofline': roofline, 'final_loss': round(final_loss, 6),
+               'top_kernels': [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(args.cpu_size)
+            except Exception as ex:  # the baseline is a reported number, never a reason to lose the GPU measurement
+                out['cpu_baseline'] = {'value': None, 'error': repr(ex)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,191 @@
+/*
+ * libsynthsr_hip.so — C ABI of the MI355X (gfx950) hot path of SynthSR:
+ * on-the-fly synthetic brain generator + 3-D U-Net forward/backward.
+ *
+ * The reference has no FFI: this path sits behind its Python API / Keras Layer protocol
+ * (SURVEY.md §8b).  Each entry point below replaces the TensorFlow graph ops that one
+ * reference function emits; the reference file:line it stands in for is cited per function.
+ *
+ * Conventions
+ *   - plain device pointers + explicit sizes; no allocation, no ownership transfer, no global
+ *     state; every call is stream-ordered on `stream` (a hipStream_t) and re-entrant.
+ *   - volumes are NDHWC / channels-last, float32 unless stated, 3 spatial dims [d0][d1][d2][C].
+ *   - return value: 0 (SYNTHSR_OK) or a negative SYNTHSR_E* code (argument/shape error or a
+ *     HIP launch error); the Python layer turns these into the reference's exception types.
+ *   - random draws are inputs: either explicit device buffers (parity "tape") or a
+ *     (philox key, offset) pair for the in-kernel generator.
+ */
+#ifndef SYNTHSR_HIP_H
+#define SYNTHSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYNTHSR_OK 0
+#define SYNTHSR_EINVAL (-1)   /* bad argument / unsupported shape */
+#define SYNTHSR_ELAUNCH (-2)  /* hip launch error */
+
+typedef void* synthsr_stream_t; /* hipStream_t */
+
+/* library / device introspection */
+int synthsr_abi_version(void);
+const char* synthsr_build_arch(void);
+
+/* ------------------------------------------------------------------ generator: resampler core */
+
+/* nrn_utils.resize via nrn_layers.Resize (ext/neuron/utils.py:127-154, ext/neuron/layers.py:361-394):
+ * sample position i + (i/zoom - i), zoom = out/in; method 0 = linear (edge-clamped trilinear,
+ * ext/neuron/utils.py:67-110), 1 = nearest (round-half-even, :113-122). in [i0,i1,i2,C] -> out [o0,o1,o2,C] */
+int synthsr_resize_f32(const float* in, float* out, int C, const int in_shape[3], const int out_shape[3],
+                       int method, synthsr_stream_t stream);
+
+/* integrate_vec 'ss' branch via VecInt (ext/neuron/utils.py:365-369, ext/neuron/layers.py:241-272):
+ * v /= 2^nb_steps; repeat nb_steps: v += transform(v, v).  v, scratch: [s0,s1,s2,3]; result left in v. */
+int synthsr_svf_integrate(float* v, float* scratch, const int shape[3], int nb_steps, synthsr_stream_t stream);
+
+/* SpatialTransformer with a single affine (ext/neuron/layers.py:148-151, utils.py:160-219 affine_to_shift,
+ * :289-320 transform), linear interpolation.  aff = rows 0..2 of the 4x4 (row-major, 12 floats). */
+int synthsr_affine_resample_linear(const float* in, float* out, int C, const int shape[3], const float aff[12],
+                                   synthsr_stream_t stream);
+
+/* ------------------------------------------------------------------ generator: fused label->intensity */
+
+typedef struct {
+  int in_shape[3];    /* label volume (after optional padding) */
+  int out_shape[3];   /* crop shape (RandomCrop, ext/lab2im/layers.py:252-270) */
+  int crop[3];        /* crop origin */
+  int flip;           /* reverse axis 0 after the crop (RandomFlip, layers.py:391-427) */
+  int has_field;      /* elastic part present */
+  int has_affine;     /* affine part present (else position = x + u, ext/neuron/layers.py:148-149) */
+  int half_shape[3];  /* shape of the integrated half-resolution SVF */
+  float aff[12];      /* affine rows 0..2 (identity if no affine) */
+  int n_channels;     /* synthetic channels (<= 4) */
+  int lut_size;       /* max(generation_labels)+1 */
+  int swap_lut_size;  /* 0 = no L/R swap LUT */
+  /* per-channel post-ops fused behind the GMM (BiasFieldCorruption layers.py:1067-1097 and the
+   * clip of IntensityAugmentation :1215): */
+  int bias_on[4];       /* apply exp(bias) * x */
+  int bias_shape[4][3]; /* small bias grid per channel */
+  float clip_hi;        /* <=0: no clip */
+  int use_philox;       /* 0: noise buffer, 1: in-kernel Philox4x32-10 */
+  uint32_t philox_key[2];
+  uint64_t philox_offset;
+} synthsr_deform_params;
+
+/* Fuses RandomSpatialDeformation's final SpatialTransformer(nearest) (layers.py:200-203;
+ * combine_non_linear_and_aff_to_shift utils.py:222-286; full-res Resize of the field layers.py:196),
+ * RandomCrop, RandomFlip (+LUT swap), SampleConditionalGMM (layers.py:480-498), BiasFieldCorruption and
+ * the clip + min/max reduction of IntensityAugmentation (layers.py:1214-1231).
+ *   labels   int32 [in_shape]                 field_half float [half_shape,3] (may be NULL)
+ *   gmm_lut  float [2][n_channels][lut_size]  (means then stds)
+ *   swap_lut int32 [swap_lut_size] or NULL    noise float [out_shape, n_channels] or NULL (philox)
+ *   bias_small float, concatenated small grids of the channels with bias_on (already scaled by std)
+ *   seg_out  int32 [out_shape] or NULL        chan_out float planar [n_channels][out_shape]
+ *   minmax   uint32 [n_channels][2] ordered-encoded min/max, must be initialised by synthsr_minmax_init */
+int synthsr_deform_gmm(const int32_t* labels, const float* field_half, const float* gmm_lut,
+                       const int32_t* swap_lut, const float* noise, const float* bias_small, int32_t* seg_out,
+                       float* chan_out, uint32_t* minmax, const synthsr_deform_params* p,
+                       synthsr_stream_t stream);
+
+int synthsr_minmax_init(uint32_t* minmax, int n_pairs, synthsr_stream_t stream);
+/* generic min/max over n floats into one ordered-encoded pair (IntensityAugmentation on a real image) */
+int synthsr_minmax_reduce(const float* x, int64_t n, uint32_t* minmax, synthsr_stream_t stream);
+
+/* IntensityAugmentation normalise + gamma (layers.py:1235-1242): x = ((clip(x,m,M)-m)/(M-m+1e-7))^gexp,
+ * m,M decoded on device from `minmax`; in place allowed. gexp = exp(gamma) computed on host; <=0: skip pow */
+int synthsr_normalise_gamma(const float* x, float* out, int64_t n, const uint32_t* minmax, float gexp,
+                            synthsr_stream_t stream);
+
+/* GaussianBlur (layers.py:732-767): tf.nn.conv3d(...,'SAME') of one channel with a full 3-D kernel built on
+ * the host (edit_tensors.py:86-181).  out element o is written at out[o*out_stride + out_offset]; if
+ * fill_offset >= 0 the value fill_value is also written at out[o*out_stride + fill_offset]
+ * (all-ones reliability map, edit_tensors.py:333). kernel: device float [k0*k1*k2]. */
+int synthsr_blur3d(const float* in, float* out, const int shape[3], const float* kernel, const int ksize[3],
+                   int out_stride, int out_offset, int fill_offset, float fill_value, synthsr_stream_t stream);
+
+/* reliability map (edit_tensors.py:313-329): out[o*stride+offset] = w0[o0]*w1[o1]*w2[o2]; w concatenated */
+int synthsr_outer3(const float* w, float* out, const int shape[3], int out_stride, int out_offset,
+                   synthsr_stream_t stream);
+
+/* strided copy: out[i*out_stride+out_offset] = in[i*in_stride+in_offset] */
+int synthsr_copy_strided(const float* in, float* out, int64_t n, int in_stride, int in_offset, int out_stride,
+                         int out_offset, synthsr_stream_t stream);
+
+/* ------------------------------------------------------------------ U-Net (ext/neuron/models.py:256-498) */
+
+/* Keras Conv3D(k=3,'same') weights are [3][3][3][Cin][Cout].  Packs them into the MFMA B-fragment order
+ * used by synthsr_conv3d_fwd.  mode 0: forward; mode 1: data-gradient (taps flipped, Cin<->Cout swapped).
+ * Returns the number of floats written (or required if packed==NULL), negative on error. */
+int64_t synthsr_conv3d_pack(const float* w, float* packed, int Cin, int Cout, int mode, synthsr_stream_t stream);
+
+/* Conv3D 3x3x3 'same' + bias + activation (0 linear, 1 ELU alpha=1) — models.py:316,444.
+ * in [d0,d1,d2,Cin], out [d0,d1,d2,Cout]; wpacked from synthsr_conv3d_pack(Cin,Cout,mode).
+ * bias may be NULL (data-gradient use). */
+int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
+                       int Cin, int Cout, int act, synthsr_stream_t stream);
+
+/* weight gradient: dw[3][3][3][Cin][Cout] += sum_v in[v+t-1][ci] * dout[v][co]   (dw must be zeroed by caller) */
+int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout,
+                         synthsr_stream_t stream);
+
+/* dz = dy * ELU'(y) (y = saved activation output), optional dy2 added first (skip-connection gradient),
+ * dbias[c] += sum_v dz[v][c]  (dbias zeroed by caller; may be NULL) */
+int synthsr_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
+                    synthsr_stream_t stream);
+
+/* BatchNormalization(axis=-1), training mode (models.py:351,477; Keras 2.3.1 semantics, eps=1e-3):
+ * stats[0..C) = mean, stats[C..2C) = biased variance over the nvox voxels */
+int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* ws /* 2C doubles scratch */,
+                     synthsr_stream_t stream);
+/* y = gamma*(x-mean)*rsqrt(var+eps)+beta */
+int synthsr_bn_apply(const float* x, float* y, int64_t nvox, int C, const float* stats, const float* gamma,
+                     const float* beta, float eps, synthsr_stream_t stream);
+/* fused BN apply + MaxPooling3D(2) (models.py:356): x [d0,d1,d2,C] -> y [d0/2,d1/2,d2/2,C] */
+int synthsr_bn_maxpool(const float* x, float* y, const int shape[3], int C, const float* stats, const float* gamma,
+                       const float* beta, float eps, synthsr_stream_t stream);
+/* backward of the fused BN + max-pool: dy [d/2], x [d] -> dbn [d] (gradient w.r.t. the BN output) */
+int synthsr_bn_maxpool_bwd(const float* dy, const float* x, float* dbn, const int shape[3], int C,
+                           const float* stats, const float* gamma, const float* beta, float eps,
+                           synthsr_stream_t stream);
+/* BN backward, pass 1: sums[0..C) = sum dy, sums[C..2C) = sum dy*xhat (zeroed by caller) */
+int synthsr_bn_bwd_reduce(const float* dy, const float* x, int64_t nvox, int C, const float* stats, float eps,
+                          float* sums, synthsr_stream_t stream);
+/* BN backward, pass 2: dx = gamma*invstd*(dy - sum_dy/n - xhat*sum_dyxhat/n); dgamma = sum_dyxhat; dbeta = sum_dy */
+int synthsr_bn_bwd_apply(const float* dy, const float* x, float* dx, int64_t nvox, int C, const float* stats,
+                         const float* gamma, float eps, const float* sums, synthsr_stream_t stream);
+
+/* UpSampling3D(2) nearest of BN(lo) + concatenate([skip, up]) (models.py:426-434):
+ * skip [d0,d1,d2,Cs], lo [d0/2,d1/2,d2/2,Cl] -> out [d0,d1,d2,Cs+Cl]; BN (stats,gamma,beta) applied to lo */
+int synthsr_upsample_concat(const float* skip, const float* lo, float* out, const int shape[3], int Cs, int Cl,
+                            const float* stats, const float* gamma, const float* beta, float eps,
+                            synthsr_stream_t stream);
+/* backward: dcat [d,Cs+Cl] -> dskip [d,Cs] (written), dlo_bn [d/2,Cl] = sum over the 2^3 children */
+int synthsr_upsample_concat_bwd(const float* dcat, float* dskip, float* dlo_bn, const int shape[3], int Cs, int Cl,
+                                synthsr_stream_t stream);
+
+/* unet_likelihood: Conv3D(nb_labels=1, 1x1x1, linear) on BN(x) (models.py:480-481) fused with the
+ * L1 loss of metrics_model (SynthSR/metrics_model.py:102-104):
+ *   pred[v] = sum_c w[c]*bn(x[v][c]) + b (+ residual[v*res_stride+res_off] if residual != NULL)
+ *   loss += sum_v |pred - target| / nvox        (loss: device float, zeroed by caller)
+ *   dpred[v] = sign(pred-target)/nvox */
+int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats, const float* gamma,
+                        const float* beta, float eps, const float* w, const float* b, const float* residual,
+                        int res_stride, int res_off, const float* target, float* pred, float* dpred, float* loss,
+                        synthsr_stream_t stream);
+/* head backward: dbn[v][c] = dpred[v]*w[c]; dw[c] += sum_v dpred[v]*bn(x[v][c]); db += sum_v dpred[v] */
+int synthsr_head_bwd(const float* dpred, const float* x, int64_t nvox, int C, const float* stats,
+                     const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw,
+                     float* db, synthsr_stream_t stream);
+
+/* keras.optimizers.Adam (Keras 2.3.1; SynthSR/training.py:444): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+ * p -= lr_t*m/(sqrt(v)+eps).  lr already includes the 1/(1+decay*iter) factor. */
+int synthsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                      float beta2, float eps, float grad_scale, synthsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYNTHSR_HIP_H */

@@ -201,9 +201,10 @@ def random_spatial_deformation(vols, methods, aff, u_std, n_field, nonlin_std, n
         svf = resize(svf, half, 'linear')
         svf = integrate_vec(svf, 7)
         field = resize(svf, list(shape), 'linear')
-    if aff is None:
-        aff = np.eye(4, dtype=F)
-    shift = affine_elastic_shift(aff, field, shape)
+    if aff is None and field is None:
+        return [np.asarray(v) for v in vols], None
+    # a single dense transform is used as the shift directly (ext/neuron/layers.py:148-151)
+    shift = field if aff is None else affine_elastic_shift(aff, field, shape)
     outs = []
     for v, m in zip(vols, methods):
         o = transform(f32(v), shift, m)  # inputs are cast to float32 (:167) ...

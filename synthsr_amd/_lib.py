@@ -1,0 +1,107 @@
+"""ctypes binding of libsynthsr_hip.so (C ABI declared in include/synthsr_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, this raises.
+torch is used only as the owner of device memory and streams (`tensor.data_ptr()`,
+`torch.cuda.current_stream().cuda_stream`).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsynthsr_hip.so')
+
+_lib = None
+
+I3 = c_int * 3
+F12 = c_float * 12
+
+
+class DeformParams(Structure):
+    """mirror of synthsr_deform_params"""
+    _fields_ = [('in_shape', c_int * 3), ('out_shape', c_int * 3), ('crop', c_int * 3), ('flip', c_int),
+                ('has_field', c_int), ('has_affine', c_int), ('half_shape', c_int * 3), ('aff', c_float * 12),
+                ('n_channels', c_int), ('lut_size', c_int), ('swap_lut_size', c_int), ('bias_on', c_int * 4),
+                ('bias_shape', (c_int * 3) * 4), ('clip_hi', c_float), ('use_philox', c_int),
+                ('philox_key', c_uint32 * 2), ('philox_offset', c_uint64)]
+
+
+_P = c_void_p
+_S = c_void_p  # stream
+
+SIGNATURES = {
+    'synthsr_abi_version': (c_int, []),
+    'synthsr_build_arch': (c_char_p, []),
+    'synthsr_resize_f32': (c_int, [_P, _P, c_int, POINTER(c_int), POINTER(c_int), c_int, _S]),
+    'synthsr_svf_integrate': (c_int, [_P, _P, POINTER(c_int), c_int, _S]),
+    'synthsr_affine_resample_linear': (c_int, [_P, _P, c_int, POINTER(c_int), POINTER(c_float), _S]),
+    'synthsr_deform_gmm': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(DeformParams), _S]),
+    'synthsr_minmax_init': (c_int, [_P, c_int, _S]),
+    'synthsr_minmax_reduce': (c_int, [_P, c_int64, _P, _S]),
+    'synthsr_normalise_gamma': (c_int, [_P, _P, c_int64, _P, c_float, _S]),
+    'synthsr_blur3d': (c_int, [_P, _P, POINTER(c_int), _P, POINTER(c_int), c_int, c_int, c_int, c_float, _S]),
+    'synthsr_outer3': (c_int, [_P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_copy_strided': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_pack': (c_int64, [_P, _P, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_fwd': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),
+    'synthsr_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P, _S]),
+    'synthsr_bn_apply': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _S]),
+    'synthsr_bn_maxpool': (c_int, [_P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _S]),
+    'synthsr_bn_maxpool_bwd': (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _S]),
+    'synthsr_bn_bwd_reduce': (c_int, [_P, _P, c_int64, c_int, _P, c_float, _P, _S]),
+    'synthsr_bn_bwd_apply': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
+    'synthsr_upsample_concat': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _P, _P, _P, c_float, _S]),
+    'synthsr_upsample_concat_bwd': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_head_l1_fwd': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P, _P, _P,
+                                    _P, _S]),
+    'synthsr_head_bwd': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
+    'synthsr_adam_step': (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _S]),
+}
+
+
+class SynthSRHipError(RuntimeError):
+    pass
+
+
+def load():
+    """load the shared library (once); raises if it has not been built"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SynthSRHipError('%s not found: build it with `python -m synthsr_amd.build` (hipcc, gfx950). '
+                              'There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise ValueError('synthsr_hip: invalid argument / unsupported shape in %s' % what)
+    raise SynthSRHipError('synthsr_hip: HIP launch error (%d) in %s' % (rc, what))
+
+
+def i3(seq):
+    return I3(*[int(s) for s in seq])
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'tensors handed to the HIP library must be contiguous device tensors'
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,521 @@
+// Synthetic-brain generator kernels (gfx950).  HBM-bound gather / stencil / elementwise work:
+// one thread per output voxel, coalesced along the fastest spatial axis, no MFMA.
+//
+// THIS FILE MUST BE COMPILED WITH -ffp-contract=off: label indexing has to be bit-exact with the
+// oracle, whose float32 coordinate pipeline rounds after every multiply and every add
+// (reference op order: ext/neuron/utils.py:68-110, 150, 271-286, 316-317).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// edge-clamped trilinear setup for one axis — ext/neuron/utils.py:68-84
+struct Axis {
+  int i0, i1;
+  float w0, w1;  // weight of the floor corner (diff_loc1) and of the ceil corner (1 - diff_loc1)
+};
+
+__device__ __forceinline__ Axis axis_setup(float loc, int n) {
+  Axis a;
+  const float mx = (float)(n - 1);
+  const float fl = floorf(loc);
+  const float cl = fminf(fmaxf(loc, 0.f), mx);
+  const float f0 = fminf(fmaxf(fl, 0.f), mx);
+  const float f1 = fminf(fmaxf(f0 + 1.f, 0.f), mx);
+  a.w0 = f1 - cl;
+  a.w1 = 1.f - a.w0;
+  a.i0 = (int)f0;
+  a.i1 = (int)f1;
+  return a;
+}
+
+// value of channel c at the 8 corners, accumulated in the reference's corner order
+// itertools.product([0,1], repeat=3) with weight (w[c0][0]*w[c1][1])*w[c2][2]  (utils.py:88-110, 530-534)
+template <typename F>
+__device__ __forceinline__ float tri_accum(const Axis& a0, const Axis& a1, const Axis& a2, F fetch) {
+  float acc;
+  {
+    const float w = (a0.w0 * a1.w0) * a2.w0;
+    acc = w * fetch(a0.i0, a1.i0, a2.i0);
+  }
+  acc = acc + ((a0.w0 * a1.w0) * a2.w1) * fetch(a0.i0, a1.i0, a2.i1);
+  acc = acc + ((a0.w0 * a1.w1) * a2.w0) * fetch(a0.i0, a1.i1, a2.i0);
+  acc = acc + ((a0.w0 * a1.w1) * a2.w1) * fetch(a0.i0, a1.i1, a2.i1);
+  acc = acc + ((a0.w1 * a1.w0) * a2.w0) * fetch(a0.i1, a1.i0, a2.i0);
+  acc = acc + ((a0.w1 * a1.w0) * a2.w1) * fetch(a0.i1, a1.i0, a2.i1);
+  acc = acc + ((a0.w1 * a1.w1) * a2.w0) * fetch(a0.i1, a1.i1, a2.i0);
+  acc = acc + ((a0.w1 * a1.w1) * a2.w1) * fetch(a0.i1, a1.i1, a2.i1);
+  return acc;
+}
+
+// resize sample position: i + (i/zoom - i)  (utils.py:150 then :317)
+__device__ __forceinline__ float resize_pos(int i, float zoom) {
+  const float g = (float)i;
+  return g + (g / zoom - g);
+}
+
+struct Shape3 {
+  int d[3];
+};
+
+// ------------------------------------------------------------------------------------------
+__global__ void resize_kernel(const float* __restrict__ in, float* __restrict__ out, int C, Shape3 is, Shape3 os,
+                              float z0, float z1, float z2, int method) {
+  const int64_t n = (int64_t)os.d[0] * os.d[1] * os.d[2];
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int o2 = (int)(v % os.d[2]);
+    const int o1 = (int)((v / os.d[2]) % os.d[1]);
+    const int o0 = (int)(v / ((int64_t)os.d[2] * os.d[1]));
+    const float l0 = resize_pos(o0, z0), l1 = resize_pos(o1, z1), l2 = resize_pos(o2, z2);
+    if (method == 1) {
+      int r0 = (int)rintf(l0), r1 = (int)rintf(l1), r2 = (int)rintf(l2);
+      r0 = min(max(r0, 0), is.d[0] - 1);
+      r1 = min(max(r1, 0), is.d[1] - 1);
+      r2 = min(max(r2, 0), is.d[2] - 1);
+      const float* src = in + (((int64_t)r0 * is.d[1] + r1) * is.d[2] + r2) * C;
+      for (int c = 0; c < C; ++c) out[v * C + c] = src[c];
+    } else {
+      const Axis a0 = axis_setup(l0, is.d[0]), a1 = axis_setup(l1, is.d[1]), a2 = axis_setup(l2, is.d[2]);
+      for (int c = 0; c < C; ++c) {
+        out[v * C + c] = tri_accum(a0, a1, a2, [&](int i, int j, int k) {
+          return in[(((int64_t)i * is.d[1] + j) * is.d[2] + k) * C + c];
+        });
+      }
+    }
+  }
+}
+
+// one scaling-and-squaring step: out = s*v + interp(s*v, x + s*v)   (utils.py:366-369; s = 2^-n only on step 0)
+__global__ void svf_step_kernel(const float* __restrict__ in, float* __restrict__ out, Shape3 s, float scale) {
+  const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int i2 = (int)(v % s.d[2]);
+    const int i1 = (int)((v / s.d[2]) % s.d[1]);
+    const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));
+    const float v0 = in[v * 3 + 0] * scale, v1 = in[v * 3 + 1] * scale, v2 = in[v * 3 + 2] * scale;
+    const Axis a0 = axis_setup((float)i0 + v0, s.d[0]);
+    const Axis a1 = axis_setup((float)i1 + v1, s.d[1]);
+    const Axis a2 = axis_setup((float)i2 + v2, s.d[2]);
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      r[c] = tri_accum(a0, a1, a2, [&](int i, int j, int k) {
+        return in[(((int64_t)i * s.d[1] + j) * s.d[2] + k) * 3 + c] * scale;
+      });
+    }
+    out[v * 3 + 0] = v0 + r[0];
+    out[v * 3 + 1] = v1 + r[1];
+    out[v * 3 + 2] = v2 + r[2];
+  }
+}
+
+struct Aff {
+  float a[12];
+};
+
+// sampling position of voxel (i0,i1,i2): x + (A.[x_c + u; 1] - x_c)   (utils.py:271-286, 316-317)
+__device__ __forceinline__ void affine_pos(const Aff& A, const int S[3], int i0, int i1, int i2, float u0, float u1,
+                                           float u2, bool has_u, bool has_aff, float pos[3]) {
+  if (!has_aff) {  // single dense transform: shift = u
+    pos[0] = (float)i0 + u0;
+    pos[1] = (float)i1 + u1;
+    pos[2] = (float)i2 + u2;
+    return;
+  }
+  const float c0 = (float)i0 - (float)((S[0] - 1) / 2.0);
+  const float c1 = (float)i1 - (float)((S[1] - 1) / 2.0);
+  const float c2 = (float)i2 - (float)((S[2] - 1) / 2.0);
+  const float m0 = has_u ? c0 + u0 : c0;
+  const float m1 = has_u ? c1 + u1 : c1;
+  const float m2 = has_u ? c2 + u2 : c2;
+  const float l0 = ((A.a[0] * m0 + A.a[1] * m1) + A.a[2] * m2) + A.a[3];
+  const float l1 = ((A.a[4] * m0 + A.a[5] * m1) + A.a[6] * m2) + A.a[7];
+  const float l2 = ((A.a[8] * m0 + A.a[9] * m1) + A.a[10] * m2) + A.a[11];
+  pos[0] = (float)i0 + (l0 - c0);
+  pos[1] = (float)i1 + (l1 - c1);
+  pos[2] = (float)i2 + (l2 - c2);
+}
+
+__global__ void affine_resample_kernel(const float* __restrict__ in, float* __restrict__ out, int C, Shape3 s,
+                                       Aff A) {
+  const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int i2 = (int)(v % s.d[2]);
+    const int i1 = (int)((v / s.d[2]) % s.d[1]);
+    const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));
+    float pos[3];
+    affine_pos(A, s.d, i0, i1, i2, 0.f, 0.f, 0.f, false, true, pos);
+    const Axis a0 = axis_setup(pos[0], s.d[0]), a1 = axis_setup(pos[1], s.d[1]), a2 = axis_setup(pos[2], s.d[2]);
+    for (int c = 0; c < C; ++c) {
+      out[v * C + c] = tri_accum(a0, a1, a2, [&](int i, int j, int k) {
+        return in[(((int64_t)i * s.d[1] + j) * s.d[2] + k) * C + c];
+      });
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter = (voxel_lo, voxel_hi, offset_lo, offset_hi)
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0;
+    c[1] = lo1;
+    c[2] = n2;
+    c[3] = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__device__ __forceinline__ void box_muller(uint32_t r0, uint32_t r1, float& n0, float& n1) {
+  const float u1 = (float)((r0 >> 8) + 1u) * 5.9604644775390625e-08f;  // (0, 1]
+  const float u2 = (float)(r1 >> 8) * 5.9604644775390625e-08f;         // [0, 1)
+  const float rad = sqrtf(-2.0f * logf(u1));
+  const float ang = 6.283185307179586f * u2;
+  n0 = rad * cosf(ang);
+  n1 = rad * sinf(ang);
+}
+
+// ------------------------------------------------------------------------------------------
+// fused: full-res field (trilinear from the half-res SVF) -> affine∘elastic position -> nearest label
+// -> [crop, flip, L/R swap] -> GMM -> [bias] -> [clip] -> planar channel + block min/max
+__global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restrict__ labels,
+                                                         const float* __restrict__ field,
+                                                         const float* __restrict__ gmm_lut,
+                                                         const int32_t* __restrict__ swap_lut,
+                                                         const float* __restrict__ noise,
+                                                         const float* __restrict__ bias_small,
+                                                         int32_t* __restrict__ seg_out, float* __restrict__ chan_out,
+                                                         uint32_t* __restrict__ minmax, synthsr_deform_params p) {
+  const int64_t n = (int64_t)p.out_shape[0] * p.out_shape[1] * p.out_shape[2];
+  const int C = p.n_channels;
+  float lmin[4], lmax[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    lmin[c] = INFINITY;
+    lmax[c] = -INFINITY;
+  }
+  Aff A;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) A.a[i] = p.aff[i];
+  const float zf0 = p.has_field ? (float)((double)p.in_shape[0] / (double)p.half_shape[0]) : 1.f;
+  const float zf1 = p.has_field ? (float)((double)p.in_shape[1] / (double)p.half_shape[1]) : 1.f;
+  const float zf2 = p.has_field ? (float)((double)p.in_shape[2] / (double)p.half_shape[2]) : 1.f;
+
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x) {
+    const int o2 = (int)(o % p.out_shape[2]);
+    const int o1 = (int)((o / p.out_shape[2]) % p.out_shape[1]);
+    const int o0 = (int)(o / ((int64_t)p.out_shape[2] * p.out_shape[1]));
+    // undo flip (tf.reverse along axis 0), then crop offset -> voxel of the deformed full grid
+    const int i0 = (p.flip ? (p.out_shape[0] - 1 - o0) : o0) + p.crop[0];
+    const int i1 = o1 + p.crop[1];
+    const int i2 = o2 + p.crop[2];
+    float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+    if (p.has_field) {  // Resize(linear) of the integrated SVF to full size (layers.py:196), evaluated on the fly
+      const Axis a0 = axis_setup(resize_pos(i0, zf0), p.half_shape[0]);
+      const Axis a1 = axis_setup(resize_pos(i1, zf1), p.half_shape[1]);
+      const Axis a2 = axis_setup(resize_pos(i2, zf2), p.half_shape[2]);
+      const int h1 = p.half_shape[1], h2 = p.half_shape[2];
+      u0 = tri_accum(a0, a1, a2, [&](int i, int j, int k) { return field[(((int64_t)i * h1 + j) * h2 + k) * 3 + 0]; });
+      u1 = tri_accum(a0, a1, a2, [&](int i, int j, int k) { return field[(((int64_t)i * h1 + j) * h2 + k) * 3 + 1]; });
+      u2 = tri_accum(a0, a1, a2, [&](int i, int j, int k) { return field[(((int64_t)i * h1 + j) * h2 + k) * 3 + 2]; });
+    }
+    float pos[3];
+    affine_pos(A, p.in_shape, i0, i1, i2, u0, u1, u2, p.has_field != 0, p.has_affine != 0, pos);
+    int r0 = (int)rintf(pos[0]), r1 = (int)rintf(pos[1]), r2 = (int)rintf(pos[2]);  // tf.round: half to even
+    r0 = min(max(r0, 0), p.in_shape[0] - 1);
+    r1 = min(max(r1, 0), p.in_shape[1] - 1);
+    r2 = min(max(r2, 0), p.in_shape[2] - 1);
+    int lab = labels[((int64_t)r0 * p.in_shape[1] + r1) * p.in_shape[2] + r2];
+    if (p.flip && swap_lut != nullptr && lab >= 0 && lab < p.swap_lut_size) lab = swap_lut[lab];
+    if (seg_out) seg_out[o] = lab;
+
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.use_philox) {
+      uint32_t c[4] = {(uint32_t)o, (uint32_t)((uint64_t)o >> 32), (uint32_t)p.philox_offset,
+                       (uint32_t)(p.philox_offset >> 32)};
+      philox4x32_10(c, p.philox_key[0], p.philox_key[1]);
+      box_muller(c[0], c[1], nz[0], nz[1]);
+      if (C > 2) box_muller(c[2], c[3], nz[2], nz[3]);
+    } else {
+      for (int c = 0; c < C; ++c) nz[c] = noise[o * C + c];
+    }
+    const bool known = (lab >= 0 && lab < p.lut_size);
+    int boff = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < C) {
+        const float mu = known ? gmm_lut[c * p.lut_size + lab] : 0.f;
+        const float sd = known ? gmm_lut[(C + c) * p.lut_size + lab] : 0.f;
+        float x = sd * nz[c] + mu;  // layers.py:498
+        const int b0 = p.bias_shape[c][0], b1 = p.bias_shape[c][1], b2 = p.bias_shape[c][2];
+        if (b0 > 0) {
+          if (p.bias_on[c]) {  // layers.py:1083-1088 (field lives on the OUTPUT grid)
+            const float z0 = (float)((double)p.out_shape[0] / (double)b0);
+            const float z1 = (float)((double)p.out_shape[1] / (double)b1);
+            const float z2 = (float)((double)p.out_shape[2] / (double)b2);
+            const Axis a0 = axis_setup(resize_pos(o0, z0), b0);
+            const Axis a1 = axis_setup(resize_pos(o1, z1), b1);
+            const Axis a2 = axis_setup(resize_pos(o2, z2), b2);
+            const float* bs = bias_small + boff;
+            const float b = tri_accum(a0, a1, a2, [&](int i, int j, int k) { return bs[(i * b1 + j) * b2 + k]; });
+            x = expf(b) * x;
+          }
+          boff += b0 * b1 * b2;
+        }
+        if (p.clip_hi > 0.f) {
+          x = fminf(fmaxf(x, 0.f), p.clip_hi);
+          if (x == 0.f) x = 0.f;  // canonical +0
+        }
+        chan_out[(int64_t)c * n + o] = x;
+        lmin[c] = fminf(lmin[c], x);
+        lmax[c] = fmaxf(lmax[c], x);
+      }
+    }
+  }
+  // block min/max -> one atomic pair per wave per channel
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < C) {
+      const float mn = syn_wave_min(lmin[c]), mx = syn_wave_max(lmax[c]);
+      if ((threadIdx.x & 63) == 0) {
+        atomicMin(&minmax[2 * c + 0], syn_f2ord(mn));
+        atomicMax(&minmax[2 * c + 1], syn_f2ord(mx));
+      }
+    }
+  }
+}
+
+__global__ void minmax_init_kernel(uint32_t* mm, int n_pairs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pairs) {
+    mm[2 * i + 0] = 0xFFFFFFFFu;
+    mm[2 * i + 1] = 0u;
+  }
+}
+
+__global__ void minmax_reduce_kernel(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ mm) {
+  float mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  mn = syn_wave_min(mn);
+  mx = syn_wave_max(mx);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&mm[0], syn_f2ord(mn));
+    atomicMax(&mm[1], syn_f2ord(mx));
+  }
+}
+
+__global__ void normalise_gamma_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
+                                       const uint32_t* __restrict__ mm, float gexp) {
+  const float m = syn_ord2f(mm[0]), M = syn_ord2f(mm[1]);
+  const float den = (M - m) + 1e-7f;  // K.epsilon(), layers.py:1236
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = fminf(fmaxf(x[i], m), M);
+    v = (v - m) / den;
+    if (gexp > 0.f) v = powf(v, gexp);
+    out[i] = v;
+  }
+}
+
+// zero-padded cross-correlation, float32 accumulation in (z,y,x) raster order of the taps
+__global__ __launch_bounds__(256) void blur3d_kernel(const float* __restrict__ in, float* __restrict__ out, Shape3 s,
+                                                     const float* __restrict__ kern, Shape3 ks, int ostride,
+                                                     int ooff, int foff, float fval) {
+  __shared__ float kw[512];
+  const int nk = ks.d[0] * ks.d[1] * ks.d[2];
+  for (int i = threadIdx.x; i < nk; i += blockDim.x) kw[i] = kern[i];
+  __syncthreads();
+  const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  const int p0 = ks.d[0] / 2, p1 = ks.d[1] / 2, p2 = ks.d[2] / 2;
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int i2 = (int)(v % s.d[2]);
+    const int i1 = (int)((v / s.d[2]) % s.d[1]);
+    const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));
+    float acc = 0.f;
+    for (int a = 0; a < ks.d[0]; ++a) {
+      const int z = i0 + a - p0;
+      for (int b = 0; b < ks.d[1]; ++b) {
+        const int y = i1 + b - p1;
+        for (int c = 0; c < ks.d[2]; ++c) {
+          const int x = i2 + c - p2;
+          const bool ok = (z >= 0) & (z < s.d[0]) & (y >= 0) & (y < s.d[1]) & (x >= 0) & (x < s.d[2]);
+          const float val = ok ? in[((int64_t)z * s.d[1] + y) * s.d[2] + x] : 0.f;
+          acc = acc + val * kw[(a * ks.d[1] + b) * ks.d[2] + c];
+        }
+      }
+    }
+    out[v * ostride + ooff] = acc;
+    if (foff >= 0) out[v * ostride + foff] = fval;
+  }
+}
+
+__global__ void outer3_kernel(const float* __restrict__ w, float* __restrict__ out, Shape3 s, int ostride, int ooff) {
+  const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int i2 = (int)(v % s.d[2]);
+    const int i1 = (int)((v / s.d[2]) % s.d[1]);
+    const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));
+    // the reference multiplies the three 1-D maps in float64 and casts once (edit_tensors.py:326-328)
+    const double r = ((double)w[i0] * (double)w[s.d[0] + i1]) * (double)w[s.d[0] + s.d[1] + i2];
+    out[v * ostride + ooff] = (float)r;
+  }
+}
+
+__global__ void copy_strided_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int is, int io,
+                                    int os, int oo) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i * os + oo] = in[i * is + io];
+}
+
+inline bool bad_shape(const int s[3]) { return s[0] <= 0 || s[1] <= 0 || s[2] <= 0; }
+
+}  // namespace
+
+extern "C" {
+
+int synthsr_resize_f32(const float* in, float* out, int C, const int in_shape[3], const int out_shape[3], int method,
+                       synthsr_stream_t stream) {
+  if (!in || !out || C <= 0 || bad_shape(in_shape) || bad_shape(out_shape) || (method != 0 && method != 1))
+    return SYNTHSR_EINVAL;
+  Shape3 is{{in_shape[0], in_shape[1], in_shape[2]}}, os{{out_shape[0], out_shape[1], out_shape[2]}};
+  const float z0 = (float)((double)out_shape[0] / (double)in_shape[0]);
+  const float z1 = (float)((double)out_shape[1] / (double)in_shape[1]);
+  const float z2 = (float)((double)out_shape[2] / (double)in_shape[2]);
+  const int64_t n = (int64_t)os.d[0] * os.d[1] * os.d[2];
+  hipLaunchKernelGGL(resize_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, is, os, z0,
+                     z1, z2, method);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_svf_integrate(float* v, float* scratch, const int shape[3], int nb_steps, synthsr_stream_t stream) {
+  if (!v || !scratch || bad_shape(shape) || nb_steps < 0 || nb_steps > 30) return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  const float scale = 1.0f / (float)(1u << nb_steps);
+  float* a = v;
+  float* b = scratch;
+  if (nb_steps == 0) return SYNTHSR_OK;
+  for (int i = 0; i < nb_steps; ++i) {
+    hipLaunchKernelGGL(svf_step_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, s,
+                       i == 0 ? scale : 1.0f);
+    SYN_CHECK_LAUNCH();
+    float* t = a;
+    a = b;
+    b = t;
+  }
+  if (a != v) {
+    if (hipMemcpyAsync(v, a, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) !=
+        hipSuccess)
+      return SYNTHSR_ELAUNCH;
+  }
+  return SYNTHSR_OK;
+}
+
+int synthsr_affine_resample_linear(const float* in, float* out, int C, const int shape[3], const float aff[12],
+                                   synthsr_stream_t stream) {
+  if (!in || !out || !aff || C <= 0 || bad_shape(shape)) return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  Aff A;
+  for (int i = 0; i < 12; ++i) A.a[i] = aff[i];
+  const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  hipLaunchKernelGGL(affine_resample_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, C, s,
+                     A);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_deform_gmm(const int32_t* labels, const float* field_half, const float* gmm_lut, const int32_t* swap_lut,
+                       const float* noise, const float* bias_small, int32_t* seg_out, float* chan_out,
+                       uint32_t* minmax, const synthsr_deform_params* p, synthsr_stream_t stream) {
+  if (!labels || !gmm_lut || !chan_out || !minmax || !p) return SYNTHSR_EINVAL;
+  if (bad_shape(p->in_shape) || bad_shape(p->out_shape)) return SYNTHSR_EINVAL;
+  if (p->n_channels < 1 || p->n_channels > 4 || p->lut_size < 1) return SYNTHSR_EINVAL;
+  if (p->has_field && (!field_half || bad_shape(p->half_shape))) return SYNTHSR_EINVAL;
+  if (!p->use_philox && !noise) return SYNTHSR_EINVAL;
+  if (p->swap_lut_size > 0 && !swap_lut) return SYNTHSR_EINVAL;
+  for (int d = 0; d < 3; ++d)
+    if (p->crop[d] < 0 || p->crop[d] + p->out_shape[d] > p->in_shape[d]) return SYNTHSR_EINVAL;
+  for (int c = 0; c < p->n_channels; ++c) {
+    if (p->bias_shape[c][0] > 0 && !bias_small) return SYNTHSR_EINVAL;
+    if (p->bias_shape[c][0] > 0 && (p->bias_shape[c][1] <= 0 || p->bias_shape[c][2] <= 0)) return SYNTHSR_EINVAL;
+  }
+  const int64_t n = (int64_t)p->out_shape[0] * p->out_shape[1] * p->out_shape[2];
+  hipLaunchKernelGGL(deform_gmm_kernel, dim3(syn_grid(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, labels,
+                     field_half, gmm_lut, p->swap_lut_size > 0 ? swap_lut : nullptr, noise, bias_small, seg_out,
+                     chan_out, minmax, *p);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_minmax_init(uint32_t* minmax, int n_pairs, synthsr_stream_t stream) {
+  if (!minmax || n_pairs < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(minmax_init_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, minmax, n_pairs);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_minmax_reduce(const float* x, int64_t n, uint32_t* minmax, synthsr_stream_t stream) {
+  if (!x || !minmax || n < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(syn_grid(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, n,
+                     minmax);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_normalise_gamma(const float* x, float* out, int64_t n, const uint32_t* minmax, float gexp,
+                            synthsr_stream_t stream) {
+  if (!x || !out || !minmax || n < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(normalise_gamma_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n,
+                     minmax, gexp);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_blur3d(const float* in, float* out, const int shape[3], const float* kernel, const int ksize[3],
+                   int out_stride, int out_offset, int fill_offset, float fill_value, synthsr_stream_t stream) {
+  if (!in || !out || !kernel || bad_shape(shape) || bad_shape(ksize)) return SYNTHSR_EINVAL;
+  if (ksize[0] * ksize[1] * ksize[2] > 512 || !(ksize[0] & 1) || !(ksize[1] & 1) || !(ksize[2] & 1))
+    return SYNTHSR_EINVAL;
+  if (out_stride < 1 || out_offset < 0 || out_offset >= out_stride || fill_offset >= out_stride) return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}}, ks{{ksize[0], ksize[1], ksize[2]}};
+  const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  hipLaunchKernelGGL(blur3d_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, s, kernel, ks,
+                     out_stride, out_offset, fill_offset, fill_value);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_outer3(const float* w, float* out, const int shape[3], int out_stride, int out_offset,
+                   synthsr_stream_t stream) {
+  if (!w || !out || bad_shape(shape) || out_stride < 1 || out_offset < 0 || out_offset >= out_stride)
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  hipLaunchKernelGGL(outer3_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w, out, s, out_stride,
+                     out_offset);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_copy_strided(const float* in, float* out, int64_t n, int in_stride, int in_offset, int out_stride,
+                         int out_offset, synthsr_stream_t stream) {
+  if (!in || !out || n < 1 || in_stride < 1 || out_stride < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(copy_strided_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n,
+                     in_stride, in_offset, out_stride, out_offset);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_abi_version(void) { return 1; }
+const char* synthsr_build_arch(void) { return "gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,584 @@
+// HBM-bound U-Net kernels (gfx950): ELU backward, BatchNorm (stats / apply / backward), fused
+// BN+max-pool, fused BN+upsample+concat, 1x1x1 head + L1 loss, Keras-semantics Adam.
+// NDHWC: a tensor is [nvox][C]; all kernels move float4 per lane (16 B x 64 lanes = 1 KiB per wave op).
+//
+// Channel reductions use 384-thread workgroups: every channel count of the U-Net (24..576, all
+// multiples of 24) divided by 4 divides 96, so with a grid stride that is a multiple of 384 float4
+// lanes each thread keeps a fixed group of 4 channels -> register partials, one LDS pass, one
+// global atomic per (block, channel).
+#include "common.h"
+
+namespace {
+
+constexpr int RB = 384;  // reduction block size (6 waves)
+
+struct Shape3 {
+  int d[3];
+};
+
+__device__ __forceinline__ float elu_grad_from_y(float y) { return y > 0.f ? 1.f : y + 1.f; }  // alpha = 1
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// block-level channel reduction of NV float4 partials held by threads with a fixed channel group
+template <int NV>
+__device__ __forceinline__ void block_channel_reduce(float4 (&part)[NV], int c4, int C4, bool fixed, float* smem) {
+  // smem: NV * C4 * 4 floats, zeroed by the caller before accumulation started
+  if (fixed) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      atomicAdd(&smem[(k * C4 + c4) * 4 + 0], part[k].x);
+      atomicAdd(&smem[(k * C4 + c4) * 4 + 1], part[k].y);
+      atomicAdd(&smem[(k * C4 + c4) * 4 + 2], part[k].z);
+      atomicAdd(&smem[(k * C4 + c4) * 4 + 3], part[k].w);
+    }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ ELU backward
+// dz = (dy [+ dy2]) * elu'(y); dbias[c] += sum dz
+__global__ __launch_bounds__(RB) void elu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                     const float* __restrict__ y, float* __restrict__ dz,
+                                                     float* __restrict__ dbias, int64_t n4, int C4) {
+  extern __shared__ float smem[];
+  const bool fixed = (RB % C4) == 0;
+  if (dbias)
+    for (int i = threadIdx.x; i < C4 * 4; i += RB) smem[i] = 0.f;
+  __syncthreads();
+  float4 part[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < n4; i += stride) {
+    float4 g = ld4(dy + i * 4);
+    if (dy2) {
+      const float4 g2 = ld4(dy2 + i * 4);
+      g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+    }
+    const float4 a = ld4(y + i * 4);
+    float4 r;
+    r.x = g.x * elu_grad_from_y(a.x);
+    r.y = g.y * elu_grad_from_y(a.y);
+    r.z = g.z * elu_grad_from_y(a.z);
+    r.w = g.w * elu_grad_from_y(a.w);
+    st4(dz + i * 4, r);
+    if (dbias) {
+      if (fixed) {
+        part[0].x += r.x; part[0].y += r.y; part[0].z += r.z; part[0].w += r.w;
+      } else {
+        const int c4 = (int)(i % C4);
+        atomicAdd(&smem[c4 * 4 + 0], r.x);
+        atomicAdd(&smem[c4 * 4 + 1], r.y);
+        atomicAdd(&smem[c4 * 4 + 2], r.z);
+        atomicAdd(&smem[c4 * 4 + 3], r.w);
+      }
+    }
+  }
+  if (dbias) {
+    block_channel_reduce<1>(part, threadIdx.x % C4, C4, fixed, smem);
+    for (int i = threadIdx.x; i < C4 * 4; i += RB) atomicAdd(&dbias[i], smem[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ BN statistics
+__global__ __launch_bounds__(RB) void bn_stats_kernel(const float* __restrict__ x, int64_t n4, int C4,
+                                                      double* __restrict__ ws) {
+  extern __shared__ float smem[];  // [2][C4*4]
+  const bool fixed = (RB % C4) == 0;
+  for (int i = threadIdx.x; i < 2 * C4 * 4; i += RB) smem[i] = 0.f;
+  __syncthreads();
+  float4 part[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < n4; i += stride) {
+    const float4 a = ld4(x + i * 4);
+    if (fixed) {
+      part[0].x += a.x; part[0].y += a.y; part[0].z += a.z; part[0].w += a.w;
+      part[1].x += a.x * a.x; part[1].y += a.y * a.y; part[1].z += a.z * a.z; part[1].w += a.w * a.w;
+    } else {
+      const int c4 = (int)(i % C4);
+      atomicAdd(&smem[c4 * 4 + 0], a.x);
+      atomicAdd(&smem[c4 * 4 + 1], a.y);
+      atomicAdd(&smem[c4 * 4 + 2], a.z);
+      atomicAdd(&smem[c4 * 4 + 3], a.w);
+      atomicAdd(&smem[(C4 + c4) * 4 + 0], a.x * a.x);
+      atomicAdd(&smem[(C4 + c4) * 4 + 1], a.y * a.y);
+      atomicAdd(&smem[(C4 + c4) * 4 + 2], a.z * a.z);
+      atomicAdd(&smem[(C4 + c4) * 4 + 3], a.w * a.w);
+    }
+  }
+  block_channel_reduce<2>(part, threadIdx.x % C4, C4, fixed, smem);
+  for (int i = threadIdx.x; i < 2 * C4 * 4; i += RB) atomicAdd(&ws[i], (double)smem[i]);
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats, int C, double inv_n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const double m = ws[c] * inv_n;
+    double v = ws[C + c] * inv_n - m * m;
+    if (v < 0.0) v = 0.0;
+    stats[c] = (float)m;
+    stats[C + c] = (float)v;
+  }
+}
+
+// per-channel affine of BN: y = x*sc + sh, sc = gamma*rsqrt(var+eps), sh = beta - mean*sc
+__device__ __forceinline__ void bn_coeff(const float* stats, const float* gamma, const float* beta, float eps, int C,
+                                         int c, float& sc, float& sh) {
+  const float inv = rsqrtf(stats[C + c] + eps) * gamma[c];
+  sc = inv;
+  sh = beta[c] - stats[c] * inv;
+}
+
+__device__ __forceinline__ void bn_coeff4(const float* stats, const float* gamma, const float* beta, float eps, int C,
+                                          int c, float4& sc, float4& sh) {
+  bn_coeff(stats, gamma, beta, eps, C, c + 0, sc.x, sh.x);
+  bn_coeff(stats, gamma, beta, eps, C, c + 1, sc.y, sh.y);
+  bn_coeff(stats, gamma, beta, eps, C, c + 2, sc.z, sh.z);
+  bn_coeff(stats, gamma, beta, eps, C, c + 3, sc.w, sh.w);
+}
+
+__device__ __forceinline__ float4 fma4(float4 a, float4 s, float4 h) {
+  return make_float4(a.x * s.x + h.x, a.y * s.y + h.y, a.z * s.z + h.z, a.w * s.w + h.w);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
+                                                       int C, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps) {
+  const int C4 = C / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    float4 sc, sh;
+    bn_coeff4(stats, gamma, beta, eps, C, c, sc, sh);
+    st4(y + i * 4, fma4(ld4(x + i * 4), sc, sh));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ BN + max-pool 2^3
+__global__ __launch_bounds__(256) void bn_maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, Shape3 s,
+                                                         int C, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps) {
+  const int C4 = C / 4;
+  const int o0 = s.d[0] / 2, o1 = s.d[1] / 2, o2 = s.d[2] / 2;
+  const int64_t n4 = (int64_t)o0 * o1 * o2 * C4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    int64_t v = i / C4;
+    const int p2 = (int)(v % o2);
+    v /= o2;
+    const int p1 = (int)(v % o1);
+    const int p0 = (int)(v / o1);
+    float4 sc, sh;
+    bn_coeff4(stats, gamma, beta, eps, C, c, sc, sh);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int64_t vi = ((int64_t)(2 * p0 + a) * s.d[1] + (2 * p1 + b)) * s.d[2] + (2 * p2 + d);
+          const float4 t = fma4(ld4(x + vi * C + c), sc, sh);
+          m.x = fmaxf(m.x, t.x); m.y = fmaxf(m.y, t.y); m.z = fmaxf(m.z, t.z); m.w = fmaxf(m.w, t.w);
+        }
+    st4(y + i * 4, m);
+  }
+}
+
+// gradient w.r.t. the BN output: routed to the FIRST maximum of each 2^3 window (raster order)
+__global__ __launch_bounds__(256) void bn_maxpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             float* __restrict__ dbn, Shape3 s, int C,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps) {
+  const int C4 = C / 4;
+  const int o0 = s.d[0] / 2, o1 = s.d[1] / 2, o2 = s.d[2] / 2;
+  const int64_t n4 = (int64_t)o0 * o1 * o2 * C4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    int64_t v = i / C4;
+    const int p2 = (int)(v % o2);
+    v /= o2;
+    const int p1 = (int)(v % o1);
+    const int p0 = (int)(v / o1);
+    float4 sc, sh;
+    bn_coeff4(stats, gamma, beta, eps, C, c, sc, sh);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int ax = 0, ay = 0, az = 0, aw = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t vi = ((int64_t)(2 * p0 + (k >> 2)) * s.d[1] + (2 * p1 + ((k >> 1) & 1))) * s.d[2] + (2 * p2 + (k & 1));
+      const float4 t = fma4(ld4(x + vi * C + c), sc, sh);
+      if (t.x > m.x) { m.x = t.x; ax = k; }
+      if (t.y > m.y) { m.y = t.y; ay = k; }
+      if (t.z > m.z) { m.z = t.z; az = k; }
+      if (t.w > m.w) { m.w = t.w; aw = k; }
+    }
+    const float4 g = ld4(dy + i * 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t vi = ((int64_t)(2 * p0 + (k >> 2)) * s.d[1] + (2 * p1 + ((k >> 1) & 1))) * s.d[2] + (2 * p2 + (k & 1));
+      st4(dbn + vi * C + c, make_float4(ax == k ? g.x : 0.f, ay == k ? g.y : 0.f, az == k ? g.z : 0.f, aw == k ? g.w : 0.f));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ BN backward
+__global__ __launch_bounds__(RB) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           int64_t n4, int C, const float* __restrict__ stats,
+                                                           float eps, float* __restrict__ sums) {
+  extern __shared__ float smem[];  // [2][C]
+  const int C4 = C / 4;
+  const bool fixed = (RB % C4) == 0;
+  for (int i = threadIdx.x; i < 2 * C; i += RB) smem[i] = 0.f;
+  __syncthreads();
+  float4 part[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    const float4 g = ld4(dy + i * 4);
+    const float4 a = ld4(x + i * 4);
+    float4 xh;
+    xh.x = (a.x - stats[c + 0]) * rsqrtf(stats[C + c + 0] + eps);
+    xh.y = (a.y - stats[c + 1]) * rsqrtf(stats[C + c + 1] + eps);
+    xh.z = (a.z - stats[c + 2]) * rsqrtf(stats[C + c + 2] + eps);
+    xh.w = (a.w - stats[c + 3]) * rsqrtf(stats[C + c + 3] + eps);
+    if (fixed) {
+      part[0].x += g.x; part[0].y += g.y; part[0].z += g.z; part[0].w += g.w;
+      part[1].x += g.x * xh.x; part[1].y += g.y * xh.y; part[1].z += g.z * xh.z; part[1].w += g.w * xh.w;
+    } else {
+      atomicAdd(&smem[c + 0], g.x); atomicAdd(&smem[c + 1], g.y);
+      atomicAdd(&smem[c + 2], g.z); atomicAdd(&smem[c + 3], g.w);
+      atomicAdd(&smem[C + c + 0], g.x * xh.x); atomicAdd(&smem[C + c + 1], g.y * xh.y);
+      atomicAdd(&smem[C + c + 2], g.z * xh.z); atomicAdd(&smem[C + c + 3], g.w * xh.w);
+    }
+  }
+  block_channel_reduce<2>(part, threadIdx.x % C4, C4, fixed, smem);
+  for (int i = threadIdx.x; i < 2 * C; i += RB) atomicAdd(&sums[i], smem[i]);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dx, int64_t n4, int C,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, float eps,
+                                                           const float* __restrict__ sums, float inv_n) {
+  const int C4 = C / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const float4 g = ld4(dy + i * 4);
+    const float4 a = ld4(x + i * 4);
+    float r[4];
+    const float gg[4] = {g.x, g.y, g.z, g.w}, aa[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float inv = rsqrtf(stats[C + c + k] + eps);
+      const float xh = (aa[k] - stats[c + k]) * inv;
+      r[k] = gamma[c + k] * inv * (gg[k] - sums[c + k] * inv_n - xh * sums[C + c + k] * inv_n);
+    }
+    st4(dx + i * 4, make_float4(r[0], r[1], r[2], r[3]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ upsample + concat
+__global__ __launch_bounds__(256) void upsample_concat_kernel(const float* __restrict__ skip,
+                                                              const float* __restrict__ lo, float* __restrict__ out,
+                                                              Shape3 s, int Cs, int Cl,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps) {
+  const int C = Cs + Cl, C4 = C / 4;
+  const int64_t n4 = (int64_t)s.d[0] * s.d[1] * s.d[2] * C4;
+  const int l1 = s.d[1] / 2, l2 = s.d[2] / 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    int64_t v = i / C4;
+    float4 r;
+    if (c < Cs) {
+      r = ld4(skip + v * Cs + c);
+    } else {
+      const int i2 = (int)(v % s.d[2]);
+      const int i1 = (int)((v / s.d[2]) % s.d[1]);
+      const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));
+      const int64_t lv = ((int64_t)(i0 >> 1) * l1 + (i1 >> 1)) * l2 + (i2 >> 1);
+      float4 sc, sh;
+      bn_coeff4(stats, gamma, beta, eps, Cl, c - Cs, sc, sh);
+      r = fma4(ld4(lo + lv * Cl + (c - Cs)), sc, sh);
+    }
+    st4(out + i * 4, r);
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_concat_bwd_kernel(const float* __restrict__ dcat,
+                                                                  float* __restrict__ dskip,
+                                                                  float* __restrict__ dlo, Shape3 s, int Cs, int Cl) {
+  const int C = Cs + Cl;
+  const int Cs4 = Cs / 4, Cl4 = Cl / 4;
+  const int64_t nv = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  const int l0 = s.d[0] / 2, l1 = s.d[1] / 2, l2 = s.d[2] / 2;
+  const int64_t nskip4 = nv * Cs4;
+  const int64_t nlo4 = (int64_t)l0 * l1 * l2 * Cl4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nskip4 + nlo4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nskip4) {
+      const int c = (int)(i % Cs4) * 4;
+      const int64_t v = i / Cs4;
+      st4(dskip + v * Cs + c, ld4(dcat + v * C + c));
+    } else {
+      const int64_t j = i - nskip4;
+      const int c = (int)(j % Cl4) * 4;
+      int64_t v = j / Cl4;
+      const int p2 = (int)(v % l2);
+      v /= l2;
+      const int p1 = (int)(v % l1);
+      const int p0 = (int)(v / l1);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t vi = ((int64_t)(2 * p0 + (k >> 2)) * s.d[1] + (2 * p1 + ((k >> 1) & 1))) * s.d[2] + (2 * p2 + (k & 1));
+        const float4 t = ld4(dcat + vi * C + Cs + c);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+      st4(dlo + j * 4, acc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ head + L1 loss
+__global__ __launch_bounds__(256) void head_l1_fwd_kernel(const float* __restrict__ x, int64_t nvox, int C,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          const float* __restrict__ residual, int rs, int ro,
+                                                          const float* __restrict__ target, float* __restrict__ pred,
+                                                          float* __restrict__ dpred, float* __restrict__ loss,
+                                                          float inv_n) {
+  extern __shared__ float smem[];  // weff[C], then 1 float bias_eff
+  // fold BN into the 1x1x1 conv: pred = sum_c (w*sc)[c]*x[c] + (b + sum_c w[c]*sh[c])
+  float* weff = smem;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float sc, sh;
+    bn_coeff(stats, gamma, beta, eps, C, c, sc, sh);
+    weff[c] = sc;         // keep scale and shift separately: pred accumulates w*(x*sc+sh) like the unfused graph
+    weff[C + c] = sh;
+    weff[2 * C + c] = w[c];
+  }
+  __syncthreads();
+  float lsum = 0.f;
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    const float* xp = x + v * C;
+    for (int c = 0; c < C; c += 4) {
+      const float4 a = ld4(xp + c);
+      acc += weff[2 * C + c + 0] * (a.x * weff[c + 0] + weff[C + c + 0]);
+      acc += weff[2 * C + c + 1] * (a.y * weff[c + 1] + weff[C + c + 1]);
+      acc += weff[2 * C + c + 2] * (a.z * weff[c + 2] + weff[C + c + 2]);
+      acc += weff[2 * C + c + 3] * (a.w * weff[c + 3] + weff[C + c + 3]);
+    }
+    acc += b[0];
+    if (residual) acc += residual[v * rs + ro];
+    if (pred) pred[v] = acc;
+    const float e = acc - target[v];
+    lsum += fabsf(e);
+    if (dpred) dpred[v] = (e > 0.f ? inv_n : (e < 0.f ? -inv_n : 0.f));
+  }
+  lsum = syn_wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss, lsum * inv_n);
+}
+
+__global__ __launch_bounds__(RB) void head_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ x,
+                                                      int64_t n4, int C, const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps,
+                                                      const float* __restrict__ w, float* __restrict__ dbn,
+                                                      float* __restrict__ dw, float* __restrict__ db) {
+  extern __shared__ float smem[];  // [C] dw partials + 1 db
+  const int C4 = C / 4;
+  const bool fixed = (RB % C4) == 0;
+  for (int i = threadIdx.x; i < C + 1; i += RB) smem[i] = 0.f;
+  __syncthreads();
+  float4 part[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+  float dbp = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    const int64_t v = i / C4;
+    const float g = dpred[v];
+    float4 sc, sh;
+    bn_coeff4(stats, gamma, beta, eps, C, c, sc, sh);
+    const float4 bn = fma4(ld4(x + i * 4), sc, sh);
+    st4(dbn + i * 4, make_float4(g * w[c + 0], g * w[c + 1], g * w[c + 2], g * w[c + 3]));
+    if (fixed) {
+      part[0].x += g * bn.x; part[0].y += g * bn.y; part[0].z += g * bn.z; part[0].w += g * bn.w;
+    } else {
+      atomicAdd(&smem[c + 0], g * bn.x); atomicAdd(&smem[c + 1], g * bn.y);
+      atomicAdd(&smem[c + 2], g * bn.z); atomicAdd(&smem[c + 3], g * bn.w);
+    }
+    if (c == 0) dbp += g;
+  }
+  atomicAdd(&smem[C], dbp);
+  block_channel_reduce<1>(part, threadIdx.x % C4, C4, fixed, smem);
+  for (int i = threadIdx.x; i < C; i += RB) atomicAdd(&dw[i], smem[i]);
+  if (threadIdx.x == 0) atomicAdd(db, smem[C]);
+}
+
+// ------------------------------------------------------------------------------------------ Adam (Keras 2.3.1)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_t,
+                                                   float b1, float b2, float eps, float gs) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+inline bool ok_c4(int C) { return C > 0 && (C % 4) == 0 && C <= 4096; }
+inline bool bad_shape(const int s[3]) { return s[0] <= 0 || s[1] <= 0 || s[2] <= 0; }
+inline bool odd_shape(const int s[3]) { return (s[0] | s[1] | s[2]) & 1; }
+
+}  // namespace
+
+extern "C" {
+
+int synthsr_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
+                    synthsr_stream_t stream) {
+  if (!dy || !y || !dz || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(elu_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
+                     dy2, y, dz, dbias, n4, C / 4);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* ws, synthsr_stream_t stream) {
+  if (!x || !stats || !ws || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  if (hipMemsetAsync(ws, 0, 2 * C * sizeof(double), (hipStream_t)stream) != hipSuccess) return SYNTHSR_ELAUNCH;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
+                     (hipStream_t)stream, x, n4, C / 4, ws);
+  SYN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, stats, C,
+                     1.0 / (double)nvox);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bn_apply(const float* x, float* y, int64_t nvox, int C, const float* stats, const float* gamma,
+                     const float* beta, float eps, synthsr_stream_t stream) {
+  if (!x || !y || !stats || !gamma || !beta || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n4, C, stats,
+                     gamma, beta, eps);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bn_maxpool(const float* x, float* y, const int shape[3], int C, const float* stats, const float* gamma,
+                       const float* beta, float eps, synthsr_stream_t stream) {
+  if (!x || !y || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C)) return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_maxpool_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, s, C, stats,
+                     gamma, beta, eps);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bn_maxpool_bwd(const float* dy, const float* x, float* dbn, const int shape[3], int C, const float* stats,
+                           const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  if (!dy || !x || !dbn || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C))
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_maxpool_bwd_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dbn, s,
+                     C, stats, gamma, beta, eps);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bn_bwd_reduce(const float* dy, const float* x, int64_t nvox, int C, const float* stats, float eps,
+                          float* sums, synthsr_stream_t stream) {
+  if (!dy || !x || !stats || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
+                     (hipStream_t)stream, dy, x, n4, C, stats, eps, sums);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bn_bwd_apply(const float* dy, const float* x, float* dx, int64_t nvox, int C, const float* stats,
+                         const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
+  if (!dy || !x || !dx || !stats || !gamma || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n4, C,
+                     stats, gamma, eps, sums, (float)(1.0 / (double)nvox));
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_upsample_concat(const float* skip, const float* lo, float* out, const int shape[3], int Cs, int Cl,
+                            const float* stats, const float* gamma, const float* beta, float eps,
+                            synthsr_stream_t stream) {
+  if (!skip || !lo || !out || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(Cs) ||
+      !ok_c4(Cl))
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n4 = (int64_t)s.d[0] * s.d[1] * s.d[2] * ((Cs + Cl) / 4);
+  hipLaunchKernelGGL(upsample_concat_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, skip, lo, out,
+                     s, Cs, Cl, stats, gamma, beta, eps);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_upsample_concat_bwd(const float* dcat, float* dskip, float* dlo_bn, const int shape[3], int Cs, int Cl,
+                                synthsr_stream_t stream) {
+  if (!dcat || !dskip || !dlo_bn || bad_shape(shape) || odd_shape(shape) || !ok_c4(Cs) || !ok_c4(Cl))
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t nv = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  const int64_t n4 = nv * (Cs / 4) + (nv / 8) * (Cl / 4);
+  hipLaunchKernelGGL(upsample_concat_bwd_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, dcat,
+                     dskip, dlo_bn, s, Cs, Cl);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta,
+                        float eps, const float* w, const float* b, const float* residual, int res_stride, int res_off,
+                        const float* target, float* pred, float* dpred, float* loss, synthsr_stream_t stream) {
+  if (!x || !stats || !gamma || !beta || !w || !b || !target || !loss || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  if (residual && (res_stride < 1 || res_off < 0 || res_off >= res_stride)) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(head_l1_fwd_kernel, dim3(syn_grid(nvox, 256, 4096)), dim3(256), 3 * C * sizeof(float),
+                     (hipStream_t)stream, x, nvox, C, stats, gamma, beta, eps, w, b, residual, res_stride, res_off,
+                     target, pred, dpred, loss, (float)(1.0 / (double)nvox));
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_head_bwd(const float* dpred, const float* x, int64_t nvox, int C, const float* stats, const float* gamma,
+                     const float* beta, float eps, const float* w, float* dbn, float* dw, float* db,
+                     synthsr_stream_t stream) {
+  if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C))
+    return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
+                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                      float eps, float grad_scale, synthsr_stream_t stream) {
+  if (!p || !g || !m || !v || n < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(adam_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
+                     beta2, eps, grad_scale);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,344 @@
+"""Host-side (numpy, float32) parameter math of the generator: everything that is O(1) per volume and
+feeds the HIP kernels as small arguments — 4x4 affine sampling, blur-kernel weights, shape arithmetic,
+look-up tables, reliability-map profiles.  The per-voxel work is in csrc/generator.hip.
+
+float32 op order follows the reference graph (file:line cited per function) so that the kernels see the
+same coefficients the reference's TF graph would compute; 4x4 products are k-ordered multiply/add
+chains (TF's own accumulation order is third-party and unpinned).
+"""
+import math
+import numpy as np
+
+_F = np.float32
+
+
+def _f(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def _mm(a, b):
+    a, b = _f(a), _f(b)
+    out = a[:, :1] * b[:1, :]
+    for k in range(1, a.shape[1]):
+        out = out + a[:, k:k + 1] * b[k:k + 1, :]
+    return out
+
+
+def reformat_to_list(var, length=None, dtype=None):
+    """ext/lab2im/utils.py:319-370 for the value kinds the hot path passes (number, sequence, 1-D array)"""
+    if var is None:
+        return None
+    if isinstance(var, np.ndarray):
+        var = np.squeeze(var).tolist() if var.ndim else [var.item()]
+    if isinstance(var, (int, float, bool, str, np.integer, np.floating, np.bool_)):
+        var = [var]
+    elif isinstance(var, tuple):
+        var = list(var)
+    if not isinstance(var, list):
+        raise TypeError('variable should be an int, float, bool, str, list, tuple or numpy array, had %s' % type(var))
+    if length is not None:
+        if len(var) == 1:
+            var = var * length
+        elif len(var) != length:
+            raise ValueError('if var is a list/tuple/numpy array, it should be of length 1 or %d, had %s'
+                             % (length, var))
+    if dtype is not None:
+        conv = {'int': int, 'float': float, 'bool': bool, 'str': str}[dtype]
+        var = [conv(v) for v in var]
+    return var
+
+
+def reformat_to_n_channels_array(var, n_dims=3, n_channels=1):
+    """ext/lab2im/utils.py:373-407"""
+    if var is None:
+        return None
+    if isinstance(var, (int, float, np.integer, np.floating)):
+        return np.full((n_channels, n_dims), float(var))
+    arr = np.array(var, dtype=np.float64)
+    if arr.ndim <= 1:
+        arr = arr.reshape(-1)
+        if arr.size == 1:
+            return np.full((n_channels, n_dims), float(arr[0]))
+        if arr.size != n_dims:
+            raise ValueError('if var is a list/tuple, it should be of length 1 or n_dims, had %s' % (var,))
+        return np.tile(arr.reshape(1, n_dims), (n_channels, 1))
+    if arr.shape != (n_channels, n_dims):
+        raise ValueError('if array, var should be of shape (n_channels, n_dims), had %s' % (arr.shape,))
+    return arr
+
+
+def load_array_if_path(var, load_as_numpy=True):
+    """ext/lab2im/utils.py:287-316"""
+    if isinstance(var, str) and load_as_numpy:
+        if not var.endswith(('.npy', '.npz')):
+            raise ValueError('%s is not the path to a numpy array' % var)
+        return np.load(var)
+    return var
+
+
+def find_closest_number_divisible_by_m(n, m):
+    return n if n % m == 0 else int(n / m) * m
+
+
+def get_resample_shape(shape, factor):
+    """ext/lab2im/utils.py:577-588"""
+    factor = reformat_to_list(factor, length=len(shape))
+    return [math.ceil(shape[i] * factor[i]) for i in range(len(shape))]
+
+
+def get_padding_margin(cropping, loss_cropping):
+    """ext/lab2im/utils.py:601-614"""
+    if cropping is None or loss_cropping is None:
+        return None
+    cropping = reformat_to_list(cropping)
+    loss_cropping = reformat_to_list(loss_cropping)
+    n = max(len(cropping), len(loss_cropping))
+    cropping = reformat_to_list(cropping, length=n)
+    loss_cropping = reformat_to_list(loss_cropping, length=n)
+    pm = [int((cropping[i] - loss_cropping[i]) / 2) for i in range(n)]
+    return pm[0] if len(pm) == 1 else pm
+
+
+def get_shapes(labels_shape, output_shape, atlas_res, target_res, padding_margin, output_div_by_n):
+    """SynthSR/labels_to_image_model.py:269-335 -> (cropping_shape, output_shape, padding_margin)"""
+    atlas_res = reformat_to_list(atlas_res)
+    n_dims = len(atlas_res)
+    target_res = reformat_to_list(target_res)
+    labels_shape = list(labels_shape)
+    if padding_margin is not None:
+        padding_margin = reformat_to_list(padding_margin, length=n_dims, dtype='int')
+        labels_shape = [labels_shape[i] + 2 * padding_margin[i] for i in range(n_dims)]
+    resample_factor = None
+    if atlas_res != target_res:
+        resample_factor = [atlas_res[i] / float(target_res[i]) for i in range(n_dims)]
+    if output_shape is not None:
+        output_shape = reformat_to_list(output_shape, length=n_dims, dtype='int')
+        if resample_factor is not None:
+            output_shape = [min(int(labels_shape[i] * resample_factor[i]), output_shape[i]) for i in range(n_dims)]
+        else:
+            output_shape = [min(labels_shape[i], output_shape[i]) for i in range(n_dims)]
+        if output_div_by_n is not None:
+            tmp = [find_closest_number_divisible_by_m(s, output_div_by_n) for s in output_shape]
+            if output_shape != tmp:
+                print('output shape {0} not divisible by {1}, changed to {2}'.format(output_shape, output_div_by_n, tmp))
+                output_shape = tmp
+        if resample_factor is not None:
+            cropping_shape = [int(np.around(output_shape[i] / resample_factor[i], 0)) for i in range(n_dims)]
+        else:
+            cropping_shape = output_shape
+    else:
+        if output_div_by_n is not None:
+            if resample_factor is not None:
+                output_shape = [int(labels_shape[i] * resample_factor[i]) for i in range(n_dims)]
+                output_shape = [find_closest_number_divisible_by_m(s, output_div_by_n) for s in output_shape]
+                cropping_shape = [int(np.around(output_shape[i] / resample_factor[i], 0)) for i in range(n_dims)]
+            else:
+                cropping_shape = [find_closest_number_divisible_by_m(s, output_div_by_n) for s in labels_shape]
+                output_shape = cropping_shape
+        else:
+            cropping_shape = labels_shape
+            if resample_factor is not None:
+                output_shape = [int(cropping_shape[i] * resample_factor[i]) for i in range(n_dims)]
+            else:
+                output_shape = cropping_shape
+    return cropping_shape, output_shape, padding_margin
+
+
+def get_ras_axes(aff, n_dims=3):
+    """ext/lab2im/edit_volumes.py:591-606"""
+    aff_inverted = np.linalg.inv(aff)
+    img_ras_axes = np.argmax(np.absolute(aff_inverted[0:n_dims, 0:n_dims]), axis=0)
+    for i in range(n_dims):
+        if i not in img_ras_axes:
+            unique, counts = np.unique(img_ras_axes, return_counts=True)
+            incorrect_value = unique[np.argmax(counts)]
+            img_ras_axes[np.where(img_ras_axes == incorrect_value)[0][-1]] = i
+    return img_ras_axes
+
+
+def uniform_f32(u, lo, hi):
+    """tf.random.uniform(shape, minval, maxval) applied to a raw U[0,1) draw, float32"""
+    lo, hi = _f(lo), _f(hi)
+    return _f(u) * (hi - lo) + lo
+
+
+def bounds_pair(b, centre, size):
+    """hyperparameter -> (min[size], max[size]) — utils.draw_value_from_distribution (utils.py:1002-1016)"""
+    b = load_array_if_path(b)
+    if isinstance(b, np.ndarray):
+        if b.shape[0] % 2 != 0:
+            raise AssertionError('number of rows of parameter_range should be divisible by 2')
+        if b.shape[0] != 2:
+            raise NotImplementedError('multi-modality (2n, m) bounds are not supported on the device path yet')
+        return b[0].astype(np.float64), b[1].astype(np.float64)
+    if b is None:
+        raise ValueError('None bounds have caller-specific defaults; pass a number')
+    if isinstance(b, (int, float, np.integer, np.floating)):
+        return np.full(size, centre - b, np.float64), np.full(size, centre + b, np.float64)
+    if isinstance(b, (list, tuple)):
+        assert len(b) == 2, 'if list, parameter_range should be of length 2.'
+        return np.full(size, b[0], np.float64), np.full(size, b[1], np.float64)
+    raise ValueError('parameter_range should either be None, a number, a sequence, or a numpy array.')
+
+
+def sample_affine(u, rotation_bounds=False, scaling_bounds=False, shearing_bounds=False, translation_bounds=False):
+    """utils.sample_affine_transform (ext/lab2im/utils.py:675-752) for one item, 3-D.
+    u: dict of raw uniforms {'rot':[3], 'shear':[6], 'scale':[3], 'trans':[3]} (only the enabled ones)."""
+    eye = np.eye(3, dtype=_F)
+    R = Sh = S = eye
+    if rotation_bounds is not False:
+        lo, hi = bounds_pair(rotation_bounds, 0., 3)
+        r = uniform_f32(u['rot'], lo, hi) * _F(np.pi) / _F(180)  # utils.py:757
+        c, s = np.cos(r), np.sin(r)
+        Rx = _f([[1, 0, 0], [0, c[0], -s[0]], [0, s[0], c[0]]])
+        Ry = _f([[c[1], 0, s[1]], [0, 1, 0], [-s[1], 0, c[1]]])
+        Rz = _f([[c[2], -s[2], 0], [s[2], c[2], 0], [0, 0, 1]])
+        R = _mm(_mm(Rx, Ry), Rz)  # :782
+    if shearing_bounds is not False:
+        lo, hi = bounds_pair(shearing_bounds, 0., 6)
+        h = uniform_f32(u['shear'], lo, hi)
+        Sh = _f([[1, h[0], h[1]], [h[2], 1, h[3]], [h[4], h[5], 1]])
+    if scaling_bounds is not False:
+        lo, hi = bounds_pair(scaling_bounds, 1., 3)
+        S = np.diag(uniform_f32(u['scale'], lo, hi)).astype(_F)
+    T = np.zeros((4, 4), _F)
+    T[:3, :3] = _mm(S, _mm(Sh, R))  # :735
+    if translation_bounds is not False:
+        lo, hi = bounds_pair(translation_bounds, 0., 3)
+        T[:3, 3] = uniform_f32(u['trans'], lo, hi)
+    T[3, 3] = 1
+    return T
+
+
+def matmul4(a, b):
+    return _mm(a, b)
+
+
+def invert_affine(T):
+    """tf.linalg.inv on a 4x4 (SynthSR/labels_to_image_model.py:207); float64 solve rounded to float32"""
+    return np.linalg.inv(np.asarray(T, dtype=np.float64)).astype(_F)
+
+
+def blurring_sigma_for_downsampling(current_res, downsample_res, mult_coef=None, thickness=None):
+    """ext/lab2im/edit_tensors.py:41-65 (numpy branch)"""
+    current_res = np.array(current_res, dtype=np.float64)
+    downsample_res = np.array(downsample_res, dtype=np.float64)
+    if thickness is not None:
+        downsample_res = np.minimum(downsample_res, np.array(thickness, dtype=np.float64))
+    if mult_coef is None:
+        sigma = 0.75 * downsample_res / current_res
+        sigma[downsample_res == current_res] = 0.5
+    else:
+        sigma = mult_coef * downsample_res / current_res
+    sigma[downsample_res == 0] = 0
+    return sigma
+
+
+def blur_window(sigma):
+    """edit_tensors.py:124"""
+    return [int(w) for w in (np.int32(np.ceil(2.5 * np.array(sigma, dtype=np.float64)) / 2) * 2 + 1)]
+
+
+def gaussian_kernel(sigma, u_blur=None, blur_range=None):
+    """et.gaussian_kernel, non-separable branch (ext/lab2im/edit_tensors.py:156-181), float32 [k0,k1,k2]"""
+    sig = _f(sigma)
+    if blur_range is not None and blur_range != 1:
+        sig = sig * uniform_f32(u_blur, 1 / blur_range, blur_range)  # :121
+    ws = blur_window(sigma)
+    g = np.meshgrid(*[np.arange(w, dtype=_F) for w in ws], indexing='ij')
+    diff = np.stack([g[d] - _F((ws[d] - 1) / 2) for d in range(3)], -1)
+    s = sig.reshape(1, 1, 1, 3)
+    zero = s == 0
+    s1 = np.where(zero, _F(1), s)
+    e = -np.square(diff) / (_F(2) * s1 ** 2)
+    nrm = e - np.log(np.where(zero, _F(1), _F(np.sqrt(2 * np.pi)) * s))
+    k = np.exp(np.sum(nrm, -1, dtype=_F))
+    return (k / np.sum(k, dtype=_F)).astype(_F)
+
+
+def is_separable_sigma(sigma):
+    """GaussianBlur.build (ext/lab2im/layers.py:720)"""
+    return bool(np.linalg.norm(np.array(sigma, dtype=np.float64)) > 5)
+
+
+def reliability_profile(n_out, n_down):
+    """one axis of the reliability map, float64 (ext/lab2im/edit_tensors.py:313-323)"""
+    up = n_out / n_down
+    loc = np.arange(0, n_out, up)
+    fl = np.int32(np.floor(loc))
+    ce = np.int32(np.clip(fl + 1, 0, n_out - 1))
+    w = np.zeros(n_out)
+    w[fl] = 1 - (loc - fl)
+    w[ce] = w[ce] + (loc - fl)
+    return w
+
+
+def get_mapping_lut(source, dest=None):
+    """ext/lab2im/utils.py:894-914"""
+    source = np.array(reformat_to_list(source), dtype='int32')
+    if dest is None:
+        dest = np.arange(source.shape[0], dtype='int32')
+    else:
+        assert len(source) == len(dest), 'label_list and new_label_list should have the same length'
+        dest = np.array(reformat_to_list(dest, dtype='int'))
+    lut = np.zeros(np.max(source) + 1, dtype='int32')
+    for s, d in zip(source, dest):
+        lut[s] = d
+    return lut
+
+
+def flip_swap_lut(label_list, n_neutral_labels):
+    """RandomFlip.build (ext/lab2im/layers.py:375-386); None when there are no sided labels"""
+    label_list = np.asarray(label_list)
+    n = len(label_list)
+    if n_neutral_labels is None or n_neutral_labels == n:
+        return None
+    split = np.split(label_list, [n_neutral_labels, n_neutral_labels + int((n - n_neutral_labels) / 2)])
+    return get_mapping_lut(label_list, np.concatenate((split[0], split[2], split[1])))
+
+
+def gmm_luts(generation_labels, means, stds):
+    """SampleConditionalGMM's scatter_nd LUTs for one item (ext/lab2im/layers.py:472-495) -> [2, C, L] float32.
+    tf.scatter_nd accumulates duplicate labels; so does np.add.at."""
+    generation_labels = np.asarray(generation_labels).astype(np.int64)
+    means, stds = _f(means), _f(stds)
+    C = means.shape[-1]
+    L = int(generation_labels.max()) + 1
+    lut = np.zeros((2, C, L), _F)
+    for c in range(C):
+        np.add.at(lut[0, c], generation_labels, means[:, c])
+        np.add.at(lut[1, c], generation_labels, stds[:, c])
+    return lut
+
+
+def draw_value_from_distribution(hyperparameter, size=1, distribution='uniform', centre=0., default_range=10.0,
+                                 positive_only=False, rng=None):
+    """numpy branch of utils.draw_value_from_distribution (ext/lab2im/utils.py:961-1049)"""
+    rng = np.random if rng is None else rng
+    if hyperparameter is False:
+        return None
+    hyperparameter = load_array_if_path(hyperparameter)
+    if not isinstance(hyperparameter, np.ndarray):
+        if hyperparameter is None:
+            hyperparameter = np.array([[centre - default_range] * size, [centre + default_range] * size])
+        elif isinstance(hyperparameter, (int, float)):
+            hyperparameter = np.array([[centre - hyperparameter] * size, [centre + hyperparameter] * size])
+        elif isinstance(hyperparameter, (list, tuple)):
+            assert len(hyperparameter) == 2, 'if list, parameter_range should be of length 2.'
+            hyperparameter = np.transpose(np.tile(np.array(hyperparameter), (size, 1)))
+        else:
+            raise ValueError('parameter_range should either be None, a number, a sequence, or a numpy array.')
+    else:
+        assert hyperparameter.shape[0] % 2 == 0, 'number of rows of parameter_range should be divisible by 2'
+        n_modalities = int(hyperparameter.shape[0] / 2)
+        modality_idx = 2 * int(rng.randint(n_modalities) if hasattr(rng, 'randint') else rng.integers(n_modalities))
+        hyperparameter = hyperparameter[modality_idx: modality_idx + 2, :]
+    if distribution == 'uniform':
+        value = rng.uniform(low=hyperparameter[0, :], high=hyperparameter[1, :])
+    elif distribution == 'normal':
+        value = rng.normal(loc=hyperparameter[0, :], scale=hyperparameter[1, :])
+    else:
+        raise ValueError("Distribution not supported, should be 'uniform' or 'normal'.")
+    if positive_only:
+        value[value < 0] = 0
+    return value

@@ -1,0 +1,202 @@
+"""Thin tensor-level wrappers over the C ABI (include/synthsr_hip.h) for the U-Net kernels.
+
+Tensors are contiguous float32 device tensors in NDHWC order ([d0,d1,d2,C]; batch handled by the
+caller).  No autograd, no CPU fallback: each function is one (or a few) kernel launches on the
+current stream.
+"""
+import ctypes
+import torch
+
+from . import _lib
+
+BN_EPS = 1e-3  # keras.layers.BatchNormalization default epsilon (Keras 2.3.1)
+
+# optional per-launch timing of the conv kernels (bench.py): list of (kind, shape, Cin, Cout, start_evt, end_evt)
+_prof = None
+
+
+def profile_start():
+    global _prof
+    _prof = []
+
+
+def profile_stop():
+    global _prof
+    p, _prof = _prof, None
+    return p
+
+
+class _Timed:
+    def __init__(self, kind, shape, cin, cout):
+        self.meta = (kind, tuple(int(s) for s in shape), int(cin), int(cout))
+
+    def __enter__(self):
+        if _prof is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if _prof is not None:
+            self.e.record()
+            _prof.append(self.meta + (self.s, self.e))
+
+
+def _L():
+    return _lib.load()
+
+
+def pack_conv_weights(w, mode=0, out=None):
+    """w: Keras Conv3D kernel [3,3,3,Cin,Cout] -> MFMA fragment order (mode 0 fwd, 1 data-gradient)"""
+    lib = _L()
+    Cin, Cout = int(w.shape[3]), int(w.shape[4])
+    n = lib.synthsr_conv3d_pack(None, None, Cin, Cout, mode, None)
+    if n < 0:
+        _lib.check(int(n), 'conv3d_pack(size)')
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w.device)
+    assert out.numel() == n
+    r = lib.synthsr_conv3d_pack(_lib.ptr(w), _lib.ptr(out), Cin, Cout, mode, _lib.stream())
+    if r < 0:
+        _lib.check(int(r), 'conv3d_pack')
+    return out
+
+
+def conv3d(x, wpacked, bias, Cout, act=1, out=None):
+    """x [d0,d1,d2,Cin] -> [d0,d1,d2,Cout]; act: 0 linear, 1 ELU"""
+    lib = _L()
+    s = x.shape
+    if out is None:
+        out = torch.empty((s[0], s[1], s[2], Cout), dtype=torch.float32, device=x.device)
+    with _Timed('conv3d_fwd' if bias is not None else 'conv3d_dgrad', s[:3], s[3], Cout):
+        _lib.check(lib.synthsr_conv3d_fwd(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out),
+                                          _lib.i3(s[:3]), int(s[3]), int(Cout), int(act), _lib.stream()), 'conv3d_fwd')
+    return out
+
+
+def conv3d_wgrad(x, dout, dw):
+    """dw [3,3,3,Cin,Cout] += sum_v x[v+t-1] (x) dout[v]"""
+    lib = _L()
+    s = x.shape
+    with _Timed('conv3d_wgrad', s[:3], s[3], dout.shape[3]):
+        _lib.check(lib.synthsr_conv3d_wgrad(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.i3(s[:3]), int(s[3]),
+                                            int(dout.shape[3]), _lib.stream()), 'conv3d_wgrad')
+    return dw
+
+
+def elu_bwd(dy, y, dy2=None, dbias=None, out=None):
+    lib = _L()
+    C = int(y.shape[-1])
+    nvox = y.numel() // C
+    if out is None:
+        out = torch.empty_like(y)
+    _lib.check(lib.synthsr_elu_bwd(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(out), _lib.ptr(dbias), nvox, C,
+                                   _lib.stream()), 'elu_bwd')
+    return out
+
+
+def bn_stats(x, stats, ws):
+    lib = _L()
+    C = int(x.shape[-1])
+    _lib.check(lib.synthsr_bn_stats(_lib.ptr(x), x.numel() // C, C, _lib.ptr(stats), _lib.ptr(ws), _lib.stream()),
+               'bn_stats')
+    return stats
+
+
+def bn_apply(x, stats, gamma, beta, out=None, eps=BN_EPS):
+    lib = _L()
+    C = int(x.shape[-1])
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.synthsr_bn_apply(_lib.ptr(x), _lib.ptr(out), x.numel() // C, C, _lib.ptr(stats), _lib.ptr(gamma),
+                                    _lib.ptr(beta), eps, _lib.stream()), 'bn_apply')
+    return out
+
+
+def bn_maxpool(x, stats, gamma, beta, out=None, eps=BN_EPS):
+    lib = _L()
+    s = x.shape
+    if out is None:
+        out = torch.empty((s[0] // 2, s[1] // 2, s[2] // 2, s[3]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.synthsr_bn_maxpool(_lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), _lib.ptr(stats),
+                                      _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.stream()), 'bn_maxpool')
+    return out
+
+
+def bn_maxpool_bwd(dy, x, stats, gamma, beta, out=None, eps=BN_EPS):
+    lib = _L()
+    s = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.synthsr_bn_maxpool_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]),
+                                          _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.stream()),
+               'bn_maxpool_bwd')
+    return out
+
+
+def bn_bwd(dy, x, stats, gamma, sums, out=None, eps=BN_EPS):
+    """sums [2C] (zeroed by caller) receives [sum dy (=dbeta), sum dy*xhat (=dgamma)]; returns dx"""
+    lib = _L()
+    C = int(x.shape[-1])
+    nvox = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.synthsr_bn_bwd_reduce(_lib.ptr(dy), _lib.ptr(x), nvox, C, _lib.ptr(stats), eps, _lib.ptr(sums),
+                                         _lib.stream()), 'bn_bwd_reduce')
+    _lib.check(lib.synthsr_bn_bwd_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), nvox, C, _lib.ptr(stats),
+                                        _lib.ptr(gamma), eps, _lib.ptr(sums), _lib.stream()), 'bn_bwd_apply')
+    return out
+
+
+def upsample_concat(skip, lo, stats, gamma, beta, out=None, eps=BN_EPS):
+    lib = _L()
+    s = skip.shape
+    Cs, Cl = int(s[3]), int(lo.shape[3])
+    if out is None:
+        out = torch.empty((s[0], s[1], s[2], Cs + Cl), dtype=torch.float32, device=skip.device)
+    _lib.check(lib.synthsr_upsample_concat(_lib.ptr(skip), _lib.ptr(lo), _lib.ptr(out), _lib.i3(s[:3]), Cs, Cl,
+                                           _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.stream()),
+               'upsample_concat')
+    return out
+
+
+def upsample_concat_bwd(dcat, Cs, Cl, dskip=None, dlo=None):
+    lib = _L()
+    s = dcat.shape
+    if dskip is None:
+        dskip = torch.empty((s[0], s[1], s[2], Cs), dtype=torch.float32, device=dcat.device)
+    if dlo is None:
+        dlo = torch.empty((s[0] // 2, s[1] // 2, s[2] // 2, Cl), dtype=torch.float32, device=dcat.device)
+    _lib.check(lib.synthsr_upsample_concat_bwd(_lib.ptr(dcat), _lib.ptr(dskip), _lib.ptr(dlo), _lib.i3(s[:3]), Cs, Cl,
+                                               _lib.stream()), 'upsample_concat_bwd')
+    return dskip, dlo
+
+
+def head_l1_fwd(x, stats, gamma, beta, w, b, target, loss, pred=None, dpred=None, residual=None, res_stride=1,
+                res_off=0, eps=BN_EPS):
+    lib = _L()
+    C = int(x.shape[-1])
+    nvox = x.numel() // C
+    _lib.check(lib.synthsr_head_l1_fwd(_lib.ptr(x), nvox, C, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps,
+                                       _lib.ptr(w), _lib.ptr(b), _lib.ptr(residual), int(res_stride), int(res_off),
+                                       _lib.ptr(target), _lib.ptr(pred), _lib.ptr(dpred), _lib.ptr(loss),
+                                       _lib.stream()), 'head_l1_fwd')
+    return loss
+
+
+def head_bwd(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS):
+    lib = _L()
+    C = int(x.shape[-1])
+    nvox = x.numel() // C
+    _lib.check(lib.synthsr_head_bwd(_lib.ptr(dpred), _lib.ptr(x), nvox, C, _lib.ptr(stats), _lib.ptr(gamma),
+                                    _lib.ptr(beta), eps, _lib.ptr(w), _lib.ptr(dbn), _lib.ptr(dw), _lib.ptr(db),
+                                    _lib.stream()), 'head_bwd')
+    return dbn
+
+
+def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    lib = _L()
+    _lib.check(lib.synthsr_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), float(lr_t),
+                                     float(beta1), float(beta2), float(eps), float(grad_scale), _lib.stream()),
+               'adam_step')

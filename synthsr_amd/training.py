@@ -1,0 +1,292 @@
+"""`training()` — same positional order, keyword names and defaults as SynthSR/training.py:38-89; the
+Keras graph {generator -> U-Net -> loss} + `fit_generator` becomes an explicit loop over HIP kernels:
+
+    per step:  host input sampler (model_inputs.py)  ->  generator kernels (labels_to_image_model.py)
+               ->  U-Net forward + L1 (unet.py)  ->  backward  ->  [RCCL all-reduce of the flat gradient
+               buffer, bucketed and overlapped with the rest of the backward]  ->  Keras-semantics Adam.
+
+Data parallel: one process per GPU (`torchrun`), batch 1 per GPU, per-rank random streams, gradient
+average over ranks; BN statistics stay per replica (reference semantics at batch 1).
+Checkpoints: `{epoch:03d}.npz` with Keras layer names as keys (rank 0 only).
+"""
+import os
+import time
+import numpy as np
+
+from . import host_math as hm
+from . import volumes
+from .brain_generator import BrainGenerator
+from .unet import unet as build_unet
+
+
+class GradBucketReducer:
+    """All-reduces a flat gradient buffer in buckets, tail first (the backward produces the gradients of
+    the last layers first), overlapping communication with the remaining backward.  Works with any
+    torch.distributed backend (RCCL on GPU, gloo in the CPU tests)."""
+
+    def __init__(self, flat_grads, bucket_elems=2 * 1024 * 1024, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.g = flat_grads
+        self.bucket = int(bucket_elems)
+        self.group = group
+        self.hi = flat_grads.numel()
+        self.works = []
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def start(self):
+        self.hi = self.g.numel()
+        self.works = []
+
+    def ready(self, offset_lo, force=False):
+        """every gradient at flat offset >= offset_lo is final"""
+        if self.world == 1:
+            return
+        if offset_lo >= self.hi:
+            return
+        if force or (self.hi - offset_lo) >= self.bucket:
+            self.works.append(self.dist.all_reduce(self.g[offset_lo:self.hi], op=self.dist.ReduceOp.SUM,
+                                                   group=self.group, async_op=True))
+            self.hi = offset_lo
+
+    def finish(self):
+        self.ready(0, force=True)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        return 1.0 / self.world  # gradient scale for the optimizer
+
+
+class Trainer:
+    """generator + U-Net + L1 + Adam for one rank"""
+
+    def __init__(self, brain_generator, net, lr=1e-4, lr_decay=0.0, work_with_residual_channel=None,
+                 distributed=False, bucket_elems=2 * 1024 * 1024):
+        self.bg = brain_generator
+        self.gen = brain_generator.labels_to_image_model
+        self.net = net
+        self.lr, self.lr_decay = lr, lr_decay
+        self.residual = work_with_residual_channel
+        self.reducer = GradBucketReducer(net.grads, bucket_elems) if distributed else None
+        self.resident_labels = None
+
+    def make_labels_resident(self, label_maps):
+        """upload a pool of int32 label maps once; steps then pick from the pool on the device"""
+        import torch
+        self.resident_labels = [torch.from_numpy(np.ascontiguousarray(m, dtype=np.int32)).to(self.gen.device)
+                                for m in label_maps]
+
+    def step(self, model_inputs=None, draws=None, label_index=None):
+        """one training step; returns the loss as a 1-element device tensor (no host sync)"""
+        gen, net = self.gen, self.net
+        if model_inputs is None:
+            model_inputs = next(self.bg.model_inputs_generator)
+        labels, means, stds = model_inputs[:3]
+        if label_index is not None and self.resident_labels is not None:
+            image, target, _ = gen.generate(self.resident_labels[label_index], np.asarray(means)[0],
+                                            np.asarray(stds)[0], draws, labels_on_device=True)
+        else:
+            image, target, _ = gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0], np.asarray(stds)[0],
+                                            draws)
+        residual, rs, ro = None, 1, 0
+        if self.residual is not None:
+            residual, rs, ro = image, image.shape[-1], int(self.residual[0])
+        loss, _ = net.loss_l1(image, target.reshape(-1), residual=residual, res_stride=rs, res_off=ro)
+        if self.reducer is not None:
+            self.reducer.start()
+            net.backward(on_grad_ready=self.reducer.ready)
+            scale = self.reducer.finish()
+        else:
+            net.backward()
+            scale = 1.0
+        net.adam_step(self.lr, self.lr_decay, grad_scale=scale)
+        net.update_moving_stats()
+        return loss
+
+
+def save_checkpoint(path, net):
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    sd['optimizer/iterations'] = np.array(net.iterations)
+    sd['optimizer/m'] = net.adam_m.cpu().numpy()
+    sd['optimizer/v'] = net.adam_v.cpu().numpy()
+    np.savez(path, **sd)
+
+
+def load_checkpoint(path, net, by_name=True, skip=()):
+    import torch
+    z = np.load(path)
+    sd = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith('optimizer/') and
+          not any(k.startswith(s) for s in skip)}
+    net.load_state_dict(sd, strict=False)
+    if 'optimizer/m' in z.files and z['optimizer/m'].shape[0] == net.n_params and not skip:
+        net.adam_m.copy_(torch.from_numpy(z['optimizer/m']))
+        net.adam_v.copy_(torch.from_numpy(z['optimizer/v']))
+        net.iterations = int(z['optimizer/iterations'])
+
+
+def training(labels_dir,
+             model_dir,
+             prior_means,
+             prior_stds,
+             path_generation_labels,
+             segmentation_label_list=None,
+             segmentation_label_equivalency=None,
+             segmentation_model_file=None,
+             fs_header_segnet=False,
+             relative_weight_segmentation=0.25,
+             prior_distributions='normal',
+             images_dir=None,
+             path_generation_classes=None,
+             FS_sort=True,
+             batchsize=1,
+             input_channels=True,
+             output_channel=0,
+             target_res=None,
+             output_shape=None,
+             flipping=True,
+             padding_margin=None,
+             scaling_bounds=0.15,
+             rotation_bounds=15,
+             shearing_bounds=0.02,
+             translation_bounds=5,
+             nonlin_std=4.,
+             nonlin_shape_factor=0.03125,
+             simulate_registration_error=True,
+             data_res=None,
+             thickness=None,
+             randomise_res=None,
+             downsample=True,
+             blur_range=1.15,
+             build_reliability_maps=True,
+             bias_field_std=.3,
+             bias_shape_factor=0.03125,
+             n_levels=5,
+             nb_conv_per_level=2,
+             conv_size=3,
+             unet_feat_count=24,
+             feat_multiplier=2,
+             dropout=0,
+             activation='elu',
+             lr=1e-4,
+             lr_decay=0,
+             epochs=100,
+             steps_per_epoch=1000,
+             regression_metric='l1',
+             work_with_residual_channel=None,
+             loss_cropping=None,
+             checkpoint=None,
+             model_file_has_different_lhood_layer=False,
+             seed=0,
+             verbose=True):
+    """Parameters as documented in SynthSR/training.py:90-240 (+ `seed`, `verbose`)."""
+    import torch
+    n_channels = len(hm.reformat_to_list(input_channels))
+    if output_channel is not None:
+        output_channel = list(hm.reformat_to_list(output_channel))
+    # checks, training.py:252-271
+    if (images_dir is None) & (output_channel is None):
+        raise Exception('please provide a value for output_channel or image_dir')
+    elif (images_dir is not None) & (output_channel is not None):
+        raise Exception('please provide a value either for output_channel or image_dir, but not both at the same time')
+    if output_channel is not None:
+        if any(x >= n_channels for x in output_channel):
+            raise Exception('indices in output_channel cannot be greater than the total number of channels')
+    if work_with_residual_channel is not None:
+        work_with_residual_channel = hm.reformat_to_list(work_with_residual_channel)
+        if output_channel is not None:
+            if len(work_with_residual_channel) != len(output_channel):
+                raise Exception('The number or residual channels and output channels must be the same')
+        if any(x >= n_channels for x in work_with_residual_channel):
+            raise Exception('indices in work_with_residual_channel cannot be greater than the total number of channels')
+        if build_reliability_maps:
+            # the reference repeats the python list here (`2 * list`, F11) instead of doubling the indices
+            raise NotImplementedError('work_with_residual_channel together with build_reliability_maps=True is '
+                                      'ill-defined in the reference (SURVEY F11); set build_reliability_maps=False')
+    if segmentation_model_file is not None:
+        raise NotImplementedError('segmentation-regularised loss is not built yet (SURVEY §8f-3)')
+    if regression_metric != 'l1':
+        raise NotImplementedError("only regression_metric='l1' is built yet")
+    if loss_cropping not in (None, 0):
+        raise NotImplementedError('loss_cropping is not built yet')
+    if dropout != 0:
+        raise NotImplementedError('dropout is not supported')
+    if batchsize != 1:
+        raise NotImplementedError('batchsize 1 per GPU (use more GPUs for a larger effective batch)')
+
+    dist_on = 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1
+    rank, world = 0, 1
+    if dist_on:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            dist.init_process_group('nccl')
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+    generation_labels, n_neutral_labels = volumes.get_list_labels(label_list=path_generation_labels,
+                                                                  labels_dir=labels_dir, FS_sort=FS_sort)
+    if rank == 0:
+        os.makedirs(model_dir, exist_ok=True)
+    if loss_cropping == 0:
+        padding_margin = None
+    elif padding_margin is None:
+        padding_margin = hm.get_padding_margin(output_shape, loss_cropping)
+
+    rng = np.random.Generator(np.random.Philox(key=(int(seed) << 20) + rank))
+    brain_generator = BrainGenerator(labels_dir=labels_dir, images_dir=images_dir, generation_labels=generation_labels,
+                                     n_neutral_labels=n_neutral_labels, padding_margin=padding_margin,
+                                     batchsize=batchsize, input_channels=input_channels,
+                                     output_channel=output_channel, target_res=target_res, output_shape=output_shape,
+                                     output_div_by_n=2 ** n_levels, generation_classes=path_generation_classes,
+                                     prior_means=prior_means, prior_stds=prior_stds,
+                                     prior_distributions=prior_distributions, flipping=flipping,
+                                     scaling_bounds=scaling_bounds, rotation_bounds=rotation_bounds,
+                                     shearing_bounds=shearing_bounds, translation_bounds=translation_bounds,
+                                     nonlin_std=nonlin_std, nonlin_shape_factor=nonlin_shape_factor,
+                                     simulate_registration_error=simulate_registration_error,
+                                     randomise_res=randomise_res, data_res=data_res, thickness=thickness,
+                                     downsample=downsample, blur_range=blur_range,
+                                     build_reliability_maps=build_reliability_maps, bias_field_std=bias_field_std,
+                                     bias_shape_factor=bias_shape_factor, rng=rng)
+    brain_generator.labels_to_image_model.seed(seed, rank)
+    unet_input_shape = brain_generator.model_output_shape
+    net = build_unet(nb_features=unet_feat_count, input_shape=unet_input_shape, nb_levels=n_levels,
+                     conv_size=conv_size, nb_labels=len(output_channel), feat_mult=feat_multiplier,
+                     nb_conv_per_level=nb_conv_per_level, conv_dropout=dropout, final_pred_activation='linear',
+                     batch_norm=-1, activation=activation, input_model=brain_generator.labels_to_image_model,
+                     seed=seed)
+    init_epoch = 0
+    if checkpoint is not None:
+        if verbose and rank == 0:
+            print('loading', checkpoint)
+        skip = ('%s_likelihood' % net.prefix,) if model_file_has_different_lhood_layer else ()
+        load_checkpoint(checkpoint, net, skip=skip)
+        try:
+            init_epoch = int(os.path.basename(checkpoint)[:3])
+        except ValueError:
+            init_epoch = 0
+    if dist_on:
+        import torch.distributed as dist
+        dist.broadcast(net.params, 0)  # identical initial weights on every rank
+        net.repack()
+    trainer = Trainer(brain_generator, net, lr, lr_decay, work_with_residual_channel, distributed=dist_on)
+
+    log_path = os.path.join(model_dir, 'logs', 'loss.csv')
+    if rank == 0:
+        os.makedirs(os.path.dirname(log_path), exist_ok=True)
+    for epoch in range(init_epoch, epochs):
+        t0 = time.time()
+        acc = torch.zeros(1, device=net.device)
+        for _ in range(steps_per_epoch):
+            acc += trainer.step()
+        mean_loss = float(acc.item()) / steps_per_epoch
+        if not np.isfinite(mean_loss):  # tf.debugging.check_numerics in IdentityLoss (metrics_model.py:228)
+            raise FloatingPointError('Loss not finite')
+        if rank == 0:
+            dt = time.time() - t0
+            if verbose:
+                print('Epoch %d/%d - %.1fs - loss: %.6f - %.2f volumes/s/GPU' % (epoch + 1, epochs, dt, mean_loss,
+                                                                                  steps_per_epoch / dt))
+            with open(log_path, 'a') as f:
+                f.write('%d,%.8f,%.3f\n' % (epoch + 1, mean_loss, dt))
+            save_checkpoint(os.path.join(model_dir, '%03d.npz' % (epoch + 1)), net)
+    return net

@@ -1,0 +1,364 @@
+"""3-D U-Net of ext/neuron/models.py:26-145 (`unet` = `conv_enc` :256-360 + `conv_dec` :363-498) as SynthSR
+builds it (SynthSR/training.py:330-341): per level Conv3D(3^3,'same')+ELU x nb_conv_per_level ->
+BatchNormalization(axis=-1) -> MaxPooling3D(2); decoder UpSampling3D(2) -> concatenate([skip, up]) with
+skip = PRE-BN output of conv_downarm_{l}_{last} -> convs -> BN; head Conv3D(nb_labels, 1x1x1), linear.
+
+MI355X-native: explicit forward/backward over hand-written HIP kernels (ops.py), no autograd.
+All trainable parameters live in ONE flat float32 buffer (same for gradients and the two Adam
+moments): one Adam launch, one RCCL all-reduce over a contiguous buffer.  Parameter names are the Keras
+layer names (`unet_conv_downarm_0_0/kernel` ...), so a Keras .h5 maps 1:1 later.
+
+Batch size 1 per replica (the configuration of every BASELINE config); BN uses batch statistics in
+training and moving statistics in inference, moving averages updated with Keras 2.3.1 semantics.
+"""
+import math
+import numpy as np
+import torch
+
+from . import ops
+
+
+class UNet3D:
+    def __init__(self, nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None,
+                 feat_mult=1, nb_conv_per_level=1, batch_norm=None, activation='elu', device=None, seed=0,
+                 final_pred_activation='linear'):
+        if conv_size != 3:
+            raise NotImplementedError('only conv_size=3 is supported')
+        if activation != 'elu':
+            raise NotImplementedError("only activation='elu' is supported")
+        if batch_norm not in (-1, len(input_shape) - 1 + 1, 4):
+            raise NotImplementedError('batch_norm=-1 (channels-last BatchNormalization after each level) is required')
+        if nb_labels != 1:
+            raise NotImplementedError('only one output channel (nb_labels=1) is supported yet')
+        if final_pred_activation != 'linear':
+            raise NotImplementedError("only final_pred_activation='linear' is supported")
+        if len(input_shape) != 4:
+            raise NotImplementedError('3-D volumes only')
+        self.prefix = name if prefix is None else prefix
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.input_shape = [int(s) for s in input_shape]
+        self.nb_levels = L = int(nb_levels)
+        self.nconv = int(nb_conv_per_level)
+        self.feats = [int(np.round(nb_features * feat_mult ** l)) for l in range(L)]
+        for s in self.input_shape[:3]:
+            if s % (2 ** (L - 1)) != 0:
+                raise ValueError('spatial shape must be divisible by 2**(nb_levels-1)')
+        self.shapes = [[s // (2 ** l) for s in self.input_shape[:3]] for l in range(L)]
+        cin = self.input_shape[3]
+
+        # ---- parameter table (forward order); BN stored as [beta | gamma] so that the backward reduction
+        # [sum dy | sum dy*xhat] lands directly on [dbeta | dgamma]
+        self.specs = []  # (name, shape, kind)
+        self.enc, self.dec = [], []
+        c = cin
+        for l in range(L):
+            convs = []
+            for k in range(self.nconv):
+                nm = '%s_conv_downarm_%d_%d' % (self.prefix, l, k)
+                convs.append(self._add_conv(nm, c, self.feats[l]))
+                c = self.feats[l]
+            bn = self._add_bn('%s_bn_down_%d' % (self.prefix, l), c)
+            self.enc.append(dict(convs=convs, bn=bn))
+        for k in range(L - 1):
+            l = L - 2 - k
+            c_in = self.feats[l] + c
+            convs = []
+            for j in range(self.nconv):
+                nm = '%s_conv_uparm_%d_%d' % (self.prefix, L + k, j)
+                convs.append(self._add_conv(nm, c_in, self.feats[l]))
+                c_in = self.feats[l]
+            c = self.feats[l]
+            bn = self._add_bn('%s_bn_up_%d' % (self.prefix, k), c)
+            self.dec.append(dict(convs=convs, bn=bn, level=l))
+        self.head = dict(name='%s_likelihood' % self.prefix, cin=c,
+                         w=self._add('%s_likelihood/kernel' % self.prefix, (c, 1), 'head_w'),
+                         b=self._add('%s_likelihood/bias' % self.prefix, (1,), 'bias'))
+        self.n_params = sum(int(np.prod(s[1])) for s in self.specs)
+        dev = self.device
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.iterations = 0
+        self.offsets = {}
+        off = 0
+        for nm, shp, kind in self.specs:
+            self.offsets[nm] = (off, tuple(shp), kind)
+            off += int(np.prod(shp))
+        # BN statistics (batch + moving), flat [per layer: mean(C) | var(C)]
+        self.bn_layers = [e['bn'] for e in self.enc] + [d['bn'] for d in self.dec]
+        nst = sum(2 * b['C'] for b in self.bn_layers)
+        self.bn_batch = torch.zeros(nst, dtype=torch.float32, device=dev)
+        self.bn_moving = torch.zeros(nst, dtype=torch.float32, device=dev)
+        self.bn_corr = torch.ones(nst, dtype=torch.float32, device=dev)
+        self.bn_ws = torch.zeros(2 * max(b['C'] for b in self.bn_layers), dtype=torch.float64, device=dev)
+        o = 0
+        lvl_of = [l for l in range(L)] + [d['level'] for d in self.dec]
+        for b, l in zip(self.bn_layers, lvl_of):
+            b['soff'] = o
+            C = b['C']
+            self.bn_moving[o + C:o + 2 * C] = 1.0  # moving_variance initialised to ones
+            n = float(np.prod(self.shapes[l]))
+            self.bn_corr[o + C:o + 2 * C] = n / (n - (1.0 + ops.BN_EPS))  # Keras 2.3.1 sample-variance correction
+            o += 2 * C
+        self.bn_momentum = 0.99
+        self.training = True
+        self._bufs = {}
+        self.init_weights(seed)
+
+    # ------------------------------------------------------------------ parameter bookkeeping
+    def _add(self, name, shape, kind):
+        self.specs.append((name, tuple(shape), kind))
+        return name
+
+    def _add_conv(self, name, cin, cout):
+        return dict(name=name, cin=cin, cout=cout, w=self._add(name + '/kernel', (3, 3, 3, cin, cout), 'kernel'),
+                    b=self._add(name + '/bias', (cout,), 'bias'), wp=None, wpd=None)
+
+    def _add_bn(self, name, C):
+        return dict(name=name, C=C, beta=self._add(name + '/beta', (C,), 'beta'),
+                    gamma=self._add(name + '/gamma', (C,), 'gamma'))
+
+    def view(self, name, buf=None):
+        off, shp, _ = self.offsets[name]
+        buf = self.params if buf is None else buf
+        return buf[off:off + int(np.prod(shp))].view(*shp)
+
+    def named_parameters(self):
+        return [(nm, self.view(nm)) for nm, _, _ in self.specs]
+
+    def init_weights(self, seed=0):
+        """Keras defaults: glorot_uniform kernels, zero biases, gamma=1, beta=0"""
+        g = torch.Generator(device='cpu')
+        g.manual_seed(int(seed))
+        for nm, shp, kind in self.specs:
+            v = self.view(nm)
+            if kind == 'kernel':
+                fan_in, fan_out = 27 * shp[3], 27 * shp[4]
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                v.copy_((torch.rand(shp, generator=g) * 2 - 1) * lim)
+            elif kind == 'head_w':
+                lim = math.sqrt(6.0 / (shp[0] + shp[1]))
+                v.copy_((torch.rand(shp, generator=g) * 2 - 1) * lim)
+            elif kind == 'gamma':
+                v.fill_(1.0)
+            else:
+                v.zero_()
+        self.repack()
+
+    def all_convs(self):
+        for e in self.enc:
+            for c in e['convs']:
+                yield c
+        for d in self.dec:
+            for c in d['convs']:
+                yield c
+
+    def repack(self):
+        """refresh the MFMA-fragment-ordered copies of the conv kernels (after init / optimizer step / load)"""
+        first = True
+        for c in self.all_convs():
+            w = self.view(c['w'])
+            c['wp'] = ops.pack_conv_weights(w, 0, c['wp'])
+            if not first:  # the first layer's input has no gradient
+                c['wpd'] = ops.pack_conv_weights(w, 1, c['wpd'])
+            first = False
+
+    def state_dict(self):
+        sd = {nm: self.view(nm).detach().cpu().clone() for nm, _, _ in self.specs}
+        for b in self.bn_layers:
+            o, C = b['soff'], b['C']
+            sd[b['name'] + '/moving_mean'] = self.bn_moving[o:o + C].cpu().clone()
+            sd[b['name'] + '/moving_variance'] = self.bn_moving[o + C:o + 2 * C].cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        for nm, _, _ in self.specs:
+            if nm in sd:
+                self.view(nm).copy_(torch.as_tensor(sd[nm]).to(self.device).reshape(self.view(nm).shape))
+            elif strict:
+                raise KeyError(nm)
+        for b in self.bn_layers:
+            o, C = b['soff'], b['C']
+            if b['name'] + '/moving_mean' in sd:
+                self.bn_moving[o:o + C].copy_(torch.as_tensor(sd[b['name'] + '/moving_mean']).to(self.device))
+                self.bn_moving[o + C:o + 2 * C].copy_(torch.as_tensor(sd[b['name'] + '/moving_variance']).to(self.device))
+        self.repack()
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, key, shape):
+        t = self._bufs.get(key)
+        n = int(np.prod(shape))
+        if t is None or t.numel() < n:
+            t = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._bufs[key] = t
+        return t[:n].view(*shape)
+
+    def _stats(self, bn):
+        o, C = bn['soff'], bn['C']
+        src = self.bn_batch if self.training else self.bn_moving
+        return src[o:o + 2 * C]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        """x [d0,d1,d2,Cin] -> saves activations; returns the last decoder activation (pre-BN) and its BN"""
+        L = self.nb_levels
+        self.saved = dict(x=[], enc=[], cat=[], dec=[])
+        cur = x
+        for l in range(L):
+            e = self.enc[l]
+            self.saved['x'].append(cur)
+            acts = []
+            for k, c in enumerate(e['convs']):
+                cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1,
+                                 out=self.buf('enc%d_%d' % (l, k), self.shapes[l] + [c['cout']]))
+                acts.append(cur)
+            self.saved['enc'].append(acts)
+            if self.training:
+                ops.bn_stats(cur, self._stats(e['bn']), self.bn_ws)
+            if l < L - 1:
+                cur = ops.bn_maxpool(cur, self._stats(e['bn']), self.view(e['bn']['gamma']), self.view(e['bn']['beta']),
+                                     out=self.buf('pool%d' % l, self.shapes[l + 1] + [e['bn']['C']]))
+        low, low_bn = cur, self.enc[L - 1]['bn']
+        for k, d in enumerate(self.dec):
+            l = d['level']
+            skip = self.saved['enc'][l][-1]
+            cat = ops.upsample_concat(skip, low, self._stats(low_bn), self.view(low_bn['gamma']),
+                                      self.view(low_bn['beta']),
+                                      out=self.buf('cat%d' % k, self.shapes[l] + [skip.shape[3] + low.shape[3]]))
+            self.saved['cat'].append(cat)
+            cur = cat
+            acts = []
+            for j, c in enumerate(d['convs']):
+                cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1,
+                                 out=self.buf('dec%d_%d' % (k, j), self.shapes[l] + [c['cout']]))
+                acts.append(cur)
+            self.saved['dec'].append(acts)
+            if self.training:
+                ops.bn_stats(cur, self._stats(d['bn']), self.bn_ws)
+            low, low_bn = cur, d['bn']
+        self.saved['last'] = (low, low_bn)
+        return low, low_bn
+
+    def loss_l1(self, x, target, residual=None, res_stride=1, res_off=0, want_pred=False):
+        """forward + unet_likelihood + L1 (SynthSR/metrics_model.py:102-104). Returns (loss tensor[1], pred|None)"""
+        low, bn = self.forward(x)
+        nvox = low.numel() // low.shape[3]
+        self.loss_buf = self.buf('loss', [1])
+        self.loss_buf.zero_()
+        self.dpred = self.buf('dpred', [nvox])
+        pred = self.buf('pred', [nvox]) if want_pred else None
+        ops.head_l1_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']), self.view(self.head['w']),
+                        self.view(self.head['b']), target, self.loss_buf, pred=pred, dpred=self.dpred,
+                        residual=residual, res_stride=res_stride, res_off=res_off)
+        return self.loss_buf, pred
+
+    def predict(self, x):
+        """inference forward (moving statistics): x [d0,d1,d2,Cin] -> [d0,d1,d2,1]"""
+        was = self.training
+        self.training = False
+        try:
+            low, bn = self.forward(x)
+            nvox = low.numel() // low.shape[3]
+            zero_t = self.buf('zero_t', [nvox])
+            zero_t.zero_()
+            loss = self.buf('loss', [1])
+            loss.zero_()
+            pred = self.buf('pred', [nvox])
+            ops.head_l1_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
+                            self.view(self.head['w']), self.view(self.head['b']), zero_t, loss, pred=pred)
+        finally:
+            self.training = was
+        return pred.view(*self.input_shape[:3], 1)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, on_grad_ready=None):
+        """gradients of the L1 loss w.r.t. every parameter into self.grads (zeroed here).
+        on_grad_ready(offset_lo): optional hook called when every gradient at flat offset >= offset_lo is final
+        (used to overlap the RCCL all-reduce with the rest of the backward)."""
+        L = self.nb_levels
+        G = self.grads
+        G.zero_()
+        low, bn = self.saved['last']
+        C = low.shape[3]
+        g = self.buf('gA', list(low.shape))
+        ops.head_bwd(self.dpred, low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
+                     self.view(self.head['w']), g, self.view(self.head['w'], G), self.view(self.head['b'], G))
+        dskips = [None] * L
+        for k in range(len(self.dec) - 1, -1, -1):
+            d = self.dec[k]
+            l = d['level']
+            acts = self.saved['dec'][k]
+            g = self._bn_backward(g, acts[-1], d['bn'])
+            g = self._convs_backward(g, None, d['convs'], acts, self.saved['cat'][k], need_dx=True, tag='d%d' % k)
+            # g = d(concat)
+            Cs = self.feats[l]
+            Cl = g.shape[3] - Cs
+            dskips[l], g = ops.upsample_concat_bwd(g, Cs, Cl, dskip=self.buf('dskip%d' % l, self.shapes[l] + [Cs]),
+                                                   dlo=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
+            if on_grad_ready is not None:
+                on_grad_ready(self.offsets[d['convs'][0]['w']][0])
+        for l in range(L - 1, -1, -1):
+            e = self.enc[l]
+            acts = self.saved['enc'][l]
+            if l < L - 1:
+                g = ops.bn_maxpool_bwd(g, acts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
+                                       self.view(e['bn']['beta']), out=self.buf('gpool%d' % l, list(acts[-1].shape)))
+            g = self._bn_backward(g, acts[-1], e['bn'])
+            g = self._convs_backward(g, dskips[l], e['convs'], acts, self.saved['x'][l], need_dx=(l > 0), tag='e%d' % l)
+            if on_grad_ready is not None:
+                on_grad_ready(self.offsets[e['convs'][0]['w']][0])
+        return G
+
+    def _bn_backward(self, g, x, bn):
+        off = self.offsets[bn['beta']][0]
+        sums = self.grads[off:off + 2 * bn['C']]  # [dbeta | dgamma]
+        return ops.bn_bwd(g, x, self._stats(bn), self.view(bn['gamma']), sums,
+                          out=self.buf('gbn', list(x.shape)))
+
+    def _convs_backward(self, g, g2, convs, acts, x_in, need_dx, tag):
+        """g (+g2) = gradient w.r.t. the output of the last conv's ELU. Returns gradient w.r.t. x_in (or None)."""
+        for j in range(len(convs) - 1, -1, -1):
+            c = convs[j]
+            y = acts[j]
+            dz = ops.elu_bwd(g, y, dy2=g2, dbias=self.view(c['b'], self.grads), out=self.buf('dz', list(y.shape)))
+            g2 = None
+            xin = acts[j - 1] if j > 0 else x_in
+            ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads))
+            if j > 0 or need_dx:
+                g = ops.conv3d(dz, c['wpd'], None, c['cin'], 0, out=self.buf('dx_%s_%d' % (tag, j & 1),
+                                                                             list(xin.shape)))
+            else:
+                g = None
+        return g
+
+    # ------------------------------------------------------------------ optimizer (keras.optimizers.Adam, 2.3.1)
+    def adam_step(self, lr=1e-4, decay=0.0, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        if decay > 0:
+            lr = lr * (1.0 / (1.0 + decay * self.iterations))
+        t = self.iterations + 1
+        lr_t = lr * (math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+        ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, lr_t, beta1, beta2, eps, grad_scale)
+        self.iterations = t
+        self.repack()
+
+    def update_moving_stats(self):
+        """K.moving_average_update with momentum .99; variance gets Keras' n/(n-(1+eps)) correction"""
+        m = self.bn_momentum
+        self.bn_moving.mul_(m).add_(self.bn_batch * self.bn_corr, alpha=1.0 - m)
+
+
+def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None, feat_mult=1,
+         pool_size=2, use_logp=True, padding='same', dilation_rate_mult=1, activation='elu', skip_n_concatenations=0,
+         use_residuals=False, final_pred_activation='softmax', nb_conv_per_level=1, add_prior_layer=False,
+         layer_nb_feats=None, conv_dropout=0, batch_norm=None, input_model=None, device=None, seed=0):
+    """ext/neuron/models.py:26-47 signature.  Unsupported knobs of the over-parametrised reference raise."""
+    if pool_size != 2 or padding != 'same' or dilation_rate_mult != 1 or skip_n_concatenations != 0 or \
+            use_residuals or add_prior_layer or layer_nb_feats is not None or conv_dropout != 0:
+        raise NotImplementedError('only the configuration SynthSR.training uses is supported '
+                                  '(pool 2, same padding, no dilation/residuals/dropout/prior)')
+    net = UNet3D(nb_features, input_shape, nb_levels, conv_size, nb_labels, name=name, prefix=prefix,
+                 feat_mult=feat_mult, nb_conv_per_level=nb_conv_per_level, batch_norm=batch_norm,
+                 activation=activation, device=device, seed=seed, final_pred_activation=final_pred_activation)
+    net.input_model = input_model
+    return net

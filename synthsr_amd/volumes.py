@@ -1,0 +1,175 @@
+"""Volume IO / orientation helpers the hot path's callers need — counterparts of
+ext/lab2im/utils.py:76-160 (`load_volume`, `save_volume`), :163-206 (`get_volume_info`), :209-285
+(`get_list_labels`), :391-424 (`list_images_in_folder`) and ext/lab2im/edit_volumes.py:591-654
+(`get_ras_axes`, `align_volume_to_ref`).  NIfTI only (own reader, nifti.py; nibabel is not installed).
+"""
+import glob
+import os
+import numpy as np
+
+from . import host_math as hm
+from .nifti import read_nifti, write_nifti
+
+get_ras_axes = hm.get_ras_axes
+
+
+def get_dims(shape, max_channels=10):
+    """ext/lab2im/utils.py:558-574"""
+    if shape[-1] <= max_channels:
+        return len(shape) - 1, shape[-1]
+    return len(shape), 1
+
+
+def list_images_in_folder(path_dir, include_single_image=True, check_if_empty=True):
+    basename = os.path.basename(path_dir)
+    if include_single_image and (('.nii.gz' in basename) or ('.nii' in basename) or ('.mgz' in basename) or
+                                 ('.npz' in basename)):
+        assert os.path.isfile(path_dir), 'file %s does not exist' % path_dir
+        return [path_dir]
+    if not os.path.isdir(path_dir):
+        raise Exception('Folder does not exist: %s' % path_dir)
+    lst = sorted(glob.glob(os.path.join(path_dir, '*nii.gz')) + glob.glob(os.path.join(path_dir, '*nii')) +
+                 glob.glob(os.path.join(path_dir, '*.mgz')) + glob.glob(os.path.join(path_dir, '*.npz')))
+    if check_if_empty:
+        assert len(lst) > 0, 'no .nii, .nii.gz, .mgz or .npz image could be found in %s' % path_dir
+    return lst
+
+
+def align_volume_to_ref(volume, aff, aff_ref=None, return_aff=False, n_dims=None, return_copy=True):
+    """ext/lab2im/edit_volumes.py:609-654"""
+    new_volume = volume.copy() if return_copy else volume
+    aff_flo = np.array(aff, dtype=np.float64)
+    if aff_ref is None:
+        aff_ref = np.eye(4)
+    if n_dims is None:
+        n_dims, _ = get_dims(new_volume.shape)
+    ras_ref = get_ras_axes(aff_ref, n_dims=n_dims)
+    ras_flo = get_ras_axes(aff_flo, n_dims=n_dims)
+    aff_flo[:, ras_ref] = aff_flo[:, ras_flo]
+    for i in range(n_dims):
+        if ras_flo[i] != ras_ref[i]:
+            new_volume = np.swapaxes(new_volume, ras_flo[i], ras_ref[i])
+            swapped = int(np.where(ras_flo == ras_ref[i])[0][0])
+            ras_flo[swapped], ras_flo[i] = ras_flo[i], ras_flo[swapped]
+    dots = np.sum(aff_flo[:3, :3] * np.asarray(aff_ref)[:3, :3], axis=0)
+    for i in range(n_dims):
+        if dots[i] < 0:
+            new_volume = np.flip(new_volume, axis=i)
+            aff_flo[:, i] = -aff_flo[:, i]
+            aff_flo[:3, 3] = aff_flo[:3, 3] - aff_flo[:3, i] * (new_volume.shape[i] - 1)
+    if return_aff:
+        return new_volume, aff_flo
+    return new_volume
+
+
+def load_volume(path_volume, im_only=True, squeeze=True, dtype=None, aff_ref=None):
+    assert path_volume.endswith(('.nii', '.nii.gz', '.mgz', '.npz')), 'Unknown data file: %s' % path_volume
+    if path_volume.endswith('.mgz'):
+        raise NotImplementedError('.mgz volumes are not supported (NIfTI and npz only)')
+    if path_volume.endswith(('.nii', '.nii.gz')):
+        data, aff, header = read_nifti(path_volume)
+        volume = np.asarray(data, dtype=np.float64)  # nibabel get_fdata() semantics
+        if squeeze:
+            volume = np.squeeze(volume)
+    else:
+        volume = np.load(path_volume)['vol_data']
+        if squeeze:
+            volume = np.squeeze(volume)
+        aff, header = np.eye(4), dict(pixdim=(1.,) * 8)
+    if dtype is not None:
+        if 'int' in dtype:
+            volume = np.round(volume)
+        volume = volume.astype(dtype={'int': np.int64}.get(dtype, dtype))
+    if aff_ref is not None:
+        n_dims, _ = get_dims(list(volume.shape), max_channels=10)
+        volume, aff = align_volume_to_ref(volume, aff, aff_ref=aff_ref, return_aff=True, n_dims=n_dims)
+    if im_only:
+        return volume
+    return volume, aff, header
+
+
+def save_volume(volume, aff, header, path, res=None, dtype=None, n_dims=3):
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    if '.npz' in path:
+        np.savez_compressed(path, vol_data=volume)
+        return
+    if isinstance(aff, str) and aff == 'FS':
+        aff = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]])
+    elif aff is None:
+        aff = np.eye(4)
+    if dtype is not None and 'int' in dtype:
+        volume = np.round(volume)
+    write_nifti(path, volume, aff, dtype=dtype)
+
+
+def get_volume_info(path_volume, return_volume=False, aff_ref=None, max_channels=10):
+    im, aff, header = load_volume(path_volume, im_only=False)
+    im_shape = list(im.shape)
+    n_dims, n_channels = get_dims(im_shape, max_channels=max_channels)
+    im_shape = im_shape[:n_dims]
+    if '.nii' in path_volume:
+        data_res = np.array(header['pixdim'][1:n_dims + 1], dtype=np.float64)
+    else:
+        data_res = np.array([1.0] * n_dims)
+    if aff_ref is not None:
+        ras_axes = get_ras_axes(aff, n_dims=n_dims)
+        ras_axes_ref = get_ras_axes(aff_ref, n_dims=n_dims)
+        im = align_volume_to_ref(im, aff, aff_ref=aff_ref, n_dims=n_dims)
+        im_shape = np.array(im_shape)
+        data_res = np.array(data_res)
+        im_shape[ras_axes_ref] = im_shape[ras_axes]
+        data_res[ras_axes_ref] = data_res[ras_axes]
+        im_shape = im_shape.tolist()
+    if return_volume:
+        return im, im_shape, aff, n_dims, n_channels, header, data_res
+    return im_shape, aff, n_dims, n_channels, header, data_res
+
+
+_NEUTRAL_FS = [0, 14, 15, 16, 21, 22, 23, 24, 72, 77, 80, 85, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 165, 200,
+               201, 202, 203, 204, 205, 206, 207, 208, 209, 210, 251, 252, 253, 254, 255, 258, 259, 260, 331, 332, 333,
+               334, 335, 336, 337, 338, 339, 340, 502, 506, 507, 508, 509, 511, 512, 514, 515, 516, 517, 530, 531, 532,
+               533, 534, 535, 536, 537]
+
+
+def get_list_labels(label_list=None, labels_dir=None, save_label_list=None, FS_sort=False):
+    """ext/lab2im/utils.py:209-285"""
+    if label_list is not None:
+        label_list = hm.load_array_if_path(label_list)
+        label_list = np.array(hm.reformat_to_list(label_list, dtype='int'))
+    elif labels_dir is not None:
+        label_list = np.empty(0)
+        for path in list_images_in_folder(labels_dir):
+            y = load_volume(path, dtype='int32')
+            label_list = np.unique(np.concatenate((label_list, np.unique(y)))).astype('int')
+    else:
+        raise Exception('either label_list, path_label_list or labels_dir should be provided')
+    n_neutral_labels = 0
+    if FS_sort:
+        neutral, left, right = [], [], []
+        for la in label_list:
+            if la in _NEUTRAL_FS:
+                if la not in neutral:
+                    neutral.append(la)
+            elif (0 < la < 14) | (16 < la < 21) | (24 < la < 40) | (135 < la < 139) | (1000 <= la <= 1035) | \
+                    (la == 865) | (20100 < la < 20110):
+                if la not in left:
+                    left.append(la)
+            elif (39 < la < 72) | (162 < la < 165) | (2000 <= la <= 2035) | (20000 < la < 20010) | (la == 139) | \
+                    (la == 866):
+                if la not in right:
+                    right.append(la)
+            else:
+                raise Exception('label {} not in our current FS classification, '
+                                'please update get_list_labels in utils.py'.format(la))
+        label_list = np.concatenate([sorted(neutral), sorted(left), sorted(right)])
+        if ((len(left) > 0) & (len(right) > 0)) | ((len(left) == 0) & (len(right) == 0)):
+            n_neutral_labels = len(neutral)
+        else:
+            n_neutral_labels = len(label_list)
+    if save_label_list is not None:
+        np.save(save_label_list, np.int32(label_list))
+    if FS_sort:
+        return np.int32(label_list), n_neutral_labels
+    return np.int32(label_list), None

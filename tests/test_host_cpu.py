@@ -1,0 +1,181 @@
+"""CPU tests: host logic (host_math, volumes, nifti, model_inputs), C-ABI exports, 2-rank gloo gradient reducer."""
+import os
+import re
+import sys
+import ctypes
+import subprocess
+import numpy as np
+import pytest
+
+from conftest import load_golden, tape_from_golden, REPO
+from synthsr_amd import host_math as hm
+from oracle import generator_ref as R
+
+
+def test_host_math_matches_goldens_and_oracle():
+    g = load_golden('host_math')
+    tape = tape_from_golden(g, 'affine_tape')
+    for b in range(2):
+        u = dict(rot=tape[0][1][b], shear=tape[1][1][b], scale=tape[2][1][b], trans=tape[3][1][b])
+        T = hm.sample_affine(u, rotation_bounds=15, scaling_bounds=.15, shearing_bounds=.02, translation_bounds=5)
+        np.testing.assert_array_equal(T, g['affine_T'][b])
+    for name, sig in [('k050', [.5] * 3), ('k042', [.42] * 3), ('khyp', [.63, .63, 2.1])]:
+        np.testing.assert_array_equal(hm.gaussian_kernel(sig), R.gaussian_kernel(sig))
+        np.testing.assert_allclose(hm.gaussian_kernel(sig), g['gk_' + name], atol=1e-7)
+    np.testing.assert_array_equal(hm.gaussian_kernel([.42] * 3, g['gk_rand_tape_00'], 1.15),
+                                  R.gaussian_kernel([.42] * 3, g['gk_rand_tape_00'], 1.15))
+    np.testing.assert_allclose(hm.blurring_sigma_for_downsampling([1.] * 3, [1.5, 1.5, 5.], .42, [1.5, 1.5, 5.]),
+                               g['sigma_lr'])
+    np.testing.assert_array_equal(hm.flip_swap_lut(g['swap_lut_labels'], 3), g['swap_lut'])
+    assert hm.flip_swap_lut(np.arange(4), 4) is None
+    np.testing.assert_array_equal(hm.reliability_profile(192, 38), R.reliability_map_1d(192, 38))
+
+
+def test_get_shapes_matches_golden():
+    g = load_golden('host_math')
+    cases = [([160, 160, 160], None, [1.] * 3, [1.] * 3, None, 32), ([148, 187, 155], None, [1.] * 3, [1.] * 3, None, 32),
+             ([148, 187, 155], 128, [1.] * 3, [1.] * 3, None, 32), ([148, 187, 155], [96, 128, 100], [1.] * 3, [1.] * 3, 8, 32),
+             ([148, 187, 155], 160, [1.] * 3, [.7] * 3, None, 32), ([192, 192, 192], 192, [1.] * 3, [1.] * 3, None, None),
+             ([40, 48, 36], 32, [1.] * 3, [1.] * 3, None, 32)]
+    for c, ref in zip(cases, g['get_shapes_out']):
+        crop, out, _ = hm.get_shapes(*c)
+        assert list(crop) + list(out) == list(ref)
+
+
+def test_gmm_lut_accumulates_duplicates_and_unknown_labels_are_zero():
+    lut = hm.gmm_luts(np.array([0, 2, 2, 5]), np.array([[1.], [2.], [3.], [4.]]), np.ones((4, 1)))
+    assert lut.shape == (2, 1, 6)
+    np.testing.assert_array_equal(lut[0, 0], [1, 0, 5, 0, 0, 4])  # tf.scatter_nd adds duplicates; label 1,3,4 -> 0
+
+
+def test_reformat_helpers():
+    assert hm.reformat_to_list(3, length=3) == [3, 3, 3]
+    assert hm.reformat_to_list(np.array([1, 2, 3]), length=3, dtype='int') == [1, 2, 3]
+    with pytest.raises(ValueError):
+        hm.reformat_to_list([1, 2], length=3)
+    a = hm.reformat_to_n_channels_array([1.5, 1.5, 5.], 3, 2)
+    assert a.shape == (2, 3) and a[1, 2] == 5
+    assert hm.get_padding_margin(160, 128) == 16 and hm.get_padding_margin(None, 3) is None
+    assert hm.find_closest_number_divisible_by_m(187, 32) == 160
+
+
+def test_nifti_roundtrip_and_orientation(tmp_path):
+    from synthsr_amd import volumes
+    from synthsr_amd.nifti import write_nifti, read_nifti
+    rng = np.random.default_rng(0)
+    vol = rng.integers(0, 30, (12, 13, 14)).astype(np.float32)
+    aff = np.array([[0, -1.5, 0, 10], [1.2, 0, 0, -4], [0, 0, 2., 3], [0, 0, 0, 1.]])  # axes swapped + one flipped
+    p = str(tmp_path / 'v.nii.gz')
+    write_nifti(p, vol, aff)
+    d, a, h = read_nifti(p)
+    np.testing.assert_array_equal(d, vol)
+    np.testing.assert_allclose(a, aff, atol=1e-6)
+    v2, a2, _ = volumes.load_volume(p, im_only=False, dtype='int', aff_ref=np.eye(4))
+    assert v2.shape == (13, 12, 14) and v2.dtype == np.int64
+    np.testing.assert_array_equal(volumes.get_ras_axes(a2), [0, 1, 2])
+    assert all(np.diag(a2)[:3] > 0)
+    back = volumes.align_volume_to_ref(v2, a2, aff_ref=aff)
+    np.testing.assert_array_equal(back, vol.astype(np.int64))
+    shape, aff_o, n_dims, n_ch, _, res = volumes.get_volume_info(p, aff_ref=np.eye(4))
+    assert shape == [13, 12, 14] and n_dims == 3 and n_ch == 1
+    np.testing.assert_allclose(res, [1.5, 1.2, 2.], atol=1e-6)
+
+
+def test_get_list_labels_fs_sort():
+    from synthsr_amd import volumes
+    from synthsr_amd.synthetic import GENERATION_LABELS
+    lab, n_neutral = volumes.get_list_labels(label_list=GENERATION_LABELS[::-1].copy(), FS_sort=True)
+    np.testing.assert_array_equal(lab, GENERATION_LABELS)  # neutral sorted, then left sorted
+    assert n_neutral == 19  # only one hemisphere present -> all neutral (utils.py:275-278)
+    lab2, n2 = volumes.get_list_labels(label_list=[0, 41, 2, 14], FS_sort=True)
+    np.testing.assert_array_equal(lab2, [0, 14, 2, 41])
+    assert n2 == 2
+    with pytest.raises(Exception):
+        volumes.get_list_labels(label_list=[0, 99999], FS_sort=True)
+
+
+def test_model_inputs_generator_protocol():
+    from synthsr_amd.model_inputs import build_model_inputs
+    from synthsr_amd.synthetic import GENERATION_CLASSES, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR
+    maps = [np.zeros((4, 5, 6), np.int32), np.ones((4, 5, 6), np.int32)]
+    gen = build_model_inputs(None, 19, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', n_channels=1,
+                             generation_classes=GENERATION_CLASSES, rng=np.random.default_rng(0), label_maps=maps)
+    labels, means, stds = next(gen)
+    assert labels.shape == (1, 4, 5, 6, 1) and means.shape == (1, 19, 1) and stds.shape == (1, 19, 1)
+    assert (means >= 0).all() and (stds >= 0).all()
+    assert means[0, 1, 0] == means[0, 2, 0]  # labels 14 and 15 share class 3
+    with pytest.raises(ValueError):
+        next(build_model_inputs(None, 19, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', n_channels=2,
+                                generation_classes=GENERATION_CLASSES, label_maps=maps))
+    gen2 = build_model_inputs(None, 19, None, None, 'uniform', n_channels=2, batchsize=2, label_maps=maps,
+                              rng=np.random.default_rng(1))
+    l2, m2, s2 = next(gen2)
+    assert l2.shape == (2, 4, 5, 6, 1) and m2.shape == (2, 19, 2)
+    assert (m2 >= 25).all() and (m2 <= 225).all() and (s2 >= 5).all() and (s2 <= 25).all()
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """the shared library loads (no GPU needed) and exports every function include/synthsr_hip.h declares"""
+    from synthsr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from synthsr_amd import build
+        build.build(verbose=False)
+    hdr = open(os.path.join(REPO, 'include', 'synthsr_hip.h')).read()
+    declared = set(re.findall(r'\b(synthsr_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'missing export %s' % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib.synthsr_abi_version.restype = ctypes.c_int
+    assert lib.synthsr_abi_version() == 1
+    # argument validation happens before any HIP call: usable without a GPU
+    _lib.load()
+    assert _lib.load().synthsr_conv3d_pack(None, None, 24, 24, 0, None) == 27 * 3 * 2 * 128
+    assert _lib.load().synthsr_conv3d_pack(None, None, 0, 24, 0, None) == -1
+
+
+def test_product_fails_loudly_without_the_library(monkeypatch, tmp_path):
+    from synthsr_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.SynthSRHipError):
+        _lib.load()
+
+
+_GLOO_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from synthsr_amd.training import GradBucketReducer
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 10007
+g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+red = GradBucketReducer(g, bucket_elems=1500)
+red.start()
+# the backward reports readiness tail-first at layer boundaries
+for lo in (9000, 8800, 6000, 5999, 1200, 1000):
+    red.ready(lo)
+scale = red.finish()
+exp = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+assert torch.equal(g, exp), (g[:5], exp[:5])
+assert abs(scale - 1.0 / world) < 1e-12
+# weights broadcast + identical update on both ranks
+p = torch.full((5,), float(rank))
+dist.broadcast(p, 0)
+assert torch.equal(p, torch.zeros(5))
+dist.barrier()
+print('OK', rank)
+'''
+
+
+def test_grad_bucket_reducer_two_ranks_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_GLOO_WORKER)
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), str(script), REPO]
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('OK') == 2

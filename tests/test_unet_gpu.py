@@ -1,0 +1,204 @@
+"""GPU parity of the U-Net kernels (through the C ABI) against the plain PyTorch-CPU float32 restatement
+(oracle/unet_ref.py).  Tolerances: conv activations / gradients rel 2e-4 of the tensor's max-abs
+(float32 accumulation-order differences over K = 27*Cin up to 15552 and over up to 4e6 voxels);
+pointwise kernels 1e-5."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def T():
+    import torch
+    assert torch.cuda.is_available()
+    torch.manual_seed(0)
+    return torch
+
+
+def close(a, b, rel=2e-4, name=''):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-30)
+    err = (a - b).abs().max().item() / scale
+    assert err < rel, '%s: max rel err %.3e (scale %.3e)' % (name, err, scale)
+
+
+CONV_CASES = [  # (shape, Cin, Cout)
+    ((8, 8, 16), 24, 24), ((9, 7, 21), 24, 48), ((5, 6, 18), 48, 24), ((4, 4, 16), 72, 24), ((6, 5, 17), 2, 24),
+    ((6, 5, 17), 1, 24), ((4, 8, 16), 96, 96), ((3, 4, 5), 192, 384), ((4, 4, 4), 576, 192), ((10, 10, 10), 24, 1 * 16),
+    ((12, 12, 12), 8, 16), ((6, 6, 33), 144, 48),
+]
+
+
+@pytest.mark.parametrize('shape,Cin,Cout', CONV_CASES)
+def test_conv3d_fwd_dgrad_wgrad(T, shape, Cin, Cout):
+    torch = T
+    from synthsr_amd import ops
+    from oracle import unet_ref as U
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = torch.randn(*shape, Cin, generator=g)
+    w = torch.randn(3, 3, 3, Cin, Cout, generator=g) / np.sqrt(27 * Cin)
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(*shape, Cout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = U.conv3d_same(xr, wr, b)
+    yr_elu = torch.nn.functional.elu(yr)
+    yr.backward(dy)
+    xd, wd, bd, dyd = x.cuda(), w.cuda(), b.cuda(), dy.cuda()
+    wp = ops.pack_conv_weights(wd, 0)
+    close(ops.conv3d(xd, wp, bd, Cout, act=0), yr, name='fwd linear')
+    close(ops.conv3d(xd, wp, bd, Cout, act=1), yr_elu, name='fwd elu')
+    wpd = ops.pack_conv_weights(wd, 1)
+    close(ops.conv3d(dyd, wpd, None, Cin, act=0), xr.grad, name='dgrad')
+    dw = torch.zeros_like(wd)
+    ops.conv3d_wgrad(xd, dyd, dw)
+    close(dw, wr.grad, name='wgrad')
+
+
+def test_conv3d_identity_and_transpose_detecting(T):
+    """asymmetric one-hot kernels: catches a swapped tap / channel mapping that random data could average out"""
+    torch = T
+    from synthsr_amd import ops
+    x = torch.randn(6, 7, 19, 24)
+    for tap, ci, co in [((0, 1, 2), 3, 17), ((2, 0, 1), 23, 0), ((1, 1, 1), 5, 5)]:
+        w = torch.zeros(3, 3, 3, 24, 24)
+        w[tap[0], tap[1], tap[2], ci, co] = 1.0
+        y = ops.conv3d(x.cuda(), ops.pack_conv_weights(w.cuda(), 0), None, 24, act=0).cpu()
+        exp = torch.zeros(6, 7, 19)
+        xp = torch.nn.functional.pad(x[..., ci], (1, 1, 1, 1, 1, 1))
+        exp = xp[tap[0]:tap[0] + 6, tap[1]:tap[1] + 7, tap[2]:tap[2] + 19]
+        assert torch.equal(y[..., co], exp)
+        assert y.abs().sum() == exp.abs().sum()
+
+
+def test_pointwise_kernels(T):
+    torch = T
+    from synthsr_amd import ops
+    from oracle import unet_ref as U
+    shape, C = (8, 6, 10), 24
+    x = torch.randn(*shape, C) * 2 + 0.5
+    gamma, beta = torch.rand(C) + .5, torch.randn(C)
+    gamma[3] = -0.7  # negative scale: max-pool must be taken AFTER the BN
+    xd = x.cuda()
+    stats = torch.zeros(2 * C, device='cuda')
+    ws = torch.zeros(2 * C, dtype=torch.float64, device='cuda')
+    ops.bn_stats(xd, stats, ws)
+    yr, m, v = U.batchnorm_train(x, gamma, beta)
+    close(stats[:C], m, 1e-5, 'mean')
+    close(stats[C:], v, 1e-5, 'var')
+    close(ops.bn_apply(xd, stats, gamma.cuda(), beta.cuda()), yr, 1e-5, 'bn_apply')
+    close(ops.bn_maxpool(xd, stats, gamma.cuda(), beta.cuda()), U.maxpool2(yr), 1e-5, 'bn_maxpool')
+    # backward of BN + maxpool against autograd
+    xr = x.clone().requires_grad_(True)
+    y2, _, _ = U.batchnorm_train(xr, gamma, beta)
+    p = U.maxpool2(y2)
+    dp = torch.randn_like(p)
+    p.backward(dp)
+    gbn = ops.bn_maxpool_bwd(dp.cuda(), xd, stats, gamma.cuda(), beta.cuda())
+    sums = torch.zeros(2 * C, device='cuda')
+    dx = ops.bn_bwd(gbn, xd, stats, gamma.cuda(), sums)
+    close(dx, xr.grad, 2e-4, 'bn+pool backward')
+    # ELU backward + bias gradient
+    y = torch.nn.functional.elu(x)
+    dy, dy2 = torch.randn_like(y), torch.randn_like(y)
+    dbias = torch.zeros(C, device='cuda')
+    dz = ops.elu_bwd(dy.cuda(), y.cuda(), dy2=dy2.cuda(), dbias=dbias)
+    ref = (dy + dy2) * torch.where(x > 0, torch.ones_like(x), torch.exp(x))
+    close(dz, ref, 1e-5, 'elu_bwd')
+    close(dbias, ref.reshape(-1, C).sum(0), 1e-4, 'dbias')
+    # upsample + concat and its backward
+    lo = torch.randn(4, 3, 5, 48)
+    st_lo = torch.zeros(96, device='cuda')
+    ws2 = torch.zeros(96, dtype=torch.float64, device='cuda')
+    ops.bn_stats(lo.cuda(), st_lo, ws2)
+    g2, b2 = torch.rand(48) + .5, torch.randn(48)
+    cat = ops.upsample_concat(xd, lo.cuda(), st_lo, g2.cuda(), b2.cuda())
+    lo_bn, _, _ = U.batchnorm_train(lo, g2, b2)
+    close(cat, torch.cat([x, U.upsample2(lo_bn)], -1), 1e-5, 'upsample_concat')
+    dcat = torch.randn(*shape, C + 48)
+    dskip, dlo = ops.upsample_concat_bwd(dcat.cuda(), C, 48)
+    close(dskip, dcat[..., :C], 1e-6, 'dskip')
+    ref_dlo = dcat[..., C:].reshape(4, 2, 3, 2, 5, 2, 48).sum((1, 3, 5))
+    close(dlo, ref_dlo, 1e-5, 'dlo')
+
+
+def _copy_params(net, torch):
+    return {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+
+
+@pytest.mark.parametrize('feats,levels,shape,cin', [(24, 3, (16, 16, 32), 2), (8, 2, (8, 12, 16), 1), (24, 5, (32, 32, 32), 2)])
+def test_unet_loss_and_gradients_vs_autograd(T, feats, levels, shape, cin):
+    torch = T
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1,
+               feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3)
+    # make BN affine and biases non-trivial
+    g = torch.Generator().manual_seed(11)
+    for nm, v in net.named_parameters():
+        if nm.endswith('/gamma'):
+            v.copy_(torch.rand(v.shape, generator=g) + .5)
+        elif nm.endswith('/beta') or nm.endswith('/bias'):
+            v.copy_(torch.randn(v.shape, generator=g) * .1)
+    net.repack()
+    x = torch.rand(*shape, cin, generator=g)
+    target = torch.rand(*shape, 1, generator=g)
+    loss, pred = net.loss_l1(x.cuda(), target.reshape(-1).cuda(), want_pred=True)
+    pred = pred.clone()
+    net.backward()
+    P = _copy_params(net, torch)
+    stats = {}
+    pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats)
+    lr = U.l1_loss(pr, target)
+    lr.backward()
+    close(pred.view(*shape, 1), pr, 5e-4, 'prediction')
+    assert abs(loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
+    worst = 0.0
+    for nm, _, _ in net.specs:
+        got = net.view(nm, net.grads).cpu().double()
+        ref = P[nm].grad.double()
+        scale = max(ref.abs().max().item(), 1e-12)
+        err = (got - ref).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err < 5e-3, '%s grad rel err %.3e' % (nm, err)
+    # batch statistics
+    for bn in net.bn_layers:
+        o, C = bn['soff'], bn['C']
+        close(net.bn_batch[o:o + C], stats[bn['name']][0], 1e-4, bn['name'] + ' mean')
+        close(net.bn_batch[o + C:o + 2 * C], stats[bn['name']][1], 1e-4, bn['name'] + ' var')
+    # one Keras-Adam step
+    p0 = net.params.clone()
+    g0 = net.grads.clone()
+    net.adam_step(lr=1e-3)
+    pref, _, _ = U.adam_keras(p0.cpu(), g0.cpu(), torch.zeros_like(p0.cpu()), torch.zeros_like(p0.cpu()), 1, lr=1e-3)
+    close(net.params, pref, 1e-6, 'adam')
+    # inference path with moving statistics runs and is finite
+    net.update_moving_stats()
+    out = net.predict(x.cuda())
+    assert torch.isfinite(out).all() and list(out.shape) == list(shape) + [1]
+
+
+def test_training_reduces_loss(T):
+    """a few steps of the full loop (generator -> U-Net -> Adam) on a tiny volume: loss is finite and decreases on a
+    fixed sample"""
+    torch = T
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.training import Trainer
+    from synthsr_amd.unet import unet
+    from synthsr_amd.synthetic import (synthetic_label_pool, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
+                                       PRIOR_STDS_T1_HR)
+    pool = synthetic_label_pool(2, (32, 32, 32), 5)
+    bg = BrainGenerator(None, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', GENERATION_LABELS,
+                        generation_classes=GENERATION_CLASSES, output_shape=32, output_div_by_n=8, nonlin_std=4.,
+                        nonlin_shape_factor=.125, bias_shape_factor=.125, build_reliability_maps=True, downsample=True,
+                        shearing_bounds=.02, label_maps=pool, rng=np.random.default_rng(0))
+    net = unet(24, bg.model_output_shape, 3, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
+               batch_norm=-1, seed=1)
+    tr = Trainer(bg, net, lr=1e-3)
+    inputs = next(bg.model_inputs_generator)
+    draws = bg.labels_to_image_model.sample_draws()
+    losses = [tr.step(inputs, draws).item() for _ in range(8)]
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0]
