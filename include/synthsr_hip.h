@@ -117,13 +117,16 @@ int synthsr_copy_strided(const float* in, float* out, int64_t n, int in_stride, 
 /* ------------------------------------------------------------------ U-Net (ext/neuron/models.py:256-498) */
 
 /* Keras Conv3D(k=3,'same') weights are [3][3][3][Cin][Cout].  Packs them into the MFMA B-fragment order
- * used by synthsr_conv3d_fwd.  mode 0: forward; mode 1: data-gradient (taps flipped, Cin<->Cout swapped).
+ * used by synthsr_conv3d_fwd for a layer of spatial size `shape` (the output-channel tiling depends on the
+ * launch geometry chosen for that size).  mode 0: forward; mode 1: data-gradient (taps flipped, Cin<->Cout
+ * swapped; `shape`, Cin, Cout are still those of the FORWARD layer).
  * Returns the number of floats written (or required if packed==NULL), negative on error. */
-int64_t synthsr_conv3d_pack(const float* w, float* packed, int Cin, int Cout, int mode, synthsr_stream_t stream);
+int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], int Cin, int Cout, int mode,
+                            synthsr_stream_t stream);
 
 /* Conv3D 3x3x3 'same' + bias + activation (0 linear, 1 ELU alpha=1) — models.py:316,444.
- * in [d0,d1,d2,Cin], out [d0,d1,d2,Cout]; wpacked from synthsr_conv3d_pack(Cin,Cout,mode).
- * bias may be NULL (data-gradient use). */
+ * in [d0,d1,d2,Cin], out [d0,d1,d2,Cout]; wpacked from synthsr_conv3d_pack(shape,...) with the same shape.
+ * For the data-gradient call it with (dout, pack(mode 1), NULL, din, shape, Cout, Cin, 0). bias may be NULL. */
 int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
                        int Cin, int Cout, int act, synthsr_stream_t stream);
 

@@ -42,7 +42,7 @@ SIGNATURES = {
     'synthsr_blur3d': (c_int, [_P, _P, POINTER(c_int), _P, POINTER(c_int), c_int, c_int, c_int, c_float, _S]),
     'synthsr_outer3': (c_int, [_P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_copy_strided': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_pack': (c_int64, [_P, _P, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_pack': (c_int64, [_P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_conv3d_fwd': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),

@@ -13,6 +13,7 @@
 //       float atomics.
 // The data-gradient is the forward kernel on weights packed with flipped taps / swapped channels.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -22,17 +23,6 @@ constexpr int MAX_NT = 6;  // n-tiles (of 16 output channels) per workgroup
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// N (output channel) chunking shared by pack + forward
-struct NChunk {
-  int ntiles, nchunks, NT;
-};
-inline NChunk n_chunking(int Cout) {
-  NChunk r;
-  r.ntiles = cdiv(Cout, 16);
-  r.nchunks = cdiv(r.ntiles, MAX_NT);
-  r.NT = cdiv(r.ntiles, r.nchunks);
-  return r;
-}
 inline int ck_for(int Cin) { return (Cin % 24 == 0) ? 24 : 8; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -74,21 +64,32 @@ __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pac
 }
 
 // -------------------------------------------------------------------------------------------- forward
-constexpr int FT0 = 4, FT1 = 4, FT2 = 16;              // output tile
-constexpr int FH0 = 6, FH1 = 6, FH2 = 18;              // halo tile
-constexpr int FHV = FH0 * FH1 * FH2;                   // 648 halo voxels
+// output tile = 4 (z, one per wave) x MT (y, m-tiles per wave) x 16 (x, MFMA rows); MT = 4 for the large levels,
+// MT = 2 doubles the number of workgroups for the small (deep) levels.  KSPLIT: the input-channel chunks are
+// split over gridDim.z workgroups that accumulate into a zero-initialised output with float atomics; bias and
+// activation are then applied by bias_act_kernel.
+constexpr int FT0 = 4, FT2 = 16;
+constexpr int FH0 = 6, FH2 = 18;
 
-template <int CK, int NT>
+template <int CK, int NT, int MT, bool KSPLIT>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int D0, int D1, int D2, int Cin, int Cout, int ncc,
                                                             int tiles1, int tiles2, int act) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [FHV][CKP]
+  constexpr int FT1 = MT, FH1 = MT + 2, FHV = FH0 * FH1 * FH2;
   constexpr int CKP = CK + 4;
   constexpr int NCG = CK / 8;
   constexpr int C4 = CK / 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int t = blockIdx.x;
+  // XCD-aware tile order: workgroup b runs on XCD b%8 (observed dispatch order, speed only); give every XCD a
+  // contiguous range of tiles so that neighbouring tiles (shared halos) hit the same L2.  Bijective for any grid.
+  int t;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, j = b >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
   const int t2 = t % tiles2;
   t /= tiles2;
   const int t1 = t % tiles1;
@@ -96,50 +97,80 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
   const int z0 = t0 * FT0, y0 = t1 * FT1, x0 = t2 * FT2;
   const int nc = blockIdx.y;
 
-  f32x4 acc[4][NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int li = lane & 15, kq = lane >> 4;
-  int a_base[4];
+  int a_base[MT];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) a_base[m] = ((wave * FH1 + m) * FH2 + li) * CKP + 2 * kq;
+  for (int m = 0; m < MT; ++m) a_base[m] = ((wave * FH1 + m) * FH2 + li) * CKP + 2 * kq;
 
   const float* wl = wp + (size_t)nc * ncc * 27 * NCG * NT * 128 + lane * 2;
   const bool vec_ok = (Cin % 4) == 0;
 
-  for (int cc = 0; cc < ncc; ++cc) {
+  // chunk range of this workgroup (all chunks unless KSPLIT)
+  const int cpz = KSPLIT ? (ncc + (int)gridDim.z - 1) / (int)gridDim.z : ncc;
+  const int cc_lo = KSPLIT ? (int)blockIdx.z * cpz : 0;
+  const int cc_hi = min(ncc, cc_lo + cpz);
+  for (int cc = cc_lo; cc < cc_hi; ++cc) {
     __syncthreads();
-    // ---- stage the halo tile of this channel chunk (zero padding outside the volume / channel range)
-    for (int f = tid; f < FHV * C4; f += 256) {
-      const int vox = f / C4, c4 = f - vox * C4;
-      const int hx = vox % FH2, hy = (vox / FH2) % FH1, hz = vox / (FH2 * FH1);
-      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gz >= 0 && gz < D0 && gy >= 0 && gy < D1 && gx >= 0 && gx < D2) {
-        const int c = cc * CK + c4 * 4;
-        const float* src = in + (((size_t)gz * D1 + gy) * D2 + gx) * Cin + c;
-        if (vec_ok) {
-          if (c < Cin) v = ld4(src);
-        } else {
-          if (c + 0 < Cin) v.x = src[0];
-          if (c + 1 < Cin) v.y = src[1];
-          if (c + 2 < Cin) v.z = src[2];
-          if (c + 3 < Cin) v.w = src[3];
+    // ---- stage the halo tile of this channel chunk (zero padding outside the volume / channel range).
+    // Branch-free: out-of-range elements load from a clamped (valid) address and are zeroed by a select, so all
+    // global loads are issued back to back before the first LDS store and their latencies overlap.
+    {
+      constexpr int NIT = (FHV * C4 + 255) / 256;
+      constexpr int SB = (NT >= 5 && CK == 24) ? (NIT + 1) / 2 : NIT;  // batch size (register budget)
+#pragma unroll
+      for (int k0 = 0; k0 < NIT; k0 += SB) {
+        float4 stg[SB];
+#pragma unroll
+        for (int kk = 0; kk < SB; ++kk) {
+          const int f = tid + (k0 + kk) * 256;
+          const int vox = f / C4, c4 = f - vox * C4;
+          const int hx = vox % FH2, hy = (vox / FH2) % FH1, hz = vox / (FH2 * FH1);
+          const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+          const int c = cc * CK + c4 * 4;
+          const bool ok = (k0 + kk < NIT) & (f < FHV * C4) & (gz >= 0) & (gz < D0) & (gy >= 0) & (gy < D1) & (gx >= 0) &
+                          (gx < D2);
+          const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cin + c) : 0;
+          float4 v;
+          if constexpr (CK == 24) {  // Cin % 24 == 0: aligned float4, channel range always valid
+            v = ld4(in + off);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else {
+            const float* src = in + off;
+            v.x = (ok && c + 0 < Cin) ? src[0] : 0.f;
+            v.y = (ok && c + 1 < Cin) ? src[(c + 1 < Cin) ? 1 : 0] : 0.f;
+            v.z = (ok && c + 2 < Cin) ? src[(c + 2 < Cin) ? 2 : 0] : 0.f;
+            v.w = (ok && c + 3 < Cin) ? src[(c + 3 < Cin) ? 3 : 0] : 0.f;
+          }
+          stg[kk] = v;
+        }
+#pragma unroll
+        for (int kk = 0; kk < SB; ++kk) {
+          const int f = tid + (k0 + kk) * 256;
+          const int vox = f / C4, c4 = f - vox * C4;
+          if (k0 + kk < NIT && f < FHV * C4) *reinterpret_cast<float4*>(&lds[vox * CKP + c4 * 4]) = stg[kk];
         }
       }
-      *reinterpret_cast<float4*>(&lds[vox * CKP + c4 * 4]) = v;
     }
     __syncthreads();
 
     const float* wc = wl + (size_t)cc * 27 * NCG * NT * 128;
+    // Software pipeline, pinned with sched_barrier so that hipcc cannot sink the prefetches next to their uses:
+    //   B fragments of tap t+1 are requested at the top of tap t (one L2 round trip hidden behind 16*NCG*NT MFMAs),
+    //   A fragments of step (t,g)+1 are read from LDS before the MFMAs of step (t,g).
     float2 bcur[NCG][NT], bnext[NCG][NT];
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
       for (int n = 0; n < NT; ++n) bcur[g][n] = *reinterpret_cast<const float2*>(wc + (g * NT + n) * 128);
+    float2 acur[MT], anext[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acur[m] = *reinterpret_cast<const float2*>(&lds[a_base[m]]);
 
     for (int tap = 0; tap < 27; ++tap) {
       if (tap + 1 < 27) {
@@ -149,30 +180,34 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
 #pragma unroll
           for (int n = 0; n < NT; ++n) bnext[g][n] = *reinterpret_cast<const float2*>(wn + (g * NT + n) * 128);
       }
-      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-      const int toff = ((dz * FH1 + dy) * FH2 + dx) * CKP;
+      const int tn = tap + 1 < 27 ? tap + 1 : 26;
+      const int toff = (((tap / 9) * FH1 + (tap / 3) % 3) * FH2 + tap % 3) * CKP;
+      const int toff_n = (((tn / 9) * FH1 + (tn / 3) % 3) * FH2 + tn % 3) * CKP;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
-        float2 a[4];
+        const int noff = (g + 1 < NCG) ? toff + (g + 1) * 8 : toff_n;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + toff + g * 8]);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, bcur[g][n].x, acc[m][n], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) anext[m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + noff]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, bcur[g][n].y, acc[m][n], 0, 0, 0);
-      }
-      if (tap + 1 < 27) {
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m].x, bcur[g][n].x, acc[m][n], 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < NCG; ++g)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bcur[g][n] = bnext[g][n];
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m].y, bcur[g][n].y, acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acur[m] = anext[m];
       }
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bcur[g][n] = bnext[g][n];
     }
   }
 
@@ -180,25 +215,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
   const int gz = z0 + wave;
   if (gz < D0) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
       const int gy = y0 + m;
       if (gy >= D1) continue;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = (nc * NT + n) * 16 + li;
         if (co >= Cout) continue;
-        const float bv = bias ? bias[co] : 0.f;
+        const float bv = (!KSPLIT && bias) ? bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int gx = x0 + kq * 4 + r;
           if (gx < D2) {
-            float v = acc[m][n][r] + bv;
-            if (act == 1) v = v > 0.f ? v : expm1f(v);
-            out[(((size_t)gz * D1 + gy) * D2 + gx) * Cout + co] = v;
+            float* dst = out + (((size_t)gz * D1 + gy) * D2 + gx) * Cout + co;
+            if constexpr (KSPLIT) {
+              atomicAdd(dst, acc[m][n][r]);
+            } else {
+              float v = acc[m][n][r] + bv;
+              if (act == 1) v = v > 0.f ? v : expm1f(v);
+              *dst = v;
+            }
           }
         }
       }
     }
+  }
+}
+
+// bias + activation after a split-K accumulation
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t n,
+                                                       int C, int act) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = y[i] + (bias ? bias[i % C] : 0.f);
+    if (act == 1) v = v > 0.f ? v : expm1f(v);
+    y[i] = v;
   }
 }
 
@@ -210,7 +260,7 @@ constexpr int WVPX = 434;                   // 434/2 = 217 odd -> rows of [ci][v
 constexpr int WTV = WT0 * WT1 * WT2;        // 128
 constexpr int WVPD = 130;                   // 65 odd
 
-template <int CK, int NT>
+template <int CK, int NT, int MS>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __restrict__ in,
                                                               const float* __restrict__ dout, float* __restrict__ dw,
                                                               int D0, int D1, int D2, int Cin, int Cout, int tiles0,
@@ -220,11 +270,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
   float* ld = lds + CK * WVPX;     // [NT*16][WVPD]
   constexpr int MR = 27 * CK;      // GEMM rows (tap, ci)
   constexpr int MTILES = (MR + 15) / 16;
-  constexpr int MTW = (MTILES + 3) / 4;  // m-tiles per wave
+  constexpr int MTP = (MTILES + MS - 1) / MS;  // m-tiles per workgroup (the GEMM rows are split over MS workgroups)
+  constexpr int MTW = (MTP + 3) / 4;           // m-tiles per wave
   constexpr int C4 = CK / 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int cc = blockIdx.y;   // input-channel chunk
+  const int cc = blockIdx.y / MS;   // input-channel chunk
+  const int mt0 = (blockIdx.y % MS) * MTP;  // first m-tile of this workgroup
   const int nco = blockIdx.z;  // output-channel chunk
   const int co0 = nco * NT * 16;
   const bool vec_in = (Cin % 4) == 0, vec_out = (Cout % 4) == 0;
@@ -239,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
   int a_base[MTW];
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
-    int r = (wave + 4 * m) * 16 + li;
+    int r = (mt0 + wave + 4 * m) * 16 + li;
     if (r >= MR) r = MR - 1;
     const int tap = r / CK, cil = r - tap * CK;
     const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
@@ -252,69 +304,118 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
     const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
     const int z0 = t0 * WT0, y0 = t1 * WT1, x0 = t2 * WT2;
     __syncthreads();
-    // ---- stage x halo tile, transposed to [ci][voxel]
-    for (int f = tid; f < WHV * C4; f += 256) {
-      const int vox = f / C4, c4 = f - vox * C4;
-      const int hx = vox % WH2, hy = (vox / WH2) % WH1, hz = vox / (WH2 * WH1);
-      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gz >= 0 && gz < D0 && gy >= 0 && gy < D1 && gx >= 0 && gx < D2) {
-        const int c = cc * CK + c4 * 4;
-        const float* src = in + (((size_t)gz * D1 + gy) * D2 + gx) * Cin + c;
-        if (vec_in) {
-          if (c < Cin) v = ld4(src);
-        } else {
-          if (c + 0 < Cin) v.x = src[0];
-          if (c + 1 < Cin) v.y = src[1];
-          if (c + 2 < Cin) v.z = src[2];
-          if (c + 3 < Cin) v.w = src[3];
+    // ---- stage x halo tile ([ci][voxel]) and dy tile ([co][voxel]).  Branch-free (clamped address + select):
+    // the global loads of a batch are issued back to back ahead of their LDS stores.
+    {
+      constexpr int NX = (WHV * C4 + 255) / 256;
+      constexpr int ND = (WTV * NT * 4 + 255) / 256;
+      constexpr int XB = NX;  // x-tile batch
+#pragma unroll
+      for (int k0 = 0; k0 < NX; k0 += XB) {
+        float4 sx[XB];
+#pragma unroll
+        for (int kk = 0; kk < XB; ++kk) {
+          const int f = tid + (k0 + kk) * 256;
+          const int vox = f / C4, c4 = f - vox * C4;
+          const int hx = vox % WH2, hy = (vox / WH2) % WH1, hz = vox / (WH2 * WH1);
+          const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+          const int c = cc * CK + c4 * 4;
+          const bool ok = (k0 + kk < NX) & (f < WHV * C4) & (gz >= 0) & (gz < D0) & (gy >= 0) & (gy < D1) & (gx >= 0) &
+                          (gx < D2);
+          const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cin + c) : 0;
+          float4 v;
+          if constexpr (CK == 24) {
+            v = ld4(in + off);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else {
+            const float* src = in + off;
+            v.x = (ok && c + 0 < Cin) ? src[0] : 0.f;
+            v.y = (ok && c + 1 < Cin) ? src[(c + 1 < Cin) ? 1 : 0] : 0.f;
+            v.z = (ok && c + 2 < Cin) ? src[(c + 2 < Cin) ? 2 : 0] : 0.f;
+            v.w = (ok && c + 3 < Cin) ? src[(c + 3 < Cin) ? 3 : 0] : 0.f;
+          }
+          sx[kk] = v;
+        }
+#pragma unroll
+        for (int kk = 0; kk < XB; ++kk) {
+          const int f = tid + (k0 + kk) * 256;
+          const int vox = f / C4, c4 = f - vox * C4;
+          if (k0 + kk < NX && f < WHV * C4) {
+            float* d = lx + (c4 * 4) * WVPX + vox;
+            d[0] = sx[kk].x;
+            d[WVPX] = sx[kk].y;
+            d[2 * WVPX] = sx[kk].z;
+            d[3 * WVPX] = sx[kk].w;
+          }
         }
       }
-      float* d = lx + (c4 * 4) * WVPX + vox;
-      d[0] = v.x;
-      d[WVPX] = v.y;
-      d[2 * WVPX] = v.z;
-      d[3 * WVPX] = v.w;
-    }
-    // ---- stage dy tile, transposed to [co][voxel]
-    for (int f = tid; f < WTV * NT * 4; f += 256) {
-      const int vox = f / (NT * 4), c4 = f - vox * (NT * 4);
-      const int vx = vox % WT2, vy = (vox / WT2) % WT1, vz = vox / (WT2 * WT1);
-      const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gz < D0 && gy < D1 && gx < D2) {
+      float4 sd[ND];
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        const int f = tid + k * 256;
+        const int vox = f / (NT * 4), c4 = f - vox * (NT * 4);
+        const int vx = vox % WT2, vy = (vox / WT2) % WT1, vz = vox / (WT2 * WT1);
+        const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
         const int c = co0 + c4 * 4;
-        const float* src = dout + (((size_t)gz * D1 + gy) * D2 + gx) * Cout + c;
+        const bool ok = (f < WTV * NT * 4) & (gz < D0) & (gy < D1) & (gx < D2);
+        const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cout + c) : 0;
+        float4 v;
         if (vec_out) {
-          if (c < Cout) v = ld4(src);
+          const bool okc = ok && c < Cout;
+          v = ld4(dout + (okc ? off : 0));
+          if (!okc) v = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-          if (c + 0 < Cout) v.x = src[0];
-          if (c + 1 < Cout) v.y = src[1];
-          if (c + 2 < Cout) v.z = src[2];
-          if (c + 3 < Cout) v.w = src[3];
+          const float* src = dout + off;
+          v.x = (ok && c + 0 < Cout) ? src[0] : 0.f;
+          v.y = (ok && c + 1 < Cout) ? src[(c + 1 < Cout) ? 1 : 0] : 0.f;
+          v.z = (ok && c + 2 < Cout) ? src[(c + 2 < Cout) ? 2 : 0] : 0.f;
+          v.w = (ok && c + 3 < Cout) ? src[(c + 3 < Cout) ? 3 : 0] : 0.f;
+        }
+        sd[k] = v;
+      }
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        const int f = tid + k * 256;
+        const int vox = f / (NT * 4), c4 = f - vox * (NT * 4);
+        if (f < WTV * NT * 4) {
+          float* d = ld + (c4 * 4) * WVPD + vox;
+          d[0] = sd[k].x;
+          d[WVPD] = sd[k].y;
+          d[2 * WVPD] = sd[k].z;
+          d[3 * WVPD] = sd[k].w;
         }
       }
-      float* d = ld + (c4 * 4) * WVPD + vox;
-      d[0] = v.x;
-      d[WVPD] = v.y;
-      d[2 * WVPD] = v.z;
-      d[3 * WVPD] = v.w;
     }
     __syncthreads();
-    // ---- 32 k-steps of 4 voxels
-#pragma unroll 2
-    for (int ks = 0; ks < WTV / 4; ++ks) {
-      const int k = ks * 4 + kq;  // this lane's voxel within the tile
-      const int vx = k & 15, vy = (k >> 4) & 3, vz = k >> 6;
-      const int voff = (vz * WH1 + vy) * WH2 + vx;
-      float b[NT];
+    // ---- 32 k-steps of 4 voxels; the LDS reads of step ks+1 are issued before the MFMAs of step ks
+    {
+      float acur[MTW], anext[MTW], bcur[NT], bnext[NT];
+      {
+        const int voff = (((kq >> 6) * WH1 + ((kq >> 4) & 3)) * WH2) + (kq & 15);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) b[n] = ld[b_base + n * 16 * WVPD + ks * 4];
+        for (int n = 0; n < NT; ++n) bcur[n] = ld[b_base + n * 16 * WVPD];
 #pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        const float a = lx[a_base[m] + voff];
+        for (int m = 0; m < MTW; ++m) acur[m] = lx[a_base[m] + voff];
+      }
+      for (int ks = 0; ks < WTV / 4; ++ks) {
+        const int kn = (ks + 1 < WTV / 4) ? ks + 1 : ks;
+        const int k = kn * 4 + kq;
+        const int voff = (((k >> 6) * WH1 + ((k >> 4) & 3)) * WH2) + (k & 15);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) bnext[n] = ld[b_base + n * 16 * WVPD + kn * 4];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) anext[m] = lx[a_base[m] + voff];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m], bcur[n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acur[m] = anext[m];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bcur[n] = bnext[n];
       }
     }
   }
@@ -324,7 +425,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
   for (int m = 0; m < MTW; ++m) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = (wave + 4 * m) * 16 + kq * 4 + r;
+      if (wave + 4 * m >= MTP) continue;  // m-tile belongs to the next workgroup of the split
+      const int row = (mt0 + wave + 4 * m) * 16 + kq * 4 + r;
       if (row >= MR) continue;
       const int tap = row / CK, cil = row - tap * CK;
       const int ci = cc * CK + cil;
@@ -338,52 +440,102 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
   }
 }
 
-template <int CK, int NT>
+struct FwdPlan {
+  int nt, mt, ksplit, nchunks, ncc, ck;
+};
+
+// Launch geometry for one layer: enough workgroups to fill 256 CUs x 2 even on the deep, small levels.
+inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout) {
+  FwdPlan p;
+  p.ck = ck_for(Cin);
+  p.ncc = cdiv(Cin, p.ck);
+  const int ntiles = cdiv(Cout, 16);
+  auto wgs = [&](int mt, int nt) { return (int64_t)cdiv(s[0], FT0) * cdiv(s[1], mt) * cdiv(s[2], FT2) * cdiv(ntiles, nt); };
+  p.mt = 4;
+  int max_nt = MAX_NT;
+  if (wgs(4, std::min(MAX_NT, ntiles)) < 768) {
+    p.mt = 2;
+    max_nt = 3;
+  }
+  p.nchunks = cdiv(ntiles, max_nt);
+  p.nt = cdiv(ntiles, p.nchunks);
+  p.ksplit = 1;
+  const int64_t w = wgs(p.mt, p.nt);
+  if (w < 512 && p.ncc >= 4) {
+    int ks = (int)cdiv(1024, (int)w);
+    if (ks > p.ncc / 2) ks = p.ncc / 2;
+    if (ks > 8) ks = 8;
+    if (ks >= 2) p.ksplit = ks;
+  }
+  return p;
+}
+
+template <int CK, int NT, int MT, bool KS>
 int launch_fwd(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
-               int ncc, int nchunks, int act, hipStream_t st) {
-  const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], FT1), tiles2 = cdiv(s[2], FT2);
-  const size_t smem = (size_t)FHV * (CK + 4) * sizeof(float);
+               const FwdPlan& pl, int act, hipStream_t st) {
+  const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], MT), tiles2 = cdiv(s[2], FT2);
+  const size_t smem = (size_t)FH0 * (MT + 2) * FH2 * (CK + 4) * sizeof(float);
   static bool attr_done = false;
-  auto kern = conv3d_fwd_kernel<CK, NT>;
+  auto kern = conv3d_fwd_kernel<CK, NT, MT, KS>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles0 * tiles1 * tiles2, nchunks), dim3(256), smem, st, in, wp, bias, out, s[0], s[1],
-                     s[2], Cin, Cout, ncc, tiles1, tiles2, act);
-  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+  const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
+  if (KS) {
+    if (hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles0 * tiles1 * tiles2, pl.nchunks, KS ? pl.ksplit : 1), dim3(256), smem, st, in, wp,
+                     bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act);
+  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  if (KS && (bias != nullptr || act != 0)) {
+    hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act);
+    if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  }
+  return SYNTHSR_OK;
 }
 
-template <int CK>
-int dispatch_fwd(int NT, const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin,
-                 int Cout, int ncc, int nchunks, int act, hipStream_t st) {
-  switch (NT) {
-    case 1: return launch_fwd<CK, 1>(in, wp, bias, out, s, Cin, Cout, ncc, nchunks, act, st);
-    case 2: return launch_fwd<CK, 2>(in, wp, bias, out, s, Cin, Cout, ncc, nchunks, act, st);
-    case 3: return launch_fwd<CK, 3>(in, wp, bias, out, s, Cin, Cout, ncc, nchunks, act, st);
-    case 4: return launch_fwd<CK, 4>(in, wp, bias, out, s, Cin, Cout, ncc, nchunks, act, st);
-    case 5: return launch_fwd<CK, 5>(in, wp, bias, out, s, Cin, Cout, ncc, nchunks, act, st);
-    case 6: return launch_fwd<CK, 6>(in, wp, bias, out, s, Cin, Cout, ncc, nchunks, act, st);
+template <int CK, int NT>
+int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
+                  const FwdPlan& pl, int act, hipStream_t st) {
+  if (pl.mt == 4) return launch_fwd<CK, NT, 4, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+  if constexpr (NT <= 3) {
+    if (pl.ksplit > 1) return launch_fwd<CK, NT, 2, true>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    return launch_fwd<CK, NT, 2, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
   }
   return SYNTHSR_EINVAL;
 }
 
-template <int CK, int NT>
+template <int CK>
+int dispatch_fwd(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
+                 const FwdPlan& pl, int act, hipStream_t st) {
+  switch (pl.nt) {
+    case 1: return dispatch_fwd2<CK, 1>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    case 2: return dispatch_fwd2<CK, 2>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    case 3: return dispatch_fwd2<CK, 3>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    case 4: return dispatch_fwd2<CK, 4>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    case 5: return dispatch_fwd2<CK, 5>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    case 6: return dispatch_fwd2<CK, 6>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+  }
+  return SYNTHSR_EINVAL;
+}
+
+template <int CK, int NT, int MS>
 int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], int Cin, int Cout, hipStream_t st) {
   const int tiles0 = cdiv(s[0], WT0), tiles1 = cdiv(s[1], WT1), tiles2 = cdiv(s[2], WT2);
   const int ntiles = tiles0 * tiles1 * tiles2;
   const int ncc = cdiv(Cin, CK), nco = cdiv(Cout, NT * 16);
-  int gx = 2048 / (ncc * nco);
+  int gx = 2048 / (ncc * nco * MS);
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   const size_t smem = ((size_t)CK * WVPX + (size_t)NT * 16 * WVPD) * sizeof(float);
   static bool attr_done = false;
-  auto kern = conv3d_wgrad_kernel<CK, NT>;
+  auto kern = conv3d_wgrad_kernel<CK, NT, MS>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(gx, ncc, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout, tiles0,
+  hipLaunchKernelGGL(kern, dim3(gx, ncc * MS, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout, tiles0,
                      tiles1, tiles2);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
@@ -392,17 +544,17 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
 
 extern "C" {
 
-int64_t synthsr_conv3d_pack(const float* w, float* packed, int Cin, int Cout, int mode, synthsr_stream_t stream) {
-  if (Cin < 1 || Cout < 1 || (mode != 0 && mode != 1)) return SYNTHSR_EINVAL;
+int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], int Cin, int Cout, int mode,
+                            synthsr_stream_t stream) {
+  if (!shape || Cin < 1 || Cout < 1 || (mode != 0 && mode != 1) || shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
+    return SYNTHSR_EINVAL;
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
-  const int CK = ck_for(CinE);
-  const int ncc = cdiv(CinE, CK);
-  const NChunk nch = n_chunking(CoutE);
-  const int64_t total = (int64_t)nch.nchunks * ncc * 27 * (CK / 8) * nch.NT * 128;
+  const FwdPlan pl = plan_fwd(shape, CinE, CoutE);
+  const int64_t total = (int64_t)pl.nchunks * pl.ncc * 27 * (pl.ck / 8) * pl.nt * 128;
   if (!packed) return total;
   if (!w) return SYNTHSR_EINVAL;
   hipLaunchKernelGGL(pack_kernel, dim3(syn_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cin, Cout,
-                     mode, CK, ncc, nch.NT, nch.nchunks, total);
+                     mode, pl.ck, pl.ncc, pl.nt, pl.nchunks, total);
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   return total;
 }
@@ -412,12 +564,9 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
   if (!in || !wpacked || !out || !shape || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1 ||
       (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
-  const int CK = ck_for(Cin);
-  const int ncc = cdiv(Cin, CK);
-  const NChunk nch = n_chunking(Cout);
-  if (CK == 24)
-    return dispatch_fwd<24>(nch.NT, in, wpacked, bias, out, shape, Cin, Cout, ncc, nch.nchunks, act, (hipStream_t)stream);
-  return dispatch_fwd<8>(nch.NT, in, wpacked, bias, out, shape, Cin, Cout, ncc, nch.nchunks, act, (hipStream_t)stream);
+  const FwdPlan pl = plan_fwd(shape, Cin, Cout);
+  if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream);
+  return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream);
 }
 
 int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout,
@@ -431,13 +580,13 @@ int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const in
   const int NT = cdiv(nt_all, nco);
   hipStream_t st = (hipStream_t)stream;
   if (CK == 24) {
-    if (NT == 1) return launch_wgrad<24, 1>(in, dout, dw, shape, Cin, Cout, st);
-    if (NT == 2) return launch_wgrad<24, 2>(in, dout, dw, shape, Cin, Cout, st);
-    return launch_wgrad<24, 3>(in, dout, dw, shape, Cin, Cout, st);
+    if (NT == 1) return launch_wgrad<24, 1, 1>(in, dout, dw, shape, Cin, Cout, st);
+    if (NT == 2) return launch_wgrad<24, 2, 1>(in, dout, dw, shape, Cin, Cout, st);
+    return launch_wgrad<24, 3, 2>(in, dout, dw, shape, Cin, Cout, st);
   }
-  if (NT == 1) return launch_wgrad<8, 1>(in, dout, dw, shape, Cin, Cout, st);
-  if (NT == 2) return launch_wgrad<8, 2>(in, dout, dw, shape, Cin, Cout, st);
-  return launch_wgrad<8, 3>(in, dout, dw, shape, Cin, Cout, st);
+  if (NT == 1) return launch_wgrad<8, 1, 1>(in, dout, dw, shape, Cin, Cout, st);
+  if (NT == 2) return launch_wgrad<8, 2, 1>(in, dout, dw, shape, Cin, Cout, st);
+  return launch_wgrad<8, 3, 1>(in, dout, dw, shape, Cin, Cout, st);
 }
 
 }  // extern "C"

@@ -47,17 +47,19 @@ def _L():
     return _lib.load()
 
 
-def pack_conv_weights(w, mode=0, out=None):
-    """w: Keras Conv3D kernel [3,3,3,Cin,Cout] -> MFMA fragment order (mode 0 fwd, 1 data-gradient)"""
+def pack_conv_weights(w, shape, mode=0, out=None):
+    """w: Keras Conv3D kernel [3,3,3,Cin,Cout] -> MFMA fragment order for a layer of spatial size `shape`
+    (mode 0 fwd, 1 data-gradient)"""
     lib = _L()
     Cin, Cout = int(w.shape[3]), int(w.shape[4])
-    n = lib.synthsr_conv3d_pack(None, None, Cin, Cout, mode, None)
+    s3 = _lib.i3(shape[:3])
+    n = lib.synthsr_conv3d_pack(None, None, s3, Cin, Cout, mode, None)
     if n < 0:
         _lib.check(int(n), 'conv3d_pack(size)')
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=w.device)
     assert out.numel() == n
-    r = lib.synthsr_conv3d_pack(_lib.ptr(w), _lib.ptr(out), Cin, Cout, mode, _lib.stream())
+    r = lib.synthsr_conv3d_pack(_lib.ptr(w), _lib.ptr(out), s3, Cin, Cout, mode, _lib.stream())
     if r < 0:
         _lib.check(int(r), 'conv3d_pack')
     return out

@@ -55,7 +55,7 @@ class UNet3D:
             convs = []
             for k in range(self.nconv):
                 nm = '%s_conv_downarm_%d_%d' % (self.prefix, l, k)
-                convs.append(self._add_conv(nm, c, self.feats[l]))
+                convs.append(self._add_conv(nm, c, self.feats[l], self.shapes[l]))
                 c = self.feats[l]
             bn = self._add_bn('%s_bn_down_%d' % (self.prefix, l), c)
             self.enc.append(dict(convs=convs, bn=bn))
@@ -65,7 +65,7 @@ class UNet3D:
             convs = []
             for j in range(self.nconv):
                 nm = '%s_conv_uparm_%d_%d' % (self.prefix, L + k, j)
-                convs.append(self._add_conv(nm, c_in, self.feats[l]))
+                convs.append(self._add_conv(nm, c_in, self.feats[l], self.shapes[l]))
                 c_in = self.feats[l]
             c = self.feats[l]
             bn = self._add_bn('%s_bn_up_%d' % (self.prefix, k), c)
@@ -111,8 +111,8 @@ class UNet3D:
         self.specs.append((name, tuple(shape), kind))
         return name
 
-    def _add_conv(self, name, cin, cout):
-        return dict(name=name, cin=cin, cout=cout, w=self._add(name + '/kernel', (3, 3, 3, cin, cout), 'kernel'),
+    def _add_conv(self, name, cin, cout, shape):
+        return dict(name=name, cin=cin, cout=cout, shape=list(shape), w=self._add(name + '/kernel', (3, 3, 3, cin, cout), 'kernel'),
                     b=self._add(name + '/bias', (cout,), 'bias'), wp=None, wpd=None)
 
     def _add_bn(self, name, C):
@@ -159,9 +159,9 @@ class UNet3D:
         first = True
         for c in self.all_convs():
             w = self.view(c['w'])
-            c['wp'] = ops.pack_conv_weights(w, 0, c['wp'])
+            c['wp'] = ops.pack_conv_weights(w, c['shape'], 0, c['wp'])
             if not first:  # the first layer's input has no gradient
-                c['wpd'] = ops.pack_conv_weights(w, 1, c['wpd'])
+                c['wpd'] = ops.pack_conv_weights(w, c['shape'], 1, c['wpd'])
             first = False
 
     def state_dict(self):

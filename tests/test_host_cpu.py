@@ -131,8 +131,9 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.synthsr_abi_version() == 1
     # argument validation happens before any HIP call: usable without a GPU
     _lib.load()
-    assert _lib.load().synthsr_conv3d_pack(None, None, 24, 24, 0, None) == 27 * 3 * 2 * 128
-    assert _lib.load().synthsr_conv3d_pack(None, None, 0, 24, 0, None) == -1
+    big = _lib.i3([160, 160, 160])
+    assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 27 * 3 * 2 * 128
+    assert _lib.load().synthsr_conv3d_pack(None, None, big, 0, 24, 0, None) == -1
 
 
 def test_product_fails_loudly_without_the_library(monkeypatch, tmp_path):

@@ -27,7 +27,8 @@ def close(a, b, rel=2e-4, name=''):
 CONV_CASES = [  # (shape, Cin, Cout)
     ((8, 8, 16), 24, 24), ((9, 7, 21), 24, 48), ((5, 6, 18), 48, 24), ((4, 4, 16), 72, 24), ((6, 5, 17), 2, 24),
     ((6, 5, 17), 1, 24), ((4, 8, 16), 96, 96), ((3, 4, 5), 192, 384), ((4, 4, 4), 576, 192), ((10, 10, 10), 24, 1 * 16),
-    ((12, 12, 12), 8, 16), ((6, 6, 33), 144, 48),
+    ((12, 12, 12), 8, 16), ((6, 6, 33), 144, 48), ((10, 10, 10), 384, 384), ((20, 20, 20), 96, 192),
+    ((40, 40, 40), 48, 96), ((48, 40, 64), 24, 24), ((32, 48, 64), 72, 24),
 ]
 
 
@@ -47,10 +48,10 @@ def test_conv3d_fwd_dgrad_wgrad(T, shape, Cin, Cout):
     yr_elu = torch.nn.functional.elu(yr)
     yr.backward(dy)
     xd, wd, bd, dyd = x.cuda(), w.cuda(), b.cuda(), dy.cuda()
-    wp = ops.pack_conv_weights(wd, 0)
+    wp = ops.pack_conv_weights(wd, shape, 0)
     close(ops.conv3d(xd, wp, bd, Cout, act=0), yr, name='fwd linear')
     close(ops.conv3d(xd, wp, bd, Cout, act=1), yr_elu, name='fwd elu')
-    wpd = ops.pack_conv_weights(wd, 1)
+    wpd = ops.pack_conv_weights(wd, shape, 1)
     close(ops.conv3d(dyd, wpd, None, Cin, act=0), xr.grad, name='dgrad')
     dw = torch.zeros_like(wd)
     ops.conv3d_wgrad(xd, dyd, dw)
@@ -65,7 +66,7 @@ def test_conv3d_identity_and_transpose_detecting(T):
     for tap, ci, co in [((0, 1, 2), 3, 17), ((2, 0, 1), 23, 0), ((1, 1, 1), 5, 5)]:
         w = torch.zeros(3, 3, 3, 24, 24)
         w[tap[0], tap[1], tap[2], ci, co] = 1.0
-        y = ops.conv3d(x.cuda(), ops.pack_conv_weights(w.cuda(), 0), None, 24, act=0).cpu()
+        y = ops.conv3d(x.cuda(), ops.pack_conv_weights(w.cuda(), (6, 7, 19), 0), None, 24, act=0).cpu()
         exp = torch.zeros(6, 7, 19)
         xp = torch.nn.functional.pad(x[..., ci], (1, 1, 1, 1, 1, 1))
         exp = xp[tap[0]:tap[0] + 6, tap[1]:tap[1] + 7, tap[2]:tap[2] + 19]
