@@ -130,6 +130,9 @@ int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], i
 int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
                        int Cin, int Cout, int act, synthsr_stream_t stream);
 
+/* tuning / A-B switch, process-wide: option 0 = use the persistent forward kernel on the large levels (default 1) */
+int synthsr_conv3d_set_option(int option, int value);
+
 /* weight gradient: dw[3][3][3][Cin][Cout] += sum_v in[v+t-1][ci] * dout[v][co]   (dw must be zeroed by caller) */
 int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout,
                          synthsr_stream_t stream);

@@ -64,6 +64,46 @@ __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pac
 }
 
 // -------------------------------------------------------------------------------------------- forward
+// Epilogue of one wave: D fragments (row = (lane>>4)*4 + reg -> x, col = lane&15 -> channel) are transposed through a
+// wave-private LDS slab so that each global store instruction writes 64 x 16 B of CONSECUTIVE addresses (a (z,y)
+// row of 16 voxels x Cout channels is contiguous in NDHWC); direct fragment stores would emit 64-byte pieces.
+// slab: 16 x (NT*16) floats.  Requires Cout % 4 == 0 (else the scalar path below).
+template <int NT, int MT>
+__device__ __forceinline__ void store_tile_rows(f32x4 (&acc)[MT][NT], float* slab, float* __restrict__ out,
+                                                const float* __restrict__ bias, int act, int nc, int gz, int y0, int x0,
+                                                int D1, int D2, int Cout, int lane) {
+  const int li = lane & 15, kq = lane >> 4;
+  constexpr int NW = NT * 16;
+  const int c_lo = nc * NW;
+  const int wc = min(Cout - c_lo, NW);  // channels of this chunk
+  const int wc4 = wc >> 2;
+  const int nx = min(16, D2 - x0);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int gy = y0 + m;
+    if (gy >= D1) continue;  // wave-uniform
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = c_lo + n * 16 + li;
+      const float bv = (bias && co < Cout) ? bias[co] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[m][n][r] + bv;
+        if (act == 1) v = v > 0.f ? v : expm1f(v);
+        slab[(kq * 4 + r) * NW + n * 16 + li] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* row = out + (((size_t)gz * D1 + gy) * D2 + x0) * Cout + c_lo;
+    for (int idx = lane; idx < nx * wc4; idx += 64) {
+      const int x = idx / wc4, c4 = idx - x * wc4;
+      const float4 v = *reinterpret_cast<const float4*>(&slab[x * NW + c4 * 4]);
+      *reinterpret_cast<float4*>(row + (size_t)x * Cout + c4 * 4) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // output tile = 4 (z, one per wave) x MT (y, m-tiles per wave) x 16 (x, MFMA rows); MT = 4 for the large levels,
 // MT = 2 doubles the number of workgroups for the small (deep) levels.  KSPLIT: the input-channel chunks are
 // split over gridDim.z workgroups that accumulate into a zero-initialised output with float atomics; bias and
@@ -81,6 +121,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
   constexpr int CKP = CK + 4;
   constexpr int NCG = CK / 8;
   constexpr int C4 = CK / 4;
+  const int dbg = act >> 8;  // diagnostic mask (synthsr_conv3d_set_option 1): 1 no B loads, 2 no A reads, 4 no staging, 8 no stores
+  act &= 0xff;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware tile order: workgroup b runs on XCD b%8 (observed dispatch order, speed only); give every XCD a
   // contiguous range of tiles so that neighbouring tiles (shared halos) hit the same L2.  Bijective for any grid.
@@ -120,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
     // ---- stage the halo tile of this channel chunk (zero padding outside the volume / channel range).
     // Branch-free: out-of-range elements load from a clamped (valid) address and are zeroed by a select, so all
     // global loads are issued back to back before the first LDS store and their latencies overlap.
-    {
+    if (!(dbg & 4)) {
       constexpr int NIT = (FHV * C4 + 255) / 256;
       constexpr int SB = (NT >= 5 && CK == 24) ? (NIT + 1) / 2 : NIT;  // batch size (register budget)
 #pragma unroll
@@ -173,12 +215,183 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
     for (int m = 0; m < MT; ++m) acur[m] = *reinterpret_cast<const float2*>(&lds[a_base[m]]);
 
     for (int tap = 0; tap < 27; ++tap) {
+      if (tap + 1 < 27 && !(dbg & 1)) {
+        const float* wn = wc + (size_t)(tap + 1) * NCG * NT * 128;
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bnext[g][n] = *reinterpret_cast<const float2*>(wn + (g * NT + n) * 128);
+      }
+      const int tn = tap + 1 < 27 ? tap + 1 : 26;
+      const int toff = (((tap / 9) * FH1 + (tap / 3) % 3) * FH2 + tap % 3) * CKP;
+      const int toff_n = (((tn / 9) * FH1 + (tn / 3) % 3) * FH2 + tn % 3) * CKP;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        const int noff = (g + 1 < NCG) ? toff + (g + 1) * 8 : toff_n;
+        if (!(dbg & 2))
+#pragma unroll
+          for (int m = 0; m < MT; ++m) anext[m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + noff]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m].x, bcur[g][n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m].y, bcur[g][n].y, acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acur[m] = anext[m];
+      }
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bcur[g][n] = bnext[g][n];
+    }
+  }
+
+  // ---- epilogue
+  const int gz = z0 + wave;
+  if (gz < D0 && !(dbg & 8)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int gy = y0 + m;
+      if (gy >= D1) continue;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int co = (nc * NT + n) * 16 + li;
+        if (co >= Cout) continue;
+        const float bv = (!KSPLIT && bias) ? bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gx = x0 + kq * 4 + r;
+          if (gx < D2) {
+            float* dst = out + (((size_t)gz * D1 + gy) * D2 + gx) * Cout + co;
+            if constexpr (KSPLIT) {
+              atomicAdd(dst, acc[m][n][r]);
+            } else {
+              float v = acc[m][n][r] + bv;
+              if (act == 1) v = v > 0.f ? v : expm1f(v);
+              *dst = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- persistent variant for the large levels (CK = 24, 4x4x16 tiles) ----------------------------------------
+// gridDim.x workgroups (2 per CU) walk the (tile, channel-chunk) items round-robin.  While the 27 taps of item i
+// run on the matrix cores, the halo tile of item i+1 is fetched into registers: one 16-byte global load per tap,
+// interleaved with the B-fragment loads, so its HBM latency hides behind ~2 taps (~100 MFMAs) of compute.
+// Only the LDS store phase (2 barriers) separates two items; the output stores of an item overlap the next one.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float* __restrict__ in,
+                                                                    const float* __restrict__ wp,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ out, int D0, int D1, int D2,
+                                                                    int Cin, int Cout, int ncc, int tiles1, int tiles2,
+                                                                    int ntiles, int act) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CK = 24, MT = 4;
+  constexpr int FT1 = MT, FH1 = MT + 2, FHV = FH0 * FH1 * FH2;
+  constexpr int CKP = CK + 4, NCG = CK / 8, C4 = CK / 4;
+  constexpr int NIT = (FHV * C4 + 255) / 256;  // 16 halo float4 per thread
+  static_assert(NIT <= 27, "one halo load per tap");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int nc = blockIdx.y;
+  const int nitems = ntiles * ncc;
+  // XCD-aware order: in every round of gridDim.x items, workgroup b (XCD b%8) takes position (b%8)*(G/8) + b/8,
+  // so each XCD's L2 serves a contiguous run of neighbouring tiles.  gridDim.x is a multiple of 8.
+  const int G = gridDim.x;
+  const int my_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+
+  int a_base[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a_base[m] = ((wave * FH1 + m) * FH2 + li) * CKP + 2 * kq;
+  const float* wl = wp + (size_t)nc * ncc * 27 * NCG * NT * 128 + lane * 2;
+
+  // halo slot k of this thread: element f = tid + 256 k of the [FHV][C4] tile (recomputed, not kept in registers)
+  auto halo_load = [&](int k, int z0, int y0, int x0, int cc) -> float4 {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));  // opaque: keeps the slot arithmetic inside the loop instead of 16 x 4 hoisted registers
+    const int f = tv + k * 256;
+    const int vox = f / C4, c4 = f - vox * C4;
+    const int hx = vox % FH2, hy = (vox / FH2) % FH1, hz = vox / (FH2 * FH1);
+    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool ok = (f < FHV * C4) & (gz >= 0) & (gz < D0) & (gy >= 0) & (gy < D1) & (gx >= 0) & (gx < D2);
+    const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cin + cc * CK + c4 * 4) : 0;
+    float4 v = ld4(in + off);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+  };
+  auto decode = [&](int item, int& z0, int& y0, int& x0, int& cc) {
+    const int t = item / ncc;
+    cc = item - t * ncc;
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    z0 = t0 * FT0;
+    y0 = t1 * FT1;
+    x0 = t2 * FT2;
+  };
+
+  f32x4 acc[MT][NT];
+  float4 stg[NIT];
+  int item = my_pos;
+  if (item >= nitems) return;
+  int z0, y0, x0, cc;
+  decode(item, z0, y0, x0, cc);
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) stg[k] = halo_load(k, z0, y0, x0, cc);
+
+  while (true) {
+    const int nitem = item + G;
+    const bool has_next = nitem < nitems;
+    int nz0 = 0, ny0 = 0, nx0 = 0, ncc_ = 0;
+    if (has_next) decode(nitem, nz0, ny0, nx0, ncc_);
+    if (cc == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();  // every wave has finished reading the previous item's tile
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      int tv = tid;
+      asm volatile("" : "+v"(tv));
+      const int f = tv + k * 256;
+      const int vox = f / C4, c4 = f - vox * C4;
+      if (f < FHV * C4) *reinterpret_cast<float4*>(&lds[vox * CKP + c4 * 4]) = stg[k];
+    }
+    __syncthreads();
+
+    const float* wc = wl + (size_t)cc * 27 * NCG * NT * 128;
+    float2 bcur[NCG][NT], bnext[NCG][NT];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bcur[g][n] = *reinterpret_cast<const float2*>(wc + (g * NT + n) * 128);
+    float2 acur[MT], anext[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acur[m] = *reinterpret_cast<const float2*>(&lds[a_base[m]]);
+
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
       if (tap + 1 < 27) {
         const float* wn = wc + (size_t)(tap + 1) * NCG * NT * 128;
 #pragma unroll
         for (int g = 0; g < NCG; ++g)
 #pragma unroll
           for (int n = 0; n < NT; ++n) bnext[g][n] = *reinterpret_cast<const float2*>(wn + (g * NT + n) * 128);
+      }
+      if (tap < NIT) {
+        if (has_next) stg[tap] = halo_load(tap, nz0, ny0, nx0, ncc_);  // wave-uniform branch
       }
       const int tn = tap + 1 < 27 ? tap + 1 : 26;
       const int toff = (((tap / 9) * FH1 + (tap / 3) % 3) * FH2 + tap % 3) * CKP;
@@ -209,36 +422,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
 #pragma unroll
         for (int n = 0; n < NT; ++n) bcur[g][n] = bnext[g][n];
     }
-  }
 
-  // ---- epilogue: D row = (lane>>4)*4 + reg -> x within the 16-voxel row, col = lane&15 -> output channel
-  const int gz = z0 + wave;
-  if (gz < D0) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int gy = y0 + m;
-      if (gy >= D1) continue;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int co = (nc * NT + n) * 16 + li;
-        if (co >= Cout) continue;
-        const float bv = (!KSPLIT && bias) ? bias[co] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gx = x0 + kq * 4 + r;
-          if (gx < D2) {
-            float* dst = out + (((size_t)gz * D1 + gy) * D2 + gx) * Cout + co;
-            if constexpr (KSPLIT) {
-              atomicAdd(dst, acc[m][n][r]);
-            } else {
-              float v = acc[m][n][r] + bv;
-              if (act == 1) v = v > 0.f ? v : expm1f(v);
-              *dst = v;
-            }
-          }
-        }
-      }
+    if (cc == ncc - 1) {  // epilogue of this tile (Cout % 4 == 0 is guaranteed by the launcher)
+      __syncthreads();
+      const int gz = z0 + wave;
+      if (gz < D0)
+        store_tile_rows<NT, MT>(acc, lds + wave * (16 * NT * 16), out, bias, act, nc, gz, y0, x0, D1, D2, Cout, lane);
     }
+    if (!has_next) break;
+    item = nitem;
+    z0 = nz0;
+    y0 = ny0;
+    x0 = nx0;
+    cc = ncc_;
   }
 }
 
@@ -300,93 +496,114 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
   const int b_base = li * WVPD + kq;
 
   const int ntiles = tiles0 * tiles1 * tiles2;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  constexpr int NX = (WHV * C4 + 255) / 256;
+  constexpr int ND = (WTV * NT * 4 + 255) / 256;
+  // Global loads of one tile (x halo + dy), branch-free (clamped address + select).  The slot arithmetic goes
+  // through an opaque copy of tid so that hipcc recomputes it per call instead of hoisting 14 x 4 registers.
+  auto load_x = [&](int k, int z0, int y0, int x0) -> float4 {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    const int f = tv + k * 256;
+    const int vox = f / C4, c4 = f - vox * C4;
+    const int hx = vox % WH2, hy = (vox / WH2) % WH1, hz = vox / (WH2 * WH1);
+    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const int c = cc * CK + c4 * 4;
+    const bool ok = (f < WHV * C4) & (gz >= 0) & (gz < D0) & (gy >= 0) & (gy < D1) & (gx >= 0) & (gx < D2);
+    const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cin + c) : 0;
+    float4 v;
+    if constexpr (CK == 24) {
+      v = ld4(in + off);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const float* src = in + off;
+      v.x = (ok && c + 0 < Cin) ? src[0] : 0.f;
+      v.y = (ok && c + 1 < Cin) ? src[(c + 1 < Cin) ? 1 : 0] : 0.f;
+      v.z = (ok && c + 2 < Cin) ? src[(c + 2 < Cin) ? 2 : 0] : 0.f;
+      v.w = (ok && c + 3 < Cin) ? src[(c + 3 < Cin) ? 3 : 0] : 0.f;
+    }
+    return v;
+  };
+  auto load_d = [&](int k, int z0, int y0, int x0) -> float4 {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    const int f = tv + k * 256;
+    const int vox = f / (NT * 4), c4 = f - vox * (NT * 4);
+    const int vx = vox % WT2, vy = (vox / WT2) % WT1, vz = vox / (WT2 * WT1);
+    const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+    const int c = co0 + c4 * 4;
+    const bool ok = (f < WTV * NT * 4) & (gz < D0) & (gy < D1) & (gx < D2);
+    const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cout + c) : 0;
+    float4 v;
+    if (vec_out) {
+      const bool okc = ok && c < Cout;
+      v = ld4(dout + (okc ? off : 0));
+      if (!okc) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const float* src = dout + off;
+      v.x = (ok && c + 0 < Cout) ? src[0] : 0.f;
+      v.y = (ok && c + 1 < Cout) ? src[(c + 1 < Cout) ? 1 : 0] : 0.f;
+      v.z = (ok && c + 2 < Cout) ? src[(c + 2 < Cout) ? 2 : 0] : 0.f;
+      v.w = (ok && c + 3 < Cout) ? src[(c + 3 < Cout) ? 3 : 0] : 0.f;
+    }
+    return v;
+  };
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
     const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
-    const int z0 = t0 * WT0, y0 = t1 * WT1, x0 = t2 * WT2;
-    __syncthreads();
-    // ---- stage x halo tile ([ci][voxel]) and dy tile ([co][voxel]).  Branch-free (clamped address + select):
-    // the global loads of a batch are issued back to back ahead of their LDS stores.
-    {
-      constexpr int NX = (WHV * C4 + 255) / 256;
-      constexpr int ND = (WTV * NT * 4 + 255) / 256;
-      constexpr int XB = NX;  // x-tile batch
+    z0 = t0 * WT0;
+    y0 = t1 * WT1;
+    x0 = t2 * WT2;
+  };
+  float4 sx[NX], sd[ND];
+  if ((int)blockIdx.x < ntiles) {
+    int z0, y0, x0;
+    tile_origin(blockIdx.x, z0, y0, x0);
 #pragma unroll
-      for (int k0 = 0; k0 < NX; k0 += XB) {
-        float4 sx[XB];
+    for (int k = 0; k < NX; ++k) sx[k] = load_x(k, z0, y0, x0);
 #pragma unroll
-        for (int kk = 0; kk < XB; ++kk) {
-          const int f = tid + (k0 + kk) * 256;
-          const int vox = f / C4, c4 = f - vox * C4;
-          const int hx = vox % WH2, hy = (vox / WH2) % WH1, hz = vox / (WH2 * WH1);
-          const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-          const int c = cc * CK + c4 * 4;
-          const bool ok = (k0 + kk < NX) & (f < WHV * C4) & (gz >= 0) & (gz < D0) & (gy >= 0) & (gy < D1) & (gx >= 0) &
-                          (gx < D2);
-          const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cin + c) : 0;
-          float4 v;
-          if constexpr (CK == 24) {
-            v = ld4(in + off);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-          } else {
-            const float* src = in + off;
-            v.x = (ok && c + 0 < Cin) ? src[0] : 0.f;
-            v.y = (ok && c + 1 < Cin) ? src[(c + 1 < Cin) ? 1 : 0] : 0.f;
-            v.z = (ok && c + 2 < Cin) ? src[(c + 2 < Cin) ? 2 : 0] : 0.f;
-            v.w = (ok && c + 3 < Cin) ? src[(c + 3 < Cin) ? 3 : 0] : 0.f;
-          }
-          sx[kk] = v;
-        }
+    for (int k = 0; k < ND; ++k) sd[k] = load_d(k, z0, y0, x0);
+  }
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();  // previous tile fully consumed
+    // ---- registers -> LDS, transposed: x [ci][voxel], dy [co][voxel]
 #pragma unroll
-        for (int kk = 0; kk < XB; ++kk) {
-          const int f = tid + (k0 + kk) * 256;
-          const int vox = f / C4, c4 = f - vox * C4;
-          if (k0 + kk < NX && f < WHV * C4) {
-            float* d = lx + (c4 * 4) * WVPX + vox;
-            d[0] = sx[kk].x;
-            d[WVPX] = sx[kk].y;
-            d[2 * WVPX] = sx[kk].z;
-            d[3 * WVPX] = sx[kk].w;
-          }
-        }
+    for (int k = 0; k < NX; ++k) {
+      int tv = tid;
+      asm volatile("" : "+v"(tv));
+      const int f = tv + k * 256;
+      const int vox = f / C4, c4 = f - vox * C4;
+      if (f < WHV * C4) {
+        float* d = lx + (c4 * 4) * WVPX + vox;
+        d[0] = sx[k].x;
+        d[WVPX] = sx[k].y;
+        d[2 * WVPX] = sx[k].z;
+        d[3 * WVPX] = sx[k].w;
       }
-      float4 sd[ND];
+    }
 #pragma unroll
-      for (int k = 0; k < ND; ++k) {
-        const int f = tid + k * 256;
-        const int vox = f / (NT * 4), c4 = f - vox * (NT * 4);
-        const int vx = vox % WT2, vy = (vox / WT2) % WT1, vz = vox / (WT2 * WT1);
-        const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
-        const int c = co0 + c4 * 4;
-        const bool ok = (f < WTV * NT * 4) & (gz < D0) & (gy < D1) & (gx < D2);
-        const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cout + c) : 0;
-        float4 v;
-        if (vec_out) {
-          const bool okc = ok && c < Cout;
-          v = ld4(dout + (okc ? off : 0));
-          if (!okc) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-          const float* src = dout + off;
-          v.x = (ok && c + 0 < Cout) ? src[0] : 0.f;
-          v.y = (ok && c + 1 < Cout) ? src[(c + 1 < Cout) ? 1 : 0] : 0.f;
-          v.z = (ok && c + 2 < Cout) ? src[(c + 2 < Cout) ? 2 : 0] : 0.f;
-          v.w = (ok && c + 3 < Cout) ? src[(c + 3 < Cout) ? 3 : 0] : 0.f;
-        }
-        sd[k] = v;
-      }
-#pragma unroll
-      for (int k = 0; k < ND; ++k) {
-        const int f = tid + k * 256;
-        const int vox = f / (NT * 4), c4 = f - vox * (NT * 4);
-        if (f < WTV * NT * 4) {
-          float* d = ld + (c4 * 4) * WVPD + vox;
-          d[0] = sd[k].x;
-          d[WVPD] = sd[k].y;
-          d[2 * WVPD] = sd[k].z;
-          d[3 * WVPD] = sd[k].w;
-        }
+    for (int k = 0; k < ND; ++k) {
+      int tv = tid;
+      asm volatile("" : "+v"(tv));
+      const int f = tv + k * 256;
+      const int vox = f / (NT * 4), c4 = f - vox * (NT * 4);
+      if (f < WTV * NT * 4) {
+        float* d = ld + (c4 * 4) * WVPD + vox;
+        d[0] = sd[k].x;
+        d[WVPD] = sd[k].y;
+        d[2 * WVPD] = sd[k].z;
+        d[3 * WVPD] = sd[k].w;
       }
     }
     __syncthreads();
+    // ---- prefetch the next tile of this workgroup into the (now free) staging registers; the loads complete
+    // while the 32 k-steps below keep the matrix cores busy
+    if (t + (int)gridDim.x < ntiles) {
+      int z0, y0, x0;
+      tile_origin(t + gridDim.x, z0, y0, x0);
+#pragma unroll
+      for (int k = 0; k < NX; ++k) sx[k] = load_x(k, z0, y0, x0);
+#pragma unroll
+      for (int k = 0; k < ND; ++k) sd[k] = load_d(k, z0, y0, x0);
+    }
     // ---- 32 k-steps of 4 voxels; the LDS reads of step ks+1 are issued before the MFMAs of step ks
     {
       float acur[MTW], anext[MTW], bcur[NT], bnext[NT];
@@ -440,8 +657,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
   }
 }
 
+static int g_persist = 1;
+static int g_force_mt = 0;
+static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
+
 struct FwdPlan {
-  int nt, mt, ksplit, nchunks, ncc, ck;
+  int nt, mt, ksplit, nchunks, ncc, ck, persist;
 };
 
 // Launch geometry for one layer: enough workgroups to fill 256 CUs x 2 even on the deep, small levels.
@@ -453,13 +674,14 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout) {
   auto wgs = [&](int mt, int nt) { return (int64_t)cdiv(s[0], FT0) * cdiv(s[1], mt) * cdiv(s[2], FT2) * cdiv(ntiles, nt); };
   p.mt = 4;
   int max_nt = MAX_NT;
-  if (wgs(4, std::min(MAX_NT, ntiles)) < 768) {
+  if (wgs(4, std::min(MAX_NT, ntiles)) < 768 || (g_force_mt == 2 && ntiles <= 3)) {
     p.mt = 2;
     max_nt = 3;
   }
   p.nchunks = cdiv(ntiles, max_nt);
   p.nt = cdiv(ntiles, p.nchunks);
   p.ksplit = 1;
+  p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist) ? 1 : 0;
   const int64_t w = wgs(p.mt, p.nt);
   if (w < 512 && p.ncc >= 4) {
     int ks = (int)cdiv(1024, (int)w);
@@ -486,7 +708,7 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
     if (hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(tiles0 * tiles1 * tiles2, pl.nchunks, KS ? pl.ksplit : 1), dim3(256), smem, st, in, wp,
-                     bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act);
+                     bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act | (g_dbg << 8));
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   if (KS && (bias != nullptr || act != 0)) {
     hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act);
@@ -495,10 +717,36 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
   return SYNTHSR_OK;
 }
 
+template <int NT>
+int launch_fwd_persist(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
+                       const FwdPlan& pl, int act, hipStream_t st) {
+  const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
+  const int ntiles = tiles0 * tiles1 * tiles2;
+  const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
+  static bool attr_done = false;
+  auto kern = conv3d_fwd_persist_kernel<NT>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  int gx = 512 / pl.nchunks;  // 2 workgroups per CU in total
+  gx = std::max(8, (gx / 8) * 8);
+  const int64_t nitems = (int64_t)ntiles * pl.ncc;
+  while (gx > 8 && gx > nitems) gx -= 8;
+  hipLaunchKernelGGL(kern, dim3(gx, pl.nchunks), dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, Cout,
+                     pl.ncc, tiles1, tiles2, ntiles, act);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
 template <int CK, int NT>
 int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
                   const FwdPlan& pl, int act, hipStream_t st) {
-  if (pl.mt == 4) return launch_fwd<CK, NT, 4, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+  if (pl.mt == 4) {
+    if constexpr (CK == 24 && NT <= 3) {
+      if (pl.persist) return launch_fwd_persist<NT>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    }
+    return launch_fwd<CK, NT, 4, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+  }
   if constexpr (NT <= 3) {
     if (pl.ksplit > 1) return launch_fwd<CK, NT, 2, true>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
     return launch_fwd<CK, NT, 2, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
@@ -567,6 +815,22 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream);
   return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream);
+}
+
+int synthsr_conv3d_set_option(int option, int value) {
+  if (option == 0) {
+    g_persist = value ? 1 : 0;
+    return SYNTHSR_OK;
+  }
+  if (option == 1) {
+    g_dbg = value & 0xff;
+    return SYNTHSR_OK;
+  }
+  if (option == 2) {
+    g_force_mt = value;
+    return SYNTHSR_OK;
+  }
+  return SYNTHSR_EINVAL;
 }
 
 int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout,
