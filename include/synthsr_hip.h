@@ -130,6 +130,30 @@ int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], i
 int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
                        int Cin, int Cout, int act, synthsr_stream_t stream);
 
+/* --- nearest-upsample folding (decoder conv on concatenate([skip, UpSampling3D(2)(lo)]), models.py:426-444) ------
+ * A 3x3x3 conv over an up-sampled tensor equals 8 parity-wise 2x2x2 convs over the low-res tensor with summed taps
+ * (3.4x fewer FLOPs, same result up to float32 re-association).  The layer is evaluated as
+ *   out = act( conv3(skip; W[:, :Cs]) + upconv(lo; W[:, Cs:]) + bias ).
+ * `w` is the layer's Keras kernel [3][3][3][Cin_total][Cout]; (ci_off, Cin) selects the input-channel range. */
+int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3], int Cin_total, int ci_off, int Cin,
+                               int Cout, int mode, int up /* 0 plain, 1: 8 parity weight sets, shape = lo shape */,
+                               synthsr_stream_t stream);
+/* out[2*lo_shape, Cout] = act(upconv(lo [lo_shape, Cl]) + addend + bias); wpacked8 from pack_ex(..., mode 0, up 1) */
+int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* bias, const float* addend, float* out,
+                          const int lo_shape[3], int Cl, int Cout, int act, synthsr_stream_t stream);
+/* dlo[lo_shape, Cl] = adjoint of upconv applied to dout [2*lo_shape, Cout]; wpacked8 from pack_ex(..., mode 1, up 1) */
+int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo, const int lo_shape[3], int Cl, int Cout,
+                            synthsr_stream_t stream);
+/* per-parity weight gradients dwc[8][27][Cl][Cout] (zeroed by the caller) ... */
+int synthsr_conv3d_up_wgrad(const float* lo, const float* dout, float* dwc, const int lo_shape[3], int Cl, int Cout,
+                            synthsr_stream_t stream);
+/* ... folded back onto the original taps: dw[27][Cin_total][Cout] (+=) at channels [ci_off, ci_off+Cl) */
+int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_off, int Cl, int Cout,
+                             synthsr_stream_t stream);
+/* weight gradient of a layer part: in has Cin channels, dw rows are Cin_total wide, written at ci_off */
+int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
+                            int Cin, int Cout, synthsr_stream_t stream);
+
 /* tuning / A-B switch, process-wide: option 0 = use the persistent forward kernel on the large levels (default 1) */
 int synthsr_conv3d_set_option(int option, int value);
 

@@ -30,8 +30,22 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // -------------------------------------------------------------------------------------------- pack
 // packed[nc][cc][tap][cg][nt][lane][2]; lane=(kq=lane>>4, j=lane&15):
 //   W_eff[tap][cc*CK + cg*8 + 2*kq + s][(nc*NT + nt)*16 + j]
-__global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin, int Cout, int mode, int CK,
-                            int ncc, int NT, int nchunks, int64_t total) {
+// taps of the original 3-tap axis that fold onto low-res slot s under output parity p (see ConvExt)
+__device__ __forceinline__ int up_axis_taps(int p, int s, int t[2]) {
+  if (p == 0) {
+    if (s == 0) { t[0] = 0; return 1; }
+    if (s == 1) { t[0] = 1; t[1] = 2; return 2; }
+    return 0;
+  }
+  if (s == 1) { t[0] = 0; t[1] = 1; return 2; }
+  if (s == 2) { t[0] = 2; return 1; }
+  return 0;
+}
+
+// w: Keras kernel [27][Cin_total][Cout]; the layer (or layer part) uses input channels [ci_off, ci_off+Cin).
+// parity < 0: plain weights.  parity 0..7: combined weights of the nearest-upsample folding in 27-slot form.
+__global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin_total, int ci_off, int Cin,
+                            int Cout, int mode, int CK, int ncc, int NT, int nchunks, int parity, int64_t total) {
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
   const int NCG = CK / 8;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
@@ -50,20 +64,51 @@ __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ pac
     const int cc = (int)(r % ncc);
     const int nc = (int)(r / ncc);
     const int kq = lane >> 4, j = lane & 15;
-    const int ci = cc * CK + cg * 8 + 2 * kq + s;
-    const int co = (nc * NT + nt) * 16 + j;
+    const int cie = cc * CK + cg * 8 + 2 * kq + s;
+    const int coe = (nc * NT + nt) * 16 + j;
     float v = 0.f;
-    if (ci < CinE && co < CoutE) {
-      if (mode == 0)
-        v = w[((int64_t)tap * Cin + ci) * Cout + co];
-      else
-        v = w[((int64_t)(26 - tap) * Cin + co) * Cout + ci];
+    if (cie < CinE && coe < CoutE) {
+      const int slot = mode ? 26 - tap : tap;              // tap slot in forward orientation
+      const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;  // layer channel indices
+      if (parity < 0) {
+        v = w[((int64_t)slot * Cin_total + ci) * Cout + co];
+      } else {
+        int tz[2], ty[2], tx[2];
+        const int nz = up_axis_taps((parity >> 2) & 1, slot / 9, tz);
+        const int ny = up_axis_taps((parity >> 1) & 1, (slot / 3) % 3, ty);
+        const int nx = up_axis_taps(parity & 1, slot % 3, tx);
+        for (int a = 0; a < nz; ++a)
+          for (int b = 0; b < ny; ++b)
+            for (int c = 0; c < nx; ++c)
+              v += w[((int64_t)((tz[a] * 3 + ty[b]) * 3 + tx[c]) * Cin_total + ci) * Cout + co];
+      }
     }
     packed[idx] = v;
   }
 }
 
-// -------------------------------------------------------------------------------------------- forward
+// dW of the up-sampled input channels from the 8 per-parity 27-slot gradients: every original tap t belongs to exactly
+// one slot per parity.  dw[27][Cin_total][Cout] (+= at channels [ci_off, ci_off+Cl)), dwc[8][27][Cl][Cout].
+__global__ void up_unpack_kernel(const float* __restrict__ dwc, float* __restrict__ dw, int Cin_total, int ci_off, int Cl,
+                                 int Cout, int64_t total) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % Cout);
+    const int ci = (int)((idx / Cout) % Cl);
+    const int t = (int)(idx / ((int64_t)Cout * Cl));
+    const int tz = t / 9, ty = (t / 3) % 3, tx = t % 3;
+    float acc = 0.f;
+    for (int p = 0; p < 8; ++p) {
+      const int pz = (p >> 2) & 1, py = (p >> 1) & 1, px = p & 1;
+      const int sz = pz ? (tz == 2 ? 2 : 1) : (tz == 0 ? 0 : 1);
+      const int sy = py ? (ty == 2 ? 2 : 1) : (ty == 0 ? 0 : 1);
+      const int sx = px ? (tx == 2 ? 2 : 1) : (tx == 0 ? 0 : 1);
+      acc += dwc[(((int64_t)p * 27 + (sz * 3 + sy) * 3 + sx) * Cl + ci) * Cout + co];
+    }
+    dw[((int64_t)t * Cin_total + ci_off + ci) * Cout + co] += acc;
+  }
+}
+
 // Epilogue of one wave: D fragments (row = (lane>>4)*4 + reg -> x, col = lane&15 -> channel) are transposed through a
 // wave-private LDS slab so that each global store instruction writes 64 x 16 B of CONSECUTIVE addresses (a (z,y)
 // row of 16 voxels x Cout channels is contiguous in NDHWC); direct fragment stores would emit 64-byte pieces.
@@ -111,11 +156,38 @@ __device__ __forceinline__ void store_tile_rows(f32x4 (&acc)[MT][NT], float* sla
 constexpr int FT0 = 4, FT2 = 16;
 constexpr int FH0 = 6, FH2 = 18;
 
+// Nearest-upsample folding.  A 3x3x3 conv applied to UpSampling3D(2)(x) equals, for each output parity
+// p = (pz,py,px), a 2x2x2 conv on x itself whose weights are sums of the original taps that read the same low-res
+// voxel: per axis  p=0: slots {0 <- tap 0, 1 <- taps 1+2},  p=1: slots {1 <- taps 0+1, 2 <- tap 2}  (slot s reads
+// low-res offset s-1).  3.4x fewer FLOPs on the up-sampled 2/3 of every decoder conv.  The parity convs run through
+// the same kernels with a tap mask and strided input/output views.
+struct ConvExt {
+  int mode;            // 0 plain; 1 up-forward (parity = blockIdx.z, strided OUTPUT); 2 up-data-gradient (loop over
+                       // the 8 parities, strided INPUT, one accumulated output)
+  const float* addend; // mode 1: added before bias/activation, indexed like the output
+  int64_t wstride;     // packed-weight stride between parities
+};
+
+__host__ __device__ inline uint32_t up_tapmask(int p, bool flipped) {
+  uint32_t m = 0;
+  for (int sz = 0; sz < 3; ++sz)
+    for (int sy = 0; sy < 3; ++sy)
+      for (int sx = 0; sx < 3; ++sx) {
+        const int pz = (p >> 2) & 1, py = (p >> 1) & 1, px = p & 1;
+        const bool ok = (pz ? sz >= 1 : sz <= 1) && (py ? sy >= 1 : sy <= 1) && (px ? sx >= 1 : sx <= 1);
+        if (ok) {
+          const int t = flipped ? (((2 - sz) * 3 + (2 - sy)) * 3 + (2 - sx)) : ((sz * 3 + sy) * 3 + sx);
+          m |= 1u << t;
+        }
+      }
+  return m;
+}
+
 template <int CK, int NT, int MT, bool KSPLIT>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int D0, int D1, int D2, int Cin, int Cout, int ncc,
-                                                            int tiles1, int tiles2, int act) {
+                                                            int tiles1, int tiles2, int act, ConvExt ext) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [FHV][CKP]
   constexpr int FT1 = MT, FH1 = MT + 2, FHV = FH0 * FH1 * FH2;
   constexpr int CKP = CK + 4;
@@ -151,13 +223,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
   for (int m = 0; m < MT; ++m) a_base[m] = ((wave * FH1 + m) * FH2 + li) * CKP + 2 * kq;
 
   const float* wl = wp + (size_t)nc * ncc * 27 * NCG * NT * 128 + lane * 2;
-  const bool vec_ok = (Cin % 4) == 0;
 
   // chunk range of this workgroup (all chunks unless KSPLIT)
   const int cpz = KSPLIT ? (ncc + (int)gridDim.z - 1) / (int)gridDim.z : ncc;
   const int cc_lo = KSPLIT ? (int)blockIdx.z * cpz : 0;
   const int cc_hi = min(ncc, cc_lo + cpz);
-  for (int cc = cc_lo; cc < cc_hi; ++cc) {
+  const int npar = (ext.mode == 2) ? 8 : 1;          // parities accumulated inside this workgroup
+  const int opar = (ext.mode == 1) ? (int)blockIdx.z : 0;  // output parity of this workgroup
+  for (int it = 0; it < npar * (cc_hi - cc_lo); ++it) {
+    const int ipar = it / (cc_hi - cc_lo);
+    const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
+    const int par = (ext.mode == 1) ? opar : ipar;
+    const uint32_t tapmask = ext.mode == 0 ? 0x7FFFFFFu : up_tapmask(par, ext.mode == 2);
+    // input view: conv-grid voxel g -> tensor voxel g*is + io (mode 2 reads one parity sub-lattice of a 2x tensor)
+    const int is = (ext.mode == 2) ? 2 : 1;
+    const int io0 = (ext.mode == 2) ? (par >> 2) & 1 : 0, io1 = (ext.mode == 2) ? (par >> 1) & 1 : 0,
+              io2 = (ext.mode == 2) ? par & 1 : 0;
     __syncthreads();
     // ---- stage the halo tile of this channel chunk (zero padding outside the volume / channel range).
     // Branch-free: out-of-range elements load from a clamped (valid) address and are zeroed by a select, so all
@@ -177,7 +258,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
           const int c = cc * CK + c4 * 4;
           const bool ok = (k0 + kk < NIT) & (f < FHV * C4) & (gz >= 0) & (gz < D0) & (gy >= 0) & (gy < D1) & (gx >= 0) &
                           (gx < D2);
-          const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cin + c) : 0;
+          const size_t off =
+              ok ? ((((size_t)(gz * is + io0) * (D1 * is) + (gy * is + io1)) * (D2 * is) + (gx * is + io2)) * Cin + c) : 0;
           float4 v;
           if constexpr (CK == 24) {  // Cin % 24 == 0: aligned float4, channel range always valid
             v = ld4(in + off);
@@ -201,30 +283,36 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
     }
     __syncthreads();
 
-    const float* wc = wl + (size_t)cc * 27 * NCG * NT * 128;
+    const float* wc = wl + (size_t)cc * 27 * NCG * NT * 128 + (size_t)par * ext.wstride;
     // Software pipeline, pinned with sched_barrier so that hipcc cannot sink the prefetches next to their uses:
-    //   B fragments of tap t+1 are requested at the top of tap t (one L2 round trip hidden behind 16*NCG*NT MFMAs),
-    //   A fragments of step (t,g)+1 are read from LDS before the MFMAs of step (t,g).
+    //   B fragments of the next active tap are requested at the top of a tap (one L2 round trip hidden behind
+    //   16*NCG*NT MFMAs), A fragments of step (t,g)+1 are read from LDS before the MFMAs of step (t,g).
+    int tap = __builtin_ctz(tapmask);
+    auto tap_off = [](int t) { return (((t / 9) * FH1 + (t / 3) % 3) * FH2 + t % 3) * CKP; };
     float2 bcur[NCG][NT], bnext[NCG][NT];
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bcur[g][n] = *reinterpret_cast<const float2*>(wc + (g * NT + n) * 128);
+      for (int n = 0; n < NT; ++n)
+        bcur[g][n] = *reinterpret_cast<const float2*>(wc + (size_t)tap * NCG * NT * 128 + (g * NT + n) * 128);
     float2 acur[MT], anext[MT];
+    {
+      const int o = tap_off(tap);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acur[m] = *reinterpret_cast<const float2*>(&lds[a_base[m]]);
-
-    for (int tap = 0; tap < 27; ++tap) {
-      if (tap + 1 < 27 && !(dbg & 1)) {
-        const float* wn = wc + (size_t)(tap + 1) * NCG * NT * 128;
+      for (int m = 0; m < MT; ++m) acur[m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + o]);
+    }
+    while (tap < 27) {
+      const uint32_t rem = (tap + 1 < 27) ? (tapmask >> (tap + 1)) : 0u;
+      const int tn = rem ? tap + 1 + __builtin_ctz(rem) : 27;
+      if (tn < 27 && !(dbg & 1)) {
+        const float* wn = wc + (size_t)tn * NCG * NT * 128;
 #pragma unroll
         for (int g = 0; g < NCG; ++g)
 #pragma unroll
           for (int n = 0; n < NT; ++n) bnext[g][n] = *reinterpret_cast<const float2*>(wn + (g * NT + n) * 128);
       }
-      const int tn = tap + 1 < 27 ? tap + 1 : 26;
-      const int toff = (((tap / 9) * FH1 + (tap / 3) % 3) * FH2 + tap % 3) * CKP;
-      const int toff_n = (((tn / 9) * FH1 + (tn / 3) % 3) * FH2 + tn % 3) * CKP;
+      const int toff = tap_off(tap);
+      const int toff_n = tap_off(tn < 27 ? tn : tap);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
@@ -251,6 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
       for (int g = 0; g < NCG; ++g)
 #pragma unroll
         for (int n = 0; n < NT; ++n) bcur[g][n] = bnext[g][n];
+      tap = tn;
     }
   }
 
@@ -270,13 +359,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
         for (int r = 0; r < 4; ++r) {
           const int gx = x0 + kq * 4 + r;
           if (gx < D2) {
-            float* dst = out + (((size_t)gz * D1 + gy) * D2 + gx) * Cout + co;
+            const int os = (ext.mode == 1) ? 2 : 1;
+            const size_t oidx = (((size_t)(gz * os + ((opar >> 2) & 1)) * (D1 * os) + (gy * os + ((opar >> 1) & 1))) *
+                                     (D2 * os) + (gx * os + (opar & 1))) * Cout + co;
             if constexpr (KSPLIT) {
-              atomicAdd(dst, acc[m][n][r]);
+              atomicAdd(out + oidx, acc[m][n][r]);
             } else {
               float v = acc[m][n][r] + bv;
+              if (ext.addend) v += ext.addend[oidx];
               if (act == 1) v = v > 0.f ? v : expm1f(v);
-              *dst = v;
+              out[oidx] = v;
             }
           }
         }
@@ -456,23 +548,42 @@ constexpr int WVPX = 434;                   // 434/2 = 217 odd -> rows of [ci][v
 constexpr int WTV = WT0 * WT1 * WT2;        // 128
 constexpr int WVPD = 130;                   // 65 odd
 
-template <int CK, int NT, int MS>
+struct WgExt {
+  int up;          // 1: nearest-upsample folding — parity = blockIdx.y % 8, dout is read on that parity sub-lattice of
+                   // the 2x tensor, the 8 active taps of the parity are the GEMM rows, dw += parity * dwstride
+  int cin_total;   // row length of dw in input channels
+  int ci_off;      // first input channel of this layer part inside dw
+  int64_t dwstride;
+};
+
+template <int CK, int NT, int MS, int NTAPS>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __restrict__ in,
                                                               const float* __restrict__ dout, float* __restrict__ dw,
                                                               int D0, int D1, int D2, int Cin, int Cout, int tiles0,
-                                                              int tiles1, int tiles2) {
+                                                              int tiles1, int tiles2, WgExt ext) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lx = lds;                 // [CK][WVPX]
   float* ld = lds + CK * WVPX;     // [NT*16][WVPD]
-  constexpr int MR = 27 * CK;      // GEMM rows (tap, ci)
+  constexpr int MR = NTAPS * CK;   // GEMM rows (tap, ci)
   constexpr int MTILES = (MR + 15) / 16;
   constexpr int MTP = (MTILES + MS - 1) / MS;  // m-tiles per workgroup (the GEMM rows are split over MS workgroups)
   constexpr int MTW = (MTP + 3) / 4;           // m-tiles per wave
   constexpr int C4 = CK / 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int cc = blockIdx.y / MS;   // input-channel chunk
-  const int mt0 = (blockIdx.y % MS) * MTP;  // first m-tile of this workgroup
+  static_assert(NTAPS == 27 || MS == 1, "the parity variant does not split the GEMM rows");
+  const int par = (NTAPS == 8) ? (int)(blockIdx.y & 7) : 0;
+  const int cc = (NTAPS == 8) ? (int)(blockIdx.y >> 3) : (int)(blockIdx.y / MS);  // input-channel chunk
+  const int mt0 = (NTAPS == 8) ? 0 : (int)(blockIdx.y % MS) * MTP;  // first m-tile of this workgroup
+  const uint32_t tapmask = (NTAPS == 8) ? up_tapmask(par, false) : 0x7FFFFFFu;
+  auto nth_tap = [&](int i) {  // i-th active tap of the mask
+    if (NTAPS == 27) return i;
+    uint32_t m = tapmask;
+    for (int k = 0; k < i; ++k) m &= m - 1;
+    return (int)__builtin_ctz(m);
+  };
+  const int ds = (NTAPS == 8) ? 2 : 1;  // dout view: low-res grid voxel g -> tensor voxel 2g + parity
+  const int dp0 = (par >> 2) & 1, dp1 = (par >> 1) & 1, dp2 = par & 1;
   const int nco = blockIdx.z;  // output-channel chunk
   const int co0 = nco * NT * 16;
   const bool vec_in = (Cin % 4) == 0, vec_out = (Cout % 4) == 0;
@@ -489,7 +600,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
   for (int m = 0; m < MTW; ++m) {
     int r = (mt0 + wave + 4 * m) * 16 + li;
     if (r >= MR) r = MR - 1;
-    const int tap = r / CK, cil = r - tap * CK;
+    const int ti = r / CK, cil = r - ti * CK;
+    const int tap = nth_tap(ti);
     const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
     a_base[m] = cil * WVPX + (dz * WH1 + dy) * WH2 + dx;
   }
@@ -532,7 +644,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
     const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
     const int c = co0 + c4 * 4;
     const bool ok = (f < WTV * NT * 4) & (gz < D0) & (gy < D1) & (gx < D2);
-    const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cout + c) : 0;
+    const size_t off =
+        ok ? ((((size_t)(gz * ds + dp0) * (D1 * ds) + (gy * ds + dp1)) * (D2 * ds) + (gx * ds + dp2)) * Cout + c) : 0;
     float4 v;
     if (vec_out) {
       const bool okc = ok && c < Cout;
@@ -645,13 +758,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
       if (wave + 4 * m >= MTP) continue;  // m-tile belongs to the next workgroup of the split
       const int row = (mt0 + wave + 4 * m) * 16 + kq * 4 + r;
       if (row >= MR) continue;
-      const int tap = row / CK, cil = row - tap * CK;
+      const int ti = row / CK, cil = row - ti * CK;
+      const int tap = nth_tap(ti);
       const int ci = cc * CK + cil;
       if (ci >= Cin) continue;
+      float* dwp = dw + (size_t)par * ext.dwstride;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = co0 + n * 16 + li;
-        if (co < Cout) atomicAdd(&dw[((size_t)tap * Cin + ci) * Cout + co], acc[m][n][r]);
+        if (co < Cout) atomicAdd(&dwp[((size_t)tap * ext.cin_total + ext.ci_off + ci) * Cout + co], acc[m][n][r]);
       }
     }
   }
@@ -666,7 +781,7 @@ struct FwdPlan {
 };
 
 // Launch geometry for one layer: enough workgroups to fill 256 CUs x 2 even on the deep, small levels.
-inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout) {
+inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
   FwdPlan p;
   p.ck = ck_for(Cin);
   p.ncc = cdiv(Cin, p.ck);
@@ -683,7 +798,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout) {
   p.ksplit = 1;
   p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist) ? 1 : 0;
   const int64_t w = wgs(p.mt, p.nt);
-  if (w < 512 && p.ncc >= 4) {
+  if (w < 512 && p.ncc >= 4 && plain) {
     int ks = (int)cdiv(1024, (int)w);
     if (ks > p.ncc / 2) ks = p.ncc / 2;
     if (ks > 8) ks = 8;
@@ -694,7 +809,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout) {
 
 template <int CK, int NT, int MT, bool KS>
 int launch_fwd(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
-               const FwdPlan& pl, int act, hipStream_t st) {
+               const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], MT), tiles2 = cdiv(s[2], FT2);
   const size_t smem = (size_t)FH0 * (MT + 2) * FH2 * (CK + 4) * sizeof(float);
   static bool attr_done = false;
@@ -707,8 +822,9 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
   if (KS) {
     if (hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles0 * tiles1 * tiles2, pl.nchunks, KS ? pl.ksplit : 1), dim3(256), smem, st, in, wp,
-                     bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act | (g_dbg << 8));
+  const int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
+  hipLaunchKernelGGL(kern, dim3(tiles0 * tiles1 * tiles2, pl.nchunks, gz), dim3(256), smem, st, in, wp, bias, out, s[0],
+                     s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act | (g_dbg << 8), ext);
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   if (KS && (bias != nullptr || act != 0)) {
     hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act);
@@ -740,71 +856,110 @@ int launch_fwd_persist(const float* in, const float* wp, const float* bias, floa
 
 template <int CK, int NT>
 int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
-                  const FwdPlan& pl, int act, hipStream_t st) {
+                  const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
   if (pl.mt == 4) {
     if constexpr (CK == 24 && NT <= 3) {
-      if (pl.persist) return launch_fwd_persist<NT>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+      if (pl.persist && ext.mode == 0) return launch_fwd_persist<NT>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
     }
-    return launch_fwd<CK, NT, 4, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    return launch_fwd<CK, NT, 4, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
   }
   if constexpr (NT <= 3) {
-    if (pl.ksplit > 1) return launch_fwd<CK, NT, 2, true>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
-    return launch_fwd<CK, NT, 2, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    if (pl.ksplit > 1) return launch_fwd<CK, NT, 2, true>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
+    return launch_fwd<CK, NT, 2, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
   }
   return SYNTHSR_EINVAL;
 }
 
 template <int CK>
 int dispatch_fwd(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
-                 const FwdPlan& pl, int act, hipStream_t st) {
+                 const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
   switch (pl.nt) {
-    case 1: return dispatch_fwd2<CK, 1>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
-    case 2: return dispatch_fwd2<CK, 2>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
-    case 3: return dispatch_fwd2<CK, 3>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
-    case 4: return dispatch_fwd2<CK, 4>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
-    case 5: return dispatch_fwd2<CK, 5>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
-    case 6: return dispatch_fwd2<CK, 6>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+    case 1: return dispatch_fwd2<CK, 1>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
+    case 2: return dispatch_fwd2<CK, 2>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
+    case 3: return dispatch_fwd2<CK, 3>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
+    case 4: return dispatch_fwd2<CK, 4>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
+    case 5: return dispatch_fwd2<CK, 5>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
+    case 6: return dispatch_fwd2<CK, 6>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
   }
   return SYNTHSR_EINVAL;
 }
 
-template <int CK, int NT, int MS>
-int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], int Cin, int Cout, hipStream_t st) {
+template <int CK, int NT, int MS, int NTAPS>
+int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], int Cin, int Cout, hipStream_t st,
+                 const WgExt& ext) {
   const int tiles0 = cdiv(s[0], WT0), tiles1 = cdiv(s[1], WT1), tiles2 = cdiv(s[2], WT2);
   const int ntiles = tiles0 * tiles1 * tiles2;
   const int ncc = cdiv(Cin, CK), nco = cdiv(Cout, NT * 16);
-  int gx = 2048 / (ncc * nco * MS);
+  const int ymul = (NTAPS == 8) ? 8 : MS;
+  int gx = 2048 / (ncc * nco * ymul);
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   const size_t smem = ((size_t)CK * WVPX + (size_t)NT * 16 * WVPD) * sizeof(float);
   static bool attr_done = false;
-  auto kern = conv3d_wgrad_kernel<CK, NT, MS>;
+  auto kern = conv3d_wgrad_kernel<CK, NT, MS, NTAPS>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(gx, ncc * MS, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout, tiles0,
-                     tiles1, tiles2);
+  hipLaunchKernelGGL(kern, dim3(gx, ncc * ymul, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout,
+                     tiles0, tiles1, tiles2, ext);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+template <int NTAPS>
+int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout, hipStream_t st,
+                   const WgExt& ext) {
+  const int CK = ck_for(Cin);
+  // output-channel chunks of <= 48 (3 n-tiles) keep the accumulators of all taps x 24 ci in registers
+  const int nt_all = cdiv(Cout, 16);
+  const int nco = cdiv(nt_all, 3);
+  const int NT = cdiv(nt_all, nco);
+  if (CK == 24) {
+    if (NT == 1) return launch_wgrad<24, 1, 1, NTAPS>(in, dout, dw, shape, Cin, Cout, st, ext);
+    if (NT == 2) return launch_wgrad<24, 2, 1, NTAPS>(in, dout, dw, shape, Cin, Cout, st, ext);
+    if constexpr (NTAPS == 27) return launch_wgrad<24, 3, 2, 27>(in, dout, dw, shape, Cin, Cout, st, ext);
+    return launch_wgrad<24, 3, 1, NTAPS>(in, dout, dw, shape, Cin, Cout, st, ext);
+  }
+  if (NT == 1) return launch_wgrad<8, 1, 1, NTAPS>(in, dout, dw, shape, Cin, Cout, st, ext);
+  if (NT == 2) return launch_wgrad<8, 2, 1, NTAPS>(in, dout, dw, shape, Cin, Cout, st, ext);
+  return launch_wgrad<8, 3, 1, NTAPS>(in, dout, dw, shape, Cin, Cout, st, ext);
 }
 
 }  // namespace
 
 extern "C" {
 
-int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], int Cin, int Cout, int mode,
-                            synthsr_stream_t stream) {
-  if (!shape || Cin < 1 || Cout < 1 || (mode != 0 && mode != 1) || shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
+int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3], int Cin_total, int ci_off, int Cin,
+                               int Cout, int mode, int up, synthsr_stream_t stream) {
+  if (!shape || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1) ||
+      shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
     return SYNTHSR_EINVAL;
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
-  const FwdPlan pl = plan_fwd(shape, CinE, CoutE);
-  const int64_t total = (int64_t)pl.nchunks * pl.ncc * 27 * (pl.ck / 8) * pl.nt * 128;
+  const FwdPlan pl = plan_fwd(shape, CinE, CoutE, !up);
+  const int64_t per = (int64_t)pl.nchunks * pl.ncc * 27 * (pl.ck / 8) * pl.nt * 128;
+  const int64_t total = per * (up ? 8 : 1);
   if (!packed) return total;
   if (!w) return SYNTHSR_EINVAL;
-  hipLaunchKernelGGL(pack_kernel, dim3(syn_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cin, Cout,
-                     mode, pl.ck, pl.ncc, pl.nt, pl.nchunks, total);
-  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  for (int p = 0; p < (up ? 8 : 1); ++p) {
+    hipLaunchKernelGGL(pack_kernel, dim3(syn_grid(per, 256)), dim3(256), 0, (hipStream_t)stream, w, packed + p * per,
+                       Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.nt, pl.nchunks, up ? p : -1, per);
+    if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  }
   return total;
+}
+
+int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], int Cin, int Cout, int mode,
+                            synthsr_stream_t stream) {
+  return synthsr_conv3d_pack_ex(w, packed, shape, Cin, 0, Cin, Cout, mode, 0, stream);
+}
+
+int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_off, int Cl, int Cout,
+                             synthsr_stream_t stream) {
+  if (!dwc || !dw || Cl < 1 || Cout < 1 || ci_off < 0 || ci_off + Cl > Cin_total) return SYNTHSR_EINVAL;
+  const int64_t total = (int64_t)27 * Cl * Cout;
+  hipLaunchKernelGGL(up_unpack_kernel, dim3(syn_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dwc, dw, Cin_total,
+                     ci_off, Cl, Cout, total);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
 int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3], int Cin,
@@ -813,9 +968,36 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
       (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
-  if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream);
-  return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream);
+  const ConvExt ext{0, nullptr, 0};
+  if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
+  return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
 }
+
+int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* bias, const float* addend, float* out,
+                          const int lo_shape[3], int Cl, int Cout, int act, synthsr_stream_t stream) {
+  if (!lo || !wpacked8 || !out || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 ||
+      lo_shape[2] < 1 || (act != 0 && act != 1))
+    return SYNTHSR_EINVAL;
+  const FwdPlan pl = plan_fwd(lo_shape, Cl, Cout, false);
+  const int64_t wstride = (int64_t)pl.nchunks * pl.ncc * 27 * (pl.ck / 8) * pl.nt * 128;
+  const ConvExt ext{1, addend, wstride};
+  if (pl.ck == 24) return dispatch_fwd<24>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
+  return dispatch_fwd<8>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
+}
+
+int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo, const int lo_shape[3], int Cl, int Cout,
+                            synthsr_stream_t stream) {
+  if (!dout || !wpacked8 || !dlo || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 ||
+      lo_shape[2] < 1)
+    return SYNTHSR_EINVAL;
+  // effective conv: input channels = Cout (of the forward layer), output channels = Cl
+  const FwdPlan pl = plan_fwd(lo_shape, Cout, Cl, false);
+  const int64_t wstride = (int64_t)pl.nchunks * pl.ncc * 27 * (pl.ck / 8) * pl.nt * 128;
+  const ConvExt ext{2, nullptr, wstride};
+  if (pl.ck == 24) return dispatch_fwd<24>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);
+  return dispatch_fwd<8>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);
+}
+
 
 int synthsr_conv3d_set_option(int option, int value) {
   if (option == 0) {
@@ -833,24 +1015,26 @@ int synthsr_conv3d_set_option(int option, int value) {
   return SYNTHSR_EINVAL;
 }
 
+int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
+                            int Cin, int Cout, synthsr_stream_t stream) {
+  if (!in || !dout || !dw || !shape || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || shape[0] < 1 ||
+      shape[1] < 1 || shape[2] < 1)
+    return SYNTHSR_EINVAL;
+  const WgExt ext{0, Cin_total, ci_off, 0};
+  return dispatch_wgrad<27>(in, dout, dw, shape, Cin, Cout, (hipStream_t)stream, ext);
+}
+
 int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout,
                          synthsr_stream_t stream) {
-  if (!in || !dout || !dw || !shape || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
+  return synthsr_conv3d_wgrad_ex(in, dout, dw, shape, Cin, 0, Cin, Cout, stream);
+}
+
+int synthsr_conv3d_up_wgrad(const float* lo, const float* dout, float* dwc, const int lo_shape[3], int Cl, int Cout,
+                            synthsr_stream_t stream) {
+  if (!lo || !dout || !dwc || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1)
     return SYNTHSR_EINVAL;
-  const int CK = ck_for(Cin);
-  // output-channel chunks of <= 48 (3 n-tiles) keep 27 taps x 24 ci of accumulators in registers
-  const int nt_all = cdiv(Cout, 16);
-  const int nco = cdiv(nt_all, 3);
-  const int NT = cdiv(nt_all, nco);
-  hipStream_t st = (hipStream_t)stream;
-  if (CK == 24) {
-    if (NT == 1) return launch_wgrad<24, 1, 1>(in, dout, dw, shape, Cin, Cout, st);
-    if (NT == 2) return launch_wgrad<24, 2, 1>(in, dout, dw, shape, Cin, Cout, st);
-    return launch_wgrad<24, 3, 2>(in, dout, dw, shape, Cin, Cout, st);
-  }
-  if (NT == 1) return launch_wgrad<8, 1, 1>(in, dout, dw, shape, Cin, Cout, st);
-  if (NT == 2) return launch_wgrad<8, 2, 1>(in, dout, dw, shape, Cin, Cout, st);
-  return launch_wgrad<8, 3, 1>(in, dout, dw, shape, Cin, Cout, st);
+  const WgExt ext{1, Cl, 0, (int64_t)27 * Cl * Cout};
+  return dispatch_wgrad<8>(lo, dout, dwc, lo_shape, Cl, Cout, (hipStream_t)stream, ext);
 }
 
 }  // extern "C"

@@ -65,6 +65,75 @@ def pack_conv_weights(w, shape, mode=0, out=None):
     return out
 
 
+def pack_conv_weights_ex(w, shape, ci_off, cin, mode=0, up=False, out=None):
+    """pack the input-channel range [ci_off, ci_off+cin) of a Keras kernel w [3,3,3,Cin_total,Cout]; `up`: the 8 parity
+    weight sets of the nearest-upsample folding (shape = LOW-RES spatial shape)"""
+    lib = _L()
+    cin_total, cout = int(w.shape[3]), int(w.shape[4])
+    s3 = _lib.i3(shape[:3])
+    n = lib.synthsr_conv3d_pack_ex(None, None, s3, cin_total, int(ci_off), int(cin), cout, mode, int(bool(up)), None)
+    if n < 0:
+        _lib.check(int(n), 'conv3d_pack_ex(size)')
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w.device)
+    assert out.numel() == n
+    r = lib.synthsr_conv3d_pack_ex(_lib.ptr(w), _lib.ptr(out), s3, cin_total, int(ci_off), int(cin), cout, mode,
+                                   int(bool(up)), _lib.stream())
+    if r < 0:
+        _lib.check(int(r), 'conv3d_pack_ex')
+    return out
+
+
+def conv3d_up(lo, wpacked8, bias, addend, Cout, act=1, out=None):
+    """act(conv3(UpSampling3D(2)(lo)) + addend + bias) evaluated on the low-res tensor (8 parity convs)"""
+    lib = _L()
+    s = lo.shape
+    if out is None:
+        out = torch.empty((2 * s[0], 2 * s[1], 2 * s[2], Cout), dtype=torch.float32, device=lo.device)
+    with _Timed('conv3d_up_fwd', s[:3], s[3], Cout):
+        _lib.check(lib.synthsr_conv3d_up_fwd(_lib.ptr(lo), _lib.ptr(wpacked8), _lib.ptr(bias), _lib.ptr(addend),
+                                             _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), int(Cout), int(act),
+                                             _lib.stream()), 'conv3d_up_fwd')
+    return out
+
+
+def conv3d_up_dgrad(dout, wpacked8, Cl, out=None):
+    """gradient w.r.t. the low-res tensor of conv3d_up; dout [2*lo_shape, Cout]"""
+    lib = _L()
+    s = dout.shape
+    lo_shape = (s[0] // 2, s[1] // 2, s[2] // 2)
+    if out is None:
+        out = torch.empty(lo_shape + (Cl,), dtype=torch.float32, device=dout.device)
+    with _Timed('conv3d_up_dgrad', lo_shape, Cl, s[3]):
+        _lib.check(lib.synthsr_conv3d_up_dgrad(_lib.ptr(dout), _lib.ptr(wpacked8), _lib.ptr(out), _lib.i3(lo_shape),
+                                               int(Cl), int(s[3]), _lib.stream()), 'conv3d_up_dgrad')
+    return out
+
+
+def conv3d_up_wgrad(lo, dout, dwc, dw, ci_off):
+    """weight gradient of the up-sampled channel range: dwc [8,27,Cl,Cout] scratch (zeroed here), dw (+=)"""
+    lib = _L()
+    s = lo.shape
+    dwc.zero_()
+    with _Timed('conv3d_up_wgrad', s[:3], s[3], dout.shape[3]):
+        _lib.check(lib.synthsr_conv3d_up_wgrad(_lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]), int(s[3]),
+                                               int(dout.shape[3]), _lib.stream()), 'conv3d_up_wgrad')
+    _lib.check(lib.synthsr_conv3d_up_unpack(_lib.ptr(dwc), _lib.ptr(dw), int(dw.shape[3]), int(ci_off), int(s[3]),
+                                            int(dout.shape[3]), _lib.stream()), 'conv3d_up_unpack')
+    return dw
+
+
+def conv3d_wgrad_part(x, dout, dw, ci_off):
+    """dw [3,3,3,Cin_total,Cout] += gradient of the input-channel range [ci_off, ci_off + x.shape[3])"""
+    lib = _L()
+    s = x.shape
+    with _Timed('conv3d_wgrad', s[:3], s[3], dout.shape[3]):
+        _lib.check(lib.synthsr_conv3d_wgrad_ex(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.i3(s[:3]),
+                                               int(dw.shape[3]), int(ci_off), int(s[3]), int(dout.shape[3]),
+                                               _lib.stream()), 'conv3d_wgrad_ex')
+    return dw
+
+
 def conv3d(x, wpacked, bias, Cout, act=1, out=None):
     """x [d0,d1,d2,Cin] -> [d0,d1,d2,Cout]; act: 0 linear, 1 ELU"""
     lib = _L()

@@ -21,7 +21,7 @@ from . import ops
 class UNet3D:
     def __init__(self, nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None,
                  feat_mult=1, nb_conv_per_level=1, batch_norm=None, activation='elu', device=None, seed=0,
-                 final_pred_activation='linear'):
+                 final_pred_activation='linear', fold_upsample='auto'):
         if conv_size != 3:
             raise NotImplementedError('only conv_size=3 is supported')
         if activation != 'elu':
@@ -69,7 +69,13 @@ class UNet3D:
                 c_in = self.feats[l]
             c = self.feats[l]
             bn = self._add_bn('%s_bn_up_%d' % (self.prefix, k), c)
-            self.dec.append(dict(convs=convs, bn=bn, level=l))
+            # nearest-upsample folding of the first conv of the stage (ops.conv3d_up): worth it where the low-res grid
+            # still fills the GPU; the deep stages keep the materialised concat + split-K path
+            lo_vox = int(np.prod(self.shapes[l + 1]))
+            fold = (lo_vox >= 32768) if fold_upsample == 'auto' else bool(fold_upsample)
+            convs[0]['fold'] = fold
+            convs[0]['cs'] = self.feats[l]
+            self.dec.append(dict(convs=convs, bn=bn, level=l, fold=fold))
         self.head = dict(name='%s_likelihood' % self.prefix, cin=c,
                          w=self._add('%s_likelihood/kernel' % self.prefix, (c, 1), 'head_w'),
                          b=self._add('%s_likelihood/bias' % self.prefix, (1,), 'bias'))
@@ -159,6 +165,14 @@ class UNet3D:
         first = True
         for c in self.all_convs():
             w = self.view(c['w'])
+            if c.get('fold'):
+                cs, cl = c['cs'], c['cin'] - c['cs']
+                lo_shape = [s // 2 for s in c['shape']]
+                c['wp_s'] = ops.pack_conv_weights_ex(w, c['shape'], 0, cs, 0, False, c.get('wp_s'))
+                c['wpd_s'] = ops.pack_conv_weights_ex(w, c['shape'], 0, cs, 1, False, c.get('wpd_s'))
+                c['wp_u'] = ops.pack_conv_weights_ex(w, lo_shape, cs, cl, 0, True, c.get('wp_u'))
+                c['wpd_u'] = ops.pack_conv_weights_ex(w, lo_shape, cs, cl, 1, True, c.get('wpd_u'))
+                continue
             c['wp'] = ops.pack_conv_weights(w, c['shape'], 0, c['wp'])
             if not first:  # the first layer's input has no gradient
                 c['wpd'] = ops.pack_conv_weights(w, c['shape'], 1, c['wpd'])
@@ -223,13 +237,25 @@ class UNet3D:
         for k, d in enumerate(self.dec):
             l = d['level']
             skip = self.saved['enc'][l][-1]
-            cat = ops.upsample_concat(skip, low, self._stats(low_bn), self.view(low_bn['gamma']),
-                                      self.view(low_bn['beta']),
-                                      out=self.buf('cat%d' % k, self.shapes[l] + [skip.shape[3] + low.shape[3]]))
-            self.saved['cat'].append(cat)
-            cur = cat
             acts = []
+            if d['fold']:
+                c0 = d['convs'][0]
+                lo_bn = ops.bn_apply(low, self._stats(low_bn), self.view(low_bn['gamma']), self.view(low_bn['beta']),
+                                     out=self.buf('lobn%d' % k, list(low.shape)))
+                self.saved['cat'].append((skip, lo_bn))
+                tmp = ops.conv3d(skip, c0['wp_s'], None, c0['cout'], 0, out=self.buf('foldtmp', self.shapes[l] + [c0['cout']]))
+                cur = ops.conv3d_up(lo_bn, c0['wp_u'], self.view(c0['b']), tmp, c0['cout'], 1,
+                                    out=self.buf('dec%d_0' % k, self.shapes[l] + [c0['cout']]))
+                acts.append(cur)
+            else:
+                cat = ops.upsample_concat(skip, low, self._stats(low_bn), self.view(low_bn['gamma']),
+                                          self.view(low_bn['beta']),
+                                          out=self.buf('cat%d' % k, self.shapes[l] + [skip.shape[3] + low.shape[3]]))
+                self.saved['cat'].append(cat)
+                cur = cat
             for j, c in enumerate(d['convs']):
+                if d['fold'] and j == 0:
+                    continue
                 cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1,
                                  out=self.buf('dec%d_%d' % (k, j), self.shapes[l] + [c['cout']]))
                 acts.append(cur)
@@ -290,12 +316,25 @@ class UNet3D:
             l = d['level']
             acts = self.saved['dec'][k]
             g = self._bn_backward(g, acts[-1], d['bn'])
-            g = self._convs_backward(g, None, d['convs'], acts, self.saved['cat'][k], need_dx=True, tag='d%d' % k)
-            # g = d(concat)
             Cs = self.feats[l]
-            Cl = g.shape[3] - Cs
-            dskips[l], g = ops.upsample_concat_bwd(g, Cs, Cl, dskip=self.buf('dskip%d' % l, self.shapes[l] + [Cs]),
-                                                   dlo=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
+            if d['fold']:
+                skip, lo_bn = self.saved['cat'][k]
+                Cl = lo_bn.shape[3]
+                # all convs but the first: regular; the first one through the folded kernels
+                g = self._convs_backward(g, None, d['convs'][1:], acts[1:], acts[0], need_dx=True, tag='d%d' % k)
+                c0 = d['convs'][0]
+                dz = ops.elu_bwd(g, acts[0], dbias=self.view(c0['b'], self.grads), out=self.buf('dz', list(acts[0].shape)))
+                dW = self.view(c0['w'], self.grads)
+                ops.conv3d_wgrad_part(skip, dz, dW, 0)
+                ops.conv3d_up_wgrad(lo_bn, dz, self.buf('dwc', [8, 27, Cl, c0['cout']]), dW, Cs)
+                dskips[l] = ops.conv3d(dz, c0['wpd_s'], None, Cs, 0, out=self.buf('dskip%d' % l, self.shapes[l] + [Cs]))
+                g = ops.conv3d_up_dgrad(dz, c0['wpd_u'], Cl, out=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
+            else:
+                g = self._convs_backward(g, None, d['convs'], acts, self.saved['cat'][k], need_dx=True, tag='d%d' % k)
+                # g = d(concat)
+                Cl = g.shape[3] - Cs
+                dskips[l], g = ops.upsample_concat_bwd(g, Cs, Cl, dskip=self.buf('dskip%d' % l, self.shapes[l] + [Cs]),
+                                                       dlo=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
             if on_grad_ready is not None:
                 on_grad_ready(self.offsets[d['convs'][0]['w']][0])
         for l in range(L - 1, -1, -1):
@@ -351,7 +390,8 @@ class UNet3D:
 def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None, feat_mult=1,
          pool_size=2, use_logp=True, padding='same', dilation_rate_mult=1, activation='elu', skip_n_concatenations=0,
          use_residuals=False, final_pred_activation='softmax', nb_conv_per_level=1, add_prior_layer=False,
-         layer_nb_feats=None, conv_dropout=0, batch_norm=None, input_model=None, device=None, seed=0):
+         layer_nb_feats=None, conv_dropout=0, batch_norm=None, input_model=None, device=None, seed=0,
+         fold_upsample='auto'):
     """ext/neuron/models.py:26-47 signature.  Unsupported knobs of the over-parametrised reference raise."""
     if pool_size != 2 or padding != 'same' or dilation_rate_mult != 1 or skip_n_concatenations != 0 or \
             use_residuals or add_prior_layer or layer_nb_feats is not None or conv_dropout != 0:
@@ -359,6 +399,7 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
                                   '(pool 2, same padding, no dilation/residuals/dropout/prior)')
     net = UNet3D(nb_features, input_shape, nb_levels, conv_size, nb_labels, name=name, prefix=prefix,
                  feat_mult=feat_mult, nb_conv_per_level=nb_conv_per_level, batch_norm=batch_norm,
-                 activation=activation, device=device, seed=seed, final_pred_activation=final_pred_activation)
+                 activation=activation, device=device, seed=seed, final_pred_activation=final_pred_activation,
+                 fold_upsample=fold_upsample)
     net.input_model = input_model
     return net

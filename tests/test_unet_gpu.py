@@ -74,6 +74,43 @@ def test_conv3d_identity_and_transpose_detecting(T):
         assert int((y != 0).sum()) == int((exp != 0).sum())  # nothing leaks into other channels / voxels
 
 
+@pytest.mark.parametrize('lo_shape,Cs,Cl,Cout', [((6, 5, 9), 24, 48, 24), ((4, 4, 8), 48, 96, 48), ((3, 2, 3), 24, 24, 48),
+                                                 ((20, 20, 24), 24, 48, 24)])
+def test_upsample_folded_conv(T, lo_shape, Cs, Cl, Cout):
+    """conv on concatenate([skip, UpSampling3D(2)(lo)]) evaluated as conv3(skip) + 8 parity convs on lo: forward,
+    both data gradients and the full weight gradient against autograd on the materialised concat"""
+    torch = T
+    from synthsr_amd import ops
+    from oracle import unet_ref as U
+    g = torch.Generator().manual_seed(Cs + 7 * Cl)
+    full = tuple(2 * s for s in lo_shape)
+    skip = torch.randn(*full, Cs, generator=g)
+    lo = torch.randn(*lo_shape, Cl, generator=g)
+    w = torch.randn(3, 3, 3, Cs + Cl, Cout, generator=g) / np.sqrt(27 * (Cs + Cl))
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(*full, Cout, generator=g)
+    sr, lr, wr = skip.clone().requires_grad_(True), lo.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = torch.nn.functional.elu(U.conv3d_same(torch.cat([sr, U.upsample2(lr)], -1), wr, b))
+    # backward through the pre-activation to compare with our dz-based kernels: dz = dy * elu'(y)
+    yr.backward(dy)
+    dz = dy * torch.where(yr.detach() > 0, torch.ones_like(dy), yr.detach() + 1)
+    wd, sd, ld, dzd = w.cuda(), skip.cuda(), lo.cuda(), dz.cuda()
+    wp_s = ops.pack_conv_weights_ex(wd, full, 0, Cs, 0, False)
+    wp_u = ops.pack_conv_weights_ex(wd, lo_shape, Cs, Cl, 0, True)
+    tmp = ops.conv3d(sd, wp_s, None, Cout, act=0)
+    y = ops.conv3d_up(ld, wp_u, b.cuda(), tmp, Cout, act=1)
+    close(y, yr, name='folded forward')
+    wpd_s = ops.pack_conv_weights_ex(wd, full, 0, Cs, 1, False)
+    wpd_u = ops.pack_conv_weights_ex(wd, lo_shape, Cs, Cl, 1, True)
+    close(ops.conv3d(dzd, wpd_s, None, Cs, act=0), sr.grad, name='dskip')
+    close(ops.conv3d_up_dgrad(dzd, wpd_u, Cl), lr.grad, name='dlo')
+    dw = torch.zeros_like(wd)
+    ops.conv3d_wgrad_part(sd, dzd, dw, 0)
+    dwc = torch.empty(8, 27, Cl, Cout, device='cuda')
+    ops.conv3d_up_wgrad(ld, dzd, dwc, dw, Cs)
+    close(dw, wr.grad, name='dW')
+
+
 def test_pointwise_kernels(T):
     torch = T
     from synthsr_amd import ops
@@ -129,13 +166,15 @@ def _copy_params(net, torch):
     return {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
 
 
+@pytest.mark.parametrize('fold', [False, True])
 @pytest.mark.parametrize('feats,levels,shape,cin', [(24, 3, (16, 16, 32), 2), (8, 2, (8, 12, 16), 1), (24, 5, (32, 32, 32), 2)])
-def test_unet_loss_and_gradients_vs_autograd(T, feats, levels, shape, cin):
+def test_unet_loss_and_gradients_vs_autograd(T, feats, levels, shape, cin, fold):
     torch = T
     from synthsr_amd.unet import unet
     from oracle import unet_ref as U
     net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1,
-               feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3)
+               feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3,
+               fold_upsample=fold)
     # make BN affine and biases non-trivial
     g = torch.Generator().manual_seed(11)
     for nm, v in net.named_parameters():
