@@ -154,6 +154,13 @@ int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_
 int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
                             int Cin, int Cout, synthsr_stream_t stream);
 
+/* launch geometry the kernels will use: out = {chunk width CK, #ci chunks, n-tiles per workgroup, #n chunks, MT, ksplit} */
+int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int out[6]);
+/* packs every layer of a network in ONE launch.  jobs_dev: int64 [njobs][12] = {w_off, dst_off, count, cin_total,
+ * ci_off, cin, cout, mode, ck, ncc, nt, parity(-1 plain)}; w_off / dst_off are float offsets into params / packed */
+int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* jobs_dev, int njobs,
+                            synthsr_stream_t stream);
+
 /* tuning / A-B switch, process-wide: option 0 = use the persistent forward kernel on the large levels (default 1) */
 int synthsr_conv3d_set_option(int option, int value);
 
@@ -165,6 +172,11 @@ int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const in
  * dbias[c] += sum_v dz[v][c]  (dbias zeroed by caller; may be NULL) */
 int synthsr_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
                     synthsr_stream_t stream);
+
+/* fused BN backward + ELU backward: dy is the gradient w.r.t. BN(y); y the conv+ELU output that the BN normalised;
+ * sums from synthsr_bn_bwd_reduce.  dz = (bn_bwd(dy) + dy2) * ELU'(y); dbias += sum dz */
+int synthsr_bn_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
+                       const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream);
 
 /* BatchNormalization(axis=-1), training mode (models.py:351,477; Keras 2.3.1 semantics, eps=1e-3):
  * stats[0..C) = mean, stats[C..2C) = biased variance over the nvox voxels */

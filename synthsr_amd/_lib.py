@@ -45,6 +45,8 @@ SIGNATURES = {
     'synthsr_conv3d_pack': (c_int64, [_P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_conv3d_fwd': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_conv3d_set_option': (c_int, [c_int, c_int]),
+    'synthsr_conv3d_plan': (c_int, [POINTER(c_int), c_int, c_int, c_int, POINTER(c_int)]),
+    'synthsr_conv3d_pack_all': (c_int, [_P, _P, _P, c_int, _S]),
     'synthsr_conv3d_pack_ex': (c_int64, [_P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_up_fwd': (c_int, [_P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_conv3d_up_dgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
@@ -53,6 +55,7 @@ SIGNATURES = {
     'synthsr_conv3d_wgrad_ex': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),
+    'synthsr_bn_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
     'synthsr_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P, _S]),
     'synthsr_bn_apply': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _S]),
     'synthsr_bn_maxpool': (c_int, [_P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _S]),

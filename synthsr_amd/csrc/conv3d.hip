@@ -44,47 +44,67 @@ __device__ __forceinline__ int up_axis_taps(int p, int s, int t[2]) {
 
 // w: Keras kernel [27][Cin_total][Cout]; the layer (or layer part) uses input channels [ci_off, ci_off+Cin).
 // parity < 0: plain weights.  parity 0..7: combined weights of the nearest-upsample folding in 27-slot form.
-__global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin_total, int ci_off, int Cin,
-                            int Cout, int mode, int CK, int ncc, int NT, int nchunks, int parity, int64_t total) {
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
+                                            int Cout, int mode, int CK, int ncc, int NT, int parity) {
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
   const int NCG = CK / 8;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = idx;
-    const int s = (int)(r & 1);
-    r >>= 1;
-    const int lane = (int)(r & 63);
-    r >>= 6;
-    const int nt = (int)(r % NT);
-    r /= NT;
-    const int cg = (int)(r % NCG);
-    r /= NCG;
-    const int tap = (int)(r % 27);
-    r /= 27;
-    const int cc = (int)(r % ncc);
-    const int nc = (int)(r / ncc);
-    const int kq = lane >> 4, j = lane & 15;
-    const int cie = cc * CK + cg * 8 + 2 * kq + s;
-    const int coe = (nc * NT + nt) * 16 + j;
-    float v = 0.f;
-    if (cie < CinE && coe < CoutE) {
-      const int slot = mode ? 26 - tap : tap;              // tap slot in forward orientation
-      const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;  // layer channel indices
-      if (parity < 0) {
-        v = w[((int64_t)slot * Cin_total + ci) * Cout + co];
-      } else {
-        int tz[2], ty[2], tx[2];
-        const int nz = up_axis_taps((parity >> 2) & 1, slot / 9, tz);
-        const int ny = up_axis_taps((parity >> 1) & 1, (slot / 3) % 3, ty);
-        const int nx = up_axis_taps(parity & 1, slot % 3, tx);
-        for (int a = 0; a < nz; ++a)
-          for (int b = 0; b < ny; ++b)
-            for (int c = 0; c < nx; ++c)
-              v += w[((int64_t)((tz[a] * 3 + ty[b]) * 3 + tx[c]) * Cin_total + ci) * Cout + co];
-      }
+  int64_t r = idx;
+  const int s = (int)(r & 1);
+  r >>= 1;
+  const int lane = (int)(r & 63);
+  r >>= 6;
+  const int nt = (int)(r % NT);
+  r /= NT;
+  const int cg = (int)(r % NCG);
+  r /= NCG;
+  const int tap = (int)(r % 27);
+  r /= 27;
+  const int cc = (int)(r % ncc);
+  const int nc = (int)(r / ncc);
+  const int kq = lane >> 4, j = lane & 15;
+  const int cie = cc * CK + cg * 8 + 2 * kq + s;
+  const int coe = (nc * NT + nt) * 16 + j;
+  float v = 0.f;
+  if (cie < CinE && coe < CoutE) {
+    const int slot = mode ? 26 - tap : tap;                            // tap slot in forward orientation
+    const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;  // layer channel indices
+    if (parity < 0) {
+      v = w[((int64_t)slot * Cin_total + ci) * Cout + co];
+    } else {
+      int tz[2], ty[2], tx[2];
+      const int nz = up_axis_taps((parity >> 2) & 1, slot / 9, tz);
+      const int ny = up_axis_taps((parity >> 1) & 1, (slot / 3) % 3, ty);
+      const int nx = up_axis_taps(parity & 1, slot % 3, tx);
+      for (int a = 0; a < nz; ++a)
+        for (int b = 0; b < ny; ++b)
+          for (int c = 0; c < nx; ++c)
+            v += w[((int64_t)((tz[a] * 3 + ty[b]) * 3 + tx[c]) * Cin_total + ci) * Cout + co];
     }
-    packed[idx] = v;
   }
+  return v;
+}
+
+__global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin_total, int ci_off, int Cin,
+                            int Cout, int mode, int CK, int ncc, int NT, int nchunks, int parity, int64_t total) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x)
+    packed[idx] = pack_value(w, idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, NT, parity);
+}
+
+// one launch for every layer of the network: jobs[j] = {w_off, dst_off, count, cin_total, ci_off, cin, cout, mode, ck,
+// ncc, nt, parity} (int64 each), blockIdx.y = job
+constexpr int PACK_JOB_FIELDS = 12;
+__global__ void pack_all_kernel(const float* __restrict__ params, float* __restrict__ packed,
+                                const int64_t* __restrict__ jobs) {
+  const int64_t* jb = jobs + (int64_t)blockIdx.y * PACK_JOB_FIELDS;
+  const float* w = params + jb[0];
+  float* dst = packed + jb[1];
+  const int64_t count = jb[2];
+  const int cin_total = (int)jb[3], ci_off = (int)jb[4], cin = (int)jb[5], cout = (int)jb[6], mode = (int)jb[7],
+            ck = (int)jb[8], ncc = (int)jb[9], nt = (int)jb[10], parity = (int)jb[11];
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < count;
+       idx += (int64_t)gridDim.x * blockDim.x)
+    dst[idx] = pack_value(w, idx, cin_total, ci_off, cin, cout, mode, ck, ncc, nt, parity);
 }
 
 // dW of the up-sampled input channels from the 8 per-parity 27-slot gradients: every original tap t belongs to exactly
@@ -951,6 +971,25 @@ int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3]
 int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], int Cin, int Cout, int mode,
                             synthsr_stream_t stream) {
   return synthsr_conv3d_pack_ex(w, packed, shape, Cin, 0, Cin, Cout, mode, 0, stream);
+}
+
+int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int out[6]) {
+  if (!shape || !out || CinE < 1 || CoutE < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
+  const FwdPlan pl = plan_fwd(shape, CinE, CoutE, plain != 0);
+  out[0] = pl.ck;
+  out[1] = pl.ncc;
+  out[2] = pl.nt;
+  out[3] = pl.nchunks;
+  out[4] = pl.mt;
+  out[5] = pl.ksplit;
+  return SYNTHSR_OK;
+}
+
+int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* jobs_dev, int njobs,
+                            synthsr_stream_t stream) {
+  if (!params || !packed || !jobs_dev || njobs < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(pack_all_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, params, packed, jobs_dev);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
 int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_off, int Cl, int Cout,

@@ -39,9 +39,14 @@ __device__ __forceinline__ void block_channel_reduce(float4 (&part)[NV], int c4,
 
 // ------------------------------------------------------------------------------------------ ELU backward
 // dz = (dy [+ dy2]) * elu'(y); dbias[c] += sum dz
+// Optional fused BatchNorm backward (bn_sums != nullptr): the incoming gradient is w.r.t. the BN OUTPUT of y and is
+// first mapped to the BN input, g <- gamma*invstd*(g - sum_dy/n - xhat*sum_dyxhat/n), saving one full pass.
 __global__ __launch_bounds__(RB) void elu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
                                                      const float* __restrict__ y, float* __restrict__ dz,
-                                                     float* __restrict__ dbias, int64_t n4, int C4) {
+                                                     float* __restrict__ dbias, int64_t n4, int C4,
+                                                     const float* __restrict__ bn_stats,
+                                                     const float* __restrict__ bn_gamma,
+                                                     const float* __restrict__ bn_sums, float eps, float inv_n) {
   extern __shared__ float smem[];
   const bool fixed = (RB % C4) == 0;
   if (dbias)
@@ -51,11 +56,23 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const float* __restrict__ d
   const int64_t stride = (int64_t)gridDim.x * RB;
   for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < n4; i += stride) {
     float4 g = ld4(dy + i * 4);
+    const float4 a = ld4(y + i * 4);
+    if (bn_sums) {
+      const int C = C4 * 4, c = (int)(i % C4) * 4;
+      float gg[4] = {g.x, g.y, g.z, g.w};
+      const float aa[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float inv = rsqrtf(bn_stats[C + c + k] + eps);
+        const float xh = (aa[k] - bn_stats[c + k]) * inv;
+        gg[k] = bn_gamma[c + k] * inv * (gg[k] - bn_sums[c + k] * inv_n - xh * bn_sums[C + c + k] * inv_n);
+      }
+      g = make_float4(gg[0], gg[1], gg[2], gg[3]);
+    }
     if (dy2) {
       const float4 g2 = ld4(dy2 + i * 4);
       g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
     }
-    const float4 a = ld4(y + i * 4);
     float4 r;
     r.x = g.x * elu_grad_from_y(a.x);
     r.y = g.y * elu_grad_from_y(a.y);
@@ -450,7 +467,18 @@ int synthsr_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz
   if (!dy || !y || !dz || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
   hipLaunchKernelGGL(elu_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
-                     dy2, y, dz, dbias, n4, C / 4);
+                     dy2, y, dz, dbias, n4, C / 4, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     0.f, 0.f);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bn_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
+                       const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
+  if (!dy || !y || !dz || !stats || !gamma || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(elu_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
+                     dy2, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps, (float)(1.0 / (double)nvox));
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

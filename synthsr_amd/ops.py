@@ -167,6 +167,27 @@ def elu_bwd(dy, y, dy2=None, dbias=None, out=None):
     return out
 
 
+def bn_reduce_bwd(dy, x, stats, sums, eps=BN_EPS):
+    """pass 1 of the BN backward: sums [2C] (zeroed by caller) += [sum dy, sum dy*xhat]"""
+    lib = _L()
+    C = int(x.shape[-1])
+    _lib.check(lib.synthsr_bn_bwd_reduce(_lib.ptr(dy), _lib.ptr(x), x.numel() // C, C, _lib.ptr(stats), eps,
+                                         _lib.ptr(sums), _lib.stream()), 'bn_bwd_reduce')
+    return sums
+
+
+def bn_elu_bwd(dy, y, stats, gamma, sums, dy2=None, dbias=None, out=None, eps=BN_EPS):
+    """fused pass 2 of the BN backward + ELU backward (dy = gradient w.r.t. BN(y))"""
+    lib = _L()
+    C = int(y.shape[-1])
+    if out is None:
+        out = torch.empty_like(y)
+    _lib.check(lib.synthsr_bn_elu_bwd(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(out), _lib.ptr(dbias),
+                                      y.numel() // C, C, _lib.ptr(stats), _lib.ptr(gamma), eps, _lib.ptr(sums),
+                                      _lib.stream()), 'bn_elu_bwd')
+    return out
+
+
 def bn_stats(x, stats, ws):
     lib = _L()
     C = int(x.shape[-1])

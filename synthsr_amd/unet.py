@@ -160,23 +160,61 @@ class UNet3D:
             for c in d['convs']:
                 yield c
 
-    def repack(self):
-        """refresh the MFMA-fragment-ordered copies of the conv kernels (after init / optimizer step / load)"""
+    def _pack_jobs(self):
+        """job table for synthsr_conv3d_pack_all: every packed weight set of the network, one flat destination"""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        jobs, off = [], 0
+
+        def plan(shape, cin_e, cout_e, plain):
+            out = (ctypes.c_int * 6)()
+            _lib.check(lib.synthsr_conv3d_plan(_lib.i3(shape), cin_e, cout_e, int(plain), out), 'conv3d_plan')
+            return list(out)
+
+        def add(c, key, shape, ci_off, cin, mode, up):
+            nonlocal off
+            cin_total, cout = c['cin'], c['cout']
+            cin_e, cout_e = (cout, cin) if mode else (cin, cout)
+            ck, ncc, nt, nchunks, _, _ = plan(shape, cin_e, cout_e, not up)
+            per = nchunks * ncc * 27 * (ck // 8) * nt * 128
+            w_off = self.offsets[c['w']][0]
+            c[key + '_off'] = (off, per * (8 if up else 1))
+            for p in range(8 if up else 1):
+                jobs.append([w_off, off, per, cin_total, ci_off, cin, cout, mode, ck, ncc, nt, p if up else -1])
+                off += per
+
         first = True
         for c in self.all_convs():
-            w = self.view(c['w'])
             if c.get('fold'):
                 cs, cl = c['cs'], c['cin'] - c['cs']
                 lo_shape = [s // 2 for s in c['shape']]
-                c['wp_s'] = ops.pack_conv_weights_ex(w, c['shape'], 0, cs, 0, False, c.get('wp_s'))
-                c['wpd_s'] = ops.pack_conv_weights_ex(w, c['shape'], 0, cs, 1, False, c.get('wpd_s'))
-                c['wp_u'] = ops.pack_conv_weights_ex(w, lo_shape, cs, cl, 0, True, c.get('wp_u'))
-                c['wpd_u'] = ops.pack_conv_weights_ex(w, lo_shape, cs, cl, 1, True, c.get('wpd_u'))
-                continue
-            c['wp'] = ops.pack_conv_weights(w, c['shape'], 0, c['wp'])
-            if not first:  # the first layer's input has no gradient
-                c['wpd'] = ops.pack_conv_weights(w, c['shape'], 1, c['wpd'])
+                add(c, 'wp_s', c['shape'], 0, cs, 0, False)
+                add(c, 'wpd_s', c['shape'], 0, cs, 1, False)
+                add(c, 'wp_u', lo_shape, cs, cl, 0, True)
+                add(c, 'wpd_u', lo_shape, cs, cl, 1, True)
+            else:
+                add(c, 'wp', c['shape'], 0, c['cin'], 0, False)
+                if not first:  # the first layer's input has no gradient
+                    add(c, 'wpd', c['shape'], 0, c['cin'], 1, False)
             first = False
+        self._packed = torch.empty(off, dtype=torch.float32, device=self.device)
+        self._jobs = torch.tensor(jobs, dtype=torch.int64, device=self.device)
+        for c in self.all_convs():
+            for key in ('wp', 'wpd', 'wp_s', 'wpd_s', 'wp_u', 'wpd_u'):
+                if key + '_off' in c:
+                    o, n = c[key + '_off']
+                    c[key] = self._packed[o:o + n]
+
+    def repack(self):
+        """refresh the MFMA-fragment-ordered copies of ALL conv kernels in one launch (after init / optimizer step /
+        load)"""
+        from . import _lib
+        if getattr(self, '_jobs', None) is None:
+            self._pack_jobs()
+        _lib.check(_lib.load().synthsr_conv3d_pack_all(_lib.ptr(self.params), _lib.ptr(self._packed),
+                                                       _lib.ptr(self._jobs), int(self._jobs.shape[0]), _lib.stream()),
+                   'conv3d_pack_all')
 
     def state_dict(self):
         sd = {nm: self.view(nm).detach().cpu().clone() for nm, _, _ in self.specs}
@@ -305,6 +343,7 @@ class UNet3D:
         L = self.nb_levels
         G = self.grads
         G.zero_()
+        self._pending_bn = None
         low, bn = self.saved['last']
         C = low.shape[3]
         g = self.buf('gA', list(low.shape))
@@ -323,7 +362,7 @@ class UNet3D:
                 # all convs but the first: regular; the first one through the folded kernels
                 g = self._convs_backward(g, None, d['convs'][1:], acts[1:], acts[0], need_dx=True, tag='d%d' % k)
                 c0 = d['convs'][0]
-                dz = ops.elu_bwd(g, acts[0], dbias=self.view(c0['b'], self.grads), out=self.buf('dz', list(acts[0].shape)))
+                dz = self._elu_backward(g, acts[0], None, self.view(c0['b'], self.grads))
                 dW = self.view(c0['w'], self.grads)
                 ops.conv3d_wgrad_part(skip, dz, dW, 0)
                 ops.conv3d_up_wgrad(lo_bn, dz, self.buf('dwc', [8, 27, Cl, c0['cout']]), dW, Cs)
@@ -350,17 +389,28 @@ class UNet3D:
         return G
 
     def _bn_backward(self, g, x, bn):
+        """pass 1 (channel sums = dbeta | dgamma); pass 2 is fused into the ELU backward of the conv that produced x"""
         off = self.offsets[bn['beta']][0]
         sums = self.grads[off:off + 2 * bn['C']]  # [dbeta | dgamma]
-        return ops.bn_bwd(g, x, self._stats(bn), self.view(bn['gamma']), sums,
-                          out=self.buf('gbn', list(x.shape)))
+        ops.bn_reduce_bwd(g, x, self._stats(bn), sums)
+        self._pending_bn = (bn, sums)
+        return g
+
+    def _elu_backward(self, g, y, dy2, dbias):
+        """ELU backward of a conv output y; consumes a pending BN backward (y was the BN input)"""
+        out = self.buf('dz', list(y.shape))
+        pend, self._pending_bn = self._pending_bn, None
+        if pend is not None:
+            bn, sums = pend
+            return ops.bn_elu_bwd(g, y, self._stats(bn), self.view(bn['gamma']), sums, dy2=dy2, dbias=dbias, out=out)
+        return ops.elu_bwd(g, y, dy2=dy2, dbias=dbias, out=out)
 
     def _convs_backward(self, g, g2, convs, acts, x_in, need_dx, tag):
         """g (+g2) = gradient w.r.t. the output of the last conv's ELU. Returns gradient w.r.t. x_in (or None)."""
         for j in range(len(convs) - 1, -1, -1):
             c = convs[j]
             y = acts[j]
-            dz = ops.elu_bwd(g, y, dy2=g2, dbias=self.view(c['b'], self.grads), out=self.buf('dz', list(y.shape)))
+            dz = self._elu_backward(g, y, g2, self.view(c['b'], self.grads))
             g2 = None
             xin = acts[j - 1] if j > 0 else x_in
             ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads))
