@@ -108,6 +108,8 @@ def main():
     ap.add_argument('--size', type=int, default=160)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-size', type=int, default=96)
+    ap.add_argument('--force-allreduce', action='store_true',
+                    help='initialise RCCL and run the bucketed gradient all-reduce even at world size 1 (path test)')
     args = ap.parse_args()
 
     import torch
@@ -124,7 +126,9 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node N for --gpus N'
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_allreduce:
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     S = args.size
@@ -142,7 +146,7 @@ def main():
     if world > 1:
         dist.broadcast(net.params, 0)
         net.repack()
-    tr = Trainer(bg, net, lr=1e-4, distributed=world > 1)
+    tr = Trainer(bg, net, lr=1e-4, distributed=world > 1 or args.force_allreduce, force_allreduce=args.force_allreduce)
     tr.make_labels_resident(pool)
     pick = np.random.default_rng(rank)
 
@@ -210,7 +214,7 @@ def main():
             except Exception as ex:  # the baseline is a reported number, never a reason to lose the GPU measurement
                 out['cpu_baseline'] = {'value': None, 'error': repr(ex)}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_allreduce:
         dist.barrier()
         dist.destroy_process_group()
 

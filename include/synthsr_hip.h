@@ -154,14 +154,17 @@ int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_
 int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
                             int Cin, int Cout, synthsr_stream_t stream);
 
-/* launch geometry the kernels will use: out = {chunk width CK, #ci chunks, n-tiles per workgroup, #n chunks, MT, ksplit} */
-int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int out[6]);
-/* packs every layer of a network in ONE launch.  jobs_dev: int64 [njobs][12] = {w_off, dst_off, count, cin_total,
- * ci_off, cin, cout, mode, ck, ncc, nt, parity(-1 plain)}; w_off / dst_off are float offsets into params / packed */
+/* launch geometry the kernels will use: out = {chunk width CK, #ci chunks, n-tiles per workgroup, #n chunks, MT, ksplit,
+ * NV (output channels kept on the vector ALUs), floats per packed weight set} */
+int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int64_t out[8]);
+/* packs every layer of a network in ONE launch.  jobs_dev: int64 [njobs][14] = {w_off, dst_off, count, cin_total,
+ * ci_off, cin, cout, mode, ck, ncc, nt, parity(-1 plain), nv, mfma_count}; w_off / dst_off are float offsets */
 int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* jobs_dev, int njobs,
                             synthsr_stream_t stream);
 
-/* tuning / A-B switch, process-wide: option 0 = use the persistent forward kernel on the large levels (default 1) */
+/* tuning / A-B switch, process-wide: option 0 = persistent forward kernel on the large levels (default 1),
+ * 1 = diagnostic ablation mask, 2 = force MT, 3 = EXPERIMENTAL MFMA+VALU co-execution for Cout % 16 == 8 (default 0).  Options
+ * that change the launch geometry must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
 
 /* weight gradient: dw[3][3][3][Cin][Cout] += sum_v in[v+t-1][ci] * dout[v][co]   (dw must be zeroed by caller) */

@@ -44,9 +44,41 @@ __device__ __forceinline__ int up_axis_taps(int p, int s, int t[2]) {
 
 // w: Keras kernel [27][Cin_total][Cout]; the layer (or layer part) uses input channels [ci_off, ci_off+Cin).
 // parity < 0: plain weights.  parity 0..7: combined weights of the nearest-upsample folding in 27-slot form.
-__device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
-                                            int Cout, int mode, int CK, int ncc, int NT, int parity) {
+// value of the effective weight W_eff[tap][cie][coe] of a (possibly transposed / parity-folded) layer part
+__device__ __forceinline__ float weight_value(const float* __restrict__ w, int tap, int cie, int coe, int Cin_total,
+                                              int ci_off, int Cin, int Cout, int mode, int parity) {
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
+  if (cie >= CinE || coe >= CoutE) return 0.f;
+  const int slot = mode ? 26 - tap : tap;                            // tap slot in forward orientation
+  const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;  // layer channel indices
+  if (parity < 0) return w[((int64_t)slot * Cin_total + ci) * Cout + co];
+  int tz[2], ty[2], tx[2];
+  const int nz = up_axis_taps((parity >> 2) & 1, slot / 9, tz);
+  const int ny = up_axis_taps((parity >> 1) & 1, (slot / 3) % 3, ty);
+  const int nx = up_axis_taps(parity & 1, slot % 3, tx);
+  float v = 0.f;
+  for (int a = 0; a < nz; ++a)
+    for (int b = 0; b < ny; ++b)
+      for (int c = 0; c < nx; ++c) v += w[((int64_t)((tz[a] * 3 + ty[b]) * 3 + tx[c]) * Cin_total + ci) * Cout + co];
+  return v;
+}
+
+// packed layout of one weight set: MFMA section [nc][cc][tap][cg][nt][lane][2] (B fragments), followed — when the layer
+// keeps NV output channels on the vector ALUs — by the VALU section [cc][tap][ci (CK)][NV] (wave-uniform scalar loads)
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
+                                            int Cout, int mode, int CK, int ncc, int NT, int parity, int NV,
+                                            int64_t mfma_count) {
+  if (idx >= mfma_count) {
+    int64_t r = idx - mfma_count;
+    const int v = (int)(r % NV);
+    r /= NV;
+    const int cil = (int)(r % CK);
+    r /= CK;
+    const int tap = (int)(r % 27);
+    const int cc = (int)(r / 27);
+    const int coutE = mode ? Cin : Cout;
+    return weight_value(w, tap, cc * CK + cil, coutE - NV + v, Cin_total, ci_off, Cin, Cout, mode, parity);
+  }
   const int NCG = CK / 8;
   int64_t r = idx;
   const int s = (int)(r & 1);
@@ -64,36 +96,22 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t
   const int kq = lane >> 4, j = lane & 15;
   const int cie = cc * CK + cg * 8 + 2 * kq + s;
   const int coe = (nc * NT + nt) * 16 + j;
-  float v = 0.f;
-  if (cie < CinE && coe < CoutE) {
-    const int slot = mode ? 26 - tap : tap;                            // tap slot in forward orientation
-    const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;  // layer channel indices
-    if (parity < 0) {
-      v = w[((int64_t)slot * Cin_total + ci) * Cout + co];
-    } else {
-      int tz[2], ty[2], tx[2];
-      const int nz = up_axis_taps((parity >> 2) & 1, slot / 9, tz);
-      const int ny = up_axis_taps((parity >> 1) & 1, (slot / 3) % 3, ty);
-      const int nx = up_axis_taps(parity & 1, slot % 3, tx);
-      for (int a = 0; a < nz; ++a)
-        for (int b = 0; b < ny; ++b)
-          for (int c = 0; c < nx; ++c)
-            v += w[((int64_t)((tz[a] * 3 + ty[b]) * 3 + tx[c]) * Cin_total + ci) * Cout + co];
-    }
-  }
-  return v;
+  const int coutE = mode ? Cin : Cout;
+  if (coe >= coutE - NV) return 0.f;  // channels owned by the VALU section
+  return weight_value(w, tap, cie, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
 }
 
 __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin_total, int ci_off, int Cin,
-                            int Cout, int mode, int CK, int ncc, int NT, int nchunks, int parity, int64_t total) {
+                            int Cout, int mode, int CK, int ncc, int NT, int nchunks, int parity, int NV,
+                            int64_t mfma_count, int64_t total) {
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x)
-    packed[idx] = pack_value(w, idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, NT, parity);
+    packed[idx] = pack_value(w, idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, NT, parity, NV, mfma_count);
 }
 
 // one launch for every layer of the network: jobs[j] = {w_off, dst_off, count, cin_total, ci_off, cin, cout, mode, ck,
-// ncc, nt, parity} (int64 each), blockIdx.y = job
-constexpr int PACK_JOB_FIELDS = 12;
+// ncc, nt, parity, nv, mfma_count} (int64 each), blockIdx.y = job
+constexpr int PACK_JOB_FIELDS = 14;
 __global__ void pack_all_kernel(const float* __restrict__ params, float* __restrict__ packed,
                                 const int64_t* __restrict__ jobs) {
   const int64_t* jb = jobs + (int64_t)blockIdx.y * PACK_JOB_FIELDS;
@@ -101,10 +119,11 @@ __global__ void pack_all_kernel(const float* __restrict__ params, float* __restr
   float* dst = packed + jb[1];
   const int64_t count = jb[2];
   const int cin_total = (int)jb[3], ci_off = (int)jb[4], cin = (int)jb[5], cout = (int)jb[6], mode = (int)jb[7],
-            ck = (int)jb[8], ncc = (int)jb[9], nt = (int)jb[10], parity = (int)jb[11];
+            ck = (int)jb[8], ncc = (int)jb[9], nt = (int)jb[10], parity = (int)jb[11], nv = (int)jb[12];
+  const int64_t mfma_count = jb[13];
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < count;
        idx += (int64_t)gridDim.x * blockDim.x)
-    dst[idx] = pack_value(w, idx, cin_total, ci_off, cin, cout, mode, ck, ncc, nt, parity);
+    dst[idx] = pack_value(w, idx, cin_total, ci_off, cin, cout, mode, ck, ncc, nt, parity, nv, mfma_count);
 }
 
 // dW of the up-sampled input channels from the 8 per-parity 27-slot gradients: every original tap t belongs to exactly
@@ -186,6 +205,7 @@ struct ConvExt {
                        // the 8 parities, strided INPUT, one accumulated output)
   const float* addend; // mode 1: added before bias/activation, indexed like the output
   int64_t wstride;     // packed-weight stride between parities
+  int64_t valu_off;    // offset of the VALU weight section inside one packed weight set
 };
 
 __host__ __device__ inline uint32_t up_tapmask(int p, bool flipped) {
@@ -203,7 +223,7 @@ __host__ __device__ inline uint32_t up_tapmask(int p, bool flipped) {
   return m;
 }
 
-template <int CK, int NT, int MT, bool KSPLIT>
+template <int CK, int NT, int MT, bool KSPLIT, int NV>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int D0, int D1, int D2, int Cin, int Cout, int ncc,
@@ -236,6 +256,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // vector-ALU share (NV > 0): lane l owns voxel (z = wave, y = l>>4, x = l&15) of the tile and accumulates the last
+  // NV output channels with v_fma, weights from SGPRs (VALU section of the packed buffer), in the shadow of the MFMAs
+  static_assert(NV == 0 || (MT == 4 && !KSPLIT && CK == 24), "VALU share needs the 4x4x16 tile");
+  float accv[NV > 0 ? NV : 1];
+#pragma unroll
+  for (int v = 0; v < (NV > 0 ? NV : 1); ++v) accv[v] = 0.f;
+  const int vbase = ((wave * FH1 + (lane >> 4)) * FH2 + (lane & 15)) * CKP;
 
   const int li = lane & 15, kq = lane >> 4;
   int a_base[MT];
@@ -304,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
     __syncthreads();
 
     const float* wc = wl + (size_t)cc * 27 * NCG * NT * 128 + (size_t)par * ext.wstride;
+    const float* wvc = wp + ext.valu_off + (size_t)par * ext.wstride + (size_t)cc * 27 * CK * (NV > 0 ? NV : 1);
     // Software pipeline, pinned with sched_barrier so that hipcc cannot sink the prefetches next to their uses:
     //   B fragments of the next active tap are requested at the top of a tap (one L2 round trip hidden behind
     //   16*NCG*NT MFMAs), A fragments of step (t,g)+1 are read from LDS before the MFMAs of step (t,g).
@@ -316,10 +345,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
       for (int n = 0; n < NT; ++n)
         bcur[g][n] = *reinterpret_cast<const float2*>(wc + (size_t)tap * NCG * NT * 128 + (g * NT + n) * 128);
     float2 acur[MT], anext[MT];
+    float4 xcur[2], xnext[2];
     {
       const int o = tap_off(tap);
 #pragma unroll
       for (int m = 0; m < MT; ++m) acur[m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + o]);
+      if constexpr (NV > 0) {
+        xcur[0] = *reinterpret_cast<const float4*>(&lds[vbase + o]);
+        xcur[1] = *reinterpret_cast<const float4*>(&lds[vbase + o + 4]);
+      }
     }
     while (tap < 27) {
       const uint32_t rem = (tap + 1 < 27) ? (tapmask >> (tap + 1)) : 0u;
@@ -340,7 +374,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
         if (!(dbg & 2))
 #pragma unroll
           for (int m = 0; m < MT; ++m) anext[m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + noff]);
+        if constexpr (NV > 0) {
+          xnext[0] = *reinterpret_cast<const float4*>(&lds[vbase + noff]);
+          xnext[1] = *reinterpret_cast<const float4*>(&lds[vbase + noff + 4]);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NV > 0) {  // 8 ci x NV co v_fma per lane; weights are wave-uniform -> scalar loads
+          const float* wv = wvc + ((size_t)tap * CK + g * 8) * NV;
+          const float xs[8] = {xcur[0].x, xcur[0].y, xcur[0].z, xcur[0].w, xcur[1].x, xcur[1].y, xcur[1].z, xcur[1].w};
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) accv[v] = fmaf(xs[c], wv[c * NV + v], accv[v]);
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -351,9 +397,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m].y, bcur[g][n].y, acc[m][n], 0, 0, 0);
+        if constexpr (NV > 0) {  // interleave: one MFMA, then its share of the packed v_fma (issued in the MFMA's shadow)
+#pragma unroll
+          for (int q = 0; q < 2 * MT * NT; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (8 * NV / 2) / (2 * MT * NT), 0);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MT; ++m) acur[m] = anext[m];
+        if constexpr (NV > 0) {
+          xcur[0] = xnext[0];
+          xcur[1] = xnext[1];
+        }
       }
 #pragma unroll
       for (int g = 0; g < NCG; ++g)
@@ -373,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = (nc * NT + n) * 16 + li;
-        if (co >= Cout) continue;
+        if (co >= Cout - NV) continue;
         const float bv = (!KSPLIT && bias) ? bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -392,6 +449,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
             }
           }
         }
+      }
+    }
+  }
+  if constexpr (NV > 0) {  // the lane's own voxel, channels Cout-NV .. Cout-1
+    const int vy = y0 + (lane >> 4), vx = x0 + (lane & 15);
+    if (gz < D0 && vy < D1 && vx < D2 && !(dbg & 8)) {
+      const int os = (ext.mode == 1) ? 2 : 1;
+      const size_t oidx = (((size_t)(gz * os + ((opar >> 2) & 1)) * (D1 * os) + (vy * os + ((opar >> 1) & 1))) * (D2 * os) +
+                           (vx * os + (opar & 1))) * Cout + (Cout - NV);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float r = accv[v] + (bias ? bias[Cout - NV + v] : 0.f);
+        if (ext.addend) r += ext.addend[oidx + v];
+        if (act == 1) r = r > 0.f ? r : expm1f(r);
+        out[oidx + v] = r;
       }
     }
   }
@@ -794,10 +866,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
 
 static int g_persist = 1;
 static int g_force_mt = 0;
+static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout % 16 == 8 remainder channels on the
+                          // vector ALUs.  Correct, but hipcc serialises the scalar weight loads / v_pk_fma block behind
+                          // the MFMAs, so it is slower than padding to 32 columns until the issue order is hand-pinned.
 static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
 
 struct FwdPlan {
-  int nt, mt, ksplit, nchunks, ncc, ck, persist;
+  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv;
+  int64_t mfma_count() const { return (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128; }
+  int64_t count() const { return mfma_count() + (int64_t)ncc * 27 * ck * nv; }
 };
 
 // Launch geometry for one layer: enough workgroups to fill 256 CUs x 2 even on the deep, small levels.
@@ -816,9 +893,18 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
   p.nchunks = cdiv(ntiles, max_nt);
   p.nt = cdiv(ntiles, p.nchunks);
   p.ksplit = 1;
-  p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist) ? 1 : 0;
+  p.nv = 0;
+  // MFMA + VALU co-execution: the matrix and vector pipes of a SIMD run concurrently, so instead of padding
+  // Cout = 16 a + 8 to 16 (a + 1) MFMA columns (25 % waste at Cout = 24) the last 8 output channels are computed with
+  // v_fma (weights from SGPRs, activations from the same LDS tile) in the shadow of the MFMAs of the first 16 a.
+  if (g_hybrid && p.ck == 24 && p.mt == 4 && (Cout % 16) == 8 && Cout >= 24 && ntiles <= 5) {
+    p.nv = 8;
+    p.nchunks = 1;
+    p.nt = (Cout - 8) / 16;
+  }
+  p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist && p.nv == 0) ? 1 : 0;
   const int64_t w = wgs(p.mt, p.nt);
-  if (w < 512 && p.ncc >= 4 && plain) {
+  if (w < 512 && p.ncc >= 4 && plain && p.nv == 0) {
     int ks = (int)cdiv(1024, (int)w);
     if (ks > p.ncc / 2) ks = p.ncc / 2;
     if (ks > 8) ks = 8;
@@ -827,13 +913,13 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
   return p;
 }
 
-template <int CK, int NT, int MT, bool KS>
+template <int CK, int NT, int MT, bool KS, int NV = 0>
 int launch_fwd(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
                const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], MT), tiles2 = cdiv(s[2], FT2);
   const size_t smem = (size_t)FH0 * (MT + 2) * FH2 * (CK + 4) * sizeof(float);
   static bool attr_done = false;
-  auto kern = conv3d_fwd_kernel<CK, NT, MT, KS>;
+  auto kern = conv3d_fwd_kernel<CK, NT, MT, KS, NV>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
@@ -878,6 +964,9 @@ template <int CK, int NT>
 int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
                   const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
   if (pl.mt == 4) {
+    if constexpr (CK == 24 && NT <= 4) {
+      if (pl.nv == 8) return launch_fwd<CK, NT, 4, false, 8>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
+    }
     if constexpr (CK == 24 && NT <= 3) {
       if (pl.persist && ext.mode == 0) return launch_fwd_persist<NT>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
     }
@@ -956,13 +1045,14 @@ int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3]
     return SYNTHSR_EINVAL;
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
   const FwdPlan pl = plan_fwd(shape, CinE, CoutE, !up);
-  const int64_t per = (int64_t)pl.nchunks * pl.ncc * 27 * (pl.ck / 8) * pl.nt * 128;
+  const int64_t per = pl.count();
   const int64_t total = per * (up ? 8 : 1);
   if (!packed) return total;
   if (!w) return SYNTHSR_EINVAL;
   for (int p = 0; p < (up ? 8 : 1); ++p) {
     hipLaunchKernelGGL(pack_kernel, dim3(syn_grid(per, 256)), dim3(256), 0, (hipStream_t)stream, w, packed + p * per,
-                       Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.nt, pl.nchunks, up ? p : -1, per);
+                       Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.nt, pl.nchunks, up ? p : -1, pl.nv,
+                       pl.mfma_count(), per);
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   }
   return total;
@@ -973,7 +1063,7 @@ int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], i
   return synthsr_conv3d_pack_ex(w, packed, shape, Cin, 0, Cin, Cout, mode, 0, stream);
 }
 
-int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int out[6]) {
+int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int64_t out[8]) {
   if (!shape || !out || CinE < 1 || CoutE < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, CinE, CoutE, plain != 0);
   out[0] = pl.ck;
@@ -982,6 +1072,8 @@ int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int 
   out[3] = pl.nchunks;
   out[4] = pl.mt;
   out[5] = pl.ksplit;
+  out[6] = pl.nv;
+  out[7] = pl.count();
   return SYNTHSR_OK;
 }
 
@@ -1007,7 +1099,7 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
       (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
-  const ConvExt ext{0, nullptr, 0};
+  const ConvExt ext{0, nullptr, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
 }
@@ -1018,8 +1110,8 @@ int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* b
       lo_shape[2] < 1 || (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(lo_shape, Cl, Cout, false);
-  const int64_t wstride = (int64_t)pl.nchunks * pl.ncc * 27 * (pl.ck / 8) * pl.nt * 128;
-  const ConvExt ext{1, addend, wstride};
+  const int64_t wstride = pl.count();
+  const ConvExt ext{1, addend, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
 }
@@ -1031,8 +1123,8 @@ int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo
     return SYNTHSR_EINVAL;
   // effective conv: input channels = Cout (of the forward layer), output channels = Cl
   const FwdPlan pl = plan_fwd(lo_shape, Cout, Cl, false);
-  const int64_t wstride = (int64_t)pl.nchunks * pl.ncc * 27 * (pl.ck / 8) * pl.nt * 128;
-  const ConvExt ext{2, nullptr, wstride};
+  const int64_t wstride = pl.count();
+  const ConvExt ext{2, nullptr, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);
 }
@@ -1049,6 +1141,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 2) {
     g_force_mt = value;
+    return SYNTHSR_OK;
+  }
+  if (option == 3) {
+    g_hybrid = value ? 1 : 0;
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;

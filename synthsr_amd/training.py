@@ -24,7 +24,7 @@ class GradBucketReducer:
     the last layers first), overlapping communication with the remaining backward.  Works with any
     torch.distributed backend (RCCL on GPU, gloo in the CPU tests)."""
 
-    def __init__(self, flat_grads, bucket_elems=2 * 1024 * 1024, group=None):
+    def __init__(self, flat_grads, bucket_elems=2 * 1024 * 1024, group=None, force=False):
         import torch.distributed as dist
         self.dist = dist
         self.g = flat_grads
@@ -33,6 +33,7 @@ class GradBucketReducer:
         self.hi = flat_grads.numel()
         self.works = []
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.force = bool(force) and dist.is_available() and dist.is_initialized()  # run the collectives at world 1 too
 
     def start(self):
         self.hi = self.g.numel()
@@ -40,7 +41,7 @@ class GradBucketReducer:
 
     def ready(self, offset_lo, force=False):
         """every gradient at flat offset >= offset_lo is final"""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if offset_lo >= self.hi:
             return
@@ -61,13 +62,13 @@ class Trainer:
     """generator + U-Net + L1 + Adam for one rank"""
 
     def __init__(self, brain_generator, net, lr=1e-4, lr_decay=0.0, work_with_residual_channel=None,
-                 distributed=False, bucket_elems=2 * 1024 * 1024):
+                 distributed=False, bucket_elems=2 * 1024 * 1024, force_allreduce=False):
         self.bg = brain_generator
         self.gen = brain_generator.labels_to_image_model
         self.net = net
         self.lr, self.lr_decay = lr, lr_decay
         self.residual = work_with_residual_channel
-        self.reducer = GradBucketReducer(net.grads, bucket_elems) if distributed else None
+        self.reducer = GradBucketReducer(net.grads, bucket_elems, force=force_allreduce) if distributed else None
         self.resident_labels = None
 
     def make_labels_resident(self, label_maps):

@@ -168,20 +168,21 @@ class UNet3D:
         jobs, off = [], 0
 
         def plan(shape, cin_e, cout_e, plain):
-            out = (ctypes.c_int * 6)()
+            out = (ctypes.c_int64 * 8)()
             _lib.check(lib.synthsr_conv3d_plan(_lib.i3(shape), cin_e, cout_e, int(plain), out), 'conv3d_plan')
-            return list(out)
+            return [int(v) for v in out]
 
         def add(c, key, shape, ci_off, cin, mode, up):
             nonlocal off
             cin_total, cout = c['cin'], c['cout']
             cin_e, cout_e = (cout, cin) if mode else (cin, cout)
-            ck, ncc, nt, nchunks, _, _ = plan(shape, cin_e, cout_e, not up)
-            per = nchunks * ncc * 27 * (ck // 8) * nt * 128
+            ck, ncc, nt, nchunks, _, _, nv, per = plan(shape, cin_e, cout_e, not up)
+            mfma_count = nchunks * ncc * 27 * (ck // 8) * nt * 128
             w_off = self.offsets[c['w']][0]
             c[key + '_off'] = (off, per * (8 if up else 1))
             for p in range(8 if up else 1):
-                jobs.append([w_off, off, per, cin_total, ci_off, cin, cout, mode, ck, ncc, nt, p if up else -1])
+                jobs.append([w_off, off, per, cin_total, ci_off, cin, cout, mode, ck, ncc, nt, p if up else -1, nv,
+                             mfma_count])
                 off += per
 
         first = True

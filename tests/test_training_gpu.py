@@ -1,0 +1,88 @@
+"""GPU end-to-end: the `training()` entry point on NIfTI label maps (checkpoint + resume), BrainGenerator.generate_brain,
+and bench.py under torch.distributed.run with the RCCL gradient all-reduce path forced at world size 1."""
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_labels(tmp_path, n=2, shape=(40, 36, 48)):
+    from synthsr_amd.nifti import write_nifti
+    from synthsr_amd.synthetic import synthetic_label_map
+    d = tmp_path / 'labels'
+    d.mkdir()
+    for i in range(n):
+        write_nifti(str(d / ('brain%d_labels.nii.gz' % i)), synthetic_label_map(shape, 10 + i).astype(np.float32))
+    return str(d)
+
+
+def test_training_entry_point_checkpoint_and_resume(tmp_path):
+    import torch
+    from synthsr_amd.training import training
+    from synthsr_amd.synthetic import GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR
+    labels_dir = _write_labels(tmp_path)
+    np.save(tmp_path / 'gl.npy', GENERATION_LABELS)
+    np.save(tmp_path / 'gc.npy', GENERATION_CLASSES)
+    np.save(tmp_path / 'pm.npy', PRIOR_MEANS_T1_HR)
+    np.save(tmp_path / 'ps.npy', PRIOR_STDS_T1_HR)
+    model_dir = str(tmp_path / 'models')
+    kw = dict(path_generation_classes=str(tmp_path / 'gc.npy'), output_shape=32, n_levels=3, unet_feat_count=24,
+              nonlin_shape_factor=.125, bias_shape_factor=.125, steps_per_epoch=3, verbose=False)
+    net = training(labels_dir, model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'), str(tmp_path / 'gl.npy'),
+                   epochs=1, **kw)
+    assert net.iterations == 3
+    ck = os.path.join(model_dir, '001.npz')
+    assert os.path.exists(ck)
+    z = np.load(ck)
+    assert 'unet_conv_downarm_0_0/kernel' in z.files and z['unet_conv_downarm_0_0/kernel'].shape == (3, 3, 3, 2, 24)
+    assert 'unet_bn_down_0/moving_variance' in z.files and 'unet_likelihood/kernel' in z.files
+    log = open(os.path.join(model_dir, 'logs', 'loss.csv')).read().strip().split('\n')
+    assert len(log) == 1 and np.isfinite(float(log[0].split(',')[1]))
+    # resume from the checkpoint: epoch parsed from the file name, optimizer state restored
+    net2 = training(labels_dir, model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'), str(tmp_path / 'gl.npy'),
+                    epochs=2, checkpoint=ck, **kw)
+    assert net2.iterations == 6 and os.path.exists(os.path.join(model_dir, '002.npz'))
+    # argument validation mirrors the reference's exceptions
+    with pytest.raises(Exception):
+        training(labels_dir, model_dir, None, None, str(tmp_path / 'gl.npy'), output_channel=None)
+    with pytest.raises(Exception):
+        training(labels_dir, model_dir, None, None, str(tmp_path / 'gl.npy'), output_channel=3)
+
+
+def test_brain_generator_generate_brain(tmp_path):
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.synthetic import GENERATION_LABELS
+    labels_dir = _write_labels(tmp_path, 1, (40, 36, 48))
+    bg = BrainGenerator(labels_dir, None, None, 'uniform', GENERATION_LABELS, output_shape=32, output_div_by_n=8,
+                        build_reliability_maps=True)
+    image, target = bg.generate_brain()
+    assert image.shape == (32, 32, 32, 2) and target.shape == (32, 32, 32)
+    assert np.isfinite(image).all() and (image[..., 1] == 1).all() and 0 <= target.min() and target.max() <= 1 + 1e-6
+    assert bg.model_output_shape == [32, 32, 32, 2] and bg.n_dims == 3 and bg.aff.shape == (4, 4)
+    # padding margin (PadAroundCentre) and 2 input channels with registration error run through
+    bg2 = BrainGenerator(labels_dir, None, None, 'uniform', GENERATION_LABELS, output_shape=32, output_div_by_n=8,
+                         padding_margin=4, input_channels=[True, True], output_channel=1,
+                         data_res=np.array([[1., 1., 3.], [1., 1., 1.]]), thickness=np.array([[1., 1., 3.], [1., 1., 1.]]),
+                         downsample=True, build_reliability_maps=True)
+    im2, tg2 = bg2.generate_brain()
+    assert im2.shape == (32, 32, 32, 4) and np.isfinite(im2).all()
+    assert set(np.unique(np.round(im2[..., 1], 6)).tolist()) != {1.0}  # channel 0 is down-sampled in z: sparse map
+
+
+def test_bench_under_torchrun_with_forced_allreduce():
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '3',
+           '--warmup', '1', '--size', '64', '--no-cpu-baseline', '--force-allreduce']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and np.isfinite(d['final_loss'])
+    assert d['roofline']['bound'] == 'mfma' and 0 < d['roofline']['frac'] < 1
