@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--size', type=int, default=160)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-size', type=int, default=96)
+    ap.add_argument('--fold', default='auto', help="nearest-upsample folding of the decoder convs: auto | all | none")
     ap.add_argument('--force-allreduce', action='store_true',
                     help='initialise RCCL and run the bucketed gradient all-reduce even at world size 1 (path test)')
     args = ap.parse_args()
@@ -142,7 +143,8 @@ def main():
                         label_maps=pool, rng=rng)  # = training() defaults, SynthSR/training.py:57-73
     bg.labels_to_image_model.seed(0, rank)
     net = unet(24, bg.model_output_shape, 5, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
-               batch_norm=-1, activation='elu', seed=0)
+               batch_norm=-1, activation='elu', seed=0,
+               fold_upsample={'auto': 'auto', 'all': True, 'none': False}[args.fold])
     if world > 1:
         dist.broadcast(net.params, 0)
         net.repack()
@@ -173,6 +175,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     final_loss = float(loss.item())
+    if not np.isfinite(final_loss):  # tf.debugging.check_numerics of the reference's IdentityLoss
+        raise FloatingPointError('non-finite loss after %d steps: the measurement is invalid' % args.steps)
 
     if rank == 0:
         # per-kernel aggregation of the conv launches recorded inside the timed region

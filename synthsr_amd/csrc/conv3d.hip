@@ -515,9 +515,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
   };
-  auto decode = [&](int item, int& z0, int& y0, int& x0, int& cc) {
-    const int t = item / ncc;
-    cc = item - t * ncc;
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
     const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
     z0 = t0 * FT0;
     y0 = t1 * FT1;
@@ -526,18 +524,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
 
   f32x4 acc[MT][NT];
   float4 stg[NIT];
-  int item = my_pos;
-  if (item >= nitems) return;
-  int z0, y0, x0, cc;
-  decode(item, z0, y0, x0, cc);
+  // items of this workgroup: its tiles (my_pos, my_pos + G, ...), and for each tile ALL channel chunks in order, so that
+  // the accumulators of a tile stay in this workgroup's registers
+  int tile = my_pos;
+  if (tile >= ntiles) return;
+  (void)nitems;
+  int z0, y0, x0, cc = 0;
+  tile_origin(tile, z0, y0, x0);
 #pragma unroll
   for (int k = 0; k < NIT; ++k) stg[k] = halo_load(k, z0, y0, x0, cc);
 
   while (true) {
-    const int nitem = item + G;
-    const bool has_next = nitem < nitems;
-    int nz0 = 0, ny0 = 0, nx0 = 0, ncc_ = 0;
-    if (has_next) decode(nitem, nz0, ny0, nx0, ncc_);
+    const int ncc_ = (cc + 1 < ncc) ? cc + 1 : 0;
+    const int ntile = (cc + 1 < ncc) ? tile : tile + G;
+    const bool has_next = ntile < ntiles;
+    int nz0 = z0, ny0 = y0, nx0 = x0;
+    if (has_next && ntile != tile) tile_origin(ntile, nz0, ny0, nx0);
     if (cc == 0) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
         store_tile_rows<NT, MT>(acc, lds + wave * (16 * NT * 16), out, bias, act, nc, gz, y0, x0, D1, D2, Cout, lane);
     }
     if (!has_next) break;
-    item = nitem;
+    tile = ntile;
     z0 = nz0;
     y0 = ny0;
     x0 = nx0;

@@ -69,10 +69,10 @@ class UNet3D:
                 c_in = self.feats[l]
             c = self.feats[l]
             bn = self._add_bn('%s_bn_up_%d' % (self.prefix, k), c)
-            # nearest-upsample folding of the first conv of the stage (ops.conv3d_up): worth it where the low-res grid
-            # still fills the GPU; the deep stages keep the materialised concat + split-K path
+            # nearest-upsample folding of the first conv of the stage (ops.conv3d_up): 3.4x fewer FLOPs on the up-sampled
+            # channels; measured faster on every level of the 160^3 network (parity = grid.z keeps the GPU filled)
             lo_vox = int(np.prod(self.shapes[l + 1]))
-            fold = (lo_vox >= 32768) if fold_upsample == 'auto' else bool(fold_upsample)
+            fold = (lo_vox >= 512) if fold_upsample == 'auto' else bool(fold_upsample)
             convs[0]['fold'] = fold
             convs[0]['cs'] = self.feats[l]
             self.dec.append(dict(convs=convs, bn=bn, level=l, fold=fold))

@@ -29,6 +29,8 @@ CONV_CASES = [  # (shape, Cin, Cout)
     ((6, 5, 17), 1, 24), ((4, 8, 16), 96, 96), ((3, 4, 5), 192, 384), ((4, 4, 4), 576, 192), ((10, 10, 10), 24, 1 * 16),
     ((12, 12, 12), 8, 16), ((6, 6, 33), 144, 48), ((10, 10, 10), 384, 384), ((20, 20, 20), 96, 192),
     ((40, 40, 40), 48, 96), ((48, 40, 64), 24, 24), ((32, 48, 64), 72, 24),
+    # large enough (>= 768 tiles) for the persistent forward kernel: 1, 2 and 3 input-channel chunks, ragged edges
+    ((64, 64, 64), 24, 24), ((40, 64, 80), 48, 48), ((32, 64, 96), 72, 24), ((61, 50, 70), 48, 24),
 ]
 
 
