@@ -25,6 +25,8 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 inline int ck_for(int Cin) { return (Cin % 24 == 0) ? 24 : 8; }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // -------------------------------------------------------------------------------------------- pack
@@ -485,8 +487,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
   constexpr int CK = 24, MT = 4;
   constexpr int FT1 = MT, FH1 = MT + 2, FHV = FH0 * FH1 * FH2;
   constexpr int CKP = CK + 4, NCG = CK / 8, C4 = CK / 4;
-  constexpr int NIT = (FHV * C4 + 255) / 256;  // 16 halo float4 per thread
-  static_assert(NIT <= 27, "one halo load per tap");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int nc = blockIdx.y;
@@ -501,19 +501,55 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
   for (int m = 0; m < MT; ++m) a_base[m] = ((wave * FH1 + m) * FH2 + li) * CKP + 2 * kq;
   const float* wl = wp + (size_t)nc * ncc * 27 * NCG * NT * 128 + lane * 2;
 
-  // halo slot k of this thread: element f = tid + 256 k of the [FHV][C4] tile (recomputed, not kept in registers)
-  auto halo_load = [&](int k, int z0, int y0, int x0, int cc) -> float4 {
-    int tv = tid;
-    asm volatile("" : "+v"(tv));  // opaque: keeps the slot arithmetic inside the loop instead of 16 x 4 hoisted registers
-    const int f = tv + k * 256;
-    const int vox = f / C4, c4 = f - vox * C4;
-    const int hx = vox % FH2, hy = (vox / FH2) % FH1, hz = vox / (FH2 * FH1);
-    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-    const bool ok = (f < FHV * C4) & (gz >= 0) & (gz < D0) & (gy >= 0) & (gy < D1) & (gx >= 0) & (gx < D2);
-    const size_t off = ok ? ((((size_t)gz * D1 + gy) * D2 + gx) * Cin + cc * CK + c4 * 4) : 0;
-    float4 v = ld4(in + off);
-    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    return v;
+  // ---- VALU-lean addressing.  On CDNA4 every vector-ALU instruction takes ~3-4 cycles out of the SIMD's MFMA issue
+  // (tools/ubench/mfma_issue.hip), so the per-item address arithmetic is moved to the scalar unit:
+  //  * halo staging: in every z-plane of the 6x6x18 halo tile, thread t owns the same <= 3 (y, x, channel-quad) columns
+  //    j = t + 256 i of the plane's 648 float4.  Their byte offsets relative to the tile origin and their LDS addresses
+  //    are computed ONCE per kernel; per item only `offset + scalar` and a bit-mask validity test remain.  The loads are
+  //    raw buffer loads: soffset carries the z-plane (scalar), out-of-volume elements get an offset beyond
+  //    num_records and come back as zeros (hardware range check) -- no per-element clamping or selects.
+  //  * B fragments: buffer loads with voffset = lane*8, soffset = scalar (chunk, tap), immediate = (g, n).
+  constexpr int PLANE4 = FH1 * FH2 * C4;  // 648 float4 per halo z-plane
+  constexpr int NJ = (PLANE4 + 255) / 256;  // 3 columns per thread
+  constexpr int NLD = NJ * FH0;             // 18 halo loads per item
+  static_assert(NLD <= 27, "one halo load per tap");
+  constexpr uint32_t OOB = 0x80000000u;  // > num_records (launcher guarantees tensor bytes < 2^31)
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wp), 0, (int)((int64_t)gridDim.y * ncc * 27 * NCG * NT * 128 * 4), 0x00020000);
+  int rel[NJ], ldsa[NJ];
+  uint32_t cmask[NJ];  // one-hot (1 << hy) | (1 << (8 + hx)); all ones for j >= 648
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = tid + 256 * i;
+    const int hy = j / (FH2 * C4), r = j - hy * (FH2 * C4), hx = r / C4, c4 = r - hx * C4;
+    rel[i] = ((hy * D2 + hx) * Cin + c4 * 4) * 4;
+    ldsa[i] = ((hy * FH2 + hx) * CKP + c4 * 4);
+    cmask[i] = j < PLANE4 ? ((1u << hy) | (1u << (8 + hx))) : 0xFFFFFFFFu;
+  }
+  const int plane_bytes = D1 * D2 * Cin * 4;
+  // per item: voff[i] = byte offset of column i inside plane z (or OOB)
+  auto item_offsets = [&](int y0, int x0, int cc, uint32_t (&voff)[NJ]) {
+    // invalid local rows/columns of this tile (scalar): hy valid iff 0 <= y0-1+hy < D1
+    uint32_t bad = 0x80000000u;  // bit 31: always-invalid marker for j >= 648
+#pragma unroll
+    for (int h = 0; h < FH1; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH2; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (8 + h)) : 0u;
+    const int yx = (((y0 - 1) * D2 + (x0 - 1)) * Cin + cc * CK) * 4;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) voff[i] = (cmask[i] & bad) ? OOB : (uint32_t)(rel[i] + yx);
+  };
+  // halo load k = plane * NJ + i
+  auto halo_load = [&](int k, int z0, const uint32_t (&voff)[NJ]) -> float4 {
+    const int hz = k / NJ, i = k - hz * NJ;
+    const int gz = z0 - 1 + hz;
+    const bool pv = (unsigned)gz < (unsigned)D0;  // scalar
+    const uint32_t vo = pv ? voff[i] : OOB;
+    const int so = pv ? gz * plane_bytes : 0;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, so, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   };
   auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
     const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
@@ -521,9 +557,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
     y0 = t1 * FT1;
     x0 = t2 * FT2;
   };
+  auto bload = [&](int soff, int idx) -> float2 {  // idx = g*NT + n; immediates stay below 4096
+    const int hi = idx >> 2, lo = idx & 3;
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, lane * 8 + lo * 512, soff + hi * 2048, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+  };
 
   f32x4 acc[MT][NT];
-  float4 stg[NIT];
+  float4 stg[NLD];
   // items of this workgroup: its tiles (my_pos, my_pos + G, ...), and for each tile ALL channel chunks in order, so that
   // the accumulators of a tile stay in this workgroup's registers
   int tile = my_pos;
@@ -531,8 +572,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
   (void)nitems;
   int z0, y0, x0, cc = 0;
   tile_origin(tile, z0, y0, x0);
+  {
+    uint32_t voff[NJ];
+    item_offsets(y0, x0, cc, voff);
 #pragma unroll
-  for (int k = 0; k < NIT; ++k) stg[k] = halo_load(k, z0, y0, x0, cc);
+    for (int k = 0; k < NLD; ++k) stg[k] = halo_load(k, z0, voff);
+  }
 
   while (true) {
     const int ncc_ = (cc + 1 < ncc) ? cc + 1 : 0;
@@ -540,6 +585,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
     const bool has_next = ntile < ntiles;
     int nz0 = z0, ny0 = y0, nx0 = x0;
     if (has_next && ntile != tile) tile_origin(ntile, nz0, ny0, nx0);
+    uint32_t nvoff[NJ];
+    item_offsets(ny0, nx0, ncc_, nvoff);
     if (cc == 0) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -548,36 +595,37 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
     }
     __syncthreads();  // every wave has finished reading the previous item's tile
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      int tv = tid;
-      asm volatile("" : "+v"(tv));
-      const int f = tv + k * 256;
-      const int vox = f / C4, c4 = f - vox * C4;
-      if (f < FHV * C4) *reinterpret_cast<float4*>(&lds[vox * CKP + c4 * 4]) = stg[k];
+    for (int i = 0; i < NJ; ++i) {
+      if (i < NJ - 1 || tid + 256 * i < PLANE4) {
+#pragma unroll
+        for (int hz = 0; hz < FH0; ++hz)
+          *reinterpret_cast<float4*>(&lds[ldsa[i] + hz * (FH1 * FH2 * CKP)]) = stg[hz * NJ + i];
+      }
     }
     __syncthreads();
 
-    const float* wc = wl + (size_t)cc * 27 * NCG * NT * 128;
-    float2 bcur[NCG][NT], bnext[NCG][NT];
+    const int wsoff = ((nc * ncc + cc) * 27) * (NCG * NT * 512);  // bytes
+    // Register ping-pong, statically indexed (the tap loop is fully unrolled): fragments are prefetched into the set the
+    // MFMAs are NOT reading, so no v_mov copies follow the MFMAs.
+    float2 bb[2][NCG][NT];
+    float2 aa[2][MT];
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bcur[g][n] = *reinterpret_cast<const float2*>(wc + (g * NT + n) * 128);
-    float2 acur[MT], anext[MT];
+      for (int n = 0; n < NT; ++n) bb[0][g][n] = bload(wsoff, g * NT + n);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acur[m] = *reinterpret_cast<const float2*>(&lds[a_base[m]]);
+    for (int m = 0; m < MT; ++m) aa[0][m] = *reinterpret_cast<const float2*>(&lds[a_base[m]]);
 
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       if (tap + 1 < 27) {
-        const float* wn = wc + (size_t)(tap + 1) * NCG * NT * 128;
 #pragma unroll
         for (int g = 0; g < NCG; ++g)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bnext[g][n] = *reinterpret_cast<const float2*>(wn + (g * NT + n) * 128);
+          for (int n = 0; n < NT; ++n) bb[(tap + 1) & 1][g][n] = bload(wsoff + (tap + 1) * (NCG * NT * 512), g * NT + n);
       }
-      if (tap < NIT) {
-        if (has_next) stg[tap] = halo_load(tap, nz0, ny0, nx0, ncc_);  // wave-uniform branch
+      if (tap < NLD) {
+        if (has_next) stg[tap] = halo_load(tap, nz0, nvoff);  // wave-uniform branch
       }
       const int tn = tap + 1 < 27 ? tap + 1 : 26;
       const int toff = (((tap / 9) * FH1 + (tap / 3) % 3) * FH2 + tap % 3) * CKP;
@@ -585,28 +633,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
+        const int st = tap * NCG + g;  // compile-time after unrolling
         const int noff = (g + 1 < NCG) ? toff + (g + 1) * 8 : toff_n;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) anext[m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + noff]);
+        for (int m = 0; m < MT; ++m) aa[(st + 1) & 1][m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + noff]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m].x, bcur[g][n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[st & 1][m].x, bb[tap & 1][g][n].x, acc[m][n], 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m].y, bcur[g][n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[st & 1][m].y, bb[tap & 1][g][n].y, acc[m][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acur[m] = anext[m];
       }
-#pragma unroll
-      for (int g = 0; g < NCG; ++g)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bcur[g][n] = bnext[g][n];
     }
 
     if (cc == ncc - 1) {  // epilogue of this tile (Cout % 4 == 0 is guaranteed by the launcher)
