@@ -27,6 +27,16 @@ inline int ck_for(int Cin) { return (Cin % 24 == 0) ? 24 : 8; }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// ELU(alpha = 1) for the fused epilogues.  Vector-ALU instructions next to MFMAs are not free on gfx950 (see the
+// persistent kernel), so instead of libm's expm1f (~22 instructions) the negative branch is 2^(v log2 e) - 1 through
+// v_exp_f32, switched to a degree-5 Taylor polynomial on (-1/8, 0] where the subtraction would cancel.
+// |error| < 2e-7 absolute and < 2e-6 relative to expm1 (tests/test_unet_gpu.py::test_elu_epilogue_accuracy).
+__device__ __forceinline__ float elu_f(float v) {
+  const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f;
+  const float p = v * fmaf(v, fmaf(v, fmaf(v, fmaf(v, 1.f / 120.f, 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
+  const float n = v > -0.125f ? p : e;
+  return v > 0.f ? v : n;
+}
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // -------------------------------------------------------------------------------------------- pack
@@ -175,7 +185,7 @@ __device__ __forceinline__ void store_tile_rows(f32x4 (&acc)[MT][NT], float* sla
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[m][n][r] + bv;
-        if (act == 1) v = v > 0.f ? v : expm1f(v);
+        if (act == 1) v = elu_f(v);
         slab[(kq * 4 + r) * NW + n * 16 + li] = v;
       }
     }
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
             } else {
               float v = acc[m][n][r] + bv;
               if (ext.addend) v += ext.addend[oidx];
-              if (act == 1) v = v > 0.f ? v : expm1f(v);
+              if (act == 1) v = elu_f(v);
               out[oidx] = v;
             }
           }
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
       for (int v = 0; v < NV; ++v) {
         float r = accv[v] + (bias ? bias[Cout - NV + v] : 0.f);
         if (ext.addend) r += ext.addend[oidx + v];
-        if (act == 1) r = r > 0.f ? r : expm1f(r);
+        if (act == 1) r = elu_f(r);
         out[oidx + v] = r;
       }
     }
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, co
                                                        int C, int act) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float v = y[i] + (bias ? bias[i % C] : 0.f);
-    if (act == 1) v = v > 0.f ? v : expm1f(v);
+    if (act == 1) v = elu_f(v);
     y[i] = v;
   }
 }
@@ -909,6 +919,221 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
   }
 }
 
+// ---- VALU-lean weight gradient (CK = 24, Cout % 4 == 0, tensors < 2 GiB).  Same tiling and LDS layout as
+// conv3d_wgrad_kernel; what changes is everything next to the MFMAs (a vector-ALU instruction costs 3-4 cycles of
+// MFMA issue on gfx950, tools/ubench/mfma_issue.hip):
+//  * per-thread staging columns (global byte offset, LDS address, validity bit) are computed once per kernel; per tile
+//    only "offset or out-of-range" selects remain, z-planes / row pairs travel in the scalar soffset of raw buffer
+//    loads, zero padding comes from the hardware range check;
+//  * the 32 k-steps are fully unrolled: LDS reads use immediate offsets and the A/B fragments ping-pong between two
+//    statically indexed register sets (no copies).
+template <int NT, int MS, int NTAPS>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* __restrict__ in,
+                                                                   const float* __restrict__ dout,
+                                                                   float* __restrict__ dw, int D0, int D1, int D2,
+                                                                   int Cin, int Cout, int tiles0, int tiles1, int tiles2,
+                                                                   WgExt ext) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CK = 24;
+  float* lx = lds;              // [CK][WVPX]
+  float* ld = lds + CK * WVPX;  // [NT*16][WVPD]
+  constexpr int MR = NTAPS * CK;
+  constexpr int MTILES = (MR + 15) / 16;
+  constexpr int MTP = (MTILES + MS - 1) / MS;
+  constexpr int MTW = (MTP + 3) / 4;
+  constexpr int C4 = CK / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  static_assert(NTAPS == 27 || MS == 1, "the parity variant does not split the GEMM rows");
+  const int par = (NTAPS == 8) ? (int)(blockIdx.y & 7) : 0;
+  const int cc = (NTAPS == 8) ? (int)(blockIdx.y >> 3) : (int)(blockIdx.y / MS);
+  const int mt0 = (NTAPS == 8) ? 0 : (int)(blockIdx.y % MS) * MTP;
+  const uint32_t tapmask = (NTAPS == 8) ? up_tapmask(par, false) : 0x7FFFFFFu;
+  auto nth_tap = [&](int i) {
+    if (NTAPS == 27) return i;
+    uint32_t m = tapmask;
+    for (int k = 0; k < i; ++k) m &= m - 1;
+    return (int)__builtin_ctz(m);
+  };
+  const int ds = (NTAPS == 8) ? 2 : 1;
+  const int dp0 = (par >> 2) & 1, dp1 = (par >> 1) & 1, dp2 = par & 1;
+  const int co0 = blockIdx.z * NT * 16;
+  constexpr uint32_t OOB = 0x80000000u;
+
+  f32x4 acc[MTW][NT];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // A rows r = (mt0 + wave + 4m)*16 + li -> (tap, ci); the k index of the lane (kq) is folded into the base
+  int a_base[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    int r = (mt0 + wave + 4 * m) * 16 + li;
+    if (r >= MR) r = MR - 1;
+    const int ti = r / CK, cil = r - ti * CK;
+    const int tap = nth_tap(ti);
+    a_base[m] = cil * WVPX + ((tap / 9) * WH1 + (tap / 3) % 3) * WH2 + tap % 3 + kq;
+  }
+  const int b_base = li * WVPD + kq;
+
+  // ---- x halo: 4 z-planes of 6 x 18 voxels x 6 channel quads = 648 float4 per plane, 3 columns per thread
+  constexpr int PL4 = WH1 * WH2 * C4, NJ = (PL4 + 255) / 256, NX = NJ * WH0;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  int xrel[NJ], xlds[NJ];
+  uint32_t xmask[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = tid + 256 * i;
+    const int hy = j / (WH2 * C4), r = j - hy * (WH2 * C4), hx = r / C4, c4 = r - hx * C4;
+    xrel[i] = ((hy * D2 + hx) * Cin + c4 * 4) * 4;
+    xlds[i] = (c4 * 4) * WVPX + hy * WH2 + hx;
+    xmask[i] = j < PL4 ? ((1u << hy) | (1u << (8 + hx))) : 0xFFFFFFFFu;
+  }
+  const int xplane = D1 * D2 * Cin * 4;
+  // ---- dy tile: 8 (z,y) rows of 16 voxels x QN channel quads; row pieces are contiguous in memory
+  constexpr int QN = NT * 4, RQ = 16 * QN, ND = QN / 2;
+  constexpr int P = (QN == 12) ? 3 : 1;      // period of the (row, column) pattern in i
+  constexpr int RPP = 256 * P / RQ;          // rows advanced per period (4, 2, 4)
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dout), 0, (int)((int64_t)D0 * D1 * D2 * ds * ds * ds * Cout * 4), 0x00020000);
+  const int dsx = ds * Cout * 4, dsy = ds * (D2 * ds) * Cout * 4;  // byte strides of the dy view
+  const int64_t dsz = (int64_t)ds * (D1 * ds) * (D2 * ds) * Cout * 4;
+  const int dconst = ((dp0 * (D1 * ds) + dp1) * (D2 * ds) + dp2) * Cout * 4;
+  int drel[P], dlds[P];
+  uint32_t dmask[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int j = tid + 256 * p;
+    const int row = j / RQ, w = j - row * RQ, vx = w / QN, c4 = w - vx * QN;
+    drel[p] = row * dsy + vx * dsx + (co0 + c4 * 4) * 4;   // row < 4: vz = 0, vy = row
+    dlds[p] = (c4 * 4) * WVPD + row * WT2 + vx;
+    dmask[p] = (co0 + c4 * 4 < Cout) ? ((1u << row) | (1u << (8 + vx))) : 0xFFFFFFFFu;
+  }
+
+  const int ntiles = tiles0 * tiles1 * tiles2;
+  float4 sx[NX], sd[ND];
+  auto as_f4 = [](u32x4 v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); };
+  auto load_tile = [&](int t) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    const int z0 = t0 * WT0, y0 = t1 * WT1, x0 = t2 * WT2;
+    // x halo
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < WH1; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < WH2; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (8 + h)) : 0u;
+    const int yx = (((y0 - 1) * D2 + (x0 - 1)) * Cin + cc * CK) * 4;
+    uint32_t xo[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) xo[i] = (xmask[i] & bad) ? OOB : (uint32_t)(xrel[i] + yx);
+#pragma unroll
+    for (int hz = 0; hz < WH0; ++hz) {
+      const int gz = z0 - 1 + hz;
+      const bool pv = (unsigned)gz < (unsigned)D0;
+      const int so = pv ? gz * xplane : 0;
+#pragma unroll
+      for (int i = 0; i < NJ; ++i)
+        sx[hz * NJ + i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? xo[i] : OOB), so, 0));
+    }
+    // dy rows
+    uint32_t dbad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < WT1; ++h) dbad |= (y0 + h >= D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < WT2; ++h) dbad |= (x0 + h >= D2) ? (1u << (8 + h)) : 0u;
+    const int64_t dbase = (int64_t)z0 * dsz + (int64_t)y0 * dsy + (int64_t)x0 * dsx + dconst;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int p = i % P, q = i / P;
+      const int rowadd = q * RPP;            // rows 0..7: vz = rowadd >> 2 (+0), vy += rowadd & 3
+      const int vz = rowadd >> 2, dvy = rowadd & 3;
+      const bool pv = z0 + vz < D0;
+      // validity of vy + dvy: shift the y bits of the bad mask down by dvy
+      const uint32_t badq = ((dbad & 0xFFu) >> dvy) | (dbad & 0xFFFFFF00u);
+      const uint32_t vo = ((dmask[p] & badq) || !pv) ? OOB : (uint32_t)drel[p];
+      const int so = pv ? (int)(dbase + vz * dsz + (int64_t)dvy * dsy) : 0;
+      sd[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rdo, (int)vo, so, 0));
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      if (i < NJ - 1 || tid + 256 * i < PL4) {
+#pragma unroll
+        for (int hz = 0; hz < WH0; ++hz) {
+          float* d = lx + xlds[i] + hz * (WH1 * WH2);
+          const float4 v = sx[hz * NJ + i];
+          d[0] = v.x;
+          d[WVPX] = v.y;
+          d[2 * WVPX] = v.z;
+          d[3 * WVPX] = v.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int p = i % P, q = i / P;
+      float* d = ld + dlds[p] + q * RPP * WT2;
+      const float4 v = sd[i];
+      d[0] = v.x;
+      d[WVPD] = v.y;
+      d[2 * WVPD] = v.z;
+      d[3 * WVPD] = v.w;
+    }
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);  // lands while the 32 k-steps below run
+    float aa[2][MTW], bb[2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bb[0][n] = ld[b_base + n * 16 * WVPD];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) aa[0][m] = lx[a_base[m]];
+#pragma unroll
+    for (int ks = 0; ks < WTV / 4; ++ks) {
+      constexpr int LAST = WTV / 4 - 1;
+      const int kn = ks < LAST ? ks + 1 : LAST;
+      const int voff = ((kn >> 4) * WH1 + ((kn >> 2) & 3)) * WH2 + 4 * (kn & 3);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bb[(ks + 1) & 1][n] = ld[b_base + n * 16 * WVPD + kn * 4];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) aa[(ks + 1) & 1][m] = lx[a_base[m] + voff];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[ks & 1][m], bb[ks & 1][n], acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- flush: D row = (lane>>4)*4 + reg -> (tap, ci), col = lane&15 -> co
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (wave + 4 * m >= MTP) continue;
+      const int row = (mt0 + wave + 4 * m) * 16 + kq * 4 + r;
+      if (row >= MR) continue;
+      const int ti = row / CK, cil = row - ti * CK;
+      const int tap = nth_tap(ti);
+      const int ci = cc * CK + cil;
+      if (ci >= Cin) continue;
+      float* dwp = dw + (size_t)par * ext.dwstride;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int co = co0 + n * 16 + li;
+        if (co < Cout) atomicAdd(&dwp[((size_t)tap * ext.cin_total + ext.ci_off + ci) * Cout + co], acc[m][n][r]);
+      }
+    }
+  }
+}
+
 static int g_persist = 1;
 static int g_force_mt = 0;
 static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout % 16 == 8 remainder channels on the
@@ -1049,6 +1274,22 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   const size_t smem = ((size_t)CK * WVPX + (size_t)NT * 16 * WVPD) * sizeof(float);
+  if constexpr (CK == 24) {
+    const int dsc = (NTAPS == 8) ? 8 : 1;
+    const int64_t xbytes = (int64_t)s[0] * s[1] * s[2] * Cin * 4, dbytes = (int64_t)s[0] * s[1] * s[2] * dsc * Cout * 4;
+    if ((Cout % 4) == 0 && xbytes < (1ll << 31) && dbytes < (1ll << 31) && !(g_dbg & 16)) {
+      static bool lean_attr_done = false;
+      auto lkern = conv3d_wgrad_lean_kernel<NT, MS, NTAPS>;
+      if (!lean_attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lkern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        lean_attr_done = true;
+      }
+      hipLaunchKernelGGL(lkern, dim3(gx, ncc * ymul, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout,
+                         tiles0, tiles1, tiles2, ext);
+      return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+    }
+  }
   static bool attr_done = false;
   auto kern = conv3d_wgrad_kernel<CK, NT, MS, NTAPS>;
   if (!attr_done) {

@@ -76,6 +76,24 @@ def test_conv3d_identity_and_transpose_detecting(T):
         assert int((y != 0).sum()) == int((exp != 0).sum())  # nothing leaks into other channels / voxels
 
 
+@pytest.mark.parametrize('shape', [(6, 7, 19), (80, 80, 80)])  # plain and persistent kernels
+def test_elu_epilogue_accuracy(T, shape):
+    """the fused ELU (exp2-based, csrc/conv3d.hip elu_f) against expm1 in float64 through an identity convolution:
+    tolerance 2e-7 absolute, 2e-6 relative"""
+    torch = T
+    from synthsr_amd import ops
+    n = shape[0] * shape[1] * shape[2] * 24
+    x = torch.cat([-torch.logspace(-7, 1.2, n // 2), torch.randn(n - n // 2) * 3])[torch.randperm(n)].reshape(*shape, 24)
+    w = torch.zeros(3, 3, 3, 24, 24)
+    w[1, 1, 1] = torch.eye(24)
+    y = ops.conv3d(x.cuda(), ops.pack_conv_weights(w.cuda(), shape, 0), None, 24, act=1).cpu().double()
+    xd = x.double()
+    ref = torch.where(xd > 0, xd, torch.expm1(xd))
+    err = (y - ref).abs()
+    assert float(err.max()) < 2e-7
+    assert float((err / ref.abs().clamp_min(1e-30)).max()) < 2e-6
+
+
 @pytest.mark.parametrize('lo_shape,Cs,Cl,Cout', [((6, 5, 9), 24, 48, 24), ((4, 4, 8), 48, 96, 48), ((3, 2, 3), 24, 24, 48),
                                                  ((20, 20, 24), 24, 48, 24)])
 def test_upsample_folded_conv(T, lo_shape, Cs, Cl, Cout):
