@@ -677,6 +677,207 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
   }
 }
 
+// ---- VALU-lean forward kernel for the non-persistent cases (CK = 24, NT <= 3): deep levels (MT = 2, optional
+// split-K) and the nearest-upsample-folded parity convolutions (NTAPS = 8).  Same tile, LDS layout and packed weights
+// as conv3d_fwd_kernel; the address arithmetic is taken off the vector ALU as in the persistent kernel:
+//  * the tile of a workgroup is fixed, so the per-thread halo columns (byte offset incl. tile origin, LDS address,
+//    validity) are computed once; the channel chunk, the parity origin and the z-plane travel in the scalar soffset of
+//    raw buffer loads, zero padding is the hardware range check;
+//  * taps are unrolled statically (27, or the 2x2x2 window of a parity conv whose position inside the 3x3x3 stencil is a
+//    per-parity shift of the LDS base and of the scalar weight offset), so LDS reads and weight loads use immediates
+//    and the A/B fragments ping-pong between statically indexed register sets.
+template <int NT, int MT, bool KSPLIT, int NTAPS>
+__global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __restrict__ in,
+                                                                 const float* __restrict__ wp,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int D0, int D1, int D2, int Cin, int Cout, int ncc,
+                                                                 int tiles1, int tiles2, int act, ConvExt ext) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [FHV][CKP]
+  constexpr int CK = 24, FT1 = MT, FH1 = MT + 2, CKP = CK + 4, NCG = CK / 8, C4 = CK / 4;
+  constexpr int PL4 = FH1 * FH2 * C4, NJ = (PL4 + 255) / 256, NLD = NJ * FH0;
+  constexpr uint32_t OOB = 0x80000000u;
+  static_assert(NTAPS == 27 || !KSPLIT, "parity convs are not split over K");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int t;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, j = b >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int t2 = t % tiles2;
+  t /= tiles2;
+  const int t1 = t % tiles1;
+  const int t0 = t / tiles1;
+  const int z0 = t0 * FT0, y0 = t1 * FT1, x0 = t2 * FT2;
+  const int nc = blockIdx.y;
+  const int mode = (NTAPS == 8) ? ext.mode : 0;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, kq = lane >> 4;
+  int a_base[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a_base[m] = ((wave * FH1 + m) * FH2 + li) * CKP + 2 * kq;
+
+  // input view: conv-grid voxel g -> tensor voxel g*is + io (mode 2 reads one parity sub-lattice of the 2x tensor)
+  const int is = (mode == 2) ? 2 : 1;
+  const int sX = is * Cin * 4, sY = is * (D2 * is) * Cin * 4, sZ = is * (D1 * is) * (D2 * is) * Cin * 4;  // bytes
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * is * is * is * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7FFFFFF0, 0x00020000);
+  uint32_t vrel[NJ];
+  int ldsa[NJ];
+  {
+    uint32_t bad = 0;
+#pragma unroll
+    for (int h = 0; h < FH1; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH2; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (8 + h)) : 0u;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const int j = tid + 256 * i;
+      const int hy = j / (FH2 * C4), r = j - hy * (FH2 * C4), hx = r / C4, c4 = r - hx * C4;
+      const bool ok = (j < PL4) && !(((1u << hy) | (1u << (8 + hx))) & bad);
+      vrel[i] = ok ? (uint32_t)((y0 - 1 + hy) * sY + (x0 - 1 + hx) * sX + c4 * 16) : OOB;
+      ldsa[i] = (hy * FH2 + hx) * CKP + c4 * 4;
+    }
+  }
+  constexpr int TAPB = NCG * NT * 512;  // bytes of packed weights per tap
+  auto bload = [&](int soff, int idx) -> float2 {
+    const int hi = idx >> 2, lo = idx & 3;
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, lane * 8 + lo * 512, soff + hi * 2048, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+  };
+
+  const int cpz = KSPLIT ? (ncc + (int)gridDim.z - 1) / (int)gridDim.z : ncc;
+  const int cc_lo = KSPLIT ? (int)blockIdx.z * cpz : 0;
+  const int cc_hi = min(ncc, cc_lo + cpz);
+  const int npar = (mode == 2) ? 8 : 1;
+  const int opar = (mode == 1) ? (int)blockIdx.z : 0;
+  for (int it = 0; it < npar * (cc_hi - cc_lo); ++it) {
+    const int ipar = it / (cc_hi - cc_lo);
+    const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
+    const int par = (mode == 1) ? opar : ipar;
+    const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+    const int pconst = (mode == 2) ? ((pz * (D1 * 2) + py) * (D2 * 2) + px) * Cin * 4 : 0;
+    // position of the 2x2x2 window inside the 3x3x3 stencil (see up_tapmask): mode 1 shift = parity, mode 2 (flipped
+    // taps) shift = 1 - parity
+    const int shz = (NTAPS == 8) ? (mode == 2 ? 1 - pz : pz) : 0, shy = (NTAPS == 8) ? (mode == 2 ? 1 - py : py) : 0,
+              shx = (NTAPS == 8) ? (mode == 2 ? 1 - px : px) : 0;
+    const int shtap = (shz * 3 + shy) * 3 + shx;
+    const int shlds = ((shz * FH1 + shy) * FH2 + shx) * CKP;
+    __syncthreads();
+    {
+      float4 stg[NLD];
+#pragma unroll
+      for (int hz = 0; hz < FH0; ++hz) {
+        const int gz = z0 - 1 + hz;
+        const bool pv = (unsigned)gz < (unsigned)D0;
+        const int so = (pv ? gz * sZ : 0) + cc * (CK * 4) + pconst;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? vrel[i] : OOB), so, 0);
+          stg[hz * NJ + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) {
+        if (i < NJ - 1 || tid + 256 * i < PL4) {
+#pragma unroll
+          for (int hz = 0; hz < FH0; ++hz)
+            *reinterpret_cast<float4*>(&lds[ldsa[i] + hz * (FH1 * FH2 * CKP)]) = stg[hz * NJ + i];
+        }
+      }
+    }
+    __syncthreads();
+
+    const int wsoff = (int)(((int64_t)(nc * ncc + cc) * 27 + shtap) * TAPB + (int64_t)par * ext.wstride * 4);
+    int ab[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ab[m] = a_base[m] + shlds;
+    auto tap_id = [](int i) { return NTAPS == 27 ? i : ((i >> 2) & 1) * 9 + ((i >> 1) & 1) * 3 + (i & 1); };
+    auto tap_lds = [&](int i) {
+      const int tt = tap_id(i);
+      return (((tt / 9) * FH1 + (tt / 3) % 3) * FH2 + tt % 3) * CKP;
+    };
+    float2 bb[2][NCG][NT];
+    float2 aa[2][MT];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bb[0][g][n] = bload(wsoff + tap_id(0) * TAPB, g * NT + n);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) aa[0][m] = *reinterpret_cast<const float2*>(&lds[ab[m] + tap_lds(0)]);
+#pragma unroll
+    for (int ti = 0; ti < NTAPS; ++ti) {
+      if (ti + 1 < NTAPS) {
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bb[(ti + 1) & 1][g][n] = bload(wsoff + tap_id(ti + 1) * TAPB, g * NT + n);
+      }
+      const int toff = tap_lds(ti);
+      const int toff_n = tap_lds(ti + 1 < NTAPS ? ti + 1 : ti);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        const int st = ti * NCG + g;
+        const int noff = (g + 1 < NCG) ? toff + (g + 1) * 8 : toff_n;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) aa[(st + 1) & 1][m] = *reinterpret_cast<const float2*>(&lds[ab[m] + noff]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[st & 1][m].x, bb[ti & 1][g][n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[st & 1][m].y, bb[ti & 1][g][n].y, acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- epilogue
+  const int gz = z0 + wave;
+  if (gz < D0) {
+    const int os = (mode == 1) ? 2 : 1;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int gy = y0 + m;
+      if (gy >= D1) continue;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int co = (nc * NT + n) * 16 + li;
+        if (co >= Cout) continue;
+        const float bv = (!KSPLIT && bias) ? bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gx = x0 + kq * 4 + r;
+          if (gx < D2) {
+            const size_t oidx = (((size_t)(gz * os + ((opar >> 2) & 1)) * (D1 * os) + (gy * os + ((opar >> 1) & 1))) *
+                                     (D2 * os) + (gx * os + (opar & 1))) * Cout + co;
+            if constexpr (KSPLIT) {
+              atomicAdd(out + oidx, acc[m][n][r]);
+            } else {
+              float v = acc[m][n][r] + bv;
+              if (ext.addend) v += ext.addend[oidx];
+              if (act == 1) v = elu_f(v);
+              out[oidx] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // bias + activation after a split-K accumulation
 __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t n,
                                                        int C, int act) {
@@ -1188,6 +1389,47 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
                const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], MT), tiles2 = cdiv(s[2], FT2);
   const size_t smem = (size_t)FH0 * (MT + 2) * FH2 * (CK + 4) * sizeof(float);
+  if constexpr (CK == 24 && NT <= 3 && NV == 0) {
+    const int64_t in_bytes = (int64_t)s[0] * s[1] * s[2] * (ext.mode == 2 ? 8 : 1) * Cin * 4;
+    const int64_t w_bytes = pl.count() * 4 * (ext.mode ? 8 : 1);
+    if (in_bytes < (1ll << 31) && w_bytes < (1ll << 31) && !(g_dbg & 32)) {
+      const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
+      if (KS) {
+        if (hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
+      }
+      const int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
+      const dim3 grid(tiles0 * tiles1 * tiles2, pl.nchunks, gz);
+      if (ext.mode == 0) {
+        static bool done27 = false;
+        auto k27 = conv3d_fwd_lean_kernel<NT, MT, KS, 27>;
+        if (!done27) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k27), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+          done27 = true;
+        }
+        hipLaunchKernelGGL(k27, grid, dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1,
+                           tiles2, act, ext);
+      } else {
+        if constexpr (!KS) {
+          static bool done8 = false;
+          auto k8 = conv3d_fwd_lean_kernel<NT, MT, false, 8>;
+          if (!done8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            done8 = true;
+          }
+          hipLaunchKernelGGL(k8, grid, dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1,
+                             tiles2, act, ext);
+        } else {
+          return SYNTHSR_EINVAL;
+        }
+      }
+      if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+      if (KS && (bias != nullptr || act != 0)) {
+        hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act);
+        if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+      }
+      return SYNTHSR_OK;
+    }
+  }
   static bool attr_done = false;
   auto kern = conv3d_fwd_kernel<CK, NT, MT, KS, NV>;
   if (!attr_done) {
