@@ -130,6 +130,11 @@ int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], i
 int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
                        int Cin, int Cout, int act, synthsr_stream_t stream);
 
+/* out = act(conv3(in) + addend + bias); addend is indexed like out and may alias it (in-place accumulation).  Layers
+ * that are split over input channels (small deep levels) accumulate with atomics and require addend == out or NULL. */
+int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* bias, const float* addend, float* out,
+                           const int shape[3], int Cin, int Cout, int act, synthsr_stream_t stream);
+
 /* --- nearest-upsample folding (decoder conv on concatenate([skip, UpSampling3D(2)(lo)]), models.py:426-444) ------
  * A 3x3x3 conv over an up-sampled tensor equals 8 parity-wise 2x2x2 convs over the low-res tensor with summed taps
  * (3.4x fewer FLOPs, same result up to float32 re-association).  The layer is evaluated as

@@ -166,8 +166,8 @@ __global__ void up_unpack_kernel(const float* __restrict__ dwc, float* __restric
 // slab: 16 x (NT*16) floats.  Requires Cout % 4 == 0 (else the scalar path below).
 template <int NT, int MT>
 __device__ __forceinline__ void store_tile_rows(f32x4 (&acc)[MT][NT], float* slab, float* __restrict__ out,
-                                                const float* __restrict__ bias, int act, int nc, int gz, int y0, int x0,
-                                                int D1, int D2, int Cout, int lane) {
+                                                const float* __restrict__ bias, const float* addend, int act, int nc,
+                                                int gz, int y0, int x0, int D1, int D2, int Cout, int lane) {
   const int li = lane & 15, kq = lane >> 4;
   constexpr int NW = NT * 16;
   const int c_lo = nc * NW;
@@ -183,18 +183,28 @@ __device__ __forceinline__ void store_tile_rows(f32x4 (&acc)[MT][NT], float* sla
       const int co = c_lo + n * 16 + li;
       const float bv = (bias && co < Cout) ? bias[co] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[m][n][r] + bv;
-        if (act == 1) v = elu_f(v);
-        slab[(kq * 4 + r) * NW + n * 16 + li] = v;
-      }
+      for (int r = 0; r < 4; ++r) slab[(kq * 4 + r) * NW + n * 16 + li] = acc[m][n][r] + bv;
     }
     __builtin_amdgcn_wave_barrier();
-    float* row = out + (((size_t)gz * D1 + gy) * D2 + x0) * Cout + c_lo;
+    const size_t rowoff = (((size_t)gz * D1 + gy) * D2 + x0) * Cout + c_lo;
     for (int idx = lane; idx < nx * wc4; idx += 64) {
       const int x = idx / wc4, c4 = idx - x * wc4;
-      const float4 v = *reinterpret_cast<const float4*>(&slab[x * NW + c4 * 4]);
-      *reinterpret_cast<float4*>(row + (size_t)x * Cout + c4 * 4) = v;
+      float4 v = *reinterpret_cast<const float4*>(&slab[x * NW + c4 * 4]);
+      const size_t o = rowoff + (size_t)x * Cout + c4 * 4;
+      if (addend) {  // wave-uniform; may alias out (same element read and written by this lane)
+        const float4 a = *reinterpret_cast<const float4*>(addend + o);
+        v.x += a.x;
+        v.y += a.y;
+        v.z += a.z;
+        v.w += a.w;
+      }
+      if (act == 1) {
+        v.x = elu_f(v.x);
+        v.y = elu_f(v.y);
+        v.z = elu_f(v.z);
+        v.w = elu_f(v.w);
+      }
+      *reinterpret_cast<float4*>(out + o) = v;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
                                                                     const float* __restrict__ bias,
                                                                     float* __restrict__ out, int D0, int D1, int D2,
                                                                     int Cin, int Cout, int ncc, int tiles1, int tiles2,
-                                                                    int ntiles, int act) {
+                                                                    int ntiles, int act, const float* addend) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CK = 24, MT = 4;
   constexpr int FT1 = MT, FH1 = MT + 2, FHV = FH0 * FH1 * FH2;
@@ -666,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
       __syncthreads();
       const int gz = z0 + wave;
       if (gz < D0)
-        store_tile_rows<NT, MT>(acc, lds + wave * (16 * NT * 16), out, bias, act, nc, gz, y0, x0, D1, D2, Cout, lane);
+        store_tile_rows<NT, MT>(acc, lds + wave * (16 * NT * 16), out, bias, addend, act, nc, gz, y0, x0, D1, D2, Cout, lane);
     }
     if (!has_next) break;
     tile = ntile;
@@ -757,12 +767,33 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
   const int cc_hi = min(ncc, cc_lo + cpz);
   const int npar = (mode == 2) ? 8 : 1;
   const int opar = (mode == 1) ? (int)blockIdx.z : 0;
-  for (int it = 0; it < npar * (cc_hi - cc_lo); ++it) {
+  // halo of iteration `it` (parity, chunk) -> staging registers; issued one iteration ahead so that the loads complete
+  // behind the MFMAs of the previous chunk
+  const int nit = npar * (cc_hi - cc_lo);
+  float4 stg[NLD];
+  auto halo_loads = [&](int it) {
+    const int ipar = it / (cc_hi - cc_lo);
+    const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
+    const int par = (mode == 1) ? opar : ipar;
+    const int pconst = (mode == 2) ? ((((par >> 2) & 1) * (D1 * 2) + ((par >> 1) & 1)) * (D2 * 2) + (par & 1)) * Cin * 4 : 0;
+#pragma unroll
+    for (int hz = 0; hz < FH0; ++hz) {
+      const int gz = z0 - 1 + hz;
+      const bool pv = (unsigned)gz < (unsigned)D0;
+      const int so = (pv ? gz * sZ : 0) + cc * (CK * 4) + pconst;
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? vrel[i] : OOB), so, 0);
+        stg[hz * NJ + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+    }
+  };
+  if (nit > 0) halo_loads(0);
+  for (int it = 0; it < nit; ++it) {
     const int ipar = it / (cc_hi - cc_lo);
     const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
     const int par = (mode == 1) ? opar : ipar;
     const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
-    const int pconst = (mode == 2) ? ((pz * (D1 * 2) + py) * (D2 * 2) + px) * Cin * 4 : 0;
     // position of the 2x2x2 window inside the 3x3x3 stencil (see up_tapmask): mode 1 shift = parity, mode 2 (flipped
     // taps) shift = 1 - parity
     const int shz = (NTAPS == 8) ? (mode == 2 ? 1 - pz : pz) : 0, shy = (NTAPS == 8) ? (mode == 2 ? 1 - py : py) : 0,
@@ -770,29 +801,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
     const int shtap = (shz * 3 + shy) * 3 + shx;
     const int shlds = ((shz * FH1 + shy) * FH2 + shx) * CKP;
     __syncthreads();
-    {
-      float4 stg[NLD];
 #pragma unroll
-      for (int hz = 0; hz < FH0; ++hz) {
-        const int gz = z0 - 1 + hz;
-        const bool pv = (unsigned)gz < (unsigned)D0;
-        const int so = (pv ? gz * sZ : 0) + cc * (CK * 4) + pconst;
+    for (int i = 0; i < NJ; ++i) {
+      if (i < NJ - 1 || tid + 256 * i < PL4) {
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? vrel[i] : OOB), so, 0);
-          stg[hz * NJ + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NJ; ++i) {
-        if (i < NJ - 1 || tid + 256 * i < PL4) {
-#pragma unroll
-          for (int hz = 0; hz < FH0; ++hz)
-            *reinterpret_cast<float4*>(&lds[ldsa[i] + hz * (FH1 * FH2 * CKP)]) = stg[hz * NJ + i];
-        }
+        for (int hz = 0; hz < FH0; ++hz)
+          *reinterpret_cast<float4*>(&lds[ldsa[i] + hz * (FH1 * FH2 * CKP)]) = stg[hz * NJ + i];
       }
     }
     __syncthreads();
+    if (it + 1 < nit) halo_loads(it + 1);
 
     const int wsoff = (int)(((int64_t)(nc * ncc + cc) * 27 + shtap) * TAPB + (int64_t)par * ext.wstride * 4);
     int ab[MT];
@@ -1394,8 +1412,9 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
     const int64_t w_bytes = pl.count() * 4 * (ext.mode ? 8 : 1);
     if (in_bytes < (1ll << 31) && w_bytes < (1ll << 31) && !(g_dbg & 32)) {
       const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
-      if (KS) {
-        if (hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
+      if (KS) {  // split-K accumulates with atomics: onto zeros, or onto the addend when it already sits in `out`
+        if (ext.addend && ext.addend != out) return SYNTHSR_EINVAL;
+        if (!ext.addend && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
       }
       const int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
       const dim3 grid(tiles0 * tiles1 * tiles2, pl.nchunks, gz);
@@ -1438,7 +1457,8 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
   }
   const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
   if (KS) {
-    if (hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
+    if (ext.addend && ext.addend != out) return SYNTHSR_EINVAL;
+    if (!ext.addend && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
   }
   const int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
   hipLaunchKernelGGL(kern, dim3(tiles0 * tiles1 * tiles2, pl.nchunks, gz), dim3(256), smem, st, in, wp, bias, out, s[0],
@@ -1453,7 +1473,7 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
 
 template <int NT>
 int launch_fwd_persist(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
-                       const FwdPlan& pl, int act, hipStream_t st) {
+                       const FwdPlan& pl, int act, hipStream_t st, const float* addend) {
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
   const int ntiles = tiles0 * tiles1 * tiles2;
   const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
@@ -1468,7 +1488,7 @@ int launch_fwd_persist(const float* in, const float* wp, const float* bias, floa
   const int64_t nitems = (int64_t)ntiles * pl.ncc;
   while (gx > 8 && gx > nitems) gx -= 8;
   hipLaunchKernelGGL(kern, dim3(gx, pl.nchunks), dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, Cout,
-                     pl.ncc, tiles1, tiles2, ntiles, act);
+                     pl.ncc, tiles1, tiles2, ntiles, act, addend);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
@@ -1480,7 +1500,7 @@ int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* ou
       if (pl.nv == 8) return launch_fwd<CK, NT, 4, false, 8>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
     }
     if constexpr (CK == 24 && NT <= 3) {
-      if (pl.persist && ext.mode == 0) return launch_fwd_persist<NT>(in, wp, bias, out, s, Cin, Cout, pl, act, st);
+      if (pl.persist && ext.mode == 0) return launch_fwd_persist<NT>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext.addend);
     }
     return launch_fwd<CK, NT, 4, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
   }
@@ -1628,6 +1648,17 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   const ConvExt ext{0, nullptr, 0, pl.mfma_count()};
+  if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
+  return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
+}
+
+int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* bias, const float* addend, float* out,
+                           const int shape[3], int Cin, int Cout, int act, synthsr_stream_t stream) {
+  if (!in || !wpacked || !out || !shape || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1 ||
+      (act != 0 && act != 1))
+    return SYNTHSR_EINVAL;
+  const FwdPlan pl = plan_fwd(shape, Cin, Cout);
+  const ConvExt ext{0, addend, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
 }

@@ -146,6 +146,19 @@ def conv3d(x, wpacked, bias, Cout, act=1, out=None):
     return out
 
 
+def conv3d_add(x, wpacked, bias, addend, Cout, act=1, out=None):
+    """act(conv3(x) + addend + bias); `addend` may be `out` itself (in-place accumulation)"""
+    lib = _L()
+    s = x.shape
+    if out is None:
+        out = torch.empty((s[0], s[1], s[2], Cout), dtype=torch.float32, device=x.device)
+    with _Timed('conv3d_fwd', s[:3], s[3], Cout):
+        _lib.check(lib.synthsr_conv3d_fwd_add(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(addend),
+                                              _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), int(Cout), int(act),
+                                              _lib.stream()), 'conv3d_fwd_add')
+    return out
+
+
 def conv3d_wgrad(x, dout, dw):
     """dw [3,3,3,Cin,Cout] += sum_v x[v+t-1] (x) dout[v]"""
     lib = _L()

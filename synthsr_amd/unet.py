@@ -282,9 +282,11 @@ class UNet3D:
                 lo_bn = ops.bn_apply(low, self._stats(low_bn), self.view(low_bn['gamma']), self.view(low_bn['beta']),
                                      out=self.buf('lobn%d' % k, list(low.shape)))
                 self.saved['cat'].append((skip, lo_bn))
-                tmp = ops.conv3d(skip, c0['wp_s'], None, c0['cout'], 0, out=self.buf('foldtmp', self.shapes[l] + [c0['cout']]))
-                cur = ops.conv3d_up(lo_bn, c0['wp_u'], self.view(c0['b']), tmp, c0['cout'], 1,
+                # the parity convs write the raw up-sampled part (strided stores), the skip-channel conv then adds it
+                # in place with coalesced reads and applies bias + ELU
+                cur = ops.conv3d_up(lo_bn, c0['wp_u'], None, None, c0['cout'], 0,
                                     out=self.buf('dec%d_0' % k, self.shapes[l] + [c0['cout']]))
+                cur = ops.conv3d_add(skip, c0['wp_s'], self.view(c0['b']), cur, c0['cout'], 1, out=cur)
                 acts.append(cur)
             else:
                 cat = ops.upsample_concat(skip, low, self._stats(low_bn), self.view(low_bn['gamma']),
