@@ -25,6 +25,13 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 inline int ck_for(int Cin) { return (Cin % 24 == 0) ? 24 : 8; }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {  // compile-time loop: f(std::integral_constant<int, I>) for I in [I, N)
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // ELU(alpha = 1) for the fused epilogues.  Vector-ALU instructions next to MFMAs are not free on gfx950 (see the
@@ -80,6 +87,23 @@ __device__ __forceinline__ float weight_value(const float* __restrict__ w, int t
 __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
                                             int Cout, int mode, int CK, int ncc, int NT, int parity, int NV,
                                             int64_t mfma_count) {
+  if (NT == 0) {
+    // 4x4x1-MFMA layout of the Cout = 24 layers (conv3d_fwd_p4_kernel): [cc][tap][qp 3][r 3][lane 64].  Register r of
+    // channel-octet qp holds 16 four-channel groups, G = r*16 + (lane >> 2) = h*24 + kk*6 + g  ->  input channel
+    // cc*24 + qp*8 + h*4 + kk, output channels 4g + (lane & 3); the kernel selects a group with the MFMA's ABID.
+    const int lane = (int)(idx & 63);
+    int64_t r = idx >> 6;
+    const int rr = (int)(r % 3);
+    r /= 3;
+    const int qp = (int)(r % 3);
+    r /= 3;
+    const int tap = (int)(r % 27);
+    const int cc = (int)(r / 27);
+    const int G = rr * 16 + (lane >> 2);
+    const int cie = cc * 24 + qp * 8 + (G / 24) * 4 + (G % 24) / 6;
+    const int coe = (G % 6) * 4 + (lane & 3);
+    return weight_value(w, tap, cie, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
+  }
   if (idx >= mfma_count) {
     int64_t r = idx - mfma_count;
     const int v = (int)(r % NV);
@@ -677,6 +701,194 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
       const int gz = z0 + wave;
       if (gz < D0)
         store_tile_rows<NT, MT>(acc, lds + wave * (16 * NT * 16), out, bias, addend, act, nc, gz, y0, x0, D1, D2, Cout, lane);
+    }
+    if (!has_next) break;
+    tile = ntile;
+    z0 = nz0;
+    y0 = ny0;
+    x0 = nx0;
+    cc = ncc_;
+  }
+}
+
+// ---- persistent forward kernel for Cout = 24 on v_mfma_f32_4x4x1_16B_f32 ---------------------------------------
+// The 16x16x4 MFMA pads 24 output channels to 32 columns (25 % of the matrix work wasted on every level-0 layer).
+// The 4x4x1 MFMA runs 16 independent 4x4 outer products per instruction at the same FLOP rate (512 FLOP / 8 cycles,
+// tools/ubench/mfma_4x4.hip: 136-147 TF) and its CBSZ/ABID fields broadcast ONE block of the A operand to all 16
+// blocks.  Mapping: A = weights (rows = 4 output channels), B = activations (block b, column j = voxel 4b+j = lane),
+// D[i] of lane l = out[voxel l][4g+i].  A weight register therefore holds 16 different channel groups (selected by
+// ABID) and is loaded once per wave, the lane's own voxel supplies B from the LDS halo tile with one ds_read_b128 per
+// 4 input channels, and every lane ends up with the 24 output channels of its voxel in 24 accumulator registers
+// (epilogue = 6 contiguous float4 stores per lane, no LDS transpose).  24 = 6 groups of 4: no padding.
+// Tile, halo staging and item order are those of conv3d_fwd_persist_kernel.
+__global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int D0, int D1, int D2, int Cin, int ncc, int tiles1,
+                                                               int tiles2, int ntiles, int act, const float* addend) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CK = 24, MT = 4, Cout = 24;
+  constexpr int FT1 = MT, FH1 = MT + 2;
+  constexpr int CKP = CK + 4, C4 = CK / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = gridDim.x;
+  const int my_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int vy = lane >> 4, vx = lane & 15;
+  const int xbase = ((wave * FH1 + vy) * FH2 + vx) * CKP;
+
+  constexpr int PLANE4 = FH1 * FH2 * C4, NJ = (PLANE4 + 255) / 256, NLD = NJ * FH0;
+  constexpr uint32_t OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, ncc * 27 * 9 * 256, 0x00020000);
+  int rel[NJ], ldsa[NJ];
+  uint32_t cmask[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = tid + 256 * i;
+    const int hy = j / (FH2 * C4), r = j - hy * (FH2 * C4), hx = r / C4, c4 = r - hx * C4;
+    rel[i] = ((hy * D2 + hx) * Cin + c4 * 4) * 4;
+    ldsa[i] = ((hy * FH2 + hx) * CKP + c4 * 4);
+    cmask[i] = j < PLANE4 ? ((1u << hy) | (1u << (8 + hx))) : 0xFFFFFFFFu;
+  }
+  const int plane_bytes = D1 * D2 * Cin * 4;
+  auto item_offsets = [&](int y0, int x0, int cc, uint32_t (&voff)[NJ]) {
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < FH1; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH2; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (8 + h)) : 0u;
+    const int yx = (((y0 - 1) * D2 + (x0 - 1)) * Cin + cc * CK) * 4;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) voff[i] = (cmask[i] & bad) ? OOB : (uint32_t)(rel[i] + yx);
+  };
+  auto halo_load = [&](int k, int z0, const uint32_t (&voff)[NJ]) -> float4 {
+    const int hz = k / NJ, i = k - hz * NJ;
+    const int gz = z0 - 1 + hz;
+    const bool pv = (unsigned)gz < (unsigned)D0;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? voff[i] : OOB), pv ? gz * plane_bytes : 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    z0 = t0 * FT0;
+    y0 = t1 * FT1;
+    x0 = t2 * FT2;
+  };
+  auto wload = [&](int soff, int r) -> float {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, lane * 4 + r * 256, soff, 0));
+  };
+
+  f32x4 acc[6];
+  float4 stg[NLD];
+  int tile = my_pos;
+  if (tile >= ntiles) return;
+  int z0, y0, x0, cc = 0;
+  tile_origin(tile, z0, y0, x0);
+  {
+    uint32_t voff[NJ];
+    item_offsets(y0, x0, cc, voff);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) stg[k] = halo_load(k, z0, voff);
+  }
+  // weight ring: step p of an item uses wr[p % 3]; steps are requested two ahead, and since 81 = 0 (mod 3) the ring
+  // simply continues into the next item (whose first two steps are requested by the last two steps of this one)
+  constexpr int NP = 27 * 3;
+  float wr[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    wr[0][r] = wload(0, r);
+    wr[1][r] = wload(768, r);
+  }
+
+  while (true) {
+    const int ncc_ = (cc + 1 < ncc) ? cc + 1 : 0;
+    const int ntile = (cc + 1 < ncc) ? tile : tile + G;
+    const bool has_next = ntile < ntiles;
+    int nz0 = z0, ny0 = y0, nx0 = x0;
+    if (has_next && ntile != tile) tile_origin(ntile, nz0, ny0, nx0);
+    uint32_t nvoff[NJ];
+    item_offsets(ny0, nx0, ncc_, nvoff);
+    if (cc == 0) {
+#pragma unroll
+      for (int g = 0; g < 6; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      if (i < NJ - 1 || tid + 256 * i < PLANE4) {
+#pragma unroll
+        for (int hz = 0; hz < FH0; ++hz)
+          *reinterpret_cast<float4*>(&lds[ldsa[i] + hz * (FH1 * FH2 * CKP)]) = stg[hz * NJ + i];
+      }
+    }
+    __syncthreads();
+
+    // 81 channel-octet steps (tap, qp); weights of step p live in wr[p % 3] and are requested two steps ahead, the
+    // activations of quad step s (two per octet) in xq[s & 1], read one step ahead
+    const int wsoff = cc * NP * 768, wsoff_n = ncc_ * NP * 768;
+    float4 xq[2];
+    xq[0] = *reinterpret_cast<const float4*>(&lds[xbase]);
+    sfor<0, NP>([&](auto P) {
+      constexpr int p = decltype(P)::value, tap = p / 3, qp = p % 3;
+      constexpr int toff = (((tap / 9) * FH1 + (tap / 3) % 3) * FH2 + tap % 3) * CKP;
+      if constexpr (p + 2 < NP) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) wr[(p + 2) % 3][r] = wload(wsoff + (p + 2) * 768, r);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) wr[(p + 2) % 3][r] = wload(wsoff_n + (p + 2 - NP) * 768, r);
+      }
+      if constexpr (qp == 0 && tap < NLD) {
+        if (has_next) stg[tap] = halo_load(tap, nz0, nvoff);  // wave-uniform branch
+      }
+      sfor<0, 2>([&](auto H) {
+        constexpr int h = decltype(H)::value, s = p * 2 + h;
+        // next quad step: (p, 1) after (p, 0); (p + 1, 0) after (p, 1)
+        constexpr int pn = h == 0 ? p : (p + 1 < NP ? p + 1 : p), hn = h == 0 ? 1 : 0;
+        constexpr int tn = pn / 3, qn = (pn % 3) * 2 + hn;
+        constexpr int noff = (((tn / 9) * FH1 + (tn / 3) % 3) * FH2 + tn % 3) * CKP + qn * 4;
+        (void)toff;
+        xq[(s + 1) & 1] = *reinterpret_cast<const float4*>(&lds[xbase + noff]);
+        __builtin_amdgcn_sched_barrier(0);
+        const float xs[4] = {xq[s & 1].x, xq[s & 1].y, xq[s & 1].z, xq[s & 1].w};
+        sfor<0, 24>([&](auto GI) {
+          constexpr int gi = decltype(GI)::value, kk = gi / 6, g = gi % 6, GG = h * 24 + gi;
+          acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[p % 3][GG / 16], xs[kk], acc[g], 4, GG % 16, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+
+    if (cc == ncc - 1) {  // epilogue: the lane's voxel, 24 channels = 6 float4
+      const int gz = z0 + wave, gy = y0 + vy, gx = x0 + vx;
+      if (gz < D0 && gy < D1 && gx < D2) {
+        const size_t o = (((size_t)gz * D1 + gy) * D2 + gx) * Cout;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          float4 v = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+          if (bias) {
+            v.x += bias[4 * g];
+            v.y += bias[4 * g + 1];
+            v.z += bias[4 * g + 2];
+            v.w += bias[4 * g + 3];
+          }
+          if (addend) {  // may alias out: same element read and written by this lane
+            const float4 a = *reinterpret_cast<const float4*>(addend + o + 4 * g);
+            v.x += a.x;
+            v.y += a.y;
+            v.z += a.z;
+            v.w += a.w;
+          }
+          if (act == 1) {
+            v.x = elu_f(v.x);
+            v.y = elu_f(v.y);
+            v.z = elu_f(v.z);
+            v.w = elu_f(v.w);
+          }
+          *reinterpret_cast<float4*>(out + o + 4 * g) = v;
+        }
+      }
     }
     if (!has_next) break;
     tile = ntile;
@@ -1360,10 +1572,13 @@ static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout
                           // the MFMAs, so it is slower than padding to 32 columns until the issue order is hand-pinned.
 static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
 
+static int g_p4 = 1;  // option 4: 4x4x1-MFMA kernel for the Cout = 24 layers (no padding to 32 columns)
+
 struct FwdPlan {
-  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv;
-  int64_t mfma_count() const { return (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128; }
-  int64_t count() const { return mfma_count() + (int64_t)ncc * 27 * ck * nv; }
+  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4;
+  int pack_nt() const { return p4 ? 0 : nt; }  // NT = 0 selects the 4x4x1 weight layout in pack_value
+  int64_t mfma_count() const { return p4 ? 0 : (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128; }
+  int64_t count() const { return p4 ? (int64_t)ncc * 27 * 9 * 64 : mfma_count() + (int64_t)ncc * 27 * ck * nv; }
 };
 
 // Launch geometry for one layer: enough workgroups to fill 256 CUs x 2 even on the deep, small levels.
@@ -1391,7 +1606,9 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
     p.nchunks = 1;
     p.nt = (Cout - 8) / 16;
   }
-  p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist && p.nv == 0) ? 1 : 0;
+  const bool lt2g = (int64_t)s[0] * s[1] * s[2] * Cin * 4 < (1ll << 31);  // raw buffer addressing (32-bit offsets)
+  p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist && p.nv == 0 && lt2g) ? 1 : 0;
+  p.p4 = (p.persist && plain && Cout == 24 && (Cin % 24) == 0 && g_p4) ? 1 : 0;
   const int64_t w = wgs(p.mt, p.nt);
   if (w < 512 && p.ncc >= 4 && plain && p.nv == 0) {
     int ks = (int)cdiv(1024, (int)w);
@@ -1492,9 +1709,31 @@ int launch_fwd_persist(const float* in, const float* wp, const float* bias, floa
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
+int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin,
+                  const FwdPlan& pl, int act, hipStream_t st, const float* addend) {
+  const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
+  const int ntiles = tiles0 * tiles1 * tiles2;
+  const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_fwd_p4_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  int gx = 512;
+  while (gx > 8 && gx > ntiles) gx -= 8;
+  hipLaunchKernelGGL(conv3d_fwd_p4_kernel, dim3(gx), dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, pl.ncc,
+                     tiles1, tiles2, ntiles, act, addend);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
 template <int CK, int NT>
 int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
                   const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
+  if (pl.p4) {
+    if ((int64_t)s[0] * s[1] * s[2] * Cin * 4 >= (1ll << 31) || ext.mode != 0) return SYNTHSR_EINVAL;
+    return launch_fwd_p4(in, wp, bias, out, s, Cin, pl, act, st, ext.addend);
+  }
   if (pl.mt == 4) {
     if constexpr (CK == 24 && NT <= 4) {
       if (pl.nv == 8) return launch_fwd<CK, NT, 4, false, 8>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
@@ -1599,7 +1838,7 @@ int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3]
   if (!w) return SYNTHSR_EINVAL;
   for (int p = 0; p < (up ? 8 : 1); ++p) {
     hipLaunchKernelGGL(pack_kernel, dim3(syn_grid(per, 256)), dim3(256), 0, (hipStream_t)stream, w, packed + p * per,
-                       Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.nt, pl.nchunks, up ? p : -1, pl.nv,
+                       Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.pack_nt(), pl.nchunks, up ? p : -1, pl.nv,
                        pl.mfma_count(), per);
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   }
@@ -1616,7 +1855,7 @@ int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int6
   const FwdPlan pl = plan_fwd(shape, CinE, CoutE, plain != 0);
   out[0] = pl.ck;
   out[1] = pl.ncc;
-  out[2] = pl.nt;
+  out[2] = pl.pack_nt();
   out[3] = pl.nchunks;
   out[4] = pl.mt;
   out[5] = pl.ksplit;
@@ -1704,6 +1943,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 3) {
     g_hybrid = value ? 1 : 0;
+    return SYNTHSR_OK;
+  }
+  if (option == 4) {
+    g_p4 = value ? 1 : 0;
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;
