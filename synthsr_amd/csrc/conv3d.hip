@@ -87,6 +87,16 @@ __device__ __forceinline__ float weight_value(const float* __restrict__ w, int t
 __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
                                             int Cout, int mode, int CK, int ncc, int NT, int parity, int NV,
                                             int64_t mfma_count) {
+  if (NT < 0) {
+    // first-layer layout (conv3d_fwd_c2_kernel, Cin = -NT <= 2, Cout = 24): [r][lane 64], G = r*16 + (lane >> 2) =
+    // k*6 + g with k = tap*Cin + ci; output channels 4g + (lane & 3); zero beyond k = 27*Cin
+    const int cin = -NT;
+    const int lane = (int)(idx & 63);
+    const int G = (int)(idx >> 6) * 16 + (lane >> 2);
+    const int k = G / 6, g = G % 6;
+    if (k >= 27 * cin) return 0.f;
+    return weight_value(w, k / cin, k % cin, g * 4 + (lane & 3), Cin_total, ci_off, Cin, Cout, mode, parity);
+  }
   if (NT == 0) {
     // 4x4x1-MFMA layout of the Cout = 24 layers (conv3d_fwd_p4_kernel): [cc][tap][qp 3][r 3][lane 64].  Register r of
     // channel-octet qp holds 16 four-channel groups, G = r*16 + (lane >> 2) = h*24 + kk*6 + g  ->  input channel
@@ -729,6 +739,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
   constexpr int CK = 24, MT = 4, Cout = 24;
   constexpr int FT1 = MT, FH1 = MT + 2;
   constexpr int CKP = CK + 4, C4 = CK / 4;
+  const int dbg = act >> 8;  // timing experiments (synthsr_conv3d_set_option 1): 64 no LDS restage, 128 no epilogue
+  act &= 0xff;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = gridDim.x;
   const int my_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
@@ -813,6 +825,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
 #pragma unroll
       for (int g = 0; g < 6; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if (!(dbg & 64)) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
@@ -823,6 +836,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
       }
     }
     __syncthreads();
+    }
 
     // 81 channel-octet steps (tap, qp); weights of step p live in wr[p % 3] and are requested two steps ahead, the
     // activations of quad step s (two per octet) in xq[s & 1], read one step ahead
@@ -860,7 +874,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
       });
     });
 
-    if (cc == ncc - 1) {  // epilogue: the lane's voxel, 24 channels = 6 float4
+    if (cc == ncc - 1 && !(dbg & 128)) {  // epilogue: the lane's voxel, 24 channels = 6 float4
       const int gz = z0 + wave, gy = y0 + vy, gx = x0 + vx;
       if (gz < D0 && gy < D1 && gx < D2) {
         const size_t o = (((size_t)gz * D1 + gy) * D2 + gx) * Cout;
@@ -896,6 +910,117 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
     y0 = ny0;
     x0 = nx0;
     cc = ncc_;
+  }
+}
+
+// ---- first layer (Cin <= 2, Cout = 24) on the 4x4x1 MFMA: K = 27*Cin, all weights resident in <= 21 registers ------
+// The generic path pads Cin = 2 to an 8-channel chunk (4x the matrix work) and is bound by everything but memory;
+// this kernel is bound by the 160^3 x 24 output write.  Lane = voxel as in conv3d_fwd_p4_kernel; the halo tile is
+// [648 voxels][Cin] in LDS (5 KB).
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void conv3d_fwd_c2_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int D0, int D1, int D2, int tiles1, int tiles2, int ntiles,
+                                                               int act) {
+  __shared__ __attribute__((aligned(16))) float lds[FH0 * 6 * FH2 * CIN];
+  constexpr int FH1 = 6, FHV = FH0 * FH1 * FH2, NS = (FHV + 255) / 256, Cout = 24;
+  constexpr int NG = 27 * CIN * 6, NR = (NG + 15) / 16;
+  constexpr uint32_t OOB = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vy = lane >> 4, vx = lane & 15;
+  const int xbase = ((wave * FH1 + vy) * FH2 + vx) * CIN;
+  float wr[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) wr[r] = wp[r * 64 + lane];
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * CIN * 4), 0x00020000);
+  int rel[NS], ldsa[NS];
+  uint32_t cmask[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int j = tid + 256 * i;
+    const int hz = j / (FH1 * FH2), hy = (j / FH2) % FH1, hx = j % FH2;
+    rel[i] = ((hz * D1 + hy) * D2 + hx) * CIN * 4;
+    ldsa[i] = j * CIN;
+    cmask[i] = j < FHV ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+  }
+  float stg[NS][CIN];
+  auto load_tile = [&](int t) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    const int z0 = t0 * FT0, y0 = t1 * 4, x0 = t2 * FT2;
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < FH0; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH1; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH2; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int org = (((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * CIN * 4;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int vo = (cmask[i] & bad) ? (int)OOB : rel[i] + org;
+      if constexpr (CIN == 2) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rin, vo, 0, 0);
+        stg[i][0] = __uint_as_float(v.x);
+        stg[i][1] = __uint_as_float(v.y);
+      } else {
+        stg[i][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rin, vo, 0, 0));
+      }
+    }
+  };
+  const int G = gridDim.x;
+  const int my_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  if (my_pos < ntiles) load_tile(my_pos);
+  for (int t = my_pos; t < ntiles; t += G) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    const int z0 = t0 * FT0, y0 = t1 * 4, x0 = t2 * FT2;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (i < NS - 1 || tid + 256 * i < FHV) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) lds[ldsa[i] + c] = stg[i][c];
+      }
+    }
+    __syncthreads();
+    if (t + G < ntiles) load_tile(t + G);
+    f32x4 acc[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float xq[2][CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) xq[0][c] = lds[xbase + c];
+    sfor<0, 27>([&](auto T) {
+      constexpr int tap = decltype(T)::value, tn = tap + 1 < 27 ? tap + 1 : tap;
+      constexpr int noff = (((tn / 9) * FH1 + (tn / 3) % 3) * FH2 + tn % 3) * CIN;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) xq[(tap + 1) & 1][c] = lds[xbase + noff + c];
+      sfor<0, CIN * 6>([&](auto GI) {
+        constexpr int gi = decltype(GI)::value, ci = gi / 6, g = gi % 6, GG = (tap * CIN + ci) * 6 + g;
+        acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[GG / 16], xq[tap & 1][ci], acc[g], 4, GG % 16, 0);
+      });
+    });
+    const int gz = z0 + wave, gy = y0 + vy, gx = x0 + vx;
+    if (gz < D0 && gy < D1 && gx < D2) {
+      const size_t o = (((size_t)gz * D1 + gy) * D2 + gx) * Cout;
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        float4 v = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+        if (bias) {
+          v.x += bias[4 * g];
+          v.y += bias[4 * g + 1];
+          v.z += bias[4 * g + 2];
+          v.w += bias[4 * g + 3];
+        }
+        if (act == 1) {
+          v.x = elu_f(v.x);
+          v.y = elu_f(v.y);
+          v.z = elu_f(v.z);
+          v.w = elu_f(v.w);
+        }
+        *reinterpret_cast<float4*>(out + o + 4 * g) = v;
+      }
+    }
   }
 }
 
@@ -1575,10 +1700,14 @@ static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
 static int g_p4 = 1;  // option 4: 4x4x1-MFMA kernel for the Cout = 24 layers (no padding to 32 columns)
 
 struct FwdPlan {
-  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4;
-  int pack_nt() const { return p4 ? 0 : nt; }  // NT = 0 selects the 4x4x1 weight layout in pack_value
-  int64_t mfma_count() const { return p4 ? 0 : (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128; }
-  int64_t count() const { return p4 ? (int64_t)ncc * 27 * 9 * 64 : mfma_count() + (int64_t)ncc * 27 * ck * nv; }
+  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2;
+  // NT = 0 selects the 4x4x1 weight layout in pack_value, NT = -Cin the first-layer layout
+  int pack_nt() const { return c2 ? -c2 : (p4 ? 0 : nt); }
+  int64_t mfma_count() const { return (p4 || c2) ? 0 : (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128; }
+  int64_t count() const {
+    if (c2) return (int64_t)((27 * c2 * 6 + 15) / 16) * 64;
+    return p4 ? (int64_t)ncc * 27 * 9 * 64 : mfma_count() + (int64_t)ncc * 27 * ck * nv;
+  }
 };
 
 // Launch geometry for one layer: enough workgroups to fill 256 CUs x 2 even on the deep, small levels.
@@ -1609,6 +1738,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
   const bool lt2g = (int64_t)s[0] * s[1] * s[2] * Cin * 4 < (1ll << 31);  // raw buffer addressing (32-bit offsets)
   p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist && p.nv == 0 && lt2g) ? 1 : 0;
   p.p4 = (p.persist && plain && Cout == 24 && (Cin % 24) == 0 && g_p4) ? 1 : 0;
+  p.c2 = (plain && Cout == 24 && Cin <= 2 && lt2g && g_p4) ? Cin : 0;  // first layer: 4x4x1 MFMA over K = 27*Cin
   const int64_t w = wgs(p.mt, p.nt);
   if (w < 512 && p.ncc >= 4 && plain && p.nv == 0) {
     int ks = (int)cdiv(1024, (int)w);
@@ -1723,13 +1853,32 @@ int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* ou
   int gx = 512;
   while (gx > 8 && gx > ntiles) gx -= 8;
   hipLaunchKernelGGL(conv3d_fwd_p4_kernel, dim3(gx), dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, pl.ncc,
-                     tiles1, tiles2, ntiles, act, addend);
+                     tiles1, tiles2, ntiles, act | (g_dbg << 8), addend);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+int launch_fwd_c2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int act,
+                  hipStream_t st) {
+  const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
+  const int ntiles = tiles0 * tiles1 * tiles2;
+  int gx = 2048;  // 8 workgroups per CU: the kernel is bound by its output stores, not by the matrix cores
+  while (gx > 8 && gx > ntiles) gx -= 8;
+  if (Cin == 2)
+    hipLaunchKernelGGL(conv3d_fwd_c2_kernel<2>, dim3(gx), dim3(256), 0, st, in, wp, bias, out, s[0], s[1], s[2], tiles1,
+                       tiles2, ntiles, act);
+  else
+    hipLaunchKernelGGL(conv3d_fwd_c2_kernel<1>, dim3(gx), dim3(256), 0, st, in, wp, bias, out, s[0], s[1], s[2], tiles1,
+                       tiles2, ntiles, act);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
 template <int CK, int NT>
 int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
                   const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
+  if (pl.c2) {
+    if (ext.mode != 0 || ext.addend) return SYNTHSR_EINVAL;
+    return launch_fwd_c2(in, wp, bias, out, s, Cin, act, st);
+  }
   if (pl.p4) {
     if ((int64_t)s[0] * s[1] * s[2] * Cin * 4 >= (1ll << 31) || ext.mode != 0) return SYNTHSR_EINVAL;
     return launch_fwd_p4(in, wp, bias, out, s, Cin, pl, act, st, ext.addend);
