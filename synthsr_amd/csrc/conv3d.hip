@@ -1690,6 +1690,168 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
   }
 }
 
+// ---- first-layer weight gradient (Cin <= 2, Cout = 24) on the 4x4x1 MFMA -------------------------------------------
+// dW[(tap,ci), co] = sum_v x[v+tap, ci] dz[v, co]: 27*Cin <= 54 GEMM rows.  A (broadcast via ABID) = dz: 8 consecutive
+// voxels x 24 channels are 192 contiguous floats = exactly three coalesced registers (register r, lane l <-> float
+// 64r + l = 4G + i with group G = voxel*6 + channel-quad), no LDS needed.  B = x: lane = row (tap, ci) reads its own
+// element of the voxel's neighbourhood from the [648][Cin] LDS halo tile (per-lane row offset + immediate voxel
+// offset).  One MFMA per (voxel, channel quad); D[i] of lane r = dW[row r][4g+i], kept in 24 registers per lane over
+// all tiles of the workgroup.  Lane 27*Cin reads a constant 1 and so accumulates dbias = sum_v dz[v].
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_c2_kernel(const float* __restrict__ in,
+                                                                 const float* __restrict__ dout,
+                                                                 float* __restrict__ partial, int D0, int D1, int D2,
+                                                                 int tiles1, int tiles2, int ntiles) {
+  constexpr int FH1 = 6, FHV = FH0 * FH1 * FH2, NS = (FHV + 255) / 256, Cout = 24, NROW = 27 * CIN;
+  __shared__ __attribute__((aligned(16))) float lds[2 * FHV * CIN];  // halo tile | ones (read by the dbias lane)
+  __shared__ float red[3 * 64 * 24];
+  constexpr uint32_t OOB = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < FHV * CIN; i += 256) lds[FHV * CIN + i] = 1.f;
+  // per-lane B address: row (tap, ci) of this lane inside the wave's z-plane of the halo tile
+  int rbase;
+  {
+    const int r = lane < NROW ? lane : 0;
+    const int tap = r / CIN, ci = r - tap * CIN;
+    rbase = (((wave + tap / 9) * FH1 + (tap / 3) % 3) * FH2 + tap % 3) * CIN + ci;
+    if (lane == NROW) rbase = FHV * CIN + wave * FH1 * FH2 * CIN;  // ones
+  }
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * CIN * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dout), 0, (int)((int64_t)D0 * D1 * D2 * Cout * 4), 0x00020000);
+  int rel[NS], ldsa[NS];
+  uint32_t cmask[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int j = tid + 256 * i;
+    const int hz = j / (FH1 * FH2), hy = (j / FH2) % FH1, hx = j % FH2;
+    rel[i] = ((hz * D1 + hy) * D2 + hx) * CIN * 4;
+    ldsa[i] = j * CIN;
+    cmask[i] = j < FHV ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+  }
+  int kk[3];  // voxel (0..7) of the octet that register r of this lane belongs to
+#pragma unroll
+  for (int r = 0; r < 3; ++r) kk[r] = (64 * r + lane) / 24;
+  float stg[NS][CIN];
+  float an[8][3];  // dz of the next tile (this wave's z-plane): 8 octets x 3 registers, requested one tile ahead
+  auto load_tile = [&](int t) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    const int z0 = t0 * FT0, y0 = t1 * 4, x0 = t2 * FT2;
+    {
+      const int gz = z0 + wave;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {  // octet o: row vy = o >> 1, x half o & 1
+        const int gy = y0 + (o >> 1), xs = x0 + 8 * (o & 1);
+        const bool rowok = gz < D0 && gy < D1;  // scalar
+        const int so = rowok ? (((gz * D1 + gy) * D2 + xs) * Cout) * 4 : 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int vo = (rowok && xs + kk[r] < D2) ? (64 * r + lane) * 4 : (int)OOB;
+          an[o][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdo, vo, so, 0));
+        }
+      }
+    }
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < FH0; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH1; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH2; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int org = (((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * CIN * 4;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int vo = (cmask[i] & bad) ? (int)OOB : rel[i] + org;
+      if constexpr (CIN == 2) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rin, vo, 0, 0);
+        stg[i][0] = __uint_as_float(v.x);
+        stg[i][1] = __uint_as_float(v.y);
+      } else {
+        stg[i][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rin, vo, 0, 0));
+      }
+    }
+  };
+  f32x4 acc[6];
+#pragma unroll
+  for (int g = 0; g < 6; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int G = gridDim.x;
+  const int my_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  if (my_pos < ntiles) load_tile(my_pos);
+  for (int t = my_pos; t < ntiles; t += G) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    const int z0 = t0 * FT0, y0 = t1 * 4, x0 = t2 * FT2;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (i < NS - 1 || tid + 256 * i < FHV) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) lds[ldsa[i] + c] = stg[i][c];
+      }
+    }
+    __syncthreads();
+    float ar[8][3];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) ar[o][r] = an[o][r];
+    if (t + G < ntiles) load_tile(t + G);
+    sfor<0, 8>([&](auto O) {
+      constexpr int o = decltype(O)::value;
+      float xv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xv[k] = lds[rbase + (((o >> 1) * FH2) + 8 * (o & 1) + k) * CIN];
+      sfor<0, 48>([&](auto GI) {
+        constexpr int GG = decltype(GI)::value, k = GG / 6, g = GG % 6;
+        acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[o][GG / 16], xv[k], acc[g], 4, GG % 16, 0);
+      });
+    });
+  }
+  // ---- combine the four waves (z-planes) and flush once per workgroup
+  __syncthreads();
+  if (wave > 0) {
+#pragma unroll
+    for (int g = 0; g < 6; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[((wave - 1) * 24 + g * 4 + i) * 64 + lane] = acc[g][i];
+  }
+  __syncthreads();
+  if (wave == 0) {  // partial[workgroup][lane = GEMM row][24]; rows_reduce_kernel sums the workgroups
+    float* dst = partial + ((size_t)blockIdx.x * 64 + lane) * 24;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      float4 v;
+      float* pv = &v.x;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = g * 4 + i;
+        pv[i] = acc[g][i] + red[c * 64 + lane] + red[(24 + c) * 64 + lane] + red[(48 + c) * 64 + lane];
+      }
+      *reinterpret_cast<float4*>(dst + 4 * g) = v;
+    }
+  }
+}
+
+// second stage of the first-layer weight gradient: dw / dbias += sum over workgroups of partial[wg][row][24].
+// (Thousands of workgroups adding to the same 1320 addresses with atomics serialise on the memory-side atomic units;
+// here every address receives gridDim.y adds.)
+__global__ void rows_reduce_kernel(const float* __restrict__ partial, int nwg, float* __restrict__ dw,
+                                   float* __restrict__ dbias, int nrow, int cin, int cin_total, int ci_off) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // row * 24 + c
+  if (j >= (nrow + 1) * 24) return;
+  const int row = j / 24, c = j - row * 24;
+  const int per = (nwg + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nwg, b0 + per);
+  float v = 0.f;
+  for (int b = b0; b < b1; ++b) v += partial[(size_t)b * 1536 + j];
+  if (row < nrow) {
+    const int tap = row / cin, ci = row - tap * cin;
+    atomicAdd(&dw[((size_t)tap * cin_total + ci_off + ci) * 24 + c], v);
+  } else if (dbias) {
+    atomicAdd(&dbias[c], v);
+  }
+}
+
 static int g_persist = 1;
 static int g_force_mt = 0;
 static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout % 16 == 8 remainder channels on the
@@ -1951,9 +2113,48 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
+// library-owned device scratch (grown on demand, reused by later calls on the same stream order)
+static float* lib_scratch(size_t bytes) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  if (bytes > cap) {
+    if (buf) (void)hipFree(buf);
+    buf = nullptr;
+    cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&buf), bytes) != hipSuccess) return nullptr;
+    cap = bytes;
+  }
+  return buf;
+}
+
+int launch_wgrad_c2(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int Cin, hipStream_t st,
+                    const WgExt& ext) {
+  const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
+  const int ntiles = tiles0 * tiles1 * tiles2;
+  int gx = g_force_mt > 8 ? g_force_mt : 2048;  // 8 per CU: per-tile work is short, latency is hidden by occupancy
+  while (gx > 8 && gx > ntiles) gx -= 8;
+  float* partial = lib_scratch((size_t)gx * 1536 * sizeof(float));
+  if (!partial) return SYNTHSR_ELAUNCH;
+  if (Cin == 2)
+    hipLaunchKernelGGL(conv3d_wgrad_c2_kernel<2>, dim3(gx), dim3(256), 0, st, in, dout, partial, s[0], s[1], s[2], tiles1,
+                       tiles2, ntiles);
+  else
+    hipLaunchKernelGGL(conv3d_wgrad_c2_kernel<1>, dim3(gx), dim3(256), 0, st, in, dout, partial, s[0], s[1], s[2], tiles1,
+                       tiles2, ntiles);
+  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  const int nrow = 27 * Cin;
+  hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv((nrow + 1) * 24, 64), 32), dim3(64), 0, st, partial, gx, dw, dbias, nrow,
+                     Cin, ext.cin_total, ext.ci_off);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
 template <int NTAPS>
 int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout, hipStream_t st,
                    const WgExt& ext) {
+  if constexpr (NTAPS == 27) {
+    if (Cin <= 2 && Cout == 24 && g_p4 && (int64_t)shape[0] * shape[1] * shape[2] * Cout * 4 < (1ll << 31))
+      return launch_wgrad_c2(in, dout, dw, nullptr, shape, Cin, st, ext);
+  }
   const int CK = ck_for(Cin);
   // output-channel chunks of <= 48 (3 n-tiles) keep the accumulators of all taps x 24 ci in registers
   const int nt_all = cdiv(Cout, 16);
