@@ -1257,6 +1257,7 @@ struct WgExt {
   int cin_total;   // row length of dw in input channels
   int ci_off;      // first input channel of this layer part inside dw
   int64_t dwstride;
+  int dbg;         // timing experiments: 8 = skip the flush
 };
 
 template <int CK, int NT, int MS, int NTAPS>
@@ -1669,6 +1670,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
   }
 
   // ---- flush: D row = (lane>>4)*4 + reg -> (tap, ci), col = lane&15 -> co
+  if (ext.dbg & 8) return;
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
 #pragma unroll
@@ -2082,7 +2084,8 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
   const int ntiles = tiles0 * tiles1 * tiles2;
   const int ncc = cdiv(Cin, CK), nco = cdiv(Cout, NT * 16);
   const int ymul = (NTAPS == 8) ? 8 : MS;
-  int gx = 2048 / (ncc * nco * ymul);
+  // 512 workgroups in total = the 2 per CU that fit: every extra workgroup only adds a 27*CK*Cout atomic flush
+  int gx = (g_force_mt > 8 ? g_force_mt : 512) / (ncc * nco * ymul);
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   const size_t smem = ((size_t)CK * WVPX + (size_t)NT * 16 * WVPD) * sizeof(float);
@@ -2307,7 +2310,7 @@ int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const
   if (!in || !dout || !dw || !shape || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || shape[0] < 1 ||
       shape[1] < 1 || shape[2] < 1)
     return SYNTHSR_EINVAL;
-  const WgExt ext{0, Cin_total, ci_off, 0};
+  const WgExt ext{0, Cin_total, ci_off, 0, g_dbg};
   return dispatch_wgrad<27>(in, dout, dw, shape, Cin, Cout, (hipStream_t)stream, ext);
 }
 
@@ -2320,7 +2323,7 @@ int synthsr_conv3d_up_wgrad(const float* lo, const float* dout, float* dwc, cons
                             synthsr_stream_t stream) {
   if (!lo || !dout || !dwc || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1)
     return SYNTHSR_EINVAL;
-  const WgExt ext{1, Cl, 0, (int64_t)27 * Cl * Cout};
+  const WgExt ext{1, Cl, 0, (int64_t)27 * Cl * Cout, g_dbg};
   return dispatch_wgrad<8>(lo, dout, dwc, lo_shape, Cl, Cout, (hipStream_t)stream, ext);
 }
 
