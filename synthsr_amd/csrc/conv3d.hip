@@ -1861,6 +1861,7 @@ static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout
                           // the MFMAs, so it is slower than padding to 32 columns until the issue order is hand-pinned.
 static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
 
+static int g_ks_target = 1024;  // option 5: workgroup target of the split-K heuristic
 static int g_p4 = 1;  // option 4: 4x4x1-MFMA kernel for the Cout = 24 layers (no padding to 32 columns)
 
 struct FwdPlan {
@@ -1905,7 +1906,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
   p.c2 = (plain && Cout == 24 && Cin <= 2 && lt2g && g_p4) ? Cin : 0;  // first layer: 4x4x1 MFMA over K = 27*Cin
   const int64_t w = wgs(p.mt, p.nt);
   if (w < 512 && p.ncc >= 4 && plain && p.nv == 0) {
-    int ks = (int)cdiv(1024, (int)w);
+    int ks = (int)cdiv(g_ks_target, (int)w);
     if (ks > p.ncc / 2) ks = p.ncc / 2;
     if (ks > 8) ks = 8;
     if (ks >= 2) p.ksplit = ks;
@@ -2300,6 +2301,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 4) {
     g_p4 = value ? 1 : 0;
+    return SYNTHSR_OK;
+  }
+  if (option == 5) {
+    g_ks_target = value > 0 ? value : 1024;
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;
