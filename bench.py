@@ -203,6 +203,17 @@ def main():
                     'all_conv_tflops': round(sum(conv_flops(r['kernel'], r['shape'], r['cin'], r['cout']) * r['launches']
                                                  for r in rows) / (conv_total * 1e-3) / 1e12, 2),
                     'conv_ms_per_step': round(conv_total / args.steps, 3)}
+        # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes (bench.py cannot host the
+        # profiler), committed under profiles/pmc_traffic.json; algorithmic bytes = the tensors one launch must touch
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as f:
+                pmc = json.load(f).get(roofline['kernel'])
+            if pmc and S == 160:
+                roofline['traffic'] = pmc['bytes']
+        except (OSError, ValueError):
+            pass
+        vox = dom['shape'][0] * dom['shape'][1] * dom['shape'][2]
+        roofline['algorithmic_bytes'] = 4 * vox * (dom['cin'] + dom['cout'])
         out = {'metric': 'training volumes/sec (160^3 fp32, 5-level U-Net)', 'value': round(world * args.steps / dt, 4),
                'unit': 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
