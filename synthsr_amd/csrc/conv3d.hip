@@ -2117,6 +2117,193 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
+// ---- weight gradient of a 24-input-channel chunk with Cout = 24 on the 4x4x1 MFMA ----------------------------------
+// The 16x16x4 kernel pads Cout = 24 to 32 columns and 648 (tap, ci) rows to 704.  Here (cf. conv3d_wgrad_c2_kernel):
+//   A (one block broadcast by ABID) = dz: 8 consecutive voxels x 24 channels = 192 contiguous floats = 3 coalesced
+//     registers straight from memory (register r, lane l <-> float 64 r + l);
+//   B = x: a register holds 16 blocks of 4 consecutive input channels, block = (tap, channel quad); the lane reads its
+//     element of the voxel's neighbourhood from the [voxel][24+4] LDS halo tile (per-lane row offset + immediate);
+//   D[i] of lane (block, j) = dW[tap][4 quad + j][4 g + i].
+// The 162 blocks are split over the 4 waves (41/41/40/40 -> 3 registers each, 85 % of the MFMA work useful instead of
+// 69 %); every wave walks all 256 voxels of the 4x4x16 tile: per voxel 3 ds_read_b32 + 18 MFMAs.  The dz registers of
+// the next z-plane and the x halo of the next tile are requested one plane / one tile ahead.
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_p4_kernel(const float* __restrict__ in,
+                                                                 const float* __restrict__ dout, float* __restrict__ dw,
+                                                                 int D0, int D1, int D2, int Cin, int tiles1, int tiles2,
+                                                                 int ntiles, int cin_total, int ci_off, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CK = 24, MT = 4, Cout = 24;
+  constexpr int FT1 = MT, FH1 = MT + 2, CKP = CK + 4, C4 = CK / 4;
+  constexpr int NBLK = 27 * 6, BPW = (NBLK + 3) / 4, NQ = (BPW + 15) / 16;  // 41 blocks per wave in 3 registers
+  constexpr uint32_t OOB = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cc = blockIdx.y;
+  const int G = gridDim.x;
+  const int my_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+
+  // B rows of this lane: block blk = wave*BPW + 16 q + (lane >> 2), channel 4*quad + (lane & 3)
+  int rowoff[NQ];
+  bool rowok[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int lb = 16 * q + (lane >> 2);
+    const int blk = wave * BPW + lb;
+    rowok[q] = lb < BPW && blk < NBLK;
+    const int bb = rowok[q] ? blk : 0;
+    const int tap = bb / 6, quad = bb - tap * 6;
+    rowoff[q] = (((tap / 9) * FH1 + (tap / 3) % 3) * FH2 + tap % 3) * CKP + quad * 4 + (lane & 3);
+  }
+
+  // ---- x halo staging (as conv3d_fwd_p4_kernel)
+  constexpr int PLANE4 = FH1 * FH2 * C4, NJ = (PLANE4 + 255) / 256, NLD = NJ * FH0;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dout), 0, (int)((int64_t)D0 * D1 * D2 * Cout * 4), 0x00020000);
+  int rel[NJ], ldsa[NJ];
+  uint32_t cmask[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = tid + 256 * i;
+    const int hy = j / (FH2 * C4), r = j - hy * (FH2 * C4), hx = r / C4, c4 = r - hx * C4;
+    rel[i] = ((hy * D2 + hx) * Cin + c4 * 4) * 4;
+    ldsa[i] = ((hy * FH2 + hx) * CKP + c4 * 4);
+    cmask[i] = j < PLANE4 ? ((1u << hy) | (1u << (8 + hx))) : 0xFFFFFFFFu;
+  }
+  const int plane_bytes = D1 * D2 * Cin * 4;
+  int kk[3];  // voxel (0..7) of the octet that dz register r of this lane belongs to
+#pragma unroll
+  for (int r = 0; r < 3; ++r) kk[r] = (64 * r + lane) / 24;
+  float4 stg[NLD];
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    z0 = t0 * FT0;
+    y0 = t1 * FT1;
+    x0 = t2 * FT2;
+  };
+  auto load_halo = [&](int t) {
+    int z0, y0, x0;
+    tile_origin(t, z0, y0, x0);
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < FH1; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH2; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (8 + h)) : 0u;
+    const int yx = (((y0 - 1) * D2 + (x0 - 1)) * Cin + cc * CK) * 4;
+    uint32_t voff[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) voff[i] = (cmask[i] & bad) ? OOB : (uint32_t)(rel[i] + yx);
+#pragma unroll
+    for (int hz = 0; hz < FH0; ++hz) {
+      const int gz = z0 - 1 + hz;
+      const bool pv = (unsigned)gz < (unsigned)D0;
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? voff[i] : OOB), pv ? gz * plane_bytes : 0, 0);
+        stg[hz * NJ + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+    }
+  };
+  // dz of z-plane `z` of tile (z0, y0, x0): 8 octets (row y = o >> 1, x half o & 1) x 3 registers
+  auto load_dz = [&](int z0, int y0, int x0, int z, float (&a)[8][3]) {
+    const int gz = z0 + z;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int gy = y0 + (o >> 1), xs = x0 + 8 * (o & 1);
+      const bool ok = gz < D0 && gy < D1;  // scalar
+      const int so = ok ? (((gz * D1 + gy) * D2 + xs) * Cout) * 4 : 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int vo = (ok && xs + kk[r] < D2) ? (64 * r + lane) * 4 : (int)OOB;
+        a[o][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdo, vo, so, 0));
+      }
+    }
+  };
+
+  f32x4 acc[NQ][6];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int g = 0; g < 6; ++g) acc[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float an[8][3];
+  int z0 = 0, y0 = 0, x0 = 0;
+  if (my_pos < ntiles) {
+    load_halo(my_pos);
+    tile_origin(my_pos, z0, y0, x0);
+    load_dz(z0, y0, x0, 0, an);
+  }
+  for (int t = my_pos; t < ntiles; t += G) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      if (i < NJ - 1 || tid + 256 * i < PLANE4) {
+#pragma unroll
+        for (int hz = 0; hz < FH0; ++hz)
+          *reinterpret_cast<float4*>(&lds[ldsa[i] + hz * (FH1 * FH2 * CKP)]) = stg[hz * NJ + i];
+      }
+    }
+    __syncthreads();
+    const bool has_next = t + G < ntiles;
+    if (has_next) load_halo(t + G);
+    int nz0 = z0, ny0 = y0, nx0 = x0;
+    if (has_next) tile_origin(t + G, nz0, ny0, nx0);
+    for (int z = 0; z < FT0; ++z) {
+      float ar[8][3];
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ar[o][r] = an[o][r];
+      if (z + 1 < FT0) {
+        load_dz(z0, y0, x0, z + 1, an);
+      } else if (has_next) {
+        load_dz(nz0, ny0, nx0, 0, an);
+      }
+      int rb[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) rb[q] = rowoff[q] + z * (FH1 * FH2 * CKP);
+      // 64 voxels of the plane; the B elements of voxel s+1 are read while the 18 MFMAs of voxel s issue
+      float xq[2][NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) xq[0][q] = lds[rb[q]];
+      sfor<0, 64>([&](auto S) {
+        constexpr int sv = decltype(S)::value, o = sv / 8, k = sv % 8;
+        constexpr int sn = sv + 1 < 64 ? sv + 1 : sv, on = sn / 8, kn = sn % 8;
+        constexpr int nbase = ((on >> 1) * FH2 + 8 * (on & 1) + kn) * CKP;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xq[(sv + 1) & 1][q] = lds[rb[q] + nbase];
+        __builtin_amdgcn_sched_barrier(0);
+        sfor<0, 6>([&](auto GI) {
+          constexpr int g = decltype(GI)::value, GG = k * 6 + g;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            acc[q][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[o][GG / 16], xq[sv & 1][q], acc[q][g], 4, GG % 16, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    z0 = nz0;
+    y0 = ny0;
+    x0 = nx0;
+  }
+  if (dbg & 8) return;
+  // ---- flush through LDS: the 648 x 24 partial of this workgroup is laid out like the dW chunk ([tap][ci][co]), so that
+  // every atomic instruction covers 64 consecutive floats (per-lane rows would issue 64 cache-line requests each)
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (!rowok[q]) continue;
+    const int blk = wave * BPW + 16 * q + (lane >> 2);
+    float* d = lds + (blk * 4 + (lane & 3)) * Cout;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) *reinterpret_cast<float4*>(d + 4 * g) = make_float4(acc[q][g][0], acc[q][g][1], acc[q][g][2], acc[q][g][3]);
+  }
+  __syncthreads();
+  for (int e = tid; e < 27 * CK * Cout; e += 256) {
+    const int tap = e / (CK * Cout), r = e - tap * (CK * Cout);
+    atomicAdd(dw + ((size_t)tap * cin_total + ci_off + cc * CK) * Cout + r, lds[e]);
+  }
+}
+
 // library-owned device scratch (grown on demand, reused by later calls on the same stream order)
 static float* lib_scratch(size_t bytes) {
   static float* buf = nullptr;
@@ -2158,6 +2345,26 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
   if constexpr (NTAPS == 27) {
     if (Cin <= 2 && Cout == 24 && g_p4 && (int64_t)shape[0] * shape[1] * shape[2] * Cout * 4 < (1ll << 31))
       return launch_wgrad_c2(in, dout, dw, nullptr, shape, Cin, st, ext);
+  }
+  if constexpr (NTAPS == 27) {
+    const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
+    if (Cout == 24 && (Cin % 24) == 0 && g_p4 && vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31) &&
+        !(g_dbg & 16)) {
+      const int tiles0 = cdiv(shape[0], FT0), tiles1 = cdiv(shape[1], 4), tiles2 = cdiv(shape[2], FT2);
+      const int ntiles = tiles0 * tiles1 * tiles2, ncc = Cin / 24;
+      const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_p4_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+      }
+      int gx = std::max(8, ((512 / ncc) / 8) * 8);
+      while (gx > 8 && gx > ntiles) gx -= 8;
+      hipLaunchKernelGGL(conv3d_wgrad_p4_kernel, dim3(gx, ncc), dim3(256), smem, st, in, dout, dw, shape[0], shape[1],
+                         shape[2], Cin, tiles1, tiles2, ntiles, ext.cin_total, ext.ci_off, ext.dbg);
+      return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+    }
   }
   const int CK = ck_for(Cin);
   // output-channel chunks of <= 48 (3 n-tiles) keep the accumulators of all taps x 24 ci in registers
