@@ -130,8 +130,10 @@ int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], i
 int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
                        int Cin, int Cout, int act, synthsr_stream_t stream);
 
-/* out = act(conv3(in) + addend + bias); addend is indexed like out and may alias it (in-place accumulation).  Layers
- * that are split over input channels (small deep levels) accumulate with atomics and require addend == out or NULL. */
+/* act 0/1: out = act(conv3(in) + addend + bias); addend is indexed like out and may alias it (in-place accumulation).
+ * Layers that are split over input channels (small deep levels) accumulate with atomics and require addend == out or NULL.
+ * act 2 (data gradient fused with the ELU backward of the layer below): out = conv3(in) * elu'(y), y = addend != out is
+ * that layer's ELU output, elu'(y) = 1 for y > 0 else y + 1 (layers.py ELU, models.py:283). */
 int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* bias, const float* addend, float* out,
                            const int shape[3], int Cin, int Cout, int act, synthsr_stream_t stream);
 
@@ -156,6 +158,9 @@ int synthsr_conv3d_up_wgrad(const float* lo, const float* dout, float* dwc, cons
 int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_off, int Cl, int Cout,
                              synthsr_stream_t stream);
 /* weight gradient of a layer part: in has Cin channels, dw rows are Cin_total wide, written at ci_off */
+/* as synthsr_conv3d_wgrad_ex, and dbias[Cout] += sum over voxels of dout (a constant-1 row of the same GEMM); NULL = skip */
+int synthsr_conv3d_wgrad_bias(const float* in, const float* dout, float* dw, float* dbias, const int shape[3],
+                              int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream);
 int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
                             int Cin, int Cout, synthsr_stream_t stream);
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     'synthsr_conv3d_up_dgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_conv3d_up_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_conv3d_up_unpack': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_wgrad_bias': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad_ex': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),

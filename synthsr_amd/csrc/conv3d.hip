@@ -44,6 +44,8 @@ __device__ __forceinline__ float elu_f(float v) {
   const float n = v > -0.125f ? p : e;
   return v > 0.f ? v : n;
 }
+// derivative of ELU expressed through its output y: 1 for y > 0, y + 1 (= e^x) otherwise
+__device__ __forceinline__ float elu_dy(float y) { return y > 0.f ? 1.f : y + 1.f; }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // -------------------------------------------------------------------------------------------- pack
@@ -225,7 +227,13 @@ __device__ __forceinline__ void store_tile_rows(f32x4 (&acc)[MT][NT], float* sla
       const int x = idx / wc4, c4 = idx - x * wc4;
       float4 v = *reinterpret_cast<const float4*>(&slab[x * NW + c4 * 4]);
       const size_t o = rowoff + (size_t)x * Cout + c4 * 4;
-      if (addend) {  // wave-uniform; may alias out (same element read and written by this lane)
+      if (act == 2) {  // data-gradient fused with the ELU backward of the producing layer: addend = its output y
+        const float4 a = *reinterpret_cast<const float4*>(addend + o);
+        v.x *= elu_dy(a.x);
+        v.y *= elu_dy(a.y);
+        v.z *= elu_dy(a.z);
+        v.w *= elu_dy(a.w);
+      } else if (addend) {  // wave-uniform; may alias out (same element read and written by this lane)
         const float4 a = *reinterpret_cast<const float4*>(addend + o);
         v.x += a.x;
         v.y += a.y;
@@ -499,7 +507,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
               atomicAdd(out + oidx, acc[m][n][r]);
             } else {
               float v = acc[m][n][r] + bv;
-              if (ext.addend) v += ext.addend[oidx];
+              if (act == 2) v *= elu_dy(ext.addend[oidx]);
+              else if (ext.addend) v += ext.addend[oidx];
               if (act == 1) v = elu_f(v);
               out[oidx] = v;
             }
@@ -887,7 +896,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
             v.z += bias[4 * g + 2];
             v.w += bias[4 * g + 3];
           }
-          if (addend) {  // may alias out: same element read and written by this lane
+          if (act == 2) {  // fused ELU backward of the producing layer (addend = its output)
+            const float4 a = *reinterpret_cast<const float4*>(addend + o + 4 * g);
+            v.x *= elu_dy(a.x);
+            v.y *= elu_dy(a.y);
+            v.z *= elu_dy(a.z);
+            v.w *= elu_dy(a.w);
+          } else if (addend) {  // may alias out: same element read and written by this lane
             const float4 a = *reinterpret_cast<const float4*>(addend + o + 4 * g);
             v.x += a.x;
             v.y += a.y;
@@ -1222,7 +1237,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
               atomicAdd(out + oidx, acc[m][n][r]);
             } else {
               float v = acc[m][n][r] + bv;
-              if (ext.addend) v += ext.addend[oidx];
+              if (act == 2) v *= elu_dy(ext.addend[oidx]);
+              else if (ext.addend) v += ext.addend[oidx];
               if (act == 1) v = elu_f(v);
               out[oidx] = v;
             }
@@ -1235,10 +1251,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
 
 // bias + activation after a split-K accumulation
 __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t n,
-                                                       int C, int act) {
+                                                       int C, int act, const float* __restrict__ eluy) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float v = y[i] + (bias ? bias[i % C] : 0.f);
     if (act == 1) v = elu_f(v);
+    if (act == 2) v *= elu_dy(eluy[i]);
     y[i] = v;
   }
 }
@@ -1258,6 +1275,7 @@ struct WgExt {
   int ci_off;      // first input channel of this layer part inside dw
   int64_t dwstride;
   int dbg;         // timing experiments: 8 = skip the flush
+  float* dbias;    // optional: += sum over voxels of dout (a constant-1 GEMM row), else nullptr
 };
 
 template <int CK, int NT, int MS, int NTAPS>
@@ -1492,8 +1510,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
                                                                    WgExt ext) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CK = 24;
-  float* lx = lds;              // [CK][WVPX]
-  float* ld = lds + CK * WVPX;  // [NT*16][WVPD]
+  float* lx = lds;                    // [CK + 1][WVPX]; row CK is all ones (the dbias GEMM row)
+  float* ld = lds + (CK + 1) * WVPX;  // [NT*16][WVPD]
+  for (int i = threadIdx.x; i < WVPX; i += 256) lx[CK * WVPX + i] = 1.f;
   constexpr int MR = NTAPS * CK;
   constexpr int MTILES = (MR + 15) / 16;
   constexpr int MTP = (MTILES + MS - 1) / MS;
@@ -1528,10 +1547,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
     int r = (mt0 + wave + 4 * m) * 16 + li;
+    const bool ones = NTAPS == 27 && r == MR;  // row MR: x = 1 at the centre tap -> sum of dout = dbias
     if (r >= MR) r = MR - 1;
     const int ti = r / CK, cil = r - ti * CK;
-    const int tap = nth_tap(ti);
-    a_base[m] = cil * WVPX + ((tap / 9) * WH1 + (tap / 3) % 3) * WH2 + tap % 3 + kq;
+    const int tap = ones ? 13 : nth_tap(ti);
+    a_base[m] = (ones ? CK : cil) * WVPX + ((tap / 9) * WH1 + (tap / 3) % 3) * WH2 + tap % 3 + kq;
   }
   const int b_base = li * WVPD + kq;
 
@@ -1677,6 +1697,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
     for (int r = 0; r < 4; ++r) {
       if (wave + 4 * m >= MTP) continue;
       const int row = (mt0 + wave + 4 * m) * 16 + kq * 4 + r;
+      if (NTAPS == 27 && row == MR && ext.dbias && cc == 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int co = co0 + n * 16 + li;
+          if (co < Cout) atomicAdd(&ext.dbias[co], acc[m][n][r]);
+        }
+      }
       if (row >= MR) continue;
       const int ti = row / CK, cil = row - ti * CK;
       const int tap = nth_tap(ti);
@@ -1854,6 +1881,17 @@ __global__ void rows_reduce_kernel(const float* __restrict__ partial, int nwg, f
   }
 }
 
+// dbias fallback for the generic weight-gradient kernel: per-channel sum of dout [n][C]
+__global__ void colsum_kernel(const float* __restrict__ x, int64_t n, int C, float* __restrict__ out) {
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t v0 = blockIdx.x * per, v1 = v0 + per < n ? v0 + per : n;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int64_t v = v0; v < v1; ++v) acc += x[v * C + c];
+    atomicAdd(out + c, acc);
+  }
+}
+
 static int g_persist = 1;
 static int g_force_mt = 0;
 static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout % 16 == 8 remainder channels on the
@@ -1925,8 +1963,9 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
     if (in_bytes < (1ll << 31) && w_bytes < (1ll << 31) && !(g_dbg & 32)) {
       const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
       if (KS) {  // split-K accumulates with atomics: onto zeros, or onto the addend when it already sits in `out`
-        if (ext.addend && ext.addend != out) return SYNTHSR_EINVAL;
-        if (!ext.addend && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
+        if (act != 2 && ext.addend && ext.addend != out) return SYNTHSR_EINVAL;
+        if ((act == 2 || !ext.addend) && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess)
+          return SYNTHSR_ELAUNCH;
       }
       const int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
       const dim3 grid(tiles0 * tiles1 * tiles2, pl.nchunks, gz);
@@ -1955,7 +1994,8 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
       }
       if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
       if (KS && (bias != nullptr || act != 0)) {
-        hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act);
+        hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act,
+                         act == 2 ? ext.addend : nullptr);
         if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
       }
       return SYNTHSR_OK;
@@ -1969,15 +2009,17 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
   }
   const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
   if (KS) {
-    if (ext.addend && ext.addend != out) return SYNTHSR_EINVAL;
-    if (!ext.addend && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
+    if (act != 2 && ext.addend && ext.addend != out) return SYNTHSR_EINVAL;
+    if ((act == 2 || !ext.addend) && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess)
+      return SYNTHSR_ELAUNCH;
   }
   const int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
   hipLaunchKernelGGL(kern, dim3(tiles0 * tiles1 * tiles2, pl.nchunks, gz), dim3(256), smem, st, in, wp, bias, out, s[0],
                      s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act | (g_dbg << 8), ext);
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   if (KS && (bias != nullptr || act != 0)) {
-    hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act);
+    hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act,
+                         act == 2 ? ext.addend : nullptr);
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   }
   return SYNTHSR_OK;
@@ -2089,7 +2131,7 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
   int gx = (g_force_mt > 8 ? g_force_mt : 512) / (ncc * nco * ymul);
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
-  const size_t smem = ((size_t)CK * WVPX + (size_t)NT * 16 * WVPD) * sizeof(float);
+  const size_t smem = ((size_t)(CK + 1) * WVPX + (size_t)NT * 16 * WVPD) * sizeof(float);
   if constexpr (CK == 24) {
     const int dsc = (NTAPS == 8) ? 8 : 1;
     const int64_t xbytes = (int64_t)s[0] * s[1] * s[2] * Cin * 4, dbytes = (int64_t)s[0] * s[1] * s[2] * dsc * Cout * 4;
@@ -2112,6 +2154,10 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
+  if (ext.dbias) {  // the generic kernel has no dbias row
+    hipLaunchKernelGGL(colsum_kernel, dim3(1024), dim3(64), 0, st, dout, (int64_t)s[0] * s[1] * s[2], Cout, ext.dbias);
+    if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  }
   hipLaunchKernelGGL(kern, dim3(gx, ncc * ymul, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout,
                      tiles0, tiles1, tiles2, ext);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
@@ -2130,7 +2176,8 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_p4_kernel(const float* __restrict__ in,
                                                                  const float* __restrict__ dout, float* __restrict__ dw,
                                                                  int D0, int D1, int D2, int Cin, int tiles1, int tiles2,
-                                                                 int ntiles, int cin_total, int ci_off, int dbg) {
+                                                                 int ntiles, int cin_total, int ci_off, int dbg,
+                                                                 float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CK = 24, MT = 4, Cout = 24;
   constexpr int FT1 = MT, FH1 = MT + 2, CKP = CK + 4, C4 = CK / 4;
@@ -2148,11 +2195,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_p4_kernel(const float* __
   for (int q = 0; q < NQ; ++q) {
     const int lb = 16 * q + (lane >> 2);
     const int blk = wave * BPW + lb;
-    rowok[q] = lb < BPW && blk < NBLK;
-    const int bb = rowok[q] ? blk : 0;
+    rowok[q] = lb < BPW && blk <= NBLK;  // block NBLK (a free slot of wave 3) is the dbias row, see below
+    const int bb = (lb < BPW && blk < NBLK) ? blk : 0;
     const int tap = bb / 6, quad = bb - tap * 6;
     rowoff[q] = (((tap / 9) * FH1 + (tap / 3) % 3) * FH2 + tap % 3) * CKP + quad * 4 + (lane & 3);
+    if (lb < BPW && blk == NBLK) rowoff[q] = ((FH1 + 1) * FH2 + 1) * CKP + CK + (lane & 3);  // centre tap, pad channels
   }
+  // pad channels 24..27 of every halo voxel = (1, 0, 0, 0): the staging never writes them, and lane j = 0 of block NBLK
+  // reads the 1 as its "x" -> D = sum over voxels of dz = dbias
+  static_assert(NBLK - 3 * BPW < BPW && 3 * BPW + BPW > NBLK, "block NBLK must fall into wave 3's slots");
+  for (int v = tid; v < FH0 * FH1 * FH2; v += 256)
+    *reinterpret_cast<float4*>(&lds[v * CKP + CK]) = make_float4(1.f, 0.f, 0.f, 0.f);
 
   // ---- x halo staging (as conv3d_fwd_p4_kernel)
   constexpr int PLANE4 = FH1 * FH2 * C4, NJ = (PLANE4 + 255) / 256, NLD = NJ * FH0;
@@ -2292,7 +2345,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_p4_kernel(const float* __
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     if (!rowok[q]) continue;
-    const int blk = wave * BPW + 16 * q + (lane >> 2);
+    const int blk = wave * BPW + 16 * q + (lane >> 2);  // block NBLK lands right behind the 648 x 24 dW chunk
     float* d = lds + (blk * 4 + (lane & 3)) * Cout;
 #pragma unroll
     for (int g = 0; g < 6; ++g) *reinterpret_cast<float4*>(d + 4 * g) = make_float4(acc[q][g][0], acc[q][g][1], acc[q][g][2], acc[q][g][3]);
@@ -2302,6 +2355,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_p4_kernel(const float* __
     const int tap = e / (CK * Cout), r = e - tap * (CK * Cout);
     atomicAdd(dw + ((size_t)tap * cin_total + ci_off + cc * CK) * Cout + r, lds[e]);
   }
+  if (dbias && cc == 0 && tid < Cout) atomicAdd(dbias + tid, lds[NBLK * 4 * Cout + tid]);
 }
 
 // library-owned device scratch (grown on demand, reused by later calls on the same stream order)
@@ -2344,7 +2398,7 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
                    const WgExt& ext) {
   if constexpr (NTAPS == 27) {
     if (Cin <= 2 && Cout == 24 && g_p4 && (int64_t)shape[0] * shape[1] * shape[2] * Cout * 4 < (1ll << 31))
-      return launch_wgrad_c2(in, dout, dw, nullptr, shape, Cin, st, ext);
+      return launch_wgrad_c2(in, dout, dw, ext.dbias, shape, Cin, st, ext);
   }
   if constexpr (NTAPS == 27) {
     const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
@@ -2362,7 +2416,7 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
       int gx = std::max(8, ((512 / ncc) / 8) * 8);
       while (gx > 8 && gx > ntiles) gx -= 8;
       hipLaunchKernelGGL(conv3d_wgrad_p4_kernel, dim3(gx, ncc), dim3(256), smem, st, in, dout, dw, shape[0], shape[1],
-                         shape[2], Cin, tiles1, tiles2, ntiles, ext.cin_total, ext.ci_off, ext.dbg);
+                         shape[2], Cin, tiles1, tiles2, ntiles, ext.cin_total, ext.ci_off, ext.dbg, ext.dbias);
       return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
     }
   }
@@ -2455,7 +2509,7 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
 int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* bias, const float* addend, float* out,
                            const int shape[3], int Cin, int Cout, int act, synthsr_stream_t stream) {
   if (!in || !wpacked || !out || !shape || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1 ||
-      (act != 0 && act != 1))
+      (act != 0 && act != 1 && act != 2) || (act == 2 && (!addend || addend == out)))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   const ConvExt ext{0, addend, 0, pl.mfma_count()};
@@ -2517,13 +2571,18 @@ int synthsr_conv3d_set_option(int option, int value) {
   return SYNTHSR_EINVAL;
 }
 
-int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
-                            int Cin, int Cout, synthsr_stream_t stream) {
+int synthsr_conv3d_wgrad_bias(const float* in, const float* dout, float* dw, float* dbias, const int shape[3],
+                              int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream) {
   if (!in || !dout || !dw || !shape || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || shape[0] < 1 ||
       shape[1] < 1 || shape[2] < 1)
     return SYNTHSR_EINVAL;
-  const WgExt ext{0, Cin_total, ci_off, 0, g_dbg};
+  const WgExt ext{0, Cin_total, ci_off, 0, g_dbg, dbias};
   return dispatch_wgrad<27>(in, dout, dw, shape, Cin, Cout, (hipStream_t)stream, ext);
+}
+
+int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
+                            int Cin, int Cout, synthsr_stream_t stream) {
+  return synthsr_conv3d_wgrad_bias(in, dout, dw, nullptr, shape, Cin_total, ci_off, Cin, Cout, stream);
 }
 
 int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout,
@@ -2535,7 +2594,7 @@ int synthsr_conv3d_up_wgrad(const float* lo, const float* dout, float* dwc, cons
                             synthsr_stream_t stream) {
   if (!lo || !dout || !dwc || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1)
     return SYNTHSR_EINVAL;
-  const WgExt ext{1, Cl, 0, (int64_t)27 * Cl * Cout, g_dbg};
+  const WgExt ext{1, Cl, 0, (int64_t)27 * Cl * Cout, g_dbg, nullptr};
   return dispatch_wgrad<8>(lo, dout, dwc, lo_shape, Cl, Cout, (hipStream_t)stream, ext);
 }
 

@@ -123,14 +123,15 @@ def conv3d_up_wgrad(lo, dout, dwc, dw, ci_off):
     return dw
 
 
-def conv3d_wgrad_part(x, dout, dw, ci_off):
-    """dw [3,3,3,Cin_total,Cout] += gradient of the input-channel range [ci_off, ci_off + x.shape[3])"""
+def conv3d_wgrad_part(x, dout, dw, ci_off, dbias=None):
+    """dw [3,3,3,Cin_total,Cout] += gradient of the input-channel range [ci_off, ci_off + x.shape[3]);
+    dbias [Cout] (optional) += sum over voxels of dout"""
     lib = _L()
     s = x.shape
     with _Timed('conv3d_wgrad', s[:3], s[3], dout.shape[3]):
-        _lib.check(lib.synthsr_conv3d_wgrad_ex(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.i3(s[:3]),
-                                               int(dw.shape[3]), int(ci_off), int(s[3]), int(dout.shape[3]),
-                                               _lib.stream()), 'conv3d_wgrad_ex')
+        _lib.check(lib.synthsr_conv3d_wgrad_bias(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.ptr(dbias),
+                                                 _lib.i3(s[:3]), int(dw.shape[3]), int(ci_off), int(s[3]),
+                                                 int(dout.shape[3]), _lib.stream()), 'conv3d_wgrad_bias')
     return dw
 
 
@@ -147,26 +148,22 @@ def conv3d(x, wpacked, bias, Cout, act=1, out=None):
 
 
 def conv3d_add(x, wpacked, bias, addend, Cout, act=1, out=None):
-    """act(conv3(x) + addend + bias); `addend` may be `out` itself (in-place accumulation)"""
+    """act 0/1: act(conv3(x) + addend + bias), `addend` may be `out` itself (in-place accumulation);
+    act 2: conv3(x) * elu'(addend) -- data gradient fused with the ELU backward of the layer that produced `addend`"""
     lib = _L()
     s = x.shape
     if out is None:
         out = torch.empty((s[0], s[1], s[2], Cout), dtype=torch.float32, device=x.device)
-    with _Timed('conv3d_fwd', s[:3], s[3], Cout):
+    with _Timed('conv3d_dgrad' if act == 2 else 'conv3d_fwd', s[:3], s[3], Cout):
         _lib.check(lib.synthsr_conv3d_fwd_add(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(addend),
                                               _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), int(Cout), int(act),
                                               _lib.stream()), 'conv3d_fwd_add')
     return out
 
 
-def conv3d_wgrad(x, dout, dw):
-    """dw [3,3,3,Cin,Cout] += sum_v x[v+t-1] (x) dout[v]"""
-    lib = _L()
-    s = x.shape
-    with _Timed('conv3d_wgrad', s[:3], s[3], dout.shape[3]):
-        _lib.check(lib.synthsr_conv3d_wgrad(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.i3(s[:3]), int(s[3]),
-                                            int(dout.shape[3]), _lib.stream()), 'conv3d_wgrad')
-    return dw
+def conv3d_wgrad(x, dout, dw, dbias=None):
+    """dw [3,3,3,Cin,Cout] += sum_v x[v+t-1] (x) dout[v]; dbias [Cout] (optional) += sum_v dout[v]"""
+    return conv3d_wgrad_part(x, dout, dw, 0, dbias)
 
 
 def elu_bwd(dy, y, dy2=None, dbias=None, out=None):

@@ -363,11 +363,11 @@ class UNet3D:
                 skip, lo_bn = self.saved['cat'][k]
                 Cl = lo_bn.shape[3]
                 # all convs but the first: regular; the first one through the folded kernels
-                g = self._convs_backward(g, None, d['convs'][1:], acts[1:], acts[0], need_dx=True, tag='d%d' % k)
+                dz = self._convs_backward(g, None, d['convs'][1:], acts[1:], acts[0], need_dx=True, tag='d%d' % k,
+                                          elu_below=acts[0])
                 c0 = d['convs'][0]
-                dz = self._elu_backward(g, acts[0], None, self.view(c0['b'], self.grads))
                 dW = self.view(c0['w'], self.grads)
-                ops.conv3d_wgrad_part(skip, dz, dW, 0)
+                ops.conv3d_wgrad_part(skip, dz, dW, 0, dbias=self.view(c0['b'], self.grads))
                 ops.conv3d_up_wgrad(lo_bn, dz, self.buf('dwc', [8, 27, Cl, c0['cout']]), dW, Cs)
                 dskips[l] = ops.conv3d(dz, c0['wpd_s'], None, Cs, 0, out=self.buf('dskip%d' % l, self.shapes[l] + [Cs]))
                 g = ops.conv3d_up_dgrad(dz, c0['wpd_u'], Cl, out=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
@@ -408,18 +408,32 @@ class UNet3D:
             return ops.bn_elu_bwd(g, y, self._stats(bn), self.view(bn['gamma']), sums, dy2=dy2, dbias=dbias, out=out)
         return ops.elu_bwd(g, y, dy2=dy2, dbias=dbias, out=out)
 
-    def _convs_backward(self, g, g2, convs, acts, x_in, need_dx, tag):
-        """g (+g2) = gradient w.r.t. the output of the last conv's ELU. Returns gradient w.r.t. x_in (or None)."""
+    def _convs_backward(self, g, g2, convs, acts, x_in, need_dx, tag, elu_below=None):
+        """g (+g2) = gradient w.r.t. the output of the last conv's ELU. Returns gradient w.r.t. x_in (or None);
+        with elu_below = x_in being itself an ELU output, the returned gradient is w.r.t. the pre-activation of x_in."""
+        fused = False  # g already is dz of conv j (ELU backward applied in the data-gradient epilogue of conv j+1)
         for j in range(len(convs) - 1, -1, -1):
             c = convs[j]
             y = acts[j]
-            dz = self._elu_backward(g, y, g2, self.view(c['b'], self.grads))
-            g2 = None
             xin = acts[j - 1] if j > 0 else x_in
-            ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads))
+            if fused:
+                dz = g
+                ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads), dbias=self.view(c['b'], self.grads))
+            else:
+                dz = self._elu_backward(g, y, g2, self.view(c['b'], self.grads))
+                ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads))
+            g2 = None
+            fused = False
             if j > 0 or need_dx:
-                g = ops.conv3d(dz, c['wpd'], None, c['cin'], 0, out=self.buf('dx_%s_%d' % (tag, j & 1),
-                                                                             list(xin.shape)))
+                out = self.buf('dx_%s_%d' % (tag, j & 1), list(xin.shape))
+                # the ELU backward of the layer below (no BatchNorm in between) rides in the epilogue: one pass over
+                # the activation instead of three; its dbias comes out of the weight-gradient GEMM
+                below = acts[j - 1] if j > 0 else elu_below
+                if below is not None:
+                    g = ops.conv3d_add(dz, c['wpd'], None, below, c['cin'], 2, out=out)
+                    fused = True
+                else:
+                    g = ops.conv3d(dz, c['wpd'], None, c['cin'], 0, out=out)
             else:
                 g = None
         return g

@@ -132,7 +132,9 @@ def test_c_abi_exports_every_declared_symbol():
     # argument validation happens before any HIP call: usable without a GPU
     _lib.load()
     big = _lib.i3([160, 160, 160])
-    assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 27 * 3 * 2 * 128
+    # packed sizes (query mode): Cout = 24 uses the unpadded 4x4x1-MFMA layout, 48 -> 48 the 16x16x4 B-fragment layout
+    assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 27 * 24 * 24
+    assert _lib.load().synthsr_conv3d_pack(None, None, _lib.i3([80, 80, 80]), 48, 48, 0, None) == 2 * 27 * 3 * 3 * 128
     assert _lib.load().synthsr_conv3d_pack(None, None, big, 0, 24, 0, None) == -1
 
 

@@ -58,6 +58,15 @@ def test_conv3d_fwd_dgrad_wgrad(T, shape, Cin, Cout):
     dw = torch.zeros_like(wd)
     ops.conv3d_wgrad(xd, dyd, dw)
     close(dw, wr.grad, name='wgrad')
+    # dbias from the constant-1 row of the weight-gradient GEMM
+    dw2, db = torch.zeros_like(wd), torch.zeros(Cout, device='cuda')
+    ops.conv3d_wgrad(xd, dyd, dw2, dbias=db)
+    close(dw2, wr.grad, name='wgrad (with dbias)')
+    close(db, dy.reshape(-1, Cout).sum(0), name='dbias')
+    # data gradient fused with the ELU backward of the layer below (y = that layer's ELU output)
+    ybelow = torch.nn.functional.elu(torch.randn(*shape, Cin, generator=g))
+    deriv = torch.where(ybelow > 0, torch.ones_like(ybelow), ybelow + 1)
+    close(ops.conv3d_add(dyd, wpd, None, ybelow.cuda(), Cin, act=2), xr.grad * deriv, name='dgrad * elu\'')
 
 
 def test_conv3d_identity_and_transpose_detecting(T):
