@@ -1249,6 +1249,179 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
   }
 }
 
+// ---- "brick" forward kernel for the small deep levels (40^3, 20^3, 10^3; CK = 24, plain 27-tap convs) ---------------
+// The 16-voxel MFMA rows of the kernels above are 16 consecutive x; on volumes of width 40 / 20 / 10 the padding to
+// 16-wide tiles wastes 17 / 37 / 48 % of the matrix work.  Here an m-tile is a 4(y) x 4(x) brick of one z-plane, a tile
+// is 4 z-planes of WM bricks in y (4 x 4 x 4 voxels for WM = 1: divides 40 and 20 exactly), and the WM*WN <= 4 waves are
+// arranged WM x WN: WN waves share the SAME voxels and split the output channels (each loads only its own B
+// fragments), so a 64-voxel tile still carries 4 x NT x 16 output channels of work per staged halo.  The small 6x(TY+2)x6
+// halo tile makes the launch fine-grained enough for split-K to fill the chip.  Everything else (buffer-load staging with
+// hardware zero padding, static taps, register ping-pong, packed weights) is conv3d_fwd_lean_kernel's.
+template <int NT, int WM, int WN, bool KSPLIT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const float* __restrict__ in,
+                                                                  const float* __restrict__ wp,
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  int D0, int D1, int D2, int Cin, int Cout, int ncc,
+                                                                  int tiles1, int tiles2, int act, const float* addend) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CK = 24, CKP = CK + 4, NCG = CK / 8, C4 = CK / 4, MT = 4;
+  constexpr int NTHR = 64 * WM * WN, TZ = 4, TY = 4 * WM, TX = 4;  // tile in voxels
+  constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+  constexpr int PL4 = HY * HX * C4, NJ = (PL4 + NTHR - 1) / NTHR, NLD = NJ * HZ;
+  constexpr uint32_t OOB = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int t = blockIdx.x;
+  const int t2 = t % tiles2;
+  t /= tiles2;
+  const int t1 = t % tiles1;
+  const int t0 = t / tiles1;
+  const int z0 = t0 * TZ, y0 = t1 * TY, x0 = t2 * TX;
+  const int nc = blockIdx.y * WN + wn;  // this wave's group of NT n-tiles
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, kq = lane >> 4;
+  // m-tile m of this wave = brick (z = m, y-block = wm): voxel li -> (dy = li >> 2, dx = li & 3)
+  int a_base[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a_base[m] = ((m * HY + wm * 4 + (li >> 2)) * HX + (li & 3)) * CKP + 2 * kq;
+
+  const int sX = Cin * 4, sY = D2 * Cin * 4, sZ = D1 * D2 * Cin * 4;  // bytes
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7FFFFFF0, 0x00020000);
+  uint32_t vrel[NJ];
+  int ldsa[NJ];
+  {
+    uint32_t bad = 0;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (20 + h)) : 0u;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const int j = tid + NTHR * i;
+      const int hy = j / (HX * C4), r = j - hy * (HX * C4), hx = r / C4, c4 = r - hx * C4;
+      const bool ok = (j < PL4) && !(((1u << hy) | (1u << (20 + hx))) & bad);
+      vrel[i] = ok ? (uint32_t)((y0 - 1 + hy) * sY + (x0 - 1 + hx) * sX + c4 * 16) : OOB;
+      ldsa[i] = (hy * HX + hx) * CKP + c4 * 4;
+    }
+  }
+  constexpr int TAPB = NCG * NT * 512;
+  auto bload = [&](int soff, int idx) -> float2 {
+    const int hi = idx >> 2, lo = idx & 3;
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, lane * 8 + lo * 512, soff + hi * 2048, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+  };
+  const int cpz = KSPLIT ? (ncc + (int)gridDim.z - 1) / (int)gridDim.z : ncc;
+  const int cc_lo = KSPLIT ? (int)blockIdx.z * cpz : 0;
+  const int cc_hi = min(ncc, cc_lo + cpz);
+  float4 stg[NLD];
+  auto halo_loads = [&](int cc) {
+#pragma unroll
+    for (int hz = 0; hz < HZ; ++hz) {
+      const int gz = z0 - 1 + hz;
+      const bool pv = (unsigned)gz < (unsigned)D0;
+      const int so = (pv ? gz * sZ : 0) + cc * (CK * 4);
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? vrel[i] : OOB), so, 0);
+        stg[hz * NJ + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+    }
+  };
+  if (cc_lo < cc_hi) halo_loads(cc_lo);
+  for (int cc = cc_lo; cc < cc_hi; ++cc) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      if (i < NJ - 1 || tid + NTHR * i < PL4) {
+#pragma unroll
+        for (int hz = 0; hz < HZ; ++hz) *reinterpret_cast<float4*>(&lds[ldsa[i] + hz * (HY * HX * CKP)]) = stg[hz * NJ + i];
+      }
+    }
+    __syncthreads();
+    if (cc + 1 < cc_hi) halo_loads(cc + 1);
+
+    const int wsoff = (int)(((int64_t)(nc * ncc + cc) * 27) * TAPB);
+    auto tap_lds = [](int tt) { return (((tt / 9) * HY + (tt / 3) % 3) * HX + tt % 3) * CKP; };
+    float2 bb[2][NCG][NT];
+    float2 aa[2][MT];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bb[0][g][n] = bload(wsoff, g * NT + n);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) aa[0][m] = *reinterpret_cast<const float2*>(&lds[a_base[m]]);
+#pragma unroll
+    for (int ti = 0; ti < 27; ++ti) {
+      if (ti + 1 < 27) {
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bb[(ti + 1) & 1][g][n] = bload(wsoff + (ti + 1) * TAPB, g * NT + n);
+      }
+      const int toff = tap_lds(ti);
+      const int toff_n = tap_lds(ti + 1 < 27 ? ti + 1 : ti);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        const int st = ti * NCG + g;
+        const int noff = (g + 1 < NCG) ? toff + (g + 1) * 8 : toff_n;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) aa[(st + 1) & 1][m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + noff]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[st & 1][m].x, bb[ti & 1][g][n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[st & 1][m].y, bb[ti & 1][g][n].y, acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- epilogue: D row = kq*4 + r -> brick voxel (dy = row >> 2, dx = row & 3), col = li -> channel
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int gz = z0 + m;
+    if (gz >= D0) continue;
+    const int gy = y0 + wm * 4 + kq;  // row >> 2 = kq
+    if (gy >= D1) continue;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = (nc * NT + n) * 16 + li;
+      if (co >= Cout) continue;
+      const float bv = (!KSPLIT && bias) ? bias[co] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gx = x0 + r;  // row & 3 = r
+        if (gx < D2) {
+          const size_t oidx = (((size_t)gz * D1 + gy) * D2 + gx) * Cout + co;
+          if constexpr (KSPLIT) {
+            atomicAdd(out + oidx, acc[m][n][r]);
+          } else {
+            float v = acc[m][n][r] + bv;
+            if (act == 2) v *= elu_dy(addend[oidx]);
+            else if (addend) v += addend[oidx];
+            if (act == 1) v = elu_f(v);
+            out[oidx] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // bias + activation after a split-K accumulation
 __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t n,
                                                        int C, int act, const float* __restrict__ eluy) {
@@ -1900,10 +2073,11 @@ static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout
 static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
 
 static int g_ks_target = 1024;  // option 5: workgroup target of the split-K heuristic
+static int g_brick = 1;  // option 6: brick tiles (4x4 voxels per MFMA row block) on the small deep levels
 static int g_p4 = 1;  // option 4: 4x4x1-MFMA kernel for the Cout = 24 layers (no padding to 32 columns)
 
 struct FwdPlan {
-  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2;
+  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2, brick, wn, wm;
   // NT = 0 selects the 4x4x1 weight layout in pack_value, NT = -Cin the first-layer layout
   int pack_nt() const { return c2 ? -c2 : (p4 ? 0 : nt); }
   int64_t mfma_count() const { return (p4 || c2) ? 0 : (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128; }
@@ -1942,6 +2116,35 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
   p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist && p.nv == 0 && lt2g) ? 1 : 0;
   p.p4 = (p.persist && plain && Cout == 24 && (Cin % 24) == 0 && g_p4) ? 1 : 0;
   p.c2 = (plain && Cout == 24 && Cin <= 2 && lt2g && g_p4) ? Cin : 0;  // first layer: 4x4x1 MFMA over K = 27*Cin
+  p.brick = 0;
+  p.wn = 1;
+  p.wm = 1;
+  if (g_brick && plain && p.ck == 24 && p.mt == 2 && lt2g && (Cout % 16) == 0 && p.nv == 0 && (s[0] % 4) == 0 &&
+      (s[1] % 4) == 0 && (s[2] % 4) == 0 && (s[2] % 16) != 0) {
+    // output channels: NT n-tiles per wave, WN waves side by side; `nchunks` (= groups of NT n-tiles) is the packing unit
+    p.brick = 1;
+    p.nt = (ntiles % 3 == 0) ? 3 : ((ntiles % 2 == 0) ? 2 : 1);
+    p.nchunks = ntiles / p.nt;
+    p.wn = (p.nchunks % 4 == 0) ? 4 : ((p.nchunks % 2 == 0) ? 2 : 1);
+    p.wm = (p.wn <= 2 && (s[1] % 8) == 0) ? 2 : 1;  // bricks in y per tile: must divide the volume
+    if (p.wn == 1) {  // <= 48 output channels: too little work per staged halo, the 16-wide tiles win (measured)
+      p.brick = 0;
+      p.wm = 1;
+      p.nchunks = cdiv(ntiles, max_nt);
+      p.nt = cdiv(ntiles, p.nchunks);
+    }
+  }
+  if (p.brick) {
+    const int64_t w = (int64_t)(s[0] / 4) * (s[1] / (4 * p.wm)) * (s[2] / 4) * (p.nchunks / p.wn);
+    p.ksplit = 1;
+    if (w < 400 && p.ncc >= 2) {
+      int ks = (int)cdiv(g_ks_target, (int)w);
+      if (ks > p.ncc) ks = p.ncc;
+      if (ks > 16) ks = 16;
+      if (ks >= 2) p.ksplit = ks;
+    }
+    return p;
+  }
   const int64_t w = wgs(p.mt, p.nt);
   if (w < 512 && p.ncc >= 4 && plain && p.nv == 0) {
     int ks = (int)cdiv(g_ks_target, (int)w);
@@ -2064,6 +2267,47 @@ int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* ou
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
+template <int NT, int WM, int WN, bool KS>
+int launch_fwd_brick(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
+                     const FwdPlan& pl, int act, hipStream_t st, const float* addend) {
+  const int tiles0 = cdiv(s[0], 4), tiles1 = cdiv(s[1], 4 * WM), tiles2 = cdiv(s[2], 4);
+  const size_t smem = (size_t)6 * (4 * WM + 2) * 6 * 28 * sizeof(float);
+  const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
+  if (KS) {
+    if (act != 2 && addend && addend != out) return SYNTHSR_EINVAL;
+    if ((act == 2 || !addend) && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess)
+      return SYNTHSR_ELAUNCH;
+  }
+  hipLaunchKernelGGL((conv3d_fwd_brick_kernel<NT, WM, WN, KS>),
+                     dim3(tiles0 * tiles1 * tiles2, pl.nchunks / WN, KS ? pl.ksplit : 1), dim3(64 * WM * WN), smem, st, in, wp,
+                     bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act, addend);
+  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  if (KS && (bias != nullptr || act != 0)) {
+    hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act,
+                       act == 2 ? addend : nullptr);
+    if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  }
+  return SYNTHSR_OK;
+}
+
+template <int NT, int WM, int WN>
+int dispatch_fwd_brick2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
+                        const FwdPlan& pl, int act, hipStream_t st, const float* addend) {
+  return pl.ksplit > 1 ? launch_fwd_brick<NT, WM, WN, true>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend)
+                       : launch_fwd_brick<NT, WM, WN, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend);
+}
+
+template <int NT>
+int dispatch_fwd_brick(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
+                       const FwdPlan& pl, int act, hipStream_t st, const float* addend) {
+  if (pl.wn == 4) return dispatch_fwd_brick2<NT, 1, 4>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend);
+  if (pl.wn == 2)
+    return pl.wm == 2 ? dispatch_fwd_brick2<NT, 2, 2>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend)
+                      : dispatch_fwd_brick2<NT, 1, 2>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend);
+  return pl.wm == 2 ? dispatch_fwd_brick2<NT, 2, 1>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend)
+                    : dispatch_fwd_brick2<NT, 1, 1>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend);
+}
+
 int launch_fwd_c2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int act,
                   hipStream_t st) {
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
@@ -2082,6 +2326,9 @@ int launch_fwd_c2(const float* in, const float* wp, const float* bias, float* ou
 template <int CK, int NT>
 int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
                   const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
+  if constexpr (CK == 24 && NT <= 3) {
+    if (pl.brick && ext.mode == 0) return dispatch_fwd_brick<NT>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext.addend);
+  }
   if (pl.c2) {
     if (ext.mode != 0 || ext.addend) return SYNTHSR_EINVAL;
     return launch_fwd_c2(in, wp, bias, out, s, Cin, act, st);
@@ -2566,6 +2813,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 5) {
     g_ks_target = value > 0 ? value : 1024;
+    return SYNTHSR_OK;
+  }
+  if (option == 6) {
+    g_brick = value ? 1 : 0;
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;

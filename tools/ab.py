@@ -7,7 +7,7 @@ import torch
 from synthsr_amd import ops, _lib
 
 lib = _lib.load()
-DEFAULTS = {0: 1, 1: 0, 2: 0, 3: 0, 4: 1, 5: 1024}
+DEFAULTS = {0: 1, 1: 0, 2: 0, 3: 0, 4: 1, 5: 1024, 6: 1}
 D, ci, co = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 variants = [dict((int(a), int(b)) for a, b in (kv.split('=') for kv in v.split(','))) for v in sys.argv[4:]] or [{}]
 x = torch.randn(D, D, D, ci, device='cuda')
