@@ -1257,12 +1257,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
 // fragments), so a 64-voxel tile still carries 4 x NT x 16 output channels of work per staged halo.  The small 6x(TY+2)x6
 // halo tile makes the launch fine-grained enough for split-K to fill the chip.  Everything else (buffer-load staging with
 // hardware zero padding, static taps, register ping-pong, packed weights) is conv3d_fwd_lean_kernel's.
-template <int NT, int WM, int WN, bool KSPLIT>
+template <int NT, int WM, int WN, bool KSPLIT, int NTAPS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const float* __restrict__ in,
                                                                   const float* __restrict__ wp,
                                                                   const float* __restrict__ bias, float* __restrict__ out,
                                                                   int D0, int D1, int D2, int Cin, int Cout, int ncc,
-                                                                  int tiles1, int tiles2, int act, const float* addend) {
+                                                                  int tiles1, int tiles2, int act, ConvExt ext) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CK = 24, CKP = CK + 4, NCG = CK / 8, C4 = CK / 4, MT = 4;
   constexpr int NTHR = 64 * WM * WN, TZ = 4, TY = 4 * WM, TX = 4;  // tile in voxels
@@ -1278,6 +1278,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const
   const int t0 = t / tiles1;
   const int z0 = t0 * TZ, y0 = t1 * TY, x0 = t2 * TX;
   const int nc = blockIdx.y * WN + wn;  // this wave's group of NT n-tiles
+  static_assert(NTAPS == 27 || !KSPLIT, "parity convs are not split over K");
+  const int mode = (NTAPS == 8) ? ext.mode : 0;  // 1: up-forward (parity = blockIdx.z), 2: up-data-gradient (8 parities)
+  const float* addend = ext.addend;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -1290,9 +1293,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const
 #pragma unroll
   for (int m = 0; m < MT; ++m) a_base[m] = ((m * HY + wm * 4 + (li >> 2)) * HX + (li & 3)) * CKP + 2 * kq;
 
-  const int sX = Cin * 4, sY = D2 * Cin * 4, sZ = D1 * D2 * Cin * 4;  // bytes
-  const __amdgpu_buffer_rsrc_t rin =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  const int is = (mode == 2) ? 2 : 1;  // input view: conv-grid voxel g -> tensor voxel g*is + parity
+  const int sX = is * Cin * 4, sY = is * (D2 * is) * Cin * 4, sZ = is * (D1 * is) * (D2 * is) * Cin * 4;  // bytes
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * is * is * is * Cin * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7FFFFFF0, 0x00020000);
   uint32_t vrel[NJ];
   int ldsa[NJ];
@@ -1320,13 +1324,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const
   const int cpz = KSPLIT ? (ncc + (int)gridDim.z - 1) / (int)gridDim.z : ncc;
   const int cc_lo = KSPLIT ? (int)blockIdx.z * cpz : 0;
   const int cc_hi = min(ncc, cc_lo + cpz);
+  const int npar = (mode == 2) ? 8 : 1;
+  const int opar = (mode == 1) ? (int)blockIdx.z : 0;
+  const int nit = npar * (cc_hi - cc_lo);
   float4 stg[NLD];
-  auto halo_loads = [&](int cc) {
+  auto halo_loads = [&](int it) {
+    const int ipar = it / (cc_hi - cc_lo);
+    const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
+    const int pconst =
+        (mode == 2) ? ((((ipar >> 2) & 1) * (D1 * 2) + ((ipar >> 1) & 1)) * (D2 * 2) + (ipar & 1)) * Cin * 4 : 0;
 #pragma unroll
     for (int hz = 0; hz < HZ; ++hz) {
       const int gz = z0 - 1 + hz;
       const bool pv = (unsigned)gz < (unsigned)D0;
-      const int so = (pv ? gz * sZ : 0) + cc * (CK * 4);
+      const int so = (pv ? gz * sZ : 0) + cc * (CK * 4) + pconst;
 #pragma unroll
       for (int i = 0; i < NJ; ++i) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? vrel[i] : OOB), so, 0);
@@ -1334,8 +1345,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const
       }
     }
   };
-  if (cc_lo < cc_hi) halo_loads(cc_lo);
-  for (int cc = cc_lo; cc < cc_hi; ++cc) {
+  if (nit > 0) halo_loads(0);
+  for (int it = 0; it < nit; ++it) {
+    const int ipar = it / (cc_hi - cc_lo);
+    const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
+    const int par = (mode == 1) ? opar : ipar;
+    const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+    // position of the 2x2x2 window inside the 3x3x3 stencil: mode 1 shift = parity, mode 2 (flipped taps) 1 - parity
+    const int shz = (NTAPS == 8) ? (mode == 2 ? 1 - pz : pz) : 0, shy = (NTAPS == 8) ? (mode == 2 ? 1 - py : py) : 0,
+              shx = (NTAPS == 8) ? (mode == 2 ? 1 - px : px) : 0;
+    const int shtap = (shz * 3 + shy) * 3 + shx;
+    const int shlds = ((shz * HY + shy) * HX + shx) * CKP;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
@@ -1345,35 +1365,42 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const
       }
     }
     __syncthreads();
-    if (cc + 1 < cc_hi) halo_loads(cc + 1);
+    if (it + 1 < nit) halo_loads(it + 1);
 
-    const int wsoff = (int)(((int64_t)(nc * ncc + cc) * 27) * TAPB);
-    auto tap_lds = [](int tt) { return (((tt / 9) * HY + (tt / 3) % 3) * HX + tt % 3) * CKP; };
+    const int wsoff = (int)(((int64_t)(nc * ncc + cc) * 27 + shtap) * TAPB + (int64_t)par * ext.wstride * 4);
+    int ab[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ab[m] = a_base[m] + shlds;
+    auto tap_id = [](int i) { return NTAPS == 27 ? i : ((i >> 2) & 1) * 9 + ((i >> 1) & 1) * 3 + (i & 1); };
+    auto tap_lds = [&](int i) {
+      const int tt = tap_id(i);
+      return (((tt / 9) * HY + (tt / 3) % 3) * HX + tt % 3) * CKP;
+    };
     float2 bb[2][NCG][NT];
     float2 aa[2][MT];
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bb[0][g][n] = bload(wsoff, g * NT + n);
+      for (int n = 0; n < NT; ++n) bb[0][g][n] = bload(wsoff + tap_id(0) * TAPB, g * NT + n);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) aa[0][m] = *reinterpret_cast<const float2*>(&lds[a_base[m]]);
+    for (int m = 0; m < MT; ++m) aa[0][m] = *reinterpret_cast<const float2*>(&lds[ab[m] + tap_lds(0)]);
 #pragma unroll
-    for (int ti = 0; ti < 27; ++ti) {
-      if (ti + 1 < 27) {
+    for (int ti = 0; ti < NTAPS; ++ti) {
+      if (ti + 1 < NTAPS) {
 #pragma unroll
         for (int g = 0; g < NCG; ++g)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bb[(ti + 1) & 1][g][n] = bload(wsoff + (ti + 1) * TAPB, g * NT + n);
+          for (int n = 0; n < NT; ++n) bb[(ti + 1) & 1][g][n] = bload(wsoff + tap_id(ti + 1) * TAPB, g * NT + n);
       }
       const int toff = tap_lds(ti);
-      const int toff_n = tap_lds(ti + 1 < 27 ? ti + 1 : ti);
+      const int toff_n = tap_lds(ti + 1 < NTAPS ? ti + 1 : ti);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
         const int st = ti * NCG + g;
         const int noff = (g + 1 < NCG) ? toff + (g + 1) * 8 : toff_n;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) aa[(st + 1) & 1][m] = *reinterpret_cast<const float2*>(&lds[a_base[m] + noff]);
+        for (int m = 0; m < MT; ++m) aa[(st + 1) & 1][m] = *reinterpret_cast<const float2*>(&lds[ab[m] + noff]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -1406,7 +1433,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const
       for (int r = 0; r < 4; ++r) {
         const int gx = x0 + r;  // row & 3 = r
         if (gx < D2) {
-          const size_t oidx = (((size_t)gz * D1 + gy) * D2 + gx) * Cout + co;
+          const int os = (mode == 1) ? 2 : 1;
+          const size_t oidx = (((size_t)(gz * os + ((opar >> 2) & 1)) * (D1 * os) + (gy * os + ((opar >> 1) & 1))) *
+                                   (D2 * os) + (gx * os + (opar & 1))) * Cout + co;
           if constexpr (KSPLIT) {
             atomicAdd(out + oidx, acc[m][n][r]);
           } else {
@@ -2119,7 +2148,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
   p.brick = 0;
   p.wn = 1;
   p.wm = 1;
-  if (g_brick && plain && p.ck == 24 && p.mt == 2 && lt2g && (Cout % 16) == 0 && p.nv == 0 && (s[0] % 4) == 0 &&
+  if (g_brick && p.ck == 24 && p.mt == 2 && lt2g && (Cout % 16) == 0 && p.nv == 0 && (s[0] % 4) == 0 &&
       (s[1] % 4) == 0 && (s[2] % 4) == 0 && (s[2] % 16) != 0) {
     // output channels: NT n-tiles per wave, WN waves side by side; `nchunks` (= groups of NT n-tiles) is the packing unit
     p.brick = 1;
@@ -2137,7 +2166,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
   if (p.brick) {
     const int64_t w = (int64_t)(s[0] / 4) * (s[1] / (4 * p.wm)) * (s[2] / 4) * (p.nchunks / p.wn);
     p.ksplit = 1;
-    if (w < 400 && p.ncc >= 2) {
+    if (w < 400 && p.ncc >= 2 && plain) {
       int ks = (int)cdiv(g_ks_target, (int)w);
       if (ks > p.ncc) ks = p.ncc;
       if (ks > 16) ks = 16;
@@ -2269,18 +2298,28 @@ int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* ou
 
 template <int NT, int WM, int WN, bool KS>
 int launch_fwd_brick(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
-                     const FwdPlan& pl, int act, hipStream_t st, const float* addend) {
+                     const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
   const int tiles0 = cdiv(s[0], 4), tiles1 = cdiv(s[1], 4 * WM), tiles2 = cdiv(s[2], 4);
   const size_t smem = (size_t)6 * (4 * WM + 2) * 6 * 28 * sizeof(float);
   const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
+  const float* addend = ext.addend;
   if (KS) {
     if (act != 2 && addend && addend != out) return SYNTHSR_EINVAL;
     if ((act == 2 || !addend) && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess)
       return SYNTHSR_ELAUNCH;
   }
-  hipLaunchKernelGGL((conv3d_fwd_brick_kernel<NT, WM, WN, KS>),
-                     dim3(tiles0 * tiles1 * tiles2, pl.nchunks / WN, KS ? pl.ksplit : 1), dim3(64 * WM * WN), smem, st, in, wp,
-                     bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act, addend);
+  const dim3 grid(tiles0 * tiles1 * tiles2, pl.nchunks / WN, KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1));
+  if (ext.mode == 0) {
+    hipLaunchKernelGGL((conv3d_fwd_brick_kernel<NT, WM, WN, KS, 27>), grid, dim3(64 * WM * WN), smem, st, in, wp, bias, out,
+                       s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act, ext);
+  } else {
+    if constexpr (!KS) {
+      hipLaunchKernelGGL((conv3d_fwd_brick_kernel<NT, WM, WN, false, 8>), grid, dim3(64 * WM * WN), smem, st, in, wp, bias,
+                         out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act, ext);
+    } else {
+      return SYNTHSR_EINVAL;
+    }
+  }
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   if (KS && (bias != nullptr || act != 0)) {
     hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act,
@@ -2292,20 +2331,20 @@ int launch_fwd_brick(const float* in, const float* wp, const float* bias, float*
 
 template <int NT, int WM, int WN>
 int dispatch_fwd_brick2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
-                        const FwdPlan& pl, int act, hipStream_t st, const float* addend) {
-  return pl.ksplit > 1 ? launch_fwd_brick<NT, WM, WN, true>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend)
-                       : launch_fwd_brick<NT, WM, WN, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend);
+                        const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
+  return pl.ksplit > 1 ? launch_fwd_brick<NT, WM, WN, true>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext)
+                       : launch_fwd_brick<NT, WM, WN, false>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
 }
 
 template <int NT>
 int dispatch_fwd_brick(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
-                       const FwdPlan& pl, int act, hipStream_t st, const float* addend) {
-  if (pl.wn == 4) return dispatch_fwd_brick2<NT, 1, 4>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend);
+                       const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
+  if (pl.wn == 4) return dispatch_fwd_brick2<NT, 1, 4>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
   if (pl.wn == 2)
-    return pl.wm == 2 ? dispatch_fwd_brick2<NT, 2, 2>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend)
-                      : dispatch_fwd_brick2<NT, 1, 2>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend);
-  return pl.wm == 2 ? dispatch_fwd_brick2<NT, 2, 1>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend)
-                    : dispatch_fwd_brick2<NT, 1, 1>(in, wp, bias, out, s, Cin, Cout, pl, act, st, addend);
+    return pl.wm == 2 ? dispatch_fwd_brick2<NT, 2, 2>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext)
+                      : dispatch_fwd_brick2<NT, 1, 2>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
+  return pl.wm == 2 ? dispatch_fwd_brick2<NT, 2, 1>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext)
+                    : dispatch_fwd_brick2<NT, 1, 1>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
 }
 
 int launch_fwd_c2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int act,
@@ -2327,7 +2366,7 @@ template <int CK, int NT>
 int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
                   const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
   if constexpr (CK == 24 && NT <= 3) {
-    if (pl.brick && ext.mode == 0) return dispatch_fwd_brick<NT>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext.addend);
+    if (pl.brick) return dispatch_fwd_brick<NT>(in, wp, bias, out, s, Cin, Cout, pl, act, st, ext);
   }
   if (pl.c2) {
     if (ext.mode != 0 || ext.addend) return SYNTHSR_EINVAL;
