@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--size', type=int, default=160)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-size', type=int, default=96)
+    ap.add_argument('--overlap', action='store_true', help='weight gradients on a second stream (A/B switch; slower)')
     ap.add_argument('--fold', default='auto', help="nearest-upsample folding of the decoder convs: auto | all | none")
     ap.add_argument('--force-allreduce', action='store_true',
                     help='initialise RCCL and run the bucketed gradient all-reduce even at world size 1 (path test)')
@@ -145,6 +146,7 @@ def main():
     net = unet(24, bg.model_output_shape, 5, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
                batch_norm=-1, activation='elu', seed=0,
                fold_upsample={'auto': 'auto', 'all': True, 'none': False}[args.fold])
+    net.overlap_wgrad = args.overlap
     if world > 1:
         dist.broadcast(net.params, 0)
         net.repack()

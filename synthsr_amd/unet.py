@@ -22,6 +22,11 @@ class UNet3D:
     def __init__(self, nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None,
                  feat_mult=1, nb_conv_per_level=1, batch_norm=None, activation='elu', device=None, seed=0,
                  final_pred_activation='linear', fold_upsample='auto'):
+        self.overlap_wgrad = False  # weight gradients on a second HIP stream (see _fork): measured 0.5 ms SLOWER per step
+                                    # on one MI355X (cross-stream event waits cost more than the tails they fill) ...
+        self.overlap_max_voxels = 40 ** 3  # ... on the small levels only: big persistent kernels just disturb each other
+        self._side_stream = None
+        self._side_busy = False
         if conv_size != 3:
             raise NotImplementedError('only conv_size=3 is supported')
         if activation != 'elu':
@@ -367,8 +372,13 @@ class UNet3D:
                                           elu_below=acts[0])
                 c0 = d['convs'][0]
                 dW = self.view(c0['w'], self.grads)
-                ops.conv3d_wgrad_part(skip, dz, dW, 0, dbias=self.view(c0['b'], self.grads))
-                ops.conv3d_up_wgrad(lo_bn, dz, self.buf('dwc', [8, 27, Cl, c0['cout']]), dW, Cs)
+                self._join()
+                dwc = self.buf('dwc', [8, 27, Cl, c0['cout']])
+
+                def c0_wgrads(skip=skip, dz=dz, dW=dW, lo_bn=lo_bn, dwc=dwc, c0=c0, Cs=Cs):
+                    ops.conv3d_wgrad_part(skip, dz, dW, 0, dbias=self.view(c0['b'], self.grads))
+                    ops.conv3d_up_wgrad(lo_bn, dz, dwc, dW, Cs)
+                self._fork(c0_wgrads, skip[..., 0].numel())
                 dskips[l] = ops.conv3d(dz, c0['wpd_s'], None, Cs, 0, out=self.buf('dskip%d' % l, self.shapes[l] + [Cs]))
                 g = ops.conv3d_up_dgrad(dz, c0['wpd_u'], Cl, out=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
             else:
@@ -378,6 +388,7 @@ class UNet3D:
                 dskips[l], g = ops.upsample_concat_bwd(g, Cs, Cl, dskip=self.buf('dskip%d' % l, self.shapes[l] + [Cs]),
                                                        dlo=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
             if on_grad_ready is not None:
+                self._join()
                 on_grad_ready(self.offsets[d['convs'][0]['w']][0])
         for l in range(L - 1, -1, -1):
             e = self.enc[l]
@@ -388,8 +399,30 @@ class UNet3D:
             g = self._bn_backward(g, acts[-1], e['bn'])
             g = self._convs_backward(g, dskips[l], e['convs'], acts, self.saved['x'][l], need_dx=(l > 0), tag='e%d' % l)
             if on_grad_ready is not None:
+                self._join()
                 on_grad_ready(self.offsets[e['convs'][0]['w']][0])
+        self._join()
         return G
+
+    # ---- weight gradients on a second stream: wgrad(layer) and dgrad(layer) both only read dz, so they can share
+    # the GPU; on the small deep levels neither fills 256 CUs alone.  _join() before anything overwrites dz / reads grads.
+    def _fork(self, fn, nvox=0):
+        if not self.overlap_wgrad or nvox > self.overlap_max_voxels:
+            fn()
+            return
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._side_stream):
+            self._side_stream.wait_event(ev)
+            fn()
+        self._side_busy = True
+
+    def _join(self):
+        if self._side_busy:
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+            self._side_busy = False
 
     def _bn_backward(self, g, x, bn):
         """pass 1 (channel sums = dbeta | dgamma); pass 2 is fused into the ELU backward of the conv that produced x"""
@@ -416,12 +449,14 @@ class UNet3D:
             c = convs[j]
             y = acts[j]
             xin = acts[j - 1] if j > 0 else x_in
+            self._join()  # the previous layer's wgrad still reads the buffer dz is about to reuse
             if fused:
                 dz = g
-                ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads), dbias=self.view(c['b'], self.grads))
+                self._fork(lambda: ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads),
+                                                    dbias=self.view(c['b'], self.grads)), xin[..., 0].numel())
             else:
                 dz = self._elu_backward(g, y, g2, self.view(c['b'], self.grads))
-                ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads))
+                self._fork(lambda: ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads)), xin[..., 0].numel())
             g2 = None
             fused = False
             if j > 0 or need_dx:
