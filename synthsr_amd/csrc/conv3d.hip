@@ -801,6 +801,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
   };
 
   f32x4 acc[6];
+  // results are stored from these registers, which nothing else touches until the next epilogue: re-zeroing `acc` (or
+  // reusing temporaries) right after a store would make the wave wait for the store's completion (vmcnt on gfx9)
+  float4 outreg[6];
+  float bv[24];  // bias, wave-uniform (scalar registers): loaded once, not per tile
+#pragma unroll
+  for (int c = 0; c < 24; ++c) bv[c] = bias ? bias[c] : 0.f;
   float4 stg[NLD];
   int tile = my_pos;
   if (tile >= ntiles) return;
@@ -890,12 +896,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
           float4 v = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-          if (bias) {
-            v.x += bias[4 * g];
-            v.y += bias[4 * g + 1];
-            v.z += bias[4 * g + 2];
-            v.w += bias[4 * g + 3];
-          }
+          v.x += bv[4 * g];
+          v.y += bv[4 * g + 1];
+          v.z += bv[4 * g + 2];
+          v.w += bv[4 * g + 3];
           if (act == 2) {  // fused ELU backward of the producing layer (addend = its output)
             const float4 a = *reinterpret_cast<const float4*>(addend + o + 4 * g);
             v.x *= elu_dy(a.x);
@@ -915,7 +919,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
             v.z = elu_f(v.z);
             v.w = elu_f(v.w);
           }
-          *reinterpret_cast<float4*>(out + o + 4 * g) = v;
+          outreg[g] = v;
+        }
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          asm volatile("" : "+v"(outreg[g].x), "+v"(outreg[g].y), "+v"(outreg[g].z), "+v"(outreg[g].w));  // own registers
+          *reinterpret_cast<float4*>(out + o + 4 * g) = outreg[g];
         }
       }
     }
