@@ -191,6 +191,12 @@ int synthsr_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz
 int synthsr_bn_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
                        const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream);
 
+/* the same for the BN in front of the 1x1x1 head, whose output gradient is rank-1: dy[v][c] = dpred[v]*whead[c] is
+ * formed on the fly (never stored); sums from synthsr_head_bwd_ex */
+int synthsr_bn_elu_bwd_head(const float* dpred, const float* whead, const float* y, float* dz, float* dbias, int64_t nvox,
+                            int C, const float* stats, const float* gamma, float eps, const float* sums,
+                            synthsr_stream_t stream);
+
 /* BatchNormalization(axis=-1), training mode (models.py:351,477; Keras 2.3.1 semantics, eps=1e-3):
  * stats[0..C) = mean, stats[C..2C) = biased variance over the nvox voxels */
 int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* ws /* 2C doubles scratch */,
@@ -234,6 +240,11 @@ int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats,
 int synthsr_head_bwd(const float* dpred, const float* x, int64_t nvox, int C, const float* stats,
                      const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw,
                      float* db, synthsr_stream_t stream);
+/* as above with dbn optional (NULL: not written) and, when bn_sums != NULL, the BN-backward channel sums of that rank-1
+ * gradient, bn_sums[c] += w[c] sum_v dpred,  bn_sums[C+c] += w[c] sum_v dpred*xhat[v][c]  (= synthsr_bn_bwd_reduce(dbn)) */
+int synthsr_head_bwd_ex(const float* dpred, const float* x, int64_t nvox, int C, const float* stats,
+                        const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw,
+                        float* db, float* bn_sums, synthsr_stream_t stream);
 
 /* keras.optimizers.Adam (Keras 2.3.1; SynthSR/training.py:444): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
  * p -= lr_t*m/(sqrt(v)+eps).  lr already includes the 1/(1+decay*iter) factor. */

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ dbias, int64_t n4, int C4,
                                                      const float* __restrict__ bn_stats,
                                                      const float* __restrict__ bn_gamma,
-                                                     const float* __restrict__ bn_sums, float eps, float inv_n) {
+                                                     const float* __restrict__ bn_sums, float eps, float inv_n,
+                                                     const float* __restrict__ g1, const float* __restrict__ w1) {
   extern __shared__ float smem[];
   const bool fixed = (RB % C4) == 0;
   if (dbias)
@@ -55,7 +56,14 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const float* __restrict__ d
   float4 part[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
   const int64_t stride = (int64_t)gridDim.x * RB;
   for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < n4; i += stride) {
-    float4 g = ld4(dy + i * 4);
+    float4 g;
+    if (g1) {  // rank-1 gradient of the 1x1x1 head: dy[v][c] = g1[v] * w1[c], never materialised
+      const float gv = g1[i / C4];
+      const int c = (int)(i % C4) * 4;
+      g = make_float4(gv * w1[c], gv * w1[c + 1], gv * w1[c + 2], gv * w1[c + 3]);
+    } else {
+      g = ld4(dy + i * 4);
+    }
     const float4 a = ld4(y + i * 4);
     if (bn_sums) {
       const int C = C4 * 4, c = (int)(i % C4) * 4;
@@ -409,8 +417,12 @@ __global__ __launch_bounds__(RB) void head_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
                                                       const float* __restrict__ w, float* __restrict__ dbn,
-                                                      float* __restrict__ dw, float* __restrict__ db) {
-  extern __shared__ float smem[];  // [C] dw partials + 1 db
+                                                      float* __restrict__ dw, float* __restrict__ db,
+                                                      float* __restrict__ sums) {
+  // The gradient w.r.t. the BatchNorm output is rank-1, dbn[v][c] = g[v] w[c].  With A[c] = sum_v g xhat[v][c] and
+  // B = sum_v g everything downstream is linear in (A, B):  dw = gamma A + beta B,  db = B, and the BN-backward sums
+  // sum dbn = w B, sum dbn xhat = w A -- so dbn need not be written (dbn == nullptr) nor reduced again (sums != nullptr).
+  extern __shared__ float smem[];  // [C] A partials + 1 B
   const int C4 = C / 4;
   const bool fixed = (RB % C4) == 0;
   for (int i = threadIdx.x; i < C + 1; i += RB) smem[i] = 0.f;
@@ -422,22 +434,33 @@ __global__ __launch_bounds__(RB) void head_bwd_kernel(const float* __restrict__ 
     const int c = (int)(i % C4) * 4;
     const int64_t v = i / C4;
     const float g = dpred[v];
-    float4 sc, sh;
-    bn_coeff4(stats, gamma, beta, eps, C, c, sc, sh);
-    const float4 bn = fma4(ld4(x + i * 4), sc, sh);
-    st4(dbn + i * 4, make_float4(g * w[c + 0], g * w[c + 1], g * w[c + 2], g * w[c + 3]));
+    const float4 a = ld4(x + i * 4);
+    float4 xh;
+    xh.x = (a.x - stats[c + 0]) * rsqrtf(stats[C + c + 0] + eps);
+    xh.y = (a.y - stats[c + 1]) * rsqrtf(stats[C + c + 1] + eps);
+    xh.z = (a.z - stats[c + 2]) * rsqrtf(stats[C + c + 2] + eps);
+    xh.w = (a.w - stats[c + 3]) * rsqrtf(stats[C + c + 3] + eps);
+    if (dbn) st4(dbn + i * 4, make_float4(g * w[c + 0], g * w[c + 1], g * w[c + 2], g * w[c + 3]));
     if (fixed) {
-      part[0].x += g * bn.x; part[0].y += g * bn.y; part[0].z += g * bn.z; part[0].w += g * bn.w;
+      part[0].x += g * xh.x; part[0].y += g * xh.y; part[0].z += g * xh.z; part[0].w += g * xh.w;
     } else {
-      atomicAdd(&smem[c + 0], g * bn.x); atomicAdd(&smem[c + 1], g * bn.y);
-      atomicAdd(&smem[c + 2], g * bn.z); atomicAdd(&smem[c + 3], g * bn.w);
+      atomicAdd(&smem[c + 0], g * xh.x); atomicAdd(&smem[c + 1], g * xh.y);
+      atomicAdd(&smem[c + 2], g * xh.z); atomicAdd(&smem[c + 3], g * xh.w);
     }
     if (c == 0) dbp += g;
   }
   atomicAdd(&smem[C], dbp);
   block_channel_reduce<1>(part, threadIdx.x % C4, C4, fixed, smem);
-  for (int i = threadIdx.x; i < C; i += RB) atomicAdd(&dw[i], smem[i]);
-  if (threadIdx.x == 0) atomicAdd(db, smem[C]);
+  const float B = smem[C];
+  for (int i = threadIdx.x; i < C; i += RB) {
+    const float A = smem[i];
+    atomicAdd(&dw[i], gamma[i] * A + beta[i] * B);
+    if (sums) {
+      atomicAdd(&sums[i], w[i] * B);
+      atomicAdd(&sums[C + i], w[i] * A);
+    }
+  }
+  if (threadIdx.x == 0) atomicAdd(db, B);
 }
 
 // ------------------------------------------------------------------------------------------ Adam (Keras 2.3.1)
@@ -468,7 +491,7 @@ int synthsr_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz
   const int64_t n4 = nvox * (C / 4);
   hipLaunchKernelGGL(elu_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
                      dy2, y, dz, dbias, n4, C / 4, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     0.f, 0.f);
+                     0.f, 0.f, (const float*)nullptr, (const float*)nullptr);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }
@@ -478,7 +501,20 @@ int synthsr_bn_elu_bwd(const float* dy, const float* dy2, const float* y, float*
   if (!dy || !y || !dz || !stats || !gamma || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
   hipLaunchKernelGGL(elu_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
-                     dy2, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps, (float)(1.0 / (double)nvox));
+                     dy2, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps, (float)(1.0 / (double)nvox),
+                     (const float*)nullptr, (const float*)nullptr);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bn_elu_bwd_head(const float* dpred, const float* whead, const float* y, float* dz, float* dbias, int64_t nvox,
+                            int C, const float* stats, const float* gamma, float eps, const float* sums,
+                            synthsr_stream_t stream) {
+  if (!dpred || !whead || !y || !dz || !stats || !gamma || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(elu_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream,
+                     (const float*)nullptr, (const float*)nullptr, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps,
+                     (float)(1.0 / (double)nvox), dpred, whead);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }
@@ -588,6 +624,17 @@ int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats,
   return SYNTHSR_OK;
 }
 
+int synthsr_head_bwd_ex(const float* dpred, const float* x, int64_t nvox, int C, const float* stats, const float* gamma,
+                        const float* beta, float eps, const float* w, float* dbn, float* dw, float* db, float* bn_sums,
+                        synthsr_stream_t stream) {
+  if (!dpred || !x || !stats || !gamma || !beta || !w || !dw || !db || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
+                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db, bn_sums);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
 int synthsr_head_bwd(const float* dpred, const float* x, int64_t nvox, int C, const float* stats, const float* gamma,
                      const float* beta, float eps, const float* w, float* dbn, float* dw, float* db,
                      synthsr_stream_t stream) {
@@ -595,7 +642,7 @@ int synthsr_head_bwd(const float* dpred, const float* x, int64_t nvox, int C, co
     return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
   hipLaunchKernelGGL(head_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
-                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db);
+                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db, (float*)nullptr);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

@@ -287,14 +287,27 @@ def head_l1_fwd(x, stats, gamma, beta, w, b, target, loss, pred=None, dpred=None
     return loss
 
 
-def head_bwd(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS):
+def head_bwd(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS, bn_sums=None):
+    """dbn (optional) = dpred (x) w; dw, db +=; bn_sums (optional) += BN-backward channel sums of that gradient"""
     lib = _L()
     C = int(x.shape[-1])
     nvox = x.numel() // C
-    _lib.check(lib.synthsr_head_bwd(_lib.ptr(dpred), _lib.ptr(x), nvox, C, _lib.ptr(stats), _lib.ptr(gamma),
-                                    _lib.ptr(beta), eps, _lib.ptr(w), _lib.ptr(dbn), _lib.ptr(dw), _lib.ptr(db),
-                                    _lib.stream()), 'head_bwd')
+    _lib.check(lib.synthsr_head_bwd_ex(_lib.ptr(dpred), _lib.ptr(x), nvox, C, _lib.ptr(stats), _lib.ptr(gamma),
+                                       _lib.ptr(beta), eps, _lib.ptr(w), _lib.ptr(dbn), _lib.ptr(dw), _lib.ptr(db),
+                                       _lib.ptr(bn_sums), _lib.stream()), 'head_bwd')
     return dbn
+
+
+def bn_elu_bwd_head(dpred, whead, y, stats, gamma, sums, dbias=None, out=None, eps=BN_EPS):
+    """bn_elu_bwd for the BN in front of the head: incoming gradient dpred[v]*whead[c] formed on the fly"""
+    lib = _L()
+    C = int(y.shape[-1])
+    if out is None:
+        out = torch.empty_like(y)
+    _lib.check(lib.synthsr_bn_elu_bwd_head(_lib.ptr(dpred), _lib.ptr(whead), _lib.ptr(y), _lib.ptr(out),
+                                           _lib.ptr(dbias), y.numel() // C, C, _lib.ptr(stats), _lib.ptr(gamma), eps,
+                                           _lib.ptr(sums), _lib.stream()), 'bn_elu_bwd_head')
+    return out
 
 
 def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):

@@ -354,9 +354,16 @@ class UNet3D:
         self._pending_bn = None
         low, bn = self.saved['last']
         C = low.shape[3]
-        g = self.buf('gA', list(low.shape))
+        # the gradient w.r.t. the last BatchNorm output is rank-1 (dpred[v] * w_head[c]): it is neither stored nor
+        # reduced; head_bwd emits that BN's backward sums and the first ELU backward forms it on the fly
+        off = self.offsets[bn['beta']][0]
+        sums = self.grads[off:off + 2 * bn['C']]
         ops.head_bwd(self.dpred, low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
-                     self.view(self.head['w']), g, self.view(self.head['w'], G), self.view(self.head['b'], G))
+                     self.view(self.head['w']), None, self.view(self.head['w'], G), self.view(self.head['b'], G),
+                     bn_sums=sums)
+        self._pending_bn = (bn, sums)
+        self._rank1 = (self.dpred, self.view(self.head['w']))
+        g = None
         dskips = [None] * L
         for k in range(len(self.dec) - 1, -1, -1):
             d = self.dec[k]
@@ -426,6 +433,8 @@ class UNet3D:
 
     def _bn_backward(self, g, x, bn):
         """pass 1 (channel sums = dbeta | dgamma); pass 2 is fused into the ELU backward of the conv that produced x"""
+        if g is None:  # rank-1 head gradient: head_bwd already produced the sums (backward())
+            return None
         off = self.offsets[bn['beta']][0]
         sums = self.grads[off:off + 2 * bn['C']]  # [dbeta | dgamma]
         ops.bn_reduce_bwd(g, x, self._stats(bn), sums)
@@ -438,6 +447,11 @@ class UNet3D:
         pend, self._pending_bn = self._pending_bn, None
         if pend is not None:
             bn, sums = pend
+            if g is None:  # rank-1 gradient of the head
+                dpred, whead = self._rank1
+                assert dy2 is None
+                return ops.bn_elu_bwd_head(dpred, whead, y, self._stats(bn), self.view(bn['gamma']), sums, dbias=dbias,
+                                           out=out)
             return ops.bn_elu_bwd(g, y, self._stats(bn), self.view(bn['gamma']), sums, dy2=dy2, dbias=dbias, out=out)
         return ops.elu_bwd(g, y, dy2=dy2, dbias=dbias, out=out)
 
