@@ -211,6 +211,10 @@ int synthsr_bn_maxpool(const float* x, float* y, const int shape[3], int C, cons
 int synthsr_bn_maxpool_bwd(const float* dy, const float* x, float* dbn, const int shape[3], int C,
                            const float* stats, const float* gamma, const float* beta, float eps,
                            synthsr_stream_t stream);
+/* the same, and sums[2C] += the channel sums synthsr_bn_bwd_reduce(dbn, x) would compute for the BatchNorm below the pool
+ * (sum dbn | sum dbn*xhat): the routed gradient is 7/8 zeros and already in registers here.  sums == NULL: plain. */
+int synthsr_bn_maxpool_bwd_ex(const float* dy, const float* x, float* dbn, const int shape[3], int C, const float* stats,
+                              const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream);
 /* BN backward, pass 1: sums[0..C) = sum dy, sums[C..2C) = sum dy*xhat (zeroed by caller) */
 int synthsr_bn_bwd_reduce(const float* dy, const float* x, int64_t nvox, int C, const float* stats, float eps,
                           float* sums, synthsr_stream_t stream);

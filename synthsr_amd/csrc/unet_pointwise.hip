@@ -249,6 +249,70 @@ __global__ __launch_bounds__(256) void bn_maxpool_bwd_kernel(const float* __rest
   }
 }
 
+// bn_maxpool_bwd + the channel sums of the NEXT BatchNorm backward (synthsr_bn_bwd_reduce of the routed gradient):
+// the routed gradient is 7/8 zeros, every non-zero and its xhat are in registers here, so the separate reduction pass
+// (a full read of dbn and x) is unnecessary.  RB threads so that each thread keeps a fixed channel group.
+__global__ __launch_bounds__(RB) void bn_maxpool_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 float* __restrict__ dbn, Shape3 s, int C,
+                                                                 const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps,
+                                                                 float* __restrict__ sums) {
+  extern __shared__ float smem[];  // [2][C]
+  const int C4 = C / 4;
+  const bool fixed = (RB % C4) == 0;
+  for (int i = threadIdx.x; i < 2 * C; i += RB) smem[i] = 0.f;
+  __syncthreads();
+  float4 part[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  const int o0 = s.d[0] / 2, o1 = s.d[1] / 2, o2 = s.d[2] / 2;
+  const int64_t n4 = (int64_t)o0 * o1 * o2 * C4;
+  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RB) {
+    const int c = (int)(i % C4) * 4;
+    int64_t v = i / C4;
+    const int p2 = (int)(v % o2);
+    v /= o2;
+    const int p1 = (int)(v % o1);
+    const int p0 = (int)(v / o1);
+    float4 sc, sh;
+    bn_coeff4(stats, gamma, beta, eps, C, c, sc, sh);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float4 xa = make_float4(0.f, 0.f, 0.f, 0.f);  // raw input at the arg-max
+    int ax = 0, ay = 0, az = 0, aw = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t vi = ((int64_t)(2 * p0 + (k >> 2)) * s.d[1] + (2 * p1 + ((k >> 1) & 1))) * s.d[2] + (2 * p2 + (k & 1));
+      const float4 r = ld4(x + vi * C + c);
+      const float4 t = fma4(r, sc, sh);
+      if (t.x > m.x) { m.x = t.x; ax = k; xa.x = r.x; }
+      if (t.y > m.y) { m.y = t.y; ay = k; xa.y = r.y; }
+      if (t.z > m.z) { m.z = t.z; az = k; xa.z = r.z; }
+      if (t.w > m.w) { m.w = t.w; aw = k; xa.w = r.w; }
+    }
+    const float4 g = ld4(dy + i * 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t vi = ((int64_t)(2 * p0 + (k >> 2)) * s.d[1] + (2 * p1 + ((k >> 1) & 1))) * s.d[2] + (2 * p2 + (k & 1));
+      st4(dbn + vi * C + c, make_float4(ax == k ? g.x : 0.f, ay == k ? g.y : 0.f, az == k ? g.z : 0.f, aw == k ? g.w : 0.f));
+    }
+    float4 gx;  // g * xhat(arg-max)
+    gx.x = g.x * (xa.x - stats[c + 0]) * rsqrtf(stats[C + c + 0] + eps);
+    gx.y = g.y * (xa.y - stats[c + 1]) * rsqrtf(stats[C + c + 1] + eps);
+    gx.z = g.z * (xa.z - stats[c + 2]) * rsqrtf(stats[C + c + 2] + eps);
+    gx.w = g.w * (xa.w - stats[c + 3]) * rsqrtf(stats[C + c + 3] + eps);
+    if (fixed) {
+      part[0].x += g.x; part[0].y += g.y; part[0].z += g.z; part[0].w += g.w;
+      part[1].x += gx.x; part[1].y += gx.y; part[1].z += gx.z; part[1].w += gx.w;
+    } else {
+      atomicAdd(&smem[c + 0], g.x); atomicAdd(&smem[c + 1], g.y);
+      atomicAdd(&smem[c + 2], g.z); atomicAdd(&smem[c + 3], g.w);
+      atomicAdd(&smem[C + c + 0], gx.x); atomicAdd(&smem[C + c + 1], gx.y);
+      atomicAdd(&smem[C + c + 2], gx.z); atomicAdd(&smem[C + c + 3], gx.w);
+    }
+  }
+  block_channel_reduce<2>(part, threadIdx.x % C4, C4, fixed, smem);
+  for (int i = threadIdx.x; i < 2 * C; i += RB) atomicAdd(&sums[i], smem[i]);
+}
+
 // ------------------------------------------------------------------------------------------ BN backward
 __global__ __launch_bounds__(RB) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            int64_t n4, int C, const float* __restrict__ stats,
@@ -561,6 +625,19 @@ int synthsr_bn_maxpool_bwd(const float* dy, const float* x, float* dbn, const in
   const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
   hipLaunchKernelGGL(bn_maxpool_bwd_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dbn, s,
                      C, stats, gamma, beta, eps);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bn_maxpool_bwd_ex(const float* dy, const float* x, float* dbn, const int shape[3], int C, const float* stats,
+                              const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream) {
+  if (!sums) return synthsr_bn_maxpool_bwd(dy, x, dbn, shape, C, stats, gamma, beta, eps, stream);
+  if (!dy || !x || !dbn || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C))
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_maxpool_bwd_sums_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
+                     (hipStream_t)stream, dy, x, dbn, s, C, stats, gamma, beta, eps, sums);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

@@ -226,14 +226,15 @@ def bn_maxpool(x, stats, gamma, beta, out=None, eps=BN_EPS):
     return out
 
 
-def bn_maxpool_bwd(dy, x, stats, gamma, beta, out=None, eps=BN_EPS):
+def bn_maxpool_bwd(dy, x, stats, gamma, beta, out=None, eps=BN_EPS, sums=None):
+    """gradient of maxpool(BN(x)) w.r.t. BN(x); sums [2C] (optional, += ) = bn_reduce_bwd(result, x) for free"""
     lib = _L()
     s = x.shape
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(lib.synthsr_bn_maxpool_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]),
-                                          _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.stream()),
-               'bn_maxpool_bwd')
+    _lib.check(lib.synthsr_bn_maxpool_bwd_ex(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]),
+                                             _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.ptr(sums),
+                                             _lib.stream()), 'bn_maxpool_bwd')
     return out
 
 

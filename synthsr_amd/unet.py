@@ -401,9 +401,16 @@ class UNet3D:
             e = self.enc[l]
             acts = self.saved['enc'][l]
             if l < L - 1:
+                # the pool backward also emits the sums of this level's BatchNorm backward (its output is the BN-output
+                # gradient): no separate reduction pass
+                off = self.offsets[e['bn']['beta']][0]
+                sums = self.grads[off:off + 2 * e['bn']['C']]
                 g = ops.bn_maxpool_bwd(g, acts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
-                                       self.view(e['bn']['beta']), out=self.buf('gpool%d' % l, list(acts[-1].shape)))
-            g = self._bn_backward(g, acts[-1], e['bn'])
+                                       self.view(e['bn']['beta']), out=self.buf('gpool%d' % l, list(acts[-1].shape)),
+                                       sums=sums)
+                self._pending_bn = (e['bn'], sums)
+            else:
+                g = self._bn_backward(g, acts[-1], e['bn'])
             g = self._convs_backward(g, dskips[l], e['convs'], acts, self.saved['x'][l], need_dx=(l > 0), tag='e%d' % l)
             if on_grad_ready is not None:
                 self._join()

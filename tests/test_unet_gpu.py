@@ -167,6 +167,27 @@ def test_pointwise_kernels(T):
     sums = torch.zeros(2 * C, device='cuda')
     dx = ops.bn_bwd(gbn, xd, stats, gamma.cuda(), sums)
     close(dx, xr.grad, 2e-4, 'bn+pool backward')
+    # the pool backward can emit the BN-backward sums itself; the head's rank-1 gradient likewise
+    sums2 = torch.zeros(2 * C, device='cuda')
+    gbn2 = ops.bn_maxpool_bwd(dp.cuda(), xd, stats, gamma.cuda(), beta.cuda(), sums=sums2)
+    assert torch.equal(gbn2, gbn)
+    close(sums2, sums, 1e-4, 'BN sums from the pool backward')
+    dpred, wh = torch.randn(*shape), torch.randn(C)
+    dbn = torch.empty_like(xd)
+    dw_a, db_a = torch.zeros(C, device='cuda'), torch.zeros(1, device='cuda')
+    ops.head_bwd(dpred.cuda(), xd, stats, gamma.cuda(), beta.cuda(), wh.cuda(), dbn, dw_a, db_a)
+    close(dbn, dpred[..., None] * wh, 1e-6, 'head dbn')
+    close(dw_a, (dpred[..., None] * yr).reshape(-1, C).sum(0), 1e-4, 'head dw')
+    s_ref = torch.zeros(2 * C, device='cuda')
+    ops.bn_reduce_bwd(dbn, xd, stats, s_ref)
+    dw_b, db_b, s_b = torch.zeros(C, device='cuda'), torch.zeros(1, device='cuda'), torch.zeros(2 * C, device='cuda')
+    ops.head_bwd(dpred.cuda(), xd, stats, gamma.cuda(), beta.cuda(), wh.cuda(), None, dw_b, db_b, bn_sums=s_b)
+    close(dw_b, dw_a, 1e-5, 'head dw (no dbn)')
+    close(db_b, db_a, 1e-5, 'head db (no dbn)')
+    close(s_b, s_ref, 1e-4, 'BN sums from head_bwd')
+    yelu = torch.nn.functional.elu(x).cuda()
+    close(ops.bn_elu_bwd_head(dpred.cuda(), wh.cuda(), yelu, stats, gamma.cuda(), s_ref),
+          ops.bn_elu_bwd(dbn, yelu, stats, gamma.cuda(), s_ref), 1e-6, 'rank-1 bn_elu_bwd')
     # ELU backward + bias gradient
     y = torch.nn.functional.elu(x)
     dy, dy2 = torch.randn_like(y), torch.randn_like(y)
