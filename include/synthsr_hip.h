@@ -164,9 +164,10 @@ int synthsr_conv3d_wgrad_bias(const float* in, const float* dout, float* dw, flo
 int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
                             int Cin, int Cout, synthsr_stream_t stream);
 
-/* launch geometry the kernels will use: out = {chunk width CK, #ci chunks, n-tiles per workgroup, #n chunks, MT, ksplit,
- * NV (output channels kept on the vector ALUs), floats per packed weight set} */
-int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int64_t out[8]);
+/* launch geometry the kernels will use: out = {chunk width CK, #ci chunks, n-tiles per workgroup (0: 4x4x1-MFMA layout of
+ * the Cout = 24 layers, -Cin: first-layer layout), #n chunks, MT, ksplit, NV, floats per packed weight set}.
+ * kind: 1 plain conv; 2 forward parity convs of a folded decoder conv; 0 their data gradient */
+int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int kind, int64_t out[8]);
 /* packs every layer of a network in ONE launch.  jobs_dev: int64 [njobs][14] = {w_off, dst_off, count, cin_total,
  * ci_off, cin, cout, mode, ck, ncc, nt, parity(-1 plain), nv, mfma_count}; w_off / dst_off are float offsets */
 int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* jobs_dev, int njobs,

@@ -937,6 +937,187 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
   }
 }
 
+// ---- forward parity convs of a folded decoder conv with Cout = 24 (nearest-upsample folding), 4x4x1 MFMA ---------------
+// conv3d_fwd_p4_kernel with the 2x2x2 parity windows: lane = LOW-RES voxel.  One staged low-res halo chunk serves the 4
+// output parities (py, px) of one pz (4 x 6 accumulators): 4 stagings per tile instead of the 16 of the per-parity
+// launch, no padding of the 24 output channels.  items = (tile, pz, channel chunk); each lane finally stores its 4
+// hi-res voxels (2z+pz, 2y+py, 2x+px), 24 channels each.  Weights: p4 layout of the parity-combined 27-slot kernels.
+__global__ __launch_bounds__(256, 2) void conv3d_up_fwd_p4_kernel(const float* __restrict__ in,
+                                                                  const float* __restrict__ wp,
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  int D0, int D1, int D2, int Cin, int ncc, int tiles1,
+                                                                  int tiles2, int ntiles, int act, int64_t wstride,
+                                                                  const float* addend) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CK = 24, MT = 4, Cout = 24;
+  constexpr int FT1 = MT, FH1 = MT + 2, CKP = CK + 4, C4 = CK / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = gridDim.x;
+  const int my_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int vy = lane >> 4, vx = lane & 15;
+  const int xbase = ((wave * FH1 + vy) * FH2 + vx) * CKP;
+  constexpr int PLANE4 = FH1 * FH2 * C4, NJ = (PLANE4 + 255) / 256, NLD = NJ * FH0;
+  constexpr uint32_t OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7FFFFFF0, 0x00020000);
+  int rel[NJ], ldsa[NJ];
+  uint32_t cmask[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = tid + 256 * i;
+    const int hy = j / (FH2 * C4), r = j - hy * (FH2 * C4), hx = r / C4, c4 = r - hx * C4;
+    rel[i] = ((hy * D2 + hx) * Cin + c4 * 4) * 4;
+    ldsa[i] = ((hy * FH2 + hx) * CKP + c4 * 4);
+    cmask[i] = j < PLANE4 ? ((1u << hy) | (1u << (8 + hx))) : 0xFFFFFFFFu;
+  }
+  const int plane_bytes = D1 * D2 * Cin * 4;
+  float4 stg[NLD];
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    z0 = t0 * FT0;
+    y0 = t1 * FT1;
+    x0 = t2 * FT2;
+  };
+  auto halo_loads = [&](int z0, int y0, int x0, int cc) {
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < FH1; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH2; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (8 + h)) : 0u;
+    const int yx = (((y0 - 1) * D2 + (x0 - 1)) * Cin + cc * CK) * 4;
+    uint32_t voff[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) voff[i] = (cmask[i] & bad) ? OOB : (uint32_t)(rel[i] + yx);
+#pragma unroll
+    for (int hz = 0; hz < FH0; ++hz) {
+      const int gz = z0 - 1 + hz;
+      const bool pv = (unsigned)gz < (unsigned)D0;
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? voff[i] : OOB), pv ? gz * plane_bytes : 0, 0);
+        stg[hz * NJ + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+    }
+  };
+  auto wload = [&](int soff, int r) -> float {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, lane * 4 + r * 256, soff, 0));
+  };
+  float bv[24];
+#pragma unroll
+  for (int c = 0; c < 24; ++c) bv[c] = bias ? bias[c] : 0.f;
+
+  f32x4 acc[4][6];
+  int tile = my_pos;
+  if (tile >= ntiles) return;
+  int z0, y0, x0;
+  tile_origin(tile, z0, y0, x0);
+  halo_loads(z0, y0, x0, 0);
+  const int nsub = 2 * ncc;  // items of one tile: (pz, cc)
+  int sub = 0;
+  while (true) {
+    const int pz = sub / ncc, cc = sub - pz * ncc;
+    // next item
+    const int nsub_i = (sub + 1 < nsub) ? sub + 1 : 0;
+    const int ntile = (sub + 1 < nsub) ? tile : tile + G;
+    const bool has_next = ntile < ntiles;
+    int nz0 = z0, ny0 = y0, nx0 = x0;
+    if (has_next && ntile != tile) tile_origin(ntile, nz0, ny0, nx0);
+    if (cc == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int g = 0; g < 6; ++g) acc[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      if (i < NJ - 1 || tid + 256 * i < PLANE4) {
+#pragma unroll
+        for (int hz = 0; hz < FH0; ++hz)
+          *reinterpret_cast<float4*>(&lds[ldsa[i] + hz * (FH1 * FH2 * CKP)]) = stg[hz * NJ + i];
+      }
+    }
+    __syncthreads();
+    if (has_next) halo_loads(nz0, ny0, nx0, nsub_i % ncc);
+
+    // 96 steps = 4 parities (py, px) x 8 window taps x 3 channel octets; window position inside the 3x3x3 stencil: shift =
+    // parity (see up_tapmask).  Weights of step p in wr[p % 3] (requested two steps ahead), activations of quad step s
+    // in xq[s & 1] (read one step ahead) -- as in conv3d_fwd_p4_kernel.
+    constexpr int NP = 4 * 8 * 3;
+    const int xb = xbase + pz * (FH1 * FH2 * CKP);  // z shift of the window (runtime); y / x shifts are static
+    auto wsoff = [&](int p) {  // scalar byte offset of the weights of step p
+      const int q = p / 24, ti = (p / 3) % 8, qp = p % 3;
+      const int tap = ((pz + ((ti >> 2) & 1)) * 3 + ((q >> 1) + ((ti >> 1) & 1))) * 3 + ((q & 1) + (ti & 1));
+      return (int)((int64_t)(pz * 4 + q) * wstride * 4) + cc * (27 * 9 * 256) + (tap * 3 + qp) * 768;
+    };
+    float wr[3][3];
+    float4 xq[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      wr[0][r] = wload(wsoff(0), r);
+      wr[1][r] = wload(wsoff(1), r);
+    }
+    xq[0] = *reinterpret_cast<const float4*>(&lds[xb]);
+    sfor<0, NP>([&](auto P) {
+      constexpr int p = decltype(P)::value, q = p / 24;
+      if constexpr (p + 2 < NP) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) wr[(p + 2) % 3][r] = wload(wsoff(p + 2), r);
+      }
+      sfor<0, 2>([&](auto H) {
+        constexpr int h = decltype(H)::value, sidx = p * 2 + h;
+        constexpr int pn = h == 0 ? p : (p + 1 < NP ? p + 1 : p), hn = h == 0 ? 1 : 0;
+        constexpr int qn = pn / 24, tn = (pn / 3) % 8, c4n = (pn % 3) * 2 + hn;
+        constexpr int noff = ((((tn >> 2) & 1) * FH1 + (qn >> 1) + ((tn >> 1) & 1)) * FH2 + (qn & 1) + (tn & 1)) * CKP + c4n * 4;
+        xq[(sidx + 1) & 1] = *reinterpret_cast<const float4*>(&lds[xb + noff]);
+        __builtin_amdgcn_sched_barrier(0);
+        const float xs[4] = {xq[sidx & 1].x, xq[sidx & 1].y, xq[sidx & 1].z, xq[sidx & 1].w};
+        sfor<0, 24>([&](auto GI) {
+          constexpr int gi = decltype(GI)::value, kk = gi / 6, g = gi % 6, GG = h * 24 + gi;
+          acc[q][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[p % 3][GG / 16], xs[kk], acc[q][g], 4, GG % 16, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+
+    if (cc == ncc - 1) {  // epilogue of (tile, pz): the lane's 4 hi-res voxels
+      const int gz = z0 + wave, gy = y0 + vy, gx = x0 + vx;
+      if (gz < D0 && gy < D1 && gx < D2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const size_t o = (((size_t)(2 * gz + pz) * (2 * D1) + (2 * gy + (q >> 1))) * (2 * D2) + (2 * gx + (q & 1))) * Cout;
+#pragma unroll
+          for (int g = 0; g < 6; ++g) {
+            float4 v = make_float4(acc[q][g][0] + bv[4 * g], acc[q][g][1] + bv[4 * g + 1], acc[q][g][2] + bv[4 * g + 2],
+                                   acc[q][g][3] + bv[4 * g + 3]);
+            if (addend) {  // indexed like out; may alias it
+              const float4 a = *reinterpret_cast<const float4*>(addend + o + 4 * g);
+              v.x += a.x;
+              v.y += a.y;
+              v.z += a.z;
+              v.w += a.w;
+            }
+            if (act == 1) {
+              v.x = elu_f(v.x);
+              v.y = elu_f(v.y);
+              v.z = elu_f(v.z);
+              v.w = elu_f(v.w);
+            }
+            *reinterpret_cast<float4*>(out + o + 4 * g) = v;
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    tile = ntile;
+    z0 = nz0;
+    y0 = ny0;
+    x0 = nx0;
+    sub = nsub_i;
+  }
+}
+
 // ---- first layer (Cin <= 2, Cout = 24) on the 4x4x1 MFMA: K = 27*Cin, all weights resident in <= 21 registers ------
 // The generic path pads Cin = 2 to an 8-channel chunk (4x the matrix work) and is bound by everything but memory;
 // this kernel is bound by the 160^3 x 24 output write.  Lane = voxel as in conv3d_fwd_p4_kernel; the halo tile is
@@ -2126,7 +2307,9 @@ struct FwdPlan {
 };
 
 // Launch geometry for one layer: enough workgroups to fill 256 CUs x 2 even on the deep, small levels.
-inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
+// kind: 1 plain conv, 0 parity convs of the folded decoder conv (data gradient / unspecified), 2 their forward pass
+inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
+  const bool plain = kind == 1;
   FwdPlan p;
   p.ck = ck_for(Cin);
   p.ncc = cdiv(Cin, p.ck);
@@ -2152,7 +2335,8 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, bool plain = true) {
   }
   const bool lt2g = (int64_t)s[0] * s[1] * s[2] * Cin * 4 < (1ll << 31);  // raw buffer addressing (32-bit offsets)
   p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist && p.nv == 0 && lt2g) ? 1 : 0;
-  p.p4 = (p.persist && plain && Cout == 24 && (Cin % 24) == 0 && g_p4) ? 1 : 0;
+  // 4x4x1 layouts: plain Cout = 24 layers, and the forward parity convs of a folded decoder conv with Cout = 24
+  p.p4 = (p.persist && (kind == 1 || kind == 2) && Cout == 24 && (Cin % 24) == 0 && g_p4) ? 1 : 0;
   p.c2 = (plain && Cout == 24 && Cin <= 2 && lt2g && g_p4) ? Cin : 0;  // first layer: 4x4x1 MFMA over K = 27*Cin
   p.brick = 0;
   p.wn = 1;
@@ -2371,6 +2555,24 @@ int launch_fwd_c2(const float* in, const float* wp, const float* bias, float* ou
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
+int launch_up_fwd_p4(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin,
+                     const FwdPlan& pl, int act, hipStream_t st, int64_t wstride, const float* addend) {
+  const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
+  const int ntiles = tiles0 * tiles1 * tiles2;
+  const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_up_fwd_p4_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  int gx = 512;
+  while (gx > 8 && gx > ntiles) gx -= 8;
+  hipLaunchKernelGGL(conv3d_up_fwd_p4_kernel, dim3(gx), dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin,
+                     pl.ncc, tiles1, tiles2, ntiles, act, wstride, addend);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
 template <int CK, int NT>
 int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
                   const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
@@ -2380,6 +2582,10 @@ int dispatch_fwd2(const float* in, const float* wp, const float* bias, float* ou
   if (pl.c2) {
     if (ext.mode != 0 || ext.addend) return SYNTHSR_EINVAL;
     return launch_fwd_c2(in, wp, bias, out, s, Cin, act, st);
+  }
+  if (pl.p4 && ext.mode == 1) {
+    if (pl.count() * 32 >= (1ll << 31)) return SYNTHSR_EINVAL;
+    return launch_up_fwd_p4(in, wp, bias, out, s, Cin, pl, act, st, ext.wstride, ext.addend);
   }
   if (pl.p4) {
     if ((int64_t)s[0] * s[1] * s[2] * Cin * 4 >= (1ll << 31) || ext.mode != 0) return SYNTHSR_EINVAL;
@@ -2741,7 +2947,7 @@ int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3]
       shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
     return SYNTHSR_EINVAL;
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
-  const FwdPlan pl = plan_fwd(shape, CinE, CoutE, !up);
+  const FwdPlan pl = plan_fwd(shape, CinE, CoutE, up ? (mode == 0 ? 2 : 0) : 1);
   const int64_t per = pl.count();
   const int64_t total = per * (up ? 8 : 1);
   if (!packed) return total;
@@ -2762,7 +2968,7 @@ int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], i
 
 int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int64_t out[8]) {
   if (!shape || !out || CinE < 1 || CoutE < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
-  const FwdPlan pl = plan_fwd(shape, CinE, CoutE, plain != 0);
+  const FwdPlan pl = plan_fwd(shape, CinE, CoutE, plain);
   out[0] = pl.ck;
   out[1] = pl.ncc;
   out[2] = pl.pack_nt();
@@ -2817,7 +3023,7 @@ int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* b
   if (!lo || !wpacked8 || !out || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 ||
       lo_shape[2] < 1 || (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
-  const FwdPlan pl = plan_fwd(lo_shape, Cl, Cout, false);
+  const FwdPlan pl = plan_fwd(lo_shape, Cl, Cout, 2);
   const int64_t wstride = pl.count();
   const ConvExt ext{1, addend, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
@@ -2830,7 +3036,7 @@ int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo
       lo_shape[2] < 1)
     return SYNTHSR_EINVAL;
   // effective conv: input channels = Cout (of the forward layer), output channels = Cl
-  const FwdPlan pl = plan_fwd(lo_shape, Cout, Cl, false);
+  const FwdPlan pl = plan_fwd(lo_shape, Cout, Cl, 0);
   const int64_t wstride = pl.count();
   const ConvExt ext{2, nullptr, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);

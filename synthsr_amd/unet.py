@@ -181,7 +181,8 @@ class UNet3D:
             nonlocal off
             cin_total, cout = c['cin'], c['cout']
             cin_e, cout_e = (cout, cin) if mode else (cin, cout)
-            ck, ncc, nt, nchunks, _, _, nv, per = plan(shape, cin_e, cout_e, not up)
+            # kind: 1 plain conv, 2 forward parity convs of a folded decoder conv, 0 their data gradient
+            ck, ncc, nt, nchunks, _, _, nv, per = plan(shape, cin_e, cout_e, ((2 if mode == 0 else 0) if up else 1))
             mfma_count = nchunks * ncc * 27 * (ck // 8) * nt * 128
             w_off = self.offsets[c['w']][0]
             c[key + '_off'] = (off, per * (8 if up else 1))

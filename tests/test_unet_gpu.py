@@ -104,7 +104,9 @@ def test_elu_epilogue_accuracy(T, shape):
 
 
 @pytest.mark.parametrize('lo_shape,Cs,Cl,Cout', [((6, 5, 9), 24, 48, 24), ((4, 4, 8), 48, 96, 48), ((3, 2, 3), 24, 24, 48),
-                                                 ((20, 20, 24), 24, 48, 24)])
+                                                 ((20, 20, 24), 24, 48, 24),
+                                                 # >= 768 tiles: the all-parity 4x4x1 kernel (Cout = 24), ragged x
+                                                 ((64, 48, 56), 24, 48, 24)])
 def test_upsample_folded_conv(T, lo_shape, Cs, Cl, Cout):
     """conv on concatenate([skip, UpSampling3D(2)(lo)]) evaluated as conv3(skip) + 8 parity convs on lo: forward,
     both data gradients and the full weight gradient against autograd on the materialised concat"""
