@@ -1,0 +1,118 @@
+"""Inference path of the reference's `scripts/predict_command_line.py:58-138`: resample to 1 mm,
+re-orient to RAS, min-max normalise, zero-pad to a multiple of 32, U-Net forward on the MI355X (optionally averaged
+with the left-right flipped pass), rescale / clip, crop, save.  Host steps are numpy like the reference's; the U-Net
+runs through the HIP kernels (`UNet3D.predict`, inference-mode BatchNorm with the moving statistics).
+
+The reference ships its weights as a Keras `.h5` (`models/SynthSR_v10_210712.h5`, absent from the reference checkout
+and unreadable here: no h5py); this build reads the `.npz` written by `synthsr_amd.training.save_checkpoint`, whose keys
+are the Keras layer names.
+"""
+import os
+import numpy as np
+
+from . import volumes as V
+
+DEFAULT_MODEL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'models', 'SynthSR_v10_210712.npz')
+
+
+def prepare_volume(im, aff, ct=False):
+    """predict_command_line.py:110-124.  Returns (padded [W0,W1,W2] float64, crop offsets, unpadded shape, RAS affine)"""
+    im = np.array(im, dtype=np.float64)
+    if ct:
+        im[im < 0] = 0
+        im[im > 80] = 80
+    im, aff = V.resample_volume(im, aff, [1.0, 1.0, 1.0])
+    im, aff2 = V.align_volume_to_ref(im, aff, aff_ref=np.eye(4), return_aff=True, n_dims=3)
+    im = im - np.min(im)
+    im = im / np.max(im)
+    shape = np.array(im.shape)
+    W = (np.ceil(shape / 32.0) * 32).astype('int')
+    idx = np.floor((W - shape) / 2).astype('int')
+    S = np.zeros(W)
+    S[idx[0]:idx[0] + shape[0], idx[1]:idx[1] + shape[1], idx[2]:idx[2] + shape[2]] = im
+    return S, idx, shape, aff2
+
+
+def postprocess(output, idx, shape):
+    """predict_command_line.py:131-135: intensities to [0, 128] of a 255 scale, crop the padding"""
+    pred = 255 * np.squeeze(np.asarray(output, dtype=np.float64))
+    pred[pred < 0] = 0
+    pred[pred > 128] = 128
+    return pred[idx[0]:idx[0] + shape[0], idx[1]:idx[1] + shape[1], idx[2]:idx[2] + shape[2]]
+
+
+class Predictor:
+    """The U-Net of predict_command_line.py:65-76 (24 features, 5 levels, 2 convs per level, 1 input channel), rebuilt
+    per padded volume shape (the reference's Keras graph has `None` spatial dims; weights are shape-independent)."""
+
+    def __init__(self, path_model=None, device=None, state_dict=None):
+        import torch
+        self.torch = torch
+        self.device = device or 'cuda'
+        self.state = state_dict
+        if state_dict is None:
+            path_model = path_model or DEFAULT_MODEL
+            if not os.path.isfile(path_model):
+                raise FileNotFoundError('model file %s not found. The reference distributes Keras .h5 weights; convert them '
+                                        'to the .npz layout of synthsr_amd.training.save_checkpoint (INTEGRATION.md §3)'
+                                        % path_model)
+            z = np.load(path_model)
+            self.state = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith('optimizer/')}
+        self.nets = {}
+
+    def net_for(self, shape):
+        from .unet import unet
+        key = tuple(int(s) for s in shape)
+        if key not in self.nets:
+            self.nets.clear()  # one resident network: volumes of a folder usually share their shape
+            net = unet(nb_features=24, input_shape=list(key) + [1], nb_levels=5, conv_size=3, nb_labels=1, feat_mult=2,
+                       nb_conv_per_level=2, conv_dropout=0, final_pred_activation='linear', batch_norm=-1,
+                       activation='elu', input_model=None, device=self.device)
+            net.load_state_dict(self.state, strict=False)
+            net.repack()
+            self.nets[key] = net
+        return self.nets[key]
+
+    def __call__(self, S, flipping=True):
+        """S [W0,W1,W2] (numpy) -> U-Net output [W0,W1,W2] float32 (numpy); flipping: average with the pass on the volume
+        flipped along the first (left-right) axis"""
+        torch = self.torch
+        net = self.net_for(S.shape)
+        x = torch.from_numpy(np.ascontiguousarray(S, dtype=np.float32)).to(self.device)[..., None]
+        out = net.predict(x).clone()[..., 0]
+        if flipping:
+            outf = net.predict(torch.flip(x, dims=[0]).contiguous())[..., 0]
+            out = 0.5 * out + 0.5 * torch.flip(outf, dims=[0])
+        return out.cpu().numpy()
+
+
+def predict(path_images, path_predictions, path_model=None, ct=False, disable_flipping=False, device=None, verbose=True,
+            predictor=None):
+    """Same contract as the reference script: `path_images` / `path_predictions` are both single files (.nii, .nii.gz,
+    .npz; .mgz is not readable here) or both folders."""
+    path_images = os.path.abspath(path_images)
+    basename = os.path.basename(path_images)
+    path_predictions = os.path.abspath(path_predictions)
+    if not any(ext in basename for ext in ('.nii.gz', '.nii', '.mgz', '.npz')):
+        if os.path.isfile(path_images):
+            raise Exception('extension not supported for %s, only use: nii.gz, .nii, .mgz, or .npz' % path_images)
+        images = V.list_images_in_folder(path_images)
+        os.makedirs(path_predictions, exist_ok=True)
+        outs = [os.path.join(path_predictions, os.path.basename(p)).replace('.nii', '_SynthSR.nii') for p in images]
+        outs = [p.replace('.mgz', '_SynthSR.mgz').replace('.npz', '_SynthSR.npz') for p in outs]
+    else:
+        assert os.path.isfile(path_images), "files does not exist: %s " \
+                                            "\nplease make sure the path and the extension are correct" % path_images
+        images, outs = [path_images], [path_predictions]
+    predictor = predictor or Predictor(path_model, device)
+    if verbose:
+        print('Found %d images' % len(images))
+    for i, (pin, pout) in enumerate(zip(images, outs)):
+        if verbose:
+            print('  Working on image %d ' % (i + 1))
+            print('  ' + pin)
+        im, aff, _ = V.load_volume(pin, im_only=False, dtype='float')
+        S, idx, shape, aff2 = prepare_volume(im, aff, ct=ct)
+        out = predictor(S, flipping=not disable_flipping)
+        V.save_volume(postprocess(out, idx, shape), aff2, None, pout)
+    return outs

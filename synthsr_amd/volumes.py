@@ -1,7 +1,7 @@
 """Volume IO / orientation helpers the hot path's callers need — counterparts of
 ext/lab2im/utils.py:76-160 (`load_volume`, `save_volume`), :163-206 (`get_volume_info`), :209-285
 (`get_list_labels`), :391-424 (`list_images_in_folder`) and ext/lab2im/edit_volumes.py:591-654
-(`get_ras_axes`, `align_volume_to_ref`).  NIfTI only (own reader, nifti.py; nibabel is not installed).
+(`get_ras_axes`, `align_volume_to_ref`) and :504-556 (`resample_volume`).  NIfTI only (own reader, nifti.py; nibabel is not installed).
 """
 import glob
 import os
@@ -102,6 +102,53 @@ def save_volume(volume, aff, header, path, res=None, dtype=None, n_dims=3):
     if dtype is not None and 'int' in dtype:
         volume = np.round(volume)
     write_nifti(path, volume, aff, dtype=dtype)
+
+
+def _axis_samples(n, factor):
+    """sample positions (clamped to the grid) of one axis for a zoom `factor`: the reference's
+    `arange(start, start + step*ceil(n*factor), step)` with start = -(f-1)/(2f), step = 1/f
+    (ext/lab2im/edit_volumes.py:531-544)"""
+    start = -(factor - 1.0) / (2.0 * factor)
+    step = 1.0 / factor
+    pos = np.arange(start=start, stop=start + step * np.ceil(n * factor), step=step)
+    return np.clip(pos, 0.0, n - 1.0)
+
+
+def _interp_axis(vol, pos, axis, nearest):
+    """1-D interpolation of `vol` along `axis` at fractional positions `pos` (already inside [0, n-1])"""
+    n = vol.shape[axis]
+    i0 = np.minimum(np.floor(pos).astype(np.int64), max(n - 2, 0))
+    w = pos - i0
+    i1 = np.minimum(i0 + 1, n - 1)
+    shape = [1] * vol.ndim
+    shape[axis] = -1
+    if nearest:  # scipy RegularGridInterpolator('nearest'): the upper neighbour only when strictly closer
+        return np.take(vol, np.where(w <= 0.5, i0, i1), axis=axis)
+    a, b = np.take(vol, i0, axis=axis), np.take(vol, i1, axis=axis)
+    w = w.reshape(shape)
+    return a * (1.0 - w) + b * w
+
+
+def resample_volume(volume, aff, new_vox_size, interpolation='linear', blur=True):
+    """Resize the voxels of a 3-D volume to `new_vox_size` (mm) and update the affine so that world coordinates are kept
+    (ext/lab2im/edit_volumes.py:504-556, used by scripts/predict_command_line.py:114).  Down-sampled axes are first
+    smoothed with a Gaussian of sigma = 0.25 / zoom; the separable (tri)linear resampling below is what the reference
+    obtains from RegularGridInterpolator on its clamped sampling grid.  Returns (new volume, new affine)."""
+    from scipy.ndimage import gaussian_filter
+    if interpolation not in ('linear', 'nearest'):
+        raise ValueError("interpolation should be 'linear' or 'nearest', had %s" % interpolation)
+    volume = np.asarray(volume)
+    aff = np.asarray(aff, dtype=np.float64)
+    vox = np.sqrt(np.sum(aff * aff, axis=0))[:-1]
+    factor = vox / np.array(new_vox_size, dtype=np.float64)
+    sigmas = np.where(factor > 1, 0.0, 0.25 / factor)  # no anti-aliasing blur on up-sampled axes
+    out = gaussian_filter(volume, sigmas) if blur else volume
+    for ax in range(3):
+        out = _interp_axis(out, _axis_samples(volume.shape[ax], factor[ax]), ax, interpolation == 'nearest')
+    aff2 = aff.copy()
+    aff2[:3, :3] = aff2[:3, :3] / factor[None, :]
+    aff2[:3, 3] = aff2[:3, 3] - aff2[:3, :3] @ (0.5 * (factor - 1.0))
+    return out, aff2
 
 
 def get_volume_info(path_volume, return_volume=False, aff_ref=None, max_channels=10):

@@ -261,8 +261,31 @@ def golden_graphs():
               output_channel=[0], output_shape=32, **kw)
 
 
+def golden_inference():
+    """host side of scripts/predict_command_line.py: edit_volumes.resample_volume (Gaussian pre-blur + linear
+    RegularGridInterpolator on the reference's grid) and align_volume_to_ref, on small anisotropic volumes"""
+    rng = np.random.RandomState(11)
+    out = {}
+    cases = {
+        'down': (rng.rand(14, 11, 9) * 100, np.array([[0.7, 0, 0, -10.], [0, 0.8, 0, 5.], [0, 0, 0.6, 2.], [0, 0, 0, 1.]])),
+        'up': (rng.rand(9, 8, 6) * 50, np.array([[1.5, 0, 0, 3.], [0, 1.5, 0, -4.], [0, 0, 5.0, 1.], [0, 0, 0, 1.]])),
+        # oblique / permuted orientation: x <- -z, y <- x, z <- y with anisotropic voxels (down in one axis, up in two)
+        'mixed': (rng.rand(10, 12, 7) * 80, np.array([[0, 0, -2.0, 30.], [0.9, 0, 0, -7.], [0, 1.3, 0, 4.], [0, 0, 0, 1.]])),
+    }
+    for name, (vol, aff) in cases.items():
+        v2, a2 = l2i_ev.resample_volume(vol.copy(), aff.copy(), [1.0, 1.0, 1.0])
+        v3, a3 = l2i_ev.align_volume_to_ref(v2, a2, aff_ref=np.eye(4), return_aff=True, n_dims=3)
+        out[name + '_vol'], out[name + '_aff'] = vol, aff
+        out[name + '_res_vol'], out[name + '_res_aff'] = v2, a2
+        out[name + '_ras_vol'], out[name + '_ras_aff'] = v3, a3
+    np.savez_compressed(os.path.join(OUT, 'inference.npz'), **out)
+    print('inference.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs']
+    which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs', 'inference']
+    if 'inference' in which:
+        golden_inference()
     if 'resampler' in which:
         golden_resampler()
     if 'host_math' in which:

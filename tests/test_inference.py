@@ -1,0 +1,111 @@
+"""Inference path (reference scripts/predict_command_line.py): host pre/post-processing against
+goldens produced by the reference's own functions, and the full predict() through the HIP U-Net against the oracle."""
+import os
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, 'golden', 'inference.npz')
+
+
+@pytest.mark.parametrize('case', ['down', 'up', 'mixed'])
+def test_resample_volume_matches_reference(case):
+    from synthsr_amd import volumes as V
+    z = np.load(GOLD)
+    v2, a2 = V.resample_volume(z[case + '_vol'], z[case + '_aff'], [1.0, 1.0, 1.0])
+    assert v2.shape == z[case + '_res_vol'].shape
+    np.testing.assert_allclose(v2, z[case + '_res_vol'], rtol=0, atol=1e-10)  # float64 re-association only
+    np.testing.assert_allclose(a2, z[case + '_res_aff'], rtol=0, atol=1e-12)
+    v3, a3 = V.align_volume_to_ref(v2, a2, aff_ref=np.eye(4), return_aff=True, n_dims=3)
+    np.testing.assert_allclose(v3, z[case + '_ras_vol'], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(a3, z[case + '_ras_aff'], rtol=0, atol=1e-12)
+
+
+def test_resample_volume_nearest_and_errors():
+    from synthsr_amd import volumes as V
+    vol = np.arange(4 * 3 * 2, dtype=float).reshape(4, 3, 2)
+    aff = np.diag([2.0, 1.0, 1.0, 1.0])
+    out, aff2 = V.resample_volume(vol, aff, [1.0, 1.0, 1.0], interpolation='nearest', blur=False)
+    assert out.shape == (8, 3, 2)
+    assert set(np.unique(out)) <= set(np.unique(vol))  # nearest never invents values
+    np.testing.assert_allclose(np.sqrt((aff2[:3, :3] ** 2).sum(0)), [1.0, 1.0, 1.0])
+    # world position of the first voxel's corner is preserved: centre moves by -0.5*(f-1) new voxels
+    np.testing.assert_allclose(aff2[:3, 3], [-0.5, 0.0, 0.0])
+    with pytest.raises(ValueError):
+        V.resample_volume(vol, aff, [1.0, 1.0, 1.0], interpolation='cubic')
+
+
+def test_prepare_and_postprocess():
+    from synthsr_amd.predict import prepare_volume, postprocess
+    rng = np.random.RandomState(0)
+    im = rng.rand(20, 35, 33) * 90 - 10
+    S, idx, shape, aff2 = prepare_volume(im, np.eye(4), ct=True)
+    assert S.shape == (32, 64, 64) and list(shape) == [20, 35, 33] and list(idx) == [6, 14, 15]
+    inner = S[idx[0]:idx[0] + 20, idx[1]:idx[1] + 35, idx[2]:idx[2] + 33]
+    assert inner.min() == 0.0 and inner.max() == 1.0 and S.sum() == inner.sum()
+    from scipy.ndimage import gaussian_filter
+    ct = gaussian_filter(np.clip(im, 0, 80), 0.25)  # the reference pre-blurs with sigma .25/zoom unless up-sampling (zoom 1 too)
+    np.testing.assert_allclose(inner, (ct - ct.min()) / (ct - ct.min()).max(), atol=1e-12)
+    out = rng.randn(1, 32, 64, 64, 1)
+    pred = postprocess(out, idx, shape)
+    assert pred.shape == (20, 35, 33) and pred.min() >= 0 and pred.max() <= 128
+    ref = np.clip(255 * out[0, ..., 0], 0, 128)[6:26, 14:49, 15:48]
+    np.testing.assert_allclose(pred, ref)
+
+
+def test_predict_argument_errors(tmp_path):
+    from synthsr_amd.predict import predict, Predictor
+    bad = tmp_path / 'scan.txt'
+    bad.write_text('x')
+    with pytest.raises(Exception, match='extension not supported'):
+        predict(str(bad), str(tmp_path / 'out.nii.gz'), predictor=object())
+    with pytest.raises(AssertionError):
+        predict(str(tmp_path / 'missing.nii.gz'), str(tmp_path / 'out.nii.gz'), predictor=object())
+    with pytest.raises(FileNotFoundError, match='model file'):
+        Predictor(str(tmp_path / 'nope.npz'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('flip', [True, False])
+def test_predict_end_to_end_vs_oracle(tmp_path, flip):
+    """synthetic anisotropic NIfTI -> predict() with a random-weight checkpoint; the U-Net output must equal the oracle's
+    inference-mode forward (moving statistics) on the same prepared volume: 2e-4 of the output range (fp32 convs)"""
+    import torch
+    from synthsr_amd import volumes as V
+    from synthsr_amd.predict import predict, prepare_volume, postprocess
+    from synthsr_amd.training import save_checkpoint
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    rng = np.random.RandomState(3)
+    vol = rng.rand(30, 22, 26) * 1000
+    aff = np.array([[-1.2, 0, 0, 40.], [0, 1.0, 0, -30.], [0, 0, 1.4, 5.], [0, 0, 0, 1.]])
+    pin = str(tmp_path / 'scan.nii.gz')
+    V.save_volume(vol, aff, None, pin)
+    # a random network with non-trivial moving statistics, saved in the checkpoint format
+    net = unet(24, [32, 32, 32, 1], 5, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
+               final_pred_activation='linear', seed=1)
+    g = torch.Generator().manual_seed(0)
+    net.bn_moving.copy_((torch.rand(net.bn_moving.shape, generator=g) * 0.5 + 0.25).to(net.bn_moving.device))
+    ck = str(tmp_path / 'model.npz')
+    save_checkpoint(ck, net)
+    pout = str(tmp_path / 'sub' / 'pred.nii.gz')
+    predict(pin, pout, path_model=ck, disable_flipping=not flip, verbose=False)
+    got, aff_out, _ = V.load_volume(pout, im_only=False)
+    # oracle on the same prepared input
+    im, aff_in, _ = V.load_volume(pin, im_only=False, dtype='float')
+    S, idx, shape, aff2 = prepare_volume(im, aff_in)
+    assert S.shape == (64, 32, 64)
+    sd = net.state_dict()
+    P = {k: v.float() for k, v in sd.items()}
+    x = torch.from_numpy(S.astype(np.float32))[..., None]
+    with torch.no_grad():
+        out = U.unet_forward(x, P, net.prefix, 5, 2, training=False, moving=P)[..., 0]
+        if flip:
+            outf = U.unet_forward(torch.flip(x, dims=[0]), P, net.prefix, 5, 2, training=False, moving=P)[..., 0]
+            out = 0.5 * out + 0.5 * torch.flip(outf, dims=[0])
+    ref = postprocess(out.numpy(), idx, shape)
+    assert got.shape == ref.shape == tuple(shape)
+    np.testing.assert_allclose(aff_out, aff2, atol=1e-5)
+    scale = max(np.abs(255 * out.numpy()).max(), 1.0)
+    assert np.abs(got - ref).max() / scale < 2e-4
+    assert ref.std() > 0  # not a clipped-flat image
