@@ -90,6 +90,15 @@ int synthsr_deform_gmm(const int32_t* labels, const float* field_half, const flo
                        float* chan_out, uint32_t* minmax, const synthsr_deform_params* p,
                        synthsr_stream_t stream);
 
+/* the same with a real scan as regression target (output_channel=None, labels_to_image_model.py:109-113,126-160):
+ * real_in float [in_shape] is sampled at the SAME positions with inter_method 'linear' (edge-clamped trilinear), cropped
+ * and flipped like the labels -> real_out float [out_shape]; its min/max (for IntensityAugmentation(normalise), :250)
+ * accumulate into real_minmax[2] (ordered-encoded, initialised by synthsr_minmax_init).  real_in == NULL: plain call. */
+int synthsr_deform_gmm_real(const int32_t* labels, const float* field_half, const float* gmm_lut,
+                            const int32_t* swap_lut, const float* noise, const float* bias_small, int32_t* seg_out,
+                            float* chan_out, uint32_t* minmax, const float* real_in, float* real_out,
+                            uint32_t* real_minmax, const synthsr_deform_params* p, synthsr_stream_t stream);
+
 int synthsr_minmax_init(uint32_t* minmax, int n_pairs, synthsr_stream_t stream);
 /* generic min/max over n floats into one ordered-encoded pair (IntensityAugmentation on a real image) */
 int synthsr_minmax_reduce(const float* x, int64_t n, uint32_t* minmax, synthsr_stream_t stream);

@@ -457,8 +457,10 @@ def labels_to_image(labels, means, stds, tape, generation_labels, n_neutral_labe
                     rotation_bounds=15, shearing_bounds=.012, translation_bounds=False, nonlin_std=3.,
                     nonlin_shape_factor=.0625, simulate_registration_error=True, data_res=None, thickness=None,
                     downsample=False, build_reliability_maps=False, blur_range=1.15, bias_field_std=.3,
-                    bias_shape_factor=.025):
+                    bias_shape_factor=.025, real_image=None):
     """labels int32 [X,Y,Z]; means/stds [L,C]; tape: list of (kind, array) in the reference's call order.
+    output_channel=None selects the real-image regression target (labels_to_image_model.py:71,109-113): `real_image`
+    float32 [X,Y,Z] is deformed (linear), cropped and flipped jointly with the labels, then min-max normalised (:248-255).
     Returns dict(image [X',Y',Z',Cin(+maps)], target [X',Y',Z',Ct], seg int32 [X',Y',Z'], extras)."""
     tp = tape if isinstance(tape, TapeReader) else TapeReader(tape)
     input_channels = list(input_channels)
@@ -482,11 +484,17 @@ def labels_to_image(labels, means, stds, tape, generation_labels, n_neutral_labe
     target_res = atlas_res if target_res is None else list(np.array(target_res, dtype=np.float64).reshape(-1)[:3])
     labels = np.asarray(labels)
     assert labels.ndim == 3
+    use_real = output_channel is None
+    if use_real:
+        assert real_image is not None and tuple(np.shape(real_image)) == labels.shape, 'real image of the label-map shape'
+        real = f32(real_image)
     crop_shape, out_shape = get_shapes(labels.shape, output_shape, atlas_res, target_res, padding_margin,
                                        output_div_by_n)
     if padding_margin is not None:  # PadAroundCentre, layers.py:1754
         pm = [int(padding_margin)] * 3 if np.isscalar(padding_margin) else [int(p) for p in padding_margin]
         labels = np.pad(labels, [(p, p) for p in pm])
+        if use_real:
+            real = np.pad(real, [(p, p) for p in pm])  # :119-120
     lshape = list(labels.shape)
 
     # --- deformation (:124-142)
@@ -503,18 +511,30 @@ def labels_to_image(labels, means, stds, tape, generation_labels, n_neutral_labe
         small = get_resample_shape(lshape, nonlin_shape_factor)
         u_std = tp.get('u', 1)[0]
         n_field = tp.get('n', int(np.prod(small)) * 3)
-    (lab,), shift = random_spatial_deformation([labels.astype(np.int32)[..., None]], ['nearest'], aff, u_std,
-                                               n_field, nonlin_std, nonlin_shape_factor)
+    if use_real:  # inter_method=['nearest', 'linear'] (:128-134)
+        (lab, real), shift = random_spatial_deformation([labels.astype(np.int32)[..., None], real[..., None]],
+                                                        ['nearest', 'linear'], aff, u_std, n_field, nonlin_std,
+                                                        nonlin_shape_factor)
+        real = real[..., 0]
+    else:
+        (lab,), shift = random_spatial_deformation([labels.astype(np.int32)[..., None]], ['nearest'], aff, u_std,
+                                                   n_field, nonlin_std, nonlin_shape_factor)
     lab = lab[..., 0]
     extras = dict(affine=aff, shift=shift)
     # --- crop (:145-151)
     if crop_shape != lshape:
         ci = random_crop_index(tp.get('u', 3), lshape, crop_shape)
         lab = lab[ci[0]:ci[0] + crop_shape[0], ci[1]:ci[1] + crop_shape[1], ci[2]:ci[2] + crop_shape[2]]
+        if use_real:  # the same crop (RandomCrop on the concatenated inputs, layers.py:252-270)
+            real = real[ci[0]:ci[0] + crop_shape[0], ci[1]:ci[1] + crop_shape[1], ci[2]:ci[2] + crop_shape[2]]
         extras['crop_idx'] = ci
     # --- flip (:154-162)
     if flipping:
-        (lab,), flipped = random_flip([lab], tp.get('u', 1)[0], swap_lut(generation_labels, n_neutral_labels))
+        if use_real:  # swap_labels=True only applies to the label map (layers.py:382-386)
+            (lab, real), flipped = random_flip([lab, real], tp.get('u', 1)[0],
+                                               swap_lut(generation_labels, n_neutral_labels), swap=(True, False))
+        else:
+            (lab,), flipped = random_flip([lab], tp.get('u', 1)[0], swap_lut(generation_labels, n_neutral_labels))
         extras['flipped'] = flipped
     # --- GMM (:166)
     S = lab.shape
@@ -562,6 +582,12 @@ def labels_to_image(labels, means, stds, tape, generation_labels, n_neutral_labe
             channels.append(ch)
             if build_reliability_maps:
                 channels.append(rel)
+    if use_real:  # :248-255
+        tgt = intensity_augmentation(real[..., None], None, clip=False, normalise=True, gamma_std=0)
+        if crop_shape != out_shape:
+            tgt = gaussian_blur(tgt, list(blurring_sigma_for_downsampling(atlas_res, target_res)))
+            tgt, _ = resample_tensor(tgt, out_shape)
+        targets = [tgt]
     assert tp.done(), 'tape not fully consumed'
     return dict(image=np.concatenate(channels, -1), target=np.concatenate(targets, -1),
                 seg=lab.astype(np.int32), extras=extras)

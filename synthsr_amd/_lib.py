@@ -36,6 +36,7 @@ SIGNATURES = {
     'synthsr_svf_integrate': (c_int, [_P, _P, POINTER(c_int), c_int, _S]),
     'synthsr_affine_resample_linear': (c_int, [_P, _P, c_int, POINTER(c_int), POINTER(c_float), _S]),
     'synthsr_deform_gmm': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(DeformParams), _S]),
+    'synthsr_deform_gmm_real': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(DeformParams), _S]),
     'synthsr_minmax_init': (c_int, [_P, c_int, _S]),
     'synthsr_minmax_reduce': (c_int, [_P, c_int64, _P, _S]),
     'synthsr_normalise_gamma': (c_int, [_P, _P, c_int64, _P, c_float, _S]),

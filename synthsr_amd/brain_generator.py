@@ -48,8 +48,6 @@ class BrainGenerator:
         """Parameters as in the reference (brain_generator.py:62-191).  Extra, optional:
         device (torch device), rng (numpy Generator for the host input sampler), label_maps (list of int32
         volumes already in memory, used instead of reading `labels_dir`; needs labels_dir=None)."""
-        if images_dir is not None:
-            raise NotImplementedError('real-image regression targets (images_dir) are not built yet')
         if label_maps is not None:
             self.labels_paths = None
             self.label_maps = [np.ascontiguousarray(m, dtype=np.int32) for m in label_maps]
@@ -60,7 +58,13 @@ class BrainGenerator:
             self.label_maps = None
             self.labels_shape, self.aff, self.n_dims, _, self.header, self.atlas_res = \
                 volumes.get_volume_info(self.labels_paths[0], aff_ref=np.eye(4))
-        self.images_paths = None
+        # real scans as regression targets (brain_generator.py:197-198): a folder, or a list of in-memory float volumes
+        if images_dir is None:
+            self.images_paths = None
+        elif isinstance(images_dir, (list, tuple)):
+            self.images_paths = [np.asarray(v, dtype=np.float32) for v in images_dir]
+        else:
+            self.images_paths = volumes.list_images_in_folder(images_dir)
         if generation_labels is not None:
             self.generation_labels = np.asarray(hm.load_array_if_path(generation_labels))
         else:

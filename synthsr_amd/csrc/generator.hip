@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
                                                          const float* __restrict__ noise,
                                                          const float* __restrict__ bias_small,
                                                          int32_t* __restrict__ seg_out, float* __restrict__ chan_out,
-                                                         uint32_t* __restrict__ minmax, synthsr_deform_params p) {
+                                                         uint32_t* __restrict__ minmax, const float* __restrict__ real_in,
+                                                         float* __restrict__ real_out, uint32_t* __restrict__ real_minmax,
+                                                         synthsr_deform_params p) {
   const int64_t n = (int64_t)p.out_shape[0] * p.out_shape[1] * p.out_shape[2];
   const int C = p.n_channels;
   float lmin[4], lmax[4];
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
     lmin[c] = INFINITY;
     lmax[c] = -INFINITY;
   }
+  float rmin = INFINITY, rmax = -INFINITY;  // real-image regression target (labels_to_image_model.py:126-134)
   Aff A;
 #pragma unroll
   for (int i = 0; i < 12; ++i) A.a[i] = p.aff[i];
@@ -233,6 +236,16 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
     int lab = labels[((int64_t)r0 * p.in_shape[1] + r1) * p.in_shape[2] + r2];
     if (p.flip && swap_lut != nullptr && lab >= 0 && lab < p.swap_lut_size) lab = swap_lut[lab];
     if (seg_out) seg_out[o] = lab;
+    if (real_in) {  // the same transform with inter_method 'linear' (edge-clamped trilinear, ext/neuron/utils.py:67-110)
+      const Axis r0a = axis_setup(pos[0], p.in_shape[0]);
+      const Axis r1a = axis_setup(pos[1], p.in_shape[1]);
+      const Axis r2a = axis_setup(pos[2], p.in_shape[2]);
+      const int s1 = p.in_shape[1], s2 = p.in_shape[2];
+      const float rv = tri_accum(r0a, r1a, r2a, [&](int i, int j, int k) { return real_in[((int64_t)i * s1 + j) * s2 + k]; });
+      real_out[o] = rv;
+      rmin = fminf(rmin, rv);
+      rmax = fmaxf(rmax, rv);
+    }
 
     float nz[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.use_philox) {
@@ -286,6 +299,13 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
         atomicMin(&minmax[2 * c + 0], syn_f2ord(mn));
         atomicMax(&minmax[2 * c + 1], syn_f2ord(mx));
       }
+    }
+  }
+  if (real_in && real_minmax) {
+    const float mn = syn_wave_min(rmin), mx = syn_wave_max(rmax);
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&real_minmax[0], syn_f2ord(mn));
+      atomicMax(&real_minmax[1], syn_f2ord(mx));
     }
   }
 }
@@ -436,7 +456,16 @@ int synthsr_affine_resample_linear(const float* in, float* out, int C, const int
 int synthsr_deform_gmm(const int32_t* labels, const float* field_half, const float* gmm_lut, const int32_t* swap_lut,
                        const float* noise, const float* bias_small, int32_t* seg_out, float* chan_out,
                        uint32_t* minmax, const synthsr_deform_params* p, synthsr_stream_t stream) {
+  return synthsr_deform_gmm_real(labels, field_half, gmm_lut, swap_lut, noise, bias_small, seg_out, chan_out, minmax,
+                                 nullptr, nullptr, nullptr, p, stream);
+}
+
+int synthsr_deform_gmm_real(const int32_t* labels, const float* field_half, const float* gmm_lut,
+                            const int32_t* swap_lut, const float* noise, const float* bias_small, int32_t* seg_out,
+                            float* chan_out, uint32_t* minmax, const float* real_in, float* real_out,
+                            uint32_t* real_minmax, const synthsr_deform_params* p, synthsr_stream_t stream) {
   if (!labels || !gmm_lut || !chan_out || !minmax || !p) return SYNTHSR_EINVAL;
+  if (real_in && !real_out) return SYNTHSR_EINVAL;
   if (bad_shape(p->in_shape) || bad_shape(p->out_shape)) return SYNTHSR_EINVAL;
   if (p->n_channels < 1 || p->n_channels > 4 || p->lut_size < 1) return SYNTHSR_EINVAL;
   if (p->has_field && (!field_half || bad_shape(p->half_shape))) return SYNTHSR_EINVAL;
@@ -451,7 +480,7 @@ int synthsr_deform_gmm(const int32_t* labels, const float* field_half, const flo
   const int64_t n = (int64_t)p->out_shape[0] * p->out_shape[1] * p->out_shape[2];
   hipLaunchKernelGGL(deform_gmm_kernel, dim3(syn_grid(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, labels,
                      field_half, gmm_lut, p->swap_lut_size > 0 ? swap_lut : nullptr, noise, bias_small, seg_out,
-                     chan_out, minmax, *p);
+                     chan_out, minmax, real_in, real_out, real_minmax, *p);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

@@ -12,7 +12,7 @@ Random draws are explicit (`Draws`).  In production they come from a per-rank nu
 parity tests inject the reference's recorded tape through `draws_from_tape`.
 
 Scope: synthetic regression target, fixed acquisition resolution.  `randomise_res=True`
-and real-image targets raise NotImplementedError (rows §8f-2 / §8f-4, not built yet).
+raises NotImplementedError (row §8f-2, not built yet); real-image regression targets (output_channel=None, §8f-4) are supported.
 Batch items are generated independently; for batchsize > 1 the reference sums the GMM LUT over the
 batch (F9, a bug) — that is NOT reproduced.
 """
@@ -53,9 +53,9 @@ class LabelsToImageModel:
         input_channels = [bool(c) for c in hm.reformat_to_list(input_channels)]
         self.input_channels = input_channels
         self.n_channels = n_channels = len(input_channels)
-        if output_channel is None:
-            raise NotImplementedError('real-image regression targets (output_channel=None) are not built yet')
-        self.output_channel = [int(c) for c in hm.reformat_to_list(output_channel)]
+        # output_channel=None: the regression target is a real scan fed as a 4th input (labels_to_image_model.py:71,109-113)
+        self.use_real_image = output_channel is None
+        self.output_channel = [] if output_channel is None else [int(c) for c in hm.reformat_to_list(output_channel)]
         self.idx_first_input_channel = int(np.argmax(input_channels))
         self.simulate_registration_error = hm.reformat_to_list(simulate_registration_error, length=n_channels)
         labels_shape = hm.reformat_to_list(labels_shape)
@@ -125,7 +125,7 @@ class LabelsToImageModel:
 
         # ---- output layout
         self.n_image_channels = sum(input_channels) * (2 if build_reliability_maps else 1)
-        self.n_target_channels = len(self.output_channel)
+        self.n_target_channels = 1 if self.use_real_image else len(self.output_channel)
         self.model_output_shape = list(self.output_shape) + [self.n_image_channels]
 
         # ---- persistent device buffers
@@ -142,7 +142,10 @@ class LabelsToImageModel:
         self.d_seg = torch.empty(nc, dtype=i32, device=dev)
         self.d_chan = torch.empty(n_channels * nc, dtype=f32, device=dev)
         self.d_tmp = [torch.empty(max(nc, no), dtype=f32, device=dev) for _ in range(3)]
-        self.d_minmax = torch.empty(2 * n_channels, dtype=torch.int32, device=dev)
+        self.d_minmax = torch.empty(2 * n_channels + 2, dtype=torch.int32, device=dev)  # + the real image's pair
+        if self.use_real_image:
+            self.d_real_in = torch.empty(nin, dtype=f32, device=dev)
+            self.d_real = torch.empty(nc, dtype=f32, device=dev)
         self.d_image = torch.empty(no * self.n_image_channels, dtype=f32, device=dev)
         self.d_target = torch.empty(no * self.n_target_channels, dtype=f32, device=dev)
         self.small_cap = 1 << 16  # floats of per-volume small parameters (SVF grid, bias grids, kernels, LUTs)
@@ -285,9 +288,9 @@ class LabelsToImageModel:
             return ctypes.c_void_p(self.m.d_small.data_ptr() + 4 * off)
 
     # ------------------------------------------------------------------ the generator
-    def generate(self, labels, means, stds, draws=None, labels_on_device=False):
+    def generate(self, labels, means, stds, draws=None, labels_on_device=False, real_image=None):
         """one volume.  labels: int32 [*labels_shape] (numpy, or a device tensor if labels_on_device);
-        means/stds: [L, C].  Returns (image [*S, Ci], target [*S, Ct], seg int32 [*S]) device tensors that are
+        means/stds: [L, C]; real_image: float [*labels_shape] when the model was built with output_channel=None.  Returns (image [*S, Ci], target [*S, Ct], seg int32 [*S]) device tensors that are
         views of persistent buffers (valid until the next call)."""
         torch, lib = self.torch, self.lib
         st = _lib.stream()
@@ -305,6 +308,17 @@ class LabelsToImageModel:
             self.d_labels.copy_(torch.from_numpy(np.ascontiguousarray(lab, dtype=np.int32).reshape(-1)),
                                 non_blocking=False)
             d_labels = self.d_labels
+        if self.use_real_image:
+            if real_image is None:
+                raise ValueError('this model was built with output_channel=None: a real image input is required')
+            if torch.is_tensor(real_image):
+                assert real_image.numel() == self.d_real_in.numel() and real_image.dtype == torch.float32
+                self.d_real_in.copy_(real_image.reshape(-1))
+            else:
+                real = np.asarray(real_image, dtype=np.float32)
+                if self.padding_margin is not None:  # PadAroundCentre on the real image too (:119-120)
+                    real = np.pad(real.reshape(self.input_labels_shape), [(p, p) for p in self.padding_margin])
+                self.d_real_in.copy_(torch.from_numpy(np.ascontiguousarray(real).reshape(-1)))
 
         # ---- host-side O(1) parameters
         sm = self._Small(self)
@@ -387,6 +401,9 @@ class LabelsToImageModel:
                 plan['k_tgt'] = (sm.put(kt), list(kt.shape))
             plan['gexp'] = float(np.exp(np.float32(ch['n_gamma']) * np.float32(0.5)))  # layers.py:1240-1242
             chan_plan.append(plan)
+        if self.use_real_image and self.resample_target:  # blur to target_res before the final resize (:251-255)
+            ktr = hm.gaussian_kernel(list(hm.blurring_sigma_for_downsampling(self.atlas_res, self.target_res)))
+            self.real_k_tgt = (sm.put(ktr), list(ktr.shape))
         # noise
         if d.gmm_noise is not None:
             noise = torch.from_numpy(np.ascontiguousarray(d.gmm_noise, dtype=np.float32).reshape(-1))
@@ -407,13 +424,16 @@ class LabelsToImageModel:
                                               i3(self.half_shape), 0, st), 'resize(svf)')
             _lib.check(lib.synthsr_svf_integrate(_lib.ptr(self.d_svf), _lib.ptr(self.d_svf_tmp), i3(self.half_shape), 7,
                                                  st), 'svf_integrate')
-        _lib.check(lib.synthsr_minmax_init(_lib.ptr(self.d_minmax), C, st), 'minmax_init')
-        _lib.check(lib.synthsr_deform_gmm(
+        _lib.check(lib.synthsr_minmax_init(_lib.ptr(self.d_minmax), C + 1, st), 'minmax_init')
+        real_mm = ctypes.c_void_p(self.d_minmax.data_ptr() + 8 * C)
+        _lib.check(lib.synthsr_deform_gmm_real(
             _lib.ptr(d_labels), _lib.ptr(self.d_svf) if self.apply_elastic else None, sm.dptr(off_lut),
             _lib.ptr(self.d_swap) if self.d_swap is not None else None,
             _lib.ptr(self.d_noise) if not p.use_philox else None,
             sm.dptr(off_bias) if off_bias is not None else None, _lib.ptr(self.d_seg), _lib.ptr(self.d_chan),
-            _lib.ptr(self.d_minmax), ctypes.byref(p), st), 'deform_gmm')
+            _lib.ptr(self.d_minmax), _lib.ptr(self.d_real_in) if self.use_real_image else None,
+            _lib.ptr(self.d_real) if self.use_real_image else None, real_mm if self.use_real_image else None,
+            ctypes.byref(p), st), 'deform_gmm')
 
         nc, no = self.ncrop, self.nout
         cs, os_ = i3(self.crop_shape), i3(self.output_shape)
@@ -501,6 +521,17 @@ class LabelsToImageModel:
                 _lib.check(lib.synthsr_copy_strided(rel_buf, fptr(self.d_image), no, 1, 0, Ci, img_slot, st), 'copy(map)')
                 img_slot += 1
 
+        if self.use_real_image:  # IntensityAugmentation(normalise=True) on the deformed scan (:250), then to target_res
+            r = fptr(self.d_real)
+            t0, t1, t2 = (fptr(t) for t in self.d_tmp)
+            _lib.check(lib.synthsr_normalise_gamma(r, r, nc, real_mm, 0.0, st), 'normalise(real)')
+            if self.resample_target:
+                ko, ks = self.real_k_tgt
+                _lib.check(lib.synthsr_blur3d(r, t1, cs, sm.dptr(ko), i3(ks), 1, 0, -1, 0., st), 'blur(real tgt)')
+                _lib.check(lib.synthsr_resize_f32(t1, t2, 1, cs, os_, 0, st), 'resize(real tgt)')
+                _lib.check(lib.synthsr_copy_strided(t2, fptr(self.d_target), no, 1, 0, 1, 0, st), 'copy(real tgt)')
+            else:
+                _lib.check(lib.synthsr_copy_strided(r, fptr(self.d_target), nc, 1, 0, 1, 0, st), 'copy(real tgt)')
         image = self.d_image.view(*self.output_shape, Ci)
         target = self.d_target.view(*self.output_shape, Ct)
         seg = self.d_seg.view(*self.crop_shape)
@@ -511,11 +542,13 @@ class LabelsToImageModel:
         """inputs = [labels [B,*S,1], means [B,L,C], stds [B,L,C]] -> [image [B,*S',Ci], target [B,*S',Ct]] (device)"""
         labels, means, stds = inputs[:3]
         labels = np.asarray(labels)
+        real = np.asarray(inputs[3]) if self.use_real_image else None  # 4th Keras input 'real_image_input'
         B = labels.shape[0]
         images, targets = [], []
         for b in range(B):
             img, tgt, _ = self.generate(labels[b, ..., 0], np.asarray(means)[b], np.asarray(stds)[b],
-                                        None if draws is None else draws[b])
+                                        None if draws is None else draws[b],
+                                        real_image=None if real is None else real[b, ..., 0])
             if B > 1:
                 img, tgt = img.clone(), tgt.clone()
             images.append(img)

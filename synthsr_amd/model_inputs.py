@@ -22,9 +22,11 @@ def build_model_inputs(path_label_maps,
                        generation_classes=None,
                        rng=None,
                        label_maps=None):
-    """`label_maps` (optional): list of already loaded int32 volumes replacing `path_label_maps`"""
-    if path_images is not None:
-        raise NotImplementedError('real-image regression targets are not built yet')
+    """`label_maps` (optional): list of already loaded int32 volumes replacing `path_label_maps`.
+    `path_images`: real scans matching the label maps one to one (same order); each batch then carries a 4th input, the
+    scan of the picked label map, float [B, *shape, 1] (model_inputs.py:94-96,131-132)."""
+    if path_images is not None and len(path_images) != (len(label_maps) if label_maps is not None else len(path_label_maps)):
+        raise ValueError('path_images and the label maps should have the same length')
     if generation_classes is None:
         generation_classes = np.arange(n_labels)
     n_classes = len(np.unique(generation_classes))
@@ -39,15 +41,25 @@ def build_model_inputs(path_label_maps,
             cache[idx] = volumes.load_volume(path_label_maps[idx], dtype='int', aff_ref=np.eye(4))
         return cache[idx]
 
+    img_cache = {}
+
+    def get_image(idx):
+        if idx not in img_cache:
+            v = path_images[idx]
+            img_cache[idx] = v if isinstance(v, np.ndarray) else volumes.load_volume(v, dtype='float', aff_ref=np.eye(4))
+        return img_cache[idx]
+
     def randint(n, size):
         return npr.randint(n, size=size) if hasattr(npr, 'randint') else npr.integers(n, size=size)
 
     while True:
         indices = randint(n_maps, batchsize)
-        list_label_maps, list_means, list_stds = [], [], []
+        list_label_maps, list_means, list_stds, list_images = [], [], [], []
         for idx in indices:
             lab = get_labels(int(idx))
             list_label_maps.append(lab[np.newaxis, ..., np.newaxis])
+            if path_images is not None:
+                list_images.append(np.asarray(get_image(int(idx)))[np.newaxis, ..., np.newaxis])
             means = np.empty((1, n_labels, 0))
             stds = np.empty((1, n_labels, 0))
             for channel in range(n_channels):
@@ -74,6 +86,8 @@ def build_model_inputs(path_label_maps,
             list_means.append(means)
             list_stds.append(stds)
         list_inputs = [list_label_maps, list_means, list_stds]
+        if path_images is not None:
+            list_inputs.append(list_images)
         if batchsize > 1:
             list_inputs = [np.concatenate(item, 0) for item in list_inputs]
         else:

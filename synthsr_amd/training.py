@@ -83,12 +83,13 @@ class Trainer:
         if model_inputs is None:
             model_inputs = next(self.bg.model_inputs_generator)
         labels, means, stds = model_inputs[:3]
-        if label_index is not None and self.resident_labels is not None:
+        real = np.asarray(model_inputs[3])[0, ..., 0] if getattr(gen, 'use_real_image', False) else None
+        if label_index is not None and self.resident_labels is not None and real is None:
             image, target, _ = gen.generate(self.resident_labels[label_index], np.asarray(means)[0],
                                             np.asarray(stds)[0], draws, labels_on_device=True)
         else:
             image, target, _ = gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0], np.asarray(stds)[0],
-                                            draws)
+                                            draws, real_image=real)
         residual, rs, ro = None, 1, 0
         if self.residual is not None:
             residual, rs, ro = image, image.shape[-1], int(self.residual[0])
@@ -251,7 +252,8 @@ def training(labels_dir,
     brain_generator.labels_to_image_model.seed(seed, rank)
     unet_input_shape = brain_generator.model_output_shape
     net = build_unet(nb_features=unet_feat_count, input_shape=unet_input_shape, nb_levels=n_levels,
-                     conv_size=conv_size, nb_labels=len(output_channel), feat_mult=feat_multiplier,
+                     conv_size=conv_size, nb_labels=(1 if output_channel is None else len(output_channel)),  # training.py:246-249
+                     feat_mult=feat_multiplier,
                      nb_conv_per_level=nb_conv_per_level, conv_dropout=dropout, final_pred_activation='linear',
                      batch_norm=-1, activation=activation, input_model=brain_generator.labels_to_image_model,
                      seed=seed)

@@ -208,12 +208,14 @@ def golden_layers():
     print('layers.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
 
 
-def run_graph(name, labels, means, stds, seed, **kw):
+def run_graph(name, labels, means, stds, seed, real_image=None, **kw):
     """whole labels_to_image_model() graph (SynthSR/labels_to_image_model.py:32-266)"""
     tape = shim.Tape(seed=seed)
     shim.set_tape(tape)
     NAMED.clear()
     FEED[:] = [('labels_input', labels), ('means_input', means), ('std_devs_input', stds)]
+    if real_image is not None:
+        FEED.append(('real_image_input', real_image))
     model = ref_l2i_model.labels_to_image_model(labels_shape=list(labels.shape[1:4]),
                                                 generation_labels=GEN_LABELS,
                                                 n_neutral_labels=len(GEN_LABELS),
@@ -221,6 +223,8 @@ def run_graph(name, labels, means, stds, seed, **kw):
     image, target = model.outputs
     out = dict(labels=labels, means=means, stds=stds, image=np.asarray(image), target=np.asarray(target),
                seg=np.asarray(NAMED['segmentation_target']))
+    if real_image is not None:
+        out['real_image'] = real_image
     out.update(tape_to_dict(tape))
     for k, v in kw.items():
         if v is None:
@@ -249,6 +253,17 @@ def golden_graphs():
     lab_b = load_label_crop(3, (50, 70, 60), (40, 48, 36))[None, ..., None]
     run_graph('graph_crop_s111', lab_b, means, stds, 111, input_channels=[True], output_channel=[0],
               output_shape=32, **train_defaults)
+    # (b') real-image regression target (output_channel=None, tutorials 1/3/5): a smooth synthetic "scan" deformed,
+    # cropped and flipped jointly with the labels (linear), then min-max normalised
+    def fake_scan(lab_vol, seed):
+        r = np.random.default_rng(seed)
+        lut = r.uniform(20, 200, size=int(lab_vol.max()) + 1)
+        v = lut[lab_vol[0, ..., 0]] + r.normal(0, 5, size=lab_vol.shape[1:4])
+        return v.astype(np.float32)[None, ..., None]
+    run_graph('graph_real_s131', lab, means, stds, 131, real_image=fake_scan(lab, 1), input_channels=[True],
+              output_channel=None, output_shape=32, **train_defaults)
+    run_graph('graph_real_crop_s132', lab_b, means, stds, 132, real_image=fake_scan(lab_b, 2), input_channels=[True],
+              output_channel=None, output_shape=32, **train_defaults)
     # (c) Hyperfine-like: 3 channels [False, True, True], 1.5x1.5x5, registration error, no reliability maps
     means3, stds3 = class_stats(rng, ('t1_hr', 't1_lr', 't2'))
     kw = dict(train_defaults)

@@ -112,6 +112,24 @@ def test_whole_graph_hyperfine_vs_golden(env, name, maps):
     np.testing.assert_allclose(target.cpu().numpy(), g['target'][0], atol=2e-5)
 
 
+@pytest.mark.parametrize('name', ['graph_real_s131', 'graph_real_crop_s132'])
+def test_whole_graph_real_image_target_vs_golden(env, name):
+    """output_channel=None: the real scan rides through the same fused deformation kernel with linear
+    interpolation and becomes the min-max normalised regression target"""
+    g, m = _model(name, input_channels=[True], output_channel=None)
+    draws = m.draws_from_tape(tape_from_golden(g))
+    real = g['real_image'][0, ..., 0]
+    image, target, seg = m.generate(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], draws, real_image=real)
+    np.testing.assert_array_equal(seg.cpu().numpy(), g['seg'][0, ..., 0])
+    np.testing.assert_allclose(image.cpu().numpy(), g['image'][0], atol=2e-5)
+    np.testing.assert_allclose(target.cpu().numpy(), g['target'][0], atol=2e-5)
+    # Keras-like protocol: 4 inputs [labels, means, stds, real_image]
+    out = m.predict([g['labels'], g['means'], g['stds'], g['real_image']], draws=[draws])
+    np.testing.assert_allclose(out[1][0], g['target'][0], atol=2e-5)
+    with pytest.raises(ValueError):
+        m.generate(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], draws)
+
+
 def test_random_shapes_vs_oracle(env):
     """ragged (non-cubic, odd) label maps with crop + sided labels against the oracle on fresh tapes"""
     from oracle import generator_ref as R
@@ -166,7 +184,7 @@ def test_philox_noise_matches_oracle(env):
     noise = philox_ref.normals(int(np.prod(shape)), 3, d.philox_key, d.philox_offset)
     clipped = np.clip(noise, 0, 300)
     # d_chan holds the normalised^gamma channel of the LAST processed step; recompute expectation instead:
-    mm = m.d_minmax.cpu().numpy().view(np.uint32).reshape(3, 2)
+    mm = m.d_minmax.cpu().numpy().view(np.uint32)[:6].reshape(3, 2)  # (+1 pair reserved for a real-image target)
     dec = lambda u: np.array([(~u if not (u & 0x80000000) else (u & 0x7fffffff))], dtype=np.uint32).view(np.float32)[0]
     for c in range(3):
         assert abs(dec(int(mm[c, 0])) - clipped[:, c].min()) < 1e-5

@@ -167,3 +167,18 @@ def test_whole_graph_hyperfine(name, maps, gen_labels):
     # registration-error path contains a float32 matrix inverse (third-party, unpinned): looser tolerance
     np.testing.assert_allclose(out['image'], g['image'][0], atol=2e-4)
     np.testing.assert_allclose(out['target'], g['target'][0], atol=5e-6)
+
+
+@pytest.mark.parametrize('name', ['graph_real_s131', 'graph_real_crop_s132'])
+def test_whole_graph_real_image_target(name, gen_labels):
+    """output_channel=None: the regression target is a real scan, deformed (linear) / cropped / flipped jointly with
+    the label map and min-max normalised (labels_to_image_model.py:109-113,126-160,248-255)"""
+    g = load_golden(name)
+    out = R.labels_to_image(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], tape_from_golden(g), gen_labels,
+                            len(gen_labels), output_shape=32, input_channels=[True], output_channel=None,
+                            real_image=g['real_image'][0, ..., 0], **C2_KW)
+    np.testing.assert_array_equal(out['seg'], g['seg'][0, ..., 0])
+    np.testing.assert_allclose(out['image'], g['image'][0], atol=5e-6)
+    # trilinear resampling of a [20, 200]-valued scan, then /(max-min): 1e-5 of the unit range
+    np.testing.assert_allclose(out['target'], g['target'][0], atol=1e-5)
+    assert out['target'].min() == 0.0 and abs(out['target'].max() - 1.0) < 1e-6

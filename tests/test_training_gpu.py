@@ -75,6 +75,35 @@ def test_brain_generator_generate_brain(tmp_path):
     assert set(np.unique(np.round(im2[..., 1], 6)).tolist()) != {1.0}  # channel 0 is down-sampled in z: sparse map
 
 
+def test_real_image_targets_images_dir(tmp_path):
+    """images_dir: BrainGenerator / training() with real scans as regression targets"""
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.nifti import write_nifti
+    from synthsr_amd.synthetic import GENERATION_LABELS, synthetic_label_map
+    from synthsr_amd.training import training
+    labels_dir = _write_labels(tmp_path, 2, (40, 36, 48))
+    d = tmp_path / 'images'
+    d.mkdir()
+    rng = np.random.RandomState(0)
+    lut = rng.uniform(30, 220, 64)
+    for i in range(2):  # a "scan" = intensity per label + noise, same grid as the label map
+        lab = synthetic_label_map((40, 36, 48), 10 + i)
+        write_nifti(str(d / ('brain%d.nii.gz' % i)), (lut[lab % 64] + rng.randn(*lab.shape)).astype(np.float32))
+    bg = BrainGenerator(labels_dir, None, None, 'uniform', GENERATION_LABELS, images_dir=str(d), output_channel=None,
+                        output_shape=32, output_div_by_n=8, build_reliability_maps=True)
+    image, target = bg.generate_brain()
+    assert image.shape == (32, 32, 32, 2) and target.shape == (32, 32, 32)
+    assert np.isfinite(target).all() and target.min() == 0.0 and abs(target.max() - 1.0) < 1e-5
+    assert len(np.unique(np.round(target, 3))) > 20  # a resampled scan, not a label map
+    np.save(tmp_path / 'gl.npy', GENERATION_LABELS)
+    net = training(labels_dir, str(tmp_path / 'models'), None, None, str(tmp_path / 'gl.npy'), images_dir=str(d),
+                   output_channel=None, output_shape=32, n_levels=3, unet_feat_count=24, nonlin_shape_factor=.125,
+                   bias_shape_factor=.125, steps_per_epoch=2, epochs=1, verbose=False)
+    assert net.iterations == 2
+    with pytest.raises(Exception, match='not both'):
+        training(labels_dir, str(tmp_path / 'm2'), None, None, str(tmp_path / 'gl.npy'), images_dir=str(d), output_channel=0)
+
+
 def test_bench_under_torchrun_with_forced_allreduce():
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
