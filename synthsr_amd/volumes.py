@@ -151,6 +151,40 @@ def resample_volume(volume, aff, new_vox_size, interpolation='linear', blur=True
     return out, aff2
 
 
+def resample_volume_like(vol_ref, aff_ref, vol_flo, aff_flo, interpolation='linear'):
+    """Reslice the floating volume onto the grid of the reference volume (ext/lab2im/edit_volumes.py:558-590, used by
+    scripts/predict_command_line_hyperfine.py:112): every reference voxel is mapped to floating voxel coordinates with
+    inv(aff_flo) @ aff_ref and sampled (tri)linearly or nearest; positions outside the floating grid give 0."""
+    if interpolation not in ('linear', 'nearest'):
+        raise ValueError("interpolation should be 'linear' or 'nearest', had %s" % interpolation)
+    vol_flo = np.asarray(vol_flo, dtype=np.float64)
+    T = np.linalg.inv(np.asarray(aff_flo, dtype=np.float64)) @ np.asarray(aff_ref, dtype=np.float64)
+    shape = tuple(np.shape(vol_ref)[:3])
+    g = np.stack([a.reshape(-1) for a in np.meshgrid(*[np.arange(n) for n in shape], indexing='ij')] +
+                 [np.ones(int(np.prod(shape)))])
+    pos = (T @ g)[:3]
+    n = np.array(vol_flo.shape).reshape(3, 1)
+    inside = np.all((pos >= 0) & (pos <= n - 1), axis=0)
+    pos = np.clip(pos, 0, n - 1)
+    i0 = np.minimum(np.floor(pos).astype(np.int64), np.maximum(n - 2, 0))
+    w = pos - i0
+    i1 = np.minimum(i0 + 1, n - 1)
+    if interpolation == 'nearest':
+        idx = np.where(w <= 0.5, i0, i1)
+        out = vol_flo[idx[0], idx[1], idx[2]]
+    else:
+        out = np.zeros(pos.shape[1])
+        for cz in (0, 1):
+            for cy in (0, 1):
+                for cx in (0, 1):
+                    wz = w[0] if cz else 1.0 - w[0]
+                    wy = w[1] if cy else 1.0 - w[1]
+                    wx = w[2] if cx else 1.0 - w[2]
+                    out += wz * wy * wx * vol_flo[(i1 if cz else i0)[0], (i1 if cy else i0)[1], (i1 if cx else i0)[2]]
+    out[~inside] = 0.0
+    return out.reshape(shape)
+
+
 def get_volume_info(path_volume, return_volume=False, aff_ref=None, max_channels=10):
     im, aff, header = load_volume(path_volume, im_only=False)
     im_shape = list(im.shape)

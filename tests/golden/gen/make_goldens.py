@@ -293,6 +293,13 @@ def golden_inference():
         out[name + '_vol'], out[name + '_aff'] = vol, aff
         out[name + '_res_vol'], out[name + '_res_aff'] = v2, a2
         out[name + '_ras_vol'], out[name + '_ras_aff'] = v3, a3
+    # resample_volume_like (predict_command_line_hyperfine.py:112): floating T2 resliced onto the (resampled, RAS) T1 grid
+    flo = rng.rand(11, 9, 13) * 60
+    # floating grid = the reference grid seen through a small rotation / anisotropic scaling / shift: partial overlap
+    rel = np.array([[1.4, 0.1, 0, -2.5], [-0.1, 1.6, 0.05, 1.5], [0, 0.05, 1.2, -1.0], [0, 0, 0, 1.]])
+    aff_flo = out['mixed_ras_aff'] @ rel
+    out['like_flo'], out['like_flo_aff'] = flo, aff_flo
+    out['like_out'] = l2i_ev.resample_volume_like(out['mixed_ras_vol'], out['mixed_ras_aff'], flo, aff_flo)
     np.savez_compressed(os.path.join(OUT, 'inference.npz'), **out)
     print('inference.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
 

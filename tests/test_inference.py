@@ -21,6 +21,16 @@ def test_resample_volume_matches_reference(case):
     np.testing.assert_allclose(a3, z[case + '_ras_aff'], rtol=0, atol=1e-12)
 
 
+def test_resample_volume_like_matches_reference():
+    from synthsr_amd import volumes as V
+    z = np.load(GOLD)
+    out = V.resample_volume_like(z['mixed_ras_vol'], z['mixed_ras_aff'], z['like_flo'], z['like_flo_aff'])
+    assert 0.2 < (z['like_out'] == 0).mean() < 0.8  # the golden covers inside and outside (fill value 0) of the grid
+    np.testing.assert_allclose(out, z['like_out'], rtol=0, atol=1e-10)
+    near = V.resample_volume_like(z['mixed_ras_vol'], z['mixed_ras_aff'], z['like_flo'], z['like_flo_aff'], 'nearest')
+    assert set(np.unique(near)) <= set(np.unique(z['like_flo'])) | {0.0}
+
+
 def test_resample_volume_nearest_and_errors():
     from synthsr_amd import volumes as V
     vol = np.arange(4 * 3 * 2, dtype=float).reshape(4, 3, 2)
@@ -109,3 +119,40 @@ def test_predict_end_to_end_vs_oracle(tmp_path, flip):
     scale = max(np.abs(255 * out.numpy()).max(), 1.0)
     assert np.abs(got - ref).max() / scale < 2e-4
     assert ref.std() > 0  # not a clipped-flat image
+
+
+@pytest.mark.gpu
+def test_predict_hyperfine_end_to_end_vs_oracle(tmp_path):
+    """two-input (T1, T2) variant, scripts/predict_command_line_hyperfine.py: residual prediction on the rescaled T1"""
+    import torch
+    from synthsr_amd import volumes as V
+    from synthsr_amd.predict import predict_hyperfine, prepare_hyperfine, postprocess_hyperfine
+    from synthsr_amd.training import save_checkpoint
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    rng = np.random.RandomState(5)
+    aff1 = np.array([[1.5, 0, 0, -20.], [0, 1.5, 0, -18.], [0, 0, 5.0, -30.], [0, 0, 0, 1.]])
+    aff2 = aff1 @ np.array([[1, 0.02, 0, 0.5], [-0.02, 1, 0, -0.4], [0, 0, 1, 0.3], [0, 0, 0, 1.]])
+    p1, p2 = str(tmp_path / 't1.nii.gz'), str(tmp_path / 't2.nii.gz')
+    V.save_volume(rng.rand(24, 22, 8) * 400 + 30, aff1, None, p1)
+    V.save_volume(rng.rand(24, 22, 8) * 900, aff2, None, p2)
+    net = unet(24, [32, 32, 32, 2], 5, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
+               final_pred_activation='linear', seed=2)
+    g = torch.Generator().manual_seed(1)
+    net.bn_moving.copy_((torch.rand(net.bn_moving.shape, generator=g) * 0.5 + 0.25).to(net.bn_moving.device))
+    ck = str(tmp_path / 'model_hf.npz')
+    save_checkpoint(ck, net)
+    pout = str(tmp_path / 'out.nii.gz')
+    predict_hyperfine(p1, p2, pout, path_model=ck, verbose=False)
+    got, aff_out, _ = V.load_volume(pout, im_only=False)
+    im1, a1, _ = V.load_volume(p1, im_only=False, dtype='float')
+    im2, a2, _ = V.load_volume(p2, im_only=False, dtype='float')
+    S, idx, shape, aff_mod, scaling, t1n = prepare_hyperfine(im1, a1, im2, a2)
+    assert S.shape[:3] == (64, 64, 64) and S.shape[3] == 2
+    P = {k: v.float() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        out = U.unet_forward(torch.from_numpy(S.astype(np.float32)), P, net.prefix, 5, 2, training=False, moving=P)[..., 0]
+    ref = postprocess_hyperfine(out.numpy(), idx, shape, scaling, t1n)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(aff_out, aff_mod, atol=1e-5)
+    assert np.abs(got - ref).max() / max(np.abs(ref).max(), 1.0) < 2e-4
