@@ -2111,6 +2111,199 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
   }
 }
 
+// ---- weight gradient with small box tiles for the deep levels (40^3: 4x4x8 voxels, 20^3: 4x4x4) ---------------------
+// conv3d_wgrad_lean_kernel's 2x4x16 tiles pad x = 40 / 20 to 48 / 32 (17 / 37 % of the k-steps wasted on zeros).  Same
+// GEMM (rows = (tap, ci) + the constant-1 dbias row, N = co, K = voxels), LDS layouts and unrolled k-steps; the tile is
+// TZ x TY x TX with TX a multiple of 4 so that the 4 voxels of a k-step share a (z, y) row, and the dy tile is staged
+// through generic per-thread slots (voxel-major) instead of the row-pattern of the 16-wide tile.
+template <int NT, int MS, int TZ, int TY, int TX>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_box_kernel(const float* __restrict__ in,
+                                                                  const float* __restrict__ dout, float* __restrict__ dw,
+                                                                  int D0, int D1, int D2, int Cin, int Cout, int tiles0,
+                                                                  int tiles1, int tiles2, WgExt ext) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CK = 24, C4 = CK / 4;
+  constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX, TV = TZ * TY * TX;
+  constexpr int VPX = HV + ((HV / 2) % 2 == 0 ? 2 : 0) + (HV % 2);  // even, half of it odd: conflict-free ds_read_b32
+  constexpr int VPD = TV + 2;
+  static_assert((VPX / 2) % 2 == 1 && (VPD / 2) % 2 == 1 && TX % 4 == 0, "LDS strides / k-step rows");
+  float* lx = lds;                   // [CK + 1][VPX]; row CK = ones (dbias row)
+  float* ld = lds + (CK + 1) * VPX;  // [NT*16][VPD]
+  for (int i = threadIdx.x; i < VPX; i += 256) lx[CK * VPX + i] = 1.f;
+  constexpr int MR = 27 * CK, MTILES = (MR + 15) / 16 + ((MR % 16) == 0 ? 1 : 0);
+  constexpr int MTP = (MTILES + MS - 1) / MS, MTW = (MTP + 3) / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int cc = (int)(blockIdx.y / MS);
+  const int mt0 = (int)(blockIdx.y % MS) * MTP;
+  const int co0 = blockIdx.z * NT * 16;
+  constexpr uint32_t OOB = 0x80000000u;
+
+  f32x4 acc[MTW][NT];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int a_base[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    int r = (mt0 + wave + 4 * m) * 16 + li;
+    const bool ones = r == MR;
+    if (r >= MR) r = MR - 1;
+    const int tap = ones ? 13 : r / CK, cil = r - (r / CK) * CK;
+    a_base[m] = (ones ? CK : cil) * VPX + ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3 + kq;
+  }
+  const int b_base = li * VPD + kq;
+
+  // ---- x halo: HZ planes of HY x HX voxels x 6 quads
+  constexpr int PL4 = HY * HX * C4, NJ = (PL4 + 255) / 256, NX = NJ * HZ;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  int xrel[NJ], xlds[NJ];
+  uint32_t xmask[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = tid + 256 * i;
+    const int hy = j / (HX * C4), r = j - hy * (HX * C4), hx = r / C4, c4 = r - hx * C4;
+    xrel[i] = ((hy * D2 + hx) * Cin + c4 * 4) * 4;
+    xlds[i] = (c4 * 4) * VPX + hy * HX + hx;
+    xmask[i] = j < PL4 ? ((1u << hy) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+  }
+  const int xplane = D1 * D2 * Cin * 4;
+  // ---- dy tile: TV voxels x QN quads, slot j = tid + 256 i -> (voxel = j / QN, quad = j % QN)
+  constexpr int QN = NT * 4, ND = (TV * QN + 255) / 256;
+  const __amdgpu_buffer_rsrc_t rdo =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dout), 0, (int)((int64_t)D0 * D1 * D2 * Cout * 4), 0x00020000);
+  int drel[ND], dlds[ND];
+  uint32_t dmask[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int j = tid + 256 * i;
+    const int vox = j / QN, c4 = j - vox * QN;
+    const int vx = vox % TX, vy = (vox / TX) % TY, vz = vox / (TX * TY);
+    drel[i] = (((vz * D1 + vy) * D2 + vx) * Cout + co0 + c4 * 4) * 4;
+    dlds[i] = (c4 * 4) * VPD + vox;
+    dmask[i] = (j < TV * QN && co0 + c4 * 4 < Cout) ? ((1u << vz) | (1u << (8 + vy)) | (1u << (16 + vx))) : 0xFFFFFFFFu;
+  }
+
+  const int ntiles = tiles0 * tiles1 * tiles2;
+  float4 sx[NX], sd[ND];
+  auto as_f4 = [](u32x4 v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); };
+  auto load_tile = [&](int t) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    const int z0 = t0 * TZ, y0 = t1 * TY, x0 = t2 * TX;
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int yx = (((y0 - 1) * D2 + (x0 - 1)) * Cin + cc * CK) * 4;
+    uint32_t xo[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) xo[i] = (xmask[i] & bad) ? OOB : (uint32_t)(xrel[i] + yx);
+#pragma unroll
+    for (int hz = 0; hz < HZ; ++hz) {
+      const int gz = z0 - 1 + hz;
+      const bool pv = (unsigned)gz < (unsigned)D0;
+      const int so = pv ? gz * xplane : 0;
+#pragma unroll
+      for (int i = 0; i < NJ; ++i)
+        sx[hz * NJ + i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? xo[i] : OOB), so, 0));
+    }
+    uint32_t dbad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < TZ; ++h) dbad |= (z0 + h >= D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < TY; ++h) dbad |= (y0 + h >= D1) ? (1u << (8 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < TX; ++h) dbad |= (x0 + h >= D2) ? (1u << (16 + h)) : 0u;
+    const int dbase = (((z0 * D1 + y0) * D2 + x0) * Cout) * 4;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      sd[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rdo, (int)((dmask[i] & dbad) ? OOB : (uint32_t)drel[i]), dbase, 0));
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      if (i < NJ - 1 || tid + 256 * i < PL4) {
+#pragma unroll
+        for (int hz = 0; hz < HZ; ++hz) {
+          float* d = lx + xlds[i] + hz * (HY * HX);
+          const float4 v = sx[hz * NJ + i];
+          d[0] = v.x;
+          d[VPX] = v.y;
+          d[2 * VPX] = v.z;
+          d[3 * VPX] = v.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      if (i < ND - 1 || tid + 256 * i < TV * QN) {
+        float* d = ld + dlds[i];
+        const float4 v = sd[i];
+        d[0] = v.x;
+        d[VPD] = v.y;
+        d[2 * VPD] = v.z;
+        d[3 * VPD] = v.w;
+      }
+    }
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);
+    float aa[2][MTW], bb[2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bb[0][n] = ld[b_base + n * 16 * VPD];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) aa[0][m] = lx[a_base[m]];
+#pragma unroll
+    for (int ks = 0; ks < TV / 4; ++ks) {
+      constexpr int LAST = TV / 4 - 1;
+      const int kn = ks < LAST ? ks + 1 : LAST;
+      const int k0 = kn * 4;  // first voxel of the next k-step: (z, y) row and x offset
+      const int voff = ((k0 / (TX * TY)) * HY + (k0 / TX) % TY) * HX + k0 % TX;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bb[(ks + 1) & 1][n] = ld[b_base + n * 16 * VPD + kn * 4];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) aa[(ks + 1) & 1][m] = lx[a_base[m] + voff];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[ks & 1][m], bb[ks & 1][n], acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (ext.dbg & 8) return;
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (wave + 4 * m >= MTP) continue;
+      const int row = (mt0 + wave + 4 * m) * 16 + kq * 4 + r;
+      if (row == MR && ext.dbias && cc == 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int co = co0 + n * 16 + li;
+          if (co < Cout) atomicAdd(&ext.dbias[co], acc[m][n][r]);
+        }
+      }
+      if (row >= MR) continue;
+      const int tap = row / CK, cil = row - tap * CK;
+      const int ci = cc * CK + cil;
+      if (ci >= Cin) continue;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int co = co0 + n * 16 + li;
+        if (co < Cout) atomicAdd(&dw[((size_t)tap * ext.cin_total + ext.ci_off + ci) * Cout + co], acc[m][n][r]);
+      }
+    }
+  }
+}
+
 // ---- first-layer weight gradient (Cin <= 2, Cout = 24) on the 4x4x1 MFMA -------------------------------------------
 // dW[(tap,ci), co] = sum_v x[v+tap, ci] dz[v, co]: 27*Cin <= 54 GEMM rows.  A (broadcast via ABID) = dz: 8 consecutive
 // voxels x 24 channels are 192 contiguous floats = exactly three coalesced registers (register r, lane l <-> float
@@ -2636,6 +2829,30 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
   if constexpr (CK == 24) {
     const int dsc = (NTAPS == 8) ? 8 : 1;
     const int64_t xbytes = (int64_t)s[0] * s[1] * s[2] * Cin * 4, dbytes = (int64_t)s[0] * s[1] * s[2] * dsc * Cout * 4;
+    if constexpr (NTAPS == 27) {
+      // small deep levels: box tiles that divide the volume exactly (4x4x8 for x = 40, 4x4x4 for x = 20)
+      const bool div4 = (s[0] % 4) == 0 && (s[1] % 4) == 0 && (s[2] % 4) == 0 && (s[2] % 16) != 0;
+      if (g_brick && div4 && (Cout % 4) == 0 && xbytes < (1ll << 31) && dbytes < (1ll << 31) && !(g_dbg & 16)) {
+        const bool x8 = (s[2] % 8) == 0;
+        const int tx = x8 ? 8 : 4;
+        const int bt0 = s[0] / 4, bt1 = s[1] / 4, bt2 = s[2] / tx;
+        const int bnt = bt0 * bt1 * bt2;
+        int bgx = 512 / (ncc * nco * ymul);
+        if (bgx < 1) bgx = 1;
+        if (bgx > bnt) bgx = bnt;
+        const int hv = 6 * 6 * (tx + 2), tv = 16 * tx;
+        const int vpx = hv + ((hv / 2) % 2 == 0 ? 2 : 0) + (hv % 2);
+        const size_t bsmem = ((size_t)(CK + 1) * vpx + (size_t)NT * 16 * (tv + 2)) * sizeof(float);
+        if (x8) {
+          hipLaunchKernelGGL((conv3d_wgrad_box_kernel<NT, MS, 4, 4, 8>), dim3(bgx, ncc * ymul, nco), dim3(256), bsmem, st, in,
+                             dout, dw, s[0], s[1], s[2], Cin, Cout, bt0, bt1, bt2, ext);
+        } else {
+          hipLaunchKernelGGL((conv3d_wgrad_box_kernel<NT, MS, 4, 4, 4>), dim3(bgx, ncc * ymul, nco), dim3(256), bsmem, st, in,
+                             dout, dw, s[0], s[1], s[2], Cin, Cout, bt0, bt1, bt2, ext);
+        }
+        return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+      }
+    }
     if ((Cout % 4) == 0 && xbytes < (1ll << 31) && dbytes < (1ll << 31) && !(g_dbg & 16)) {
       static bool lean_attr_done = false;
       auto lkern = conv3d_wgrad_lean_kernel<NT, MS, NTAPS>;
