@@ -2466,6 +2466,180 @@ __global__ void rows_reduce_kernel(const float* __restrict__ partial, int nwg, f
   }
 }
 
+// ---- weight gradient of the forward parity convs (folded decoder conv, Cout = 24) on the 4x4x1 MFMA ----------------
+// conv3d_wgrad_p4_kernel for one output parity: the 2x2x2 window x 6 channel quads is exactly 48 blocks = 3 B registers
+// (no idle block slots), so here the 4 waves split the VOXELS (one z-plane of the low-res tile each) and every wave
+// keeps the full 192 x 24 partial.  dz is read on the parity sub-lattice of the hi-res tensor (voxel stride 2), which
+// only changes the per-lane offsets of the three coalesced A registers.  grid = (gx, 8 parities x chunks).
+__global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float* __restrict__ in,
+                                                                    const float* __restrict__ dout,
+                                                                    float* __restrict__ dwc, int D0, int D1, int D2,
+                                                                    int Cin, int tiles1, int tiles2, int ntiles,
+                                                                    int64_t dwstride, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CK = 24, MT = 4, Cout = 24;
+  constexpr int FT1 = MT, FH1 = MT + 2, CKP = CK + 4, C4 = CK / 4, NQ = 3;
+  constexpr uint32_t OOB = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int par = blockIdx.y & 7, cc = blockIdx.y >> 3;
+  const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+  const int G = gridDim.x;
+  const int my_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+
+  // B rows of this lane: block = 16 q + (lane >> 2) = window tap * 6 + quad
+  int rowoff[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int blk = 16 * q + (lane >> 2);
+    const int ti = blk / 6, quad = blk - ti * 6;
+    const int tz = pz + ((ti >> 2) & 1), ty = py + ((ti >> 1) & 1), tx = px + (ti & 1);
+    rowoff[q] = ((tz * FH1 + ty) * FH2 + tx) * CKP + quad * 4 + (lane & 3) + wave * (FH1 * FH2 * CKP);  // + own z-plane
+  }
+  constexpr int PLANE4 = FH1 * FH2 * C4, NJ = (PLANE4 + 255) / 256, NLD = NJ * FH0;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dout), 0, (int)((int64_t)D0 * D1 * D2 * 8 * Cout * 4), 0x00020000);
+  int rel[NJ], ldsa[NJ];
+  uint32_t cmask[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = tid + 256 * i;
+    const int hy = j / (FH2 * C4), r = j - hy * (FH2 * C4), hx = r / C4, c4 = r - hx * C4;
+    rel[i] = ((hy * D2 + hx) * Cin + c4 * 4) * 4;
+    ldsa[i] = ((hy * FH2 + hx) * CKP + c4 * 4);
+    cmask[i] = j < PLANE4 ? ((1u << hy) | (1u << (8 + hx))) : 0xFFFFFFFFu;
+  }
+  const int plane_bytes = D1 * D2 * Cin * 4;
+  int kk[3], aoff[3];  // dz register r, lane l <-> float 64 r + l = 24 k + c of an octet; voxel stride 2 in the hi-res row
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int f = 64 * r + lane;
+    kk[r] = f / 24;
+    aoff[r] = (kk[r] * 2 * Cout + (f - kk[r] * 24)) * 4;
+  }
+  float4 stg[NLD];
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
+    const int t2 = t % tiles2, t1 = (t / tiles2) % tiles1, t0 = t / (tiles2 * tiles1);
+    z0 = t0 * FT0;
+    y0 = t1 * FT1;
+    x0 = t2 * FT2;
+  };
+  auto load_halo = [&](int t) {
+    int z0, y0, x0;
+    tile_origin(t, z0, y0, x0);
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < FH1; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < FH2; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (8 + h)) : 0u;
+    const int yx = (((y0 - 1) * D2 + (x0 - 1)) * Cin + cc * CK) * 4;
+    uint32_t voff[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) voff[i] = (cmask[i] & bad) ? OOB : (uint32_t)(rel[i] + yx);
+#pragma unroll
+    for (int hz = 0; hz < FH0; ++hz) {
+      const int gz = z0 - 1 + hz;
+      const bool pv = (unsigned)gz < (unsigned)D0;
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(pv ? voff[i] : OOB), pv ? gz * plane_bytes : 0, 0);
+        stg[hz * NJ + i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+    }
+  };
+  // dz of this wave's z-plane of tile (z0, y0, x0): 8 octets (row y = o >> 1, x half o & 1) x 3 registers
+  auto load_dz = [&](int z0, int y0, int x0, float (&a)[8][3]) {
+    const int gz = z0 + wave;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int gy = y0 + (o >> 1), xs = x0 + 8 * (o & 1);
+      const bool ok = gz < D0 && gy < D1;  // scalar
+      const int so = ok ? ((((2 * gz + pz) * (2 * D1) + (2 * gy + py)) * (2 * D2) + (2 * xs + px)) * Cout) * 4 : 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int vo = (ok && xs + kk[r] < D2) ? aoff[r] : (int)OOB;
+        a[o][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdo, vo, so, 0));
+      }
+    }
+  };
+
+  f32x4 acc[NQ][6];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int g = 0; g < 6; ++g) acc[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float an[8][3];
+  int z0 = 0, y0 = 0, x0 = 0;
+  if (my_pos < ntiles) {
+    load_halo(my_pos);
+    tile_origin(my_pos, z0, y0, x0);
+    load_dz(z0, y0, x0, an);
+  }
+  for (int t = my_pos; t < ntiles; t += G) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      if (i < NJ - 1 || tid + 256 * i < PLANE4) {
+#pragma unroll
+        for (int hz = 0; hz < FH0; ++hz)
+          *reinterpret_cast<float4*>(&lds[ldsa[i] + hz * (FH1 * FH2 * CKP)]) = stg[hz * NJ + i];
+      }
+    }
+    __syncthreads();
+    float ar[8][3];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) ar[o][r] = an[o][r];
+    const bool has_next = t + G < ntiles;
+    if (has_next) {
+      load_halo(t + G);
+      tile_origin(t + G, z0, y0, x0);
+      load_dz(z0, y0, x0, an);
+    }
+    float xq[2][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) xq[0][q] = lds[rowoff[q]];
+    sfor<0, 64>([&](auto S) {
+      constexpr int sv = decltype(S)::value, o = sv / 8, k = sv % 8;
+      constexpr int sn = sv + 1 < 64 ? sv + 1 : sv, on = sn / 8, kn = sn % 8;
+      constexpr int nbase = ((on >> 1) * FH2 + 8 * (on & 1) + kn) * CKP;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) xq[(sv + 1) & 1][q] = lds[rowoff[q] + nbase];
+      __builtin_amdgcn_sched_barrier(0);
+      sfor<0, 6>([&](auto GI) {
+        constexpr int g = decltype(GI)::value, GG = k * 6 + g;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          acc[q][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[o][GG / 16], xq[sv & 1][q], acc[q][g], 4, GG % 16, 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  if (dbg & 8) return;
+  // ---- combine the 4 waves (LDS float atomics into one [8 taps][24 ci][24 co] partial), then a linear atomic flush
+  __syncthreads();
+  for (int e = tid; e < 8 * CK * Cout; e += 256) lds[e] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int blk = 16 * q + (lane >> 2);
+    float* d = lds + (blk * 4 + (lane & 3)) * Cout;  // row = ti*24 + quad*4 + j
+#pragma unroll
+    for (int g = 0; g < 6; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(d + 4 * g + i, acc[q][g][i]);
+  }
+  __syncthreads();
+  float* dst = dwc + (size_t)par * dwstride;
+  for (int e = tid; e < 8 * CK * Cout; e += 256) {
+    const int ti = e / (CK * Cout), r = e - ti * (CK * Cout);
+    const int tap = ((pz + ((ti >> 2) & 1)) * 3 + (py + ((ti >> 1) & 1))) * 3 + (px + (ti & 1));
+    atomicAdd(dst + ((size_t)tap * Cin + cc * CK) * Cout + r, lds[e]);
+  }
+}
+
 // dbias fallback for the generic weight-gradient kernel: per-channel sum of dout [n][C]
 __global__ void colsum_kernel(const float* __restrict__ x, int64_t n, int C, float* __restrict__ out) {
   const int64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -3114,6 +3288,26 @@ int launch_wgrad_c2(const float* in, const float* dout, float* dw, float* dbias,
 template <int NTAPS>
 int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout, hipStream_t st,
                    const WgExt& ext) {
+  if constexpr (NTAPS == 8) {
+    const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
+    const int tiles0 = cdiv(shape[0], FT0), tiles1 = cdiv(shape[1], 4), tiles2 = cdiv(shape[2], FT2);
+    const int ntiles = tiles0 * tiles1 * tiles2, ncc = Cin / 24;
+    if (Cout == 24 && (Cin % 24) == 0 && g_p4 && ntiles >= 768 && vox * Cin * 4 < (1ll << 31) &&
+        vox * 8 * Cout * 4 < (1ll << 31) && !(g_dbg & 16)) {
+      const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_up_wgrad_p4_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+      }
+      int gx = std::max(8, ((512 / (ncc * 8)) / 8) * 8);
+      while (gx > 8 && gx > ntiles) gx -= 8;
+      hipLaunchKernelGGL(conv3d_up_wgrad_p4_kernel, dim3(gx, ncc * 8), dim3(256), smem, st, in, dout, dw, shape[0], shape[1],
+                         shape[2], Cin, tiles1, tiles2, ntiles, ext.dwstride, ext.dbg);
+      return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+    }
+  }
   if constexpr (NTAPS == 27) {
     if (Cin <= 2 && Cout == 24 && g_p4 && (int64_t)shape[0] * shape[1] * shape[2] * Cout * 4 < (1ll << 31))
       return launch_wgrad_c2(in, dout, dw, ext.dbias, shape, Cin, st, ext);
