@@ -165,7 +165,9 @@ def main():
     ops.profile_start()
     t0 = time.perf_counter()
     loss = None
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == min(3, args.steps):  # per-launch HIP events on the first 3 timed steps only (0.5 ms of host/event overhead each)
+            ops.profile_pause()
         loss = one_step()
     if world > 1:
         dist.barrier()
@@ -204,7 +206,7 @@ def main():
                     'flops_per_launch': flops_launch, 'avg_launch_ms': round(dom['avg_ms'], 4),
                     'all_conv_tflops': round(sum(conv_flops(r['kernel'], r['shape'], r['cin'], r['cout']) * r['launches']
                                                  for r in rows) / (conv_total * 1e-3) / 1e12, 2),
-                    'conv_ms_per_step': round(conv_total / args.steps, 3)}
+                    'conv_ms_per_step': round(conv_total / min(3, args.steps), 3), 'profiled_steps': min(3, args.steps)}
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes (bench.py cannot host the
         # profiler), committed under profiles/pmc_traffic.json; algorithmic bytes = the tensors one launch must touch
         try:
