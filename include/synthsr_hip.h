@@ -260,6 +260,20 @@ int synthsr_head_bwd_ex(const float* dpred, const float* x, int64_t nvox, int C,
                         const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw,
                         float* db, float* bn_sums, synthsr_stream_t stream);
 
+/* --- segmentation-regularised loss (SynthSR/metrics_model.py:136-215) -------------------------------------------------
+ * head of the frozen segmentation U-Net: probs[v][n] = softmax_n(sum_c w[c][n]*bn(x[v][c]) + b[n]); C, N <= 64 */
+int synthsr_seg_head_fwd(const float* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta,
+                         float eps, const float* w, const float* b, int N, float* probs, synthsr_stream_t stream);
+/* soft-Dice sums (ext/lab2im/layers.py:1343-1362, enable_checks=False): class k merges the segmentation labels
+ * cls_idx[k][0..2] (-1 = unused) and is compared with (seg == cls_gt[k]); sums[k] += 2 gt pred, sums[K+k] += gt^2 + pred^2
+ * (sums zeroed by the caller); loss = mean_k(1 - (sums[k] + 1e-7)/(sums[K+k] + 1e-7)) */
+int synthsr_seg_dice_sums(const float* probs, const int32_t* seg, int64_t nvox, int N, const int32_t* cls_idx,
+                          const int32_t* cls_gt, int K, float* sums, synthsr_stream_t stream);
+/* gradient of scale*loss w.r.t. the BatchNorm output in front of the head: dbn[v][c] (through label merging, softmax, 1x1x1) */
+int synthsr_seg_dice_bwd(const float* probs, const int32_t* seg, int64_t nvox, int C, int N, const float* w,
+                         const int32_t* cls_idx, const int32_t* cls_gt, int K, const float* sums, float scale, float* dbn,
+                         synthsr_stream_t stream);
+
 /* keras.optimizers.Adam (Keras 2.3.1; SynthSR/training.py:444): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
  * p -= lr_t*m/(sqrt(v)+eps).  lr already includes the 1/(1+decay*iter) factor. */
 int synthsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,

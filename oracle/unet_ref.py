@@ -47,7 +47,7 @@ def upsample2(x):
     return x.repeat_interleave(2, 0).repeat_interleave(2, 1).repeat_interleave(2, 2)
 
 
-def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, collect=None):
+def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, collect=None, softmax=False):
     """P: dict name -> tensor with the Keras layer names (`<prefix>_conv_downarm_l_k/kernel`, ...).
     Returns prediction [d0,d1,d2,1].  `collect` (dict) receives batch statistics per BN layer."""
     L = nb_levels
@@ -79,7 +79,46 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
             cur = F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias']))
         cur = bn(cur, '%s_bn_up_%d' % (prefix, k))
     w, b = P['%s_likelihood/kernel' % prefix], P['%s_likelihood/bias' % prefix]
-    return cur @ w + b
+    out = cur @ w.reshape(w.shape[-2], w.shape[-1]) + b
+    return torch.softmax(out, -1) if softmax else out  # final_pred_activation (models.py:487-494)
+
+
+def dice_loss(gt, pred, eps=1e-7):
+    """ext/lab2im/layers.py DiceLoss.call (:1334-1378) with enable_checks=False, no class / boundary weights:
+    gt, pred [..., K] -> mean_k (1 - (2 sum gt pred + eps) / (sum gt^2 + pred^2 + eps))"""
+    ax = tuple(range(gt.dim() - 1))
+    top = (2 * gt * pred).sum(ax)
+    bottom = (gt * gt + pred * pred).sum(ax)
+    return (1 - (top + eps) / (bottom + eps)).mean()
+
+
+def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, generation_labels, label_equivalency,
+                       m=None, M=None, fs_header=False):
+    """SynthSR/metrics_model.py:136-215 (add_seg_loss_to_model) for one volume: the predicted image [d0,d1,d2] is
+    normalised (:152-155), optionally permuted / flipped to the FreeSurfer orientation (:158-163), pushed through the
+    FROZEN segmentation U-Net (softmax head, inference-mode BatchNorm -- third-party Keras semantics, unpinned) and
+    compared with the generator's label map by the soft Dice over the generation labels that have an equivalent
+    (:187-207).  NB the reference builds the ground-truth one-hot as `segmentation_target == i` with i the INDEX of the
+    generation label (:191), not its value; mirrored here.  Returns the Dice loss (scalar tensor)."""
+    x = pred_image
+    if m is not None:
+        x = (torch.clamp(x, m, M) - m) / (M - m)
+    x = x[..., None]
+    if fs_header:
+        x = torch.flip(x.permute(0, 2, 1, 3), dims=[1])
+    probs = unet_forward(x, Pseg, prefix, nb_levels, nconv, training=False, moving=Pseg, softmax=True)
+    if fs_header:
+        probs = torch.flip(probs, dims=[1]).permute(0, 2, 1, 3)
+    gts, preds = [], []
+    eq = torch.as_tensor(label_equivalency)
+    for i, lab in enumerate(generation_labels):
+        idx = torch.nonzero(eq == int(lab)).reshape(-1)
+        if len(idx) > 0:
+            if len(idx) > 3:
+                raise Exception("uuummm weird that you're merging so many labels...")
+            gts.append((seg_target == i).float())
+            preds.append(sum(probs[..., int(j)] for j in idx))
+    return dice_loss(torch.stack(gts, -1), torch.stack(preds, -1))
 
 
 def l1_loss(pred, target):

@@ -72,6 +72,9 @@ SIGNATURES = {
                                     _P, _S]),
     'synthsr_bn_elu_bwd_head': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
     'synthsr_head_bwd_ex': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _S]),
+    'synthsr_seg_head_fwd': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, c_int, _P, _S]),
+    'synthsr_seg_dice_sums': (c_int, [_P, _P, c_int64, c_int, _P, _P, c_int, _P, _S]),
+    'synthsr_seg_dice_bwd': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, c_int, _P, c_float, _P, _S]),
     'synthsr_head_bwd': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
     'synthsr_adam_step': (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _S]),
 }

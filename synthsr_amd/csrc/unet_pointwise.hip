@@ -527,6 +527,131 @@ __global__ __launch_bounds__(RB) void head_bwd_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) atomicAdd(db, B);
 }
 
+// ------------------------------------------------------------------ segmentation-regularised loss (metrics_model.py:136-215)
+// Frozen segmentation U-Net head: probs[v][n] = softmax_n( sum_c W[c][n] * bn(x[v][c]) + b[n] )  (unet_likelihood, 1x1x1 conv +
+// softmax, models.py:480-494).  One thread per voxel, weights in LDS.  C <= 64, N <= 64.
+constexpr int SEG_MAXC = 64, SEG_MAXN = 64, SEG_MAXK = 64;
+
+__global__ __launch_bounds__(256) void seg_head_fwd_kernel(const float* __restrict__ x, int64_t nvox, int C,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           const float* __restrict__ W, const float* __restrict__ b, int N,
+                                                           float* __restrict__ probs) {
+  __shared__ float sw[SEG_MAXC * SEG_MAXN], ssc[SEG_MAXC], ssh[SEG_MAXC], sb[SEG_MAXN];
+  for (int i = threadIdx.x; i < C * N; i += blockDim.x) sw[i] = W[i];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) bn_coeff(stats, gamma, beta, eps, C, i, ssc[i], ssh[i]);
+  for (int i = threadIdx.x; i < N; i += blockDim.x) sb[i] = b[i];
+  __syncthreads();
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
+    float* pr = probs + v * N;
+    float mx = -INFINITY;
+    for (int n = 0; n < N; ++n) {  // logits parked in the output row (L1/L2 resident), then normalised in place
+      float acc = sb[n];
+      for (int c = 0; c < C; ++c) acc = fmaf(fmaf(x[v * C + c], ssc[c], ssh[c]), sw[c * N + n], acc);
+      pr[n] = acc;
+      mx = fmaxf(mx, acc);
+    }
+    float den = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float e = expf(pr[n] - mx);
+      pr[n] = e;
+      den += e;
+    }
+    const float inv = 1.f / den;
+    for (int n = 0; n < N; ++n) pr[n] *= inv;
+  }
+}
+
+// Soft-Dice sums over the K generation labels that have an equivalent among the segmentation labels:
+//   pred_k[v] = sum_j probs[v][cls_idx[k][j]] (up to 3 merged labels, -1 = unused),  gt_k[v] = (seg[v] == cls_gt[k])
+//   sums[k] += 2 gt pred,  sums[K + k] += gt^2 + pred^2                                   (DiceLoss, layers.py:1343-1362)
+__global__ __launch_bounds__(256) void seg_dice_sums_kernel(const float* __restrict__ probs, const int32_t* __restrict__ seg,
+                                                            int64_t nvox, int N, const int32_t* __restrict__ cls_idx,
+                                                            const int32_t* __restrict__ cls_gt, int K,
+                                                            float* __restrict__ sums) {
+  __shared__ float st[2 * SEG_MAXK];
+  for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) st[i] = 0.f;
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    const int i0 = cls_idx[3 * k], i1 = cls_idx[3 * k + 1], i2 = cls_idx[3 * k + 2], g = cls_gt[k];
+    float top = 0.f, bot = 0.f;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
+      const float* pr = probs + v * N;
+      float p = pr[i0];
+      if (i1 >= 0) p += pr[i1];
+      if (i2 >= 0) p += pr[i2];
+      const float gt = seg[v] == g ? 1.f : 0.f;
+      top += 2.f * gt * p;
+      bot += gt + p * p;
+    }
+    top = syn_wave_sum(top);
+    bot = syn_wave_sum(bot);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&st[k], top);
+      atomicAdd(&st[K + k], bot);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) atomicAdd(&sums[i], st[i]);
+}
+
+// Backward of  scale * mean_k(1 - (T_k + e)/(B_k + e))  through the label merging, the softmax and the 1x1x1 head:
+//   dpred_k = -scale/K * (2 gt_k (B_k+e) - 2 pred_k (T_k+e)) / (B_k+e)^2
+//   dlogit_n = p_n (dprob_n - S),  dprob_n = dpred_{class(n)} (0 for labels without class),  S = sum_k dpred_k pred_k
+//   dbn[v][c] = sum_n W[c][n] dlogit_n  = sum_k dpred_k sum_j W[c][idx_kj] p_idx_kj  -  S sum_n W[c][n] p_n
+__global__ __launch_bounds__(256) void seg_dice_bwd_kernel(const float* __restrict__ probs, const int32_t* __restrict__ seg,
+                                                           int64_t nvox, int C, int N, const float* __restrict__ W,
+                                                           const int32_t* __restrict__ cls_idx,
+                                                           const int32_t* __restrict__ cls_gt, int K,
+                                                           const float* __restrict__ sums, float scale,
+                                                           float* __restrict__ dbn) {
+  __shared__ float sw[SEG_MAXC * SEG_MAXN], sT[SEG_MAXK], sB[SEG_MAXK];
+  __shared__ int sidx[3 * SEG_MAXK], sgt[SEG_MAXK];
+  for (int i = threadIdx.x; i < C * N; i += blockDim.x) sw[i] = W[i];
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
+    sT[i] = sums[i] + 1e-7f;
+    sB[i] = sums[K + i] + 1e-7f;
+    sgt[i] = cls_gt[i];
+  }
+  for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) sidx[i] = cls_idx[i];
+  __syncthreads();
+  const float coef = -scale / (float)K;
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
+    const float* pr = probs + v * N;
+    float out[SEG_MAXC];
+#pragma unroll
+    for (int c = 0; c < SEG_MAXC; ++c) out[c] = 0.f;
+    float S = 0.f;
+    const int lab = seg[v];
+    for (int k = 0; k < K; ++k) {
+      const int i0 = sidx[3 * k], i1 = sidx[3 * k + 1], i2 = sidx[3 * k + 2];
+      const float p0 = pr[i0], p1 = i1 >= 0 ? pr[i1] : 0.f, p2 = i2 >= 0 ? pr[i2] : 0.f;
+      const float pk = p0 + p1 + p2;
+      const float gt = lab == sgt[k] ? 1.f : 0.f;
+      const float dp = coef * (2.f * gt * sB[k] - 2.f * pk * sT[k]) / (sB[k] * sB[k]);
+      S += dp * pk;
+#pragma unroll
+      for (int c = 0; c < SEG_MAXC; ++c)
+        if (c < C) {
+          float a = sw[c * N + i0] * p0;
+          if (i1 >= 0) a += sw[c * N + i1] * p1;
+          if (i2 >= 0) a += sw[c * N + i2] * p2;
+          out[c] += dp * a;
+        }
+    }
+    for (int n = 0; n < N; ++n) {
+      const float sp = S * pr[n];
+#pragma unroll
+      for (int c = 0; c < SEG_MAXC; ++c)
+        if (c < C) out[c] -= sw[c * N + n] * sp;
+    }
+#pragma unroll
+    for (int c = 0; c < SEG_MAXC; ++c)
+      if (c < C) dbn[v * C + c] = out[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------ Adam (Keras 2.3.1)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_t,
@@ -720,6 +845,38 @@ int synthsr_head_bwd(const float* dpred, const float* x, int64_t nvox, int C, co
   const int64_t n4 = nvox * (C / 4);
   hipLaunchKernelGGL(head_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
                      (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db, (float*)nullptr);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_seg_head_fwd(const float* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta,
+                         float eps, const float* w, const float* b, int N, float* probs, synthsr_stream_t stream) {
+  if (!x || !stats || !gamma || !beta || !w || !b || !probs || nvox < 1 || C < 1 || C > SEG_MAXC || N < 1 || N > SEG_MAXN)
+    return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(seg_head_fwd_kernel, dim3(syn_grid(nvox, 256)), dim3(256), 0, (hipStream_t)stream, x, nvox, C, stats,
+                     gamma, beta, eps, w, b, N, probs);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_seg_dice_sums(const float* probs, const int32_t* seg, int64_t nvox, int N, const int32_t* cls_idx,
+                          const int32_t* cls_gt, int K, float* sums, synthsr_stream_t stream) {
+  if (!probs || !seg || !cls_idx || !cls_gt || !sums || nvox < 1 || N < 1 || N > SEG_MAXN || K < 1 || K > SEG_MAXK)
+    return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(seg_dice_sums_kernel, dim3(syn_grid(nvox, 256, 1024)), dim3(256), 0, (hipStream_t)stream, probs, seg,
+                     nvox, N, cls_idx, cls_gt, K, sums);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_seg_dice_bwd(const float* probs, const int32_t* seg, int64_t nvox, int C, int N, const float* w,
+                         const int32_t* cls_idx, const int32_t* cls_gt, int K, const float* sums, float scale, float* dbn,
+                         synthsr_stream_t stream) {
+  if (!probs || !seg || !w || !cls_idx || !cls_gt || !sums || !dbn || nvox < 1 || C < 1 || C > SEG_MAXC || N < 1 ||
+      N > SEG_MAXN || K < 1 || K > SEG_MAXK)
+    return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(seg_dice_bwd_kernel, dim3(syn_grid(nvox, 256)), dim3(256), 0, (hipStream_t)stream, probs, seg, nvox, C,
+                     N, w, cls_idx, cls_gt, K, sums, scale, dbn);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

@@ -322,6 +322,36 @@ def bn_elu_bwd_head(dpred, whead, y, stats, gamma, sums, dbias=None, out=None, e
     return out
 
 
+def seg_head_fwd(x, stats, gamma, beta, w, b, probs, eps=BN_EPS):
+    """probs [nvox, N] = softmax(bn(x) @ w + b): head of the frozen segmentation U-Net"""
+    lib = _L()
+    C = int(x.shape[-1])
+    _lib.check(lib.synthsr_seg_head_fwd(_lib.ptr(x), x.numel() // C, C, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta),
+                                        eps, _lib.ptr(w), _lib.ptr(b), int(probs.shape[-1]), _lib.ptr(probs),
+                                        _lib.stream()), 'seg_head_fwd')
+    return probs
+
+
+def seg_dice_sums(probs, seg, cls_idx, cls_gt, sums):
+    """sums [2K] (zeroed here) <- soft-Dice numerators / denominators of the K merged classes"""
+    lib = _L()
+    sums.zero_()
+    _lib.check(lib.synthsr_seg_dice_sums(_lib.ptr(probs), _lib.ptr(seg), int(probs.shape[0]), int(probs.shape[1]),
+                                         _lib.ptr(cls_idx), _lib.ptr(cls_gt), int(cls_gt.numel()), _lib.ptr(sums),
+                                         _lib.stream()), 'seg_dice_sums')
+    return sums
+
+
+def seg_dice_bwd(probs, seg, w, cls_idx, cls_gt, sums, scale, dbn):
+    """dbn [nvox, C] = d(scale * dice_loss)/d(BatchNorm output in front of the segmentation head)"""
+    lib = _L()
+    _lib.check(lib.synthsr_seg_dice_bwd(_lib.ptr(probs), _lib.ptr(seg), int(probs.shape[0]), int(dbn.shape[-1]),
+                                        int(probs.shape[1]), _lib.ptr(w), _lib.ptr(cls_idx), _lib.ptr(cls_gt),
+                                        int(cls_gt.numel()), _lib.ptr(sums), float(scale), _lib.ptr(dbn), _lib.stream()),
+               'seg_dice_bwd')
+    return dbn
+
+
 def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
     lib = _L()
     _lib.check(lib.synthsr_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), float(lr_t),

@@ -1,0 +1,83 @@
+"""Segmentation-regularised loss, SynthSR/metrics_model.py:136-215 (`add_seg_loss_to_model`) + training.py:371-409:
+the predicted image is pushed through a FROZEN segmentation U-Net and the soft Dice between its (label-merged)
+posteriors and the generator's label map is added to the image loss with weight `rel_weight`
+(total = image_loss + rel_weight * dice, metrics_model.py:209).
+
+Everything runs on the device: U-Net forward / data-gradient backward through the HIP conv kernels
+(`UNet3D.predict_probs` / `backward_input`: inference-mode BatchNorm, no weight gradients), head softmax, Dice sums and
+their backward in `csrc/unet_pointwise.hip`.  The reference's quirk is kept: the ground-truth one-hot of generation
+label number i is `segmentation_target == i` (the INDEX, metrics_model.py:191), not `== generation_labels[i]`.
+Keras semantics of the frozen network's BatchNorm (inference statistics) are third-party and unpinned.
+"""
+import numpy as np
+
+from . import ops
+
+
+class SegmentationRegulariser:
+    def __init__(self, seg_net, generation_labels, segmentation_label_equivalency, rel_weight, m=None, M=None,
+                 fs_header=False):
+        import torch
+        self.torch = torch
+        self.net = seg_net
+        seg_net.training = False
+        seg_net.enable_input_grad()
+        self.rel_weight = float(rel_weight)
+        self.m, self.M = (None, None) if m is None else (float(m), float(M))
+        self.fs_header = bool(fs_header)
+        gen = np.asarray(generation_labels).reshape(-1)
+        eq = np.asarray(segmentation_label_equivalency).reshape(-1)
+        if len(eq) != seg_net.nb_labels:
+            raise ValueError('segmentation_label_equivalency should have one entry per label of the segmentation network, '
+                             'had %d and %d' % (len(eq), seg_net.nb_labels))
+        idx, gt = [], []
+        for i, lab in enumerate(gen):
+            j = np.where(eq == lab)[0]
+            if len(j) == 0:
+                continue
+            if len(j) > 3:
+                raise Exception("uuummm weird that you're merging so many labels...")
+            idx.append(list(j) + [-1] * (3 - len(j)))
+            gt.append(i)
+        if not idx:
+            raise ValueError('no generation label has an equivalent among the segmentation labels')
+        dev = seg_net.device
+        self.cls_idx = torch.tensor(idx, dtype=torch.int32, device=dev).reshape(-1)
+        self.cls_gt = torch.tensor(gt, dtype=torch.int32, device=dev)
+        self.K = len(gt)
+        self.sums = torch.zeros(2 * self.K, dtype=torch.float32, device=dev)
+
+    def _to_seg_frame(self, t):  # metrics_model.py:158-160: swap the last two spatial axes, then reverse the new 2nd axis
+        return self.torch.flip(t.permute(0, 2, 1), dims=[1]).contiguous() if self.fs_header else t
+
+    def _from_seg_frame(self, t):  # :162-163
+        return self.torch.flip(t, dims=[1]).permute(0, 2, 1).contiguous() if self.fs_header else t
+
+    def __call__(self, pred, seg_target, dpred):
+        """pred: predicted image, device float [nvox] (or [d0,d1,d2]); seg_target: int32 [d0,d1,d2] (the generator's
+        `segmentation_target`); dpred [nvox]: gradient of the image loss w.r.t. pred, incremented IN PLACE by
+        rel_weight * d(dice)/d(pred).  Returns the Dice loss as a 0-d device tensor."""
+        torch = self.torch
+        shape = tuple(seg_target.shape)
+        x = pred.reshape(shape)
+        if self.m is not None:  # :155
+            inside = (x > self.m) & (x < self.M)
+            x = (torch.clamp(x, self.m, self.M) - self.m) / (self.M - self.m)
+        xs = self._to_seg_frame(x)
+        seg = self._to_seg_frame(seg_target).reshape(-1)
+        net = self.net
+        if list(xs.shape) != net.input_shape[:3]:
+            raise ValueError('segmentation network built for %s, prediction is %s' % (net.input_shape[:3], list(xs.shape)))
+        probs = net.predict_probs(xs[..., None].contiguous())
+        ops.seg_dice_sums(probs, seg, self.cls_idx, self.cls_gt, self.sums)
+        T, B = self.sums[:self.K], self.sums[self.K:]
+        dice = (1.0 - (T + 1e-7) / (B + 1e-7)).mean()
+        low, _ = net.saved['last']
+        dbn = net.buf('seg_dbn', list(low.shape))
+        ops.seg_dice_bwd(probs, seg, net.view(net.head['w']), self.cls_idx, self.cls_gt, self.sums, self.rel_weight, dbn)
+        dx = net.backward_input(dbn)[..., 0]
+        dx = self._from_seg_frame(dx)
+        if self.m is not None:
+            dx = dx * inside / (self.M - self.m)
+        dpred.add_(dx.reshape(-1))
+        return dice

@@ -33,10 +33,14 @@ class UNet3D:
             raise NotImplementedError("only activation='elu' is supported")
         if batch_norm not in (-1, len(input_shape) - 1 + 1, 4):
             raise NotImplementedError('batch_norm=-1 (channels-last BatchNormalization after each level) is required')
-        if nb_labels != 1:
-            raise NotImplementedError('only one output channel (nb_labels=1) is supported yet')
-        if final_pred_activation != 'linear':
-            raise NotImplementedError("only final_pred_activation='linear' is supported")
+        # nb_labels > 1 / 'softmax': the (frozen) segmentation network of the segmentation-regularised loss
+        # (SynthSR/training.py:373-389); it is only run through predict_probs() / backward_input()
+        if final_pred_activation not in ('linear', 'softmax'):
+            raise NotImplementedError("final_pred_activation should be 'linear' or 'softmax'")
+        if (nb_labels != 1) != (final_pred_activation == 'softmax'):
+            raise NotImplementedError('supported heads: 1 linear output channel, or nb_labels > 1 with softmax')
+        self.nb_labels = int(nb_labels)
+        self.need_input_grad = False  # True: also keep the data-gradient weights of the first conv (backward_input)
         if len(input_shape) != 4:
             raise NotImplementedError('3-D volumes only')
         self.prefix = name if prefix is None else prefix
@@ -82,8 +86,8 @@ class UNet3D:
             convs[0]['cs'] = self.feats[l]
             self.dec.append(dict(convs=convs, bn=bn, level=l, fold=fold))
         self.head = dict(name='%s_likelihood' % self.prefix, cin=c,
-                         w=self._add('%s_likelihood/kernel' % self.prefix, (c, 1), 'head_w'),
-                         b=self._add('%s_likelihood/bias' % self.prefix, (1,), 'bias'))
+                         w=self._add('%s_likelihood/kernel' % self.prefix, (c, self.nb_labels), 'head_w'),
+                         b=self._add('%s_likelihood/bias' % self.prefix, (self.nb_labels,), 'bias'))
         self.n_params = sum(int(np.prod(s[1])) for s in self.specs)
         dev = self.device
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
@@ -202,7 +206,7 @@ class UNet3D:
                 add(c, 'wpd_u', lo_shape, cs, cl, 1, True)
             else:
                 add(c, 'wp', c['shape'], 0, c['cin'], 0, False)
-                if not first:  # the first layer's input has no gradient
+                if not first or self.need_input_grad:  # the first layer's input normally has no gradient
                     add(c, 'wpd', c['shape'], 0, c['cin'], 1, False)
             first = False
         self._packed = torch.empty(off, dtype=torch.float32, device=self.device)
@@ -344,17 +348,50 @@ class UNet3D:
             self.training = was
         return pred.view(*self.input_shape[:3], 1)
 
+    # ------------------------------------------------------------------ frozen use (segmentation network)
+    def enable_input_grad(self):
+        """keep data-gradient weights for the first conv as well, so that backward_input() can reach the network input"""
+        if not self.need_input_grad:
+            self.need_input_grad = True
+            self._jobs = None
+            self.repack()
+
+    def predict_probs(self, x):
+        """inference forward of a softmax-headed network: x [d0,d1,d2,Cin] -> probs [nvox, nb_labels] (activations are kept
+        for backward_input)"""
+        assert self.nb_labels > 1
+        self.training = False
+        low, bn = self.forward(x)
+        nvox = low.numel() // low.shape[3]
+        probs = self.buf('probs', [nvox, self.nb_labels])
+        ops.seg_head_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']), self.view(self.head['w']),
+                         self.view(self.head['b']), probs)
+        return probs
+
+    def backward_input(self, dbn):
+        """gradient w.r.t. the network input of a loss whose gradient w.r.t. the LAST BatchNorm output is `dbn`
+        [d0,d1,d2,C]; the network is frozen: inference-mode BatchNorm (moving statistics), no weight gradients"""
+        assert self.need_input_grad and not self.training
+        return self.backward(g_last=dbn, frozen=True)
+
     # ------------------------------------------------------------------ backward
-    def backward(self, on_grad_ready=None):
+    def backward(self, on_grad_ready=None, g_last=None, frozen=False):
         """gradients of the L1 loss w.r.t. every parameter into self.grads (zeroed here).
+        frozen=True (with g_last = gradient w.r.t. the last BatchNorm output): data gradients only, inference-mode
+        BatchNorm; returns the gradient w.r.t. the network input.
         on_grad_ready(offset_lo): optional hook called when every gradient at flat offset >= offset_lo is final
         (used to overlap the RCCL all-reduce with the rest of the backward)."""
         L = self.nb_levels
         G = self.grads
-        G.zero_()
+        self._frozen = frozen
         self._pending_bn = None
         low, bn = self.saved['last']
         C = low.shape[3]
+        if frozen:
+            if getattr(self, '_zero_sums', None) is None:
+                self._zero_sums = torch.zeros(2 * max(b['C'] for b in self.bn_layers), device=self.device)
+            return self._backward_body(g_last, on_grad_ready)
+        G.zero_()
         # the gradient w.r.t. the last BatchNorm output is rank-1 (dpred[v] * w_head[c]): it is neither stored nor
         # reduced; head_bwd emits that BN's backward sums and the first ELU backward forms it on the fly
         off = self.offsets[bn['beta']][0]
@@ -364,7 +401,12 @@ class UNet3D:
                      bn_sums=sums)
         self._pending_bn = (bn, sums)
         self._rank1 = (self.dpred, self.view(self.head['w']))
-        g = None
+        return self._backward_body(None, on_grad_ready)
+
+    def _backward_body(self, g, on_grad_ready):
+        L = self.nb_levels
+        G = self.grads
+        frozen = self._frozen
         dskips = [None] * L
         for k in range(len(self.dec) - 1, -1, -1):
             d = self.dec[k]
@@ -379,14 +421,15 @@ class UNet3D:
                 dz = self._convs_backward(g, None, d['convs'][1:], acts[1:], acts[0], need_dx=True, tag='d%d' % k,
                                           elu_below=acts[0])
                 c0 = d['convs'][0]
-                dW = self.view(c0['w'], self.grads)
-                self._join()
-                dwc = self.buf('dwc', [8, 27, Cl, c0['cout']])
+                if not frozen:
+                    dW = self.view(c0['w'], self.grads)
+                    self._join()
+                    dwc = self.buf('dwc', [8, 27, Cl, c0['cout']])
 
-                def c0_wgrads(skip=skip, dz=dz, dW=dW, lo_bn=lo_bn, dwc=dwc, c0=c0, Cs=Cs):
-                    ops.conv3d_wgrad_part(skip, dz, dW, 0, dbias=self.view(c0['b'], self.grads))
-                    ops.conv3d_up_wgrad(lo_bn, dz, dwc, dW, Cs)
-                self._fork(c0_wgrads, skip[..., 0].numel())
+                    def c0_wgrads(skip=skip, dz=dz, dW=dW, lo_bn=lo_bn, dwc=dwc, c0=c0, Cs=Cs):
+                        ops.conv3d_wgrad_part(skip, dz, dW, 0, dbias=self.view(c0['b'], self.grads))
+                        ops.conv3d_up_wgrad(lo_bn, dz, dwc, dW, Cs)
+                    self._fork(c0_wgrads, skip[..., 0].numel())
                 dskips[l] = ops.conv3d(dz, c0['wpd_s'], None, Cs, 0, out=self.buf('dskip%d' % l, self.shapes[l] + [Cs]))
                 g = ops.conv3d_up_dgrad(dz, c0['wpd_u'], Cl, out=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
             else:
@@ -405,19 +448,20 @@ class UNet3D:
                 # the pool backward also emits the sums of this level's BatchNorm backward (its output is the BN-output
                 # gradient): no separate reduction pass
                 off = self.offsets[e['bn']['beta']][0]
-                sums = self.grads[off:off + 2 * e['bn']['C']]
+                sums = None if frozen else self.grads[off:off + 2 * e['bn']['C']]
                 g = ops.bn_maxpool_bwd(g, acts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
                                        self.view(e['bn']['beta']), out=self.buf('gpool%d' % l, list(acts[-1].shape)),
                                        sums=sums)
-                self._pending_bn = (e['bn'], sums)
+                self._pending_bn = (e['bn'], self._zero_sums[:2 * e['bn']['C']] if frozen else sums)
             else:
                 g = self._bn_backward(g, acts[-1], e['bn'])
-            g = self._convs_backward(g, dskips[l], e['convs'], acts, self.saved['x'][l], need_dx=(l > 0), tag='e%d' % l)
+            g = self._convs_backward(g, dskips[l], e['convs'], acts, self.saved['x'][l], need_dx=(l > 0) or frozen,
+                                     tag='e%d' % l)
             if on_grad_ready is not None:
                 self._join()
                 on_grad_ready(self.offsets[e['convs'][0]['w']][0])
         self._join()
-        return G
+        return g if frozen else G
 
     # ---- weight gradients on a second stream: wgrad(layer) and dgrad(layer) both only read dz, so they can share
     # the GPU; on the small deep levels neither fills 256 CUs alone.  _join() before anything overwrites dz / reads grads.
@@ -443,6 +487,9 @@ class UNet3D:
         """pass 1 (channel sums = dbeta | dgamma); pass 2 is fused into the ELU backward of the conv that produced x"""
         if g is None:  # rank-1 head gradient: head_bwd already produced the sums (backward())
             return None
+        if getattr(self, '_frozen', False):  # inference-mode BatchNorm: dx = gamma * invstd * dy, i.e. zero batch sums
+            self._pending_bn = (bn, self._zero_sums[:2 * bn['C']])
+            return g
         off = self.offsets[bn['beta']][0]
         sums = self.grads[off:off + 2 * bn['C']]  # [dbeta | dgamma]
         ops.bn_reduce_bwd(g, x, self._stats(bn), sums)
@@ -472,13 +519,16 @@ class UNet3D:
             y = acts[j]
             xin = acts[j - 1] if j > 0 else x_in
             self._join()  # the previous layer's wgrad still reads the buffer dz is about to reuse
+            frozen = getattr(self, '_frozen', False)
             if fused:
                 dz = g
-                self._fork(lambda: ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads),
-                                                    dbias=self.view(c['b'], self.grads)), xin[..., 0].numel())
+                if not frozen:
+                    self._fork(lambda: ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads),
+                                                        dbias=self.view(c['b'], self.grads)), xin[..., 0].numel())
             else:
-                dz = self._elu_backward(g, y, g2, self.view(c['b'], self.grads))
-                self._fork(lambda: ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads)), xin[..., 0].numel())
+                dz = self._elu_backward(g, y, g2, None if frozen else self.view(c['b'], self.grads))
+                if not frozen:
+                    self._fork(lambda: ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads)), xin[..., 0].numel())
             g2 = None
             fused = False
             if j > 0 or need_dx:

@@ -294,3 +294,59 @@ def test_training_reduces_loss(T):
     losses = [tr.step(inputs, draws).item() for _ in range(8)]
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize('fs_header,clip', [(False, False), (True, True)])
+def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip):
+    """SynthSR/metrics_model.py:136-215: L1 + w * Dice(frozen segmentation U-Net(prediction), label map).  Loss value and
+    every gradient of the TRAINED network against torch autograd through the oracle (frozen net in inference mode)"""
+    torch = T
+    from synthsr_amd.unet import unet
+    from synthsr_amd.seg_loss import SegmentationRegulariser
+    from oracle import unet_ref as U
+    shape, levels = (16, 24, 32), 3
+    gen_labels = np.array([0, 14, 2, 3, 41, 42, 17])
+    seg_labels = np.array([0, 2, 3, 4, 41, 42, 43, 17, 53])          # labels the segmentation net predicts
+    equivalency = np.array([0, 2, 3, 3, 41, 42, 42, 17, 17])        # ... mapped onto generation-label VALUES (merges)
+    net = unet(24, list(shape) + [2], levels, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
+               final_pred_activation='linear', seed=3)
+    segshape = (shape[0], shape[2], shape[1]) if fs_header else shape
+    segnet = unet(24, list(segshape) + [1], levels, 3, len(seg_labels), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
+                  activation='elu', final_pred_activation='softmax', seed=4)
+    g = torch.Generator().manual_seed(0)
+    segnet.bn_moving.copy_((torch.rand(segnet.bn_moving.shape, generator=g) * 0.5 + 0.25).to(segnet.device))
+    m, M = (0.1, 0.7) if clip else (None, None)
+    w = 0.25
+    reg = SegmentationRegulariser(segnet, gen_labels, equivalency, w, m=m, M=M, fs_header=fs_header)
+    x = torch.rand(*shape, 2, generator=g)
+    target = torch.rand(*shape, generator=g)
+    seg_target = torch.randint(0, len(gen_labels), shape, generator=g, dtype=torch.int32)  # indices, cf. the module docstring
+    # ---- HIP
+    loss, pred = net.loss_l1(x.cuda(), target.cuda().reshape(-1), want_pred=True)
+    dice = reg(pred, seg_target.cuda(), net.dpred)
+    net.backward()
+    # ---- oracle / autograd
+    P = {k: v.clone().float().requires_grad_(True) for k, v in net.state_dict().items() if 'moving' not in k}
+    Pseg = {k: v.clone().float() for k, v in segnet.state_dict().items()}
+    pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True)[..., 0]
+    l1 = (pr - target).abs().mean()
+    dref = U.seg_regularisation(pr, seg_target, Pseg, segnet.prefix, levels, 2, gen_labels, equivalency, m=m, M=M,
+                                fs_header=fs_header)
+    g_dice = torch.autograd.grad(dref, [P[nm] for nm, _, _ in net.specs], retain_graph=True)
+    (l1 + w * dref).backward()
+    assert abs(float(loss.detach().item()) - float(l1.detach())) < 1e-5
+    assert abs(float(dice.item()) - float(dref.detach())) < 2e-5, (float(dice.item()), float(dref.detach()))
+    for nm, _, _ in net.specs:
+        close(net.view(nm, net.grads), P[nm].grad, 2e-3, 'grad ' + nm)
+    # the Dice term alone (it is ~1 % of the total gradient here): image-loss gradient zeroed, weight 1
+    reg.rel_weight = 1.0
+    loss, pred = net.loss_l1(x.cuda(), target.cuda().reshape(-1), want_pred=True)
+    net.dpred.zero_()
+    reg(pred, seg_target.cuda(), net.dpred)
+    net.backward()
+    for (nm, _, _), gd in zip(net.specs, g_dice):
+        if nm.endswith('likelihood/bias'):
+            continue  # a sum of cancelling contributions: compared absolutely below
+        close(net.view(nm, net.grads), gd, 3e-3, 'dice-only grad ' + nm)
+    hb = net.view(net.head['b'], net.grads).cpu()
+    assert float((hb - g_dice[-1]).abs().max()) < 1e-5
