@@ -62,8 +62,9 @@ class Trainer:
     """generator + U-Net + L1 + Adam for one rank"""
 
     def __init__(self, brain_generator, net, lr=1e-4, lr_decay=0.0, work_with_residual_channel=None,
-                 distributed=False, bucket_elems=2 * 1024 * 1024, force_allreduce=False):
+                 distributed=False, bucket_elems=2 * 1024 * 1024, force_allreduce=False, seg_regulariser=None):
         self.bg = brain_generator
+        self.seg = seg_regulariser  # synthsr_amd.seg_loss.SegmentationRegulariser or None
         self.gen = brain_generator.labels_to_image_model
         self.net = net
         self.lr, self.lr_decay = lr, lr_decay
@@ -85,15 +86,20 @@ class Trainer:
         labels, means, stds = model_inputs[:3]
         real = np.asarray(model_inputs[3])[0, ..., 0] if getattr(gen, 'use_real_image', False) else None
         if label_index is not None and self.resident_labels is not None and real is None:
-            image, target, _ = gen.generate(self.resident_labels[label_index], np.asarray(means)[0],
-                                            np.asarray(stds)[0], draws, labels_on_device=True)
+            image, target, seg = gen.generate(self.resident_labels[label_index], np.asarray(means)[0],
+                                              np.asarray(stds)[0], draws, labels_on_device=True)
         else:
-            image, target, _ = gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0], np.asarray(stds)[0],
-                                            draws, real_image=real)
+            image, target, seg = gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0], np.asarray(stds)[0],
+                                              draws, real_image=real)
         residual, rs, ro = None, 1, 0
         if self.residual is not None:
             residual, rs, ro = image, image.shape[-1], int(self.residual[0])
-        loss, _ = net.loss_l1(image, target.reshape(-1), residual=residual, res_stride=rs, res_off=ro)
+        loss, pred = net.loss_l1(image, target.reshape(-1), residual=residual, res_stride=rs, res_off=ro,
+                                 want_pred=self.seg is not None)
+        if self.seg is not None:  # total = image loss + w * Dice(frozen segmentation net(prediction), labels)
+            if list(seg.shape) != list(image.shape[:3]):
+                raise NotImplementedError('segmentation loss with a target resolution different from the label maps')
+            loss = loss + self.seg.rel_weight * self.seg(pred, seg, net.dpred)
         if self.reducer is not None:
             self.reducer.start()
             net.backward(on_grad_ready=self.reducer.ready)
@@ -204,8 +210,6 @@ def training(labels_dir,
             # the reference repeats the python list here (`2 * list`, F11) instead of doubling the indices
             raise NotImplementedError('work_with_residual_channel together with build_reliability_maps=True is '
                                       'ill-defined in the reference (SURVEY F11); set build_reliability_maps=False')
-    if segmentation_model_file is not None:
-        raise NotImplementedError('segmentation-regularised loss is not built yet (SURVEY §8f-3)')
     if regression_metric != 'l1':
         raise NotImplementedError("only regression_metric='l1' is built yet")
     if loss_cropping not in (None, 0):
@@ -271,7 +275,29 @@ def training(labels_dir,
         import torch.distributed as dist
         dist.broadcast(net.params, 0)  # identical initial weights on every rank
         net.repack()
-    trainer = Trainer(brain_generator, net, lr, lr_decay, work_with_residual_channel, distributed=dist_on)
+    # frozen segmentation CNN for the segmentation-regularised loss (training.py:371-409)
+    seg_reg = None
+    if segmentation_model_file is not None:
+        from .seg_loss import SegmentationRegulariser
+        segmentation_labels = np.asarray(hm.load_array_if_path(segmentation_label_list))
+        seg_shape = list(unet_input_shape[:-1])
+        if fs_header_segnet:  # the network sees the volume with its last two axes swapped (metrics_model.py:158-160)
+            seg_shape = [seg_shape[0], seg_shape[2], seg_shape[1]]
+        seg_net = build_unet(nb_features=unet_feat_count, input_shape=seg_shape + [1], nb_levels=n_levels,
+                             conv_size=conv_size, nb_labels=len(segmentation_labels), feat_mult=feat_multiplier,
+                             nb_conv_per_level=nb_conv_per_level, conv_dropout=dropout, final_pred_activation='softmax',
+                             batch_norm=-1, activation=activation, input_model=None, seed=seed + 1)
+        load_checkpoint(segmentation_model_file, seg_net)
+        m = M = None
+        if images_dir is not None:  # clip the synthesised images at the 2nd / 98th percentiles of the first real scan
+            first = volumes.list_images_in_folder(images_dir)[0]
+            im = volumes.load_volume(first, im_only=True).flatten()
+            m, M = np.percentile(im, 2), np.percentile(im, 98)
+        seg_reg = SegmentationRegulariser(seg_net, brain_generator.generation_labels,
+                                          hm.load_array_if_path(segmentation_label_equivalency),
+                                          relative_weight_segmentation, m=m, M=M, fs_header=fs_header_segnet)
+    trainer = Trainer(brain_generator, net, lr, lr_decay, work_with_residual_channel, distributed=dist_on,
+                      seg_regulariser=seg_reg)
 
     log_path = os.path.join(model_dir, 'logs', 'loss.csv')
     if rank == 0:

@@ -104,6 +104,36 @@ def test_real_image_targets_images_dir(tmp_path):
         training(labels_dir, str(tmp_path / 'm2'), None, None, str(tmp_path / 'gl.npy'), images_dir=str(d), output_channel=0)
 
 
+def test_training_with_segmentation_regularised_loss(tmp_path):
+    """training(..., segmentation_model_file=...): frozen segmentation U-Net checkpoint, label list and
+    equivalency from .npy files; loss = L1 + 0.25 * Dice"""
+    import torch
+    from synthsr_amd.training import training, save_checkpoint
+    from synthsr_amd.synthetic import GENERATION_LABELS
+    from synthsr_amd.unet import unet
+    labels_dir = _write_labels(tmp_path, 2, (32, 32, 32))
+    np.save(tmp_path / 'gl.npy', GENERATION_LABELS)
+    seg_labels = np.array([0, 2, 3, 4, 41, 42, 17])
+    np.save(tmp_path / 'seg_labels.npy', seg_labels)
+    np.save(tmp_path / 'seg_eq.npy', np.array([0, 2, 3, 4, 2, 3, 17]))  # right-hemisphere labels merged onto the left ones
+    seg_net = unet(24, [32, 32, 32, 1], 3, 3, len(seg_labels), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
+                   activation='elu', final_pred_activation='softmax', seed=9)
+    save_checkpoint(str(tmp_path / 'seg.npz'), seg_net)
+    common = dict(output_shape=32, n_levels=3, unet_feat_count=24, nonlin_shape_factor=.125, bias_shape_factor=.125,
+                  steps_per_epoch=2, epochs=1, verbose=False)
+    net = training(labels_dir, str(tmp_path / 'm_seg'), None, None, str(tmp_path / 'gl.npy'),
+                   segmentation_label_list=str(tmp_path / 'seg_labels.npy'),
+                   segmentation_label_equivalency=str(tmp_path / 'seg_eq.npy'),
+                   segmentation_model_file=str(tmp_path / 'seg.npz'), relative_weight_segmentation=0.25, **common)
+    assert net.iterations == 2
+    log = open(os.path.join(str(tmp_path / 'm_seg'), 'logs', 'loss.csv')).read().strip().split(',')
+    total = float(log[1])
+    net0 = training(labels_dir, str(tmp_path / 'm_plain'), None, None, str(tmp_path / 'gl.npy'), **common)
+    plain = float(open(os.path.join(str(tmp_path / 'm_plain'), 'logs', 'loss.csv')).read().strip().split(',')[1])
+    # same seeds, same first step: the regularised loss is the L1 loss plus 0.25 * Dice with 0 < Dice < 1
+    assert np.isfinite(total) and plain < total < plain + 0.25
+
+
 def test_bench_under_torchrun_with_forced_allreduce():
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
