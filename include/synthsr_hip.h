@@ -115,6 +115,16 @@ int synthsr_normalise_gamma(const float* x, float* out, int64_t n, const uint32_
 int synthsr_blur3d(const float* in, float* out, const int shape[3], const float* kernel, const int ksize[3],
                    int out_stride, int out_offset, int fill_offset, float fill_value, synthsr_stream_t stream);
 
+/* MimicAcquisition (ext/lab2im/layers.py:927-990; randomise_res path, labels_to_image_model.py:220) with
+ * min_subsample_res = volume_res: nearest down-sampling by down_zoom then linear up-sampling by up_zoom (both as the
+ * reference computes them from the sampled resolution, passed in as float32), fused per output voxel.
+ * out[o*out_stride + out_offset] = resampled value; if dist_offset >= 0, out[o*out_stride + dist_offset] = distance (mm)
+ * of the output voxel to the nearest acquired grid point (the 'distance map' that replaces the reliability map).
+ * out_offset < 0: only the distance map is written. */
+int synthsr_mimic_acquisition(const float* in, float* out, const int in_shape[3], const int out_shape[3],
+                              const float down_zoom[3], const float up_zoom[3], const float subsample_res[3],
+                              int out_stride, int out_offset, int dist_offset, synthsr_stream_t stream);
+
 /* reliability map (edit_tensors.py:313-329): out[o*stride+offset] = w0[o0]*w1[o1]*w2[o2]; w concatenated */
 int synthsr_outer3(const float* w, float* out, const int shape[3], int out_stride, int out_offset,
                    synthsr_stream_t stream);

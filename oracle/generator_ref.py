@@ -339,6 +339,66 @@ def gaussian_blur(x, sigma, u_blur=None, blur_range=None):
     return conv3d_same(x[..., 0], k)[..., None]
 
 
+def sample_resolution(u_axis, u_res, u_gate, u_thick, min_res, max_res_iso, prob_min=0.05):
+    """SampleResolution.call (ext/lab2im/layers.py:598-652) as SynthSR builds it (`SampleResolution(atlas_res, max_res)`:
+    max_res_iso only, return_thickness=True), one batch item.  Raw draws in call order: u_axis (the int axis pick, unused
+    by this branch but drawn, :609), u_res [3] (:625 -- three independent values despite the name), u_gate (:626),
+    u_thick [3] (:649).  Returns (resolution [3], thickness [3]) float32."""
+    del u_axis
+    lo, hi = f32(min_res), f32(max_res_iso)
+    res = f32(u_res) * (hi - lo) + lo
+    if F(f32(u_gate).reshape(-1)[0]) < F(prob_min):
+        res = lo.copy()
+    thick = f32(u_thick) * (res - lo) + lo
+    return res, thick
+
+
+def dynamic_gaussian_blur(x, sigma, u_blur, max_sigma, blur_range):
+    """DynamicGaussianBlur.call, separable branch (layers.py:810-817, |max_sigma| > 5) with
+    edit_tensors.gaussian_kernel(sigma tensor, max_sigma, blur_range, separable=True) (:86-154): per axis a 1-D kernel
+    of ceil(2.5 max_sigma)-derived width, exp(-d^2/2s^2 - log(sqrt(2 pi) s)) normalised to sum 1, applied one axis
+    after the other with zero padding.  x [X,Y,Z,1]; sigma, u_blur [3]."""
+    sig = f32(sigma)
+    if blur_range is not None and blur_range != 1:
+        sig = sig * (f32(u_blur) * (F(blur_range) - F(1 / blur_range)) + F(1 / blur_range))
+    win = blur_window(max_sigma)
+    out = f32(x)[..., 0]
+    for a in range(3):
+        if win[a] > 1:
+            loc = np.arange(win[a]).astype(F) - F((win[a] - 1) / 2)
+            e = -np.square(loc) / (F(2) * sig[a] ** 2)
+            g = np.exp(e - np.log(F(np.sqrt(2 * np.pi)) * sig[a]))
+            g = (g / g.sum(dtype=F)).astype(F)
+            shape = [1, 1, 1]
+            shape[a] = win[a]
+            out = conv3d_same(out, g.reshape(shape))
+    return out[..., None]
+
+
+def mimic_acquisition(x, subsample_res, volume_res, resample_shape):
+    """MimicAcquisition.call (layers.py:927-990) with min_subsample_res = volume_res, no noise, build_dist_map=True:
+    nearest-neighbour down-sampling to int(shape*volume_res/subsample_res) voxels -- kept inside a full-size tensor, so
+    entries beyond the down-sampled extent are edge replicas (the sampling positions are clipped, :953) -- then linear
+    up-sampling to resample_shape, plus the distance (mm) of every output voxel to the nearest acquired grid point.
+    x [X,Y,Z,1]; returns (volume [*resample_shape,1], dist [*resample_shape,1])."""
+    x = f32(x)
+    S = np.array(x.shape[:3])
+    sub = f32(subsample_res)
+    down_shape = (f32(S * np.array(volume_res, dtype=np.float64)) / sub).astype(np.int32)  # :943-944
+    down_zoom = (down_shape / S).astype(F)  # :945 (true division of ints, cast to float32)
+    up_zoom = (np.array(resample_shape, dtype=np.int32) / down_shape).astype(F)  # :946
+    g = np.stack(_grid(list(S)), -1)
+    down_loc = np.clip(g / down_zoom, F(0), f32(S))  # :949-953
+    vol = interpn(x, down_loc, 'nearest')
+    gu = np.stack(_grid(list(resample_shape)), -1)
+    up_loc = f32(gu / up_zoom)  # :968-969
+    vol = interpn(vol, up_loc, 'linear')
+    fl, ce = np.floor(up_loc), np.ceil(up_loc)
+    dist = np.minimum(up_loc - fl, ce - up_loc) * sub  # :984-986
+    dist = np.sqrt(np.sum(np.square(dist), -1, keepdims=True, dtype=F)).astype(F)
+    return vol, dist
+
+
 def blurring_sigma_for_downsampling(current_res, downsample_res, mult_coef=None, thickness=None):
     """edit_tensors.py:41-65 (numpy branch, float64 like the reference)"""
     current_res = np.array(current_res, dtype=np.float64)
@@ -457,7 +517,7 @@ def labels_to_image(labels, means, stds, tape, generation_labels, n_neutral_labe
                     rotation_bounds=15, shearing_bounds=.012, translation_bounds=False, nonlin_std=3.,
                     nonlin_shape_factor=.0625, simulate_registration_error=True, data_res=None, thickness=None,
                     downsample=False, build_reliability_maps=False, blur_range=1.15, bias_field_std=.3,
-                    bias_shape_factor=.025, real_image=None):
+                    bias_shape_factor=.025, real_image=None, randomise_res=False):
     """labels int32 [X,Y,Z]; means/stds [L,C]; tape: list of (kind, array) in the reference's call order.
     output_channel=None selects the real-image regression target (labels_to_image_model.py:71,109-113): `real_image`
     float32 [X,Y,Z] is deformed (linear), cropped and flipped jointly with the labels, then min-max normalised (:248-255).
@@ -565,13 +625,25 @@ def labels_to_image(labels, means, stds, tape, generation_labels, n_neutral_labe
                                   translation_bounds=5)
                 Tinv = np.linalg.inv(T.astype(np.float64)).astype(F)
                 ch = transform(ch, affine_elastic_shift(T, None, S), 'linear')
-            sig = blurring_sigma_for_downsampling(atlas_res, data_res[i], .42, thickness[i])  # :223
-            ch = gaussian_blur(ch, list(sig), tp.get('u', 3) if (blur_range is not None and blur_range != 1)
-                               else None, blur_range)
-            if down[i]:
-                ch, rel = resample_tensor(ch, out_shape, list(data_res[i]), atlas_res, True)  # :226
+            rr = randomise_res[i] if isinstance(randomise_res, (list, tuple)) else randomise_res
+            if rr:  # :215-220: random acquisition resolution, separable blur, acquisition mimicking + distance map
+                max_res = [9.] * 3
+                res, thick = sample_resolution(tp.get('u', 1), tp.get('u', 3), tp.get('u', 1), tp.get('u', 3), atlas_res,
+                                               max_res)
+                # blurring_sigma_for_downsampling, tensor branch (edit_tensors.py:67-82), float32
+                dres = np.minimum(res, thick)
+                sig = np.where(dres == 0, F(0), F(.42) * dres / f32(atlas_res))
+                ch = dynamic_gaussian_blur(ch, sig, tp.get('u', 3) if (blur_range is not None and blur_range != 1)
+                                           else None, 0.75 * np.array(max_res) / np.array(atlas_res), blur_range)
+                ch, rel = mimic_acquisition(ch, res, atlas_res, out_shape)
             else:
-                ch, rel = resample_tensor(ch, out_shape, build_reliability_map=True)  # :228
+                sig = blurring_sigma_for_downsampling(atlas_res, data_res[i], .42, thickness[i])  # :223
+                ch = gaussian_blur(ch, list(sig), tp.get('u', 3) if (blur_range is not None and blur_range != 1)
+                                   else None, blur_range)
+                if down[i]:
+                    ch, rel = resample_tensor(ch, out_shape, list(data_res[i]), atlas_res, True)  # :226
+                else:
+                    ch, rel = resample_tensor(ch, out_shape, build_reliability_map=True)  # :228
             if reg:  # :231-238
                 Terr = sample_affine(tp.get('u', 3), None, None, tp.get('u', 3), rotation_bounds=.5,
                                      translation_bounds=.5)

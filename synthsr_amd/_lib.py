@@ -36,6 +36,8 @@ SIGNATURES = {
     'synthsr_svf_integrate': (c_int, [_P, _P, POINTER(c_int), c_int, _S]),
     'synthsr_affine_resample_linear': (c_int, [_P, _P, c_int, POINTER(c_int), POINTER(c_float), _S]),
     'synthsr_deform_gmm': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(DeformParams), _S]),
+    'synthsr_mimic_acquisition': (c_int, [_P, _P, POINTER(c_int), POINTER(c_int), POINTER(c_float), POINTER(c_float),
+                                          POINTER(c_float), c_int, c_int, c_int, _S]),
     'synthsr_deform_gmm_real': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(DeformParams), _S]),
     'synthsr_minmax_init': (c_int, [_P, c_int, _S]),
     'synthsr_minmax_reduce': (c_int, [_P, c_int64, _P, _S]),

@@ -310,6 +310,43 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
   }
 }
 
+// MimicAcquisition (ext/lab2im/layers.py:927-990) with min_subsample_res = volume_res and a distance map: nearest-neighbour
+// down-sampling and linear up-sampling are composed per output voxel (the intermediate low-resolution tensor is never
+// written): corner j of the trilinear stencil on the (full-size, edge-replicated) down-sampled grid reads the source
+// voxel clip(rint(clip(j / down_zoom, 0, S)), 0, S-1).  dist = | min(frac, 1-frac) * subsample_res |_2.
+struct MimicP {
+  int S[3], R[3];
+  float dz[3], uz[3], sub[3];
+};
+__global__ __launch_bounds__(256) void mimic_acquisition_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                MimicP p, int ostride, int ooff, int doff) {
+  const int64_t n = (int64_t)p.R[0] * p.R[1] * p.R[2];
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x) {
+    const int o2 = (int)(o % p.R[2]);
+    const int o1 = (int)((o / p.R[2]) % p.R[1]);
+    const int o0 = (int)(o / ((int64_t)p.R[2] * p.R[1]));
+    const float u0 = (float)o0 / p.uz[0], u1 = (float)o1 / p.uz[1], u2 = (float)o2 / p.uz[2];
+    const Axis a0 = axis_setup(u0, p.S[0]);
+    const Axis a1 = axis_setup(u1, p.S[1]);
+    const Axis a2 = axis_setup(u2, p.S[2]);
+    auto src = [&](int j, int d) {  // down-sampled index -> source index (nearest, both clamps of the reference)
+      const float loc = fminf(fmaxf((float)j / p.dz[d], 0.f), (float)p.S[d]);
+      return min(max((int)rintf(loc), 0), p.S[d] - 1);
+    };
+    const int s1 = p.S[1], s2 = p.S[2];
+    const float v = tri_accum(a0, a1, a2, [&](int i, int j, int k) {
+      return in[((int64_t)src(i, 0) * s1 + src(j, 1)) * s2 + src(k, 2)];
+    });
+    if (ooff >= 0) out[o * ostride + ooff] = v;
+    if (doff >= 0) {
+      const float d0 = fminf(u0 - floorf(u0), ceilf(u0) - u0) * p.sub[0];
+      const float d1 = fminf(u1 - floorf(u1), ceilf(u1) - u1) * p.sub[1];
+      const float d2 = fminf(u2 - floorf(u2), ceilf(u2) - u2) * p.sub[2];
+      out[o * ostride + doff] = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+    }
+  }
+}
+
 __global__ void minmax_init_kernel(uint32_t* mm, int n_pairs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_pairs) {
@@ -481,6 +518,29 @@ int synthsr_deform_gmm_real(const int32_t* labels, const float* field_half, cons
   hipLaunchKernelGGL(deform_gmm_kernel, dim3(syn_grid(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, labels,
                      field_half, gmm_lut, p->swap_lut_size > 0 ? swap_lut : nullptr, noise, bias_small, seg_out,
                      chan_out, minmax, real_in, real_out, real_minmax, *p);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_mimic_acquisition(const float* in, float* out, const int in_shape[3], const int out_shape[3],
+                              const float down_zoom[3], const float up_zoom[3], const float subsample_res[3],
+                              int out_stride, int out_offset, int dist_offset, synthsr_stream_t stream) {
+  if (!in || !out || bad_shape(in_shape) || bad_shape(out_shape) || !down_zoom || !up_zoom || !subsample_res ||
+      out_stride < 1 || out_offset >= out_stride || dist_offset >= out_stride || (out_offset < 0 && dist_offset < 0) ||
+      (out_offset >= 0 && out_offset == dist_offset))
+    return SYNTHSR_EINVAL;
+  MimicP p;
+  for (int d = 0; d < 3; ++d) {
+    if (!(down_zoom[d] > 0.f) || !(up_zoom[d] > 0.f)) return SYNTHSR_EINVAL;
+    p.S[d] = in_shape[d];
+    p.R[d] = out_shape[d];
+    p.dz[d] = down_zoom[d];
+    p.uz[d] = up_zoom[d];
+    p.sub[d] = subsample_res[d];
+  }
+  const int64_t n = (int64_t)out_shape[0] * out_shape[1] * out_shape[2];
+  hipLaunchKernelGGL(mimic_acquisition_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, p,
+                     out_stride, out_offset, dist_offset);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

@@ -342,3 +342,38 @@ def draw_value_from_distribution(hyperparameter, size=1, distribution='uniform',
     if positive_only:
         value[value < 0] = 0
     return value
+
+
+def randomise_res_plan(u_rr, u_blur, blur_range, atlas_res, crop_shape, output_shape, max_res=9.0, prob_min=0.05):
+    """Host part of the randomise_res path (SynthSR/labels_to_image_model.py:215-220) for one channel, float32 like the
+    reference graph: SampleResolution (ext/lab2im/layers.py:598-652, isotropic-only branch: resolution ~ U(atlas, 9) per
+    axis, 5 % chance of the atlas resolution, thickness ~ U(atlas, resolution)), the blur sigma
+    (edit_tensors.py:67-82: .42 * min(resolution, thickness) / atlas), the three 1-D kernels of DynamicGaussianBlur
+    (edit_tensors.py:113-154; width from max_sigma = .75 * 9 / atlas) and MimicAcquisition's zoom factors
+    (layers.py:943-946).  u_rr = (axis pick [unused by this branch], u_res[3], u_gate, u_thick[3]) raw uniforms."""
+    f = np.float32
+    _, u_res, u_gate, u_thick = u_rr
+    lo = np.asarray(atlas_res, dtype=f)
+    hi = np.full(3, max_res, dtype=f)
+    res = np.asarray(u_res, dtype=f) * (hi - lo) + lo
+    if f(np.asarray(u_gate, dtype=f).reshape(-1)[0]) < f(prob_min):
+        res = lo.copy()
+    thick = np.asarray(u_thick, dtype=f) * (res - lo) + lo
+    dres = np.minimum(res, thick)
+    sig = np.where(dres == 0, f(0), f(.42) * dres / lo).astype(f)
+    if blur_range is not None and blur_range != 1:
+        sig = sig * (np.asarray(u_blur, dtype=f) * (f(blur_range) - f(1 / blur_range)) + f(1 / blur_range))
+    max_sigma = 0.75 * max_res / np.asarray(atlas_res, dtype=np.float64)
+    win = (np.int32(np.ceil(2.5 * max_sigma) / 2) * 2 + 1).tolist()
+    kernels = []
+    for a in range(3):
+        loc = np.arange(win[a]).astype(f) - f((win[a] - 1) / 2)
+        e = -np.square(loc) / (f(2) * sig[a] ** 2)
+        g = np.exp(e - np.log(f(np.sqrt(2 * np.pi)) * sig[a]))
+        kernels.append((g / g.sum(dtype=f)).astype(f))
+    S = np.asarray(crop_shape)
+    down_shape = (np.asarray(S * np.asarray(atlas_res, dtype=np.float64), dtype=f) / res).astype(np.int32)
+    down_zoom = (down_shape / S).astype(f)
+    up_zoom = (np.asarray(output_shape, dtype=np.int32) / down_shape).astype(f)
+    return dict(res=[float(v) for v in res], thickness=[float(v) for v in thick], sigma=[float(v) for v in sig],
+                kernels=kernels, down_zoom=[float(v) for v in down_zoom], up_zoom=[float(v) for v in up_zoom])

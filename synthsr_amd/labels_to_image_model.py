@@ -12,7 +12,7 @@ Random draws are explicit (`Draws`).  In production they come from a per-rank nu
 parity tests inject the reference's recorded tape through `draws_from_tape`.
 
 Scope: synthetic regression target, fixed acquisition resolution.  `randomise_res=True`
-raises NotImplementedError (row §8f-2, not built yet); real-image regression targets (output_channel=None, §8f-4) are supported.
+is supported for channels without registration error (SampleResolution / DynamicGaussianBlur / MimicAcquisition, §8f-2 generator half); real-image regression targets (output_channel=None, §8f-4) are supported.
 Batch items are generated independently; for batchsize > 1 the reference sums the GMM LUT over the
 batch (F9, a bug) — that is NOT reproduced.
 """
@@ -80,9 +80,8 @@ class LabelsToImageModel:
         self.data_res, self.thickness = data_res, thickness
         if isinstance(randomise_res, (bool, np.bool_)) or randomise_res is None:
             randomise_res = n_channels * [bool(randomise_res)]
-        if any(randomise_res):
-            raise NotImplementedError('randomise_res=True (SampleResolution/DynamicGaussianBlur/MimicAcquisition) '
-                                      'is not built yet')
+        # randomise_res (labels_to_image_model.py:215-220): per-volume random acquisition resolution / slice thickness
+        self.randomise_res = [bool(r) for r in randomise_res]
         self.crop_shape, self.output_shape, self.padding_margin = hm.get_shapes(
             labels_shape, output_shape, self.atlas_res, self.target_res, padding_margin, output_div_by_n)
         self.input_labels_shape = list(labels_shape)
@@ -117,7 +116,7 @@ class LabelsToImageModel:
         self.small_bias_shape = hm.get_resample_shape(self.crop_shape, bias_shape_factor)
         self.resample_target = self.crop_shape != self.output_shape
         for i in range(n_channels):
-            if input_channels[i] and hm.is_separable_sigma(
+            if input_channels[i] and not self.randomise_res[i] and hm.is_separable_sigma(
                     hm.blurring_sigma_for_downsampling(self.atlas_res, data_res[i], .42, thickness[i])):
                 raise NotImplementedError('separable blur branch (|sigma| > 5) is not built yet')
         if n_channels > 4:
@@ -210,6 +209,8 @@ class LabelsToImageModel:
                 reg = bool(self.simulate_registration_error[i]) and i != self.idx_first_input_channel
                 if reg:
                     c['u_regT'] = (U(3), U(3))
+                if self.randomise_res[i]:  # SampleResolution draws, ext/lab2im/layers.py:609,625,626,649
+                    c['u_rr'] = (U(1), U(3), U(1), U(3))
                 if self.blur_range is not None and self.blur_range != 1:
                     c['u_blur'] = U(3)
                 if reg:
@@ -255,6 +256,8 @@ class LabelsToImageModel:
                 reg = bool(self.simulate_registration_error[i]) and i != self.idx_first_input_channel
                 if reg:
                     c['u_regT'] = (nxt('u', 3), nxt('u', 3))
+                if self.randomise_res[i]:
+                    c['u_rr'] = (nxt('u', 1), nxt('u', 3), nxt('u', 1), nxt('u', 3))
                 if self.blur_range is not None and self.blur_range != 1:
                     c['u_blur'] = nxt('u', 3)
                 if reg:
@@ -375,7 +378,13 @@ class LabelsToImageModel:
         for i in range(C):
             ch = d.channels[i]
             plan = {}
-            if self.input_channels[i]:
+            if self.input_channels[i] and self.randomise_res[i]:
+                plan['rr'] = hm.randomise_res_plan(ch['u_rr'], ch.get('u_blur'), self.blur_range, self.atlas_res,
+                                                   self.crop_shape, self.output_shape)
+                plan['rr_k'] = [(sm.put(k), [len(k) if a == ax else 1 for a in range(3)])
+                                for ax, k in enumerate(plan['rr']['kernels'])]
+                plan['k_lr'] = None
+            elif self.input_channels[i]:
                 sig = hm.blurring_sigma_for_downsampling(self.atlas_res, self.data_res[i], .42, self.thickness[i])
                 if any(sig):
                     k = hm.gaussian_kernel(list(sig), ch.get('u_blur'), self.blur_range)
@@ -387,6 +396,7 @@ class LabelsToImageModel:
                     plan['down'] = down
                     prof = np.concatenate([hm.reliability_profile(self.output_shape[k], down[k]) for k in range(3)])
                     plan['rel_prof'] = sm.put(prof.astype(np.float32))
+            if self.input_channels[i]:
                 reg = bool(self.simulate_registration_error[i]) and i != self.idx_first_input_channel
                 if reg:
                     T = hm.sample_affine(dict(rot=ch['u_regT'][0], trans=ch['u_regT'][1]), rotation_bounds=5,
@@ -475,7 +485,7 @@ class LabelsToImageModel:
                 aff12 = _lib.F12(*[float(v) for v in plan['T'][:3].reshape(-1)])
                 _lib.check(lib.synthsr_affine_resample_linear(cur, oth, 1, cs, aff12, st), 'reg T')
                 cur, oth = oth, cur
-            simple_out = ('down' not in plan) and (not self.resample_target) and ('T' not in plan)
+            simple_out = ('down' not in plan) and (not self.resample_target) and ('T' not in plan) and ('rr' not in plan)
             if simple_out:
                 # LR blur written straight into the interleaved image (+ all-ones reliability map)
                 fill = img_slot + 1 if self.build_reliability_maps else -1
@@ -488,6 +498,33 @@ class LabelsToImageModel:
                     if fill >= 0:
                         self.d_image.view(-1, Ci)[:, fill] = 1.0
                 img_slot += 2 if self.build_reliability_maps else 1
+                continue
+            if 'rr' in plan:  # separable dynamic blur, then acquisition mimicking with the distance map (:215-220)
+                for ko, ks in plan['rr_k']:
+                    _lib.check(lib.synthsr_blur3d(cur, oth, cs, sm.dptr(ko), i3(ks), 1, 0, -1, 0., st), 'blur(rr)')
+                    cur, oth = oth, cur
+                rr = plan['rr']
+                F3 = ctypes.c_float * 3
+                if 'Tie' not in plan:  # straight into the interleaved image (+ distance map)
+                    dmap = img_slot + 1 if self.build_reliability_maps else -1
+                    _lib.check(lib.synthsr_mimic_acquisition(cur, fptr(self.d_image), cs, os_, F3(*rr['down_zoom']),
+                                                             F3(*rr['up_zoom']), F3(*rr['res']), Ci, img_slot, dmap, st),
+                               'mimic_acquisition')
+                    img_slot += 2 if self.build_reliability_maps else 1
+                    continue
+                # registration error afterwards (:231-238): volume and distance map to separate buffers, both moved by Tie
+                _lib.check(lib.synthsr_mimic_acquisition(cur, oth, cs, os_, F3(*rr['down_zoom']), F3(*rr['up_zoom']),
+                                                         F3(*rr['res']), 1, 0, -1, st), 'mimic_acquisition')
+                _lib.check(lib.synthsr_mimic_acquisition(cur, oth2, cs, os_, F3(*rr['down_zoom']), F3(*rr['up_zoom']),
+                                                         F3(*rr['res']), 1, -1, 0, st), 'mimic_acquisition(dist)')
+                aff12 = _lib.F12(*[float(v) for v in plan['Tie'][:3].reshape(-1)])
+                _lib.check(lib.synthsr_affine_resample_linear(oth, cur, 1, os_, aff12, st), 'reg Tie')
+                _lib.check(lib.synthsr_copy_strided(cur, fptr(self.d_image), no, 1, 0, Ci, img_slot, st), 'copy(img)')
+                img_slot += 1
+                if self.build_reliability_maps:
+                    _lib.check(lib.synthsr_affine_resample_linear(oth2, cur, 1, os_, aff12, st), 'reg Tie(dist)')
+                    _lib.check(lib.synthsr_copy_strided(cur, fptr(self.d_image), no, 1, 0, Ci, img_slot, st), 'copy(dist)')
+                    img_slot += 1
                 continue
             if plan['k_lr'] is not None:
                 ko, ks = plan['k_lr']

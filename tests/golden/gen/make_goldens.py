@@ -264,6 +264,25 @@ def golden_graphs():
               output_channel=None, output_shape=32, **train_defaults)
     run_graph('graph_real_crop_s132', lab_b, means, stds, 132, real_image=fake_scan(lab_b, 2), input_channels=[True],
               output_channel=None, output_shape=32, **train_defaults)
+    # (b'') randomise_res=True (fine_tuning_with_adversary defaults): SampleResolution -> separable 17-tap
+    # DynamicGaussianBlur -> MimicAcquisition with distance map.  Keras' dynamic batch dimension is emulated for
+    # edit_tensors.gaussian_kernel, which decides static-vs-batched sigma from `shape[0] is None` (edit_tensors.py:102-110)
+    _orig_gk = l2i_et.gaussian_kernel
+
+    def gk_none_batch(sigma, max_sigma=None, blur_range=None, separable=True):
+        if isinstance(sigma, shim.T) and sigma.ndim == 2:
+            sigma = sigma.view(shim.T)
+            sigma._none_batch = True
+        return _orig_gk(sigma, max_sigma, blur_range, separable)
+    l2i_et.gaussian_kernel = gk_none_batch
+    kw_rr = dict(train_defaults)
+    kw_rr.update(randomise_res=True)
+    for seed in (141, 142):
+        run_graph('graph_rr_s%d' % seed, lab, means, stds, seed, input_channels=[True], output_channel=[0],
+                  output_shape=32, **kw_rr)
+    run_graph('graph_rr_crop_s143', lab_b, means, stds, 143, input_channels=[True], output_channel=[0],
+              output_shape=32, **kw_rr)
+    l2i_et.gaussian_kernel = _orig_gk
     # (c) Hyperfine-like: 3 channels [False, True, True], 1.5x1.5x5, registration error, no reliability maps
     means3, stds3 = class_stats(rng, ('t1_hr', 't1_lr', 't2'))
     kw = dict(train_defaults)

@@ -130,6 +130,50 @@ def test_whole_graph_real_image_target_vs_golden(env, name):
         m.generate(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], draws)
 
 
+@pytest.mark.parametrize('name', ['graph_rr_s141', 'graph_rr_s142', 'graph_rr_crop_s143'])
+def test_whole_graph_randomise_res_vs_golden(env, name):
+    """randomise_res=True (generator half): random acquisition resolution, separable 17-tap blur,
+    fused nearest-down / linear-up resampling with the distance map as second image channel"""
+    g, m = _model(name, input_channels=[True], output_channel=[0], randomise_res=True)
+    draws = m.draws_from_tape(tape_from_golden(g))
+    image, target, seg = m.generate(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], draws)
+    np.testing.assert_array_equal(seg.cpu().numpy(), g['seg'][0, ..., 0])
+    np.testing.assert_allclose(image.cpu().numpy()[..., 0], g['image'][0, ..., 0], atol=2e-5)
+    np.testing.assert_allclose(image.cpu().numpy()[..., 1], g['image'][0, ..., 1], atol=2e-5)  # distance map (mm)
+    np.testing.assert_allclose(target.cpu().numpy(), g['target'][0], atol=2e-5)
+
+
+def test_randomise_res_two_channels_with_registration_vs_oracle(env):
+    """two randomised input channels, the second with simulated registration error (volume AND distance map are moved),
+    against the oracle on a fresh tape; also exercises the in-kernel Philox path end to end"""
+    from oracle import generator_ref as R
+    from synthsr_amd.labels_to_image_model import labels_to_image_model
+    rng = np.random.default_rng(3)
+    shape = (32, 32, 32)
+    labels = np.kron(np.asarray(GEN)[rng.integers(0, len(GEN), (8, 8, 8))], np.ones((4, 4, 4), np.int32)).astype(np.int32)
+    kw = dict(C2_KW)
+    kw.update(randomise_res=True)
+    m = labels_to_image_model(labels_shape=list(shape), input_channels=[True, True], output_channel=[0],
+                              generation_labels=GEN, n_neutral_labels=len(GEN), aff=np.eye(4), output_shape=32, **kw)
+    means = rng.uniform(20, 220, (len(GEN), 2)).astype(np.float32)
+    stds = rng.uniform(2, 20, (len(GEN), 2)).astype(np.float32)
+    u = lambda *s: rng.random(s, dtype=np.float32)
+    n = lambda *s: rng.standard_normal(s, dtype=np.float32)
+    chan = lambda reg: ([('u', u(1, 1, 1, 1, 1)), ('n', n(1, 4, 4, 4, 1)), ('u', u(1)), ('n', n(1, 1, 1, 1, 1))] +
+                        ([('u', u(1, 3)), ('u', u(1, 3))] if reg else []) +
+                        [('u', u(1)), ('u', u(1, 3)), ('u', np.float32([0.5])), ('u', u(1, 3)), ('u', u(1, 3))] +
+                        ([('u', u(1, 3)), ('u', u(1, 3))] if reg else []))
+    tape = [('u', u(1, 3)), ('u', u(1, 6)), ('u', u(1, 3)), ('u', u(1, 3)), ('u', u(1, 1)), ('n', n(1, 4, 4, 4, 3)),
+            ('u', u(1, 1)), ('n', n(1, 32, 32, 32, 2))] + chan(False) + chan(True)
+    ref = R.labels_to_image(labels, means, stds, tape, GEN, len(GEN), input_channels=[True, True], output_channel=[0],
+                            output_shape=32, **kw)
+    image, target, seg = m.generate(labels, means, stds, m.draws_from_tape(tape))
+    np.testing.assert_array_equal(seg.cpu().numpy(), ref['seg'])
+    assert image.shape[-1] == 4
+    np.testing.assert_allclose(image.cpu().numpy(), ref['image'], atol=2e-4)  # second channel goes through a 4x4 inverse
+    np.testing.assert_allclose(target.cpu().numpy(), ref['target'], atol=2e-5)
+
+
 def test_random_shapes_vs_oracle(env):
     """ragged (non-cubic, odd) label maps with crop + sided labels against the oracle on fresh tapes"""
     from oracle import generator_ref as R

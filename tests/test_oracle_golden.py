@@ -182,3 +182,15 @@ def test_whole_graph_real_image_target(name, gen_labels):
     # trilinear resampling of a [20, 200]-valued scan, then /(max-min): 1e-5 of the unit range
     np.testing.assert_allclose(out['target'], g['target'][0], atol=1e-5)
     assert out['target'].min() == 0.0 and abs(out['target'].max() - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize('name', ['graph_rr_s141', 'graph_rr_s142', 'graph_rr_crop_s143'])
+def test_whole_graph_randomise_res(name, gen_labels):
+    """randomise_res=True: SampleResolution -> separable 17-tap DynamicGaussianBlur -> MimicAcquisition; the
+    second image channel is the distance map (mm) to the nearest acquired grid point"""
+    g, out = _run_graph(name, gen_labels, input_channels=[True], output_channel=[0], randomise_res=True)
+    np.testing.assert_array_equal(out['seg'], g['seg'][0, ..., 0])
+    np.testing.assert_allclose(out['image'][..., 0], g['image'][0, ..., 0], atol=5e-6)
+    np.testing.assert_allclose(out['image'][..., 1], g['image'][0, ..., 1], atol=5e-6)  # distance map
+    np.testing.assert_allclose(out['target'], g['target'][0], atol=5e-6)
+    assert out['image'][..., 1].max() > 0.1  # a real (non-trivial) distance map in at least one direction
