@@ -149,6 +149,13 @@ int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], i
 int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
                        int Cin, int Cout, int act, synthsr_stream_t stream);
 
+/* synthsr_conv3d_fwd followed by synthsr_bn_stats(out) -- BatchNorm batch statistics of the layer output (stats[2C],
+ * ws = 2C doubles of scratch).  For the layers that run on the 4x4x1 kernel the sums are accumulated in the conv
+ * epilogue (per-workgroup partials + a tiny reduction; no extra pass over the activation); otherwise the two calls are
+ * simply chained. */
+int synthsr_conv3d_fwd_stats(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
+                             int Cin, int Cout, int act, float* stats, double* ws, synthsr_stream_t stream);
+
 /* act 0/1: out = act(conv3(in) + addend + bias); addend is indexed like out and may alias it (in-place accumulation).
  * Layers that are split over input channels (small deep levels) accumulate with atomics and require addend == out or NULL.
  * act 2 (data gradient fused with the ELU backward of the layer below): out = conv3(in) * elu'(y), y = addend != out is
@@ -221,6 +228,9 @@ int synthsr_bn_elu_bwd_head(const float* dpred, const float* whead, const float*
  * stats[0..C) = mean, stats[C..2C) = biased variance over the nvox voxels */
 int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* ws /* 2C doubles scratch */,
                      synthsr_stream_t stream);
+/* mean | biased variance from per-workgroup partial sums: partial[nwg][2C] = (sum | sum of squares) over nvox voxels in total */
+int synthsr_bn_stats_from_partials(const float* partial, int nwg, int64_t nvox, int C, float* stats,
+                                   synthsr_stream_t stream);
 /* y = gamma*(x-mean)*rsqrt(var+eps)+beta */
 int synthsr_bn_apply(const float* x, float* y, int64_t nvox, int C, const float* stats, const float* gamma,
                      const float* beta, float eps, synthsr_stream_t stream);

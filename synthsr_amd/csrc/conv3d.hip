@@ -743,7 +743,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_persist_kernel(const float*
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                int D0, int D1, int D2, int Cin, int ncc, int tiles1,
-                                                               int tiles2, int ntiles, int act, const float* addend) {
+                                                               int tiles2, int ntiles, int act, const float* addend,
+                                                               float* __restrict__ stats_partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CK = 24, MT = 4, Cout = 24;
   constexpr int FT1 = MT, FH1 = MT + 2;
@@ -804,12 +805,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
   // results are stored from these registers, which nothing else touches until the next epilogue: re-zeroing `acc` (or
   // reusing temporaries) right after a store would make the wave wait for the store's completion (vmcnt on gfx9)
   float4 outreg[6];
+  // optional BatchNorm statistics of the output: per-lane partial sums / sums of squares over the lane's voxels, reduced
+  // once per workgroup into stats_partial[blockIdx.x][48] (no global atomics: thousands of same-address atomics
+  // serialise); saves the separate bn_stats pass over the 393 MB activation
+  float ps[24], pq[24];
+#pragma unroll
+  for (int c = 0; c < 24; ++c) ps[c] = pq[c] = 0.f;
   float bv[24];  // bias, wave-uniform (scalar registers): loaded once, not per tile
 #pragma unroll
   for (int c = 0; c < 24; ++c) bv[c] = bias ? bias[c] : 0.f;
   float4 stg[NLD];
   int tile = my_pos;
-  if (tile >= ntiles) return;
+  if (tile >= ntiles) {
+    if (stats_partial && tid < 48) stats_partial[(size_t)blockIdx.x * 48 + tid] = 0.f;
+    return;
+  }
   int z0, y0, x0, cc = 0;
   tile_origin(tile, z0, y0, x0);
   {
@@ -920,6 +930,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
             v.w = elu_f(v.w);
           }
           outreg[g] = v;
+          if (stats_partial) {  // wave-uniform
+            ps[4 * g] += v.x;
+            ps[4 * g + 1] += v.y;
+            ps[4 * g + 2] += v.z;
+            ps[4 * g + 3] += v.w;
+            pq[4 * g] = fmaf(v.x, v.x, pq[4 * g]);
+            pq[4 * g + 1] = fmaf(v.y, v.y, pq[4 * g + 1]);
+            pq[4 * g + 2] = fmaf(v.z, v.z, pq[4 * g + 2]);
+            pq[4 * g + 3] = fmaf(v.w, v.w, pq[4 * g + 3]);
+          }
         }
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
@@ -934,6 +954,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_p4_kernel(const float* __re
     y0 = ny0;
     x0 = nx0;
     cc = ncc_;
+  }
+  if (stats_partial) {  // wave butterfly -> LDS [4 waves][48] -> one row of the partial buffer per workgroup
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 24; ++c) {
+      float a = ps[c], q = pq[c];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m, 64);
+        q += __shfl_xor(q, m, 64);
+      }
+      if (lane == 0) {
+        lds[wave * 48 + c] = a;
+        lds[wave * 48 + 24 + c] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 48) stats_partial[(size_t)blockIdx.x * 48 + tid] = lds[tid] + lds[48 + tid] + lds[96 + tid] + lds[144 + tid];
   }
 }
 
@@ -2651,6 +2689,20 @@ __global__ void colsum_kernel(const float* __restrict__ x, int64_t n, int C, flo
   }
 }
 
+// library-owned device scratch (grown on demand, reused by later calls on the same stream order)
+static float* lib_scratch(size_t bytes) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  if (bytes > cap) {
+    if (buf) (void)hipFree(buf);
+    buf = nullptr;
+    cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&buf), bytes) != hipSuccess) return nullptr;
+    cap = bytes;
+  }
+  return buf;
+}
+
 static int g_persist = 1;
 static int g_force_mt = 0;
 static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout % 16 == 8 remainder channels on the
@@ -2839,7 +2891,7 @@ int launch_fwd_persist(const float* in, const float* wp, const float* bias, floa
 }
 
 int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin,
-                  const FwdPlan& pl, int act, hipStream_t st, const float* addend) {
+                  const FwdPlan& pl, int act, hipStream_t st, const float* addend, float* stats = nullptr) {
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
   const int ntiles = tiles0 * tiles1 * tiles2;
   const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
@@ -2851,9 +2903,16 @@ int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* ou
   }
   int gx = 512;
   while (gx > 8 && gx > ntiles) gx -= 8;
+  float* partial = nullptr;
+  if (stats) {  // BatchNorm statistics of the output: per-workgroup partials in library scratch, then a tiny reduction
+    partial = lib_scratch((size_t)gx * 48 * sizeof(float));
+    if (!partial) return SYNTHSR_ELAUNCH;
+  }
   hipLaunchKernelGGL(conv3d_fwd_p4_kernel, dim3(gx), dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, pl.ncc,
-                     tiles1, tiles2, ntiles, act | (g_dbg << 8), addend);
-  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+                     tiles1, tiles2, ntiles, act | (g_dbg << 8), addend, partial);
+  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  if (stats) return synthsr_bn_stats_from_partials(partial, gx, (int64_t)s[0] * s[1] * s[2], 24, stats, st);
+  return SYNTHSR_OK;
 }
 
 template <int NT, int WM, int WN, bool KS>
@@ -3250,20 +3309,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_p4_kernel(const float* __
   if (dbias && cc == 0 && tid < Cout) atomicAdd(dbias + tid, lds[NBLK * 4 * Cout + tid]);
 }
 
-// library-owned device scratch (grown on demand, reused by later calls on the same stream order)
-static float* lib_scratch(size_t bytes) {
-  static float* buf = nullptr;
-  static size_t cap = 0;
-  if (bytes > cap) {
-    if (buf) (void)hipFree(buf);
-    buf = nullptr;
-    cap = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&buf), bytes) != hipSuccess) return nullptr;
-    cap = bytes;
-  }
-  return buf;
-}
-
 int launch_wgrad_c2(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int Cin, hipStream_t st,
                     const WgExt& ext) {
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
@@ -3427,6 +3472,20 @@ int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* b
   const ConvExt ext{0, addend, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
+}
+
+int synthsr_conv3d_fwd_stats(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
+                             int Cin, int Cout, int act, float* stats, double* ws, synthsr_stream_t stream) {
+  if (!in || !wpacked || !out || !shape || !stats || !ws || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 ||
+      shape[2] < 1 || (act != 0 && act != 1))
+    return SYNTHSR_EINVAL;
+  const int64_t nvox = (int64_t)shape[0] * shape[1] * shape[2];
+  const FwdPlan pl = plan_fwd(shape, Cin, Cout);
+  if (pl.p4 && nvox * Cin * 4 < (1ll << 31))  // statistics accumulated in the conv epilogue
+    return launch_fwd_p4(in, wpacked, bias, out, shape, Cin, pl, act, (hipStream_t)stream, nullptr, stats);
+  const int rc = synthsr_conv3d_fwd(in, wpacked, bias, out, shape, Cin, Cout, act, stream);
+  if (rc != SYNTHSR_OK) return rc;
+  return synthsr_bn_stats(out, nvox, Cout, stats, ws, stream);
 }
 
 int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* bias, const float* addend, float* out,

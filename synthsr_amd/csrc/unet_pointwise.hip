@@ -721,6 +721,41 @@ int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* 
   return SYNTHSR_OK;
 }
 
+// mean / variance from per-workgroup partial sums: partial[nwg][2C] (sum | sum of squares), accumulated in double
+__global__ void bn_stats_partials_kernel(const float* __restrict__ partial, int nwg, float* __restrict__ stats, int C,
+                                         double inv_n) {
+  const int c = blockIdx.x;  // one block per channel
+  double a = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nwg; b += blockDim.x) {
+    a += (double)partial[(size_t)b * 2 * C + c];
+    q += (double)partial[(size_t)b * 2 * C + C + c];
+  }
+  __shared__ double sa[64], sq[64];
+  sa[threadIdx.x] = a;
+  sq[threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 64; ++i) {
+      a += sa[i];
+      q += sq[i];
+    }
+    const double m = a * inv_n;
+    double v = q * inv_n - m * m;
+    if (v < 0.0) v = 0.0;
+    stats[c] = (float)m;
+    stats[C + c] = (float)v;
+  }
+}
+
+int synthsr_bn_stats_from_partials(const float* partial, int nwg, int64_t nvox, int C, float* stats,
+                                   synthsr_stream_t stream) {
+  if (!partial || !stats || nwg < 1 || nvox < 1 || C < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(bn_stats_partials_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, nwg, stats, C,
+                     1.0 / (double)nvox);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
 int synthsr_bn_apply(const float* x, float* y, int64_t nvox, int C, const float* stats, const float* gamma,
                      const float* beta, float eps, synthsr_stream_t stream) {
   if (!x || !y || !stats || !gamma || !beta || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;

@@ -158,6 +158,19 @@ def conv3d(x, wpacked, bias, Cout, act=1, out=None):
     return out
 
 
+def conv3d_stats(x, wpacked, bias, Cout, stats, ws, act=1, out=None):
+    """conv3d + BatchNorm batch statistics of its output (fused into the conv epilogue where the kernel supports it)"""
+    lib = _L()
+    s = x.shape
+    if out is None:
+        out = torch.empty((s[0], s[1], s[2], Cout), dtype=torch.float32, device=x.device)
+    with _Timed('conv3d_fwd', s[:3], s[3], Cout):
+        _lib.check(lib.synthsr_conv3d_fwd_stats(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out),
+                                                _lib.i3(s[:3]), int(s[3]), int(Cout), int(act), _lib.ptr(stats),
+                                                _lib.ptr(ws), _lib.stream()), 'conv3d_fwd_stats')
+    return out
+
+
 def conv3d_add(x, wpacked, bias, addend, Cout, act=1, out=None):
     """act 0/1: act(conv3(x) + addend + bias), `addend` may be `out` itself (in-place accumulation);
     act 2: conv3(x) * elu'(addend) -- data gradient fused with the ELU backward of the layer that produced `addend`"""

@@ -272,13 +272,16 @@ class UNet3D:
             e = self.enc[l]
             self.saved['x'].append(cur)
             acts = []
+            nconv = len(e['convs'])
             for k, c in enumerate(e['convs']):
-                cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1,
-                                 out=self.buf('enc%d_%d' % (l, k), self.shapes[l] + [c['cout']]))
+                out = self.buf('enc%d_%d' % (l, k), self.shapes[l] + [c['cout']])
+                if self.training and k == nconv - 1:  # the level's BatchNorm statistics ride in the conv epilogue
+                    cur = ops.conv3d_stats(cur, c['wp'], self.view(c['b']), c['cout'], self._stats(e['bn']), self.bn_ws,
+                                           1, out=out)
+                else:
+                    cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1, out=out)
                 acts.append(cur)
             self.saved['enc'].append(acts)
-            if self.training:
-                ops.bn_stats(cur, self._stats(e['bn']), self.bn_ws)
             if l < L - 1:
                 cur = ops.bn_maxpool(cur, self._stats(e['bn']), self.view(e['bn']['gamma']), self.view(e['bn']['beta']),
                                      out=self.buf('pool%d' % l, self.shapes[l + 1] + [e['bn']['C']]))
@@ -304,14 +307,21 @@ class UNet3D:
                                           out=self.buf('cat%d' % k, self.shapes[l] + [skip.shape[3] + low.shape[3]]))
                 self.saved['cat'].append(cat)
                 cur = cat
+            nconv = len(d['convs'])
+            stats_done = False
             for j, c in enumerate(d['convs']):
                 if d['fold'] and j == 0:
                     continue
-                cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1,
-                                 out=self.buf('dec%d_%d' % (k, j), self.shapes[l] + [c['cout']]))
+                out = self.buf('dec%d_%d' % (k, j), self.shapes[l] + [c['cout']])
+                if self.training and j == nconv - 1:
+                    cur = ops.conv3d_stats(cur, c['wp'], self.view(c['b']), c['cout'], self._stats(d['bn']), self.bn_ws,
+                                           1, out=out)
+                    stats_done = True
+                else:
+                    cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1, out=out)
                 acts.append(cur)
             self.saved['dec'].append(acts)
-            if self.training:
+            if self.training and not stats_done:  # single-conv level whose only conv was the folded one
                 ops.bn_stats(cur, self._stats(d['bn']), self.bn_ws)
             low, low_bn = cur, d['bn']
         self.saved['last'] = (low, low_bn)
