@@ -455,25 +455,45 @@ __global__ __launch_bounds__(256) void head_l1_fwd_kernel(const float* __restric
   }
   __syncthreads();
   float lsum = 0.f;
-  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
-    float acc = 0.f;
-    const float* xp = x + v * C;
-    for (int c = 0; c < C; c += 4) {
-      const float4 a = ld4(xp + c);
-      acc += weff[2 * C + c + 0] * (a.x * weff[c + 0] + weff[C + c + 0]);
-      acc += weff[2 * C + c + 1] * (a.y * weff[c + 1] + weff[C + c + 1]);
-      acc += weff[2 * C + c + 2] * (a.z * weff[c + 2] + weff[C + c + 2]);
-      acc += weff[2 * C + c + 3] * (a.w * weff[c + 3] + weff[C + c + 3]);
+  // 256 voxels per pass: the [256][C] slab is contiguous in memory -> coalesced float4 loads into an LDS tile with rows
+  // padded to C+4 floats (conflict-free 16-byte reads), then one thread per voxel (thread-per-voxel global loads touch 48
+  // cache lines per instruction and ran at 1.7 TB/s)
+  float* tile = smem + 3 * C;
+  const int C4 = C / 4, CP = C + 4;
+  for (int64_t v0 = (int64_t)blockIdx.x * 256; v0 < nvox; v0 += (int64_t)gridDim.x * 256) {
+    const int nv = (int)min((int64_t)256, nvox - v0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nv * C4; i += 256) {
+      const int vl = i / C4, q = i - vl * C4;
+      *reinterpret_cast<float4*>(&tile[vl * CP + q * 4]) = ld4(x + v0 * C + (int64_t)i * 4);
     }
-    acc += b[0];
-    if (residual) acc += residual[v * rs + ro];
-    if (pred) pred[v] = acc;
-    const float e = acc - target[v];
-    lsum += fabsf(e);
-    if (dpred) dpred[v] = (e > 0.f ? inv_n : (e < 0.f ? -inv_n : 0.f));
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+      const int64_t v = v0 + threadIdx.x;
+      float acc = 0.f;
+      const float* xp = tile + threadIdx.x * CP;
+      for (int c = 0; c < C; c += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(xp + c);
+        acc += weff[2 * C + c + 0] * (a.x * weff[c + 0] + weff[C + c + 0]);
+        acc += weff[2 * C + c + 1] * (a.y * weff[c + 1] + weff[C + c + 1]);
+        acc += weff[2 * C + c + 2] * (a.z * weff[c + 2] + weff[C + c + 2]);
+        acc += weff[2 * C + c + 3] * (a.w * weff[c + 3] + weff[C + c + 3]);
+      }
+      acc += b[0];
+      if (residual) acc += residual[v * rs + ro];
+      if (pred) pred[v] = acc;
+      const float e = acc - target[v];
+      lsum += fabsf(e);
+      if (dpred) dpred[v] = (e > 0.f ? inv_n : (e < 0.f ? -inv_n : 0.f));
+    }
   }
+  // one atomic per BLOCK on the single loss word: 16k same-address atomics (one per wave of a 4096-block grid) used to
+  // serialise into ~0.15 ms
   lsum = syn_wave_sum(lsum);
-  if ((threadIdx.x & 63) == 0) atomicAdd(loss, lsum * inv_n);
+  __shared__ float wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n);
 }
 
 __global__ __launch_bounds__(RB) void head_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ x,
@@ -854,8 +874,9 @@ int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats,
                         const float* target, float* pred, float* dpred, float* loss, synthsr_stream_t stream) {
   if (!x || !stats || !gamma || !beta || !w || !b || !target || !loss || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   if (residual && (res_stride < 1 || res_off < 0 || res_off >= res_stride)) return SYNTHSR_EINVAL;
-  hipLaunchKernelGGL(head_l1_fwd_kernel, dim3(syn_grid(nvox, 256, 4096)), dim3(256), 3 * C * sizeof(float),
-                     (hipStream_t)stream, x, nvox, C, stats, gamma, beta, eps, w, b, residual, res_stride, res_off,
+  if (C > 124) return SYNTHSR_EINVAL;  // LDS tile of 256 x (C + 4) floats
+  hipLaunchKernelGGL(head_l1_fwd_kernel, dim3(syn_grid(nvox, 256, 1024)), dim3(256),
+                     (3 * C + 256 * (C + 4)) * sizeof(float), (hipStream_t)stream, x, nvox, C, stats, gamma, beta, eps, w, b, residual, res_stride, res_off,
                      target, pred, dpred, loss, (float)(1.0 / (double)nvox));
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
