@@ -17,7 +17,7 @@ parser.add_argument("path_predictions", type=str,
 parser.add_argument("--cpu", action="store_true", help="(reference flag) CPU inference: not available in this build.")
 parser.add_argument("--threads", type=int, default=1, dest="threads", help="(reference flag) ignored.")
 parser.add_argument("--ct", action="store_true", help="use this flag for ct scans.")
-parser.add_argument("--model", default=None, help="(optional) Use a different model file (.npz checkpoint).")
+parser.add_argument("--model", default=None, help="(optional) Use a different model file (Keras .h5 or .npz checkpoint).")
 parser.add_argument("--disable_flipping", action="store_true",
                     help="(optional) Use this flag to disable flipping augmentation at test time.")
 

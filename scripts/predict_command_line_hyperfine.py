@@ -17,7 +17,7 @@ parser.add_argument("path_predictions", type=str, help="path where to save the s
                                                        "type as path_images (path to a single image or to a folder)")
 parser.add_argument("--cpu", action="store_true", help="(reference flag) CPU inference: not available in this build.")
 parser.add_argument("--threads", type=int, default=1, dest="threads", help="(reference flag) ignored.")
-parser.add_argument("--model", default=None, help="(optional) Use a different model file (.npz checkpoint).")
+parser.add_argument("--model", default=None, help="(optional) Use a different model file (Keras .h5 or .npz checkpoint).")
 
 if __name__ == '__main__':
     args = parser.parse_args()

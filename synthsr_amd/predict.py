@@ -3,9 +3,9 @@ re-orient to RAS, min-max normalise, zero-pad to a multiple of 32, U-Net forward
 with the left-right flipped pass), rescale / clip, crop, save.  Host steps are numpy like the reference's; the U-Net
 runs through the HIP kernels (`UNet3D.predict`, inference-mode BatchNorm with the moving statistics).
 
-The reference ships its weights as a Keras `.h5` (`models/SynthSR_v10_210712.h5`, absent from the reference checkout
-and unreadable here: no h5py); this build reads the `.npz` written by `synthsr_amd.training.save_checkpoint`, whose keys
-are the Keras layer names.
+The reference ships its weights as a Keras `.h5` (`models/SynthSR_v10_210712.h5`, not part of the reference
+checkout); `--model` / `path_model` take such a file (read by the library-free HDF5 reader of keras_h5.py) or the `.npz`
+written by `synthsr_amd.training.save_checkpoint`, whose keys are the same Keras layer names.
 """
 import os
 import numpy as np
@@ -54,13 +54,17 @@ class Predictor:
         self.state = state_dict
         self.n_inputs = n_inputs  # 1: predict_command_line.py; 2 (T1, T2): predict_command_line_hyperfine.py:60-71
         if state_dict is None:
-            path_model = path_model or (DEFAULT_MODEL if n_inputs == 1 else DEFAULT_MODEL_HYPERFINE)
+            if path_model is None:
+                # the reference's own file name first (scripts/predict_command_line.py:79), then our .npz layout
+                default = DEFAULT_MODEL if n_inputs == 1 else DEFAULT_MODEL_HYPERFINE
+                path_model = next((p for p in (default[:-4] + '.h5', default) if os.path.isfile(p)), default)
             if not os.path.isfile(path_model):
-                raise FileNotFoundError('model file %s not found. The reference distributes Keras .h5 weights; convert them '
-                                        'to the .npz layout of synthsr_amd.training.save_checkpoint (INTEGRATION.md §3)'
-                                        % path_model)
-            z = np.load(path_model)
-            self.state = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith('optimizer/')}
+                raise FileNotFoundError('model file %s not found (a Keras .h5 as distributed by the reference, or the '
+                                        '.npz written by synthsr_amd.training.save_checkpoint)' % path_model)
+            from .training import read_weights
+            z = read_weights(path_model)
+            self.state = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in z.items()
+                          if not k.startswith('optimizer/')}
         self.nets = {}
 
     def net_for(self, shape):

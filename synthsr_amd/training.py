@@ -7,7 +7,8 @@ Keras graph {generator -> U-Net -> loss} + `fit_generator` becomes an explicit l
 
 Data parallel: one process per GPU (`torchrun`), batch 1 per GPU, per-rank random streams, gradient
 average over ranks; BN statistics stay per replica (reference semantics at batch 1).
-Checkpoints: `{epoch:03d}.npz` with Keras layer names as keys (rank 0 only).
+Checkpoints (rank 0 only): `{epoch:03d}.npz` (weights under the Keras layer names + Adam state, exact resume) and
+`{epoch:03d}.h5` (Keras save_weights layout, the reference's file name; keras_h5.py).  `checkpoint=` takes either.
 """
 import os
 import time
@@ -113,20 +114,42 @@ class Trainer:
 
 
 def save_checkpoint(path, net):
+    """`.npz`: weights + BN moving statistics + Adam state (exact resume).  `.h5`: the weights in Keras' save_weights
+    layout under the reference's layer names (keras_h5.save_keras_weights), loadable by the reference's
+    `load_weights(path, by_name=True)`; the 1x1x1 head kernel is stored 5-D like every Conv3D kernel."""
     sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    if str(path).lower().endswith(('.h5', '.hdf5')):
+        from .keras_h5 import save_keras_weights
+        save_keras_weights(path, {k: (v.reshape((1, 1, 1) + v.shape) if k.endswith('/kernel') and v.ndim == 2 else v)
+                                  for k, v in sd.items()})
+        return
     sd['optimizer/iterations'] = np.array(net.iterations)
     sd['optimizer/m'] = net.adam_m.cpu().numpy()
     sd['optimizer/v'] = net.adam_v.cpu().numpy()
     np.savez(path, **sd)
 
 
-def load_checkpoint(path, net, by_name=True, skip=()):
-    import torch
+def read_weights(path):
+    """{name: ndarray} of a checkpoint: the .npz of save_checkpoint, or a Keras .h5 as written by the reference
+    (ModelCheckpoint / save_weights, SynthSR/training.py:430) through the library-free reader of keras_h5.py"""
+    if str(path).lower().endswith(('.h5', '.hdf5')):
+        from .keras_h5 import load_keras_weights
+        return load_keras_weights(path)
     z = np.load(path)
-    sd = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith('optimizer/') and
+    return {k: z[k] for k in z.files}
+
+
+def load_checkpoint(path, net, by_name=True, skip=()):
+    """model.load_weights(checkpoint, by_name=True) of SynthSR/training.py:363; Adam state is restored only from our
+    own .npz checkpoints (the reference's load_weights does not restore it either)"""
+    import torch
+    z = read_weights(path)
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in z.items() if not k.startswith('optimizer/') and
           not any(k.startswith(s) for s in skip)}
+    if not any(nm in sd for nm, _, _ in net.specs):
+        raise ValueError('%s holds no weight of this network (layer prefix %r)' % (path, net.prefix))
     net.load_state_dict(sd, strict=False)
-    if 'optimizer/m' in z.files and z['optimizer/m'].shape[0] == net.n_params and not skip:
+    if 'optimizer/m' in z and z['optimizer/m'].shape[0] == net.n_params and not skip:
         net.adam_m.copy_(torch.from_numpy(z['optimizer/m']))
         net.adam_v.copy_(torch.from_numpy(z['optimizer/v']))
         net.iterations = int(z['optimizer/iterations'])
@@ -318,4 +341,5 @@ def training(labels_dir,
             with open(log_path, 'a') as f:
                 f.write('%d,%.8f,%.3f\n' % (epoch + 1, mean_loss, dt))
             save_checkpoint(os.path.join(model_dir, '%03d.npz' % (epoch + 1)), net)
+            save_checkpoint(os.path.join(model_dir, '%03d.h5' % (epoch + 1)), net)  # SynthSR/training.py:429 file name
     return net
