@@ -185,6 +185,18 @@ def resample_volume_like(vol_ref, aff_ref, vol_flo, aff_flo, interpolation='line
     return out.reshape(shape)
 
 
+def rescale_volume(volume, new_min=0, new_max=255, min_percentile=2, max_percentile=98, use_positive_only=False):
+    """ext/lab2im/edit_volumes.py:148-176: clip to the [min_percentile, max_percentile] intensities (of the positive
+    voxels only if use_positive_only) and map that range linearly onto [new_min, new_max]; a constant volume gives zeros"""
+    volume = np.asarray(volume)
+    intensities = volume[volume > 0] if use_positive_only else volume.reshape(-1)
+    robust_min = np.min(intensities) if min_percentile == 0 else np.percentile(intensities, min_percentile)
+    robust_max = np.max(intensities) if max_percentile == 100 else np.percentile(intensities, max_percentile)
+    if robust_min == robust_max:
+        return np.zeros_like(volume)
+    return new_min + (np.clip(volume, robust_min, robust_max) - robust_min) / (robust_max - robust_min) * (new_max - new_min)
+
+
 def get_volume_info(path_volume, return_volume=False, aff_ref=None, max_channels=10):
     im, aff, header = load_volume(path_volume, im_only=False)
     im_shape = list(im.shape)

@@ -323,8 +323,62 @@ def golden_inference():
     print('inference.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
 
 
+def golden_estimate_priors():
+    """SynthSR/estimate_priors.py:76-310 run verbatim on small synthetic datasets written as .npz volumes (the only
+    format utils.load_volume reads without nibabel): two datasets, the second one with 2-channel images."""
+    import tempfile
+    _s = importlib.util.spec_from_file_location('ref_estimate_priors', os.path.join(REF, 'SynthSR', 'estimate_priors.py'))
+    ref_ep = importlib.util.module_from_spec(_s)
+    _s.loader.exec_module(ref_ep)
+    rng = np.random.RandomState(77)
+    labels_list = np.array([0, 2, 3, 4, 17, 41, 42, 53, 99])      # 99 never occurs
+    classes_list = np.array([0, 1, 2, 3, 2, 1, 2, 2, 4])
+    out = dict(labels_list=labels_list, classes_list=classes_list)
+    tmp = tempfile.mkdtemp()
+    dirs = []
+    for d, (n_sub, n_ch) in enumerate([(3, 1), (2, 2)]):
+        im_dir, la_dir = os.path.join(tmp, 'im%d' % d), os.path.join(tmp, 'la%d' % d)
+        os.makedirs(im_dir), os.makedirs(la_dir)
+        for i in range(n_sub):
+            lab = load_label_crop(1 + (i % 2), origin=(50 + 7 * i, 60, 50 + 5 * d), shape=(24, 24, 24)).astype('int32')
+            lab[lab == 41] = 41 if i else 2                       # a label missing from one subject
+            chans = []
+            for c in range(n_ch):
+                mu = rng.uniform(20, 200, 256)
+                im = mu[np.clip(lab, 0, 255)] + 12 * rng.standard_normal(lab.shape)
+                im[rng.uniform(size=lab.shape) < 0.03] = 0        # zeros inside structures (keep_strictly_positive)
+                im[lab == 0] *= (rng.uniform(size=lab.shape) < 0.5)[lab == 0]
+                chans.append(im)
+            im = (np.stack(chans, -1) if n_ch > 1 else chans[0]).astype('float32')
+            np.savez_compressed(os.path.join(im_dir, 's%d.npz' % i), vol_data=im)
+            np.savez_compressed(os.path.join(la_dir, 's%d.npz' % i), vol_data=lab)
+            out['d%d_image_%d' % (d, i)] = im
+            out['d%d_labels_%d' % (d, i)] = lab
+        dirs.append((im_dir, la_dir))
+    res_dir = os.path.join(tmp, 'res')
+    pm, ps = ref_ep.build_intensity_stats([d[0] for d in dirs], [d[1] for d in dirs], res_dir, labels_list, classes_list)
+    out['prior_means'], out['prior_stds'] = pm, ps
+    assert np.array_equal(np.load(os.path.join(res_dir, 'prior_means.npy')), pm)
+    pm1, ps1 = ref_ep.build_intensity_stats(dirs[0][0], dirs[0][1], res_dir, labels_list, None, rescale=False)
+    out['prior_means_noclasses_norescale'], out['prior_stds_noclasses_norescale'] = pm1, ps1
+    # single-image statistics, NaNs included (nanmedian / nan_policy='omit'), with and without the >0 filter
+    im = out['d0_image_0'].copy()
+    im[rng.uniform(size=im.shape) < 0.01] = np.nan
+    out['single_image'] = im
+    out['single_stats'] = ref_ep.sample_intensity_stats_from_image(im, out['d0_labels_0'], labels_list, classes_list)
+    out['single_stats_keep0'] = ref_ep.sample_intensity_stats_from_image(im, out['d0_labels_0'], labels_list, classes_list,
+                                                                         keep_strictly_positive=False)
+    out['rescaled'] = l2i_ev.rescale_volume(out['d0_image_1'][:12])
+    out['rescaled_pos'] = l2i_ev.rescale_volume(out['d0_image_1'][:12], new_min=-1, new_max=1, min_percentile=0,
+                                                max_percentile=99, use_positive_only=True)
+    np.savez_compressed(os.path.join(OUT, 'estimate_priors.npz'), **out)
+    print('estimate_priors', pm.shape, ps.shape, pm1.shape)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs', 'inference']
+    which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs', 'inference', 'estimate_priors']
+    if 'estimate_priors' in which:
+        golden_estimate_priors()
     if 'inference' in which:
         golden_inference()
     if 'resampler' in which:

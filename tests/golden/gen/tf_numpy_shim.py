@@ -598,7 +598,12 @@ def install(feed_queue, reference_root='/root/reference'):
     np.float = float
     np.bool = bool
     if not hasattr(scipy.stats, 'median_absolute_deviation'):
-        scipy.stats.median_absolute_deviation = scipy.stats.median_abs_deviation
+        # scipy 1.4.1 (the version the reference pins, requirements.txt:53): the result is `scale * MAD` with the
+        # default scale 1.4826; today's median_abs_deviation defaults to scale 1.0, so the old default is restated
+        def median_absolute_deviation(x, axis=0, center=np.median, scale=1.4826, nan_policy='propagate'):
+            return scale * scipy.stats.median_abs_deviation(x, axis=axis, center=center, scale=1.0,
+                                                            nan_policy=nan_policy)
+        scipy.stats.median_absolute_deviation = median_absolute_deviation
     mods, named = build_modules(feed_queue)
     sys.modules.update(mods)
     if reference_root not in sys.path:

@@ -48,6 +48,14 @@ def test_training_entry_point_checkpoint_and_resume(tmp_path):
     net2 = training(labels_dir, model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'), str(tmp_path / 'gl.npy'),
                     epochs=2, checkpoint=ck, **kw)
     assert net2.iterations == 6 and os.path.exists(os.path.join(model_dir, '002.npz'))
+    # the reference's checkpoint name, Keras layout: same weights as the .npz, and training resumes from it by name
+    from synthsr_amd.keras_h5 import load_keras_weights
+    h5 = load_keras_weights(os.path.join(model_dir, '001.h5'))
+    assert all(np.array_equal(h5[k].reshape(z[k].shape), z[k]) for k in z.files if not k.startswith('optimizer/'))
+    assert len(h5) == len([k for k in z.files if not k.startswith('optimizer/')])
+    net3 = training(labels_dir, model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'), str(tmp_path / 'gl.npy'),
+                    epochs=2, checkpoint=os.path.join(model_dir, '001.h5'), **kw)
+    assert net3.iterations == 3  # weights only: the optimizer restarts, like load_weights(by_name=True) in the reference
     # argument validation mirrors the reference's exceptions
     with pytest.raises(Exception):
         training(labels_dir, model_dir, None, None, str(tmp_path / 'gl.npy'), output_channel=None)
