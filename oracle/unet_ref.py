@@ -125,6 +125,33 @@ def l1_loss(pred, target):
     return (pred - target).abs().mean()
 
 
+def regression_loss(pred, target, kind='l1', loss_cropping=None, residual=None):
+    """SynthSR/metrics_model.py:27-132.  pred [d0,d1,d2,K] (K = 2 for 'laplace': intensity, spread), target
+    [d0,d1,d2,1], residual [d0,d1,d2,1] or None (added to the intensity channel, :53-64); loss_cropping: sizes of the
+    centred box (begin = int((shape - size) / 2), :76-90)."""
+    if kind == 'laplace':
+        intens, spread = pred[..., :1], pred[..., 1:2]
+    else:
+        intens, spread = pred, None
+    if residual is not None:
+        intens = intens + residual
+    if loss_cropping is not None:
+        size = [int(loss_cropping)] * 3 if not hasattr(loss_cropping, '__len__') else [int(v) for v in loss_cropping]
+        b = [int((s - c) / 2) for s, c in zip(target.shape[:3], size)]
+        sl = tuple(slice(b[i], b[i] + size[i]) for i in range(3))
+        intens, target = intens[sl], target[sl]
+        spread = None if spread is None else spread[sl]
+    err = intens - target
+    if kind == 'l1':
+        return err.abs().mean()
+    if kind == 'l2':
+        return (err * err).mean()
+    if kind == 'laplace':
+        bb = 1e-5 + 0.02 * torch.exp(spread)
+        return (torch.log(2 * bb) + err.abs() / bb).mean()
+    raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(kind))
+
+
 def adam_keras(p, g, m, v, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, decay=0.0):
     """keras.optimizers.Adam (2.3.1) update; t = iterations + 1. Returns (p, m, v)"""
     if decay > 0:

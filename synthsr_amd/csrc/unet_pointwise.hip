@@ -433,32 +433,44 @@ __global__ __launch_bounds__(256) void upsample_concat_bwd_kernel(const float* _
   }
 }
 
-// ------------------------------------------------------------------------------------------ head + L1 loss
-__global__ __launch_bounds__(256) void head_l1_fwd_kernel(const float* __restrict__ x, int64_t nvox, int C,
-                                                          const float* __restrict__ stats,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps,
-                                                          const float* __restrict__ w, const float* __restrict__ b,
-                                                          const float* __restrict__ residual, int rs, int ro,
-                                                          const float* __restrict__ target, float* __restrict__ pred,
-                                                          float* __restrict__ dpred, float* __restrict__ loss,
-                                                          float inv_n) {
-  extern __shared__ float smem[];  // weff[C], then 1 float bias_eff
-  // fold BN into the 1x1x1 conv: pred = sum_c (w*sc)[c]*x[c] + (b + sum_c w[c]*sh[c])
+// ------------------------------------------------------------------------------------------ head + regression loss
+// unet_likelihood (1x1x1 conv on the last BatchNorm output, K output channels) + the loss of SynthSR/metrics_model.py:30-132
+//   kind 0  'l1'      mean |pred - target|                          (K = 1)
+//   kind 1  'l2'      mean (pred - target)^2                        (K = 1)
+//   kind 2  'laplace' mean( log(2 b) + |pred_0 - target| / b ),  b = 1e-5 + 0.02 exp(pred_1)     (K = 2)
+// optionally evaluated on a centred box only (loss_cropping, metrics_model.py:70-90): voxels outside contribute neither
+// loss nor gradient; inv_n = 1 / (voxels inside).  dpred [nvox][K] is the loss gradient w.r.t. pred.
+struct HeadBox {
+  int on, d1, d2;
+  int lo[3], hi[3];
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restrict__ x, int64_t nvox, int C,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ residual, int rs, int ro,
+                                                            const float* __restrict__ target, float* __restrict__ pred,
+                                                            float* __restrict__ dpred, float* __restrict__ loss,
+                                                            float inv_n, int kind, HeadBox box) {
+  extern __shared__ float smem[];  // scale[C], shift[C], w[C][K], then the voxel tile
   float* weff = smem;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sc, sh;
     bn_coeff(stats, gamma, beta, eps, C, c, sc, sh);
     weff[c] = sc;         // keep scale and shift separately: pred accumulates w*(x*sc+sh) like the unfused graph
     weff[C + c] = sh;
-    weff[2 * C + c] = w[c];
+#pragma unroll
+    for (int k = 0; k < K; ++k) weff[2 * C + k * C + c] = w[c * K + k];
   }
   __syncthreads();
   float lsum = 0.f;
   // 256 voxels per pass: the [256][C] slab is contiguous in memory -> coalesced float4 loads into an LDS tile with rows
   // padded to C+4 floats (conflict-free 16-byte reads), then one thread per voxel (thread-per-voxel global loads touch 48
   // cache lines per instruction and ran at 1.7 TB/s)
-  float* tile = smem + 3 * C;
+  float* tile = smem + (2 + K) * C;
   const int C4 = C / 4, CP = C + 4;
   for (int64_t v0 = (int64_t)blockIdx.x * 256; v0 < nvox; v0 += (int64_t)gridDim.x * 256) {
     const int nv = (int)min((int64_t)256, nvox - v0);
@@ -470,21 +482,58 @@ __global__ __launch_bounds__(256) void head_l1_fwd_kernel(const float* __restric
     __syncthreads();
     if ((int)threadIdx.x < nv) {
       const int64_t v = v0 + threadIdx.x;
-      float acc = 0.f;
+      float acc[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] = 0.f;
       const float* xp = tile + threadIdx.x * CP;
       for (int c = 0; c < C; c += 4) {
         const float4 a = *reinterpret_cast<const float4*>(xp + c);
-        acc += weff[2 * C + c + 0] * (a.x * weff[c + 0] + weff[C + c + 0]);
-        acc += weff[2 * C + c + 1] * (a.y * weff[c + 1] + weff[C + c + 1]);
-        acc += weff[2 * C + c + 2] * (a.z * weff[c + 2] + weff[C + c + 2]);
-        acc += weff[2 * C + c + 3] * (a.w * weff[c + 3] + weff[C + c + 3]);
+        const float n0 = a.x * weff[c + 0] + weff[C + c + 0], n1 = a.y * weff[c + 1] + weff[C + c + 1];
+        const float n2 = a.z * weff[c + 2] + weff[C + c + 2], n3 = a.w * weff[c + 3] + weff[C + c + 3];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const float* wk = weff + 2 * C + k * C + c;
+          acc[k] += wk[0] * n0;
+          acc[k] += wk[1] * n1;
+          acc[k] += wk[2] * n2;
+          acc[k] += wk[3] * n3;
+        }
       }
-      acc += b[0];
-      if (residual) acc += residual[v * rs + ro];
-      if (pred) pred[v] = acc;
-      const float e = acc - target[v];
-      lsum += fabsf(e);
-      if (dpred) dpred[v] = (e > 0.f ? inv_n : (e < 0.f ? -inv_n : 0.f));
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += b[k];
+      if (residual) acc[0] += residual[v * rs + ro];
+      if (pred) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) pred[v * K + k] = acc[k];
+      }
+      bool inside = true;
+      if (box.on) {
+        const int xx = (int)(v % box.d2), yy = (int)((v / box.d2) % box.d1), zz = (int)(v / ((int64_t)box.d1 * box.d2));
+        inside = zz >= box.lo[0] && zz < box.hi[0] && yy >= box.lo[1] && yy < box.hi[1] && xx >= box.lo[2] && xx < box.hi[2];
+      }
+      const float e = acc[0] - target[v];
+      float g[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) g[k] = 0.f;
+      if (inside) {
+        const float sgn = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+        if (K == 2) {  // laplace
+          const float ex = 0.02f * expf(acc[K - 1]), bb = 1e-5f + ex, ib = 1.f / bb;
+          lsum += logf(2.f * bb) + fabsf(e) * ib;
+          g[0] = sgn * ib * inv_n;
+          g[K - 1] = (ib - fabsf(e) * ib * ib) * ex * inv_n;
+        } else if (kind == 1) {
+          lsum += e * e;
+          g[0] = 2.f * e * inv_n;
+        } else {
+          lsum += fabsf(e);
+          g[0] = sgn * inv_n;
+        }
+      }
+      if (dpred) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) dpred[v * K + k] = g[k];
+      }
     }
   }
   // one atomic per BLOCK on the single loss word: 16k same-address atomics (one per wave of a 4096-block grid) used to
@@ -494,6 +543,64 @@ __global__ __launch_bounds__(256) void head_l1_fwd_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = lsum;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(loss, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n);
+}
+
+// K-channel head backward (K > 1, e.g. the intensity + spread channels of the 'laplace' loss): the gradient w.r.t. the
+// BatchNorm output, dbn[v][c] = sum_k g[v][k] w[c][k], is written out; dw[c][k] += gamma[c] A_k[c] + beta[c] B_k,
+// db[k] += B_k with A_k[c] = sum_v g_k xhat[v][c], B_k = sum_v g_k.
+template <int K>
+__global__ __launch_bounds__(RB) void head_multi_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ x,
+                                                            int64_t n4, int C, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            const float* __restrict__ w, float* __restrict__ dbn,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+  extern __shared__ float smem[];  // A[K][C], B[K]
+  const int C4 = C / 4;
+  const bool fixed = (RB % C4) == 0;
+  for (int i = threadIdx.x; i < K * C + K; i += RB) smem[i] = 0.f;
+  __syncthreads();
+  float4 part[K];
+  float dbp[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dbp[k] = 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    const int64_t v = i / C4;
+    const float4 a = ld4(x + i * 4);
+    float4 xh;
+    xh.x = (a.x - stats[c + 0]) * rsqrtf(stats[C + c + 0] + eps);
+    xh.y = (a.y - stats[c + 1]) * rsqrtf(stats[C + c + 1] + eps);
+    xh.z = (a.z - stats[c + 2]) * rsqrtf(stats[C + c + 2] + eps);
+    xh.w = (a.w - stats[c + 3]) * rsqrtf(stats[C + c + 3] + eps);
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float g = dpred[v * K + k];
+      d.x += g * w[(c + 0) * K + k]; d.y += g * w[(c + 1) * K + k];
+      d.z += g * w[(c + 2) * K + k]; d.w += g * w[(c + 3) * K + k];
+      if (fixed) {
+        part[k].x += g * xh.x; part[k].y += g * xh.y; part[k].z += g * xh.z; part[k].w += g * xh.w;
+      } else {
+        atomicAdd(&smem[k * C + c + 0], g * xh.x); atomicAdd(&smem[k * C + c + 1], g * xh.y);
+        atomicAdd(&smem[k * C + c + 2], g * xh.z); atomicAdd(&smem[k * C + c + 3], g * xh.w);
+      }
+      if (c == 0) dbp[k] += g;
+    }
+    st4(dbn + i * 4, d);
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) atomicAdd(&smem[K * C + k], dbp[k]);
+  block_channel_reduce<K>(part, threadIdx.x % C4, C4, fixed, smem);
+  for (int i = threadIdx.x; i < C * K; i += RB) {
+    const int c = i / K, k = i - c * K;
+    atomicAdd(&dw[i], gamma[c] * smem[k * C + c] + beta[c] * smem[K * C + k]);
+  }
+  if (threadIdx.x < K) atomicAdd(&db[threadIdx.x], smem[K * C + threadIdx.x]);
 }
 
 __global__ __launch_bounds__(RB) void head_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ x,
@@ -869,15 +976,65 @@ int synthsr_upsample_concat_bwd(const float* dcat, float* dskip, float* dlo_bn, 
   return SYNTHSR_OK;
 }
 
+int synthsr_head_loss_fwd(const float* x, const int* shape, int C, const float* stats, const float* gamma,
+                          const float* beta, float eps, const float* w, const float* b, int K, const float* residual,
+                          int res_stride, int res_off, const float* target, float* pred, float* dpred, float* loss, int kind,
+                          const int* crop, synthsr_stream_t stream) {
+  if (!x || !shape || !stats || !gamma || !beta || !w || !b || !target || !loss || !ok_c4(C)) return SYNTHSR_EINVAL;
+  if (shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
+  if (residual && (res_stride < 1 || res_off < 0 || res_off >= res_stride)) return SYNTHSR_EINVAL;
+  if (kind < 0 || kind > 2 || K != (kind == 2 ? 2 : 1)) return SYNTHSR_EINVAL;
+  if (C > 120) return SYNTHSR_EINVAL;  // LDS tile of 256 x (C + 4) floats
+  const int64_t nvox = (int64_t)shape[0] * shape[1] * shape[2];
+  HeadBox box;
+  box.on = crop != nullptr;
+  box.d1 = shape[1];
+  box.d2 = shape[2];
+  int64_t n_in = nvox;
+  if (crop) {
+    n_in = 1;
+    for (int i = 0; i < 3; ++i) {
+      if (crop[i] < 0 || crop[3 + i] < 1 || crop[i] + crop[3 + i] > shape[i]) return SYNTHSR_EINVAL;
+      box.lo[i] = crop[i];
+      box.hi[i] = crop[i] + crop[3 + i];
+      n_in *= crop[3 + i];
+    }
+  } else {
+    for (int i = 0; i < 3; ++i) {
+      box.lo[i] = 0;
+      box.hi[i] = shape[i];
+    }
+  }
+  const size_t smem = ((2 + K) * C + 256 * (C + 4)) * sizeof(float);
+  const float inv_n = (float)(1.0 / (double)n_in);
+  const dim3 grid(syn_grid(nvox, 256, 1024));
+  if (K == 1)
+    hipLaunchKernelGGL(head_loss_fwd_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta,
+                       eps, w, b, residual, res_stride, res_off, target, pred, dpred, loss, inv_n, kind, box);
+  else
+    hipLaunchKernelGGL(head_loss_fwd_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta,
+                       eps, w, b, residual, res_stride, res_off, target, pred, dpred, loss, inv_n, kind, box);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
 int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta,
                         float eps, const float* w, const float* b, const float* residual, int res_stride, int res_off,
                         const float* target, float* pred, float* dpred, float* loss, synthsr_stream_t stream) {
-  if (!x || !stats || !gamma || !beta || !w || !b || !target || !loss || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
-  if (residual && (res_stride < 1 || res_off < 0 || res_off >= res_stride)) return SYNTHSR_EINVAL;
-  if (C > 124) return SYNTHSR_EINVAL;  // LDS tile of 256 x (C + 4) floats
-  hipLaunchKernelGGL(head_l1_fwd_kernel, dim3(syn_grid(nvox, 256, 1024)), dim3(256),
-                     (3 * C + 256 * (C + 4)) * sizeof(float), (hipStream_t)stream, x, nvox, C, stats, gamma, beta, eps, w, b, residual, res_stride, res_off,
-                     target, pred, dpred, loss, (float)(1.0 / (double)nvox));
+  if (nvox < 1 || nvox >= (1ll << 31)) return SYNTHSR_EINVAL;
+  const int shape[3] = {1, 1, (int)nvox};
+  return synthsr_head_loss_fwd(x, shape, C, stats, gamma, beta, eps, w, b, 1, residual, res_stride, res_off, target, pred,
+                               dpred, loss, 0, nullptr, stream);
+}
+
+int synthsr_head_bwd_multi(const float* dpred, const float* x, int64_t nvox, int C, int K, const float* stats,
+                           const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw,
+                           float* db, synthsr_stream_t stream) {
+  if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C) || K != 2)
+    return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(head_multi_bwd_kernel<2>, dim3(syn_grid(n4, RB, 1024)), dim3(RB), (2 * C + 2) * sizeof(float),
+                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

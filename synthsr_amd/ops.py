@@ -312,6 +312,43 @@ def head_l1_fwd(x, stats, gamma, beta, w, b, target, loss, pred=None, dpred=None
     return loss
 
 
+LOSS_KINDS = {'l1': 0, 'l2': 1, 'laplace': 2}
+
+
+def head_loss_fwd(x, stats, gamma, beta, w, b, target, loss, kind='l1', crop=None, pred=None, dpred=None, residual=None,
+                  res_stride=1, res_off=0, eps=BN_EPS):
+    """unet_likelihood + regression loss (metrics_model.py:30-132).  x [d0,d1,d2,C]; w [C,K] with K = 2 for 'laplace'
+    (intensity, spread), else 1; crop = (begin[3], size[3]) of the loss_cropping box or None; pred / dpred [nvox,K]"""
+    lib = _L()
+    C = int(x.shape[-1])
+    if x.dim() != 4:
+        raise ValueError('x should be [d0, d1, d2, C]')
+    K = 2 if kind == 'laplace' else 1
+    if w.numel() != C * K:
+        raise ValueError('head kernel should hold %d x %d weights for the %s loss, has %d' % (C, K, kind, w.numel()))
+    shape = _lib.I3(*[int(v) for v in x.shape[:3]])
+    box = None
+    if crop is not None:
+        box = (_lib.c_int * 6)(*([int(v) for v in crop[0]] + [int(v) for v in crop[1]]))
+    _lib.check(lib.synthsr_head_loss_fwd(_lib.ptr(x), shape, C, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps,
+                                         _lib.ptr(w), _lib.ptr(b), K, _lib.ptr(residual), int(res_stride), int(res_off),
+                                         _lib.ptr(target), _lib.ptr(pred), _lib.ptr(dpred), _lib.ptr(loss),
+                                         LOSS_KINDS[kind], box, _lib.stream()), 'head_loss_fwd')
+    return loss
+
+
+def head_bwd_multi(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS):
+    """K-channel head backward (K = 2): dbn = dpred @ w^T written, dw [C,K] and db [K] accumulated"""
+    lib = _L()
+    C = int(x.shape[-1])
+    nvox = x.numel() // C
+    K = w.numel() // C
+    _lib.check(lib.synthsr_head_bwd_multi(_lib.ptr(dpred), _lib.ptr(x), nvox, C, K, _lib.ptr(stats), _lib.ptr(gamma),
+                                          _lib.ptr(beta), eps, _lib.ptr(w), _lib.ptr(dbn), _lib.ptr(dw), _lib.ptr(db),
+                                          _lib.stream()), 'head_bwd_multi')
+    return dbn
+
+
 def head_bwd(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS, bn_sums=None):
     """dbn (optional) = dpred (x) w; dw, db +=; bn_sums (optional) += BN-backward channel sums of that gradient"""
     lib = _L()

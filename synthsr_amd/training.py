@@ -63,7 +63,19 @@ class Trainer:
     """generator + U-Net + L1 + Adam for one rank"""
 
     def __init__(self, brain_generator, net, lr=1e-4, lr_decay=0.0, work_with_residual_channel=None,
-                 distributed=False, bucket_elems=2 * 1024 * 1024, force_allreduce=False, seg_regulariser=None):
+                 distributed=False, bucket_elems=2 * 1024 * 1024, force_allreduce=False, seg_regulariser=None,
+                 regression_metric='l1', loss_cropping=None):
+        if regression_metric not in ('l1', 'l2', 'laplace'):
+            if regression_metric == 'ssim':
+                raise NotImplementedError("regression_metric='ssim' (tf.image.ssim over three slice orientations, "
+                                          "metrics_model.py:105-125) is not built")
+            raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(
+                regression_metric))  # the reference's message (metrics_model.py:127), typo included
+        if regression_metric == 'laplace' and seg_regulariser is not None:
+            raise NotImplementedError('the laplace loss together with the segmentation loss is not built')
+        if loss_cropping is not None and seg_regulariser is not None:
+            raise NotImplementedError('loss_cropping together with the segmentation loss is not built')
+        self.metric, self.loss_cropping = regression_metric, loss_cropping
         self.bg = brain_generator
         self.seg = seg_regulariser  # synthsr_amd.seg_loss.SegmentationRegulariser or None
         self.gen = brain_generator.labels_to_image_model
@@ -95,8 +107,8 @@ class Trainer:
         residual, rs, ro = None, 1, 0
         if self.residual is not None:
             residual, rs, ro = image, image.shape[-1], int(self.residual[0])
-        loss, pred = net.loss_l1(image, target.reshape(-1), residual=residual, res_stride=rs, res_off=ro,
-                                 want_pred=self.seg is not None)
+        loss, pred = net.loss(image, target.reshape(-1), self.metric, self.loss_cropping, residual=residual,
+                              res_stride=rs, res_off=ro, want_pred=self.seg is not None)
         if self.seg is not None:  # total = image loss + w * Dice(frozen segmentation net(prediction), labels)
             if list(seg.shape) != list(image.shape[:3]):
                 raise NotImplementedError('segmentation loss with a target resolution different from the label maps')
@@ -233,10 +245,10 @@ def training(labels_dir,
             # the reference repeats the python list here (`2 * list`, F11) instead of doubling the indices
             raise NotImplementedError('work_with_residual_channel together with build_reliability_maps=True is '
                                       'ill-defined in the reference (SURVEY F11); set build_reliability_maps=False')
-    if regression_metric != 'l1':
-        raise NotImplementedError("only regression_metric='l1' is built yet")
-    if loss_cropping not in (None, 0):
-        raise NotImplementedError('loss_cropping is not built yet')
+    if regression_metric == 'ssim':
+        raise NotImplementedError("regression_metric='ssim' is not built ('l1', 'l2', 'laplace' are)")
+    if regression_metric not in ('l1', 'l2', 'laplace'):
+        raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(regression_metric))
     if dropout != 0:
         raise NotImplementedError('dropout is not supported')
     if batchsize != 1:
@@ -278,8 +290,11 @@ def training(labels_dir,
                                      bias_shape_factor=bias_shape_factor, rng=rng)
     brain_generator.labels_to_image_model.seed(seed, rank)
     unet_input_shape = brain_generator.model_output_shape
+    n_output_channels = 1 if output_channel is None else len(output_channel)
+    if regression_metric == 'laplace':  # intensities + spreads (SynthSR/training.py:325-326)
+        n_output_channels *= 2
     net = build_unet(nb_features=unet_feat_count, input_shape=unet_input_shape, nb_levels=n_levels,
-                     conv_size=conv_size, nb_labels=(1 if output_channel is None else len(output_channel)),  # training.py:246-249
+                     conv_size=conv_size, nb_labels=n_output_channels,  # training.py:246-249, 325-326
                      feat_mult=feat_multiplier,
                      nb_conv_per_level=nb_conv_per_level, conv_dropout=dropout, final_pred_activation='linear',
                      batch_norm=-1, activation=activation, input_model=brain_generator.labels_to_image_model,
@@ -319,8 +334,10 @@ def training(labels_dir,
         seg_reg = SegmentationRegulariser(seg_net, brain_generator.generation_labels,
                                           hm.load_array_if_path(segmentation_label_equivalency),
                                           relative_weight_segmentation, m=m, M=M, fs_header=fs_header_segnet)
+    if loss_cropping == 0:
+        loss_cropping = None
     trainer = Trainer(brain_generator, net, lr, lr_decay, work_with_residual_channel, distributed=dist_on,
-                      seg_regulariser=seg_reg)
+                      seg_regulariser=seg_reg, regression_metric=regression_metric, loss_cropping=loss_cropping)
 
     log_path = os.path.join(model_dir, 'logs', 'loss.csv')
     if rank == 0:

@@ -37,8 +37,12 @@ class UNet3D:
         # (SynthSR/training.py:373-389); it is only run through predict_probs() / backward_input()
         if final_pred_activation not in ('linear', 'softmax'):
             raise NotImplementedError("final_pred_activation should be 'linear' or 'softmax'")
-        if (nb_labels != 1) != (final_pred_activation == 'softmax'):
-            raise NotImplementedError('supported heads: 1 linear output channel, or nb_labels > 1 with softmax')
+        # linear heads: 1 channel ('l1' / 'l2'), or 2 = intensity + spread of the 'laplace' loss (SynthSR/training.py:325-326)
+        if final_pred_activation == 'softmax' and nb_labels < 2:
+            raise NotImplementedError('a softmax head needs nb_labels > 1')
+        if final_pred_activation == 'linear' and nb_labels not in (1, 2):
+            raise NotImplementedError('supported linear heads: 1 output channel, or 2 (laplace: intensity + spread)')
+        self.final_pred_activation = final_pred_activation
         self.nb_labels = int(nb_labels)
         self.need_input_grad = False  # True: also keep the data-gradient weights of the first conv (backward_input)
         if len(input_shape) != 4:
@@ -327,21 +331,42 @@ class UNet3D:
         self.saved['last'] = (low, low_bn)
         return low, low_bn
 
-    def loss_l1(self, x, target, residual=None, res_stride=1, res_off=0, want_pred=False):
-        """forward + unet_likelihood + L1 (SynthSR/metrics_model.py:102-104). Returns (loss tensor[1], pred|None)"""
+    def loss(self, x, target, kind='l1', loss_cropping=None, residual=None, res_stride=1, res_off=0, want_pred=False):
+        """forward + unet_likelihood + regression loss (SynthSR/metrics_model.py:30-132): kind 'l1' | 'l2' | 'laplace'
+        (2-channel head: intensity, spread); loss_cropping = sizes of the centred box the loss is averaged over
+        (metrics_model.py:70-90).  Returns (loss tensor[1], pred [nvox*K] | None)"""
+        K = 2 if kind == 'laplace' else 1
+        if self.final_pred_activation != 'linear' or self.nb_labels != K:
+            raise ValueError('the %s loss needs a linear head with %d output channel(s), this network has %d (%s)'
+                             % (kind, K, self.nb_labels, self.final_pred_activation))
         low, bn = self.forward(x)
         nvox = low.numel() // low.shape[3]
+        crop = None
+        if loss_cropping is not None:
+            size = [int(loss_cropping)] * 3 if np.ndim(loss_cropping) == 0 else [int(v) for v in loss_cropping]
+            shape = [int(v) for v in low.shape[:3]]
+            if len(size) != 3 or any(c < 1 or c > s for c, s in zip(size, shape)):
+                raise ValueError('loss_cropping %s does not fit the output shape %s' % (size, shape))
+            crop = ([int((s - c) / 2) for s, c in zip(shape, size)], size)
         self.loss_buf = self.buf('loss', [1])
         self.loss_buf.zero_()
-        self.dpred = self.buf('dpred', [nvox])
-        pred = self.buf('pred', [nvox]) if want_pred else None
-        ops.head_l1_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']), self.view(self.head['w']),
-                        self.view(self.head['b']), target, self.loss_buf, pred=pred, dpred=self.dpred,
-                        residual=residual, res_stride=res_stride, res_off=res_off)
+        self.dpred = self.buf('dpred', [nvox * K])
+        pred = self.buf('pred', [nvox * K]) if want_pred else None
+        ops.head_loss_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']), self.view(self.head['w']),
+                          self.view(self.head['b']), target, self.loss_buf, kind=kind, crop=crop, pred=pred,
+                          dpred=self.dpred, residual=residual, res_stride=res_stride, res_off=res_off)
         return self.loss_buf, pred
 
+    def loss_l1(self, x, target, residual=None, res_stride=1, res_off=0, want_pred=False):
+        """forward + unet_likelihood + L1 (SynthSR/metrics_model.py:102-104). Returns (loss tensor[1], pred|None)"""
+        return self.loss(x, target, 'l1', None, residual, res_stride, res_off, want_pred)
+
     def predict(self, x):
-        """inference forward (moving statistics): x [d0,d1,d2,Cin] -> [d0,d1,d2,1]"""
+        """inference forward (moving statistics): x [d0,d1,d2,Cin] -> [d0,d1,d2,K] (K = 2 for a laplace head:
+        intensity, spread)"""
+        if self.final_pred_activation != 'linear':
+            raise ValueError('predict() is for linear heads; use predict_probs() for a softmax head')
+        K = self.nb_labels
         was = self.training
         self.training = False
         try:
@@ -351,12 +376,13 @@ class UNet3D:
             zero_t.zero_()
             loss = self.buf('loss', [1])
             loss.zero_()
-            pred = self.buf('pred', [nvox])
-            ops.head_l1_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
-                            self.view(self.head['w']), self.view(self.head['b']), zero_t, loss, pred=pred)
+            pred = self.buf('pred', [nvox * K])
+            ops.head_loss_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
+                              self.view(self.head['w']), self.view(self.head['b']), zero_t, loss,
+                              kind='laplace' if K == 2 else 'l1', pred=pred)
         finally:
             self.training = was
-        return pred.view(*self.input_shape[:3], 1)
+        return pred.view(*self.input_shape[:3], K)
 
     # ------------------------------------------------------------------ frozen use (segmentation network)
     def enable_input_grad(self):
@@ -404,6 +430,11 @@ class UNet3D:
         G.zero_()
         # the gradient w.r.t. the last BatchNorm output is rank-1 (dpred[v] * w_head[c]): it is neither stored nor
         # reduced; head_bwd emits that BN's backward sums and the first ELU backward forms it on the fly
+        if self.nb_labels > 1:  # K-channel linear head (laplace): the gradient w.r.t. the BN output is written out
+            dbn = self.buf('dbn_head', list(low.shape))
+            ops.head_bwd_multi(self.dpred, low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
+                               self.view(self.head['w']), dbn, self.view(self.head['w'], G), self.view(self.head['b'], G))
+            return self._backward_body(dbn, on_grad_ready)
         off = self.offsets[bn['beta']][0]
         sums = self.grads[off:off + 2 * bn['C']]
         ops.head_bwd(self.dpred, low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),

@@ -323,6 +323,37 @@ def golden_inference():
     print('inference.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
 
 
+def golden_metrics():
+    """SynthSR/metrics_model.py:27-132 (`metrics_model`) run verbatim on a stand-in input model: l1 / l2 / laplace, with
+    and without loss_cropping and work_with_residual_channel"""
+    import types
+    _s = importlib.util.spec_from_file_location('ref_metrics_model', os.path.join(REF, 'SynthSR', 'metrics_model.py'))
+    ref_mm = importlib.util.module_from_spec(_s)
+    _s.loader.exec_module(ref_mm)
+    rng = np.random.RandomState(5)
+    shape = (1, 14, 12, 11)  # last spatial size > 10: utils.get_dims reads a smaller one as a channel count
+    out = dict(pred1=rng.standard_normal(shape + (1,)).astype('float32'),
+               pred2=rng.standard_normal(shape + (2,)).astype('float32'),
+               target=rng.uniform(0, 1, shape + (1,)).astype('float32'),
+               image_out=rng.uniform(0, 1, shape + (2,)).astype('float32'),
+               loss_cropping=np.array([8, 6, 4]))
+
+    def run(metrics, crop, residual):
+        layers_ = {'regression_target': t(out['target']), 'image_out': t(out['image_out'])}
+        m = types.SimpleNamespace(outputs=[t(out['pred2' if metrics == 'laplace' else 'pred1'])], inputs=[],
+                                  get_layer=lambda name: types.SimpleNamespace(output=layers_[name]))
+        model = ref_mm.metrics_model(m, loss_cropping=crop, metrics=metrics, work_with_residual_channel=residual)
+        return np.asarray(model.outputs, dtype='float64')
+
+    for metrics in ('l1', 'l2', 'laplace'):
+        out['loss_%s' % metrics] = run(metrics, None, None)
+        out['loss_%s_crop' % metrics] = run(metrics, [8, 6, 4], None)
+        out['loss_%s_res1' % metrics] = run(metrics, None, [1])
+        out['loss_%s_crop_res1' % metrics] = run(metrics, [8, 6, 4], [1])
+    np.savez_compressed(os.path.join(OUT, 'metrics.npz'), **out)
+    print('metrics', {k: float(v) for k, v in out.items() if k.startswith('loss_') and v.ndim == 0})
+
+
 def golden_estimate_priors():
     """SynthSR/estimate_priors.py:76-310 run verbatim on small synthetic datasets written as .npz volumes (the only
     format utils.load_volume reads without nibabel): two datasets, the second one with 2-channel images."""
@@ -376,7 +407,9 @@ def golden_estimate_priors():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs', 'inference', 'estimate_priors']
+    which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs', 'inference', 'estimate_priors', 'metrics']
+    if 'metrics' in which:
+        golden_metrics()
     if 'estimate_priors' in which:
         golden_estimate_priors()
     if 'inference' in which:

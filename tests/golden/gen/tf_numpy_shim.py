@@ -547,10 +547,30 @@ def build_modules(feed_queue):
                 NAMED[self.name] = out
             return out
 
+    class _Merge:   # keras.layers.Add / Subtract: elementwise on a list of two tensors
+        op = None
+
+        def __init__(self, name=None, **kw):
+            self.name = name
+
+        def __call__(self, xs):
+            out = type(self).op(t(xs[0]), t(xs[1]))
+            if self.name is not None:
+                NAMED[self.name] = out
+            return out
+
+    class Add(_Merge):
+        op = staticmethod(lambda a, b: a + b)
+
+    class Subtract(_Merge):
+        op = staticmethod(lambda a, b: a - b)
+
     KL = types.ModuleType('keras.layers')
     KL.Layer = Layer
     KL.Input = Input
     KL.Lambda = Lambda
+    KL.Add = Add
+    KL.Subtract = Subtract
 
     class Model:
         def __init__(self, inputs=None, outputs=None, **kw):

@@ -3,6 +3,7 @@ reference's own source (tests/golden/gen/make_goldens.py).  CPU only.
 
 Tolerances: integer outputs bit-exact.  float32 outputs: exact (0 ulp) wherever only +,-,*,/ and
 floor/round/clip are involved (resampler); 2e-6 absolute where exp/pow/log are involved."""
+import os
 import numpy as np
 import pytest
 from conftest import load_golden, tape_from_golden
@@ -194,3 +195,20 @@ def test_whole_graph_randomise_res(name, gen_labels):
     np.testing.assert_allclose(out['image'][..., 1], g['image'][0, ..., 1], atol=5e-6)  # distance map
     np.testing.assert_allclose(out['target'], g['target'][0], atol=5e-6)
     assert out['image'][..., 1].max() > 0.1  # a real (non-trivial) distance map in at least one direction
+
+
+def test_regression_losses_match_reference_metrics_model():
+    """oracle/unet_ref.regression_loss vs SynthSR/metrics_model.py run on the shim (tests/golden/metrics.npz): l1, l2,
+    laplace x loss_cropping x residual channel"""
+    import torch
+    from oracle import unet_ref as R
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'metrics.npz'))
+    target = torch.from_numpy(g['target'][0])
+    image_out = torch.from_numpy(g['image_out'][0])
+    for kind in ('l1', 'l2', 'laplace'):
+        pred = torch.from_numpy(g['pred2' if kind == 'laplace' else 'pred1'][0])
+        for crop_tag, crop in (('', None), ('_crop', list(g['loss_cropping']))):
+            for res_tag, res in (('', None), ('_res1', image_out[..., 1:2])):
+                got = float(R.regression_loss(pred, target, kind, crop, res))
+                ref = float(g['loss_%s%s%s' % (kind, crop_tag, res_tag)])
+                assert abs(got - ref) <= 2e-6 * abs(ref), (kind, crop_tag, res_tag, got, ref)

@@ -142,6 +142,31 @@ def test_training_with_segmentation_regularised_loss(tmp_path):
     assert np.isfinite(total) and plain < total < plain + 0.25
 
 
+@pytest.mark.parametrize('metric,cropping', [('l2', 16), ('laplace', None), ('laplace', [24, 16, 16])])
+def test_training_regression_metrics_and_loss_cropping(tmp_path, metric, cropping):
+    """training(regression_metric='l2'|'laplace', loss_cropping=...) (SynthSR/training.py:85-87): the loss of a fixed
+    batch goes down over the steps, the laplace network carries the 2-channel head, 'ssim' / unknown metrics raise"""
+    from synthsr_amd.training import training
+    from synthsr_amd.synthetic import GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR
+    labels_dir = _write_labels(tmp_path, n=1)
+    for nm, a in (('gl', GENERATION_LABELS), ('gc', GENERATION_CLASSES), ('pm', PRIOR_MEANS_T1_HR), ('ps', PRIOR_STDS_T1_HR)):
+        np.save(tmp_path / (nm + '.npy'), a)
+    model_dir = str(tmp_path / 'models')
+    args = (labels_dir, model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'), str(tmp_path / 'gl.npy'))
+    kw = dict(path_generation_classes=str(tmp_path / 'gc.npy'), output_shape=32, n_levels=3, unet_feat_count=24,
+              nonlin_shape_factor=.125, bias_shape_factor=.125, steps_per_epoch=4, verbose=False, lr=1e-3)
+    net = training(*args, epochs=3, regression_metric=metric, loss_cropping=cropping, **kw)
+    assert net.nb_labels == (2 if metric == 'laplace' else 1) and net.iterations == 12
+    z = np.load(os.path.join(model_dir, '003.npz'))
+    assert z['unet_likelihood/kernel'].shape[-1] == net.nb_labels
+    log = [float(l.split(',')[1]) for l in open(os.path.join(model_dir, 'logs', 'loss.csv')).read().strip().split('\n')]
+    assert len(log) == 3 and all(np.isfinite(log)) and log[-1] < log[0]
+    with pytest.raises(NotImplementedError):
+        training(*args, regression_metric='ssim', **kw)
+    with pytest.raises(Exception):
+        training(*args, regression_metric='huber', **kw)
+
+
 def test_bench_under_torchrun_with_forced_allreduce():
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',

@@ -350,3 +350,106 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip):
         close(net.view(nm, net.grads), gd, 3e-3, 'dice-only grad ' + nm)
     hb = net.view(net.head['b'], net.grads).cpu()
     assert float((hb - g_dice[-1]).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind,crop,with_res', [('l1', None, False), ('l1', (8, 6, 12), True), ('l2', None, True),
+                                                ('l2', (10, 12, 4), False), ('laplace', None, False),
+                                                ('laplace', (8, 6, 12), True)])
+def test_head_regression_losses_vs_autograd(T, kind, crop, with_res):
+    """synthsr_head_loss_fwd / synthsr_head_bwd_multi (metrics_model.py:30-132: l1, l2, laplace, loss_cropping, residual
+    channel) against the oracle's regression_loss under autograd.  Tolerance 2e-5 relative (fp32 sums of 3k terms)."""
+    torch = T
+    from synthsr_amd import ops
+    from oracle import unet_ref as U
+    g = torch.Generator().manual_seed(21)
+    shape, C = (10, 12, 14), 24
+    K = 2 if kind == 'laplace' else 1
+    x = torch.randn(*shape, C, generator=g)
+    mean, var = torch.randn(C, generator=g) * .1, torch.rand(C, generator=g) + .5
+    gamma, beta = torch.rand(C, generator=g) + .5, torch.randn(C, generator=g) * .1
+    w = (torch.randn(C, K, generator=g) * .2).requires_grad_(True)
+    b = (torch.randn(K, generator=g) * .1).requires_grad_(True)
+    target = torch.rand(*shape, 1, generator=g)
+    image = torch.rand(*shape, 3, generator=g)
+    bn = ((x - mean) * torch.rsqrt(var + ops.BN_EPS) * gamma + beta).requires_grad_(True)
+    pred_ref = bn @ w + b
+    res = image[..., 1:2] if with_res else None
+    loss_ref = U.regression_loss(pred_ref, target, kind, crop, res)
+    loss_ref.backward()
+    stats = torch.cat([mean, var]).cuda()
+    xd = x.cuda()
+    loss = torch.zeros(1, device='cuda')
+    pred = torch.empty(x[..., 0].numel() * K, device='cuda')
+    dpred = torch.empty_like(pred)
+    box = None if crop is None else ([int((s - c) / 2) for s, c in zip(shape, crop)], list(crop))
+    ops.head_loss_fwd(xd, stats, gamma.cuda(), beta.cuda(), w.detach().cuda(), b.detach().cuda(), target.reshape(-1).cuda(),
+                      loss, kind=kind, crop=box, pred=pred, dpred=dpred, residual=image.cuda() if with_res else None,
+                      res_stride=3, res_off=1)
+    expect = pred_ref.detach().clone()
+    if with_res:
+        expect[..., :1] += res
+    close(pred.view(*shape, K), expect, 2e-5, 'pred')
+    assert abs(loss.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
+    # dloss/dpred: recover it from the autograd gradient of bn (dbn = dpred @ w^T) through head_bwd / head_bwd_multi
+    dw, db = torch.zeros(C, K, device='cuda'), torch.zeros(K, device='cuda')
+    dbn = torch.empty_like(xd)
+    if K == 1:
+        ops.head_bwd(dpred, xd, stats, gamma.cuda(), beta.cuda(), w.detach().cuda().view(-1), dbn, dw.view(-1), db)
+    else:
+        ops.head_bwd_multi(dpred, xd, stats, gamma.cuda(), beta.cuda(), w.detach().cuda(), dbn, dw, db)
+    close(dbn, bn.grad, 2e-5, 'dbn')
+    for got, ref, nm in ((dw, w.grad, 'dw'), (db, b.grad, 'db')):   # sums of +-1/N can cancel to ~0: absolute floor
+        err = (got.cpu().double() - ref.double()).abs().max().item()
+        assert err < 2e-5 * max(ref.abs().max().item(), 1e-2), '%s abs err %.3e' % (nm, err)
+    if crop is not None:  # no gradient outside the box
+        d = dpred.view(*shape, K).clone()
+        lo, sz = box
+        d[lo[0]:lo[0] + sz[0], lo[1]:lo[1] + sz[1], lo[2]:lo[2] + sz[2]] = 0
+        assert not d.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind,crop', [('l2', (8, 8, 16)), ('laplace', None), ('laplace', (16, 8, 8))])
+def test_unet_other_losses_gradients_vs_autograd(T, kind, crop):
+    """whole network under regression_metric='l2' / 'laplace' (2-channel head) and loss_cropping vs the oracle"""
+    torch = T
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    shape, cin, levels = (16, 16, 32), 2, 3
+    K = 2 if kind == 'laplace' else 1
+    net = unet(nb_features=24, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=K, feat_mult=2,
+               nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=5)
+    g = torch.Generator().manual_seed(12)
+    for nm, v in net.named_parameters():
+        if nm.endswith('/gamma'):
+            v.copy_(torch.rand(v.shape, generator=g) + .5)
+        elif nm.endswith('/beta') or nm.endswith('/bias'):
+            v.copy_(torch.randn(v.shape, generator=g) * .1)
+    net.repack()
+    x = torch.rand(*shape, cin, generator=g)
+    target = torch.rand(*shape, 1, generator=g)
+    loss, pred = net.loss(x.cuda(), target.reshape(-1).cuda(), kind, crop, residual=x.cuda(), res_stride=cin, res_off=1,
+                          want_pred=True)
+    pred = pred.clone()
+    net.backward()
+    P = _copy_params(net, torch)
+    pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True)
+    lr = U.regression_loss(pr, target, kind, crop, x[..., 1:2])
+    lr.backward()
+    expect = pr.detach().clone()
+    expect[..., :1] += x[..., 1:2]
+    close(pred.view(*shape, K), expect, 5e-4, 'prediction')
+    assert abs(loss.item() - lr.item()) < 5e-5 * max(1.0, abs(lr.item()))
+    for nm, _, _ in net.specs:
+        got = net.view(nm, net.grads).cpu().double()
+        ref = P[nm].grad.double().reshape(got.shape)
+        err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err < 5e-3, '%s grad rel err %.3e' % (nm, err)
+    net.update_moving_stats()
+    out = net.predict(x.cuda())
+    assert torch.isfinite(out).all() and list(out.shape) == list(shape) + [K]
+    with pytest.raises(ValueError):
+        net.loss(x.cuda(), target.reshape(-1).cuda(), 'l1' if K == 2 else 'laplace')
+    with pytest.raises(ValueError):
+        net.loss(x.cuda(), target.reshape(-1).cuda(), kind, (16, 16, 40))
