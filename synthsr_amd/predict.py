@@ -99,7 +99,7 @@ class Predictor:
 def predict(path_images, path_predictions, path_model=None, ct=False, disable_flipping=False, device=None, verbose=True,
             predictor=None):
     """Same contract as the reference script: `path_images` / `path_predictions` are both single files (.nii, .nii.gz,
-    .npz; .mgz is not readable here) or both folders."""
+    .npz / .mgz) or both folders."""
     path_images = os.path.abspath(path_images)
     basename = os.path.basename(path_images)
     path_predictions = os.path.abspath(path_predictions)

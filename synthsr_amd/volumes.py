@@ -64,10 +64,12 @@ def align_volume_to_ref(volume, aff, aff_ref=None, return_aff=False, n_dims=None
 
 def load_volume(path_volume, im_only=True, squeeze=True, dtype=None, aff_ref=None):
     assert path_volume.endswith(('.nii', '.nii.gz', '.mgz', '.npz')), 'Unknown data file: %s' % path_volume
-    if path_volume.endswith('.mgz'):
-        raise NotImplementedError('.mgz volumes are not supported (NIfTI and npz only)')
-    if path_volume.endswith(('.nii', '.nii.gz')):
-        data, aff, header = read_nifti(path_volume)
+    if path_volume.endswith(('.nii', '.nii.gz', '.mgz')):
+        if path_volume.endswith('.mgz'):
+            from .mgh import read_mgh
+            data, aff, header = read_mgh(path_volume)
+        else:
+            data, aff, header = read_nifti(path_volume)
         volume = np.asarray(data, dtype=np.float64)  # nibabel get_fdata() semantics
         if squeeze:
             volume = np.squeeze(volume)
@@ -101,6 +103,10 @@ def save_volume(volume, aff, header, path, res=None, dtype=None, n_dims=3):
         aff = np.eye(4)
     if dtype is not None and 'int' in dtype:
         volume = np.round(volume)
+    if path.endswith(('.mgz', '.mgh')):
+        from .mgh import write_mgh
+        write_mgh(path, volume, aff, dtype=dtype)
+        return
     write_nifti(path, volume, aff, dtype=dtype)
 
 

@@ -156,3 +156,50 @@ def test_predict_hyperfine_end_to_end_vs_oracle(tmp_path):
     assert got.shape == ref.shape
     np.testing.assert_allclose(aff_out, aff_mod, atol=1e-5)
     assert np.abs(got - ref).max() / max(np.abs(ref).max(), 1.0) < 2e-4
+
+
+def test_mgz_volumes_layout_and_round_trip(tmp_path):
+    """synthsr_amd/mgh.py (PARITY UNPINNED: no nibabel / no .mgz sample in the image): the byte layout follows the
+    published MGH header offsets, write -> read is exact for every supported type, and the affine agrees with NIfTI's"""
+    import gzip
+    import struct
+    from synthsr_amd import mgh, volumes as V
+    from synthsr_amd.nifti import write_nifti, read_nifti
+    rng = np.random.RandomState(3)
+    vol = rng.uniform(0, 200, (5, 7, 6)).astype(np.float32)
+    aff = np.array([[0., -1.5, 0., 12.], [0., 0., 2.5, -30.], [-1., 0., 0., 7.], [0., 0., 0., 1.]])
+    p = str(tmp_path / 'a.mgz')
+    V.save_volume(vol, aff, None, p)
+    raw = gzip.open(p, 'rb').read()
+    assert struct.unpack('>7i', raw[:28]) == (1, 5, 7, 6, 1, 3, 0) and struct.unpack('>h', raw[28:30]) == (1,)
+    assert np.allclose(struct.unpack('>3f', raw[30:42]), [1.0, 1.5, 2.5])
+    assert np.allclose(struct.unpack('>9f', raw[42:78]), [0, 0, -1, -1, 0, 0, 0, 1, 0])       # x_ras, y_ras, z_ras
+    centre = aff[:3, :3] @ (np.array([5, 7, 6]) / 2) + aff[:3, 3]
+    assert np.allclose(struct.unpack('>3f', raw[78:90]), centre, atol=1e-5)
+    assert len(raw) == 284 + vol.size * 4
+    assert struct.unpack('>f', raw[284 + 4:284 + 8])[0] == vol[1, 0, 0]                          # x runs fastest
+    back, aff2, hdr = V.load_volume(p, im_only=False)
+    assert back.dtype == np.float64 and np.array_equal(back, vol) and np.allclose(aff2, aff, atol=1e-5)
+    assert np.allclose(hdr['pixdim'][1:4], [1.0, 1.5, 2.5])
+    # same volume through NIfTI: identical data and affine, so predict/training treat both alike
+    write_nifti(str(tmp_path / 'a.nii.gz'), vol, aff)
+    d_n, a_n, _ = read_nifti(str(tmp_path / 'a.nii.gz'))
+    assert np.array_equal(d_n, back) and np.allclose(a_n, aff2, atol=1e-5)
+    for dt in (np.uint8, np.int16, np.int32, np.float32):
+        x = rng.randint(0, 120, (4, 3, 5, 2)).astype(dt)
+        q = str(tmp_path / ('t_%s.mgh' % np.dtype(dt).name))
+        mgh.write_mgh(q, x, aff)
+        y, a, h = mgh.read_mgh(q)
+        assert y.dtype == np.dtype(dt) and np.array_equal(x, y) and h['dims'] == (4, 3, 5, 2)
+    mgh.write_mgh(str(tmp_path / 'f64.mgz'), vol.astype(np.float64), None)
+    y, a, _ = mgh.read_mgh(str(tmp_path / 'f64.mgz'))
+    assert y.dtype == np.float32 and np.array_equal(a[:3, :3], np.eye(3)) and np.allclose(a[:3, 3], 0)
+    # goodRASFlag = 0 -> FreeSurfer's default coronal orientation
+    bad = bytearray(raw)
+    bad[28:30] = struct.pack('>h', 0)
+    (tmp_path / 'b.mgh').write_bytes(bytes(bad))
+    _, a0, _ = mgh.read_mgh(str(tmp_path / 'b.mgh'))
+    assert np.array_equal(a0[:3, :3], [[-1, 0, 0], [0, 0, 1], [0, -1, 0]])
+    (tmp_path / 'c.mgh').write_bytes(b'\0' * 300)
+    with pytest.raises(ValueError):
+        mgh.read_mgh(str(tmp_path / 'c.mgh'))
