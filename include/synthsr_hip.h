@@ -271,19 +271,21 @@ int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats,
                         int res_stride, int res_off, const float* target, float* pred, float* dpred, float* loss,
                         synthsr_stream_t stream);
 /* unet_likelihood with K output channels (w [C][K], b [K]) fused with the regression loss of metrics_model
- * (SynthSR/metrics_model.py:30-132), chosen by `kind` (training(regression_metric=...), SynthSR/training.py:85):
- *   0 'l1'  K=1  mean |pred - target|            1 'l2'  K=1  mean (pred - target)^2
- *   2 'laplace' K=2 (intensity, spread channels, training.py:325-326):  mean( log(2b) + |pred_0 - target| / b ),
- *     b = 1e-5 + 0.02 exp(pred_1)
- * shape: the volume's 3 spatial sizes (host).  crop (host, NULL = whole volume): {begin[3], size[3]} = the centred
- * loss_cropping box (metrics_model.py:70-90): the mean runs over the box, voxels outside get zero gradient.
- * residual (optional) is added to channel 0.  pred [nvox][K] (optional), dpred [nvox][K] (optional) = dloss/dpred,
- * loss: device float, zeroed by the caller. */
+ * (SynthSR/metrics_model.py:30-132), chosen by `kind` (training(regression_metric=...), SynthSR/training.py:85), for
+ * n regression targets (training(output_channel=[...]); target [nvox][n]):
+ *   0 'l1'  K=n  mean |pred - target|            1 'l2'  K=n  mean (pred - target)^2
+ *   2 'laplace' K=2n (n intensity then n spread channels, training.py:325-326):
+ *     mean( log(2b) + |pred_k - target_k| / b ),  b = 1e-5 + 0.02 exp(pred_{n+k})
+ * (means over voxels and target channels; 1 <= K <= 4).  shape: the volume's 3 spatial sizes (host).  crop (host, NULL =
+ * whole volume): {begin[3], size[3]} = the centred loss_cropping box (metrics_model.py:70-90): the mean runs over the
+ * box, voxels outside get zero gradient.  residual (optional, [nvox][res_stride]): channel res_offs[k] (host, n entries)
+ * is added to intensity channel k (work_with_residual_channel).  pred [nvox][K] (optional), dpred [nvox][K] (optional) =
+ * dloss/dpred, loss: device float, zeroed by the caller. */
 int synthsr_head_loss_fwd(const float* x, const int shape[3], int C, const float* stats, const float* gamma,
                           const float* beta, float eps, const float* w, const float* b, int K, const float* residual,
-                          int res_stride, int res_off, const float* target, float* pred, float* dpred, float* loss,
-                          int kind, const int* crop, synthsr_stream_t stream);
-/* backward of a K-channel head (K = 2): dbn[v][c] = sum_k dpred[v][k]*w[c][k] (written), dw [C][K] +=, db [K] += */
+                          int res_stride, const int* res_offs, const float* target, float* pred, float* dpred,
+                          float* loss, int kind, const int* crop, synthsr_stream_t stream);
+/* backward of a K-channel head (2 <= K <= 4): dbn[v][c] = sum_k dpred[v][k]*w[c][k] (written), dw [C][K] +=, db [K] += */
 int synthsr_head_bwd_multi(const float* dpred, const float* x, int64_t nvox, int C, int K, const float* stats,
                            const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw,
                            float* db, synthsr_stream_t stream);

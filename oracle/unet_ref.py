@@ -126,11 +126,12 @@ def l1_loss(pred, target):
 
 
 def regression_loss(pred, target, kind='l1', loss_cropping=None, residual=None):
-    """SynthSR/metrics_model.py:27-132.  pred [d0,d1,d2,K] (K = 2 for 'laplace': intensity, spread), target
-    [d0,d1,d2,1], residual [d0,d1,d2,1] or None (added to the intensity channel, :53-64); loss_cropping: sizes of the
+    """SynthSR/metrics_model.py:27-132.  pred [d0,d1,d2,K] (K = n, or 2n for 'laplace': intensities, spreads), target
+    [d0,d1,d2,n], residual [d0,d1,d2,n] or None (added to the intensity channel, :53-64); loss_cropping: sizes of the
     centred box (begin = int((shape - size) / 2), :76-90)."""
-    if kind == 'laplace':
-        intens, spread = pred[..., :1], pred[..., 1:2]
+    if kind == 'laplace':  # n intensity channels, then their n spread channels (metrics_model.py:31-46)
+        n = pred.shape[-1] // 2
+        intens, spread = pred[..., :n], pred[..., n:2 * n]
     else:
         intens, spread = pred, None
     if residual is not None:

@@ -74,7 +74,7 @@ SIGNATURES = {
     'synthsr_upsample_concat_bwd': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_head_l1_fwd': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P, _P, _P,
                                     _P, _S]),
-    'synthsr_head_loss_fwd': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, _P, _P, c_int, _P, c_int, c_int, _P, _P, _P,
+    'synthsr_head_loss_fwd': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, _P, _P, c_int, _P, c_int, _P, _P, _P, _P,
                                       _P, c_int, _P, _S]),
     'synthsr_head_bwd_multi': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
     'synthsr_bn_elu_bwd_head': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),

@@ -435,14 +435,17 @@ __global__ __launch_bounds__(256) void upsample_concat_bwd_kernel(const float* _
 
 // ------------------------------------------------------------------------------------------ head + regression loss
 // unet_likelihood (1x1x1 conv on the last BatchNorm output, K output channels) + the loss of SynthSR/metrics_model.py:30-132
-//   kind 0  'l1'      mean |pred - target|                          (K = 1)
-//   kind 1  'l2'      mean (pred - target)^2                        (K = 1)
-//   kind 2  'laplace' mean( log(2 b) + |pred_0 - target| / b ),  b = 1e-5 + 0.02 exp(pred_1)     (K = 2)
+// with n regression targets (training(output_channel=[...]), target [nvox][n]):
+//   kind 0  'l1'      mean |pred - target|                          (K = n)
+//   kind 1  'l2'      mean (pred - target)^2                        (K = n)
+//   kind 2  'laplace' mean( log(2 b) + |pred_k - target_k| / b ),  b = 1e-5 + 0.02 exp(pred_{n+k})     (K = 2 n)
+// (means over voxels AND target channels, like K.mean in the reference)
 // optionally evaluated on a centred box only (loss_cropping, metrics_model.py:70-90): voxels outside contribute neither
 // loss nor gradient; inv_n = 1 / (voxels inside).  dpred [nvox][K] is the loss gradient w.r.t. pred.
 struct HeadBox {
   int on, d1, d2;
   int lo[3], hi[3];
+  int res_off[4];  // residual channel added to intensity channel k (work_with_residual_channel)
 };
 
 template <int K>
@@ -451,10 +454,12 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            const float* __restrict__ residual, int rs, int ro,
+                                                            const float* __restrict__ residual, int rs,
                                                             const float* __restrict__ target, float* __restrict__ pred,
                                                             float* __restrict__ dpred, float* __restrict__ loss,
                                                             float inv_n, int kind, HeadBox box) {
+  constexpr int NTMAX = K;
+  const int NT = kind == 2 ? K / 2 : K;  // regression targets
   extern __shared__ float smem[];  // scale[C], shift[C], w[C][K], then the voxel tile
   float* weff = smem;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -501,7 +506,11 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restr
       }
 #pragma unroll
       for (int k = 0; k < K; ++k) acc[k] += b[k];
-      if (residual) acc[0] += residual[v * rs + ro];
+      if (residual) {
+#pragma unroll
+        for (int k = 0; k < NTMAX; ++k)
+          if (k < NT) acc[k] += residual[v * rs + box.res_off[k]];
+      }
       if (pred) {
 #pragma unroll
         for (int k = 0; k < K; ++k) pred[v * K + k] = acc[k];
@@ -511,23 +520,30 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restr
         const int xx = (int)(v % box.d2), yy = (int)((v / box.d2) % box.d1), zz = (int)(v / ((int64_t)box.d1 * box.d2));
         inside = zz >= box.lo[0] && zz < box.hi[0] && yy >= box.lo[1] && yy < box.hi[1] && xx >= box.lo[2] && xx < box.hi[2];
       }
-      const float e = acc[0] - target[v];
       float g[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) g[k] = 0.f;
       if (inside) {
-        const float sgn = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
-        if (K == 2) {  // laplace
-          const float ex = 0.02f * expf(acc[K - 1]), bb = 1e-5f + ex, ib = 1.f / bb;
-          lsum += logf(2.f * bb) + fabsf(e) * ib;
-          g[0] = sgn * ib * inv_n;
-          g[K - 1] = (ib - fabsf(e) * ib * ib) * ex * inv_n;
-        } else if (kind == 1) {
-          lsum += e * e;
-          g[0] = 2.f * e * inv_n;
-        } else {
-          lsum += fabsf(e);
-          g[0] = sgn * inv_n;
+#pragma unroll
+        for (int k = 0; k < NTMAX; ++k) {
+          if (k >= NT) continue;
+          const float e = acc[k] - target[v * NT + k];
+          const float sgn = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+          if (kind == 2) {  // laplace: spread channel NT + k
+            if constexpr (K >= 2) {
+              const int ks = (K / 2) + k;  // == NT + k
+              const float ex = 0.02f * expf(acc[ks < K ? ks : 0]), bb = 1e-5f + ex, ib = 1.f / bb;
+              lsum += logf(2.f * bb) + fabsf(e) * ib;
+              g[k] = sgn * ib * inv_n;
+              g[ks < K ? ks : 0] = (ib - fabsf(e) * ib * ib) * ex * inv_n;
+            }
+          } else if (kind == 1) {
+            lsum += e * e;
+            g[k] = 2.f * e * inv_n;
+          } else {
+            lsum += fabsf(e);
+            g[k] = sgn * inv_n;
+          }
         }
       }
       if (dpred) {
@@ -978,15 +994,23 @@ int synthsr_upsample_concat_bwd(const float* dcat, float* dskip, float* dlo_bn, 
 
 int synthsr_head_loss_fwd(const float* x, const int* shape, int C, const float* stats, const float* gamma,
                           const float* beta, float eps, const float* w, const float* b, int K, const float* residual,
-                          int res_stride, int res_off, const float* target, float* pred, float* dpred, float* loss, int kind,
-                          const int* crop, synthsr_stream_t stream) {
+                          int res_stride, const int* res_offs, const float* target, float* pred, float* dpred, float* loss,
+                          int kind, const int* crop, synthsr_stream_t stream) {
   if (!x || !shape || !stats || !gamma || !beta || !w || !b || !target || !loss || !ok_c4(C)) return SYNTHSR_EINVAL;
   if (shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
-  if (residual && (res_stride < 1 || res_off < 0 || res_off >= res_stride)) return SYNTHSR_EINVAL;
-  if (kind < 0 || kind > 2 || K != (kind == 2 ? 2 : 1)) return SYNTHSR_EINVAL;
-  if (C > 120) return SYNTHSR_EINVAL;  // LDS tile of 256 x (C + 4) floats
+  if (kind < 0 || kind > 2 || K < 1 || K > 4 || (kind == 2 && (K & 1))) return SYNTHSR_EINVAL;
+  const int NT = kind == 2 ? K / 2 : K;
+  if (C > 116) return SYNTHSR_EINVAL;  // LDS: (2 + K) C + 256 (C + 4) floats
   const int64_t nvox = (int64_t)shape[0] * shape[1] * shape[2];
   HeadBox box;
+  for (int k = 0; k < 4; ++k) box.res_off[k] = 0;
+  if (residual) {
+    if (res_stride < 1 || !res_offs) return SYNTHSR_EINVAL;
+    for (int k = 0; k < NT; ++k) {
+      if (res_offs[k] < 0 || res_offs[k] >= res_stride) return SYNTHSR_EINVAL;
+      box.res_off[k] = res_offs[k];
+    }
+  }
   box.on = crop != nullptr;
   box.d1 = shape[1];
   box.d2 = shape[2];
@@ -1006,14 +1030,18 @@ int synthsr_head_loss_fwd(const float* x, const int* shape, int C, const float* 
     }
   }
   const size_t smem = ((2 + K) * C + 256 * (C + 4)) * sizeof(float);
-  const float inv_n = (float)(1.0 / (double)n_in);
+  const float inv_n = (float)(1.0 / ((double)n_in * NT));
   const dim3 grid(syn_grid(nvox, 256, 1024));
-  if (K == 1)
-    hipLaunchKernelGGL(head_loss_fwd_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta,
-                       eps, w, b, residual, res_stride, res_off, target, pred, dpred, loss, inv_n, kind, box);
-  else
-    hipLaunchKernelGGL(head_loss_fwd_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta,
-                       eps, w, b, residual, res_stride, res_off, target, pred, dpred, loss, inv_n, kind, box);
+#define SYN_HEAD_FWD(KK)                                                                                                 \
+  hipLaunchKernelGGL(head_loss_fwd_kernel<KK>, grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta, \
+                     eps, w, b, residual, res_stride, target, pred, dpred, loss, inv_n, kind, box)
+  switch (K) {
+    case 1: SYN_HEAD_FWD(1); break;
+    case 2: SYN_HEAD_FWD(2); break;
+    case 3: SYN_HEAD_FWD(3); break;
+    default: SYN_HEAD_FWD(4); break;
+  }
+#undef SYN_HEAD_FWD
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }
@@ -1023,18 +1051,27 @@ int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats,
                         const float* target, float* pred, float* dpred, float* loss, synthsr_stream_t stream) {
   if (nvox < 1 || nvox >= (1ll << 31)) return SYNTHSR_EINVAL;
   const int shape[3] = {1, 1, (int)nvox};
-  return synthsr_head_loss_fwd(x, shape, C, stats, gamma, beta, eps, w, b, 1, residual, res_stride, res_off, target, pred,
+  return synthsr_head_loss_fwd(x, shape, C, stats, gamma, beta, eps, w, b, 1, residual, res_stride, &res_off, target, pred,
                                dpred, loss, 0, nullptr, stream);
 }
 
 int synthsr_head_bwd_multi(const float* dpred, const float* x, int64_t nvox, int C, int K, const float* stats,
                            const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw,
                            float* db, synthsr_stream_t stream) {
-  if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C) || K != 2)
+  if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C) || K < 2 || K > 4)
     return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(head_multi_bwd_kernel<2>, dim3(syn_grid(n4, RB, 1024)), dim3(RB), (2 * C + 2) * sizeof(float),
-                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db);
+  const dim3 grid(syn_grid(n4, RB, 1024));
+  const size_t smem = (K * C + K) * sizeof(float);
+#define SYN_HEAD_BWD(KK)                                                                                             \
+  hipLaunchKernelGGL(head_multi_bwd_kernel<KK>, grid, dim3(RB), smem, (hipStream_t)stream, dpred, x, n4, C, stats, gamma, \
+                     beta, eps, w, dbn, dw, db)
+  switch (K) {
+    case 2: SYN_HEAD_BWD(2); break;
+    case 3: SYN_HEAD_BWD(3); break;
+    default: SYN_HEAD_BWD(4); break;
+  }
+#undef SYN_HEAD_BWD
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

@@ -5,6 +5,7 @@ caller).  No autograd, no CPU fallback: each function is one (or a few) kernel l
 current stream.
 """
 import ctypes
+import numpy as np
 import torch
 
 from . import _lib
@@ -317,28 +318,37 @@ LOSS_KINDS = {'l1': 0, 'l2': 1, 'laplace': 2}
 
 def head_loss_fwd(x, stats, gamma, beta, w, b, target, loss, kind='l1', crop=None, pred=None, dpred=None, residual=None,
                   res_stride=1, res_off=0, eps=BN_EPS):
-    """unet_likelihood + regression loss (metrics_model.py:30-132).  x [d0,d1,d2,C]; w [C,K] with K = 2 for 'laplace'
-    (intensity, spread), else 1; crop = (begin[3], size[3]) of the loss_cropping box or None; pred / dpred [nvox,K]"""
+    """unet_likelihood + regression loss (metrics_model.py:30-132).  x [d0,d1,d2,C]; w [C,K]; target [nvox*n] for n
+    regression targets: K = n ('l1', 'l2') or 2n ('laplace': intensities then spreads); crop = (begin[3], size[3]) of the
+    loss_cropping box or None; residual [nvox, res_stride] with res_off = the channel (or one per target) added to the
+    intensities; pred / dpred [nvox*K]"""
     lib = _L()
     C = int(x.shape[-1])
     if x.dim() != 4:
         raise ValueError('x should be [d0, d1, d2, C]')
-    K = 2 if kind == 'laplace' else 1
-    if w.numel() != C * K:
-        raise ValueError('head kernel should hold %d x %d weights for the %s loss, has %d' % (C, K, kind, w.numel()))
+    K = w.numel() // C
+    nvox = x.numel() // C
+    n = K // 2 if kind == 'laplace' else K
+    if w.numel() != C * K or K < 1 or K > 4 or (kind == 'laplace' and K % 2) or target.numel() != nvox * n:
+        raise ValueError('head with %d output channels / target of %d values do not fit the %s loss on %d voxels'
+                         % (K, target.numel(), kind, nvox))
     shape = _lib.I3(*[int(v) for v in x.shape[:3]])
     box = None
     if crop is not None:
         box = (_lib.c_int * 6)(*([int(v) for v in crop[0]] + [int(v) for v in crop[1]]))
+    offs = [int(res_off)] * n if np.ndim(res_off) == 0 else [int(v) for v in res_off]
+    if len(offs) != n:
+        raise ValueError('one residual channel per regression target is needed (%d given, %d targets)' % (len(offs), n))
+    offs = (_lib.c_int * 4)(*(offs + [0] * (4 - n)))
     _lib.check(lib.synthsr_head_loss_fwd(_lib.ptr(x), shape, C, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps,
-                                         _lib.ptr(w), _lib.ptr(b), K, _lib.ptr(residual), int(res_stride), int(res_off),
+                                         _lib.ptr(w), _lib.ptr(b), K, _lib.ptr(residual), int(res_stride), offs,
                                          _lib.ptr(target), _lib.ptr(pred), _lib.ptr(dpred), _lib.ptr(loss),
                                          LOSS_KINDS[kind], box, _lib.stream()), 'head_loss_fwd')
     return loss
 
 
 def head_bwd_multi(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS):
-    """K-channel head backward (K = 2): dbn = dpred @ w^T written, dw [C,K] and db [K] accumulated"""
+    """K-channel head backward (2 <= K <= 4): dbn = dpred @ w^T written, dw [C,K] and db [K] accumulated"""
     lib = _L()
     C = int(x.shape[-1])
     nvox = x.numel() // C

@@ -71,8 +71,8 @@ class Trainer:
                                           "metrics_model.py:105-125) is not built")
             raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(
                 regression_metric))  # the reference's message (metrics_model.py:127), typo included
-        if regression_metric == 'laplace' and seg_regulariser is not None:
-            raise NotImplementedError('the laplace loss together with the segmentation loss is not built')
+        if (regression_metric == 'laplace' or net.nb_labels != 1) and seg_regulariser is not None:
+            raise NotImplementedError('the segmentation loss needs a single-channel l1 / l2 prediction')
         if loss_cropping is not None and seg_regulariser is not None:
             raise NotImplementedError('loss_cropping together with the segmentation loss is not built')
         self.metric, self.loss_cropping = regression_metric, loss_cropping
@@ -106,7 +106,7 @@ class Trainer:
                                               draws, real_image=real)
         residual, rs, ro = None, 1, 0
         if self.residual is not None:
-            residual, rs, ro = image, image.shape[-1], int(self.residual[0])
+            residual, rs, ro = image, image.shape[-1], [int(c) for c in self.residual]
         loss, pred = net.loss(image, target.reshape(-1), self.metric, self.loss_cropping, residual=residual,
                               res_stride=rs, res_off=ro, want_pred=self.seg is not None)
         if self.seg is not None:  # total = image loss + w * Dice(frozen segmentation net(prediction), labels)

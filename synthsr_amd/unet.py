@@ -37,11 +37,12 @@ class UNet3D:
         # (SynthSR/training.py:373-389); it is only run through predict_probs() / backward_input()
         if final_pred_activation not in ('linear', 'softmax'):
             raise NotImplementedError("final_pred_activation should be 'linear' or 'softmax'")
-        # linear heads: 1 channel ('l1' / 'l2'), or 2 = intensity + spread of the 'laplace' loss (SynthSR/training.py:325-326)
+        # linear heads: one channel per regression target ('l1' / 'l2'), or intensity + spread channels per target for the
+        # 'laplace' loss (SynthSR/training.py:246-249, 325-326)
         if final_pred_activation == 'softmax' and nb_labels < 2:
             raise NotImplementedError('a softmax head needs nb_labels > 1')
-        if final_pred_activation == 'linear' and nb_labels not in (1, 2):
-            raise NotImplementedError('supported linear heads: 1 output channel, or 2 (laplace: intensity + spread)')
+        if final_pred_activation == 'linear' and not 1 <= nb_labels <= 4:
+            raise NotImplementedError('linear heads have 1 to 4 output channels')
         self.final_pred_activation = final_pred_activation
         self.nb_labels = int(nb_labels)
         self.need_input_grad = False  # True: also keep the data-gradient weights of the first conv (backward_input)
@@ -333,12 +334,16 @@ class UNet3D:
 
     def loss(self, x, target, kind='l1', loss_cropping=None, residual=None, res_stride=1, res_off=0, want_pred=False):
         """forward + unet_likelihood + regression loss (SynthSR/metrics_model.py:30-132): kind 'l1' | 'l2' | 'laplace'
-        (2-channel head: intensity, spread); loss_cropping = sizes of the centred box the loss is averaged over
-        (metrics_model.py:70-90).  Returns (loss tensor[1], pred [nvox*K] | None)"""
-        K = 2 if kind == 'laplace' else 1
-        if self.final_pred_activation != 'linear' or self.nb_labels != K:
-            raise ValueError('the %s loss needs a linear head with %d output channel(s), this network has %d (%s)'
-                             % (kind, K, self.nb_labels, self.final_pred_activation))
+        with n = target.numel() / nvox regression targets (head channels: n, or 2n for laplace = intensities, spreads);
+        loss_cropping = sizes of the centred box the loss is averaged over (metrics_model.py:70-90); residual
+        [nvox, res_stride]: channel(s) res_off added to the intensities.  Returns (loss tensor[1], pred [nvox*K] | None)"""
+        K = self.nb_labels
+        nvox_in = int(np.prod(self.input_shape[:3]))
+        n = K // 2 if kind == 'laplace' else K
+        if self.final_pred_activation != 'linear' or (kind == 'laplace' and K % 2) or target.numel() != nvox_in * n:
+            raise ValueError('the %s loss on %d regression target(s) needs a linear head with %d output channels, this '
+                             'network has %d (%s)' % (kind, target.numel() // nvox_in, (2 if kind == 'laplace' else 1) *
+                                                      (target.numel() // nvox_in), K, self.final_pred_activation))
         low, bn = self.forward(x)
         nvox = low.numel() // low.shape[3]
         crop = None
@@ -362,8 +367,8 @@ class UNet3D:
         return self.loss(x, target, 'l1', None, residual, res_stride, res_off, want_pred)
 
     def predict(self, x):
-        """inference forward (moving statistics): x [d0,d1,d2,Cin] -> [d0,d1,d2,K] (K = 2 for a laplace head:
-        intensity, spread)"""
+        """inference forward (moving statistics): x [d0,d1,d2,Cin] -> [d0,d1,d2,K] (K = head channels: one per
+        regression target; intensities then spreads for a laplace head)"""
         if self.final_pred_activation != 'linear':
             raise ValueError('predict() is for linear heads; use predict_probs() for a softmax head')
         K = self.nb_labels
@@ -372,14 +377,13 @@ class UNet3D:
         try:
             low, bn = self.forward(x)
             nvox = low.numel() // low.shape[3]
-            zero_t = self.buf('zero_t', [nvox])
+            zero_t = self.buf('zero_t', [nvox * K])
             zero_t.zero_()
             loss = self.buf('loss', [1])
             loss.zero_()
             pred = self.buf('pred', [nvox * K])
             ops.head_loss_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
-                              self.view(self.head['w']), self.view(self.head['b']), zero_t, loss,
-                              kind='laplace' if K == 2 else 'l1', pred=pred)
+                              self.view(self.head['w']), self.view(self.head['b']), zero_t, loss, kind='l1', pred=pred)
         finally:
             self.training = was
         return pred.view(*self.input_shape[:3], K)

@@ -167,6 +167,27 @@ def test_training_regression_metrics_and_loss_cropping(tmp_path, metric, croppin
         training(*args, regression_metric='huber', **kw)
 
 
+def test_training_two_output_channels_with_residuals(tmp_path):
+    """training(input_channels=[True, True], output_channel=[0, 1], work_with_residual_channel=[0, 1]) (SynthSR/
+    training.py:246-249, metrics_model.py:53-64): 2-channel head, per-target residual channels"""
+    from synthsr_amd.training import training
+    from synthsr_amd.synthetic import GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR
+    labels_dir = _write_labels(tmp_path, n=1)
+    np.save(tmp_path / 'gl.npy', GENERATION_LABELS)
+    np.save(tmp_path / 'gc.npy', GENERATION_CLASSES)
+    np.save(tmp_path / 'pm.npy', np.concatenate([PRIOR_MEANS_T1_HR, PRIOR_MEANS_T1_HR[:, ::-1]]))
+    np.save(tmp_path / 'ps.npy', np.concatenate([PRIOR_STDS_T1_HR, PRIOR_STDS_T1_HR]))
+    model_dir = str(tmp_path / 'models')
+    net = training(labels_dir, model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'), str(tmp_path / 'gl.npy'),
+                   path_generation_classes=str(tmp_path / 'gc.npy'), input_channels=[True, True], output_channel=[0, 1],
+                   work_with_residual_channel=[0, 1], build_reliability_maps=False, output_shape=32, n_levels=3,
+                   unet_feat_count=24, nonlin_shape_factor=.125, bias_shape_factor=.125, steps_per_epoch=4, epochs=3,
+                   verbose=False, lr=1e-3)
+    assert net.nb_labels == 2 and net.input_shape[3] == 2
+    log = [float(l.split(',')[1]) for l in open(os.path.join(model_dir, 'logs', 'loss.csv')).read().strip().split('\n')]
+    assert len(log) == 3 and all(np.isfinite(log)) and log[-1] < log[0]
+
+
 def test_bench_under_torchrun_with_forced_allreduce():
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',

@@ -353,10 +353,12 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kind,crop,with_res', [('l1', None, False), ('l1', (8, 6, 12), True), ('l2', None, True),
-                                                ('l2', (10, 12, 4), False), ('laplace', None, False),
-                                                ('laplace', (8, 6, 12), True)])
-def test_head_regression_losses_vs_autograd(T, kind, crop, with_res):
+@pytest.mark.parametrize('kind,crop,with_res,n', [('l1', None, False, 1), ('l1', (8, 6, 12), True, 1), ('l2', None, True, 1),
+                                                  ('l2', (10, 12, 4), False, 1), ('laplace', None, False, 1),
+                                                  ('laplace', (8, 6, 12), True, 1), ('l1', (8, 6, 12), True, 2),
+                                                  ('l2', None, True, 3), ('l1', None, False, 4),
+                                                  ('laplace', (8, 6, 12), True, 2)])
+def test_head_regression_losses_vs_autograd(T, kind, crop, with_res, n):
     """synthsr_head_loss_fwd / synthsr_head_bwd_multi (metrics_model.py:30-132: l1, l2, laplace, loss_cropping, residual
     channel) against the oracle's regression_loss under autograd.  Tolerance 2e-5 relative (fp32 sums of 3k terms)."""
     torch = T
@@ -364,17 +366,18 @@ def test_head_regression_losses_vs_autograd(T, kind, crop, with_res):
     from oracle import unet_ref as U
     g = torch.Generator().manual_seed(21)
     shape, C = (10, 12, 14), 24
-    K = 2 if kind == 'laplace' else 1
+    K = 2 * n if kind == 'laplace' else n
     x = torch.randn(*shape, C, generator=g)
     mean, var = torch.randn(C, generator=g) * .1, torch.rand(C, generator=g) + .5
     gamma, beta = torch.rand(C, generator=g) + .5, torch.randn(C, generator=g) * .1
     w = (torch.randn(C, K, generator=g) * .2).requires_grad_(True)
     b = (torch.randn(K, generator=g) * .1).requires_grad_(True)
-    target = torch.rand(*shape, 1, generator=g)
-    image = torch.rand(*shape, 3, generator=g)
+    target = torch.rand(*shape, n, generator=g)
+    image = torch.rand(*shape, 5, generator=g)
+    res_ch = [3, 1, 4, 0][:n]
     bn = ((x - mean) * torch.rsqrt(var + ops.BN_EPS) * gamma + beta).requires_grad_(True)
     pred_ref = bn @ w + b
-    res = image[..., 1:2] if with_res else None
+    res = image[..., res_ch] if with_res else None
     loss_ref = U.regression_loss(pred_ref, target, kind, crop, res)
     loss_ref.backward()
     stats = torch.cat([mean, var]).cuda()
@@ -385,10 +388,10 @@ def test_head_regression_losses_vs_autograd(T, kind, crop, with_res):
     box = None if crop is None else ([int((s - c) / 2) for s, c in zip(shape, crop)], list(crop))
     ops.head_loss_fwd(xd, stats, gamma.cuda(), beta.cuda(), w.detach().cuda(), b.detach().cuda(), target.reshape(-1).cuda(),
                       loss, kind=kind, crop=box, pred=pred, dpred=dpred, residual=image.cuda() if with_res else None,
-                      res_stride=3, res_off=1)
+                      res_stride=5, res_off=res_ch if n > 1 else res_ch[0])
     expect = pred_ref.detach().clone()
     if with_res:
-        expect[..., :1] += res
+        expect[..., :n] += res
     close(pred.view(*shape, K), expect, 2e-5, 'pred')
     assert abs(loss.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
     # dloss/dpred: recover it from the autograd gradient of bn (dbn = dpred @ w^T) through head_bwd / head_bwd_multi
