@@ -285,6 +285,23 @@ int synthsr_head_loss_fwd(const float* x, const int shape[3], int C, const float
                           const float* beta, float eps, const float* w, const float* b, int K, const float* residual,
                           int res_stride, const int* res_offs, const float* target, float* pred, float* dpred,
                           float* loss, int kind, const int* crop, synthsr_stream_t stream);
+/* regression_metric='ssim' (SynthSR/metrics_model.py:105-125; tf.image.ssim(max_val=1): 11x11 Gaussian window sigma 1.5,
+ * 'VALID', k1 .01, k2 .03).  Building blocks, orchestrated by synthsr_amd/ops.py:ssim_loss; all volumes planar float32.
+ *   products: maps [4][box] = pred, target, pred*target, pred^2 + target^2 over the (loss_cropping) box `crop`
+ *             ({begin[3], size[3]}, host; NULL = whole volume `shape`)
+ *   filter:   11-tap correlation (host `taps`) along `axis` of `nmaps` volumes of `shape`; full = 0: 'VALID' (length - 10),
+ *             full = 1: its transpose (length + 10, zero padded) used by the backward pass
+ *   point:    filtered = [4][nq] (mu_x, mu_y, e_xy, e_2) -> *loss += scale * sum(luminance * cs); grads (optional) [3][nq]
+ *             = scale * d(lum*cs)/d(mu_x, e_xy, e_2)
+ *   combine:  dpred[box] += G0 + target*G1 + 2*pred*G2 with gback = [3][box] the gradient maps filtered back */
+int synthsr_ssim_products(const float* pred, const float* target, const int shape[3], const int* crop, float* maps,
+                          synthsr_stream_t stream);
+int synthsr_ssim_filter(const float* in, float* out, const int shape[3], int axis, int full, int nmaps, const float* taps,
+                        synthsr_stream_t stream);
+int synthsr_ssim_point(const float* filtered, int64_t nq, float max_val, float scale, float* loss, float* grads,
+                       synthsr_stream_t stream);
+int synthsr_ssim_combine(const float* gback, const float* pred, const float* target, const int shape[3], const int* crop,
+                         float* dpred, synthsr_stream_t stream);
 /* backward of a K-channel head (2 <= K <= 4): dbn[v][c] = sum_k dpred[v][k]*w[c][k] (written), dw [C][K] +=, db [K] += */
 int synthsr_head_bwd_multi(const float* dpred, const float* x, int64_t nvox, int C, int K, const float* stats,
                            const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw,

@@ -331,8 +331,11 @@ def conv3d_same(x, k):
 
 
 def gaussian_blur(x, sigma, u_blur=None, blur_range=None):
-    """GaussianBlur.call, non-separable (layers.py:732-767); x [X,Y,Z,1]"""
-    assert np.linalg.norm(np.array(sigma, dtype=np.float64)) <= 5, 'separable branch not restated'
+    """GaussianBlur.call (layers.py:732-767); x [X,Y,Z,1].  |sigma| > 5 (layers.py:720): separable branch = one 1-D kernel
+    per axis whose window is wider than 1, applied in turn (:747-749) -- the same kernels as dynamic_gaussian_blur with
+    max_sigma = sigma"""
+    if np.linalg.norm(np.array(sigma, dtype=np.float64)) > 5:
+        return dynamic_gaussian_blur(x, sigma, u_blur, sigma, blur_range)
     if not any(sigma):
         return f32(x)
     k = gaussian_kernel(sigma, u_blur, blur_range)

@@ -125,6 +125,45 @@ def l1_loss(pred, target):
     return (pred - target).abs().mean()
 
 
+def tf_image_ssim(img1, img2, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    """tf.image.ssim of TensorFlow 2.0 (tensorflow/python/ops/image_ops_impl.py: `ssim` -> `_ssim_per_channel` ->
+    `_ssim_helper`, window `_fspecial_gauss`), restated from the published algorithm -- TensorFlow is a third-party
+    dependency of the reference (requirements.txt: tensorflow-gpu==2.0.0), not vendored, so this restatement is UNPINNED.
+    img1, img2 [..., H, W, C]; returns [...] = mean over channels of the per-channel SSIM."""
+    coords = torch.arange(filter_size, dtype=torch.float32) - (filter_size - 1) / 2.0
+    g = coords ** 2 * (-0.5 / (filter_sigma * filter_sigma))
+    g = (g.reshape(1, -1) + g.reshape(-1, 1)).reshape(-1)
+    kernel = torch.softmax(g, 0).reshape(1, 1, filter_size, filter_size)      # 2-D window, sums to 1
+    lead, (H, W, C) = img1.shape[:-3], img1.shape[-3:]
+
+    def reducer(x):                                                             # depthwise_conv2d(..., 'VALID')
+        x = x.reshape(-1, H, W, C).permute(0, 3, 1, 2).reshape(-1, 1, H, W)
+        y = F.conv2d(x, kernel)
+        return y.reshape(-1, C, y.shape[-2], y.shape[-1]).permute(0, 2, 3, 1)
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    mean0, mean1 = reducer(img1), reducer(img2)
+    num0 = mean0 * mean1 * 2.0
+    den0 = mean0 ** 2 + mean1 ** 2
+    luminance = (num0 + c1) / (den0 + c1)
+    num1 = reducer(img1 * img2) * 2.0
+    den1 = reducer(img1 ** 2 + img2 ** 2)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    ssim_val = (luminance * cs).mean(dim=(1, 2))                               # [-1, C]
+    return ssim_val.mean(-1).reshape(lead)
+
+
+def ssim_loss(pred, target):
+    """metrics_model.py:105-125, pred / target [d0,d1,d2,1] (batch of one): the three tf.image.ssim terms exactly as the
+    reference composes them -- including `ssim_xz`, whose perm [0,1,3,2,4] only swaps the window axes"""
+    if target.shape[-1] > 1:
+        raise Exception('SSIM metric does not currently support multiple channels')
+    x, y = pred[None], target[None]
+    ssim_xy = tf_image_ssim(x, y, 1.0)
+    ssim_xz = tf_image_ssim(x.permute(0, 1, 3, 2, 4), y.permute(0, 1, 3, 2, 4), 1.0)
+    ssim_yz = tf_image_ssim(x.permute(0, 2, 3, 1, 4), y.permute(0, 2, 3, 1, 4), 1.0)
+    return -(1 / 3) * ssim_xy.mean() - (1 / 3) * ssim_xz.mean() - (1 / 3) * ssim_yz.mean()
+
+
 def regression_loss(pred, target, kind='l1', loss_cropping=None, residual=None):
     """SynthSR/metrics_model.py:27-132.  pred [d0,d1,d2,K] (K = n, or 2n for 'laplace': intensities, spreads), target
     [d0,d1,d2,n], residual [d0,d1,d2,n] or None (added to the intensity channel, :53-64); loss_cropping: sizes of the
@@ -142,6 +181,8 @@ def regression_loss(pred, target, kind='l1', loss_cropping=None, residual=None):
         sl = tuple(slice(b[i], b[i] + size[i]) for i in range(3))
         intens, target = intens[sl], target[sl]
         spread = None if spread is None else spread[sl]
+    if kind == 'ssim':
+        return ssim_loss(intens, target)
     err = intens - target
     if kind == 'l1':
         return err.abs().mean()

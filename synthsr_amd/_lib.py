@@ -77,6 +77,10 @@ SIGNATURES = {
     'synthsr_head_loss_fwd': (c_int, [_P, _P, c_int, _P, _P, _P, c_float, _P, _P, c_int, _P, c_int, _P, _P, _P, _P,
                                       _P, c_int, _P, _S]),
     'synthsr_head_bwd_multi': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
+    'synthsr_ssim_products': (c_int, [_P, _P, _P, _P, _P, _S]),
+    'synthsr_ssim_filter': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _S]),
+    'synthsr_ssim_point': (c_int, [_P, c_int64, c_float, c_float, _P, _P, _S]),
+    'synthsr_ssim_combine': (c_int, [_P, _P, _P, _P, _P, _P, _S]),
     'synthsr_bn_elu_bwd_head': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
     'synthsr_head_bwd_ex': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _S]),
     'synthsr_seg_head_fwd': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, c_int, _P, _S]),

@@ -15,6 +15,7 @@ ARCH = 'gfx950'
 
 SOURCES = [('generator.hip', ['-ffp-contract=off']),
            ('unet_pointwise.hip', []),
+           ('ssim.hip', []),
            ('conv3d.hip', [])]
 
 

@@ -256,6 +256,23 @@ def gaussian_kernel(sigma, u_blur=None, blur_range=None):
     return (k / np.sum(k, dtype=_F)).astype(_F)
 
 
+def gaussian_kernels_separable(sigma, u_blur=None, blur_range=None):
+    """et.gaussian_kernel(..., separable=True) (ext/lab2im/edit_tensors.py:125-154) for a fixed sigma: per axis a float32
+    1-D kernel exp(-d^2/2s^2 - log(sqrt(2 pi) s)) normalised to sum 1, or None where the window is 1 wide"""
+    sig = _f(sigma)
+    if blur_range is not None and blur_range != 1:
+        sig = sig * uniform_f32(u_blur, 1 / blur_range, blur_range)
+    out = []
+    for a, w in enumerate(blur_window(sigma)):
+        if w <= 1:
+            out.append(None)
+            continue
+        loc = np.arange(w).astype(_F) - _F((w - 1) / 2)
+        g = np.exp(-np.square(loc) / (_F(2) * sig[a] ** 2) - np.log(_F(np.sqrt(2 * np.pi)) * sig[a]))
+        out.append((g / g.sum(dtype=_F)).astype(_F))
+    return out
+
+
 def is_separable_sigma(sigma):
     """GaussianBlur.build (ext/lab2im/layers.py:720)"""
     return bool(np.linalg.norm(np.array(sigma, dtype=np.float64)) > 5)

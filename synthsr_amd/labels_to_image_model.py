@@ -115,10 +115,6 @@ class LabelsToImageModel:
         self.bias_shape_factor = bias_shape_factor
         self.small_bias_shape = hm.get_resample_shape(self.crop_shape, bias_shape_factor)
         self.resample_target = self.crop_shape != self.output_shape
-        for i in range(n_channels):
-            if input_channels[i] and not self.randomise_res[i] and hm.is_separable_sigma(
-                    hm.blurring_sigma_for_downsampling(self.atlas_res, data_res[i], .42, thickness[i])):
-                raise NotImplementedError('separable blur branch (|sigma| > 5) is not built yet')
         if n_channels > 4:
             raise NotImplementedError('at most 4 synthetic channels')
 
@@ -386,9 +382,13 @@ class LabelsToImageModel:
                 plan['k_lr'] = None
             elif self.input_channels[i]:
                 sig = hm.blurring_sigma_for_downsampling(self.atlas_res, self.data_res[i], .42, self.thickness[i])
-                if any(sig):
+                if hm.is_separable_sigma(sig):  # |sigma| > 5: one 1-D pass per axis (layers.py:720,747-749)
+                    ks1 = hm.gaussian_kernels_separable(list(sig), ch.get('u_blur'), self.blur_range)
+                    plan['k_lr'] = [(sm.put(k), [len(k) if a == ax else 1 for a in range(3)])
+                                    for ax, k in enumerate(ks1) if k is not None] or None
+                elif any(sig):
                     k = hm.gaussian_kernel(list(sig), ch.get('u_blur'), self.blur_range)
-                    plan['k_lr'] = (sm.put(k), list(k.shape))
+                    plan['k_lr'] = [(sm.put(k), list(k.shape))]
                 else:
                     plan['k_lr'] = None
                 if self.downsample[i] and list(self.data_res[i]) != list(self.atlas_res):
@@ -490,7 +490,10 @@ class LabelsToImageModel:
                 # LR blur written straight into the interleaved image (+ all-ones reliability map)
                 fill = img_slot + 1 if self.build_reliability_maps else -1
                 if plan['k_lr'] is not None:
-                    ko, ks = plan['k_lr']
+                    for ko, ks in plan['k_lr'][:-1]:
+                        _lib.check(lib.synthsr_blur3d(cur, oth, cs, sm.dptr(ko), i3(ks), 1, 0, -1, 0., st), 'blur(lr)')
+                        cur, oth = oth, cur
+                    ko, ks = plan['k_lr'][-1]
                     _lib.check(lib.synthsr_blur3d(cur, fptr(self.d_image), cs, sm.dptr(ko), i3(ks), Ci, img_slot, fill,
                                                   1.0, st), 'blur(lr)')
                 else:
@@ -526,8 +529,7 @@ class LabelsToImageModel:
                     _lib.check(lib.synthsr_copy_strided(cur, fptr(self.d_image), no, 1, 0, Ci, img_slot, st), 'copy(dist)')
                     img_slot += 1
                 continue
-            if plan['k_lr'] is not None:
-                ko, ks = plan['k_lr']
+            for ko, ks in (plan['k_lr'] or []):
                 _lib.check(lib.synthsr_blur3d(cur, oth, cs, sm.dptr(ko), i3(ks), 1, 0, -1, 0., st), 'blur(lr)')
                 cur, oth = oth, cur
             cur_shape = self.crop_shape

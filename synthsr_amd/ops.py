@@ -347,6 +347,67 @@ def head_loss_fwd(x, stats, gamma, beta, w, b, target, loss, kind='l1', crop=Non
     return loss
 
 
+_SSIM_TAPS = None
+
+
+def ssim_taps():
+    """1-D factor of TensorFlow's `_fspecial_gauss(11, 1.5)` window (softmax of -(x^2+y^2)/(2 sigma^2) = outer product
+    of the normalised 1-D Gaussians), float32"""
+    global _SSIM_TAPS
+    if _SSIM_TAPS is None:
+        c = np.arange(11, dtype=np.float32) - np.float32(5)
+        g = np.exp(np.square(c) * np.float32(-0.5 / (1.5 * 1.5)), dtype=np.float32)
+        _SSIM_TAPS = (g / g.sum(dtype=np.float32)).astype(np.float32)
+    return _SSIM_TAPS
+
+
+SSIM_ORIENTATIONS = (((1, 2), 2.0 / 3.0), ((2, 0), 1.0 / 3.0))  # window axes, weight (metrics_model.py:109-125: xy + xz
+# are both slices across axis 0 - the xz transpose only swaps the window axes; yz = slices across axis 1)
+
+
+def ssim_loss(pred, target, shape, loss, dpred, crop=None, scratch=None):
+    """loss += -(1/3)(ssim_xy + ssim_xz + ssim_yz) of SynthSR/metrics_model.py:105-125 and dpred = its gradient w.r.t.
+    pred (zero outside the loss_cropping box).  pred, target, dpred: [nvox] of the volume `shape`; crop = (begin[3],
+    size[3]) or None; scratch(key, numel) -> float32 device buffer (reused between steps)"""
+    lib = _L()
+    st = _lib.stream()
+    shape = [int(v) for v in shape]
+    lo, n = ([0, 0, 0], shape) if crop is None else ([int(v) for v in crop[0]], [int(v) for v in crop[1]])
+    if any(n[a] < 11 for a in (0, 1, 2)):
+        raise ValueError('the SSIM window needs at least 11 voxels per axis, the loss is evaluated on %s' % (n,))
+    if scratch is None:
+        cache = {}
+
+        def scratch(key, numel):
+            if key not in cache or cache[key].numel() < numel:
+                cache[key] = torch.empty(numel, dtype=torch.float32, device=pred.device)
+            return cache[key]
+    nb = n[0] * n[1] * n[2]
+    sh3 = _lib.I3(*shape)
+    box = None if crop is None else (_lib.c_int * 6)(*(lo + n))
+    taps = (ctypes.c_float * 11)(*[float(v) for v in ssim_taps()])
+    maps = scratch('ssim_maps', 4 * nb)
+    t1 = scratch('ssim_t1', 4 * nb)
+    t2 = scratch('ssim_t2', 4 * nb)
+    _lib.check(lib.synthsr_ssim_products(_lib.ptr(pred), _lib.ptr(target), sh3, box, _lib.ptr(maps), st), 'ssim_products')
+    dpred.zero_()
+    for (a, b), weight in SSIM_ORIENTATIONS:
+        sa = list(n)
+        sa[a] -= 10
+        sab = list(sa)
+        sab[b] -= 10
+        nq = sab[0] * sab[1] * sab[2]
+        _lib.check(lib.synthsr_ssim_filter(_lib.ptr(maps), _lib.ptr(t1), _lib.I3(*n), a, 0, 4, taps, st), 'ssim_filter')
+        _lib.check(lib.synthsr_ssim_filter(_lib.ptr(t1), _lib.ptr(t2), _lib.I3(*sa), b, 0, 4, taps, st), 'ssim_filter')
+        _lib.check(lib.synthsr_ssim_point(_lib.ptr(t2), nq, 1.0, -weight / nq, _lib.ptr(loss), _lib.ptr(t1), st),
+                   'ssim_point')
+        _lib.check(lib.synthsr_ssim_filter(_lib.ptr(t1), _lib.ptr(t2), _lib.I3(*sab), b, 1, 3, taps, st), 'ssim_filter')
+        _lib.check(lib.synthsr_ssim_filter(_lib.ptr(t2), _lib.ptr(t1), _lib.I3(*sa), a, 1, 3, taps, st), 'ssim_filter')
+        _lib.check(lib.synthsr_ssim_combine(_lib.ptr(t1), _lib.ptr(pred), _lib.ptr(target), sh3, box, _lib.ptr(dpred), st),
+                   'ssim_combine')
+    return loss
+
+
 def head_bwd_multi(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS):
     """K-channel head backward (2 <= K <= 4): dbn = dpred @ w^T written, dw [C,K] and db [K] accumulated"""
     lib = _L()

@@ -65,10 +65,7 @@ class Trainer:
     def __init__(self, brain_generator, net, lr=1e-4, lr_decay=0.0, work_with_residual_channel=None,
                  distributed=False, bucket_elems=2 * 1024 * 1024, force_allreduce=False, seg_regulariser=None,
                  regression_metric='l1', loss_cropping=None):
-        if regression_metric not in ('l1', 'l2', 'laplace'):
-            if regression_metric == 'ssim':
-                raise NotImplementedError("regression_metric='ssim' (tf.image.ssim over three slice orientations, "
-                                          "metrics_model.py:105-125) is not built")
+        if regression_metric not in ('l1', 'l2', 'laplace', 'ssim'):
             raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(
                 regression_metric))  # the reference's message (metrics_model.py:127), typo included
         if (regression_metric == 'laplace' or net.nb_labels != 1) and seg_regulariser is not None:
@@ -245,9 +242,7 @@ def training(labels_dir,
             # the reference repeats the python list here (`2 * list`, F11) instead of doubling the indices
             raise NotImplementedError('work_with_residual_channel together with build_reliability_maps=True is '
                                       'ill-defined in the reference (SURVEY F11); set build_reliability_maps=False')
-    if regression_metric == 'ssim':
-        raise NotImplementedError("regression_metric='ssim' is not built ('l1', 'l2', 'laplace' are)")
-    if regression_metric not in ('l1', 'l2', 'laplace'):
+    if regression_metric not in ('l1', 'l2', 'laplace', 'ssim'):
         raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(regression_metric))
     if dropout != 0:
         raise NotImplementedError('dropout is not supported')

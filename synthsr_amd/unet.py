@@ -333,13 +333,15 @@ class UNet3D:
         return low, low_bn
 
     def loss(self, x, target, kind='l1', loss_cropping=None, residual=None, res_stride=1, res_off=0, want_pred=False):
-        """forward + unet_likelihood + regression loss (SynthSR/metrics_model.py:30-132): kind 'l1' | 'l2' | 'laplace'
+        """forward + unet_likelihood + regression loss (SynthSR/metrics_model.py:30-132): kind 'l1' | 'l2' | 'laplace' | 'ssim'
         with n = target.numel() / nvox regression targets (head channels: n, or 2n for laplace = intensities, spreads);
         loss_cropping = sizes of the centred box the loss is averaged over (metrics_model.py:70-90); residual
         [nvox, res_stride]: channel(s) res_off added to the intensities.  Returns (loss tensor[1], pred [nvox*K] | None)"""
         K = self.nb_labels
         nvox_in = int(np.prod(self.input_shape[:3]))
         n = K // 2 if kind == 'laplace' else K
+        if kind == 'ssim' and (K != 1 or target.numel() != nvox_in):
+            raise Exception('SSIM metric does not currently support multiple channels')  # metrics_model.py:108-109
         if self.final_pred_activation != 'linear' or (kind == 'laplace' and K % 2) or target.numel() != nvox_in * n:
             raise ValueError('the %s loss on %d regression target(s) needs a linear head with %d output channels, this '
                              'network has %d (%s)' % (kind, target.numel() // nvox_in, (2 if kind == 'laplace' else 1) *
@@ -357,6 +359,14 @@ class UNet3D:
         self.loss_buf.zero_()
         self.dpred = self.buf('dpred', [nvox * K])
         pred = self.buf('pred', [nvox * K]) if want_pred else None
+        if kind == 'ssim':  # the head kernel only produces the prediction; loss and gradient come from the SSIM kernels
+            pred = self.buf('pred', [nvox])
+            ops.head_loss_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
+                              self.view(self.head['w']), self.view(self.head['b']), target, self.buf('loss_unused', [1]),
+                              kind='l1', pred=pred, residual=residual, res_stride=res_stride, res_off=res_off)
+            ops.ssim_loss(pred, target, low.shape[:3], self.loss_buf, self.dpred, crop=crop,
+                          scratch=lambda key, numel: self.buf(key, [numel]))
+            return self.loss_buf, pred
         ops.head_loss_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']), self.view(self.head['w']),
                           self.view(self.head['b']), target, self.loss_buf, kind=kind, crop=crop, pred=pred,
                           dpred=self.dpred, residual=residual, res_stride=res_stride, res_off=res_off)

@@ -323,6 +323,30 @@ def golden_inference():
     print('inference.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
 
 
+def golden_separable_blur():
+    """GaussianBlur separable branch (|sigma| > 5, ext/lab2im/layers.py:720,747-756 with edit_tensors.gaussian_kernel
+    separable=True): fixed and blur_range-randomised, one axis with a 1-wide window (skipped), plus a whole
+    labels_to_image_model graph of a 12 mm-thick-slice channel"""
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0, 1, (1, 20, 18, 30, 1)).astype('float32')
+    out = dict(blur_in=x)
+    out['sep_fixed'] = np.asarray(l2i_layers.GaussianBlur(sigma=[1.0, 0.3, 5.2])(t(x)))     # 0.3 -> window 1: axis skipped
+    tape = shim.Tape(seed=61)
+    shim.set_tape(tape)
+    out['sep_rand'] = np.asarray(l2i_layers.GaussianBlur([2.0, 1.1, 4.6], 1.15)(t(x)))
+    out.update(tape_to_dict(tape, 'sep_tape'))
+    np.savez_compressed(os.path.join(OUT, 'layers_separable.npz'), **out)
+    lab = load_label_crop(1, origin=(64, 72, 58), shape=(32, 32, 32))[None, ..., None]
+    means, stds = class_stats(np.random.default_rng(62))
+    kw = dict(atlas_res=[1., 1., 1.], target_res=None, output_div_by_n=32, padding_margin=None, flipping=True,
+              scaling_bounds=.15, rotation_bounds=15, shearing_bounds=.02, translation_bounds=5, nonlin_std=4.,
+              nonlin_shape_factor=.125, simulate_registration_error=True, randomise_res=False, downsample=True,
+              build_reliability_maps=True, blur_range=1.15, bias_field_std=.3, bias_shape_factor=.125)
+    run_graph('graph_thick_s151', lab, means, stds, 151, input_channels=[True], output_channel=[0], output_shape=32,
+              data_res=[1., 1., 12.5], thickness=[1., 1., 12.5], **kw)
+    print('separable', out['sep_fixed'].shape)
+
+
 def golden_metrics():
     """SynthSR/metrics_model.py:27-132 (`metrics_model`) run verbatim on a stand-in input model: l1 / l2 / laplace, with
     and without loss_cropping and work_with_residual_channel"""
@@ -407,9 +431,11 @@ def golden_estimate_priors():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs', 'inference', 'estimate_priors', 'metrics']
+    which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs', 'inference', 'estimate_priors', 'metrics', 'separable']
     if 'metrics' in which:
         golden_metrics()
+    if 'separable' in which:
+        golden_separable_blur()
     if 'estimate_priors' in which:
         golden_estimate_priors()
     if 'inference' in which:

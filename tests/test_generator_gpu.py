@@ -112,6 +112,17 @@ def test_whole_graph_hyperfine_vs_golden(env, name, maps):
     np.testing.assert_allclose(target.cpu().numpy(), g['target'][0], atol=2e-5)
 
 
+def test_whole_graph_thick_slices_separable_blur_vs_golden(env):
+    """12.5 mm slices: |sigma| > 5 -> the separable branch of GaussianBlur (three 1-D blur3d passes)"""
+    res = np.array([[1., 1., 12.5]])
+    g, m = _model('graph_thick_s151', input_channels=[True], output_channel=[0], data_res=res, thickness=res)
+    draws = m.draws_from_tape(tape_from_golden(g))
+    image, target, seg = m.generate(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], draws)
+    np.testing.assert_array_equal(seg.cpu().numpy(), g['seg'][0, ..., 0])
+    np.testing.assert_allclose(image.cpu().numpy(), g['image'][0], atol=2e-5)
+    np.testing.assert_allclose(target.cpu().numpy(), g['target'][0], atol=2e-5)
+
+
 @pytest.mark.parametrize('name', ['graph_real_s131', 'graph_real_crop_s132'])
 def test_whole_graph_real_image_target_vs_golden(env, name):
     """output_channel=None: the real scan rides through the same fused deformation kernel with linear

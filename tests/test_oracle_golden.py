@@ -212,3 +212,43 @@ def test_regression_losses_match_reference_metrics_model():
                 got = float(R.regression_loss(pred, target, kind, crop, res))
                 ref = float(g['loss_%s%s%s' % (kind, crop_tag, res_tag)])
                 assert abs(got - ref) <= 2e-6 * abs(ref), (kind, crop_tag, res_tag, got, ref)
+
+
+def test_separable_gaussian_blur():
+    """GaussianBlur with |sigma| > 5 (separable 1-D passes, layers.py:720,747-749): fixed (one axis with a 1-wide window
+    is skipped) and blur_range-randomised; then the whole graph of a 12.5 mm-slice channel"""
+    g = load_golden('layers_separable')
+    x = g['blur_in'][0]
+    np.testing.assert_allclose(R.gaussian_blur(x, [1.0, 0.3, 5.2]), g['sep_fixed'][0], atol=2e-6)
+    np.testing.assert_allclose(R.gaussian_blur(x, [2.0, 1.1, 4.6], g['sep_tape_00'].reshape(-1), 1.15), g['sep_rand'][0],
+                               atol=2e-6)
+    assert np.abs(R.gaussian_blur(x, [1.0, 0.3, 5.2]) - x).max() > 0.1
+
+
+def test_whole_graph_thick_slices_separable_blur(gen_labels):
+    res = np.array([[1., 1., 12.5]])
+    g, out = _run_graph('graph_thick_s151', gen_labels, input_channels=[True], output_channel=[0], data_res=res,
+                        thickness=res)
+    np.testing.assert_array_equal(out['seg'], g['seg'][0, ..., 0])
+    np.testing.assert_allclose(out['image'], g['image'][0], atol=5e-6)
+    np.testing.assert_allclose(out['target'], g['target'][0], atol=5e-6)
+
+
+def test_ssim_restatement_vs_scikit_image_and_reference_composition():
+    """oracle tf_image_ssim (TF 2.0 algorithm restated) against scikit-image's Gaussian-weighted SSIM on the same slices
+    (tests/golden/ssim_skimage.npz); and the reference's 3-term composition: its `ssim_xz` equals `ssim_xy`"""
+    import torch
+    from oracle import unet_ref as U
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ssim_skimage.npz'))
+    x, y = torch.from_numpy(g['x'])[..., None], torch.from_numpy(g['y'])[..., None]
+    got = U.tf_image_ssim(x[None], y[None], 1.0)[0].numpy()
+    np.testing.assert_allclose(got, g['ssim'], atol=2e-6)
+    assert abs(got[4] - 1) < 1e-6 and got[5] < 0
+    xy = U.tf_image_ssim(x[None], y[None], 1.0)
+    xz = U.tf_image_ssim(x[None].permute(0, 1, 3, 2, 4), y[None].permute(0, 1, 3, 2, 4), 1.0)
+    np.testing.assert_allclose(xy.numpy(), xz.numpy(), atol=2e-6)
+    yz = U.tf_image_ssim(x[None].permute(0, 2, 3, 1, 4), y[None].permute(0, 2, 3, 1, 4), 1.0)
+    total = float(U.regression_loss(x, y, 'ssim'))
+    assert abs(total - float(-(2 / 3) * xy.mean() - (1 / 3) * yz.mean())) < 1e-6
+    with pytest.raises(Exception):
+        U.regression_loss(torch.cat([x, x], -1), torch.cat([y, y], -1), 'ssim')

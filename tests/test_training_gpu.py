@@ -142,10 +142,11 @@ def test_training_with_segmentation_regularised_loss(tmp_path):
     assert np.isfinite(total) and plain < total < plain + 0.25
 
 
-@pytest.mark.parametrize('metric,cropping', [('l2', 16), ('laplace', None), ('laplace', [24, 16, 16])])
+@pytest.mark.parametrize('metric,cropping', [('l2', 16), ('laplace', None), ('laplace', [24, 16, 16]), ('ssim', None),
+                                             ('ssim', 24)])
 def test_training_regression_metrics_and_loss_cropping(tmp_path, metric, cropping):
     """training(regression_metric='l2'|'laplace', loss_cropping=...) (SynthSR/training.py:85-87): the loss of a fixed
-    batch goes down over the steps, the laplace network carries the 2-channel head, 'ssim' / unknown metrics raise"""
+    batch goes down over the steps, the laplace network carries the 2-channel head, unknown metrics raise"""
     from synthsr_amd.training import training
     from synthsr_amd.synthetic import GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR
     labels_dir = _write_labels(tmp_path, n=1)
@@ -161,8 +162,6 @@ def test_training_regression_metrics_and_loss_cropping(tmp_path, metric, croppin
     assert z['unet_likelihood/kernel'].shape[-1] == net.nb_labels
     log = [float(l.split(',')[1]) for l in open(os.path.join(model_dir, 'logs', 'loss.csv')).read().strip().split('\n')]
     assert len(log) == 3 and all(np.isfinite(log)) and log[-1] < log[0]
-    with pytest.raises(NotImplementedError):
-        training(*args, regression_metric='ssim', **kw)
     with pytest.raises(Exception):
         training(*args, regression_metric='huber', **kw)
 

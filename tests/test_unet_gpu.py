@@ -413,7 +413,8 @@ def test_head_regression_losses_vs_autograd(T, kind, crop, with_res, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kind,crop', [('l2', (8, 8, 16)), ('laplace', None), ('laplace', (16, 8, 8))])
+@pytest.mark.parametrize('kind,crop', [('l2', (8, 8, 16)), ('laplace', None), ('laplace', (16, 8, 8)), ('ssim', None),
+                                       ('ssim', (12, 14, 24))])
 def test_unet_other_losses_gradients_vs_autograd(T, kind, crop):
     """whole network under regression_metric='l2' / 'laplace' (2-channel head) and loss_cropping vs the oracle"""
     torch = T
@@ -454,5 +455,35 @@ def test_unet_other_losses_gradients_vs_autograd(T, kind, crop):
     assert torch.isfinite(out).all() and list(out.shape) == list(shape) + [K]
     with pytest.raises(ValueError):
         net.loss(x.cuda(), target.reshape(-1).cuda(), 'l1' if K == 2 else 'laplace')
+    if kind == 'ssim':
+        return
     with pytest.raises(ValueError):
         net.loss(x.cuda(), target.reshape(-1).cuda(), kind, (16, 16, 40))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,crop', [((14, 16, 13), None), ((20, 24, 30), (12, 16, 14)), ((32, 32, 32), None)])
+def test_ssim_loss_and_gradient_vs_autograd(T, shape, crop):
+    """regression_metric='ssim' kernels (separable 11-tap passes, forward and transposed) against the oracle's
+    tf.image.ssim restatement under autograd.  Tolerance 2e-5 on the loss, 2e-4 of the gradient range (fp32, the oracle
+    uses the 121-tap 2-D window, the kernels its two 1-D factors)"""
+    torch = T
+    from synthsr_amd import ops
+    from oracle import unet_ref as U
+    g = torch.Generator().manual_seed(31)
+    pred = torch.rand(*shape, 1, generator=g).requires_grad_(True)
+    target = (0.6 * pred.detach() + 0.4 * torch.rand(*shape, 1, generator=g))
+    ref = U.regression_loss(pred, target, 'ssim', crop)
+    ref.backward()
+    loss = torch.zeros(1, device='cuda')
+    dpred = torch.full((pred.numel(),), 7.0, device='cuda')          # must be overwritten, not accumulated into
+    box = None if crop is None else ([int((s - c) / 2) for s, c in zip(shape, crop)], list(crop))
+    ops.ssim_loss(pred.detach().reshape(-1).cuda(), target.reshape(-1).cuda(), shape, loss, dpred, crop=box)
+    assert abs(loss.item() - ref.item()) < 2e-5
+    close(dpred.view(*shape, 1), pred.grad, 2e-4, 'dpred')
+    # identical volumes: SSIM = 1 -> loss -1, zero gradient
+    loss.zero_()
+    ops.ssim_loss(target.reshape(-1).cuda(), target.reshape(-1).cuda(), shape, loss, dpred, crop=box)
+    assert abs(loss.item() + 1.0) < 1e-5 and dpred.abs().max().item() < 1e-6
+    with pytest.raises(ValueError):
+        ops.ssim_loss(target.reshape(-1).cuda(), target.reshape(-1).cuda(), shape, loss, dpred, crop=([0, 0, 0], [10, 12, 12]))
