@@ -187,15 +187,17 @@ def main():
         agg = {}
         for kind, shape, cin, cout, s, e in prof:
             key = (kind, shape, cin, cout)
-            a = agg.setdefault(key, [0.0, 0])
-            a[0] += s.elapsed_time(e)
-            a[1] += 1
+            agg.setdefault(key, []).append(s.elapsed_time(e))
         rows = []
-        for (kind, shape, cin, cout), (ms, cnt) in agg.items():
+        for (kind, shape, cin, cout), samples in agg.items():
             fl = conv_flops(kind, shape, cin, cout)
+            ms, cnt = float(sum(samples)), len(samples)
+            # `rank_ms` orders the kernels by median x launches: a single stalled launch (first touch under a profiler)
+            # must not promote a tiny kernel to "dominant"; the reported figures stay plain averages
             rows.append(dict(kernel=kind, shape=list(shape), cin=cin, cout=cout, launches=cnt,
-                             avg_ms=ms / cnt, tflops=fl / (ms / cnt * 1e-3) / 1e12, total_ms=ms))
-        rows.sort(key=lambda r: -r['total_ms'])
+                             avg_ms=ms / cnt, tflops=fl / (ms / cnt * 1e-3) / 1e12, total_ms=ms,
+                             rank_ms=float(np.median(samples)) * cnt))
+        rows.sort(key=lambda r: -r['rank_ms'])
         conv_total = sum(r['total_ms'] for r in rows)
         dom = rows[0]
         flops_launch = conv_flops(dom['kernel'], dom['shape'], dom['cin'], dom['cout'])
