@@ -200,7 +200,8 @@ int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* j
                             synthsr_stream_t stream);
 
 /* tuning / A-B switch, process-wide: option 0 = persistent forward kernel on the large levels (default 1),
- * 1 = diagnostic ablation mask, 2 = force MT, 3 = EXPERIMENTAL MFMA+VALU co-execution for Cout % 16 == 8 (default 0).  Options
+ * 1 = diagnostic ablation mask, 2 = force MT, 3 = EXPERIMENTAL MFMA+VALU co-execution for Cout % 16 == 8 (default 0),
+ * 4 = 4x4x1-MFMA kernels, 5 = split-K workgroup target, 6 = brick tiles, 7 = parity split of small up-conv data gradients.  Options
  * that change the launch geometry must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
 

@@ -1345,7 +1345,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
   const int cpz = KSPLIT ? (ncc + (int)gridDim.z - 1) / (int)gridDim.z : ncc;
   const int cc_lo = KSPLIT ? (int)blockIdx.z * cpz : 0;
   const int cc_hi = min(ncc, cc_lo + cpz);
-  const int npar = (mode == 2) ? 8 : 1;
+  // mode 2 sums 8 parity convs into one output: all in this workgroup, or (small deep levels: too few tiles to fill
+  // the chip) split over gridDim.z workgroups that accumulate with atomics onto a zeroed output
+  const bool psplit = (NTAPS == 8) && mode == 2 && gridDim.z > 1;
+  const int npar = (mode == 2) ? 8 / (int)gridDim.z : 1;
+  const int par_lo = (mode == 2) ? (int)blockIdx.z * npar : 0;
   const int opar = (mode == 1) ? (int)blockIdx.z : 0;
   // halo of iteration `it` (parity, chunk) -> staging registers; issued one iteration ahead so that the loads complete
   // behind the MFMAs of the previous chunk
@@ -1354,7 +1358,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
   auto halo_loads = [&](int it) {
     const int ipar = it / (cc_hi - cc_lo);
     const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
-    const int par = (mode == 1) ? opar : ipar;
+    const int par = (mode == 1) ? opar : ipar + par_lo;
     const int pconst = (mode == 2) ? ((((par >> 2) & 1) * (D1 * 2) + ((par >> 1) & 1)) * (D2 * 2) + (par & 1)) * Cin * 4 : 0;
 #pragma unroll
     for (int hz = 0; hz < FH0; ++hz) {
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
   for (int it = 0; it < nit; ++it) {
     const int ipar = it / (cc_hi - cc_lo);
     const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
-    const int par = (mode == 1) ? opar : ipar;
+    const int par = (mode == 1) ? opar : ipar + par_lo;
     const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
     // position of the 2x2x2 window inside the 3x3x3 stencil (see up_tapmask): mode 1 shift = parity, mode 2 (flipped
     // taps) shift = 1 - parity
@@ -1461,7 +1465,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_lean_kernel(const float* __
           if (gx < D2) {
             const size_t oidx = (((size_t)(gz * os + ((opar >> 2) & 1)) * (D1 * os) + (gy * os + ((opar >> 1) & 1))) *
                                      (D2 * os) + (gx * os + (opar & 1))) * Cout + co;
-            if constexpr (KSPLIT) {
+            if (KSPLIT || psplit) {
               atomicAdd(out + oidx, acc[m][n][r]);
             } else {
               float v = acc[m][n][r] + bv;
@@ -1552,13 +1556,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const
   const int cpz = KSPLIT ? (ncc + (int)gridDim.z - 1) / (int)gridDim.z : ncc;
   const int cc_lo = KSPLIT ? (int)blockIdx.z * cpz : 0;
   const int cc_hi = min(ncc, cc_lo + cpz);
-  const int npar = (mode == 2) ? 8 : 1;
+  const bool psplit = (NTAPS == 8) && mode == 2 && gridDim.z > 1;  // parities over gridDim.z workgroups (atomics)
+  const int npar = (mode == 2) ? 8 / (int)gridDim.z : 1;
+  const int par_lo = (mode == 2) ? (int)blockIdx.z * npar : 0;
   const int opar = (mode == 1) ? (int)blockIdx.z : 0;
   const int nit = npar * (cc_hi - cc_lo);
   float4 stg[NLD];
   auto halo_loads = [&](int it) {
-    const int ipar = it / (cc_hi - cc_lo);
-    const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
+    const int ipar = it / (cc_hi - cc_lo) + par_lo;
+    const int cc = cc_lo + (it % (cc_hi - cc_lo));
     const int pconst =
         (mode == 2) ? ((((ipar >> 2) & 1) * (D1 * 2) + ((ipar >> 1) & 1)) * (D2 * 2) + (ipar & 1)) * Cin * 4 : 0;
 #pragma unroll
@@ -1577,7 +1583,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const
   for (int it = 0; it < nit; ++it) {
     const int ipar = it / (cc_hi - cc_lo);
     const int cc = cc_lo + it - ipar * (cc_hi - cc_lo);
-    const int par = (mode == 1) ? opar : ipar;
+    const int par = (mode == 1) ? opar : ipar + par_lo;
     const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
     // position of the 2x2x2 window inside the 3x3x3 stencil: mode 1 shift = parity, mode 2 (flipped taps) 1 - parity
     const int shz = (NTAPS == 8) ? (mode == 2 ? 1 - pz : pz) : 0, shy = (NTAPS == 8) ? (mode == 2 ? 1 - py : py) : 0,
@@ -1664,7 +1670,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3d_fwd_brick_kernel(const
           const int os = (mode == 1) ? 2 : 1;
           const size_t oidx = (((size_t)(gz * os + ((opar >> 2) & 1)) * (D1 * os) + (gy * os + ((opar >> 1) & 1))) *
                                    (D2 * os) + (gx * os + (opar & 1))) * Cout + co;
-          if constexpr (KSPLIT) {
+          if (KSPLIT || psplit) {
             atomicAdd(out + oidx, acc[m][n][r]);
           } else {
             float v = acc[m][n][r] + bv;
@@ -2796,6 +2802,17 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
   return p;
 }
 
+// mode 2 (data gradient of a folded decoder conv = sum of 8 parity convs): number of workgroups along z the parities are
+// spread over.  1 = all eight inside one workgroup (plain stores); more only when the launch would not fill the chip
+// (20^3 / 10^3 levels: 120 workgroups ran at 16-34 % of the MFMA peak), then every workgroup adds its share atomically.
+static int g_psplit = 1;  // option 7: 0 disables
+inline int parity_split(int64_t workgroups, const float* bias, int act, const ConvExt& ext) {
+  if (!g_psplit || bias != nullptr || act != 0 || ext.addend != nullptr) return 1;
+  int ps = 1;
+  while (ps < 8 && workgroups * ps < 400) ps *= 2;
+  return ps;
+}
+
 template <int CK, int NT, int MT, bool KS, int NV = 0>
 int launch_fwd(const float* in, const float* wp, const float* bias, float* out, const int s[3], int Cin, int Cout,
                const FwdPlan& pl, int act, hipStream_t st, const ConvExt& ext) {
@@ -2811,7 +2828,11 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
         if ((act == 2 || !ext.addend) && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess)
           return SYNTHSR_ELAUNCH;
       }
-      const int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
+      int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
+      if (!KS && ext.mode == 2) {  // few tiles (deep levels): the 8 parity convs of the data gradient go to separate
+        gz = parity_split((int64_t)tiles0 * tiles1 * tiles2 * pl.nchunks, bias, act, ext);  // workgroups (atomics)
+        if (gz > 1 && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
+      }
       const dim3 grid(tiles0 * tiles1 * tiles2, pl.nchunks, gz);
       if (ext.mode == 0) {
         static bool done27 = false;
@@ -2927,7 +2948,12 @@ int launch_fwd_brick(const float* in, const float* wp, const float* bias, float*
     if ((act == 2 || !addend) && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess)
       return SYNTHSR_ELAUNCH;
   }
-  const dim3 grid(tiles0 * tiles1 * tiles2, pl.nchunks / WN, KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1));
+  int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
+  if (!KS && ext.mode == 2) {
+    gz = parity_split((int64_t)tiles0 * tiles1 * tiles2 * (pl.nchunks / WN), bias, act, ext);
+    if (gz > 1 && hipMemsetAsync(out, 0, (size_t)nout * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
+  }
+  const dim3 grid(tiles0 * tiles1 * tiles2, pl.nchunks / WN, gz);
   if (ext.mode == 0) {
     hipLaunchKernelGGL((conv3d_fwd_brick_kernel<NT, WM, WN, KS, 27>), grid, dim3(64 * WM * WN), smem, st, in, wp, bias, out,
                        s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act, ext);
@@ -3541,6 +3567,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 6) {
     g_brick = value ? 1 : 0;
+    return SYNTHSR_OK;
+  }
+  if (option == 7) {
+    g_psplit = value ? 1 : 0;
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;
