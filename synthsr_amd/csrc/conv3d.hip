@@ -2511,10 +2511,12 @@ __global__ void rows_reduce_kernel(const float* __restrict__ partial, int nwg, f
 }
 
 // ---- weight gradient of the forward parity convs (folded decoder conv, Cout = 24) on the 4x4x1 MFMA ----------------
-// conv3d_wgrad_p4_kernel for one output parity: the 2x2x2 window x 6 channel quads is exactly 48 blocks = 3 B registers
-// (no idle block slots), so here the 4 waves split the VOXELS (one z-plane of the low-res tile each) and every wave
-// keeps the full 192 x 24 partial.  dz is read on the parity sub-lattice of the hi-res tensor (voxel stride 2), which
-// only changes the per-lane offsets of the three coalesced A registers.  grid = (gx, 8 parities x chunks).
+// conv3d_wgrad_p4_kernel for the parity convs of a folded decoder conv: the 2x2x2 window x 6 channel quads of ONE output
+// parity is exactly 48 blocks = 3 B registers (no idle block slots).  Each of the 4 waves owns one parity (blockIdx.y picks
+// the parity half) and walks all 256 low-res voxels of the staged tile, so one halo tile feeds 4 x 256 x 18 MFMAs -- with
+// the waves splitting the voxels of a single parity instead (first version) the same tile fed a quarter of that and the
+// matrix pipes were busy 59 % of the time.  dz is read on the wave's parity sub-lattice of the hi-res tensor (voxel
+// stride 2), which only changes the per-lane offsets of the three coalesced A registers.  grid = (gx, 2 x chunks).
 __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float* __restrict__ in,
                                                                     const float* __restrict__ dout,
                                                                     float* __restrict__ dwc, int D0, int D1, int D2,
@@ -2524,8 +2526,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
   constexpr int CK = 24, MT = 4, Cout = 24;
   constexpr int FT1 = MT, FH1 = MT + 2, CKP = CK + 4, C4 = CK / 4, NQ = 3;
   constexpr uint32_t OOB = 0x80000000u;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int par = blockIdx.y & 7, cc = blockIdx.y >> 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int par = (blockIdx.y & 1) * 4 + wave, cc = blockIdx.y >> 1;
   const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
   const int G = gridDim.x;
   const int my_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
@@ -2537,7 +2540,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
     const int blk = 16 * q + (lane >> 2);
     const int ti = blk / 6, quad = blk - ti * 6;
     const int tz = pz + ((ti >> 2) & 1), ty = py + ((ti >> 1) & 1), tx = px + (ti & 1);
-    rowoff[q] = ((tz * FH1 + ty) * FH2 + tx) * CKP + quad * 4 + (lane & 3) + wave * (FH1 * FH2 * CKP);  // + own z-plane
+    rowoff[q] = ((tz * FH1 + ty) * FH2 + tx) * CKP + quad * 4 + (lane & 3);
   }
   constexpr int PLANE4 = FH1 * FH2 * C4, NJ = (PLANE4 + 255) / 256, NLD = NJ * FH0;
   const __amdgpu_buffer_rsrc_t rin =
@@ -2592,9 +2595,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
       }
     }
   };
-  // dz of this wave's z-plane of tile (z0, y0, x0): 8 octets (row y = o >> 1, x half o & 1) x 3 registers
-  auto load_dz = [&](int z0, int y0, int x0, float (&a)[8][3]) {
-    const int gz = z0 + wave;
+  // dz of z-plane `z` of tile (z0, y0, x0) on this wave's parity: 8 octets (row y = o >> 1, x half o & 1) x 3 registers
+  auto load_dz = [&](int z0, int y0, int x0, int z, float (&a)[8][3]) {
+    const int gz = z0 + z;
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
       const int gy = y0 + (o >> 1), xs = x0 + 8 * (o & 1);
@@ -2618,7 +2621,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
   if (my_pos < ntiles) {
     load_halo(my_pos);
     tile_origin(my_pos, z0, y0, x0);
-    load_dz(z0, y0, x0, an);
+    load_dz(z0, y0, x0, 0, an);
   }
   for (int t = my_pos; t < ntiles; t += G) {
     __syncthreads();
@@ -2631,56 +2634,70 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
       }
     }
     __syncthreads();
-    float ar[8][3];
-#pragma unroll
-    for (int o = 0; o < 8; ++o)
-#pragma unroll
-      for (int r = 0; r < 3; ++r) ar[o][r] = an[o][r];
     const bool has_next = t + G < ntiles;
-    if (has_next) {
-      load_halo(t + G);
-      tile_origin(t + G, z0, y0, x0);
-      load_dz(z0, y0, x0, an);
-    }
-    float xq[2][NQ];
+    if (has_next) load_halo(t + G);
+    int nz0 = z0, ny0 = y0, nx0 = x0;
+    if (has_next) tile_origin(t + G, nz0, ny0, nx0);
+    for (int z = 0; z < FT0; ++z) {
+      float ar[8][3];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) xq[0][q] = lds[rowoff[q]];
-    sfor<0, 64>([&](auto S) {
-      constexpr int sv = decltype(S)::value, o = sv / 8, k = sv % 8;
-      constexpr int sn = sv + 1 < 64 ? sv + 1 : sv, on = sn / 8, kn = sn % 8;
-      constexpr int nbase = ((on >> 1) * FH2 + 8 * (on & 1) + kn) * CKP;
+      for (int o = 0; o < 8; ++o)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) xq[(sv + 1) & 1][q] = lds[rowoff[q] + nbase];
-      __builtin_amdgcn_sched_barrier(0);
-      sfor<0, 6>([&](auto GI) {
-        constexpr int g = decltype(GI)::value, GG = k * 6 + g;
+        for (int r = 0; r < 3; ++r) ar[o][r] = an[o][r];
+      if (z + 1 < FT0) {
+        load_dz(z0, y0, x0, z + 1, an);
+      } else if (has_next) {
+        load_dz(nz0, ny0, nx0, 0, an);
+      }
+      int rb[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          acc[q][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[o][GG / 16], xq[sv & 1][q], acc[q][g], 4, GG % 16, 0);
+      for (int q = 0; q < NQ; ++q) rb[q] = rowoff[q] + z * (FH1 * FH2 * CKP);
+      float xq[2][NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) xq[0][q] = lds[rb[q]];
+      sfor<0, 64>([&](auto S) {
+        constexpr int sv = decltype(S)::value, o = sv / 8, k = sv % 8;
+        constexpr int sn = sv + 1 < 64 ? sv + 1 : sv, on = sn / 8, kn = sn % 8;
+        constexpr int nbase = ((on >> 1) * FH2 + 8 * (on & 1) + kn) * CKP;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xq[(sv + 1) & 1][q] = lds[rb[q] + nbase];
+        __builtin_amdgcn_sched_barrier(0);
+        sfor<0, 6>([&](auto GI) {
+          constexpr int g = decltype(GI)::value, GG = k * 6 + g;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            acc[q][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[o][GG / 16], xq[sv & 1][q], acc[q][g], 4, GG % 16, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
       });
-      __builtin_amdgcn_sched_barrier(0);
-    });
+    }
+    z0 = nz0;
+    y0 = ny0;
+    x0 = nx0;
   }
   if (dbg & 8) return;
-  // ---- combine the 4 waves (LDS float atomics into one [8 taps][24 ci][24 co] partial), then a linear atomic flush
-  __syncthreads();
-  for (int e = tid; e < 8 * CK * Cout; e += 256) lds[e] = 0.f;
-  __syncthreads();
+  // ---- flush, one wave (= one parity) at a time through LDS: its [8 taps][24 ci][24 co] partial is laid out linearly so
+  // that every global atomic instruction covers 64 consecutive floats
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int blk = 16 * q + (lane >> 2);
-    float* d = lds + (blk * 4 + (lane & 3)) * Cout;  // row = ti*24 + quad*4 + j
+      for (int q = 0; q < NQ; ++q) {
+        const int blk = 16 * q + (lane >> 2);
+        float* d = lds + (blk * 4 + (lane & 3)) * Cout;  // row = ti*24 + quad*4 + j
 #pragma unroll
-    for (int g = 0; g < 6; ++g)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) atomicAdd(d + 4 * g + i, acc[q][g][i]);
-  }
-  __syncthreads();
-  float* dst = dwc + (size_t)par * dwstride;
-  for (int e = tid; e < 8 * CK * Cout; e += 256) {
-    const int ti = e / (CK * Cout), r = e - ti * (CK * Cout);
-    const int tap = ((pz + ((ti >> 2) & 1)) * 3 + (py + ((ti >> 1) & 1))) * 3 + (px + (ti & 1));
-    atomicAdd(dst + ((size_t)tap * Cin + cc * CK) * Cout + r, lds[e]);
+        for (int g = 0; g < 6; ++g)
+          *reinterpret_cast<float4*>(d + 4 * g) = make_float4(acc[q][g][0], acc[q][g][1], acc[q][g][2], acc[q][g][3]);
+      }
+    }
+    __syncthreads();
+    const int wp = (blockIdx.y & 1) * 4 + w, wz = (wp >> 2) & 1, wy = (wp >> 1) & 1, wx = wp & 1;
+    float* dst = dwc + (size_t)wp * dwstride;
+    for (int e = tid; e < 8 * CK * Cout; e += 256) {
+      const int ti = e / (CK * Cout), r = e - ti * (CK * Cout);
+      const int tap = ((wz + ((ti >> 2) & 1)) * 3 + (wy + ((ti >> 1) & 1))) * 3 + (wx + (ti & 1));
+      atomicAdd(dst + ((size_t)tap * Cin + cc * CK) * Cout + r, lds[e]);
+    }
   }
 }
 
@@ -3372,9 +3389,9 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
       }
-      int gx = std::max(8, ((512 / (ncc * 8)) / 8) * 8);
+      int gx = std::max(8, ((512 / (ncc * 2)) / 8) * 8);  // each workgroup carries 4 of the 8 parities (one per wave)
       while (gx > 8 && gx > ntiles) gx -= 8;
-      hipLaunchKernelGGL(conv3d_up_wgrad_p4_kernel, dim3(gx, ncc * 8), dim3(256), smem, st, in, dout, dw, shape[0], shape[1],
+      hipLaunchKernelGGL(conv3d_up_wgrad_p4_kernel, dim3(gx, ncc * 2), dim3(256), smem, st, in, dout, dw, shape[0], shape[1],
                          shape[2], Cin, tiles1, tiles2, ntiles, ext.dwstride, ext.dbg);
       return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
     }
