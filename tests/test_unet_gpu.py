@@ -487,3 +487,59 @@ def test_ssim_loss_and_gradient_vs_autograd(T, shape, crop):
     assert abs(loss.item() + 1.0) < 1e-5 and dpred.abs().max().item() < 1e-6
     with pytest.raises(ValueError):
         ops.ssim_loss(target.reshape(-1).cuda(), target.reshape(-1).cuda(), shape, loss, dpred, crop=([0, 0, 0], [10, 12, 12]))
+
+
+def _sample_voxels(shape, n, seed):
+    """corners, edges, tile borders of the 4x4x16 tiling and random interior voxels"""
+    rng = np.random.RandomState(seed)
+    d0, d1, d2 = shape
+    pts = [(0, 0, 0), (d0 - 1, d1 - 1, d2 - 1), (0, d1 - 1, 0), (d0 - 1, 0, d2 - 1), (3, 3, 15), (4, 4, 16), (d0 - 4, 3, 16),
+           (d0 // 2, d1 // 2, d2 // 2), (d0 - 1, d1 // 2, 15), (7, d1 - 1, d2 - 16)]
+    pts += [tuple(int(rng.randint(0, s)) for s in shape) for _ in range(n - len(pts))]
+    return np.array(pts)
+
+
+@pytest.mark.gpu
+def test_full_size_160_convs_on_sampled_voxels(T):
+    """BASELINE size (160^3, the level-0 layers: 24->24 on the 4x4x1 kernels, 2->24 first layer): forward and data
+    gradient checked on 150 voxels (corners, tile borders, random) against the direct float64 sum over the 27 x Cin
+    neighbourhood; weight gradient and dbias against float64 GEMMs of the shifted tensors.  Tolerance 2e-5 of the range."""
+    torch = T
+    from synthsr_amd import ops
+    S = (160, 160, 160)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    vox = _sample_voxels(S, 150, 3)
+    for cin in (24, 2):
+        x = torch.randn(*S, cin, device='cuda', generator=g)
+        w = torch.randn(3, 3, 3, cin, 24, device='cuda', generator=g) * 0.1
+        b = torch.randn(24, device='cuda', generator=g)
+        y = ops.conv3d(x, ops.pack_conv_weights(w, S, 0), b, 24, act=0)
+        xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1, 1, 1))
+        w64 = w.double().cpu().numpy().reshape(27 * cin, 24)
+        ref = np.stack([xp[z:z + 3, yy:yy + 3, xx:xx + 3].double().cpu().numpy().reshape(-1) @ w64
+                        for z, yy, xx in vox]) + b.double().cpu().numpy()
+        got = y[vox[:, 0], vox[:, 1], vox[:, 2]].double().cpu().numpy()
+        assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max(), (cin, np.abs(got - ref).max())
+        del xp
+        dy = torch.randn(*S, 24, device='cuda', generator=g)
+        if cin == 24:   # data gradient: dx[v][ci] = sum_t sum_co w[t][ci][co] dy[v - (t - 1)][co]
+            dx = ops.conv3d(dy, ops.pack_conv_weights(w, S, 1), None, cin, act=0)
+            dyp = torch.nn.functional.pad(dy, (0, 0, 1, 1, 1, 1, 1, 1))
+            wf = torch.flip(w, dims=[0, 1, 2]).permute(0, 1, 2, 4, 3).double().cpu().numpy().reshape(27 * 24, cin)
+            ref = np.stack([dyp[z:z + 3, yy:yy + 3, xx:xx + 3].double().cpu().numpy().reshape(-1) @ wf for z, yy, xx in vox])
+            got = dx[vox[:, 0], vox[:, 1], vox[:, 2]].double().cpu().numpy()
+            assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max()
+            del dyp, dx
+        dw = torch.zeros(3, 3, 3, cin, 24, device='cuda')
+        db = torch.zeros(24, device='cuda')
+        ops.conv3d_wgrad(x, dy, dw, dbias=db)
+        dy2 = dy.reshape(-1, 24).double()
+        xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1, 1, 1))
+        for tz, ty, tx in [(0, 0, 0), (1, 1, 1), (2, 0, 1), (0, 2, 2), (2, 2, 2)]:
+            xs = xp[tz:tz + 160, ty:ty + 160, tx:tx + 160].reshape(-1, cin).double()
+            ref = (xs.t() @ dy2)
+            close(dw[tz, ty, tx], ref, 2e-5, 'dw tap %d%d%d cin %d' % (tz, ty, tx, cin))
+            del xs
+        close(db, dy2.sum(0), 2e-5, 'dbias')
+        del xp, dy2, dy, x, y
+        torch.cuda.empty_cache()
