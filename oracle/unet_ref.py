@@ -93,7 +93,7 @@ def dice_loss(gt, pred, eps=1e-7):
 
 
 def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, generation_labels, label_equivalency,
-                       m=None, M=None, fs_header=False):
+                       m=None, M=None, fs_header=False, loss_cropping=None):
     """SynthSR/metrics_model.py:136-215 (add_seg_loss_to_model) for one volume: the predicted image [d0,d1,d2] is
     normalised (:152-155), optionally permuted / flipped to the FreeSurfer orientation (:158-163), pushed through the
     FROZEN segmentation U-Net (softmax head, inference-mode BatchNorm -- third-party Keras semantics, unpinned) and
@@ -109,6 +109,11 @@ def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, g
     probs = unet_forward(x, Pseg, prefix, nb_levels, nconv, training=False, moving=Pseg, softmax=True)
     if fs_header:
         probs = torch.flip(probs, dims=[1]).permute(0, 2, 1, 3)
+    if loss_cropping is not None:  # :166-183: posteriors and label map cropped to the centred box
+        size = [int(loss_cropping)] * 3 if not hasattr(loss_cropping, '__len__') else [int(v) for v in loss_cropping]
+        b = [int((s - c) / 2) for s, c in zip(seg_target.shape, size)]
+        sl = tuple(slice(b[i], b[i] + size[i]) for i in range(3))
+        probs, seg_target = probs[sl], seg_target[sl]
     gts, preds = [], []
     eq = torch.as_tensor(label_equivalency)
     for i, lab in enumerate(generation_labels):

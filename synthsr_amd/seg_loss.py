@@ -53,10 +53,12 @@ class SegmentationRegulariser:
     def _from_seg_frame(self, t):  # :162-163
         return self.torch.flip(t, dims=[1]).permute(0, 2, 1).contiguous() if self.fs_header else t
 
-    def __call__(self, pred, seg_target, dpred):
+    def __call__(self, pred, seg_target, dpred, loss_cropping=None):
         """pred: predicted image, device float [nvox] (or [d0,d1,d2]); seg_target: int32 [d0,d1,d2] (the generator's
         `segmentation_target`); dpred [nvox]: gradient of the image loss w.r.t. pred, incremented IN PLACE by
-        rel_weight * d(dice)/d(pred).  Returns the Dice loss as a 0-d device tensor."""
+        rel_weight * d(dice)/d(pred).  loss_cropping: sizes of the centred box the Dice is evaluated on
+        (metrics_model.py:166-183: the network still sees the whole volume, posteriors and labels are cropped).
+        Returns the Dice loss as a 0-d device tensor."""
         torch = self.torch
         shape = tuple(seg_target.shape)
         x = pred.reshape(shape)
@@ -69,6 +71,18 @@ class SegmentationRegulariser:
         if list(xs.shape) != net.input_shape[:3]:
             raise ValueError('segmentation network built for %s, prediction is %s' % (net.input_shape[:3], list(xs.shape)))
         probs = net.predict_probs(xs[..., None].contiguous())
+        if loss_cropping is not None:
+            # outside the box: no ground-truth class (label -1) and zero posteriors, which removes those voxels from both
+            # Dice sums and - the softmax Jacobian p_i (delta_ij - p_j) vanishing with p - from the gradient
+            size = [int(loss_cropping)] * 3 if np.ndim(loss_cropping) == 0 else [int(v) for v in loss_cropping]
+            if len(size) != 3 or any(c < 1 or c > d for c, d in zip(size, shape)):
+                raise ValueError('loss_cropping %s does not fit the output shape %s' % (size, list(shape)))
+            lo = [int((d - c) / 2) for d, c in zip(shape, size)]
+            mask = torch.zeros(shape, dtype=torch.bool, device=probs.device)
+            mask[lo[0]:lo[0] + size[0], lo[1]:lo[1] + size[1], lo[2]:lo[2] + size[2]] = True
+            mask = self._to_seg_frame(mask).reshape(-1)
+            seg = torch.where(mask, seg, torch.full_like(seg, -1))
+            probs.mul_(mask[:, None])
         ops.seg_dice_sums(probs, seg, self.cls_idx, self.cls_gt, self.sums)
         T, B = self.sums[:self.K], self.sums[self.K:]
         dice = (1.0 - (T + 1e-7) / (B + 1e-7)).mean()

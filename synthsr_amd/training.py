@@ -70,8 +70,6 @@ class Trainer:
                 regression_metric))  # the reference's message (metrics_model.py:127), typo included
         if (regression_metric == 'laplace' or net.nb_labels != 1) and seg_regulariser is not None:
             raise NotImplementedError('the segmentation loss needs a single-channel l1 / l2 prediction')
-        if loss_cropping is not None and seg_regulariser is not None:
-            raise NotImplementedError('loss_cropping together with the segmentation loss is not built')
         self.metric, self.loss_cropping = regression_metric, loss_cropping
         self.bg = brain_generator
         self.seg = seg_regulariser  # synthsr_amd.seg_loss.SegmentationRegulariser or None
@@ -109,7 +107,7 @@ class Trainer:
         if self.seg is not None:  # total = image loss + w * Dice(frozen segmentation net(prediction), labels)
             if list(seg.shape) != list(image.shape[:3]):
                 raise NotImplementedError('segmentation loss with a target resolution different from the label maps')
-            loss = loss + self.seg.rel_weight * self.seg(pred, seg, net.dpred)
+            loss = loss + self.seg.rel_weight * self.seg(pred, seg, net.dpred, self.loss_cropping)
         if self.reducer is not None:
             self.reducer.start()
             net.backward(on_grad_ready=self.reducer.ready)

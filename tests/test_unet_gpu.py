@@ -296,8 +296,9 @@ def test_training_reduces_loss(T):
     assert losses[-1] < losses[0]
 
 
-@pytest.mark.parametrize('fs_header,clip', [(False, False), (True, True)])
-def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip):
+@pytest.mark.parametrize('fs_header,clip,crop', [(False, False, None), (True, True, None), (True, False, (12, 16, 20)),
+                                                 (False, True, (8, 24, 12))])
+def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
     """SynthSR/metrics_model.py:136-215: L1 + w * Dice(frozen segmentation U-Net(prediction), label map).  Loss value and
     every gradient of the TRAINED network against torch autograd through the oracle (frozen net in inference mode)"""
     torch = T
@@ -323,7 +324,7 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip):
     seg_target = torch.randint(0, len(gen_labels), shape, generator=g, dtype=torch.int32)  # indices, cf. the module docstring
     # ---- HIP
     loss, pred = net.loss_l1(x.cuda(), target.cuda().reshape(-1), want_pred=True)
-    dice = reg(pred, seg_target.cuda(), net.dpred)
+    dice = reg(pred, seg_target.cuda(), net.dpred, crop)
     net.backward()
     # ---- oracle / autograd
     P = {k: v.clone().float().requires_grad_(True) for k, v in net.state_dict().items() if 'moving' not in k}
@@ -331,7 +332,7 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip):
     pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True)[..., 0]
     l1 = (pr - target).abs().mean()
     dref = U.seg_regularisation(pr, seg_target, Pseg, segnet.prefix, levels, 2, gen_labels, equivalency, m=m, M=M,
-                                fs_header=fs_header)
+                                fs_header=fs_header, loss_cropping=crop)
     g_dice = torch.autograd.grad(dref, [P[nm] for nm, _, _ in net.specs], retain_graph=True)
     (l1 + w * dref).backward()
     assert abs(float(loss.detach().item()) - float(l1.detach())) < 1e-5
@@ -342,7 +343,7 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip):
     reg.rel_weight = 1.0
     loss, pred = net.loss_l1(x.cuda(), target.cuda().reshape(-1), want_pred=True)
     net.dpred.zero_()
-    reg(pred, seg_target.cuda(), net.dpred)
+    reg(pred, seg_target.cuda(), net.dpred, crop)
     net.backward()
     for (nm, _, _), gd in zip(net.specs, g_dice):
         if nm.endswith('likelihood/bias'):
