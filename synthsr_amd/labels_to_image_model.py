@@ -11,8 +11,9 @@ Random draws are explicit (`Draws`).  In production they come from a per-rank nu
 (host, O(500) values per volume) plus an in-kernel Philox4x32-10 stream for the per-voxel GMM noise;
 parity tests inject the reference's recorded tape through `draws_from_tape`.
 
-Scope: synthetic regression target, fixed acquisition resolution.  `randomise_res=True`
-is supported for channels without registration error (SampleResolution / DynamicGaussianBlur / MimicAcquisition, §8f-2 generator half); real-image regression targets (output_channel=None, §8f-4) are supported.
+Scope: synthetic or real-image (output_channel=None, §8f-4) regression targets; fixed acquisition
+resolution (non-separable or, for |sigma| > 5, separable blur) or `randomise_res=True` (SampleResolution /
+DynamicGaussianBlur / MimicAcquisition, §8f-2 generator half), with or without registration error.
 Batch items are generated independently; for batchsize > 1 the reference sums the GMM LUT over the
 batch (F9, a bug) — that is NOT reproduced.
 """
