@@ -1,6 +1,9 @@
 #!/usr/bin/env python
-"""Command-line launcher with the flags of the reference's scripts/training.py:21-93.
-Multi-GPU: python -m torch.distributed.run --nproc-per-node N scripts/training.py ..."""
+"""Command-line launcher of `synthsr_amd.training.training` with the flags of the reference's scripts/training.py:21-93
+(same names, destinations and defaults, so existing job scripts keep working).
+
+    python scripts/training.py <labels_dir> <model_dir> <prior_means.npy> <prior_stds.npy> <generation_labels.npy> [flags]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 scripts/training.py ...     (N GPUs)"""
 import os
 import sys
 from argparse import ArgumentParser
@@ -9,68 +12,51 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from synthsr_amd.training import training  # noqa: E402
 
 
-def infer(x):
-    """ext/lab2im/utils.py:821-832: float, then bool, else str"""
+def number_bool_or_text(text):
+    """values such as --scaling 0.2, --input_channels True, --target_res path.npy (the reference's `infer`,
+    ext/lab2im/utils.py:821-832: a float if it parses as one, else the booleans 'True' / 'False', else the string)"""
     try:
-        return float(x)
+        return float(text)
     except ValueError:
-        if x == 'False':
-            return False
-        if x == 'True':
-            return True
-        if not isinstance(x, str):
-            raise TypeError('input should be an int/float/boolean/str, had {}'.format(type(x)))
-        return x
+        return {'True': True, 'False': False}.get(text, text)
 
 
-parser = ArgumentParser()
-parser.add_argument("labels_dir", type=str)
-parser.add_argument("model_dir", type=str)
-parser.add_argument("prior_means", type=str)
-parser.add_argument("prior_stds", type=str)
-parser.add_argument("path_generation_labels", type=str)
-parser.add_argument("--prior_distributions", type=str, dest="prior_distributions", default='normal')
-parser.add_argument("--images_dir", type=str, dest="images_dir", default=None)
-parser.add_argument("--generation_classes", type=str, dest="path_generation_classes", default=None)
-parser.add_argument("--no_FS_sort", action='store_false', dest="FS_sort")
-parser.add_argument("--batchsize", type=int, dest="batchsize", default=1)
-parser.add_argument("--input_channels", type=infer, dest="input_channels", default=True)
-parser.add_argument("--output_channel", type=int, dest="output_channel", default=0)
-parser.add_argument("--target_res", type=infer, dest="target_res", default=None)
-parser.add_argument("--output_shape", type=int, dest="output_shape", default=None)
-parser.add_argument("--no_flipping", action='store_false', dest="flipping")
-parser.add_argument("--padding_margin", type=int, dest="padding_margin", default=None)
-parser.add_argument("--scaling", type=infer, dest="scaling_bounds", default=0.15)
-parser.add_argument("--rotation", type=infer, dest="rotation_bounds", default=15)
-parser.add_argument("--shearing", type=infer, dest="shearing_bounds", default=.02)
-parser.add_argument("--translation", type=infer, dest="translation_bounds", default=5)
-parser.add_argument("--nonlin_std", type=float, dest="nonlin_std", default=4.)
-parser.add_argument("--nonlin_shape_factor", type=float, dest="nonlin_shape_factor", default=.03125)
-parser.add_argument("--no_simulate_registration_error", action='store_false', dest="simulate_registration_error")
-parser.add_argument("--data_res", type=infer, dest="data_res", default=None)
-parser.add_argument("--thickness", type=infer, dest="thickness", default=None)
-parser.add_argument("--randomise_res", action='store_true', dest="randomise_res")
-parser.add_argument("--no_downsample", action='store_false', dest="downsample")
-parser.add_argument("--blur_range", type=float, dest="blur_range", default=1.15)
-parser.add_argument("--no_reliability_maps", action='store_false', dest="build_reliability_maps")
-parser.add_argument("--bias_std", type=float, dest="bias_field_std", default=.3)
-parser.add_argument("--bias_shape_factor", type=float, dest="bias_shape_factor", default=.03125)
-parser.add_argument("--n_levels", type=int, dest="n_levels", default=5)
-parser.add_argument("--conv_per_level", type=int, dest="nb_conv_per_level", default=2)
-parser.add_argument("--conv_size", type=int, dest="conv_size", default=3)
-parser.add_argument("--unet_feat", type=int, dest="unet_feat_count", default=24)
-parser.add_argument("--feat_mult", type=int, dest="feat_multiplier", default=2)
-parser.add_argument("--dropout", type=float, dest="dropout", default=0.)
-parser.add_argument("--activation", type=str, dest="activation", default='elu')
-parser.add_argument("--lr", type=float, dest="lr", default=1e-4)
-parser.add_argument("--lr_decay", type=float, dest="lr_decay", default=0)
-parser.add_argument("--epochs", type=int, dest="epochs", default=100)
-parser.add_argument("--steps_per_epoch", type=int, dest="steps_per_epoch", default=1000)
-parser.add_argument("--regression_metric", type=str, dest="regression_metric", default='l1')
-parser.add_argument("--work_with_residual_channel", type=int, dest="work_with_residual_channel", default=None)
-parser.add_argument("--loss_cropping", type=int, dest="loss_cropping", default=None)
-parser.add_argument("--checkpoint", type=str, dest="checkpoint", default=None)
-parser.add_argument("--seed", type=int, dest="seed", default=0)
+POSITIONAL = ('labels_dir', 'model_dir', 'prior_means', 'prior_stds', 'path_generation_labels')
+# (flag, keyword of training(), type, default)
+VALUED = [
+    ('prior_distributions', None, str, 'normal'), ('images_dir', None, str, None),
+    ('generation_classes', 'path_generation_classes', str, None), ('batchsize', None, int, 1),
+    ('input_channels', None, number_bool_or_text, True), ('output_channel', None, int, 0),
+    ('target_res', None, number_bool_or_text, None), ('output_shape', None, int, None),
+    ('padding_margin', None, int, None), ('scaling', 'scaling_bounds', number_bool_or_text, 0.15),
+    ('rotation', 'rotation_bounds', number_bool_or_text, 15), ('shearing', 'shearing_bounds', number_bool_or_text, .02),
+    ('translation', 'translation_bounds', number_bool_or_text, 5), ('nonlin_std', None, float, 4.),
+    ('nonlin_shape_factor', None, float, .03125), ('data_res', None, number_bool_or_text, None),
+    ('thickness', None, number_bool_or_text, None), ('blur_range', None, float, 1.15),
+    ('bias_std', 'bias_field_std', float, .3), ('bias_shape_factor', None, float, .03125), ('n_levels', None, int, 5),
+    ('conv_per_level', 'nb_conv_per_level', int, 2), ('conv_size', None, int, 3), ('unet_feat', 'unet_feat_count', int, 24),
+    ('feat_mult', 'feat_multiplier', int, 2), ('dropout', None, float, 0.), ('activation', None, str, 'elu'),
+    ('lr', None, float, 1e-4), ('lr_decay', None, float, 0), ('epochs', None, int, 100),
+    ('steps_per_epoch', None, int, 1000), ('regression_metric', None, str, 'l1'),
+    ('work_with_residual_channel', None, int, None), ('loss_cropping', None, int, None), ('checkpoint', None, str, None),
+    ('seed', None, int, 0),
+]
+# switches: (flag, keyword, value stored when the flag is present)
+SWITCHES = [('no_FS_sort', 'FS_sort', False), ('no_flipping', 'flipping', False),
+            ('no_simulate_registration_error', 'simulate_registration_error', False), ('randomise_res', 'randomise_res', True),
+            ('no_downsample', 'downsample', False), ('no_reliability_maps', 'build_reliability_maps', False)]
+
+
+def build_parser():
+    parser = ArgumentParser(description=__doc__.split('\n')[0])
+    for name in POSITIONAL:
+        parser.add_argument(name, type=str)
+    for flag, keyword, kind, default in VALUED:
+        parser.add_argument('--' + flag, dest=keyword or flag, type=kind, default=default)
+    for flag, keyword, stored in SWITCHES:
+        parser.add_argument('--' + flag, dest=keyword, action='store_true' if stored else 'store_false')
+    return parser
+
 
 if __name__ == '__main__':
-    training(**vars(parser.parse_args()))
+    training(**vars(build_parser().parse_args()))

@@ -1,95 +1,81 @@
-"""Host input sampler — counterpart of SynthSR/model_inputs.py:25-139 (`build_model_inputs`).
+"""Host input sampler: picks label maps and draws the per-class GMM parameters of every batch - the job of
+SynthSR/model_inputs.py:25-139 (`build_model_inputs`), same generator protocol: each `next()` gives
+`[labels [B,*S,1] int32, means [B,L,C], stds [B,L,C]]` (+ `image [B,*S,1]` when real scans are given).
 
-Same generator protocol: yields `[labels [B,*S,1] int32, means [B,L,C], stds [B,L,C]]`.  Differences that
-are deliberate: label maps are read from disk ONCE and cached (the reference gunzips a
-17 MB NIfTI every step, model_inputs.py:91), and an explicit numpy Generator can be supplied for
-reproducible per-rank streams (the reference uses the unseeded global numpy RNG).
-"""
+Deliberate differences: label maps and scans are read from disk once and kept (the reference gunzips a
+17 MB NIfTI every step, model_inputs.py:91), in-memory volumes are accepted, and an explicit numpy Generator gives
+reproducible per-rank streams (the reference draws from the unseeded global numpy state)."""
 import numpy as np
 
 from . import host_math as hm
 from . import volumes
 
+# defaults of the class means / standard deviations when no prior is given (model_inputs.py:118-121)
+_MEAN_CENTRE, _MEAN_RANGE, _STD_CENTRE, _STD_RANGE = 125., 100., 15., 10.
 
-def build_model_inputs(path_label_maps,
-                       n_labels,
-                       prior_means,
-                       prior_stds,
-                       prior_distributions,
-                       path_images=None,
-                       batchsize=1,
-                       n_channels=1,
-                       generation_classes=None,
-                       rng=None,
-                       label_maps=None):
-    """`label_maps` (optional): list of already loaded int32 volumes replacing `path_label_maps`.
-    `path_images`: real scans matching the label maps one to one (same order); each batch then carries a 4th input, the
-    scan of the picked label map, float [B, *shape, 1] (model_inputs.py:94-96,131-132)."""
-    if path_images is not None and len(path_images) != (len(label_maps) if label_maps is not None else len(path_label_maps)):
+
+class _Lazy:
+    """volumes addressed by index: arrays are used as they are, paths are loaded (RAS frame) on first use and kept"""
+
+    def __init__(self, items, dtype):
+        self.items, self.dtype, self.loaded = items, dtype, {}
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        item = self.items[i]
+        if isinstance(item, np.ndarray):
+            return item
+        if i not in self.loaded:
+            self.loaded[i] = volumes.load_volume(item, dtype=self.dtype, aff_ref=np.eye(4))
+        return self.loaded[i]
+
+
+def _channel_prior(prior, channel, n_channels, name):
+    """rows [2c, 2c+2) of a stacked (2*n_channels, K) prior array; anything else (None, number, pair) serves all channels"""
+    if not isinstance(prior, np.ndarray):
+        return prior
+    if prior.shape[0] / 2 != n_channels:
+        raise ValueError("the number of blocks in %s does not match n_channels." % name)
+    return prior[2 * channel:2 * channel + 2, :]
+
+
+def build_model_inputs(path_label_maps, n_labels, prior_means, prior_stds, prior_distributions, path_images=None,
+                       batchsize=1, n_channels=1, generation_classes=None, rng=None, label_maps=None):
+    """`label_maps` (optional): already loaded int32 volumes replacing `path_label_maps`.  `path_images`: real scans (paths
+    or arrays) matching the label maps one to one, in the same order (model_inputs.py:94-96,131-132)."""
+    maps = _Lazy(label_maps if label_maps is not None else path_label_maps, 'int')
+    scans = None if path_images is None else _Lazy(path_images, 'float')
+    if scans is not None and len(scans) != len(maps):
         raise ValueError('path_images and the label maps should have the same length')
-    if generation_classes is None:
-        generation_classes = np.arange(n_labels)
-    n_classes = len(np.unique(generation_classes))
-    npr = np.random if rng is None else rng
-    cache = {}
-    n_maps = len(label_maps) if label_maps is not None else len(path_label_maps)
+    classes = np.arange(n_labels) if generation_classes is None else generation_classes
+    n_classes = len(np.unique(classes))
+    legacy = rng is None or hasattr(rng, 'randint')           # numpy's global state / RandomState vs Generator
+    source = np.random if rng is None else rng
 
-    def get_labels(idx):
-        if label_maps is not None:
-            return label_maps[idx]
-        if idx not in cache:
-            cache[idx] = volumes.load_volume(path_label_maps[idx], dtype='int', aff_ref=np.eye(4))
-        return cache[idx]
-
-    img_cache = {}
-
-    def get_image(idx):
-        if idx not in img_cache:
-            v = path_images[idx]
-            img_cache[idx] = v if isinstance(v, np.ndarray) else volumes.load_volume(v, dtype='float', aff_ref=np.eye(4))
-        return img_cache[idx]
-
-    def randint(n, size):
-        return npr.randint(n, size=size) if hasattr(npr, 'randint') else npr.integers(n, size=size)
+    def class_stats():
+        """[1, L, C] means and stds: one draw per class and channel, spread over the labels of the class"""
+        cols_m, cols_s = [], []
+        for c in range(n_channels):
+            m = hm.draw_value_from_distribution(_channel_prior(prior_means, c, n_channels, 'prior_means'), n_classes,
+                                                prior_distributions, _MEAN_CENTRE, _MEAN_RANGE, positive_only=True, rng=rng)
+            s = hm.draw_value_from_distribution(_channel_prior(prior_stds, c, n_channels, 'prior_stds'), n_classes,
+                                                prior_distributions, _STD_CENTRE, _STD_RANGE, positive_only=True, rng=rng)
+            cols_m.append(m[classes])
+            cols_s.append(s[classes])
+        if not cols_m:
+            return np.empty((1, n_labels, 0)), np.empty((1, n_labels, 0))
+        return np.stack(cols_m, -1)[None], np.stack(cols_s, -1)[None]
 
     while True:
-        indices = randint(n_maps, batchsize)
-        list_label_maps, list_means, list_stds, list_images = [], [], [], []
-        for idx in indices:
-            lab = get_labels(int(idx))
-            list_label_maps.append(lab[np.newaxis, ..., np.newaxis])
-            if path_images is not None:
-                list_images.append(np.asarray(get_image(int(idx)))[np.newaxis, ..., np.newaxis])
-            means = np.empty((1, n_labels, 0))
-            stds = np.empty((1, n_labels, 0))
-            for channel in range(n_channels):
-                if isinstance(prior_means, np.ndarray):
-                    if prior_means.shape[0] / 2 != n_channels:
-                        raise ValueError("the number of blocks in prior_means does not match n_channels.")
-                    tmp_prior_means = prior_means[2 * channel:2 * channel + 2, :]
-                else:
-                    tmp_prior_means = prior_means
-                if isinstance(prior_stds, np.ndarray):
-                    if prior_stds.shape[0] / 2 != n_channels:
-                        raise ValueError("the number of blocks in prior_stds does not match n_channels.")
-                    tmp_prior_stds = prior_stds[2 * channel:2 * channel + 2, :]
-                else:
-                    tmp_prior_stds = prior_stds
-                tmp_classes_means = hm.draw_value_from_distribution(tmp_prior_means, n_classes, prior_distributions,
-                                                                    125., 100., positive_only=True, rng=rng)
-                tmp_classes_stds = hm.draw_value_from_distribution(tmp_prior_stds, n_classes, prior_distributions,
-                                                                   15., 10., positive_only=True, rng=rng)
-                tmp_means = tmp_classes_means[generation_classes][np.newaxis, :, np.newaxis]
-                tmp_stds = tmp_classes_stds[generation_classes][np.newaxis, :, np.newaxis]
-                means = np.concatenate([means, tmp_means], axis=-1)
-                stds = np.concatenate([stds, tmp_stds], axis=-1)
-            list_means.append(means)
-            list_stds.append(stds)
-        list_inputs = [list_label_maps, list_means, list_stds]
-        if path_images is not None:
-            list_inputs.append(list_images)
-        if batchsize > 1:
-            list_inputs = [np.concatenate(item, 0) for item in list_inputs]
-        else:
-            list_inputs = [item[0] for item in list_inputs]
-        yield list_inputs
+        picks = source.randint(len(maps), size=batchsize) if legacy else source.integers(len(maps), size=batchsize)
+        batch = [[], [], []] + ([[]] if scans is not None else [])
+        for i in (int(p) for p in picks):
+            batch[0].append(maps[i][None, ..., None])
+            if scans is not None:
+                batch[3].append(np.asarray(scans[i])[None, ..., None])
+            means, stds = class_stats()
+            batch[1].append(means)
+            batch[2].append(stds)
+        yield [np.concatenate(items, 0) if batchsize > 1 else items[0] for items in batch]

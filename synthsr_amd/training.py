@@ -162,60 +162,18 @@ def load_checkpoint(path, net, by_name=True, skip=()):
         net.iterations = int(z['optimizer/iterations'])
 
 
-def training(labels_dir,
-             model_dir,
-             prior_means,
-             prior_stds,
-             path_generation_labels,
-             segmentation_label_list=None,
-             segmentation_label_equivalency=None,
-             segmentation_model_file=None,
-             fs_header_segnet=False,
-             relative_weight_segmentation=0.25,
-             prior_distributions='normal',
-             images_dir=None,
-             path_generation_classes=None,
-             FS_sort=True,
-             batchsize=1,
-             input_channels=True,
-             output_channel=0,
-             target_res=None,
-             output_shape=None,
-             flipping=True,
-             padding_margin=None,
-             scaling_bounds=0.15,
-             rotation_bounds=15,
-             shearing_bounds=0.02,
-             translation_bounds=5,
-             nonlin_std=4.,
-             nonlin_shape_factor=0.03125,
-             simulate_registration_error=True,
-             data_res=None,
-             thickness=None,
-             randomise_res=None,
-             downsample=True,
-             blur_range=1.15,
-             build_reliability_maps=True,
-             bias_field_std=.3,
-             bias_shape_factor=0.03125,
-             n_levels=5,
-             nb_conv_per_level=2,
-             conv_size=3,
-             unet_feat_count=24,
-             feat_multiplier=2,
-             dropout=0,
-             activation='elu',
-             lr=1e-4,
-             lr_decay=0,
-             epochs=100,
-             steps_per_epoch=1000,
-             regression_metric='l1',
-             work_with_residual_channel=None,
-             loss_cropping=None,
-             checkpoint=None,
-             model_file_has_different_lhood_layer=False,
-             seed=0,
-             verbose=True):
+def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_labels, segmentation_label_list=None,
+             segmentation_label_equivalency=None, segmentation_model_file=None, fs_header_segnet=False,
+             relative_weight_segmentation=0.25, prior_distributions='normal', images_dir=None,
+             path_generation_classes=None, FS_sort=True, batchsize=1, input_channels=True, output_channel=0,
+             target_res=None, output_shape=None, flipping=True, padding_margin=None, scaling_bounds=0.15,
+             rotation_bounds=15, shearing_bounds=0.02, translation_bounds=5, nonlin_std=4.,
+             nonlin_shape_factor=0.03125, simulate_registration_error=True, data_res=None, thickness=None,
+             randomise_res=None, downsample=True, blur_range=1.15, build_reliability_maps=True, bias_field_std=.3,
+             bias_shape_factor=0.03125, n_levels=5, nb_conv_per_level=2, conv_size=3, unet_feat_count=24,
+             feat_multiplier=2, dropout=0, activation='elu', lr=1e-4, lr_decay=0, epochs=100, steps_per_epoch=1000,
+             regression_metric='l1', work_with_residual_channel=None, loss_cropping=None, checkpoint=None,
+             model_file_has_different_lhood_layer=False, seed=0, verbose=True):
     """Parameters as documented in SynthSR/training.py:90-240 (+ `seed`, `verbose`)."""
     import torch
     n_channels = len(hm.reformat_to_list(input_channels))
