@@ -25,27 +25,28 @@ def _mm(a, b):
 
 
 def reformat_to_list(var, length=None, dtype=None):
-    """ext/lab2im/utils.py:319-370 for the value kinds the hot path passes (number, sequence, 1-D array)"""
+    """A parameter given as number / string / sequence / array as a python list (behaviour of ext/lab2im/utils.py:319-370
+    for the value kinds this package passes): singletons are repeated to `length`, items cast to `dtype` ('int', 'float',
+    'bool', 'str')."""
     if var is None:
         return None
+    scalars = (int, float, bool, str, np.integer, np.floating, np.bool_)
     if isinstance(var, np.ndarray):
-        var = np.squeeze(var).tolist() if var.ndim else [var.item()]
-    if isinstance(var, (int, float, bool, str, np.integer, np.floating, np.bool_)):
-        var = [var]
-    elif isinstance(var, tuple):
-        var = list(var)
-    if not isinstance(var, list):
+        var = var.item() if var.size == 1 else np.squeeze(var).tolist()
+    if isinstance(var, scalars):
+        items = [var]
+    elif isinstance(var, (list, tuple)):
+        items = list(var)
+    else:
         raise TypeError('variable should be an int, float, bool, str, list, tuple or numpy array, had %s' % type(var))
-    if length is not None:
-        if len(var) == 1:
-            var = var * length
-        elif len(var) != length:
-            raise ValueError('if var is a list/tuple/numpy array, it should be of length 1 or %d, had %s'
-                             % (length, var))
+    if length is not None and len(items) != length:
+        if len(items) != 1:
+            raise ValueError('if var is a list/tuple/numpy array, it should be of length 1 or %d, had %s' % (length, items))
+        items = items * length
     if dtype is not None:
-        conv = {'int': int, 'float': float, 'bool': bool, 'str': str}[dtype]
-        var = [conv(v) for v in var]
-    return var
+        cast = {'int': int, 'float': float, 'bool': bool, 'str': str}[dtype]
+        items = [cast(v) for v in items]
+    return items
 
 
 def reformat_to_n_channels_array(var, n_dims=3, n_channels=1):
@@ -87,73 +88,61 @@ def get_resample_shape(shape, factor):
 
 
 def get_padding_margin(cropping, loss_cropping):
-    """ext/lab2im/utils.py:601-614"""
+    """margin to pad the label maps with so that a centre box of `loss_cropping` inside a patch of `cropping` never sees
+    padded borders: half the difference per axis (ext/lab2im/utils.py:601-614); an int if both are given as one number"""
     if cropping is None or loss_cropping is None:
         return None
-    cropping = reformat_to_list(cropping)
-    loss_cropping = reformat_to_list(loss_cropping)
-    n = max(len(cropping), len(loss_cropping))
-    cropping = reformat_to_list(cropping, length=n)
-    loss_cropping = reformat_to_list(loss_cropping, length=n)
-    pm = [int((cropping[i] - loss_cropping[i]) / 2) for i in range(n)]
-    return pm[0] if len(pm) == 1 else pm
+    outer, inner = reformat_to_list(cropping), reformat_to_list(loss_cropping)
+    n = max(len(outer), len(inner))
+    outer, inner = reformat_to_list(outer, length=n), reformat_to_list(inner, length=n)
+    margins = [int((o - i) / 2) for o, i in zip(outer, inner)]
+    return margins if n > 1 else margins[0]
 
 
 def get_shapes(labels_shape, output_shape, atlas_res, target_res, padding_margin, output_div_by_n):
-    """SynthSR/labels_to_image_model.py:269-335 -> (cropping_shape, output_shape, padding_margin)"""
-    atlas_res = reformat_to_list(atlas_res)
-    n_dims = len(atlas_res)
-    target_res = reformat_to_list(target_res)
-    labels_shape = list(labels_shape)
+    """(cropping_shape, output_shape, padding_margin) of the generator, the arithmetic of SynthSR/labels_to_image_model.py:
+    269-335: the output is at most what the (padded) label map gives at the target resolution, floored to a multiple of
+    `output_div_by_n`; the patch cropped from the label map is the output divided by the zoom (rounded)."""
+    res_in, res_out = reformat_to_list(atlas_res), reformat_to_list(target_res)
+    nd = len(res_in)
+    size = [int(v) for v in labels_shape]
     if padding_margin is not None:
-        padding_margin = reformat_to_list(padding_margin, length=n_dims, dtype='int')
-        labels_shape = [labels_shape[i] + 2 * padding_margin[i] for i in range(n_dims)]
-    resample_factor = None
-    if atlas_res != target_res:
-        resample_factor = [atlas_res[i] / float(target_res[i]) for i in range(n_dims)]
-    if output_shape is not None:
-        output_shape = reformat_to_list(output_shape, length=n_dims, dtype='int')
-        if resample_factor is not None:
-            output_shape = [min(int(labels_shape[i] * resample_factor[i]), output_shape[i]) for i in range(n_dims)]
-        else:
-            output_shape = [min(labels_shape[i], output_shape[i]) for i in range(n_dims)]
-        if output_div_by_n is not None:
-            tmp = [find_closest_number_divisible_by_m(s, output_div_by_n) for s in output_shape]
-            if output_shape != tmp:
-                print('output shape {0} not divisible by {1}, changed to {2}'.format(output_shape, output_div_by_n, tmp))
-                output_shape = tmp
-        if resample_factor is not None:
-            cropping_shape = [int(np.around(output_shape[i] / resample_factor[i], 0)) for i in range(n_dims)]
-        else:
-            cropping_shape = output_shape
-    else:
-        if output_div_by_n is not None:
-            if resample_factor is not None:
-                output_shape = [int(labels_shape[i] * resample_factor[i]) for i in range(n_dims)]
-                output_shape = [find_closest_number_divisible_by_m(s, output_div_by_n) for s in output_shape]
-                cropping_shape = [int(np.around(output_shape[i] / resample_factor[i], 0)) for i in range(n_dims)]
-            else:
-                cropping_shape = [find_closest_number_divisible_by_m(s, output_div_by_n) for s in labels_shape]
-                output_shape = cropping_shape
-        else:
-            cropping_shape = labels_shape
-            if resample_factor is not None:
-                output_shape = [int(cropping_shape[i] * resample_factor[i]) for i in range(n_dims)]
-            else:
-                output_shape = cropping_shape
-    return cropping_shape, output_shape, padding_margin
+        padding_margin = reformat_to_list(padding_margin, length=nd, dtype='int')
+        size = [v + 2 * m for v, m in zip(size, padding_margin)]
+    zoom = None if res_in == res_out else [a / float(t) for a, t in zip(res_in, res_out)]
+
+    def at_target_res(shape):
+        return list(shape) if zoom is None else [int(v * z) for v, z in zip(shape, zoom)]
+
+    def at_atlas_res(shape):
+        return list(shape) if zoom is None else [int(np.around(v / z, 0)) for v, z in zip(shape, zoom)]
+
+    def snapped(shape):
+        return list(shape) if output_div_by_n is None else [find_closest_number_divisible_by_m(v, output_div_by_n)
+                                                            for v in shape]
+    largest = at_target_res(size)
+    if output_shape is None:
+        out = snapped(largest)
+        crop = size if output_div_by_n is None else at_atlas_res(out)
+        return crop, out, padding_margin
+    wanted = reformat_to_list(output_shape, length=nd, dtype='int')
+    out = [min(a, b) for a, b in zip(largest, wanted)]
+    if snapped(out) != out:
+        print('output shape {0} not divisible by {1}, changed to {2}'.format(out, output_div_by_n, snapped(out)))
+        out = snapped(out)
+    return at_atlas_res(out), out, padding_margin
 
 
 def get_ras_axes(aff, n_dims=3):
-    """ext/lab2im/edit_volumes.py:591-606"""
-    aff_inverted = np.linalg.inv(aff)
-    img_ras_axes = np.argmax(np.absolute(aff_inverted[0:n_dims, 0:n_dims]), axis=0)
-    for i in range(n_dims):
-        if i not in img_ras_axes:
-            unique, counts = np.unique(img_ras_axes, return_counts=True)
-            incorrect_value = unique[np.argmax(counts)]
-            img_ras_axes[np.where(img_ras_axes == incorrect_value)[0][-1]] = i
-    return img_ras_axes
+    """for every image axis the world (R, A, S) axis it runs along: the largest |entry| of its column of inv(aff); if two
+    image axes claim the same world axis, the later one takes the unclaimed axis (ext/lab2im/edit_volumes.py:591-606)"""
+    weight = np.abs(np.linalg.inv(aff)[:n_dims, :n_dims])
+    axes = weight.argmax(axis=0)
+    for free in [i for i in range(n_dims) if i not in axes]:
+        values, counts = np.unique(axes, return_counts=True)
+        crowded = values[counts.argmax()]
+        axes[np.flatnonzero(axes == crowded)[-1]] = free
+    return axes
 
 
 def uniform_f32(u, lo, hi):
@@ -220,18 +209,18 @@ def invert_affine(T):
 
 
 def blurring_sigma_for_downsampling(current_res, downsample_res, mult_coef=None, thickness=None):
-    """ext/lab2im/edit_tensors.py:41-65 (numpy branch)"""
-    current_res = np.array(current_res, dtype=np.float64)
-    downsample_res = np.array(downsample_res, dtype=np.float64)
+    """std dev (in voxels of `current_res`) of the Gaussian that mimics an acquisition at `downsample_res` with slices of
+    `thickness`: coef * min(resolution, thickness) / current; coef .75 by default (.5 where nothing changes); 0 where the
+    target resolution is 0 (ext/lab2im/edit_tensors.py:41-65, numpy branch)"""
+    cur = np.asarray(current_res, dtype=np.float64)
+    acq = np.array(downsample_res, dtype=np.float64)
     if thickness is not None:
-        downsample_res = np.minimum(downsample_res, np.array(thickness, dtype=np.float64))
+        acq = np.minimum(acq, np.asarray(thickness, dtype=np.float64))
     if mult_coef is None:
-        sigma = 0.75 * downsample_res / current_res
-        sigma[downsample_res == current_res] = 0.5
+        sigma = np.where(acq == cur, 0.5, 0.75 * acq / cur)
     else:
-        sigma = mult_coef * downsample_res / current_res
-    sigma[downsample_res == 0] = 0
-    return sigma
+        sigma = mult_coef * acq / cur
+    return np.where(acq == 0, 0.0, sigma)
 
 
 def blur_window(sigma):
@@ -291,16 +280,15 @@ def reliability_profile(n_out, n_down):
 
 
 def get_mapping_lut(source, dest=None):
-    """ext/lab2im/utils.py:894-914"""
-    source = np.array(reformat_to_list(source), dtype='int32')
+    """int32 look-up table lut[source[i]] = dest[i] (default dest = 0..n-1), zeros elsewhere (ext/lab2im/utils.py:894-914)"""
+    keys = np.asarray(reformat_to_list(source), dtype=np.int32)
     if dest is None:
-        dest = np.arange(source.shape[0], dtype='int32')
+        values = np.arange(len(keys), dtype=np.int32)
     else:
         assert len(source) == len(dest), 'label_list and new_label_list should have the same length'
-        dest = np.array(reformat_to_list(dest, dtype='int'))
-    lut = np.zeros(np.max(source) + 1, dtype='int32')
-    for s, d in zip(source, dest):
-        lut[s] = d
+        values = np.asarray(reformat_to_list(dest, dtype='int'))
+    lut = np.zeros(int(keys.max()) + 1, dtype=np.int32)
+    lut[keys] = values            # later duplicates win, as in an element-by-element fill
     return lut
 
 
@@ -330,35 +318,33 @@ def gmm_luts(generation_labels, means, stds):
 
 def draw_value_from_distribution(hyperparameter, size=1, distribution='uniform', centre=0., default_range=10.0,
                                  positive_only=False, rng=None):
-    """numpy branch of utils.draw_value_from_distribution (ext/lab2im/utils.py:961-1049)"""
-    rng = np.random if rng is None else rng
+    """`size` values from U(a, b) or N(a, b) with (a, b) given as in ext/lab2im/utils.py:961-1049 (numpy branch): None ->
+    centre -/+ default_range; a number r -> centre -/+ r; a pair -> (a, b) for every value; an array [2 m, size] -> one of
+    its m two-row blocks, picked at random, row 0 = a, row 1 = b per value.  False -> None (feature switched off)."""
     if hyperparameter is False:
         return None
-    hyperparameter = load_array_if_path(hyperparameter)
-    if not isinstance(hyperparameter, np.ndarray):
-        if hyperparameter is None:
-            hyperparameter = np.array([[centre - default_range] * size, [centre + default_range] * size])
-        elif isinstance(hyperparameter, (int, float)):
-            hyperparameter = np.array([[centre - hyperparameter] * size, [centre + hyperparameter] * size])
-        elif isinstance(hyperparameter, (list, tuple)):
-            assert len(hyperparameter) == 2, 'if list, parameter_range should be of length 2.'
-            hyperparameter = np.transpose(np.tile(np.array(hyperparameter), (size, 1)))
-        else:
-            raise ValueError('parameter_range should either be None, a number, a sequence, or a numpy array.')
+    source = np.random if rng is None else rng
+    hp = load_array_if_path(hyperparameter)
+    if isinstance(hp, np.ndarray):
+        assert hp.shape[0] % 2 == 0, 'number of rows of parameter_range should be divisible by 2'
+        n_blocks = hp.shape[0] // 2
+        block = int(source.randint(n_blocks) if hasattr(source, 'randint') else source.integers(n_blocks))
+        first, second = hp[2 * block, :], hp[2 * block + 1, :]
+    elif hp is None or isinstance(hp, (int, float)):
+        half = default_range if hp is None else hp
+        first, second = np.full(size, centre - half), np.full(size, centre + half)
+    elif isinstance(hp, (list, tuple)):
+        assert len(hp) == 2, 'if list, parameter_range should be of length 2.'
+        first, second = np.repeat(hp[0], size), np.repeat(hp[1], size)
     else:
-        assert hyperparameter.shape[0] % 2 == 0, 'number of rows of parameter_range should be divisible by 2'
-        n_modalities = int(hyperparameter.shape[0] / 2)
-        modality_idx = 2 * int(rng.randint(n_modalities) if hasattr(rng, 'randint') else rng.integers(n_modalities))
-        hyperparameter = hyperparameter[modality_idx: modality_idx + 2, :]
+        raise ValueError('parameter_range should either be None, a number, a sequence, or a numpy array.')
     if distribution == 'uniform':
-        value = rng.uniform(low=hyperparameter[0, :], high=hyperparameter[1, :])
+        value = source.uniform(low=first, high=second)
     elif distribution == 'normal':
-        value = rng.normal(loc=hyperparameter[0, :], scale=hyperparameter[1, :])
+        value = source.normal(loc=first, scale=second)
     else:
         raise ValueError("Distribution not supported, should be 'uniform' or 'normal'.")
-    if positive_only:
-        value[value < 0] = 0
-    return value
+    return np.maximum(value, 0) if positive_only else value
 
 
 def randomise_res_plan(u_rr, u_blur, blur_range, atlas_res, crop_shape, output_shape, max_res=9.0, prob_min=0.05):

@@ -1,7 +1,7 @@
-"""Volume IO / orientation helpers the hot path's callers need — counterparts of
-ext/lab2im/utils.py:76-160 (`load_volume`, `save_volume`), :163-206 (`get_volume_info`), :209-285
-(`get_list_labels`), :391-424 (`list_images_in_folder`) and ext/lab2im/edit_volumes.py:591-654
-(`get_ras_axes`, `align_volume_to_ref`) and :504-556 (`resample_volume`).  NIfTI only (own reader, nifti.py; nibabel is not installed).
+"""Volume IO / orientation helpers the callers of the hot path need.  Same names, arguments and results as the reference's
+ext/lab2im/utils.py:76-160 (`load_volume`, `save_volume`), :163-206 (`get_volume_info`), :209-285 (`get_list_labels`),
+:391-424 (`list_images_in_folder`), ext/lab2im/edit_volumes.py:591-654 (`get_ras_axes`, `align_volume_to_ref`), :504-556
+(`resample_volume`) and :148-176 (`rescale_volume`); NIfTI / MGZ through this package's own readers (nifti.py, mgh.py).
 """
 import glob
 import os
@@ -20,46 +20,44 @@ def get_dims(shape, max_channels=10):
     return len(shape), 1
 
 
+_VOLUME_EXTENSIONS = ('.nii.gz', '.nii', '.mgz', '.npz')
+
+
 def list_images_in_folder(path_dir, include_single_image=True, check_if_empty=True):
-    basename = os.path.basename(path_dir)
-    if include_single_image and (('.nii.gz' in basename) or ('.nii' in basename) or ('.mgz' in basename) or
-                                 ('.npz' in basename)):
+    """sorted paths of the volumes (.nii, .nii.gz, .mgz, .npz) of a folder; the path of a single volume gives [path]"""
+    name = os.path.basename(path_dir)
+    if include_single_image and any(ext in name for ext in _VOLUME_EXTENSIONS):
         assert os.path.isfile(path_dir), 'file %s does not exist' % path_dir
         return [path_dir]
     if not os.path.isdir(path_dir):
         raise Exception('Folder does not exist: %s' % path_dir)
-    lst = sorted(glob.glob(os.path.join(path_dir, '*nii.gz')) + glob.glob(os.path.join(path_dir, '*nii')) +
-                 glob.glob(os.path.join(path_dir, '*.mgz')) + glob.glob(os.path.join(path_dir, '*.npz')))
-    if check_if_empty:
-        assert len(lst) > 0, 'no .nii, .nii.gz, .mgz or .npz image could be found in %s' % path_dir
-    return lst
+    found = sorted(os.path.join(path_dir, f) for f in os.listdir(path_dir)
+                   if not f.startswith('.') and f.endswith(('nii.gz', 'nii', '.mgz', '.npz')))
+    assert found or not check_if_empty, 'no .nii, .nii.gz, .mgz or .npz image could be found in %s' % path_dir
+    return found
 
 
 def align_volume_to_ref(volume, aff, aff_ref=None, return_aff=False, n_dims=None, return_copy=True):
-    """ext/lab2im/edit_volumes.py:609-654"""
-    new_volume = volume.copy() if return_copy else volume
-    aff_flo = np.array(aff, dtype=np.float64)
-    if aff_ref is None:
-        aff_ref = np.eye(4)
+    """Re-orders and flips the spatial axes of `volume` (affine `aff`) so that they run along the same world axes, in the
+    same direction, as those of a volume with affine `aff_ref` (identity = RAS); result of
+    ext/lab2im/edit_volumes.py:609-654.  Returns the volume (a view unless return_copy), and its affine if return_aff."""
+    out = volume.copy() if return_copy else volume
+    aff_new = np.array(aff, dtype=np.float64)
+    aff_ref = np.eye(4) if aff_ref is None else np.asarray(aff_ref)
     if n_dims is None:
-        n_dims, _ = get_dims(new_volume.shape)
-    ras_ref = get_ras_axes(aff_ref, n_dims=n_dims)
-    ras_flo = get_ras_axes(aff_flo, n_dims=n_dims)
-    aff_flo[:, ras_ref] = aff_flo[:, ras_flo]
-    for i in range(n_dims):
-        if ras_flo[i] != ras_ref[i]:
-            new_volume = np.swapaxes(new_volume, ras_flo[i], ras_ref[i])
-            swapped = int(np.where(ras_flo == ras_ref[i])[0][0])
-            ras_flo[swapped], ras_flo[i] = ras_flo[i], ras_flo[swapped]
-    dots = np.sum(aff_flo[:3, :3] * np.asarray(aff_ref)[:3, :3], axis=0)
-    for i in range(n_dims):
-        if dots[i] < 0:
-            new_volume = np.flip(new_volume, axis=i)
-            aff_flo[:, i] = -aff_flo[:, i]
-            aff_flo[:3, 3] = aff_flo[:3, 3] - aff_flo[:3, i] * (new_volume.shape[i] - 1)
-    if return_aff:
-        return new_volume, aff_flo
-    return new_volume
+        n_dims, _ = get_dims(out.shape)
+    # get_ras_axes: world axis -> image axis.  Output image axis to[w] must carry what input image axis frm[w] carries.
+    to, frm = get_ras_axes(aff_ref, n_dims=n_dims), get_ras_axes(aff_new, n_dims=n_dims)
+    order = np.arange(out.ndim)
+    order[to] = frm
+    out = np.transpose(out, order)
+    aff_new[:, to] = aff_new[:, frm].copy()
+    # an axis pointing against its reference axis is reversed; the origin moves to the other end of that axis
+    for k in np.flatnonzero(np.sum(aff_new[:3, :3] * aff_ref[:3, :3], axis=0)[:n_dims] < 0):
+        out = np.flip(out, axis=k)
+        aff_new[:, k] = -aff_new[:, k]
+        aff_new[:3, 3] -= aff_new[:3, k] * (out.shape[k] - 1)
+    return (out, aff_new) if return_aff else out
 
 
 def load_volume(path_volume, im_only=True, squeeze=True, dtype=None, aff_ref=None):
@@ -204,26 +202,18 @@ def rescale_volume(volume, new_min=0, new_max=255, min_percentile=2, max_percent
 
 
 def get_volume_info(path_volume, return_volume=False, aff_ref=None, max_channels=10):
+    """([volume,] spatial shape, affine, n_dims, n_channels, header, voxel size) of a volume file; with `aff_ref` the
+    shape and voxel size (and the volume) are given in the axis order of that orientation (ext/lab2im/utils.py:163-206)"""
     im, aff, header = load_volume(path_volume, im_only=False)
-    im_shape = list(im.shape)
-    n_dims, n_channels = get_dims(im_shape, max_channels=max_channels)
-    im_shape = im_shape[:n_dims]
-    if '.nii' in path_volume:
-        data_res = np.array(header['pixdim'][1:n_dims + 1], dtype=np.float64)
-    else:
-        data_res = np.array([1.0] * n_dims)
+    n_dims, n_channels = get_dims(list(im.shape), max_channels=max_channels)
+    shape = np.array(im.shape[:n_dims])
+    res = np.array(header['pixdim'][1:n_dims + 1], dtype=np.float64) if '.nii' in path_volume else np.ones(n_dims)
     if aff_ref is not None:
-        ras_axes = get_ras_axes(aff, n_dims=n_dims)
-        ras_axes_ref = get_ras_axes(aff_ref, n_dims=n_dims)
+        here, there = get_ras_axes(aff, n_dims=n_dims), get_ras_axes(aff_ref, n_dims=n_dims)
         im = align_volume_to_ref(im, aff, aff_ref=aff_ref, n_dims=n_dims)
-        im_shape = np.array(im_shape)
-        data_res = np.array(data_res)
-        im_shape[ras_axes_ref] = im_shape[ras_axes]
-        data_res[ras_axes_ref] = data_res[ras_axes]
-        im_shape = im_shape.tolist()
-    if return_volume:
-        return im, im_shape, aff, n_dims, n_channels, header, data_res
-    return im_shape, aff, n_dims, n_channels, header, data_res
+        shape[there], res[there] = shape[here].copy(), res[here].copy()
+    info = (shape.tolist(), aff, n_dims, n_channels, header, res)
+    return (im,) + info if return_volume else info
 
 
 _NEUTRAL_FS = [0, 14, 15, 16, 21, 22, 23, 24, 72, 77, 80, 85, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 165, 200,
@@ -232,43 +222,40 @@ _NEUTRAL_FS = [0, 14, 15, 16, 21, 22, 23, 24, 72, 77, 80, 85, 100, 101, 102, 103
                533, 534, 535, 536, 537]
 
 
+# FreeSurfer label values by side (the classification of ext/lab2im/utils.py:239-262), inclusive ranges
+_LEFT_FS = ((1, 13), (17, 20), (25, 39), (136, 138), (1000, 1035), (865, 865), (20101, 20109))
+_RIGHT_FS = ((40, 71), (163, 164), (2000, 2035), (20001, 20009), (139, 139), (866, 866))
+
+
+def _fs_side(label):
+    if label in _NEUTRAL_FS:
+        return 0
+    for side, ranges in ((1, _LEFT_FS), (2, _RIGHT_FS)):
+        if any(lo <= label <= hi for lo, hi in ranges):
+            return side
+    raise Exception('label {} not in our current FS classification, '
+                    'please update get_list_labels in utils.py'.format(label))
+
+
 def get_list_labels(label_list=None, labels_dir=None, save_label_list=None, FS_sort=False):
-    """ext/lab2im/utils.py:209-285"""
+    """(int32 label values, n_neutral_labels | None): the given list, or every value found in the label maps of
+    `labels_dir`; with FS_sort ordered [neutral, left, right] (each ascending), n_neutral counting the whole list when only
+    one side is present (ext/lab2im/utils.py:209-285)"""
     if label_list is not None:
-        label_list = hm.load_array_if_path(label_list)
-        label_list = np.array(hm.reformat_to_list(label_list, dtype='int'))
+        labels = np.array(hm.reformat_to_list(hm.load_array_if_path(label_list), dtype='int'))
     elif labels_dir is not None:
-        label_list = np.empty(0)
+        labels = np.zeros(0, dtype='int')
         for path in list_images_in_folder(labels_dir):
-            y = load_volume(path, dtype='int32')
-            label_list = np.unique(np.concatenate((label_list, np.unique(y)))).astype('int')
+            labels = np.union1d(labels, np.unique(load_volume(path, dtype='int32'))).astype('int')
     else:
         raise Exception('either label_list, path_label_list or labels_dir should be provided')
-    n_neutral_labels = 0
+    n_neutral = None
     if FS_sort:
-        neutral, left, right = [], [], []
-        for la in label_list:
-            if la in _NEUTRAL_FS:
-                if la not in neutral:
-                    neutral.append(la)
-            elif (0 < la < 14) | (16 < la < 21) | (24 < la < 40) | (135 < la < 139) | (1000 <= la <= 1035) | \
-                    (la == 865) | (20100 < la < 20110):
-                if la not in left:
-                    left.append(la)
-            elif (39 < la < 72) | (162 < la < 165) | (2000 <= la <= 2035) | (20000 < la < 20010) | (la == 139) | \
-                    (la == 866):
-                if la not in right:
-                    right.append(la)
-            else:
-                raise Exception('label {} not in our current FS classification, '
-                                'please update get_list_labels in utils.py'.format(la))
-        label_list = np.concatenate([sorted(neutral), sorted(left), sorted(right)])
-        if ((len(left) > 0) & (len(right) > 0)) | ((len(left) == 0) & (len(right) == 0)):
-            n_neutral_labels = len(neutral)
-        else:
-            n_neutral_labels = len(label_list)
+        sides = np.array([_fs_side(int(v)) for v in labels], dtype=int)
+        groups = [np.unique(labels[sides == k]) for k in range(3)]
+        labels = np.concatenate(groups)
+        one_sided = (len(groups[1]) > 0) != (len(groups[2]) > 0)
+        n_neutral = len(labels) if one_sided else len(groups[0])
     if save_label_list is not None:
-        np.save(save_label_list, np.int32(label_list))
-    if FS_sort:
-        return np.int32(label_list), n_neutral_labels
-    return np.int32(label_list), None
+        np.save(save_label_list, np.int32(labels))
+    return np.int32(labels), n_neutral
