@@ -176,7 +176,10 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
              model_file_has_different_lhood_layer=False, seed=0, verbose=True):
     """Parameters as documented in SynthSR/training.py:90-240 (+ `seed`, `verbose`)."""
     import torch
-    n_channels = len(hm.reformat_to_list(input_channels))
+    # the launcher script hands `--input_channels` over as text (scripts/training.py:36 of the reference): 'True' / 'False'
+    input_channels = [{'True': True, 'False': False}.get(c, c) if isinstance(c, str) else c
+                      for c in hm.reformat_to_list(input_channels)]
+    n_channels = len(input_channels)
     if output_channel is not None:
         output_channel = list(hm.reformat_to_list(output_channel))
     # checks, training.py:252-271
