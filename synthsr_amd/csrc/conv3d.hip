@@ -104,7 +104,7 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t
     // channel-octet qp holds 16 four-channel groups, G = r*16 + (lane >> 2) = h*24 + kk*6 + g  ->  input channel
     // cc*24 + qp*8 + h*4 + kk, output channels 4g + (lane & 3); the kernel selects a group with the MFMA's ABID.
     const int lane = (int)(idx & 63);
-    int64_t r = idx >> 6;
+    uint32_t r = (uint32_t)(idx >> 6);  // 32-bit index arithmetic: a weight set has < 2^31 values (checked by the launcher)
     const int rr = (int)(r % 3);
     r /= 3;
     const int qp = (int)(r % 3);
@@ -117,7 +117,7 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t
     return weight_value(w, tap, cie, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
   }
   if (idx >= mfma_count) {
-    int64_t r = idx - mfma_count;
+    uint32_t r = (uint32_t)(idx - mfma_count);
     const int v = (int)(r % NV);
     r /= NV;
     const int cil = (int)(r % CK);
@@ -128,7 +128,7 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t
     return weight_value(w, tap, cc * CK + cil, coutE - NV + v, Cin_total, ci_off, Cin, Cout, mode, parity);
   }
   const int NCG = CK / 8;
-  int64_t r = idx;
+  uint32_t r = (uint32_t)idx;
   const int s = (int)(r & 1);
   r >>= 1;
   const int lane = (int)(r & 63);
@@ -3448,6 +3448,7 @@ int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3]
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
   const FwdPlan pl = plan_fwd(shape, CinE, CoutE, up ? (mode == 0 ? 2 : 0) : 1);
   const int64_t per = pl.count();
+  if (per >= (1ll << 31)) return SYNTHSR_EINVAL;  // pack_value indexes one weight set with 32-bit arithmetic
   const int64_t total = per * (up ? 8 : 1);
   if (!packed) return total;
   if (!w) return SYNTHSR_EINVAL;
