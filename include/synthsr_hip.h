@@ -336,6 +336,24 @@ int synthsr_seg_dice_bwd(const float* probs, const int32_t* seg, int64_t nvox, i
 int synthsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
                       float beta2, float eps, float grad_scale, synthsr_stream_t stream);
 
+/* ------------------------------------------------------------------ WGAN-GP critic pieces
+ * (SynthSR/fine_tuning_with_adversary.py:482-508 `make_discriminator`, :579-595 `build_discriminator_loss`) */
+/* LeakyReLU: dy == NULL: out = x > 0 ? x : alpha x (in place allowed); else out = dy * (x > 0 ? 1 : alpha), x = layer output */
+int synthsr_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float alpha, synthsr_stream_t stream);
+/* stride-2 'same' Conv3D of an even-sized volume = its stride-1 result at the odd positions: lo[o] = hi[2 o + 1]
+ * (hi [2 lo_shape, C]), and the adjoint hi = 0 except hi[2 o + 1] = lo[o] */
+int synthsr_pick_odd(const float* hi, float* lo, const int lo_shape[3], int C, synthsr_stream_t stream);
+int synthsr_spread_odd(const float* lo, float* hi, const int lo_shape[3], int C, synthsr_stream_t stream);
+/* Dense: y [n_out] = b + x [n_in] . W [n_in][n_out] (Keras layout; n_out <= 1024; b optional) */
+int synthsr_dense_fwd(const float* x, const float* W, const float* b, float* y, int64_t n_in, int n_out,
+                      synthsr_stream_t stream);
+/* dx [n_in] = W dy (optional, written), dW [n_in][n_out] += x (x) dy (optional) */
+int synthsr_dense_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, int64_t n_in, int n_out,
+                      synthsr_stream_t stream);
+/* out = a x + b y (y optional) ; *out += sum x^2 */
+int synthsr_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, synthsr_stream_t stream);
+int synthsr_sumsq(const float* x, int64_t n, float* out, synthsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -207,3 +207,38 @@ def adam_keras(p, g, m, v, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, decay=0.0):
     m = b1 * m + (1 - b1) * g
     v = b2 * v + (1 - b2) * g * g
     return p - lr_t * m / (v.sqrt() + eps), m, v
+
+
+# ---------------------------------------------------------------------- WGAN-GP critic (fine_tuning_with_adversary.py)
+def critic_forward(x, P, name='discriminator', n_levels=4, alpha=0.2):
+    """make_discriminator (SynthSR/fine_tuning_with_adversary.py:482-508) for one volume x [d0,d1,d2,C]: per level a
+    stride-1 and a stride-2 Conv3D(3, 'same') each followed by LeakyReLU(.2), Flatten (channels last), Dense + LeakyReLU,
+    Dense(1).  TensorFlow's 'same' padding of a stride-2 conv on an even size is (0, 1).  Third-party Keras layers:
+    UNPINNED restatement.  Returns the scalar D(x)."""
+    h = to_ncdhw(x)
+    i = 0
+    for _ in range(n_levels):
+        for stride in (1, 2):
+            w = P['%s_conv_%d/kernel' % (name, i)].permute(4, 3, 0, 1, 2)
+            b = P['%s_conv_%d/bias' % (name, i)]
+            if stride == 1:
+                h = F.conv3d(h, w, b, padding=1)
+            else:
+                h = F.conv3d(F.pad(h, (0, 1, 0, 1, 0, 1)), w, b, stride=2)
+            h = F.leaky_relu(h, alpha)
+            i += 1
+    f = from_ncdhw(h).reshape(-1)
+    h9 = F.leaky_relu(f @ P['%s_dense_0/kernel' % name] + P['%s_dense_0/bias' % name], alpha)
+    return (h9 @ P['%s_dense_1/kernel' % name] + P['%s_dense_1/bias' % name]).reshape(())
+
+
+def critic_loss(real, fake, u_mix, P, name='discriminator', n_levels=4, gp_weight=10.0):
+    """build_discriminator_loss (:579-595) with RandomWeightedAverage (:604-624) and Gradients (:627-642), batch of one:
+    -D(real) + D(fake) + gp_weight (1 - ||grad_x D(x_hat)||_2)^2.  Returns (loss, grad norm); differentiable w.r.t. P."""
+    d_real = critic_forward(real, P, name, n_levels)
+    d_fake = critic_forward(fake, P, name, n_levels)
+    x_hat = (u_mix * real + (1 - u_mix) * fake).detach().requires_grad_(True)
+    d_hat = critic_forward(x_hat, P, name, n_levels)
+    g, = torch.autograd.grad(d_hat, x_hat, create_graph=True)
+    norm = torch.sqrt((g * g).sum())
+    return -d_real + d_fake + gp_weight * (1 - norm) ** 2, norm

@@ -81,6 +81,13 @@ SIGNATURES = {
     'synthsr_ssim_filter': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _S]),
     'synthsr_ssim_point': (c_int, [_P, c_int64, c_float, c_float, _P, _P, _S]),
     'synthsr_ssim_combine': (c_int, [_P, _P, _P, _P, _P, _P, _S]),
+    'synthsr_leaky_relu': (c_int, [_P, _P, _P, c_int64, c_float, _S]),
+    'synthsr_pick_odd': (c_int, [_P, _P, _P, c_int, _S]),
+    'synthsr_spread_odd': (c_int, [_P, _P, _P, c_int, _S]),
+    'synthsr_dense_fwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, _S]),
+    'synthsr_dense_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),
+    'synthsr_axpby': (c_int, [_P, _P, _P, c_int64, c_float, c_float, _S]),
+    'synthsr_sumsq': (c_int, [_P, c_int64, _P, _S]),
     'synthsr_bn_elu_bwd_head': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
     'synthsr_head_bwd_ex': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _S]),
     'synthsr_seg_head_fwd': (c_int, [_P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, c_int, _P, _S]),

@@ -16,6 +16,7 @@ ARCH = 'gfx950'
 SOURCES = [('generator.hip', ['-ffp-contract=off']),
            ('unet_pointwise.hip', []),
            ('ssim.hip', []),
+           ('critic.hip', []),
            ('conv3d.hip', [])]
 
 

@@ -1,0 +1,208 @@
+"""WGAN-GP critic of the adversarial fine-tuning (SynthSR/fine_tuning_with_adversary.py:482-508 `make_discriminator`,
+:579-595 `build_discriminator_loss`, :604-642 `RandomWeightedAverage` / `Gradients`) on the HIP kernels.
+
+Network: n_levels x [Conv3D(f, 3, stride 1) + LeakyReLU(.2), Conv3D(f, 3, stride 2) + LeakyReLU(.2)], f = n_filters 2^level,
+Flatten (channels last), Dense(n_filters 2^n_levels) + LeakyReLU(.2), Dense(1).  Strided layers = stride-1 kernel + odd
+positions (csrc/critic.hip).
+
+Critic loss on (real, fake):  -D(real) + D(fake) + lambda (1 - ||grad_x D(x_hat)||_2)^2,  x_hat = w real + (1 - w) fake.
+The network is piecewise linear, so the gradient of the penalty w.r.t. the weights needs no second derivatives of the
+activations: with delta_l the back-propagated signals of grad_x D and u_0 = d penalty / d grad_x D, a "masked forward" pass
+u_l = mask_l * conv_l(u_{l-1}) gives  d penalty / d W_l = weight-gradient(u_{l-1}, delta_l)  (the backward pass is linear in
+every W_l); biases get no penalty gradient.
+
+First functional version: every convolution goes through the generic (CK = 8) kernels because the critic's channel
+counts (32 ... 256) are not multiples of 24, and the strided layers compute 8x the needed outputs - correct, not fast."""
+import numpy as np
+import torch
+
+from . import ops
+
+ALPHA = 0.2
+
+
+class Critic3D:
+    def __init__(self, input_shape, n_filters=32, n_levels=4, device=None, seed=0, name='discriminator'):
+        if len(input_shape) != 4:
+            raise NotImplementedError('3-D volumes only')
+        shape = [int(s) for s in input_shape[:3]]
+        if any(s % (2 ** n_levels) for s in shape):
+            raise ValueError('spatial shape %s must be divisible by 2**n_levels = %d' % (shape, 2 ** n_levels))
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.input_shape, self.name = shape + [int(input_shape[3])], name
+        self.convs, self.specs = [], []
+        cin = self.input_shape[3]
+        for level in range(n_levels):
+            f = n_filters * 2 ** level
+            for stride in (1, 2):
+                i = len(self.convs)
+                self.convs.append(dict(cin=cin, cout=f, stride=stride, shape=list(shape),
+                                       w=self._add('%s_conv_%d/kernel' % (name, i), (3, 3, 3, cin, f)),
+                                       b=self._add('%s_conv_%d/bias' % (name, i), (f,))))
+                cin = f
+                if stride == 2:
+                    shape = [s // 2 for s in shape]
+        self.flat_shape = shape + [cin]
+        n_flat, n_dense = int(np.prod(self.flat_shape)), n_filters * 2 ** n_levels
+        self.dense = [dict(n_in=n_flat, n_out=n_dense, w=self._add('%s_dense_0/kernel' % name, (n_flat, n_dense)),
+                           b=self._add('%s_dense_0/bias' % name, (n_dense,))),
+                      dict(n_in=n_dense, n_out=1, w=self._add('%s_dense_1/kernel' % name, (n_dense, 1)),
+                           b=self._add('%s_dense_1/bias' % name, (1,)))]
+        self.n_params = sum(int(np.prod(s)) for _, s in self.specs)
+        self.offsets, off = {}, 0
+        for nm, shp in self.specs:
+            self.offsets[nm] = (off, shp)
+            off += int(np.prod(shp))
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.adam_m, self.adam_v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        self.iterations = 0
+        self._bufs = {}
+        g = torch.Generator().manual_seed(int(seed))
+        for nm, shp in self.specs:   # Keras defaults: glorot_uniform kernels, zero biases
+            if nm.endswith('/kernel'):
+                rf = int(np.prod(shp[:-2])) if len(shp) > 2 else 1
+                limit = float(np.sqrt(6.0 / (rf * shp[-2] + rf * shp[-1])))
+                self.view(nm).copy_(((torch.rand(shp, generator=g) * 2 - 1) * limit).to(self.device))
+        self.repack()
+
+    # ------------------------------------------------------------------ bookkeeping
+    def _add(self, name, shape):
+        self.specs.append((name, tuple(shape)))
+        return name
+
+    def view(self, name, buf=None):
+        off, shp = self.offsets[name]
+        return (self.params if buf is None else buf)[off:off + int(np.prod(shp))].view(*shp)
+
+    def buf(self, key, shape):
+        n = int(np.prod(shape))
+        t = self._bufs.get(key)
+        if t is None or t.numel() < n:
+            t = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._bufs[key] = t
+        return t[:n].view(*shape)
+
+    def repack(self):
+        for c in self.convs:
+            c['wp'] = ops.pack_conv_weights(self.view(c['w']), c['shape'], 0, out=c.get('wp'))
+            c['wpd'] = ops.pack_conv_weights(self.view(c['w']), c['shape'], 1, out=c.get('wpd'))
+
+    def state_dict(self):
+        return {nm: self.view(nm).detach().cpu().clone() for nm, _ in self.specs}
+
+    def load_state_dict(self, sd):
+        for nm, _ in self.specs:
+            self.view(nm).copy_(torch.as_tensor(sd[nm]).to(self.device).reshape(self.view(nm).shape))
+        self.repack()
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, x, tag='a'):
+        """x [d0,d1,d2,C] -> D(x) as a 1-element device tensor; the LeakyReLU outputs are kept under `tag`"""
+        hs = [x]
+        cur = x
+        for i, c in enumerate(self.convs):
+            full = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 0,
+                              out=self.buf('full', c['shape'] + [c['cout']]) if c['stride'] == 2 else
+                              self.buf('h%s%d' % (tag, i), c['shape'] + [c['cout']]))
+            cur = ops.pick_odd(full, out=self.buf('h%s%d' % (tag, i), [s // 2 for s in c['shape']] + [c['cout']])) \
+                if c['stride'] == 2 else full
+            ops.leaky_relu(cur, ALPHA)
+            hs.append(cur)
+        d0, d1 = self.dense
+        h9 = ops.dense_fwd(cur.reshape(-1), self.view(d0['w']), self.view(d0['b']), out=self.buf('h%s_d' % tag, [d0['n_out']]))
+        ops.leaky_relu(h9, ALPHA)
+        out = ops.dense_fwd(h9, self.view(d1['w']), self.view(d1['b']), out=self.buf('out' + tag, [1]))
+        self._saved = dict(hs=hs, h9=h9, tag=tag)
+        return out
+
+    def backward(self, dout=1.0, weight_grads=True, input_grad=False, keep_deltas=False):
+        """back-propagates dD = dout through the pass stored by the last forward(): accumulates the weight gradients into
+        self.grads (weight_grads), returns grad_x D * dout (input_grad), keeps the per-layer signals for the penalty"""
+        hs, h9 = self._saved['hs'], self._saved['h9']
+        d0, d1 = self.dense
+        G = self.grads
+        dD = self.buf('dD', [1])
+        dD.fill_(float(dout))
+        dh9 = self.buf('dh9', [d1['n_in']])
+        ops.dense_bwd(h9, self.view(d1['w']), dD, dx=dh9, dW=self.view(d1['w'], G) if weight_grads else None)
+        delta9 = ops.leaky_relu_bwd(dh9, h9, ALPHA, out=self.buf('delta9', [d1['n_in']]))
+        flat = hs[-1].reshape(-1)
+        dflat = self.buf('dflat', [d0['n_in']])
+        ops.dense_bwd(flat, self.view(d0['w']), delta9, dx=dflat, dW=self.view(d0['w'], G) if weight_grads else None)
+        if weight_grads:
+            self.view(d1['b'], G).add_(dD)
+            self.view(d0['b'], G).add_(delta9)
+        deltas = [None] * len(self.convs)
+        delta = ops.leaky_relu_bwd(dflat.view(*hs[-1].shape), hs[-1], ALPHA,
+                                   out=self.buf('delta%d' % (len(self.convs) - 1), list(hs[-1].shape)))
+        g = None
+        for i in range(len(self.convs) - 1, -1, -1):
+            c = self.convs[i]
+            deltas[i] = delta
+            dz = ops.spread_odd(delta, out=self.buf('dzfull', c['shape'] + [c['cout']])) if c['stride'] == 2 else delta
+            if weight_grads:
+                ops.conv3d_wgrad(hs[i], dz, self.view(c['w'], G), dbias=self.view(c['b'], G))
+            if i > 0 or input_grad:
+                g = ops.conv3d(dz, c['wpd'], None, c['cin'], 0, out=self.buf('g%d' % (i & 1), c['shape'] + [c['cin']]))
+                if i > 0:
+                    delta = ops.leaky_relu_bwd(g, hs[i], ALPHA, out=self.buf('delta%d' % (i - 1), list(hs[i].shape)))
+        if keep_deltas:
+            self._deltas, self._delta9 = deltas, delta9
+        return g if input_grad else None
+
+    def input_gradient(self, x, dout=1.0):
+        """dout * grad_x D(x) (critic frozen): the adversarial term of the generator loss"""
+        self.forward(x, tag='g')
+        return self.backward(dout, weight_grads=False, input_grad=True)
+
+    # ------------------------------------------------------------------ WGAN-GP
+    def critic_loss_and_grads(self, real, fake, u_mix, gp_weight=10.0):
+        """loss = -D(real) + D(fake) + gp_weight (1 - ||grad D(x_hat)||)^2 with x_hat = u real + (1 - u) fake
+        (build_discriminator_loss, batch of one); self.grads = its gradient.  Returns (loss, D(real), D(fake), ||grad||)"""
+        self.grads.zero_()
+        d_real = self.forward(real, 'a').clone()
+        self.backward(-1.0)
+        d_fake = self.forward(fake, 'a').clone()
+        self.backward(+1.0)
+        x_hat = ops.axpby(real, fake, float(u_mix), 1.0 - float(u_mix), out=self.buf('x_hat', list(real.shape)))
+        self.forward(x_hat, 'p')
+        g0 = self.backward(1.0, weight_grads=False, input_grad=True, keep_deltas=True)
+        nsq = self.buf('nsq', [1])
+        nsq.zero_()
+        ops.sumsq(g0, nsq)
+        norm = float(torch.sqrt(nsq).item())          # one host sync per critic step, like Keras' train_on_batch return
+        penalty = gp_weight * (1.0 - norm) ** 2
+        if norm > 0:
+            self._penalty_backward(g0, gp_weight * 2.0 * (norm - 1.0) / norm)
+        loss = -float(d_real.item()) + float(d_fake.item()) + penalty
+        return loss, float(d_real.item()), float(d_fake.item()), norm
+
+    def _penalty_backward(self, g0, scale):
+        """adds d penalty / d W to self.grads: masked forward pass of u_0 = scale * grad_x D(x_hat)"""
+        hs, h9 = self._saved['hs'], self._saved['h9']
+        G = self.grads
+        u = ops.axpby(g0, None, scale, 0.0, out=self.buf('u0', list(g0.shape)))
+        for i, c in enumerate(self.convs):
+            delta = self._deltas[i]
+            dz = ops.spread_odd(delta, out=self.buf('dzfull', c['shape'] + [c['cout']])) if c['stride'] == 2 else delta
+            ops.conv3d_wgrad(u, dz, self.view(c['w'], G))
+            full = ops.conv3d(u, c['wp'], None, c['cout'], 0, out=self.buf('full', c['shape'] + [c['cout']]))
+            v = ops.pick_odd(full, out=self.buf('v%d' % (i & 1), [s // 2 for s in c['shape']] + [c['cout']])) \
+                if c['stride'] == 2 else full
+            u = ops.leaky_relu_bwd(v, hs[i + 1], ALPHA, out=self.buf('u%d' % ((i + 1) & 1), list(hs[i + 1].shape)))
+        d0, d1 = self.dense
+        uflat = u.reshape(-1)
+        ops.dense_bwd(uflat, self.view(d0['w']), self._delta9, dx=None, dW=self.view(d0['w'], G))
+        v9 = ops.dense_fwd(uflat, self.view(d0['w']), None, out=self.buf('v9', [d0['n_out']]))
+        self.view(d1['w'], G).view(-1).add_(ops.leaky_relu_bwd(v9, h9, ALPHA, out=self.buf('m9v9', [d0['n_out']])))
+
+    def adam_step(self, lr=1e-4, decay=0.0, beta1=0.9, beta2=0.999, eps=1e-7):
+        """keras.optimizers.Adam (2.3.1) update of the critic, then re-packs the conv weights"""
+        if decay > 0:
+            lr = lr * (1.0 / (1.0 + decay * self.iterations))
+        self.iterations += 1
+        t = self.iterations
+        lr_t = lr * (np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
+        ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, lr_t, beta1, beta2, eps)
+        self.repack()

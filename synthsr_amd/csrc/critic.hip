@@ -1,0 +1,169 @@
+// Pointwise / dense pieces of the WGAN-GP critic of SynthSR/fine_tuning_with_adversary.py:482-508 (`make_discriminator`:
+// [Conv3D(3, stride 1) + LeakyReLU(.2), Conv3D(3, stride 2) + LeakyReLU(.2)] x n_levels -> Flatten -> Dense ->
+// LeakyReLU(.2) -> Dense(1)).  The 3x3x3 convolutions run through conv3d.hip; a stride-2 'same' convolution of an even-sized
+// volume is its stride-1 result at the odd positions (TensorFlow pads 0 in front and 1 behind), so `pick_odd` /
+// `spread_odd` turn the stride-1 kernels (forward, data gradient, weight gradient) into the strided layer.  All HBM-bound.
+#include "common.h"
+
+namespace {
+
+// y = x > 0 ? x : alpha x (in place allowed); with dy: dx = dy * (y > 0 ? 1 : alpha), y being the layer OUTPUT (its sign is
+// the input's sign)
+__global__ __launch_bounds__(256) void leaky_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    float* __restrict__ out, int64_t n, float alpha) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    out[i] = dy ? dy[i] * (v > 0.f ? 1.f : alpha) : (v > 0.f ? v : alpha * v);
+  }
+}
+
+// forward = 1: lo[o] = hi[2 o + 1] (channels-last, hi [2d0,2d1,2d2,C], lo [d0,d1,d2,C]);
+// forward = 0: hi = 0 except hi[2 o + 1] = lo[o] (the adjoint)
+__global__ __launch_bounds__(256) void odd_kernel(float* __restrict__ hi, float* __restrict__ lo, int d0, int d1, int d2,
+                                                  int C, int forward) {
+  if (forward) {
+    const int64_t n = (int64_t)d0 * d1 * d2 * C;
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const int c = (int)(i % C);
+      int64_t v = i / C;
+      const int x = (int)(v % d2);
+      v /= d2;
+      const int y = (int)(v % d1), z = (int)(v / d1);
+      lo[i] = hi[((((int64_t)(2 * z + 1) * (2 * d1)) + (2 * y + 1)) * (2 * d2) + (2 * x + 1)) * C + c];
+    }
+  } else {
+    const int64_t n = (int64_t)d0 * d1 * d2 * 8 * C;
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const int c = (int)(i % C);
+      int64_t v = i / C;
+      const int x = (int)(v % (2 * d2));
+      v /= 2 * d2;
+      const int y = (int)(v % (2 * d1)), z = (int)(v / (2 * d1));
+      const bool odd = (x & 1) && (y & 1) && (z & 1);
+      hi[i] = odd ? lo[(((int64_t)(z >> 1) * d1 + (y >> 1)) * d2 + (x >> 1)) * C + c] : 0.f;
+    }
+  }
+}
+
+// Dense layer y[j] = b[j] + sum_i x[i] W[i][j]  (W [n_in][n_out], Keras layout).  One workgroup per slab of rows, partial
+// sums to LDS, then atomics on the n_out outputs (n_out <= 1024): W (up to 524 MB) is streamed once, coalesced along j.
+__global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                        const float* __restrict__ b, float* __restrict__ y, int64_t n_in,
+                                                        int n_out, int rows_per_block) {
+  extern __shared__ float acc[];  // [n_out]
+  for (int j = threadIdx.x; j < n_out; j += 256) acc[j] = (blockIdx.x == 0 && b) ? b[j] : 0.f;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n_in, r0 + rows_per_block);
+  for (int j = threadIdx.x; j < n_out; j += 256) {
+    float s = 0.f;
+    for (int64_t i = r0; i < r1; ++i) s += x[i] * W[i * n_out + j];
+    acc[j] += s;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n_out; j += 256) atomicAdd(&y[j], acc[j]);
+}
+
+// backward of the dense layer: dx[i] = sum_j W[i][j] dy[j] (optional), dW[i][j] += scale_w * x[i] dy[j] (optional)
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                        const float* __restrict__ dy, float* __restrict__ dx,
+                                                        float* __restrict__ dW, int64_t n_in, int n_out) {
+  extern __shared__ float sdy[];  // [n_out]
+  for (int j = threadIdx.x; j < n_out; j += 256) sdy[j] = dy[j];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n_in; i += (int64_t)gridDim.x * 4) {  // one wave per row
+    const float xi = x ? x[i] : 0.f;
+    float s = 0.f;
+    for (int j = lane; j < n_out; j += 64) {
+      if (dx) s += W[i * n_out + j] * sdy[j];
+      if (dW) dW[i * n_out + j] += xi * sdy[j];
+    }
+    if (dx) {
+      s = syn_wave_sum(s);
+      if (lane == 0) dx[i] = s;
+    }
+  }
+}
+
+// out = a * x + b * y (elementwise; y optional)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                    float* __restrict__ out, int64_t n, float a, float b) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+// *out += sum x^2
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  float s = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  s = syn_wave_sum(s);
+  __shared__ float w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, w[0] + w[1] + w[2] + w[3]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int synthsr_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float alpha, synthsr_stream_t stream) {
+  if (!x || !out || n < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(leaky_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, out, n, alpha);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_pick_odd(const float* hi, float* lo, const int* lo_shape, int C, synthsr_stream_t stream) {
+  if (!hi || !lo || !lo_shape || C < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1) return SYNTHSR_EINVAL;
+  const int64_t n = (int64_t)lo_shape[0] * lo_shape[1] * lo_shape[2] * C;
+  hipLaunchKernelGGL(odd_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(hi), lo,
+                     lo_shape[0], lo_shape[1], lo_shape[2], C, 1);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_spread_odd(const float* lo, float* hi, const int* lo_shape, int C, synthsr_stream_t stream) {
+  if (!hi || !lo || !lo_shape || C < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1) return SYNTHSR_EINVAL;
+  const int64_t n = (int64_t)lo_shape[0] * lo_shape[1] * lo_shape[2] * 8 * C;
+  hipLaunchKernelGGL(odd_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, hi, const_cast<float*>(lo),
+                     lo_shape[0], lo_shape[1], lo_shape[2], C, 0);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_dense_fwd(const float* x, const float* W, const float* b, float* y, int64_t n_in, int n_out,
+                      synthsr_stream_t stream) {
+  if (!x || !W || !y || n_in < 1 || n_out < 1 || n_out > 1024) return SYNTHSR_EINVAL;
+  if (hipMemsetAsync(y, 0, (size_t)n_out * sizeof(float), (hipStream_t)stream) != hipSuccess) return SYNTHSR_ELAUNCH;
+  const int rows = (int)std::max<int64_t>(1, syn_cdiv(n_in, 2048));
+  hipLaunchKernelGGL(dense_fwd_kernel, dim3((unsigned)syn_cdiv(n_in, rows)), dim3(256), n_out * sizeof(float),
+                     (hipStream_t)stream, x, W, b, y, n_in, n_out, rows);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_dense_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, int64_t n_in, int n_out,
+                      synthsr_stream_t stream) {
+  if (!W || !dy || (!dx && !dW) || (dW && !x) || n_in < 1 || n_out < 1 || n_out > 1024) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(dense_bwd_kernel, dim3(syn_grid(n_in, 4, 4096)), dim3(256), n_out * sizeof(float), (hipStream_t)stream,
+                     x, W, dy, dx, dW, n_in, n_out);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, synthsr_stream_t stream) {
+  if (!x || !out || n < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(axpby_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, out, n, a, b);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_sumsq(const float* x, int64_t n, float* out, synthsr_stream_t stream) {
+  if (!x || !out || n < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(syn_grid(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+}  // extern "C"

@@ -478,3 +478,66 @@ def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0
     _lib.check(lib.synthsr_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel(), float(lr_t),
                                      float(beta1), float(beta2), float(eps), float(grad_scale), _lib.stream()),
                'adam_step')
+
+
+# ---------------------------------------------------------------------- WGAN-GP critic pieces (csrc/critic.hip)
+def leaky_relu(x, alpha=0.2, out=None):
+    """LeakyReLU (in place when out is None)"""
+    out = x if out is None else out
+    _lib.check(_L().synthsr_leaky_relu(_lib.ptr(x), None, _lib.ptr(out), x.numel(), float(alpha), _lib.stream()), 'leaky_relu')
+    return out
+
+
+def leaky_relu_bwd(dy, y, alpha=0.2, out=None):
+    """dx = dy * (y > 0 ? 1 : alpha); y = the LeakyReLU output"""
+    out = torch.empty_like(dy) if out is None else out
+    _lib.check(_L().synthsr_leaky_relu(_lib.ptr(y), _lib.ptr(dy), _lib.ptr(out), y.numel(), float(alpha), _lib.stream()),
+               'leaky_relu_bwd')
+    return out
+
+
+def pick_odd(hi, out=None):
+    """hi [2a,2b,2c,C] -> [a,b,c,C]: the odd positions (= a stride-2 'same' conv evaluated through the stride-1 kernel)"""
+    s = hi.shape
+    lo_shape = (s[0] // 2, s[1] // 2, s[2] // 2)
+    out = torch.empty(lo_shape + (s[3],), dtype=torch.float32, device=hi.device) if out is None else out
+    _lib.check(_L().synthsr_pick_odd(_lib.ptr(hi), _lib.ptr(out), _lib.i3(lo_shape), int(s[3]), _lib.stream()), 'pick_odd')
+    return out
+
+
+def spread_odd(lo, out=None):
+    """adjoint of pick_odd: zeros except at the odd positions"""
+    s = lo.shape
+    out = torch.empty((2 * s[0], 2 * s[1], 2 * s[2], s[3]), dtype=torch.float32, device=lo.device) if out is None else out
+    _lib.check(_L().synthsr_spread_odd(_lib.ptr(lo), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), _lib.stream()), 'spread_odd')
+    return out
+
+
+def dense_fwd(x, W, b, out=None):
+    """y [n_out] = b + x [n_in] . W [n_in, n_out]"""
+    n_in, n_out = int(W.shape[0]), int(W.shape[1])
+    out = torch.empty(n_out, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.check(_L().synthsr_dense_fwd(_lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(out), n_in, n_out, _lib.stream()),
+               'dense_fwd')
+    return out
+
+
+def dense_bwd(x, W, dy, dx=None, dW=None):
+    """dx [n_in] = W dy (written, if given); dW += x (x) dy (if given)"""
+    n_in, n_out = int(W.shape[0]), int(W.shape[1])
+    _lib.check(_L().synthsr_dense_bwd(_lib.ptr(x), _lib.ptr(W), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dW), n_in, n_out,
+                                      _lib.stream()), 'dense_bwd')
+    return dx
+
+
+def axpby(x, y, a, b, out=None):
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_L().synthsr_axpby(_lib.ptr(x), _lib.ptr(y), _lib.ptr(out), x.numel(), float(a), float(b), _lib.stream()),
+               'axpby')
+    return out
+
+
+def sumsq(x, out):
+    """out[0] += sum x^2"""
+    _lib.check(_L().synthsr_sumsq(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.stream()), 'sumsq')
+    return out

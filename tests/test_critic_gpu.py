@@ -1,0 +1,78 @@
+"""WGAN-GP critic (synthsr_amd/critic.py, csrc/critic.hip) against the oracle's torch restatement with autograd,
+including the double backward of the gradient penalty (oracle/unet_ref.py:critic_loss).  SURVEY §8a U4 / §8f row 2."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rel, name=''):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-30)
+    err = (a - b).abs().max().item() / scale
+    assert err < rel, '%s: max rel err %.3e (scale %.3e)' % (name, err, scale)
+
+
+def test_critic_pieces():
+    import torch
+    from synthsr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 4, 8, 5, generator=g)
+    y = ops.leaky_relu(x.cuda().clone())
+    assert torch.equal(y.cpu(), torch.where(x > 0, x, 0.2 * x))
+    dy = torch.randn(6, 4, 8, 5, generator=g)
+    assert torch.equal(ops.leaky_relu_bwd(dy.cuda(), y).cpu(), dy * torch.where(x > 0, torch.ones(()), torch.full((), 0.2)))
+    lo = ops.pick_odd(x.cuda())
+    assert torch.equal(lo.cpu(), x[1::2, 1::2, 1::2])
+    hi = ops.spread_odd(lo)
+    ref = torch.zeros_like(x)
+    ref[1::2, 1::2, 1::2] = x[1::2, 1::2, 1::2]
+    assert torch.equal(hi.cpu(), ref)
+    W, b, v = torch.randn(700, 96, generator=g), torch.randn(96, generator=g), torch.randn(700, generator=g)
+    close(ops.dense_fwd(v.cuda(), W.cuda(), b.cuda()), v @ W + b, 1e-5, 'dense_fwd')
+    dyv = torch.randn(96, generator=g)
+    dx, dW = torch.empty(700, device='cuda'), torch.ones(700, 96, device='cuda')
+    ops.dense_bwd(v.cuda(), W.cuda(), dyv.cuda(), dx=dx, dW=dW)
+    close(dx, W @ dyv, 1e-5, 'dense dx')
+    close(dW, 1 + v[:, None] * dyv[None, :], 1e-6, 'dense dW')
+    s = torch.zeros(1, device='cuda')
+    ops.sumsq(v.cuda(), s)
+    assert abs(s.item() - float((v.double() ** 2).sum())) < 1e-3
+    close(ops.axpby(v.cuda(), (2 * v).cuda(), 0.25, 0.5), 1.25 * v, 1e-6, 'axpby')
+
+
+@pytest.mark.parametrize('shape,n_filters,n_levels', [((16, 16, 16), 8, 2), ((8, 16, 24), 32, 3)])
+def test_critic_loss_and_gradients_vs_autograd(shape, n_filters, n_levels):
+    """-D(real) + D(fake) + 10 (1 - ||grad D(x_hat)||)^2 and its gradient w.r.t. every critic parameter (the penalty term
+    through the masked forward pass) against autograd with create_graph; the input gradient used by the generator step"""
+    import torch
+    from synthsr_amd.critic import Critic3D
+    from oracle import unet_ref as U
+    net = Critic3D(list(shape) + [1], n_filters=n_filters, n_levels=n_levels, seed=1)
+    g = torch.Generator().manual_seed(7)
+    for nm, _ in net.specs:                      # non-zero biases, larger weights (so that the penalty is active)
+        v = net.view(nm)
+        v.copy_((torch.randn(v.shape, generator=g) * (0.1 if nm.endswith('bias') else 1.0)).to(v.device) *
+                (1.0 if nm.endswith('bias') else 3.0 * v.abs().max().item()))
+    net.repack()
+    real, fake = torch.rand(*shape, 1, generator=g), torch.rand(*shape, 1, generator=g)
+    u = 0.3
+    loss, d_real, d_fake, norm = net.critic_loss_and_grads(real.cuda(), fake.cuda(), u, gp_weight=10.0)
+    P = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    ref, nref = U.critic_loss(real, fake, u, P, net.name, n_levels, 10.0)
+    ref.backward()
+    assert abs(norm - float(nref)) < 2e-4 * float(nref), (norm, float(nref))
+    assert abs(loss - float(ref)) < 2e-4 * max(1.0, abs(float(ref))), (loss, float(ref))
+    assert abs(float(nref) - 1.0) > 0.05            # the penalty contributes
+    for nm, _ in net.specs:
+        close(net.view(nm, net.grads), P[nm].grad, 2e-3, 'grad ' + nm)
+    # generator side: -w * grad_x D(x)
+    x = fake.clone().requires_grad_(True)
+    d = U.critic_forward(x, {k: v.detach() for k, v in P.items()}, net.name, n_levels)
+    gx, = torch.autograd.grad(d, x)
+    close(net.input_gradient(fake.cuda(), dout=-0.01), -0.01 * gx, 2e-3, 'input gradient')
+    # one Adam step moves the parameters and re-packs the conv weights (D changes)
+    before = net.forward(real.cuda()).item()
+    net.adam_step(lr=1e-3)
+    assert net.forward(real.cuda()).item() != before
