@@ -23,6 +23,13 @@ from .training import load_checkpoint, save_checkpoint
 from .unet import unet as build_unet
 
 
+def make_discriminator(input_shape, n_filters=32, n_levels=4, mask_input=False, device=None, seed=0):
+    """the critic network of fine_tuning_with_adversary.py:482-502 as a `Critic3D`"""
+    if mask_input:
+        raise NotImplementedError('mask_input (critic on label-masked volumes) is not built')
+    return Critic3D(input_shape, n_filters=n_filters, n_levels=n_levels, device=device, seed=seed)
+
+
 class AdversarialTrainer:
     """generator (U-Net) + critic for one GPU: `critic_step()` / `generator_step()` each draw a new training sample"""
 
@@ -156,7 +163,7 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
         if verbose:
             print('loading', checkpoint_generator)
         load_checkpoint(checkpoint_generator, generator)
-    critic = Critic3D(list(unet_input_shape[:-1]) + [n_output_channels], seed=seed + 2)   # make_discriminator defaults
+    critic = make_discriminator(list(unet_input_shape[:-1]) + [n_output_channels], seed=seed + 2)
     seg_reg = None
     if segmentation_model_file is not None:
         from .seg_loss import SegmentationRegulariser

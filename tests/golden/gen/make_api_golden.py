@@ -8,7 +8,8 @@ import os
 
 REF = '/root/reference'
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'api.json')
-TARGETS = [('SynthSR/training.py', 'training'), ('SynthSR/brain_generator.py', 'BrainGenerator.__init__'),
+TARGETS = [('SynthSR/training.py', 'training'), ('SynthSR/fine_tuning_with_adversary.py', 'training'),
+           ('SynthSR/fine_tuning_with_adversary.py', 'make_discriminator'), ('SynthSR/brain_generator.py', 'BrainGenerator.__init__'),
            ('SynthSR/labels_to_image_model.py', 'labels_to_image_model'), ('SynthSR/model_inputs.py', 'build_model_inputs'),
            ('ext/neuron/models.py', 'unet'), ('SynthSR/estimate_priors.py', 'build_intensity_stats'),
            ('SynthSR/estimate_priors.py', 'sample_intensity_stats_from_image'),

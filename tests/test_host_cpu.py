@@ -224,7 +224,9 @@ def test_public_signatures_match_reference():
     import json
     from synthsr_amd import training as T, brain_generator as B, labels_to_image_model as L, model_inputs as M
     from synthsr_amd import unet as U, estimate_priors as E, volumes as V
-    here = {'SynthSR/training.py:training': T.training, 'SynthSR/brain_generator.py:BrainGenerator.__init__': B.BrainGenerator.__init__,
+    from synthsr_amd import fine_tuning_with_adversary as A
+    here = {'SynthSR/training.py:training': T.training, 'SynthSR/fine_tuning_with_adversary.py:training': A.training,
+            'SynthSR/fine_tuning_with_adversary.py:make_discriminator': A.make_discriminator, 'SynthSR/brain_generator.py:BrainGenerator.__init__': B.BrainGenerator.__init__,
             'SynthSR/labels_to_image_model.py:labels_to_image_model': L.labels_to_image_model,
             'SynthSR/model_inputs.py:build_model_inputs': M.build_model_inputs, 'ext/neuron/models.py:unet': U.unet,
             'SynthSR/estimate_priors.py:build_intensity_stats': E.build_intensity_stats,
