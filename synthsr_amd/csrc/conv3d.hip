@@ -2702,13 +2702,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
 }
 
 // dbias fallback for the generic weight-gradient kernel: per-channel sum of dout [n][C]
-__global__ void colsum_kernel(const float* __restrict__ x, int64_t n, int C, float* __restrict__ out) {
-  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-  const int64_t v0 = blockIdx.x * per, v1 = v0 + per < n ? v0 + per : n;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t n, int C,
+                                                     float* __restrict__ out) {
+  // threads run along the channels (coalesced rows of C floats), 256 / C voxel rows in flight per workgroup
+  __shared__ float part[256];
+  const int rows = C <= 256 ? 256 / C : 1;
+  for (int c0 = 0; c0 < C; c0 += 256) {  // one pass unless C > 256
+    const int width = min(256, C - c0);
+    const int r = threadIdx.x / width, c = threadIdx.x - r * width;
     float acc = 0.f;
-    for (int64_t v = v0; v < v1; ++v) acc += x[v * C + c];
-    atomicAdd(out + c, acc);
+    if (r < rows)
+      for (int64_t v = (int64_t)blockIdx.x * rows + r; v < n; v += (int64_t)gridDim.x * rows) acc += x[v * C + c0 + c];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < width) {
+      float t = 0.f;
+      for (int k = 0; k < rows; ++k) t += part[k * width + threadIdx.x];
+      atomicAdd(out + c0 + threadIdx.x, t);
+    }
+    __syncthreads();
   }
 }
 
@@ -3149,7 +3161,7 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
     attr_done = true;
   }
   if (ext.dbias) {  // the generic kernel has no dbias row
-    hipLaunchKernelGGL(colsum_kernel, dim3(1024), dim3(64), 0, st, dout, (int64_t)s[0] * s[1] * s[2], Cout, ext.dbias);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1024), dim3(256), 0, st, dout, (int64_t)s[0] * s[1] * s[2], Cout, ext.dbias);
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(gx, ncc * ymul, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout,
