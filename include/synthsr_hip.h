@@ -336,10 +336,22 @@ int synthsr_seg_dice_bwd(const float* probs, const int32_t* seg, int64_t nvox, i
 int synthsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
                       float beta2, float eps, float grad_scale, synthsr_stream_t stream);
 
+/* Stride-2 'same' Conv3D of an even-sized volume through the parity kernels of the folded decoder conv: pack the weights with
+ * synthsr_conv3d_pack_ex(..., up = 2) on the LOW-RES (output) shape - mode 0 for the forward pass, evaluated by
+ * synthsr_conv3d_up_dgrad(x_hi, packed, y_lo, lo_shape, Cl = Cout, Cout = Cin), mode 1 for the data gradient, evaluated by
+ * synthsr_conv3d_up_fwd(dy_lo, packed, NULL, NULL, dx_hi, lo_shape, Cl = Cout, Cout = Cin, 0); weight gradient:
+ * synthsr_conv3d_up_wgrad(dy_lo, x_hi, dwc, lo_shape, Cl = Cout, Cout = Cin) followed by this unpack
+ * (dwc [8][27][Cout][Cin] zeroed by the caller, dw [27][Cin][Cout] +=). */
+int synthsr_conv3d_stride_unpack(const float* dwc, float* dw, int Cin, int Cout, synthsr_stream_t stream);
+
 /* ------------------------------------------------------------------ WGAN-GP critic pieces
  * (SynthSR/fine_tuning_with_adversary.py:482-508 `make_discriminator`, :579-595 `build_discriminator_loss`) */
 /* LeakyReLU: dy == NULL: out = x > 0 ? x : alpha x (in place allowed); else out = dy * (x > 0 ? 1 : alpha), x = layer output */
 int synthsr_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float alpha, synthsr_stream_t stream);
+/* out = LeakyReLU(x + bias[c]) for channels-last x (n values, C channels); out [C] += column sums of x [n][C] */
+int synthsr_bias_leaky_relu(const float* x, const float* bias, float* out, int64_t n, int C, float alpha,
+                            synthsr_stream_t stream);
+int synthsr_colsum(const float* x, int64_t n, int C, float* out, synthsr_stream_t stream);
 /* stride-2 'same' Conv3D of an even-sized volume = its stride-1 result at the odd positions: lo[o] = hi[2 o + 1]
  * (hi [2 lo_shape, C]), and the adjoint hi = 0 except hi[2 o + 1] = lo[o] */
 int synthsr_pick_odd(const float* hi, float* lo, const int lo_shape[3], int C, synthsr_stream_t stream);

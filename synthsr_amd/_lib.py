@@ -81,6 +81,9 @@ SIGNATURES = {
     'synthsr_ssim_filter': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _S]),
     'synthsr_ssim_point': (c_int, [_P, c_int64, c_float, c_float, _P, _P, _S]),
     'synthsr_ssim_combine': (c_int, [_P, _P, _P, _P, _P, _P, _S]),
+    'synthsr_conv3d_stride_unpack': (c_int, [_P, _P, c_int, c_int, _S]),
+    'synthsr_bias_leaky_relu': (c_int, [_P, _P, _P, c_int64, c_int, c_float, _S]),
+    'synthsr_colsum': (c_int, [_P, c_int64, c_int, _P, _S]),
     'synthsr_leaky_relu': (c_int, [_P, _P, _P, c_int64, c_float, _S]),
     'synthsr_pick_odd': (c_int, [_P, _P, _P, c_int, _S]),
     'synthsr_spread_odd': (c_int, [_P, _P, _P, c_int, _S]),

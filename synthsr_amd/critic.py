@@ -2,8 +2,9 @@
 :579-595 `build_discriminator_loss`, :604-642 `RandomWeightedAverage` / `Gradients`) on the HIP kernels.
 
 Network: n_levels x [Conv3D(f, 3, stride 1) + LeakyReLU(.2), Conv3D(f, 3, stride 2) + LeakyReLU(.2)], f = n_filters 2^level,
-Flatten (channels last), Dense(n_filters 2^n_levels) + LeakyReLU(.2), Dense(1).  Strided layers = stride-1 kernel + odd
-positions (csrc/critic.hip).
+Flatten (channels last), Dense(n_filters 2^n_levels) + LeakyReLU(.2), Dense(1).  Strided layers run on the parity kernels of
+the folded decoder conv (ops.conv3d_stride2*: a stride-2 conv is a sum of eight 2x2x2-window convs on the parity
+sub-lattices of its input).
 
 Critic loss on (real, fake):  -D(real) + D(fake) + lambda (1 - ||grad_x D(x_hat)||_2)^2,  x_hat = w real + (1 - w) fake.
 The network is piecewise linear, so the gradient of the penalty w.r.t. the weights needs no second derivatives of the
@@ -11,8 +12,8 @@ activations: with delta_l the back-propagated signals of grad_x D and u_0 = d pe
 u_l = mask_l * conv_l(u_{l-1}) gives  d penalty / d W_l = weight-gradient(u_{l-1}, delta_l)  (the backward pass is linear in
 every W_l); biases get no penalty gradient.
 
-First functional version: every convolution goes through the generic (CK = 8) kernels because the critic's channel
-counts (32 ... 256) are not multiples of 24, and the strided layers compute 8x the needed outputs - correct, not fast."""
+Not optimised yet: the critic's channel counts (32 ... 256) are not multiples of 24, so every convolution takes the generic
+(CK = 8) kernels."""
 import numpy as np
 import torch
 
@@ -85,8 +86,32 @@ class Critic3D:
 
     def repack(self):
         for c in self.convs:
-            c['wp'] = ops.pack_conv_weights(self.view(c['w']), c['shape'], 0, out=c.get('wp'))
-            c['wpd'] = ops.pack_conv_weights(self.view(c['w']), c['shape'], 1, out=c.get('wpd'))
+            if c['stride'] == 2:   # parity weight sets on the OUTPUT grid (ops.conv3d_stride2*)
+                lo = [v // 2 for v in c['shape']]
+                c['wp'] = ops.pack_stride2_weights(self.view(c['w']), lo, 0, out=c.get('wp'))
+                c['wpd'] = ops.pack_stride2_weights(self.view(c['w']), lo, 1, out=c.get('wpd'))
+            else:
+                c['wp'] = ops.pack_conv_weights(self.view(c['w']), c['shape'], 0, out=c.get('wp'))
+                c['wpd'] = ops.pack_conv_weights(self.view(c['w']), c['shape'], 1, out=c.get('wpd'))
+
+    def _conv(self, c, x, out, bias=True):
+        """conv layer c on x; the stride-1 kernel adds the bias itself, the parity kernels of a stride-2 layer do not"""
+        if c['stride'] == 2:
+            return ops.conv3d_stride2(x, c['wp'], c['cout'], out=out)
+        return ops.conv3d(x, c['wp'], self.view(c['b']) if bias else None, c['cout'], 0, out=out)
+
+    def _out_shape(self, c):
+        return [v // c['stride'] for v in c['shape']] + [c['cout']]
+
+    def _wgrad(self, c, x, delta, bias):
+        """self.grads += weight (and bias) gradient of conv layer c for input x and output gradient delta"""
+        G = self.grads
+        dbias = self.view(c['b'], G) if bias else None
+        if c['stride'] == 2:
+            ops.conv3d_stride2_wgrad(x, delta, self.view(c['w'], G), self.buf('dwc', [8, 27, c['cout'], c['cin']]),
+                                     dbias=dbias)
+        else:
+            ops.conv3d_wgrad(x, delta, self.view(c['w'], G), dbias=dbias)
 
     def state_dict(self):
         return {nm: self.view(nm).detach().cpu().clone() for nm, _ in self.specs}
@@ -102,12 +127,11 @@ class Critic3D:
         hs = [x]
         cur = x
         for i, c in enumerate(self.convs):
-            full = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 0,
-                              out=self.buf('full', c['shape'] + [c['cout']]) if c['stride'] == 2 else
-                              self.buf('h%s%d' % (tag, i), c['shape'] + [c['cout']]))
-            cur = ops.pick_odd(full, out=self.buf('h%s%d' % (tag, i), [s // 2 for s in c['shape']] + [c['cout']])) \
-                if c['stride'] == 2 else full
-            ops.leaky_relu(cur, ALPHA)
+            cur = self._conv(c, cur, self.buf('h%s%d' % (tag, i), self._out_shape(c)))
+            if c['stride'] == 2:
+                ops.bias_leaky_relu(cur, self.view(c['b']), ALPHA)
+            else:
+                ops.leaky_relu(cur, ALPHA)
             hs.append(cur)
         d0, d1 = self.dense
         h9 = ops.dense_fwd(cur.reshape(-1), self.view(d0['w']), self.view(d0['b']), out=self.buf('h%s_d' % tag, [d0['n_out']]))
@@ -140,11 +164,12 @@ class Critic3D:
         for i in range(len(self.convs) - 1, -1, -1):
             c = self.convs[i]
             deltas[i] = delta
-            dz = ops.spread_odd(delta, out=self.buf('dzfull', c['shape'] + [c['cout']])) if c['stride'] == 2 else delta
             if weight_grads:
-                ops.conv3d_wgrad(hs[i], dz, self.view(c['w'], G), dbias=self.view(c['b'], G))
+                self._wgrad(c, hs[i], delta, bias=True)
             if i > 0 or input_grad:
-                g = ops.conv3d(dz, c['wpd'], None, c['cin'], 0, out=self.buf('g%d' % (i & 1), c['shape'] + [c['cin']]))
+                gbuf = self.buf('g%d' % (i & 1), c['shape'] + [c['cin']])
+                g = ops.conv3d_stride2_dgrad(delta, c['wpd'], c['cin'], out=gbuf) if c['stride'] == 2 else \
+                    ops.conv3d(delta, c['wpd'], None, c['cin'], 0, out=gbuf)
                 if i > 0:
                     delta = ops.leaky_relu_bwd(g, hs[i], ALPHA, out=self.buf('delta%d' % (i - 1), list(hs[i].shape)))
         if keep_deltas:
@@ -184,12 +209,8 @@ class Critic3D:
         G = self.grads
         u = ops.axpby(g0, None, scale, 0.0, out=self.buf('u0', list(g0.shape)))
         for i, c in enumerate(self.convs):
-            delta = self._deltas[i]
-            dz = ops.spread_odd(delta, out=self.buf('dzfull', c['shape'] + [c['cout']])) if c['stride'] == 2 else delta
-            ops.conv3d_wgrad(u, dz, self.view(c['w'], G))
-            full = ops.conv3d(u, c['wp'], None, c['cout'], 0, out=self.buf('full', c['shape'] + [c['cout']]))
-            v = ops.pick_odd(full, out=self.buf('v%d' % (i & 1), [s // 2 for s in c['shape']] + [c['cout']])) \
-                if c['stride'] == 2 else full
+            self._wgrad(c, u, self._deltas[i], bias=False)
+            v = self._conv(c, u, self.buf('v%d' % (i & 1), self._out_shape(c)), bias=False)
             u = ops.leaky_relu_bwd(v, hs[i + 1], ALPHA, out=self.buf('u%d' % ((i + 1) & 1), list(hs[i + 1].shape)))
         d0, d1 = self.dense
         uflat = u.reshape(-1)

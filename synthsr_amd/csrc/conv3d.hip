@@ -63,6 +63,19 @@ __device__ __forceinline__ int up_axis_taps(int p, int s, int t[2]) {
   return 0;
 }
 
+// A stride-2 'same' conv of an even-sized volume (TensorFlow pads (0, 1): output o reads inputs 2o, 2o+1, 2o+2) is also a
+// sum of 8 parity convs on the low-res grid: with x_p[i] = x[2 i + p], tap 0 -> (p 0, offset 0), tap 1 -> (p 1, offset 0),
+// tap 2 -> (p 0, offset +1).  In 27-slot form (slot s <-> offset s - 1) the original tap behind slot s of parity p:
+__device__ __forceinline__ int stride_axis_taps(int p, int s, int t[2]) {
+  if (p == 0 && s == 1) { t[0] = 0; return 1; }
+  if (p == 0 && s == 2) { t[0] = 2; return 1; }
+  if (p == 1 && s == 1) { t[0] = 1; return 1; }
+  return 0;
+}
+// These slots lie inside the 2x2x2 windows of the folded decoder conv's data gradient (mode 2: slots {1-p, 2-p}) and, after
+// the mode-1 flip, of its forward pass ({p, p+1}), so the strided layer runs on those kernels unchanged: forward through
+// synthsr_conv3d_up_dgrad, data gradient through synthsr_conv3d_up_fwd, with weight sets packed under parity codes 8..15.
+
 // w: Keras kernel [27][Cin_total][Cout]; the layer (or layer part) uses input channels [ci_off, ci_off+Cin).
 // parity < 0: plain weights.  parity 0..7: combined weights of the nearest-upsample folding in 27-slot form.
 // value of the effective weight W_eff[tap][cie][coe] of a (possibly transposed / parity-folded) layer part
@@ -74,9 +87,11 @@ __device__ __forceinline__ float weight_value(const float* __restrict__ w, int t
   const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;  // layer channel indices
   if (parity < 0) return w[((int64_t)slot * Cin_total + ci) * Cout + co];
   int tz[2], ty[2], tx[2];
-  const int nz = up_axis_taps((parity >> 2) & 1, slot / 9, tz);
-  const int ny = up_axis_taps((parity >> 1) & 1, (slot / 3) % 3, ty);
-  const int nx = up_axis_taps(parity & 1, slot % 3, tx);
+  const bool strided = parity >= 8;  // 8 + p: the parity sets of a stride-2 conv
+  const int nz = strided ? stride_axis_taps((parity >> 2) & 1, slot / 9, tz) : up_axis_taps((parity >> 2) & 1, slot / 9, tz);
+  const int ny = strided ? stride_axis_taps((parity >> 1) & 1, (slot / 3) % 3, ty)
+                         : up_axis_taps((parity >> 1) & 1, (slot / 3) % 3, ty);
+  const int nx = strided ? stride_axis_taps(parity & 1, slot % 3, tx) : up_axis_taps(parity & 1, slot % 3, tx);
   float v = 0.f;
   for (int a = 0; a < nz; ++a)
     for (int b = 0; b < ny; ++b)
@@ -3455,10 +3470,13 @@ extern "C" {
 int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3], int Cin_total, int ci_off, int Cin,
                                int Cout, int mode, int up, synthsr_stream_t stream) {
   if (!shape || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1) ||
-      shape[0] < 1 || shape[1] < 1 || shape[2] < 1)
+      shape[0] < 1 || shape[1] < 1 || shape[2] < 1 || up < 0 || up > 2)
     return SYNTHSR_EINVAL;
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
-  const FwdPlan pl = plan_fwd(shape, CinE, CoutE, up ? (mode == 0 ? 2 : 0) : 1);
+  // up = 1: parity sets of the folded decoder conv (forward -> up_fwd plan, data gradient -> up_dgrad plan);
+  // up = 2: parity sets of a stride-2 conv, whose FORWARD runs through up_dgrad and whose data gradient through up_fwd
+  const int kind = !up ? 1 : ((up == 1) == (mode == 0) ? 2 : 0);
+  const FwdPlan pl = plan_fwd(shape, CinE, CoutE, kind);
   const int64_t per = pl.count();
   if (per >= (1ll << 31)) return SYNTHSR_EINVAL;  // pack_value indexes one weight set with 32-bit arithmetic
   const int64_t total = per * (up ? 8 : 1);
@@ -3466,8 +3484,8 @@ int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3]
   if (!w) return SYNTHSR_EINVAL;
   for (int p = 0; p < (up ? 8 : 1); ++p) {
     hipLaunchKernelGGL(pack_kernel, dim3(syn_grid(per, 256)), dim3(256), 0, (hipStream_t)stream, w, packed + p * per,
-                       Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.pack_nt(), pl.nchunks, up ? p : -1, pl.nv,
-                       pl.mfma_count(), per);
+                       Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.pack_nt(), pl.nchunks,
+                       up ? p + (up == 2 ? 8 : 0) : -1, pl.nv, pl.mfma_count(), per);
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   }
   return total;
@@ -3496,6 +3514,29 @@ int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* j
                             synthsr_stream_t stream) {
   if (!params || !packed || !jobs_dev || njobs < 1) return SYNTHSR_EINVAL;
   hipLaunchKernelGGL(pack_all_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, params, packed, jobs_dev);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+// weight gradient of a stride-2 conv from the per-parity partials of synthsr_conv3d_up_wgrad called with lo := dy (Co
+// channels) and dout := x (the 2x tensor, Ci channels): dwc [8][27][Co][Ci], dw [27][Ci][Co] += .  Tap t of an axis sits at
+// parity p = t & 1, slot 1 - (t >> 1)  (t 0 -> (0, 1), t 1 -> (1, 1), t 2 -> (0, 0)).
+__global__ void stride_unpack_kernel(const float* __restrict__ dwc, float* __restrict__ dw, int Ci, int Co, int64_t total) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % Co);
+    const int ci = (int)((idx / Co) % Ci);
+    const int t = (int)(idx / ((int64_t)Co * Ci));
+    const int tz = t / 9, ty = (t / 3) % 3, tx = t % 3;
+    const int p = ((tz & 1) << 2) | ((ty & 1) << 1) | (tx & 1);
+    const int slot = ((1 - (tz >> 1)) * 3 + (1 - (ty >> 1))) * 3 + (1 - (tx >> 1));
+    dw[idx] += dwc[(((int64_t)p * 27 + slot) * Co + co) * Ci + ci];
+  }
+}
+
+int synthsr_conv3d_stride_unpack(const float* dwc, float* dw, int Ci, int Co, synthsr_stream_t stream) {
+  if (!dwc || !dw || Ci < 1 || Co < 1) return SYNTHSR_EINVAL;
+  const int64_t total = (int64_t)27 * Ci * Co;
+  hipLaunchKernelGGL(stride_unpack_kernel, dim3(syn_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dwc, dw, Ci, Co,
+                     total);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 

@@ -17,6 +17,37 @@ __global__ __launch_bounds__(256) void leaky_kernel(const float* __restrict__ x,
   }
 }
 
+// out = leaky(x + bias[c]) for channels-last x [n / C][C] (in place allowed)
+__global__ __launch_bounds__(256) void bias_leaky_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int64_t n, int C, float alpha) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i] + bias[(int)(i % C)];
+    out[i] = v > 0.f ? v : alpha * v;
+  }
+}
+
+// out[c] += sum over rows of x [n][C]: threads run along the channels, 256 / C rows in flight per workgroup
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ x, int64_t n, int C,
+                                                          float* __restrict__ out) {
+  __shared__ float part[256];
+  const int rows = C <= 256 ? 256 / C : 1;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int width = min(256, C - c0);
+    const int r = threadIdx.x / width, c = threadIdx.x - r * width;
+    float acc = 0.f;
+    if (r < rows)
+      for (int64_t v = (int64_t)blockIdx.x * rows + r; v < n; v += (int64_t)gridDim.x * rows) acc += x[v * C + c0 + c];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < width) {
+      float t = 0.f;
+      for (int k = 0; k < rows; ++k) t += part[k * width + threadIdx.x];
+      atomicAdd(out + c0 + threadIdx.x, t);
+    }
+    __syncthreads();
+  }
+}
+
 // forward = 1: lo[o] = hi[2 o + 1] (channels-last, hi [2d0,2d1,2d2,C], lo [d0,d1,d2,C]);
 // forward = 0: hi = 0 except hi[2 o + 1] = lo[o] (the adjoint)
 __global__ __launch_bounds__(256) void odd_kernel(float* __restrict__ hi, float* __restrict__ lo, int d0, int d1, int d2,
@@ -110,6 +141,22 @@ extern "C" {
 int synthsr_leaky_relu(const float* x, const float* dy, float* out, int64_t n, float alpha, synthsr_stream_t stream) {
   if (!x || !out || n < 1) return SYNTHSR_EINVAL;
   hipLaunchKernelGGL(leaky_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, out, n, alpha);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_bias_leaky_relu(const float* x, const float* bias, float* out, int64_t n, int C, float alpha,
+                            synthsr_stream_t stream) {
+  if (!x || !bias || !out || n < 1 || C < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(bias_leaky_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, bias, out, n, C,
+                     alpha);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_colsum(const float* x, int64_t n, int C, float* out, synthsr_stream_t stream) {
+  if (!x || !out || n < 1 || C < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3(syn_grid(n, 4, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, C, out);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

@@ -79,18 +79,18 @@ def pack_conv_weights(w, shape, mode=0, out=None):
 
 def pack_conv_weights_ex(w, shape, ci_off, cin, mode=0, up=False, out=None):
     """pack the input-channel range [ci_off, ci_off+cin) of a Keras kernel w [3,3,3,Cin_total,Cout]; `up`: the 8 parity
-    weight sets of the nearest-upsample folding (shape = LOW-RES spatial shape)"""
+    weight sets of the nearest-upsample folding (shape = LOW-RES spatial shape); up = 2: those of a stride-2 conv"""
     lib = _L()
     cin_total, cout = int(w.shape[3]), int(w.shape[4])
     s3 = _lib.i3(shape[:3])
-    n = lib.synthsr_conv3d_pack_ex(None, None, s3, cin_total, int(ci_off), int(cin), cout, mode, int(bool(up)), None)
+    n = lib.synthsr_conv3d_pack_ex(None, None, s3, cin_total, int(ci_off), int(cin), cout, mode, int(up), None)
     if n < 0:
         _lib.check(int(n), 'conv3d_pack_ex(size)')
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=w.device)
     assert out.numel() == n
     r = lib.synthsr_conv3d_pack_ex(_lib.ptr(w), _lib.ptr(out), s3, cin_total, int(ci_off), int(cin), cout, mode,
-                                   int(bool(up)), _lib.stream())
+                                   int(up), _lib.stream())
     if r < 0:
         _lib.check(int(r), 'conv3d_pack_ex')
     return out
@@ -541,3 +541,60 @@ def sumsq(x, out):
     """out[0] += sum x^2"""
     _lib.check(_L().synthsr_sumsq(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.stream()), 'sumsq')
     return out
+
+
+def bias_leaky_relu(x, bias, alpha=0.2, out=None):
+    out = x if out is None else out
+    C = int(x.shape[-1])
+    _lib.check(_L().synthsr_bias_leaky_relu(_lib.ptr(x), _lib.ptr(bias), _lib.ptr(out), x.numel(), C, float(alpha),
+                                            _lib.stream()), 'bias_leaky_relu')
+    return out
+
+
+def colsum(x, out):
+    """out [C] += column sums of x [..., C]"""
+    C = int(x.shape[-1])
+    _lib.check(_L().synthsr_colsum(_lib.ptr(x), x.numel() // C, C, _lib.ptr(out), _lib.stream()), 'colsum')
+    return out
+
+
+# stride-2 'same' Conv3D (even sizes) on the parity kernels of the folded decoder conv; weights [3,3,3,Cin,Cout]
+def pack_stride2_weights(w, lo_shape, mode=0, out=None):
+    """mode 0: forward weights, mode 1: data-gradient weights (lo_shape = OUTPUT spatial shape)"""
+    return pack_conv_weights_ex(w, lo_shape, 0, int(w.shape[3]), mode, up=2, out=out)
+
+
+def conv3d_stride2(x, wpacked8, Cout, out=None):
+    """x [2a,2b,2c,Cin] -> [a,b,c,Cout] (no bias / activation): y[o] = sum_t w[t] x[2o + t]"""
+    lib = _L()
+    s = x.shape
+    lo_shape = (s[0] // 2, s[1] // 2, s[2] // 2)
+    if out is None:
+        out = torch.empty(lo_shape + (Cout,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.synthsr_conv3d_up_dgrad(_lib.ptr(x), _lib.ptr(wpacked8), _lib.ptr(out), _lib.i3(lo_shape), int(Cout),
+                                           int(s[3]), _lib.stream()), 'conv3d_stride2')
+    return out
+
+
+def conv3d_stride2_dgrad(dy, wpacked8d, Cin, out=None):
+    """dy [a,b,c,Cout] -> gradient w.r.t. the stride-2 conv's input [2a,2b,2c,Cin]"""
+    lib = _L()
+    s = dy.shape
+    if out is None:
+        out = torch.empty((2 * s[0], 2 * s[1], 2 * s[2], Cin), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.synthsr_conv3d_up_fwd(_lib.ptr(dy), _lib.ptr(wpacked8d), None, None, _lib.ptr(out), _lib.i3(s[:3]),
+                                         int(s[3]), int(Cin), 0, _lib.stream()), 'conv3d_stride2_dgrad')
+    return out
+
+
+def conv3d_stride2_wgrad(x, dy, dw, dwc, dbias=None):
+    """dw [3,3,3,Cin,Cout] += sum_o x[2o + t] (x) dy[o]; dwc: scratch [8,27,Cout,Cin] (zeroed here); dbias += sum dy"""
+    lib = _L()
+    Ci, Co = int(x.shape[3]), int(dy.shape[3])
+    dwc.zero_()
+    _lib.check(lib.synthsr_conv3d_up_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dwc), _lib.i3(dy.shape[:3]), Co, Ci,
+                                           _lib.stream()), 'conv3d_stride2_wgrad')
+    _lib.check(lib.synthsr_conv3d_stride_unpack(_lib.ptr(dwc), _lib.ptr(dw), Ci, Co, _lib.stream()), 'stride_unpack')
+    if dbias is not None:
+        colsum(dy, dbias)
+    return dw

@@ -130,3 +130,33 @@ def test_adversarial_fine_tuning_end_to_end(tmp_path):
         training(str(ldir), str(idir), mdir, None, None, str(tmp_path / 'gl.npy'), output_channel=0)
     with pytest.raises(Exception, match='output_channel or image_dir'):
         training(str(ldir), None, mdir, None, None, str(tmp_path / 'gl.npy'))
+
+
+@pytest.mark.parametrize('lo_shape,cin,cout', [((4, 6, 8), 8, 16), ((8, 8, 8), 1, 32), ((6, 4, 10), 32, 32),
+                                               ((4, 4, 8), 48, 24), ((8, 8, 16), 24, 48)])
+def test_stride2_conv_on_the_parity_kernels(lo_shape, cin, cout):
+    """stride-2 'same' Conv3D (TensorFlow padding (0, 1)) forward / data gradient / weight gradient / dbias through the
+    parity kernels of the folded decoder conv (a second tap-to-slot table) against torch conv3d(stride=2) + autograd"""
+    import torch
+    import torch.nn.functional as F
+    from synthsr_amd import ops
+    g = torch.Generator().manual_seed(2)
+    hi = tuple(2 * s for s in lo_shape)
+    x = torch.randn(*hi, cin, generator=g, requires_grad=True)
+    w = (torch.randn(3, 3, 3, cin, cout, generator=g) * 0.2).requires_grad_(True)
+    xr = F.pad(x.permute(3, 0, 1, 2)[None], (0, 1, 0, 1, 0, 1))
+    y_ref = F.conv3d(xr, w.permute(4, 3, 0, 1, 2), stride=2)[0].permute(1, 2, 3, 0)
+    dy = torch.randn(*lo_shape, cout, generator=g)
+    (y_ref * dy).sum().backward()
+    wp = ops.pack_stride2_weights(w.detach().cuda(), lo_shape, 0)
+    wpd = ops.pack_stride2_weights(w.detach().cuda(), lo_shape, 1)
+    y = ops.conv3d_stride2(x.detach().cuda(), wp, cout)
+    close(y, y_ref, 2e-5, 'forward')
+    dx = ops.conv3d_stride2_dgrad(dy.cuda(), wpd, cin)
+    close(dx, x.grad, 2e-5, 'data gradient')
+    dw = torch.ones(3, 3, 3, cin, cout, device='cuda')
+    db = torch.zeros(cout, device='cuda')
+    dwc = torch.empty(8, 27, cout, cin, device='cuda')
+    ops.conv3d_stride2_wgrad(x.detach().cuda(), dy.cuda(), dw, dwc, dbias=db)
+    close(dw - 1, w.grad, 2e-5, 'weight gradient')
+    close(db, dy.reshape(-1, cout).sum(0), 2e-5, 'dbias')
