@@ -352,10 +352,6 @@ int synthsr_leaky_relu(const float* x, const float* dy, float* out, int64_t n, f
 int synthsr_bias_leaky_relu(const float* x, const float* bias, float* out, int64_t n, int C, float alpha,
                             synthsr_stream_t stream);
 int synthsr_colsum(const float* x, int64_t n, int C, float* out, synthsr_stream_t stream);
-/* stride-2 'same' Conv3D of an even-sized volume = its stride-1 result at the odd positions: lo[o] = hi[2 o + 1]
- * (hi [2 lo_shape, C]), and the adjoint hi = 0 except hi[2 o + 1] = lo[o] */
-int synthsr_pick_odd(const float* hi, float* lo, const int lo_shape[3], int C, synthsr_stream_t stream);
-int synthsr_spread_odd(const float* lo, float* hi, const int lo_shape[3], int C, synthsr_stream_t stream);
 /* Dense: y [n_out] = b + x [n_in] . W [n_in][n_out] (Keras layout; n_out <= 1024; b optional) */
 int synthsr_dense_fwd(const float* x, const float* W, const float* b, float* y, int64_t n_in, int n_out,
                       synthsr_stream_t stream);

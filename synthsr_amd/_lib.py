@@ -85,8 +85,6 @@ SIGNATURES = {
     'synthsr_bias_leaky_relu': (c_int, [_P, _P, _P, c_int64, c_int, c_float, _S]),
     'synthsr_colsum': (c_int, [_P, c_int64, c_int, _P, _S]),
     'synthsr_leaky_relu': (c_int, [_P, _P, _P, c_int64, c_float, _S]),
-    'synthsr_pick_odd': (c_int, [_P, _P, _P, c_int, _S]),
-    'synthsr_spread_odd': (c_int, [_P, _P, _P, c_int, _S]),
     'synthsr_dense_fwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, _S]),
     'synthsr_dense_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),
     'synthsr_axpby': (c_int, [_P, _P, _P, c_int64, c_float, c_float, _S]),

@@ -1,8 +1,7 @@
 // Pointwise / dense pieces of the WGAN-GP critic of SynthSR/fine_tuning_with_adversary.py:482-508 (`make_discriminator`:
 // [Conv3D(3, stride 1) + LeakyReLU(.2), Conv3D(3, stride 2) + LeakyReLU(.2)] x n_levels -> Flatten -> Dense ->
-// LeakyReLU(.2) -> Dense(1)).  The 3x3x3 convolutions run through conv3d.hip; a stride-2 'same' convolution of an even-sized
-// volume is its stride-1 result at the odd positions (TensorFlow pads 0 in front and 1 behind), so `pick_odd` /
-// `spread_odd` turn the stride-1 kernels (forward, data gradient, weight gradient) into the strided layer.  All HBM-bound.
+// LeakyReLU(.2) -> Dense(1)).  The 3x3x3 convolutions, strided ones included, run through conv3d.hip (ops.conv3d_stride2*).
+// All HBM-bound.
 #include "common.h"
 
 namespace {
@@ -45,34 +44,6 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
       atomicAdd(out + c0 + threadIdx.x, t);
     }
     __syncthreads();
-  }
-}
-
-// forward = 1: lo[o] = hi[2 o + 1] (channels-last, hi [2d0,2d1,2d2,C], lo [d0,d1,d2,C]);
-// forward = 0: hi = 0 except hi[2 o + 1] = lo[o] (the adjoint)
-__global__ __launch_bounds__(256) void odd_kernel(float* __restrict__ hi, float* __restrict__ lo, int d0, int d1, int d2,
-                                                  int C, int forward) {
-  if (forward) {
-    const int64_t n = (int64_t)d0 * d1 * d2 * C;
-    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-      const int c = (int)(i % C);
-      int64_t v = i / C;
-      const int x = (int)(v % d2);
-      v /= d2;
-      const int y = (int)(v % d1), z = (int)(v / d1);
-      lo[i] = hi[((((int64_t)(2 * z + 1) * (2 * d1)) + (2 * y + 1)) * (2 * d2) + (2 * x + 1)) * C + c];
-    }
-  } else {
-    const int64_t n = (int64_t)d0 * d1 * d2 * 8 * C;
-    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-      const int c = (int)(i % C);
-      int64_t v = i / C;
-      const int x = (int)(v % (2 * d2));
-      v /= 2 * d2;
-      const int y = (int)(v % (2 * d1)), z = (int)(v / (2 * d1));
-      const bool odd = (x & 1) && (y & 1) && (z & 1);
-      hi[i] = odd ? lo[(((int64_t)(z >> 1) * d1 + (y >> 1)) * d2 + (x >> 1)) * C + c] : 0.f;
-    }
   }
 }
 
@@ -157,24 +128,6 @@ int synthsr_bias_leaky_relu(const float* x, const float* bias, float* out, int64
 int synthsr_colsum(const float* x, int64_t n, int C, float* out, synthsr_stream_t stream) {
   if (!x || !out || n < 1 || C < 1) return SYNTHSR_EINVAL;
   hipLaunchKernelGGL(colsum_rows_kernel, dim3(syn_grid(n, 4, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, C, out);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
-}
-
-int synthsr_pick_odd(const float* hi, float* lo, const int* lo_shape, int C, synthsr_stream_t stream) {
-  if (!hi || !lo || !lo_shape || C < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1) return SYNTHSR_EINVAL;
-  const int64_t n = (int64_t)lo_shape[0] * lo_shape[1] * lo_shape[2] * C;
-  hipLaunchKernelGGL(odd_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(hi), lo,
-                     lo_shape[0], lo_shape[1], lo_shape[2], C, 1);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
-}
-
-int synthsr_spread_odd(const float* lo, float* hi, const int* lo_shape, int C, synthsr_stream_t stream) {
-  if (!hi || !lo || !lo_shape || C < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1) return SYNTHSR_EINVAL;
-  const int64_t n = (int64_t)lo_shape[0] * lo_shape[1] * lo_shape[2] * 8 * C;
-  hipLaunchKernelGGL(odd_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, hi, const_cast<float*>(lo),
-                     lo_shape[0], lo_shape[1], lo_shape[2], C, 0);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

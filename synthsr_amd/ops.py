@@ -496,23 +496,6 @@ def leaky_relu_bwd(dy, y, alpha=0.2, out=None):
     return out
 
 
-def pick_odd(hi, out=None):
-    """hi [2a,2b,2c,C] -> [a,b,c,C]: the odd positions (= a stride-2 'same' conv evaluated through the stride-1 kernel)"""
-    s = hi.shape
-    lo_shape = (s[0] // 2, s[1] // 2, s[2] // 2)
-    out = torch.empty(lo_shape + (s[3],), dtype=torch.float32, device=hi.device) if out is None else out
-    _lib.check(_L().synthsr_pick_odd(_lib.ptr(hi), _lib.ptr(out), _lib.i3(lo_shape), int(s[3]), _lib.stream()), 'pick_odd')
-    return out
-
-
-def spread_odd(lo, out=None):
-    """adjoint of pick_odd: zeros except at the odd positions"""
-    s = lo.shape
-    out = torch.empty((2 * s[0], 2 * s[1], 2 * s[2], s[3]), dtype=torch.float32, device=lo.device) if out is None else out
-    _lib.check(_L().synthsr_spread_odd(_lib.ptr(lo), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), _lib.stream()), 'spread_odd')
-    return out
-
-
 def dense_fwd(x, W, b, out=None):
     """y [n_out] = b + x [n_in] . W [n_in, n_out]"""
     n_in, n_out = int(W.shape[0]), int(W.shape[1])

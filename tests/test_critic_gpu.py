@@ -23,12 +23,12 @@ def test_critic_pieces():
     assert torch.equal(y.cpu(), torch.where(x > 0, x, 0.2 * x))
     dy = torch.randn(6, 4, 8, 5, generator=g)
     assert torch.equal(ops.leaky_relu_bwd(dy.cuda(), y).cpu(), dy * torch.where(x > 0, torch.ones(()), torch.full((), 0.2)))
-    lo = ops.pick_odd(x.cuda())
-    assert torch.equal(lo.cpu(), x[1::2, 1::2, 1::2])
-    hi = ops.spread_odd(lo)
-    ref = torch.zeros_like(x)
-    ref[1::2, 1::2, 1::2] = x[1::2, 1::2, 1::2]
-    assert torch.equal(hi.cpu(), ref)
+    yb = ops.bias_leaky_relu(x.cuda().clone(), torch.arange(5.0).cuda() - 2)
+    xb = x + (torch.arange(5.0) - 2)
+    assert torch.equal(yb.cpu(), torch.where(xb > 0, xb, 0.2 * xb))
+    cs = torch.zeros(5, device='cuda')
+    ops.colsum(x.cuda(), cs)
+    close(cs, x.reshape(-1, 5).sum(0), 1e-5, 'colsum')
     W, b, v = torch.randn(700, 96, generator=g), torch.randn(96, generator=g), torch.randn(700, generator=g)
     close(ops.dense_fwd(v.cuda(), W.cuda(), b.cuda()), v @ W + b, 1e-5, 'dense_fwd')
     dyv = torch.randn(96, generator=g)
