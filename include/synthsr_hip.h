@@ -358,6 +358,9 @@ int synthsr_dense_fwd(const float* x, const float* W, const float* b, float* y, 
 /* dx [n_in] = W dy (optional, written), dW [n_in][n_out] += x (x) dy (optional) */
 int synthsr_dense_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, int64_t n_in, int n_out,
                       synthsr_stream_t stream);
+/* out = x * y ; out[i] = lut[labels[i]] (ConvertLabels, ext/lab2im/layers.py:1659-1689; 0 outside the table) */
+int synthsr_mul(const float* x, const float* y, float* out, int64_t n, synthsr_stream_t stream);
+int synthsr_lut_gather(const int* labels, const float* lut, int n_lut, float* out, int64_t n, synthsr_stream_t stream);
 /* out = a x + b y (y optional) ; *out += sum x^2 */
 int synthsr_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, synthsr_stream_t stream);
 int synthsr_sumsq(const float* x, int64_t n, float* out, synthsr_stream_t stream);

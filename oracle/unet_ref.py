@@ -232,13 +232,14 @@ def critic_forward(x, P, name='discriminator', n_levels=4, alpha=0.2):
     return (h9 @ P['%s_dense_1/kernel' % name] + P['%s_dense_1/bias' % name]).reshape(())
 
 
-def critic_loss(real, fake, u_mix, P, name='discriminator', n_levels=4, gp_weight=10.0):
+def critic_loss(real, fake, u_mix, P, name='discriminator', n_levels=4, gp_weight=10.0, mask=None):
     """build_discriminator_loss (:579-595) with RandomWeightedAverage (:604-624) and Gradients (:627-642), batch of one:
     -D(real) + D(fake) + gp_weight (1 - ||grad_x D(x_hat)||_2)^2.  Returns (loss, grad norm); differentiable w.r.t. P."""
-    d_real = critic_forward(real, P, name, n_levels)
-    d_fake = critic_forward(fake, P, name, n_levels)
+    m = 1.0 if mask is None else mask      # make_discriminator(mask_input=True): the network sees x * mask (:485-487)
+    d_real = critic_forward(real * m, P, name, n_levels)
+    d_fake = critic_forward(fake * m, P, name, n_levels)
     x_hat = (u_mix * real + (1 - u_mix) * fake).detach().requires_grad_(True)
-    d_hat = critic_forward(x_hat, P, name, n_levels)
+    d_hat = critic_forward(x_hat * m, P, name, n_levels)
     g, = torch.autograd.grad(d_hat, x_hat, create_graph=True)
     norm = torch.sqrt((g * g).sum())
     return -d_real + d_fake + gp_weight * (1 - norm) ** 2, norm

@@ -84,6 +84,8 @@ SIGNATURES = {
     'synthsr_conv3d_stride_unpack': (c_int, [_P, _P, c_int, c_int, _S]),
     'synthsr_bias_leaky_relu': (c_int, [_P, _P, _P, c_int64, c_int, c_float, _S]),
     'synthsr_colsum': (c_int, [_P, c_int64, c_int, _P, _S]),
+    'synthsr_mul': (c_int, [_P, _P, _P, c_int64, _S]),
+    'synthsr_lut_gather': (c_int, [_P, _P, c_int, _P, c_int64, _S]),
     'synthsr_leaky_relu': (c_int, [_P, _P, _P, c_int64, c_float, _S]),
     'synthsr_dense_fwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, _S]),
     'synthsr_dense_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),

@@ -138,6 +138,7 @@ class Critic3D:
         ops.leaky_relu(h9, ALPHA)
         out = ops.dense_fwd(h9, self.view(d1['w']), self.view(d1['b']), out=self.buf('out' + tag, [1]))
         self._saved = dict(hs=hs, h9=h9, tag=tag)
+        self.last_output = out
         return out
 
     def backward(self, dout=1.0, weight_grads=True, input_grad=False, keep_deltas=False):
@@ -176,16 +177,22 @@ class Critic3D:
             self._deltas, self._delta9 = deltas, delta9
         return g if input_grad else None
 
-    def input_gradient(self, x, dout=1.0):
-        """dout * grad_x D(x) (critic frozen): the adversarial term of the generator loss"""
-        self.forward(x, tag='g')
-        return self.backward(dout, weight_grads=False, input_grad=True)
+    def input_gradient(self, x, dout=1.0, mask=None):
+        """dout * grad_x D(x [* mask]) (critic frozen): the adversarial term of the generator loss"""
+        self.forward(x if mask is None else ops.mul(x, mask, out=self.buf('xm', list(x.shape))), tag='g')
+        g = self.backward(dout, weight_grads=False, input_grad=True)
+        return g if mask is None else ops.mul(g, mask, out=g)
 
     # ------------------------------------------------------------------ WGAN-GP
-    def critic_loss_and_grads(self, real, fake, u_mix, gp_weight=10.0):
+    def critic_loss_and_grads(self, real, fake, u_mix, gp_weight=10.0, mask=None):
         """loss = -D(real) + D(fake) + gp_weight (1 - ||grad D(x_hat)||)^2 with x_hat = u real + (1 - u) fake
-        (build_discriminator_loss, batch of one); self.grads = its gradient.  Returns (loss, D(real), D(fake), ||grad||)"""
+        (build_discriminator_loss, batch of one); self.grads = its gradient.  mask (optional, `labels_to_mask`): the critic
+        sees x * mask (make_discriminator(mask_input=True)); the penalty's gradient is the one w.r.t. x_hat itself.
+        Returns (loss, D(real), D(fake), ||grad||)"""
         self.grads.zero_()
+        if mask is not None:
+            real = ops.mul(real, mask, out=self.buf('real_m', list(real.shape)))
+            fake = ops.mul(fake, mask, out=self.buf('fake_m', list(fake.shape)))
         d_real = self.forward(real, 'a').clone()
         self.backward(-1.0)
         d_fake = self.forward(fake, 'a').clone()
@@ -193,21 +200,25 @@ class Critic3D:
         x_hat = ops.axpby(real, fake, float(u_mix), 1.0 - float(u_mix), out=self.buf('x_hat', list(real.shape)))
         self.forward(x_hat, 'p')
         g0 = self.backward(1.0, weight_grads=False, input_grad=True, keep_deltas=True)
+        if mask is not None:
+            g0 = ops.mul(g0, mask, out=g0)
         nsq = self.buf('nsq', [1])
         nsq.zero_()
         ops.sumsq(g0, nsq)
         norm = float(torch.sqrt(nsq).item())          # one host sync per critic step, like Keras' train_on_batch return
         penalty = gp_weight * (1.0 - norm) ** 2
         if norm > 0:
-            self._penalty_backward(g0, gp_weight * 2.0 * (norm - 1.0) / norm)
+            self._penalty_backward(g0, gp_weight * 2.0 * (norm - 1.0) / norm, mask)
         loss = -float(d_real.item()) + float(d_fake.item()) + penalty
         return loss, float(d_real.item()), float(d_fake.item()), norm
 
-    def _penalty_backward(self, g0, scale):
+    def _penalty_backward(self, g0, scale, mask=None):
         """adds d penalty / d W to self.grads: masked forward pass of u_0 = scale * grad_x D(x_hat)"""
         hs, h9 = self._saved['hs'], self._saved['h9']
         G = self.grads
         u = ops.axpby(g0, None, scale, 0.0, out=self.buf('u0', list(g0.shape)))
+        if mask is not None:   # d(x_hat * mask)/d x_hat
+            ops.mul(u, mask, out=u)
         for i, c in enumerate(self.convs):
             self._wgrad(c, u, self._deltas[i], bias=False)
             v = self._conv(c, u, self.buf('v%d' % (i & 1), self._out_shape(c)), bias=False)

@@ -87,6 +87,19 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict_
   }
 }
 
+// out = x * y (elementwise); with lut != NULL: out[i] = lut[labels[i]] (0 for labels outside [0, n_lut)) - ConvertLabels
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                  float* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = x[i] * y[i];
+}
+__global__ __launch_bounds__(256) void lut_kernel(const int* __restrict__ labels, const float* __restrict__ lut, int n_lut,
+                                                  float* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int l = labels[i];
+    out[i] = ((unsigned)l < (unsigned)n_lut) ? lut[l] : 0.f;
+  }
+}
+
 // out = a * x + b * y (elementwise; y optional)
 __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                     float* __restrict__ out, int64_t n, float a, float b) {
@@ -148,6 +161,20 @@ int synthsr_dense_bwd(const float* x, const float* W, const float* dy, float* dx
   if (!W || !dy || (!dx && !dW) || (dW && !x) || n_in < 1 || n_out < 1 || n_out > 1024) return SYNTHSR_EINVAL;
   hipLaunchKernelGGL(dense_bwd_kernel, dim3(syn_grid(n_in, 4, 4096)), dim3(256), n_out * sizeof(float), (hipStream_t)stream,
                      x, W, dy, dx, dW, n_in, n_out);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_mul(const float* x, const float* y, float* out, int64_t n, synthsr_stream_t stream) {
+  if (!x || !y || !out || n < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(mul_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, out, n);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_lut_gather(const int* labels, const float* lut, int n_lut, float* out, int64_t n, synthsr_stream_t stream) {
+  if (!labels || !lut || !out || n < 1 || n_lut < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(lut_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, labels, lut, n_lut, out, n);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

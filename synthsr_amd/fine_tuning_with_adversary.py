@@ -7,8 +7,7 @@ sample with loss (1 - w_d [- w_dice]) L1 + w_d mean(-D(G(x))) [+ w_dice Dice] (`
 networks use Keras-semantics Adam.  Per epoch: `logs/{discriminator,generator}_loss.npy` and the two networks as
 `generator_<epoch>.h5|.npz`, `discriminator_<epoch>.h5` (Keras weight layout).
 
-First functional version (one GPU): the critic's convolutions run on the generic kernels (critic.py), `labels_to_mask` is
-not built.  Keras details that are third-party and unpinned here: BatchNormalization of the frozen generator inside the
+One GPU; the critic's convolutions run on the generic kernels (critic.py).  Keras details that are third-party and unpinned here: BatchNormalization of the frozen generator inside the
 critic update uses batch statistics (training phase, Keras 2.3.1) and does not move the moving averages."""
 import os
 import time
@@ -24,10 +23,11 @@ from .unet import unet as build_unet
 
 
 def make_discriminator(input_shape, n_filters=32, n_levels=4, mask_input=False, device=None, seed=0):
-    """the critic network of fine_tuning_with_adversary.py:482-502 as a `Critic3D`"""
-    if mask_input:
-        raise NotImplementedError('mask_input (critic on label-masked volumes) is not built')
-    return Critic3D(input_shape, n_filters=n_filters, n_levels=n_levels, device=device, seed=seed)
+    """the critic network of fine_tuning_with_adversary.py:482-502 as a `Critic3D`; with mask_input the volumes are
+    multiplied by a mask before the first layer - pass it as `mask=` to the critic's methods"""
+    critic = Critic3D(input_shape, n_filters=n_filters, n_levels=n_levels, device=device, seed=seed)
+    critic.mask_input = bool(mask_input)
+    return critic
 
 
 class AdversarialTrainer:
@@ -35,12 +35,23 @@ class AdversarialTrainer:
 
     def __init__(self, brain_generator, net, critic, lr_generator=1e-4, lr_discriminator=1e-4, lr_decay=0.0,
                  relative_weight_discriminator=0.01, gradient_penalty_weight=10.0, work_with_residual_channel=None,
-                 loss_cropping=None, seg_regulariser=None, rng=None):
+                 loss_cropping=None, seg_regulariser=None, rng=None, mask_lut=None):
         self.bg, self.gen, self.net, self.critic = brain_generator, brain_generator.labels_to_image_model, net, critic
         self.lr_g, self.lr_d, self.lr_decay = lr_generator, lr_discriminator, lr_decay
         self.w_d, self.gp = float(relative_weight_discriminator), float(gradient_penalty_weight)
         self.residual, self.loss_cropping, self.seg = work_with_residual_channel, loss_cropping, seg_regulariser
         self.rng = np.random.default_rng(0) if rng is None else rng
+        # labels_to_mask: float LUT label value -> mask value (ConvertLabels(generation_labels, labels_to_mask), :363-365)
+        self.mask_lut = None if mask_lut is None else __import__('torch').as_tensor(
+            np.asarray(mask_lut, dtype=np.float32)).to(net.device)
+
+    def _mask(self, seg, like):
+        from . import ops
+        if self.mask_lut is None:
+            return None
+        if list(seg.shape) != list(like.shape[:3]):
+            raise NotImplementedError('labels_to_mask with a target resolution different from the label maps')
+        return ops.lut_gather(seg.contiguous(), self.mask_lut).view(*like.shape[:3], 1)
 
     def _generate(self):
         inputs = next(self.bg.model_inputs_generator)
@@ -58,11 +69,12 @@ class AdversarialTrainer:
 
     def critic_step(self):
         """one update of the critic (discriminator_model.train_on_batch, :452-453); returns the critic loss"""
-        image, target, _ = self._generate()
+        image, target, seg = self._generate()
         _, pred = self._forward_generator(image, target, False)          # generator frozen: forward only
         fake = pred.view(*target.shape)
         u = float(self.rng.uniform())                                      # RandomWeightedAverage, one weight per sample
-        loss, _, _, _ = self.critic.critic_loss_and_grads(target.contiguous(), fake, u, self.gp)
+        loss, _, _, _ = self.critic.critic_loss_and_grads(target.contiguous(), fake, u, self.gp,
+                                                           mask=self._mask(seg, target))
         self.critic.adam_step(self.lr_d, self.lr_decay)
         return loss
 
@@ -76,8 +88,8 @@ class AdversarialTrainer:
         w_l1 = 1.0 - self.w_d - w_dice
         ops.axpby(net.dpred, None, w_l1, 0.0, out=net.dpred)              # d(w_l1 L1)/d pred
         fake = pred.view(*target.shape)
-        d_fake = self.critic.forward(fake, tag='g')
-        g_adv = self.critic.backward(-self.w_d, weight_grads=False, input_grad=True)   # d(w_d * -D(G))/d pred
+        g_adv = self.critic.input_gradient(fake, -self.w_d, mask=self._mask(seg, target))   # d(w_d * -D(G))/d pred
+        d_fake = self.critic.last_output
         ops.axpby(net.dpred, g_adv.reshape(-1), 1.0, 1.0, out=net.dpred)
         loss = w_l1 * float(l1.item()) - self.w_d * float(d_fake.item())
         if self.seg is not None:
@@ -122,8 +134,6 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
             raise Exception('The number or residual channels and output channels must be the same')
         if any(x >= n_channels for x in work_with_residual_channel):
             raise Exception('indices in work_with_residual_channel cannot be greater than the total number of channels')
-    if labels_to_mask is not None:
-        raise NotImplementedError('labels_to_mask (masked critic input) is not built')
     if dropout != 0:
         raise NotImplementedError('dropout is not supported')
     if batchsize != 1:
@@ -163,7 +173,11 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
         if verbose:
             print('loading', checkpoint_generator)
         load_checkpoint(checkpoint_generator, generator)
-    critic = make_discriminator(list(unet_input_shape[:-1]) + [n_output_channels], seed=seed + 2)
+    mask_lut = None
+    if labels_to_mask is not None:
+        mask_lut = hm.get_mapping_lut(generation_labels, hm.load_array_if_path(labels_to_mask))
+    critic = make_discriminator(list(unet_input_shape[:-1]) + [n_output_channels], mask_input=mask_lut is not None,
+                                seed=seed + 2)
     seg_reg = None
     if segmentation_model_file is not None:
         from .seg_loss import SegmentationRegulariser
@@ -178,7 +192,7 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
                                           relative_weight_segmentation, m=np.percentile(im, 2), M=np.percentile(im, 98))
     trainer = AdversarialTrainer(brain_generator, generator, critic, lr_generator, lr_discriminator, lr_decay,
                                  relative_weight_discriminator, gradient_penalty_weight, work_with_residual_channel,
-                                 loss_cropping, seg_reg, rng=rng)
+                                 loss_cropping, seg_reg, rng=rng, mask_lut=mask_lut)
     width = len(str(epochs))
     log_d, log_g = np.array([]), np.array([])
     for epoch in range(epochs):

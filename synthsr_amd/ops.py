@@ -581,3 +581,17 @@ def conv3d_stride2_wgrad(x, dy, dw, dwc, dbias=None):
     if dbias is not None:
         colsum(dy, dbias)
     return dw
+
+
+def mul(x, y, out=None):
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_L().synthsr_mul(_lib.ptr(x), _lib.ptr(y), _lib.ptr(out), x.numel(), _lib.stream()), 'mul')
+    return out
+
+
+def lut_gather(labels, lut, out=None):
+    """out = lut[labels] (float32; ConvertLabels of the reference): labels int32, lut float32 device tensors"""
+    out = torch.empty(labels.shape, dtype=torch.float32, device=labels.device) if out is None else out
+    _lib.check(_L().synthsr_lut_gather(_lib.ptr(labels), _lib.ptr(lut), lut.numel(), _lib.ptr(out), labels.numel(),
+                                       _lib.stream()), 'lut_gather')
+    return out

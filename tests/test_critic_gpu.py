@@ -42,8 +42,9 @@ def test_critic_pieces():
     close(ops.axpby(v.cuda(), (2 * v).cuda(), 0.25, 0.5), 1.25 * v, 1e-6, 'axpby')
 
 
-@pytest.mark.parametrize('shape,n_filters,n_levels', [((16, 16, 16), 8, 2), ((8, 16, 24), 32, 3)])
-def test_critic_loss_and_gradients_vs_autograd(shape, n_filters, n_levels):
+@pytest.mark.parametrize('shape,n_filters,n_levels,masked', [((16, 16, 16), 8, 2, False), ((8, 16, 24), 32, 3, False),
+                                                          ((16, 16, 16), 8, 2, True)])
+def test_critic_loss_and_gradients_vs_autograd(shape, n_filters, n_levels, masked):
     """-D(real) + D(fake) + 10 (1 - ||grad D(x_hat)||)^2 and its gradient w.r.t. every critic parameter (the penalty term
     through the masked forward pass) against autograd with create_graph; the input gradient used by the generator step"""
     import torch
@@ -58,9 +59,18 @@ def test_critic_loss_and_gradients_vs_autograd(shape, n_filters, n_levels):
     net.repack()
     real, fake = torch.rand(*shape, 1, generator=g), torch.rand(*shape, 1, generator=g)
     u = 0.3
-    loss, d_real, d_fake, norm = net.critic_loss_and_grads(real.cuda(), fake.cuda(), u, gp_weight=10.0)
+    mask = None
+    if masked:     # labels_to_mask: ConvertLabels(generation_labels, labels_to_mask)(segmentation) through the device LUT
+        from synthsr_amd import ops
+        seg = torch.randint(0, 6, shape, generator=g, dtype=torch.int32)
+        lut = torch.tensor([0., 1., 1., 0., 1., 1.])
+        mask = lut[seg.long()][..., None]
+        dmask = ops.lut_gather(seg.cuda(), lut.cuda())[..., None].contiguous()
+        assert torch.equal(dmask.cpu(), mask)
+    loss, d_real, d_fake, norm = net.critic_loss_and_grads(real.cuda(), fake.cuda(), u, gp_weight=10.0,
+                                                            mask=dmask if masked else None)
     P = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
-    ref, nref = U.critic_loss(real, fake, u, P, net.name, n_levels, 10.0)
+    ref, nref = U.critic_loss(real, fake, u, P, net.name, n_levels, 10.0, mask=mask)
     ref.backward()
     nref, ref = float(nref.detach()), float(ref.detach())
     assert abs(norm - nref) < 2e-4 * nref, (norm, nref)
@@ -70,9 +80,9 @@ def test_critic_loss_and_gradients_vs_autograd(shape, n_filters, n_levels):
         close(net.view(nm, net.grads), P[nm].grad, 2e-3, 'grad ' + nm)
     # generator side: -w * grad_x D(x)
     x = fake.clone().requires_grad_(True)
-    d = U.critic_forward(x, {k: v.detach() for k, v in P.items()}, net.name, n_levels)
+    d = U.critic_forward(x if mask is None else x * mask, {k: v.detach() for k, v in P.items()}, net.name, n_levels)
     gx, = torch.autograd.grad(d, x)
-    close(net.input_gradient(fake.cuda(), dout=-0.01), -0.01 * gx, 2e-3, 'input gradient')
+    close(net.input_gradient(fake.cuda(), dout=-0.01, mask=dmask if masked else None), -0.01 * gx, 2e-3, 'input gradient')
     # one Adam step moves the parameters and re-packs the conv weights (D changes)
     before = net.forward(real.cuda()).item()
     net.adam_step(lr=1e-3)
@@ -126,6 +136,13 @@ def test_adversarial_fine_tuning_end_to_end(tmp_path):
                        lr_generator=0.0, verbose=False)
     a, b = gen.state_dict(), gen2.state_dict()
     assert all(torch.equal(a[k], b[k]) for k in a if 'moving' not in k)  # lr 0: the loaded weights, untouched
+    # labels_to_mask: the critic only sees the voxels whose label maps to 1
+    to_mask = (np.asarray(GENERATION_LABELS) > 0).astype(np.int32)
+    gen3, critic3 = training(str(ldir), str(idir), str(tmp_path / 'm3'), None, None, str(tmp_path / 'gl.npy'),
+                             output_shape=32, n_levels=3, nonlin_shape_factor=.125, bias_shape_factor=.125, epochs=1,
+                             steps_per_epoch=1, first_training_ratio=2, training_ratio=1, labels_to_mask=to_mask,
+                             verbose=False)
+    assert critic3.mask_input and critic3.iterations == 2 and gen3.iterations == 1
     with pytest.raises(Exception, match='not both'):
         training(str(ldir), str(idir), mdir, None, None, str(tmp_path / 'gl.npy'), output_channel=0)
     with pytest.raises(Exception, match='output_channel or image_dir'):
