@@ -198,3 +198,39 @@ def test_bench_under_torchrun_with_forced_allreduce():
     d = json.loads(line)
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and np.isfinite(d['final_loss'])
     assert d['roofline']['bound'] == 'mfma' and 0 < d['roofline']['frac'] < 1
+
+
+@pytest.mark.parametrize('case', ['sr', 'synthesis', 'multimodal', 'real'])
+def test_generation_examples_script(tmp_path, case):
+    """scripts/tutorials/generate_examples.py (the use cases of the reference's tutorials 1-6) end to end on NIfTI files"""
+    import importlib.util
+    from synthsr_amd.nifti import write_nifti, read_nifti
+    from synthsr_amd.synthetic import (GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR,
+                                       synthetic_label_map)
+    labels_dir = _write_labels(tmp_path, 2, (64, 64, 64))
+    pri = tmp_path / 'priors'
+    pri.mkdir()
+    np.save(pri / 'generation_labels.npy', GENERATION_LABELS)
+    np.save(pri / 'generation_classes.npy', GENERATION_CLASSES)
+    for c in ('t1_hr', 't1_lr', 't2'):
+        np.save(pri / ('prior_means_%s.npy' % c), PRIOR_MEANS_T1_HR)
+        np.save(pri / ('prior_stds_%s.npy' % c), PRIOR_STDS_T1_HR)
+    argv = [case, '--labels', labels_dir, '--priors', str(pri), '--out', str(tmp_path / 'out'), '-n', '2', '--shape', '32']
+    if case == 'real':
+        img = tmp_path / 'images'
+        img.mkdir()
+        for i in range(2):
+            lab = synthetic_label_map((64, 64, 64), 10 + i)
+            write_nifti(str(img / ('brain%d.nii.gz' % i)), (10.0 * (lab % 17) + 5).astype(np.float32))
+        argv += ['--images', str(img)]
+    spec = importlib.util.spec_from_file_location('gen_examples', os.path.join(REPO, 'scripts', 'tutorials',
+                                                                              'generate_examples.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(argv)
+    n_in = {'sr': 2, 'synthesis': 1, 'multimodal': 4, 'real': 2}[case]      # input channels (+ reliability maps)
+    for i in range(2):
+        im, _, _ = read_nifti(str(tmp_path / 'out' / ('image_%d.nii.gz' % i)))
+        tg, _, _ = read_nifti(str(tmp_path / 'out' / ('target_%d.nii.gz' % i)))
+        assert im.shape[:3] == (32, 32, 32) and (im.shape[3] if im.ndim == 4 else 1) == n_in and tg.shape == (32, 32, 32)
+        assert np.isfinite(im).all() and np.isfinite(tg).all() and tg.max() > 0
