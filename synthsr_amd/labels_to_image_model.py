@@ -351,13 +351,12 @@ class LabelsToImageModel:
         off_lut = sm.put(hm.gmm_luts(self.generation_labels, means, stds))
         off_bias = None
         gates = []
+        bias_grids = []  # deform_gmm_kernel walks the grids back to back (boff += b0*b1*b2): ONE contiguous block
         for i in range(C):
             ch = d.channels[i]
             if self.input_channels[i] and self.bias_field_std > 0:
                 bstd = hm.uniform_f32(ch['u_bias_std'], 0., self.bias_field_std)  # layers.py:1080
-                o = sm.put(np.asarray(ch['n_bias'], np.float32) * bstd)
-                if off_bias is None:
-                    off_bias = o
+                bias_grids.append((np.asarray(ch['n_bias'], np.float32) * bstd).reshape(-1))
                 gate = bool(np.float32(ch['u_bias_gate']) < np.float32(0.95))  # :1090
                 p.bias_on[i] = int(gate)
                 for k in range(3):
@@ -367,6 +366,8 @@ class LabelsToImageModel:
                 p.bias_on[i] = 0
                 for k in range(3):
                     p.bias_shape[i][k] = 0
+        if bias_grids:
+            off_bias = sm.put(np.concatenate(bias_grids))
         p.clip_hi = 300.0  # IntensityAugmentation(clip=300), labels_to_image_model.py:184
         # blur kernels
         k05 = hm.gaussian_kernel([.5] * 3)

@@ -21,7 +21,7 @@ from . import ops
 class UNet3D:
     def __init__(self, nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None,
                  feat_mult=1, nb_conv_per_level=1, batch_norm=None, activation='elu', device=None, seed=0,
-                 final_pred_activation='linear', fold_upsample='auto'):
+                 final_pred_activation='linear', fold_upsample='auto', table_only=False):
         self.overlap_wgrad = False  # weight gradients on a second HIP stream (see _fork): measured 0.5 ms SLOWER per step
                                     # on one MI355X (cross-stream event waits cost more than the tails they fill) ...
         self.overlap_max_voxels = 40 ** 3  # ... on the small levels only: big persistent kernels just disturb each other
@@ -49,7 +49,8 @@ class UNet3D:
         if len(input_shape) != 4:
             raise NotImplementedError('3-D volumes only')
         self.prefix = name if prefix is None else prefix
-        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device = torch.device(device) if device is not None else (
+            torch.device('cpu') if table_only else torch.device('cuda', torch.cuda.current_device()))
         self.input_shape = [int(s) for s in input_shape]
         self.nb_levels = L = int(nb_levels)
         self.nconv = int(nb_conv_per_level)
@@ -94,6 +95,9 @@ class UNet3D:
                          w=self._add('%s_likelihood/kernel' % self.prefix, (c, self.nb_labels), 'head_w'),
                          b=self._add('%s_likelihood/bias' % self.prefix, (self.nb_labels,), 'bias'))
         self.n_params = sum(int(np.prod(s[1])) for s in self.specs)
+        self.bn_layers = [e['bn'] for e in self.enc] + [d['bn'] for d in self.dec]
+        if table_only:      # host-side inspection of the layer table (names / shapes / count): nothing is allocated
+            return
         dev = self.device
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=dev)

@@ -185,6 +185,39 @@ def test_randomise_res_two_channels_with_registration_vs_oracle(env):
     np.testing.assert_allclose(target.cpu().numpy(), ref['target'], atol=2e-5)
 
 
+def test_three_channels_with_5cubed_bias_grids_vs_oracle(env):
+    """several input channels whose bias grids are 5^3 = 125 floats (not a multiple of 4): the grids of channels 1.. must
+    be found right behind the previous one in the small-parameter block (deform_gmm_kernel: boff += b0*b1*b2)"""
+    from oracle import generator_ref as R
+    from synthsr_amd.labels_to_image_model import labels_to_image_model
+    rng = np.random.default_rng(17)
+    shape = (40, 40, 40)
+    labels = np.kron(np.asarray(GEN)[rng.integers(0, len(GEN), (10, 10, 10))], np.ones((4, 4, 4), np.int32)).astype(np.int32)
+    kw = dict(C2_KW)
+    kw.update(output_div_by_n=8, simulate_registration_error=False, bias_field_std=.6)
+    m = labels_to_image_model(labels_shape=list(shape), input_channels=[True, True, True], output_channel=[0],
+                              generation_labels=GEN, n_neutral_labels=len(GEN), aff=np.eye(4), output_shape=40, **kw)
+    assert list(m.small_bias_shape) == [5, 5, 5]
+    means = rng.uniform(20, 220, (len(GEN), 3)).astype(np.float32)
+    stds = rng.uniform(2, 20, (len(GEN), 3)).astype(np.float32)
+    u = lambda *s: rng.random(s, dtype=np.float32)
+    n = lambda *s: rng.standard_normal(s, dtype=np.float32)
+    chan = lambda: [('u', u(1, 1, 1, 1, 1)), ('n', n(1, 5, 5, 5, 1)), ('u', np.float32([0.5])), ('n', n(1, 1, 1, 1, 1)),
+                    ('u', u(3))]
+    tape = [('u', u(1, 3)), ('u', u(1, 6)), ('u', u(1, 3)), ('u', u(1, 3)), ('u', u(1, 1)), ('n', n(1, 5, 5, 5, 3)),
+            ('u', u(1, 1)), ('n', n(1, 40, 40, 40, 3))] + chan() + chan() + chan()
+    ref = R.labels_to_image(labels, means, stds, tape, GEN, len(GEN), input_channels=[True, True, True],
+                            output_channel=[0], output_shape=40, **kw)
+    # poison the staging buffer: a wrong offset must not be able to read zeros by luck
+    m.h_small.fill_(1e3)
+    m.d_small.fill_(1e3)
+    image, target, seg = m.generate(labels, means, stds, m.draws_from_tape(tape))
+    np.testing.assert_array_equal(seg.cpu().numpy(), ref['seg'])
+    assert image.shape[-1] == 6
+    np.testing.assert_allclose(image.cpu().numpy(), ref['image'], atol=2e-5)
+    np.testing.assert_allclose(target.cpu().numpy(), ref['target'], atol=2e-5)
+
+
 def test_random_shapes_vs_oracle(env):
     """ragged (non-cubic, odd) label maps with crop + sided labels against the oracle on fresh tapes"""
     from oracle import generator_ref as R
