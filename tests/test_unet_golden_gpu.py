@@ -138,7 +138,7 @@ def test_critic_vs_reference(T, tag):
     real, fake = torch.as_tensor(g[tag + '_real']).cuda(), torch.as_tensor(g[tag + '_fake']).cuda()
     net = Critic3D(list(real.shape), n_filters=int(P['discriminator_conv_0/kernel'].shape[-1]), n_levels=n_levels)
     net.load_state_dict(P)
-    mask = torch.as_tensor(g[tag + '_mask']).cuda().contiguous() if tag == 'cr_mask' else None
+    mask = torch.as_tensor(g[tag + '_mask']).float().cuda().contiguous() if tag == 'cr_mask' else None  # int32 in the reference
     mk = 1.0 if mask is None else mask
     assert abs(net.forward((real * mk).contiguous()).item() - float(g[tag + '_d_real'])) < 5e-6
     assert abs(net.forward((fake * mk).contiguous()).item() - float(g[tag + '_d_fake'])) < 5e-6
