@@ -198,9 +198,16 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
         if any(x >= n_channels for x in work_with_residual_channel):
             raise Exception('indices in work_with_residual_channel cannot be greater than the total number of channels')
         if build_reliability_maps:
-            # the reference repeats the python list here (`2 * list`, F11) instead of doubling the indices
-            raise NotImplementedError('work_with_residual_channel together with build_reliability_maps=True is '
-                                      'ill-defined in the reference (SURVEY F11); set build_reliability_maps=False')
+            # SynthSR/training.py:270-271 repeats the python LIST here (`2 * list`) instead of doubling the
+            # indices.  One residual channel c -> [c, c]: metrics_model adds image_out[..., c] twice as a 2-channel tensor
+            # that broadcasts against the 1-channel prediction / target, so the loss equals the single-channel one with
+            # the index taken IN THE INTERLEAVED image (c = 1 is the reliability map of channel 0, as in the reference);
+            # pinned by tests/golden/unet_training_graph.npz (`tg_l1_res`).  Several residual channels [a, b] -> [a, b, a, b]
+            # make keras' Add fail on shapes (4 vs 2 channels): same outcome here.
+            if len(work_with_residual_channel) > 1:
+                raise ValueError('Operands could not be broadcast together: work_with_residual_channel has %d entries and '
+                                 'build_reliability_maps=True repeats the list (SynthSR/training.py:270-271)'
+                                 % len(work_with_residual_channel))
     if regression_metric not in ('l1', 'l2', 'laplace', 'ssim'):
         raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(regression_metric))
     if dropout != 0:

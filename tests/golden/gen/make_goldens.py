@@ -253,6 +253,12 @@ def golden_graphs():
     lab_b = load_label_crop(3, (50, 70, 60), (40, 48, 36))[None, ..., None]
     run_graph('graph_crop_s111', lab_b, means, stds, 111, input_channels=[True], output_channel=[0],
               output_shape=32, **train_defaults)
+    # (b-pad) PadAroundCentre (H3): padding_margin as training() sets it when loss_cropping is used (training.py:282-285),
+    # scalar and per-axis; the padded 40^3 / 36x40x44 maps are then randomly cropped to 32^3; with a real-image target too
+    run_graph('graph_pad_s161', lab, means, stds, 161, input_channels=[True], output_channel=[0], output_shape=32,
+              **dict(train_defaults, padding_margin=4))
+    run_graph('graph_pad_s162', lab, means, stds, 162, input_channels=[True], output_channel=[0], output_shape=32,
+              **dict(train_defaults, padding_margin=[2, 4, 6]))
     # (b') real-image regression target (output_channel=None, tutorials 1/3/5): a smooth synthetic "scan" deformed,
     # cropped and flipped jointly with the labels (linear), then min-max normalised
     def fake_scan(lab_vol, seed):
@@ -264,6 +270,8 @@ def golden_graphs():
               output_channel=None, output_shape=32, **train_defaults)
     run_graph('graph_real_crop_s132', lab_b, means, stds, 132, real_image=fake_scan(lab_b, 2), input_channels=[True],
               output_channel=None, output_shape=32, **train_defaults)
+    run_graph('graph_real_pad_s163', lab, means, stds, 163, real_image=fake_scan(lab, 3), input_channels=[True],
+              output_channel=None, output_shape=32, **dict(train_defaults, padding_margin=4))
     # (b'') randomise_res=True (fine_tuning_with_adversary defaults): SampleResolution -> separable 17-tap
     # DynamicGaussianBlur -> MimicAcquisition with distance map.  Keras' dynamic batch dimension is emulated for
     # edit_tensors.gaussian_kernel, which decides static-vs-batched sigma from `shape[0] is None` (edit_tensors.py:102-110)

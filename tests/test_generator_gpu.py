@@ -99,6 +99,19 @@ def test_whole_graph_config2_vs_golden(env, name):
     np.testing.assert_allclose(target.cpu().numpy(), g['target'][0], atol=2e-5)
 
 
+@pytest.mark.parametrize('name,margin,real', [('graph_pad_s161', 4, False), ('graph_pad_s162', [2, 4, 6], False),
+                                              ('graph_real_pad_s163', 4, True)])
+def test_whole_graph_padding_margin_vs_golden(env, name, margin, real):
+    """H3: PadAroundCentre through padding_margin (scalar / per axis; labels and real image), reference graph goldens"""
+    g, m = _model(name, input_channels=[True], output_channel=None if real else [0], padding_margin=margin)
+    draws = m.draws_from_tape(tape_from_golden(g))
+    extra = dict(real_image=g['real_image'][0, ..., 0]) if real else {}
+    image, target, seg = m.generate(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], draws, **extra)
+    np.testing.assert_array_equal(seg.cpu().numpy(), g['seg'][0, ..., 0])
+    np.testing.assert_allclose(image.cpu().numpy(), g['image'][0], atol=2e-5)
+    np.testing.assert_allclose(target.cpu().numpy(), g['target'][0], atol=2e-5)
+
+
 @pytest.mark.parametrize('name,maps', [('graph_hyperfine_s121', False), ('graph_hyperfine_maps_s122', True)])
 def test_whole_graph_hyperfine_vs_golden(env, name, maps):
     res = np.array([[1.5, 1.5, 5.], [1.5, 1.5, 5.]])

@@ -260,3 +260,39 @@ def test_public_signatures_match_reference():
         problems += [(key, 'extra parameter without default', p.name) for p in params[len(ref):]
                      if p.default is inspect.Parameter.empty]
     assert not problems, problems
+
+
+def test_model_inputs_and_draws_match_reference_under_seeded_numpy():
+    """H1: SynthSR/model_inputs.py:build_model_inputs and utils.draw_value_from_distribution (numpy branch) of the
+    REFERENCE, run under a seeded global numpy state (tests/golden/gen/make_model_inputs_golden.py), against the product's
+    sampler fed from the same global state (rng=None): identical call order => identical draws, bit for bit"""
+    from conftest import load_golden
+    from synthsr_amd import host_math as hm
+    from synthsr_amd.model_inputs import build_model_inputs
+    g = load_golden('model_inputs')
+    pm, ps, pm2, ps2, classes = g['pm'], g['ps'], g['pm2'], g['ps2'], g['classes']
+    cases = [('none_u', None, 4, 'uniform', 125., 100., True), ('num_n', 7.5, 3, 'normal', 10., 2., False),
+             ('pair_u', [2., 9.], 5, 'uniform', 0., 10., False), ('pair_n', (3., .5), 5, 'normal', 0., 10., True),
+             ('arr_n', pm, 1, 'normal', 125., 100., True), ('arr2_u', np.abs(pm2), 1, 'uniform', 125., 100., False),
+             ('neg_n', np.stack([np.full(8, -1.), np.full(8, 3.)]), 1, 'normal', 0., 1., True)]
+    for tag, hp, size, dist, centre, rg, pos in cases:
+        np.random.seed(int(g['dv_' + tag + '_seed']))
+        vals = np.stack([hm.draw_value_from_distribution(hp, size, dist, centre, rg, positive_only=pos) for _ in range(3)])
+        np.testing.assert_array_equal(vals, g['dv_' + tag], err_msg=tag)
+    assert hm.draw_value_from_distribution(False) is None
+    labs = [g['lab%d' % i] for i in range(3)]
+    ims = [g['im%d' % i] for i in range(3)]
+    runs = [('a', pm, ps, 'normal', None, 1, 1, classes), ('b', pm2, ps2, 'normal', None, 1, 2, classes),
+            ('c', None, None, 'uniform', None, 1, 1, None), ('d', [30., 150.], 12., 'uniform', ims, 1, 3, classes),
+            ('e', pm, ps, 'uniform', ims, 2, 1, classes)]
+    for tag, m, s, dist, images, bs, nch, cls in runs:
+        np.random.seed(int(g['mi_%s_seed' % tag]))
+        gen = build_model_inputs(None, 9, m, s, dist, path_images=images, batchsize=bs, n_channels=nch,
+                                 generation_classes=cls, label_maps=labs)
+        for it in range(3):
+            items = next(gen)
+            assert len(items) == (4 if images is not None else 3)
+            for j, a in enumerate(items):
+                ref = g['mi_%s_%d_%d' % (tag, it, j)]
+                assert np.asarray(a).shape == ref.shape, (tag, it, j)
+                np.testing.assert_array_equal(np.asarray(a), ref, err_msg='%s %d %d' % (tag, it, j))

@@ -158,6 +158,23 @@ def test_whole_graph_config2(name, gen_labels):
     assert np.all(out['image'][..., 1] == 1)  # reliability map of a non-downsampled channel
 
 
+@pytest.mark.parametrize('name,margin,real', [('graph_pad_s161', 4, False), ('graph_pad_s162', [2, 4, 6], False),
+                                              ('graph_real_pad_s163', 4, True)])
+def test_whole_graph_padding_margin(name, margin, real, gen_labels):
+    """H3: PadAroundCentre (ext/lab2im/layers.py:1692-1755) via padding_margin, scalar and per axis, labels and real image;
+    the padded maps are then randomly cropped back to 32^3"""
+    g = load_golden(name)
+    kw = dict(C2_KW, padding_margin=margin)
+    extra = dict(real_image=g['real_image'][0, ..., 0]) if real else {}
+    out = R.labels_to_image(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], tape_from_golden(g), gen_labels,
+                            len(gen_labels), output_shape=32, input_channels=[True],
+                            output_channel=None if real else [0], **extra, **kw)
+    np.testing.assert_array_equal(out['seg'], g['seg'][0, ..., 0])
+    np.testing.assert_allclose(out['image'], g['image'][0], atol=5e-6)
+    np.testing.assert_allclose(out['target'], g['target'][0], atol=1e-5 if real else 5e-6)
+    assert (out['seg'] == 0).any()          # the zero margin is visible in the crop
+
+
 @pytest.mark.parametrize('name,maps', [('graph_hyperfine_s121', False), ('graph_hyperfine_maps_s122', True)])
 def test_whole_graph_hyperfine(name, maps, gen_labels):
     res = np.array([[1.5, 1.5, 5.], [1.5, 1.5, 5.]])

@@ -187,6 +187,30 @@ def test_training_two_output_channels_with_residuals(tmp_path):
     assert len(log) == 3 and all(np.isfinite(log)) and log[-1] < log[0]
 
 
+def test_training_tutorial7_residual_channel_with_reliability_maps(tmp_path):
+    """scripts/tutorials/7-training.py configuration: work_with_residual_channel=[0] together with build_reliability_maps
+    (the reference repeats the list, SynthSR/training.py:270-271, F11): trains, and the residual is image_out[..., 0]"""
+    from synthsr_amd.training import training
+    from synthsr_amd.synthetic import GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR
+    labels_dir = _write_labels(tmp_path, n=1)
+    np.save(tmp_path / 'gl.npy', GENERATION_LABELS)
+    np.save(tmp_path / 'gc.npy', GENERATION_CLASSES)
+    np.save(tmp_path / 'pm.npy', PRIOR_MEANS_T1_HR)
+    np.save(tmp_path / 'ps.npy', PRIOR_STDS_T1_HR)
+    model_dir = str(tmp_path / 'models')
+    kw = dict(path_generation_classes=str(tmp_path / 'gc.npy'), input_channels=[True], output_channel=[0],
+              build_reliability_maps=True, data_res=[1., 1., 3.], output_shape=32, n_levels=3, unet_feat_count=24,
+              nonlin_shape_factor=.125, bias_shape_factor=.125, steps_per_epoch=4, epochs=3, verbose=False, lr=1e-3)
+    args = (labels_dir, model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'), str(tmp_path / 'gl.npy'))
+    net = training(*args, work_with_residual_channel=[0], **kw)
+    assert net.input_shape[3] == 2
+    log = [float(l.split(',')[1]) for l in open(os.path.join(model_dir, 'logs', 'loss.csv')).read().strip().split('\n')]
+    assert len(log) == 3 and all(np.isfinite(log)) and log[-1] < log[0]
+    kw2 = dict(kw, input_channels=[True, True], output_channel=[0, 1])
+    with pytest.raises(ValueError):       # keras' Add cannot broadcast the repeated list [0, 1, 0, 1] against 2 channels
+        training(*args, work_with_residual_channel=[0, 1], **kw2)
+
+
 def test_bench_under_torchrun_with_forced_allreduce():
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
