@@ -26,30 +26,34 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, de
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(size=96, threads=None):
-    """oracle generator + U-Net fwd/bwd/Adam for ONE volume of size^3 on the host cores; scaled by voxel count"""
+def physical_cores():
+    """sockets x cores per socket from lscpu (SURVEY 8d asks for the physical count, not the thread count)"""
+    import subprocess
+    try:
+        txt = subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(':')[0].strip(): l.split(':', 1)[1].strip() for l in txt.splitlines() if ':' in l}
+        return int(kv['Socket(s)']) * int(kv['Core(s) per socket'])
+    except Exception:
+        return os.cpu_count()
+
+
+def _oracle_step_factory(size, seed=0):
+    """one oracle training step (numpy generator + PyTorch-CPU U-Net fwd / bwd / Keras-Adam with live moments) on a
+    size^3 volume of the benchmark configuration; returns a callable -> seconds"""
     import torch
     from oracle import generator_ref as R
     from oracle import unet_ref as U
     from synthsr_amd.synthetic import (synthetic_label_map, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
                                        PRIOR_STDS_T1_HR)
-    if threads:
-        torch.set_num_threads(threads)
-    cores = torch.get_num_threads()
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     labels = synthetic_label_map((size,) * 3, 1)
-    means = np.clip(rng.normal(PRIOR_MEANS_T1_HR[0], PRIOR_MEANS_T1_HR[1]), 0, None)[GENERATION_CLASSES][:, None]
-    stds = np.clip(rng.normal(PRIOR_STDS_T1_HR[0], PRIOR_STDS_T1_HR[1]), 0, None)[GENERATION_CLASSES][:, None]
     small = R.get_resample_shape([size] * 3, .03125)
     u = lambda *s: rng.random(s, dtype=np.float32)
     n = lambda *s: rng.standard_normal(s, dtype=np.float32)
-    tape = [('u', u(3)), ('u', u(6)), ('u', u(3)), ('u', u(3)), ('u', u(1)), ('n', n(*small, 3)), ('u', u(1)),
-            ('n', n(size, size, size, 1)), ('u', u(1)), ('n', n(*small)), ('u', u(1)), ('n', n(1)), ('u', u(3))]
     # random-init U-Net with the benchmark architecture
     g = torch.Generator().manual_seed(0)
     P = {}
     feats = [24, 48, 96, 192, 384]
-    cin = 2
 
     def conv(name, ci, co):
         lim = float(np.sqrt(6.0 / (27 * ci + 27 * co)))
@@ -59,7 +63,7 @@ def cpu_baseline(size=96, threads=None):
     def bn(name, c):
         P[name + '/gamma'] = torch.ones(c, requires_grad=True)
         P[name + '/beta'] = torch.zeros(c, requires_grad=True)
-    c = cin
+    c = 2
     for l in range(5):
         for k in range(2):
             conv('unet_conv_downarm_%d_%d' % (l, k), c, feats[l])
@@ -75,25 +79,61 @@ def cpu_baseline(size=96, threads=None):
         bn('unet_bn_up_%d' % k, c)
     P['unet_likelihood/kernel'] = ((torch.rand(24, 1, generator=g) * 2 - 1) * .4).requires_grad_(True)
     P['unet_likelihood/bias'] = torch.zeros(1, requires_grad=True)
-    t0 = time.time()
-    out = R.labels_to_image(labels, means, stds, tape, GENERATION_LABELS, 19, input_channels=[True],
-                            output_channel=[0], output_shape=size, output_div_by_n=32, scaling_bounds=.15,
-                            rotation_bounds=15, shearing_bounds=.02, translation_bounds=5, nonlin_std=4.,
-                            nonlin_shape_factor=.03125, downsample=True, build_reliability_maps=True, blur_range=1.15,
-                            bias_field_std=.3, bias_shape_factor=.03125)
-    t_gen = time.time() - t0
-    t0 = time.time()
-    pred = U.unet_forward(torch.from_numpy(out['image']), P, 'unet', 5, 2, training=True)
-    loss = U.l1_loss(pred, torch.from_numpy(out['target']))
-    loss.backward()
-    for k, p in P.items():
-        U.adam_keras(p.detach(), p.grad, torch.zeros_like(p), torch.zeros_like(p), 1)
-    t_net = time.time() - t0
-    scale = (size / 160.0) ** 3
-    return {'value': round(scale / (t_gen + t_net), 5), 'unit': 'volumes/s', 'cores': cores, 'kind': 'port',
-            'sample': 'one %d^3 volume (%.1f%% of the voxels of a 160^3 volume) through the oracle: numpy generator '
-                      '%.1fs + PyTorch-CPU U-Net fwd/bwd/Adam %.1fs; volumes/s scaled by voxel count; CPU restatement '
-                      '(PyTorch), not TensorFlow' % (size, 100 * scale, t_gen, t_net)}
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    state = {'t': 0}
+
+    def step():
+        t0 = time.time()
+        means = np.clip(rng.normal(PRIOR_MEANS_T1_HR[0], PRIOR_MEANS_T1_HR[1]), 0, None)[GENERATION_CLASSES][:, None]
+        stds = np.clip(rng.normal(PRIOR_STDS_T1_HR[0], PRIOR_STDS_T1_HR[1]), 0, None)[GENERATION_CLASSES][:, None]
+        tape = [('u', u(3)), ('u', u(6)), ('u', u(3)), ('u', u(3)), ('u', u(1)), ('n', n(*small, 3)), ('u', u(1)),
+                ('n', n(size, size, size, 1)), ('u', u(1)), ('n', n(*small)), ('u', u(1)), ('n', n(1)), ('u', u(3))]
+        out = R.labels_to_image(labels, means, stds, tape, GENERATION_LABELS, 19, input_channels=[True],
+                                output_channel=[0], output_shape=size, output_div_by_n=32, scaling_bounds=.15,
+                                rotation_bounds=15, shearing_bounds=.02, translation_bounds=5, nonlin_std=4.,
+                                nonlin_shape_factor=.03125, downsample=True, build_reliability_maps=True, blur_range=1.15,
+                                bias_field_std=.3, bias_shape_factor=.03125)
+        t_gen = time.time() - t0
+        for p in P.values():
+            p.grad = None
+        pred = U.unet_forward(torch.from_numpy(out['image']), P, 'unet', 5, 2, training=True)
+        loss = U.l1_loss(pred, torch.from_numpy(out['target']))
+        loss.backward()
+        state['t'] += 1
+        with torch.no_grad():
+            for k, p in P.items():
+                pn, M[k], V[k] = U.adam_keras(p, p.grad, M[k], V[k], state['t'])
+                p.copy_(pn)
+        return time.time() - t0, t_gen
+    return step
+
+
+def cpu_baseline(size_all=160, size_one=64, timed=3):
+    """the oracle (CPU restatement of the identical graph: numpy generator + PyTorch-CPU fp32 U-Net fwd / bwd /
+    Adam; NOT TensorFlow) timed on the host cores: 1 warm-up + `timed` steps with all threads at size_all^3 and with ONE
+    thread at size_one^3 (scaled by voxel count to 160^3 volumes/s)."""
+    import torch
+    cores = physical_cores()
+    nthreads_default = torch.get_num_threads()
+    res = {}
+    for tag, size, threads in (('all', size_all, nthreads_default), ('one', size_one, 1)):
+        torch.set_num_threads(threads)
+        step = _oracle_step_factory(size)
+        step()                                                   # warm-up (oneDNN primitive creation, page faults)
+        ts = [step() for _ in range(timed)]
+        scale = (size / 160.0) ** 3
+        res[tag] = dict(volumes_per_s=round(scale / float(np.mean([t[0] for t in ts])), 5), threads=threads, size=size,
+                        step_s=[round(t[0], 2) for t in ts], generator_s=round(float(np.mean([t[1] for t in ts])), 2))
+    torch.set_num_threads(nthreads_default)
+    return {'value': res['all']['volumes_per_s'], 'unit': 'volumes/s', 'cores': cores, 'kind': 'port',
+            'threads': res['all']['threads'], 'value_one_thread': res['one']['volumes_per_s'],
+            'sample': 'oracle (numpy generator + PyTorch-CPU U-Net fwd/bwd/Keras-Adam; CPU restatement, NOT TensorFlow): '
+                      '1 warm-up + %d timed steps. all threads (%d on %d physical cores): %d^3 volumes, %s s per step '
+                      '(generator %.2f s of it). one thread: %d^3 volumes (%.1f%% of the voxels of 160^3, volumes/s scaled '
+                      'by voxel count), %s s per step'
+                      % (timed, res['all']['threads'], cores, size_all, res['all']['step_s'], res['all']['generator_s'],
+                         size_one, 100 * (size_one / 160.0) ** 3, res['one']['step_s'])}
 
 
 def conv_flops(kind, shape, cin, cout):
@@ -107,7 +147,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', type=int, default=160)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-size', type=int, default=96)
+    ap.add_argument('--cpu-size', type=int, default=160, help='volume size of the all-threads CPU baseline')
     ap.add_argument('--overlap', action='store_true', help='weight gradients on a second stream (A/B switch; slower)')
     ap.add_argument('--fold', default='auto', help="nearest-upsample folding of the decoder convs: auto | all | none")
     ap.add_argument('--force-allreduce', action='store_true',
@@ -184,10 +224,10 @@ def main():
 
     if rank == 0:
         # per-kernel aggregation of the conv launches recorded inside the timed region
-        agg = {}
+        agg, gen_agg = {}, {}
         for kind, shape, cin, cout, s, e in prof:
             key = (kind, shape, cin, cout)
-            agg.setdefault(key, []).append(s.elapsed_time(e))
+            (gen_agg if kind.startswith('gen') else agg).setdefault(key, []).append(s.elapsed_time(e))
         rows = []
         for (kind, shape, cin, cout), samples in agg.items():
             fl = conv_flops(kind, shape, cin, cout)
@@ -220,6 +260,24 @@ def main():
             pass
         vox = dom['shape'][0] * dom['shape'][1] * dom['shape'][2]
         roofline['algorithmic_bytes'] = 4 * vox * (dom['cin'] + dom['cout'])
+        # the generator against ITS roofline (HBM): compulsory bytes = labels int32 in, image (C_in(+maps)) and
+        # target out, each touched once = 16 B/voxel at configs[1]; per-kernel times from the same HIP events
+        nsteps_prof = min(3, args.steps)
+        gen_ms = [v for k, v in gen_agg.items() if k[0] == 'generator']
+        roofline_generator = None
+        if gen_ms:
+            ms = float(np.mean(gen_ms[0]))
+            key = [k for k in gen_agg if k[0] == 'generator'][0]
+            nvox = S ** 3
+            comp = nvox * 4 * (1 + key[2] + key[3])
+            roofline_generator = {'bound': 'hbm', 'achieved': round(comp / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                                  'unit': 'GB/s', 'frac': round(comp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  'compulsory_bytes': comp, 'two_pass_floor_bytes': comp + 8 * nvox,
+                                  'ms_per_volume': round(ms, 4),
+                                  'kernels_ms': {k[0][4:]: round(float(np.sum(v)) / nsteps_prof, 4)
+                                                 for k, v in gen_agg.items() if k[0].startswith('gen:')},
+                                  'note': 'region time includes the host-side launch gaps of ~10 small kernels; '
+                                          'traffic per kernel: profiles/pmc_traffic.json'}
         out = {'metric': 'training volumes/sec (160^3 fp32, 5-level U-Net)', 'value': round(world * args.steps / dt, 4),
                'unit': 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
@@ -227,7 +285,9 @@ def main():
                'config': {'workload': 'configs[1]: brain_generator %d^3 batch=1 (training() defaults) + 5-level 3-D U-Net '
                                       '(24..384 features, Cin=2) fwd/bwd + Adam, fp32, random-init' % S,
                           'global_batch': world, 'parallelism': 'dp%d' % world, 'volume': [S, S, S]},
-               'roofline': roofline, 'final_loss': round(final_loss, 6),
+               'roofline': roofline, 'roofline_generator': roofline_generator, 'final_loss': round(final_loss, 6),
+               'n_ranks_seen': dist.get_world_size() if dist.is_initialized() else 1,
+               'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if dist.is_initialized() else None,
                'top_kernels': [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]}
         if world == 1 and not args.no_cpu_baseline:
             try:

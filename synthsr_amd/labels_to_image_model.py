@@ -21,6 +21,7 @@ import ctypes
 import numpy as np
 
 from . import host_math as hm
+from . import ops as _ops
 from . import _lib
 
 
@@ -431,13 +432,17 @@ class LabelsToImageModel:
 
         # ---- device pipeline
         i3 = _lib.i3
+        tk = _ops.timed      # per-kernel HIP events while bench.py profiles (free otherwise)
         if self.apply_elastic:
-            _lib.check(lib.synthsr_resize_f32(sm.dptr(off_svf), _lib.ptr(self.d_svf), 3, i3(self.small_shape),
-                                              i3(self.half_shape), 0, st), 'resize(svf)')
-            _lib.check(lib.synthsr_svf_integrate(_lib.ptr(self.d_svf), _lib.ptr(self.d_svf_tmp), i3(self.half_shape), 7,
-                                                 st), 'svf_integrate')
+            with tk('gen:svf_resize+integrate'):
+                _lib.check(lib.synthsr_resize_f32(sm.dptr(off_svf), _lib.ptr(self.d_svf), 3, i3(self.small_shape),
+                                                  i3(self.half_shape), 0, st), 'resize(svf)')
+                _lib.check(lib.synthsr_svf_integrate(_lib.ptr(self.d_svf), _lib.ptr(self.d_svf_tmp), i3(self.half_shape),
+                                                     7, st), 'svf_integrate')
         _lib.check(lib.synthsr_minmax_init(_lib.ptr(self.d_minmax), C + 1, st), 'minmax_init')
         real_mm = ctypes.c_void_p(self.d_minmax.data_ptr() + 8 * C)
+        _t_dg = tk('gen:deform_gmm')
+        _t_dg.__enter__()
         _lib.check(lib.synthsr_deform_gmm_real(
             _lib.ptr(d_labels), _lib.ptr(self.d_svf) if self.apply_elastic else None, sm.dptr(off_lut),
             _lib.ptr(self.d_swap) if self.d_swap is not None else None,
@@ -446,6 +451,7 @@ class LabelsToImageModel:
             _lib.ptr(self.d_minmax), _lib.ptr(self.d_real_in) if self.use_real_image else None,
             _lib.ptr(self.d_real) if self.use_real_image else None, real_mm if self.use_real_image else None,
             ctypes.byref(p), st), 'deform_gmm')
+        _t_dg.__exit__()
 
         nc, no = self.ncrop, self.nout
         cs, os_ = i3(self.crop_shape), i3(self.output_shape)
@@ -462,7 +468,8 @@ class LabelsToImageModel:
             x = fptr(self.d_chan, i * nc)
             mm = ctypes.c_void_p(self.d_minmax.data_ptr() + 8 * i)
             t0, t1, t2 = (fptr(t) for t in self.d_tmp)
-            _lib.check(lib.synthsr_normalise_gamma(x, x, nc, mm, plan['gexp'], st), 'normalise_gamma')
+            with tk('gen:normalise_gamma'):
+                _lib.check(lib.synthsr_normalise_gamma(x, x, nc, mm, plan['gexp'], st), 'normalise_gamma')
             is_target = i in self.output_channel
             # GaussianBlur(sigma=.5): target tap (labels_to_image_model.py:186-196)
             if is_target and not self.resample_target and not self.input_channels[i]:
@@ -470,7 +477,8 @@ class LabelsToImageModel:
                            'blur(target)')
                 tgt_slot += 1
                 continue
-            _lib.check(lib.synthsr_blur3d(x, t0, cs, sm.dptr(off_k05), k3, 1, 0, -1, 0., st), 'blur(.5)')
+            with tk('gen:blur3d(.5)'):
+                _lib.check(lib.synthsr_blur3d(x, t0, cs, sm.dptr(off_k05), k3, 1, 0, -1, 0., st), 'blur(.5)')
             if is_target:
                 if self.resample_target:
                     ko, ks = plan['k_tgt']
@@ -478,7 +486,9 @@ class LabelsToImageModel:
                     _lib.check(lib.synthsr_resize_f32(t1, t2, 1, cs, os_, 0, st), 'resize(tgt)')
                     _lib.check(lib.synthsr_copy_strided(t2, fptr(self.d_target), no, 1, 0, Ct, tgt_slot, st), 'copy(tgt)')
                 else:
-                    _lib.check(lib.synthsr_copy_strided(t0, fptr(self.d_target), nc, 1, 0, Ct, tgt_slot, st), 'copy(tgt)')
+                    with tk('gen:copy(target)'):
+                        _lib.check(lib.synthsr_copy_strided(t0, fptr(self.d_target), nc, 1, 0, Ct, tgt_slot, st),
+                                   'copy(tgt)')
                 tgt_slot += 1
             if not self.input_channels[i]:
                 continue
@@ -496,8 +506,9 @@ class LabelsToImageModel:
                         _lib.check(lib.synthsr_blur3d(cur, oth, cs, sm.dptr(ko), i3(ks), 1, 0, -1, 0., st), 'blur(lr)')
                         cur, oth = oth, cur
                     ko, ks = plan['k_lr'][-1]
-                    _lib.check(lib.synthsr_blur3d(cur, fptr(self.d_image), cs, sm.dptr(ko), i3(ks), Ci, img_slot, fill,
-                                                  1.0, st), 'blur(lr)')
+                    with tk('gen:blur3d(lr)+map'):
+                        _lib.check(lib.synthsr_blur3d(cur, fptr(self.d_image), cs, sm.dptr(ko), i3(ks), Ci, img_slot, fill,
+                                                      1.0, st), 'blur(lr)')
                 else:
                     _lib.check(lib.synthsr_copy_strided(cur, fptr(self.d_image), nc, 1, 0, Ci, img_slot, st), 'copy')
                     if fill >= 0:

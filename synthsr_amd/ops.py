@@ -38,6 +38,12 @@ def profile_pause():
         _prof_paused, _prof = _prof, None
 
 
+def timed(kind, shape=(0, 0, 0), cin=0, cout=0):
+    """context manager: HIP events around a region on the launch stream, recorded while profile_start() is active
+    (bench.py: conv launches and the generator's kernels); free otherwise"""
+    return _Timed(kind, shape, cin, cout)
+
+
 class _Timed:
     def __init__(self, kind, shape, cin, cout):
         self.meta = (kind, tuple(int(s) for s in shape), int(cin), int(cout))

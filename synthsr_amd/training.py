@@ -39,6 +39,7 @@ class GradBucketReducer:
     def start(self):
         self.hi = self.g.numel()
         self.works = []
+        self.n_launched = 0  # collectives issued for this step (diagnostics / tests)
 
     def ready(self, offset_lo, force=False):
         """every gradient at flat offset >= offset_lo is final"""
@@ -49,6 +50,7 @@ class GradBucketReducer:
         if force or (self.hi - offset_lo) >= self.bucket:
             self.works.append(self.dist.all_reduce(self.g[offset_lo:self.hi], op=self.dist.ReduceOp.SUM,
                                                    group=self.group, async_op=True))
+            self.n_launched += 1
             self.hi = offset_lo
 
     def finish(self):
@@ -93,12 +95,14 @@ class Trainer:
             model_inputs = next(self.bg.model_inputs_generator)
         labels, means, stds = model_inputs[:3]
         real = np.asarray(model_inputs[3])[0, ..., 0] if getattr(gen, 'use_real_image', False) else None
-        if label_index is not None and self.resident_labels is not None and real is None:
-            image, target, seg = gen.generate(self.resident_labels[label_index], np.asarray(means)[0],
-                                              np.asarray(stds)[0], draws, labels_on_device=True)
-        else:
-            image, target, seg = gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0], np.asarray(stds)[0],
-                                              draws, real_image=real)
+        from . import ops
+        with ops.timed('generator', gen.output_shape, gen.n_image_channels, gen.n_target_channels):
+            if label_index is not None and self.resident_labels is not None and real is None:
+                image, target, seg = gen.generate(self.resident_labels[label_index], np.asarray(means)[0],
+                                                  np.asarray(stds)[0], draws, labels_on_device=True)
+            else:
+                image, target, seg = gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0],
+                                                  np.asarray(stds)[0], draws, real_image=real)
         residual, rs, ro = None, 1, 0
         if self.residual is not None:
             residual, rs, ro = image, image.shape[-1], [int(c) for c in self.residual]

@@ -1,0 +1,59 @@
+"""Worker of tests/test_ddp_gpu.py: one rank of a 2-rank data-parallel Trainer.step (both ranks share cuda:0 on the
+one-GPU test box; `gloo` carries the collectives so that two processes on one device can talk -- on a multi-GPU node
+the same code path runs over RCCL, cf. bench.py).  Saves, per rank, the single-rank gradient of ITS sample, then the
+all-reduced gradient sum and the weights after the distributed step."""
+import os
+import sys
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    out_dir = sys.argv[1]
+    import torch
+    import torch.distributed as dist
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.training import Trainer
+    from synthsr_amd.unet import unet
+    from synthsr_amd.synthetic import (synthetic_label_pool, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
+                                       PRIOR_STDS_T1_HR)
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo')
+    S = 32
+    pool = synthetic_label_pool(2, (S, S, S), 5)
+    bg = BrainGenerator(None, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', GENERATION_LABELS,
+                        generation_classes=GENERATION_CLASSES, output_shape=S, output_div_by_n=8, nonlin_std=4.,
+                        nonlin_shape_factor=.125, bias_shape_factor=.125, build_reliability_maps=True, downsample=True,
+                        shearing_bounds=.02, label_maps=pool, rng=np.random.Generator(np.random.Philox(key=100 + rank)))
+    bg.labels_to_image_model.seed(0, rank)                    # per-rank Philox stream of the in-kernel noise
+    net = unet(24, bg.model_output_shape, 3, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
+               batch_norm=-1, seed=1 + rank)                  # DIFFERENT initial weights: the broadcast must fix that
+    dist.broadcast(net.params, 0)
+    net.repack()
+    inputs = next(bg.model_inputs_generator)
+    draws = bg.labels_to_image_model.sample_draws()
+    # (1) the gradient this rank computes alone on its own sample
+    solo = Trainer(bg, net, lr=1e-3)
+    gen = bg.labels_to_image_model
+    image, target, _ = gen.generate(np.asarray(inputs[0])[0, ..., 0], np.asarray(inputs[1])[0], np.asarray(inputs[2])[0], draws)
+    net.loss(image, target.reshape(-1), 'l1')
+    net.backward()
+    g_solo = net.grads.detach().cpu().numpy().copy()
+    w0 = net.params.detach().cpu().numpy().copy()
+    # (2) the distributed step on the same sample (tiny buckets: several all-reduces interleaved with the backward)
+    tr = Trainer(bg, net, lr=1e-3, distributed=True, bucket_elems=50000)
+    assert tr.reducer.world == world
+    loss = tr.step(inputs, draws)
+    n_buckets = getattr(tr.reducer, 'n_launched', -1)
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), g_solo=g_solo, g_sum=net.grads.detach().cpu().numpy(), w0=w0,
+             w1=net.params.detach().cpu().numpy(), loss=float(loss.item()), n_buckets=n_buckets,
+             adam_m=net.adam_m.detach().cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

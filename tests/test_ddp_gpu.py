@@ -1,0 +1,37 @@
+"""Two-rank data-parallel training step: `Trainer.step` on 2 ranks yields the SUM of the two
+single-rank gradients in the flat buffer (the optimizer applies 1/world), identical gradients on both ranks, and
+bit-identical weights afterwards -- starting from deliberately different initial weights that the rank-0 broadcast
+must override.  The hook offsets that `unet._backward_body` hands to GradBucketReducer are exercised with several
+buckets in flight.  Both ranks run on cuda:0 (one-GPU box), collectives over gloo; the RCCL flavour of the same path is
+covered by test_training_gpu.py::test_bench_under_torchrun_with_forced_allreduce and bench.py --gpus N."""
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_trainer_step_averages_gradients_and_keeps_weights_identical(tmp_path):
+    port = 29700 + (os.getpid() % 200)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'tests', '_ddp_worker.py'), str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    a, b = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+    np.testing.assert_array_equal(a['w0'], b['w0'])                     # broadcast from rank 0
+    np.testing.assert_array_equal(a['g_sum'], b['g_sum'])               # same reduced gradients everywhere
+    np.testing.assert_array_equal(a['w1'], b['w1'])                     # ... hence bit-identical weights after Adam
+    np.testing.assert_array_equal(a['adam_m'], b['adam_m'])
+    assert not np.array_equal(a['w1'], a['w0'])
+    assert abs(a['loss'] - b['loss']) > 1e-6                            # the ranks really trained on different samples
+    # all-reduced buffer = sum of the two single-rank gradients (float atomics: the re-computed gradients differ in
+    # the last bits; 1e-5 of the buffer's range)
+    expect = a['g_solo'].astype(np.float64) + b['g_solo'].astype(np.float64)
+    scale = np.abs(expect).max()
+    assert np.abs(a['g_sum'] - expect).max() < 1e-5 * scale
+    # first moment of Adam after one step = (1 - beta1) * mean gradient
+    np.testing.assert_allclose(a['adam_m'], 0.1 * 0.5 * a['g_sum'], rtol=1e-5, atol=1e-7 * scale)
+    assert int(a['n_buckets']) >= 3
