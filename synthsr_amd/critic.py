@@ -229,12 +229,13 @@ class Critic3D:
         v9 = ops.dense_fwd(uflat, self.view(d0['w']), None, out=self.buf('v9', [d0['n_out']]))
         self.view(d1['w'], G).view(-1).add_(ops.leaky_relu_bwd(v9, h9, ALPHA, out=self.buf('m9v9', [d0['n_out']])))
 
-    def adam_step(self, lr=1e-4, decay=0.0, beta1=0.9, beta2=0.999, eps=1e-7):
-        """keras.optimizers.Adam (2.3.1) update of the critic, then re-packs the conv weights"""
+    def adam_step(self, lr=1e-4, decay=0.0, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """keras.optimizers.Adam (2.3.1) update of the critic, then re-packs the conv weights; grad_scale = 1 / world
+        size when self.grads holds the all-reduced sum of a data-parallel step"""
         if decay > 0:
             lr = lr * (1.0 / (1.0 + decay * self.iterations))
         self.iterations += 1
         t = self.iterations
         lr_t = lr * (np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
-        ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, lr_t, beta1, beta2, eps)
+        ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, lr_t, beta1, beta2, eps, grad_scale)
         self.repack()

@@ -31,11 +31,20 @@ def make_discriminator(input_shape, n_filters=32, n_levels=4, mask_input=False, 
 
 
 class AdversarialTrainer:
-    """generator (U-Net) + critic for one GPU: `critic_step()` / `generator_step()` each draw a new training sample"""
+    """generator (U-Net) + critic for one rank: `critic_step()` / `generator_step()` each draw a new training sample.
+    distributed=True (one process per GPU, batch 1 each): every rank draws its own sample; the critic's gradient buffer
+    (134.6 M parameters at 160^3 = 538 MB) is all-reduced in 64 MB buckets after its backward, the U-Net's
+    through the tail-first bucketed reducer hooked into its backward (training.GradBucketReducer); both optimizers apply
+    1 / world.  The gradient penalty is per sample (each rank's own x_hat), as in a Keras batch."""
 
     def __init__(self, brain_generator, net, critic, lr_generator=1e-4, lr_discriminator=1e-4, lr_decay=0.0,
                  relative_weight_discriminator=0.01, gradient_penalty_weight=10.0, work_with_residual_channel=None,
-                 loss_cropping=None, seg_regulariser=None, rng=None, mask_lut=None):
+                 loss_cropping=None, seg_regulariser=None, rng=None, mask_lut=None, distributed=False,
+                 force_allreduce=False):
+        from .training import GradBucketReducer
+        self.gen_reducer = GradBucketReducer(net.grads, force=force_allreduce) if distributed else None
+        self.critic_reducer = GradBucketReducer(critic.grads, bucket_elems=16 * 1024 * 1024,
+                                                force=force_allreduce) if distributed else None
         self.bg, self.gen, self.net, self.critic = brain_generator, brain_generator.labels_to_image_model, net, critic
         self.lr_g, self.lr_d, self.lr_decay = lr_generator, lr_discriminator, lr_decay
         self.w_d, self.gp = float(relative_weight_discriminator), float(gradient_penalty_weight)
@@ -75,7 +84,8 @@ class AdversarialTrainer:
         u = float(self.rng.uniform())                                      # RandomWeightedAverage, one weight per sample
         loss, _, _, _ = self.critic.critic_loss_and_grads(target.contiguous(), fake, u, self.gp,
                                                            mask=self._mask(seg, target))
-        self.critic.adam_step(self.lr_d, self.lr_decay)
+        scale = self.critic_reducer.reduce_all() if self.critic_reducer is not None else 1.0
+        self.critic.adam_step(self.lr_d, self.lr_decay, grad_scale=scale)
         return loss
 
     def generator_step(self):
@@ -96,8 +106,14 @@ class AdversarialTrainer:
             if list(seg.shape) != list(image.shape[:3]):
                 raise NotImplementedError('segmentation loss with a target resolution different from the label maps')
             loss += w_dice * float(self.seg(pred, seg, net.dpred, self.loss_cropping).item())
-        net.backward()
-        net.adam_step(self.lr_g, self.lr_decay)
+        if self.gen_reducer is not None:
+            self.gen_reducer.start()
+            net.backward(on_grad_ready=self.gen_reducer.ready)
+            scale = self.gen_reducer.finish()
+        else:
+            net.backward()
+            scale = 1.0
+        net.adam_step(self.lr_g, self.lr_decay, grad_scale=scale)
         net.update_moving_stats()
         return loss
 
@@ -140,17 +156,26 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
         raise NotImplementedError('batchsize 1 only')
     if n_output_channels != 1:
         raise NotImplementedError('the adversarial path is built for one output channel')
-    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-        raise NotImplementedError('the adversarial fine-tuning runs on one GPU in this build')
+    # data parallel like training(): one process per GPU (torchrun), batch 1 per rank, per-rank random streams
+    dist_on = 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1
+    rank, world = 0, 1
+    if dist_on:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            dist.init_process_group('nccl')
+        rank, world = dist.get_rank(), dist.get_world_size()
 
     generation_labels, n_neutral_labels = volumes.get_list_labels(label_list=path_generation_labels, labels_dir=labels_dir,
                                                                   FS_sort=FS_sort)
-    os.makedirs(os.path.join(model_dir, 'logs'), exist_ok=True)
+    if rank == 0:
+        os.makedirs(os.path.join(model_dir, 'logs'), exist_ok=True)
     if loss_cropping == 0:
         padding_margin, loss_cropping = None, None
     elif padding_margin is None:
         padding_margin = hm.get_padding_margin(output_shape, loss_cropping)
-    rng = np.random.Generator(np.random.Philox(key=int(seed) << 20))
+    rng = np.random.Generator(np.random.Philox(key=(int(seed) << 20) + rank))
     brain_generator = BrainGenerator(
         labels_dir=labels_dir, images_dir=images_dir, generation_labels=generation_labels,
         n_neutral_labels=n_neutral_labels, padding_margin=padding_margin, batchsize=batchsize,
@@ -162,7 +187,7 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
         simulate_registration_error=simulate_registration_error, randomise_res=randomise_res, data_res=data_res,
         thickness=thickness, downsample=downsample, blur_range=blur_range, build_reliability_maps=build_reliability_maps,
         bias_field_std=bias_field_std, bias_shape_factor=bias_shape_factor, rng=rng)
-    brain_generator.labels_to_image_model.seed(int(seed), 0)
+    brain_generator.labels_to_image_model.seed(int(seed), rank)
     unet_input_shape = brain_generator.model_output_shape
     generator = build_unet(nb_features=unet_feat_count, input_shape=unet_input_shape, nb_levels=n_levels,
                            conv_size=conv_size, nb_labels=n_output_channels, feat_mult=feat_multiplier,
@@ -190,9 +215,15 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
         im = volumes.load_volume(volumes.list_images_in_folder(images_dir)[0], im_only=True)   # :378-380
         seg_reg = SegmentationRegulariser(seg_net, brain_generator.generation_labels, equivalency,
                                           relative_weight_segmentation, m=np.percentile(im, 2), M=np.percentile(im, 98))
+    if dist_on:                       # identical replicas: rank 0's initial / loaded weights everywhere
+        dist.broadcast(generator.params, 0)
+        dist.broadcast(generator.bn_moving, 0)
+        dist.broadcast(critic.params, 0)
+        generator.repack()
+        critic.repack()
     trainer = AdversarialTrainer(brain_generator, generator, critic, lr_generator, lr_discriminator, lr_decay,
                                  relative_weight_discriminator, gradient_penalty_weight, work_with_residual_channel,
-                                 loss_cropping, seg_reg, rng=rng, mask_lut=mask_lut)
+                                 loss_cropping, seg_reg, rng=rng, mask_lut=mask_lut, distributed=dist_on)
     width = len(str(epochs))
     log_d, log_g = np.array([]), np.array([])
     for epoch in range(epochs):
@@ -203,8 +234,15 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
             for _ in range(ratio):
                 avg_d += trainer.critic_step() / (steps_per_epoch * ratio)
             avg_g += trainer.generator_step() / steps_per_epoch
+        if dist_on:                   # epoch averages over the ranks' samples (a Keras batch of `world` samples)
+            import torch
+            acc = torch.tensor([avg_d, avg_g], dtype=torch.float64, device=generator.device)
+            dist.all_reduce(acc)
+            avg_d, avg_g = float(acc[0].item()) / world, float(acc[1].item()) / world
         if not (np.isfinite(avg_d) and np.isfinite(avg_g)):
             raise FloatingPointError('Loss not finite')
+        if rank != 0:
+            continue
         if verbose:
             print('Epoch {0:0{1}d}/{2}   discriminator loss {3:.5f}   generator loss {4:.5f}   {5:.1f}s'.format(
                 epoch + 1, width, epochs, avg_d, avg_g, time.time() - t0))

@@ -35,3 +35,35 @@ def test_two_rank_trainer_step_averages_gradients_and_keeps_weights_identical(tm
     # first moment of Adam after one step = (1 - beta1) * mean gradient
     np.testing.assert_allclose(a['adam_m'], 0.1 * 0.5 * a['g_sum'], rtol=1e-5, atol=1e-7 * scale)
     assert int(a['n_buckets']) >= 3
+
+
+def test_two_rank_adversarial_fine_tuning(tmp_path):
+    """fine_tuning_with_adversary.training() data-parallel: both networks stay identical across the
+    ranks through critic and generator updates (separate reducers; the critic's flat gradient buffer goes out in buckets),
+    the ranks train on different samples, rank 0 alone writes logs and checkpoints"""
+    from synthsr_amd.nifti import write_nifti
+    from synthsr_amd.synthetic import GENERATION_LABELS, synthetic_label_map
+    shape = (40, 36, 48)
+    (tmp_path / 'labels').mkdir()
+    (tmp_path / 'images').mkdir()
+    rng = np.random.RandomState(0)
+    lut = rng.uniform(30, 220, 64)
+    for i in range(2):
+        lab = synthetic_label_map(shape, 10 + i)
+        write_nifti(str(tmp_path / 'labels' / ('brain%d_labels.nii.gz' % i)), lab.astype(np.float32))
+        write_nifti(str(tmp_path / 'images' / ('brain%d.nii.gz' % i)), (lut[lab % 64] + rng.randn(*lab.shape)).astype(np.float32))
+    np.save(tmp_path / 'gl.npy', GENERATION_LABELS)
+    port = 29400 + (os.getpid() % 200)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'tests', '_ddp_worker.py'), str(tmp_path),
+           'adversarial']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    a, b = np.load(tmp_path / 'adv_rank0.npz'), np.load(tmp_path / 'adv_rank1.npz')
+    np.testing.assert_array_equal(a['gen'], b['gen'])
+    np.testing.assert_array_equal(a['critic'], b['critic'])
+    assert int(a['gen_iter']) == 2 and int(a['critic_iter']) == 3         # 2 generator updates, 2 + 1 critic updates
+    assert not np.array_equal(a['bn'], b['bn'])                           # per-replica BatchNorm statistics: own samples
+    files = sorted(os.listdir(tmp_path / 'models'))
+    assert 'generator_1.h5' in files and 'discriminator_1.h5' in files
+    assert np.load(tmp_path / 'models' / 'logs' / 'generator_loss.npy').shape == (1,)
