@@ -205,6 +205,30 @@ int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* j
  * that change the launch geometry must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
 
+/* ---- bf16 variants (BASELINE.json configs[3] / [4]: bf16 activations and weights, fp32 accumulation, fp32 BatchNorm
+ * statistics; csrc/conv_bf16.hip).  Activation / gradient tensors are NDHWC bfloat16 (passed as void*), parameters,
+ * parameter gradients and statistics stay float32 (fp32 master weights live in the optimizer's flat buffer).  They
+ * replace the same Keras layers as the float32 entry points (ext/neuron/models.py:297-299,412-414; the reference has no
+ * reduced-precision path: parity is stated against the float32 oracle with a bf16 tolerance).
+ * pack: fp32 Keras kernel w [27][Cin_total][Cout] -> bf16 MFMA A-fragments of channels [ci_off, ci_off + Cin); mode 0
+ * forward, 1 data gradient; returns the number of bf16 values (packed == NULL: size query).  CinE % 8 == 0, CoutE % 4 == 0 */
+int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
+                                 synthsr_stream_t stream);
+/* out = act(conv3(in) + bias); act 0 linear, 1 ELU, 2 multiply by ELU'(below) (data gradient fused with the ELU backward
+ * of the layer below; below = that layer's ELU output [vox][Cout]).  stats != NULL: BatchNorm batch statistics
+ * [mean Cout | var Cout] of the (bf16-rounded) output, accumulated in fp32 / double through `scratch`
+ * (>= synthsr_conv3d_bf16_stats_scratch floats) */
+int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, void* out, const int shape[3], int Cin,
+                            int Cout, int act, const void* below, float* stats, float* scratch, int64_t scratch_floats,
+                            synthsr_stream_t stream);
+int64_t synthsr_conv3d_bf16_stats_scratch(const int shape[3], int Cin, int Cout);
+/* dw[27][Cin][Cout] (fp32) += sum_v in[v + t - 1][ci] * dout[v][co];  dbias[Cout] += sum_v dout[v]  (may be NULL);
+ * both zeroed by the caller.  Cin % 8 == 0, Cout % 8 == 0 */
+int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float* dbias, const int shape[3],
+                              int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream);
+/* float32 [n][Cs] -> bfloat16 [n][Cd], Cd >= Cs, zero fill (the generator's image -> first-layer input, Cin 2 -> 8) */
+int synthsr_f32_to_bf16_pad(const float* src, void* dst, int64_t n, int Cs, int Cd, synthsr_stream_t stream);
+
 /* weight gradient: dw[3][3][3][Cin][Cout] += sum_v in[v+t-1][ci] * dout[v][co]   (dw must be zeroed by caller) */
 int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout,
                          synthsr_stream_t stream);

@@ -61,6 +61,11 @@ SIGNATURES = {
     'synthsr_conv3d_wgrad_bias': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad_ex': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_conv3d_bf16_pack': (c_int64, [_P, _P, c_int, c_int, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_bf16_fwd': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _P, _P, _P, c_int64, _S]),
+    'synthsr_conv3d_bf16_stats_scratch': (c_int64, [POINTER(c_int), c_int, c_int]),
+    'synthsr_conv3d_bf16_wgrad': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
+    'synthsr_f32_to_bf16_pad': (c_int, [_P, _P, c_int64, c_int, c_int, _S]),
     'synthsr_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),
     'synthsr_bn_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
     'synthsr_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P, _S]),

@@ -17,6 +17,7 @@ SOURCES = [('generator.hip', ['-ffp-contract=off']),
            ('unet_pointwise.hip', []),
            ('ssim.hip', []),
            ('critic.hip', []),
+           ('conv_bf16.hip', []),
            ('conv3d.hip', [])]
 
 

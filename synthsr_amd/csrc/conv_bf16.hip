@@ -1,0 +1,699 @@
+// 3x3x3 'same' Conv3D on NDHWC **bf16** activations / weights with fp32 accumulation (gfx950,
+// v_mfma_f32_16x16x32_bf16: A[16 x 32], B[32 x 16], D[16 x 16] fp32 in 4 accumulator registers, 16x the fp32 MFMA
+// rate).  BASELINE.json configs[3] / [4] ("bf16 with fp32 norm accum", "mixed bf16"); the reference itself is fp32
+// Keras (SynthSR/training.py:330-341), parity is against the fp32 oracle with a stated bf16 tolerance.
+//
+//   forward / data-gradient:  D[co][voxel] += A[co][(tap, ci)] * B[(tap, ci)][voxel]
+//       M = output channels (weights are the A operand, pre-packed in fragment order), N = 16 voxels of an x-row, so a
+//       lane ends up with 4 consecutive output channels of ONE voxel -> one 8-byte bf16x4 store (fp32 -> bf16 RNE).
+//       K runs over (tap, 8-channel group) pairs of a CK-channel chunk, 4 pairs = 32 K-values per MFMA; the B operand
+//       of a lane is the 16 contiguous bytes of that pair in the [voxel][CK + pad] LDS halo tile (one ds_read_b128;
+//       row stride 80 B = 5 x 16 B -> the 16 lanes of an x-row hit 16 different bank quads).
+//       Workgroup = 4 waves = 4x4x16 output voxels, wave w owns the z = w plane (4 x-rows); persistent workgroups walk
+//       the tiles XCD-contiguously, the next halo is in flight (registers) while the current one is multiplied.
+//       Epilogue: + bias, ELU | multiply by ELU'(below) (data gradient fused with the ELU backward of the layer below),
+//       optional per-workgroup BatchNorm partial sums (fp32, from the un-rounded accumulators).
+//   weight gradient:          D[(tap, ci)][co] += A[(tap, ci)][voxel] * B[voxel][co]
+//       both operands are K(voxel)-major per lane but channel-major in memory: they are read from the natural
+//       [voxel][channel] LDS images with the gfx950 transpose read ds_read_b64_tr_b16 (lane i of a 16-lane group
+//       supplies the address of 8-byte chunk C_i, lane l receives C_{4j + l/4}[l % 4], j = 0..3; probed on hardware,
+//       tools/ubench/tr_probe.hip).  A rows are (tap, channel-quad) blocks, 4 blocks per 16-row tile, so the 27 x CK/4
+//       blocks (+ one constant-1 block = dbias) fill the tiles to 99 %; the 4 waves split the row tiles and walk all 256
+//       voxels of the tile, 32 per MFMA; fp32 atomics flush once per workgroup.
+#include "common.h"
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t bf16_t;
+
+constexpr int TZ = 4, TY = 4, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HVOX = HZ * HY * HX;
+constexpr uint32_t OOB = 0x80000000u;
+
+__host__ __device__ constexpr int rowb_for(int ck) { return ck == 8 ? 48 : 80; }  // LDS row stride: odd multiple of 16 B
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ float elu_f(float v) {
+  const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f;
+  const float p = v * fmaf(v, fmaf(v, fmaf(v, fmaf(v, 1.f / 120.f, 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
+  const float n = v > -0.125f ? p : e;
+  return v > 0.f ? v : n;
+}
+__device__ __forceinline__ float elu_dy(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+__device__ __forceinline__ uint32_t f2bf(float f) {  // round to nearest even (finite inputs)
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// forward layout (A fragments): [co-chunk][cc][step][mt][lane 64][8] bf16; lane = (m = lane & 15, g = lane >> 4):
+//   pair p = 4 step + g -> tap = p / C8, c8 = p % C8;  value j: W_eff[tap][cc*CK + c8*8 + j][(chunk*MT + mt)*16 + m]
+// mode 0: W_eff = w[tap][ci_off + cie][coe]; mode 1 (data gradient): W_eff[tap][cie][coe] = w[26 - tap][ci_off + coe][cie]
+__global__ void pack_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ packed, int Cin_total, int ci_off,
+                                 int Cin, int Cout, int mode, int CK, int ncc, int MT, int nsteps, int64_t total) {
+  const int C8 = CK / 8;
+  const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r = (uint32_t)idx;
+    const int j = r & 7;
+    r >>= 3;
+    const int lane = r & 63;
+    r >>= 6;
+    const int mt = r % MT;
+    r /= MT;
+    const int step = r % nsteps;
+    r /= nsteps;
+    const int cc = r % ncc;
+    const int chunk = r / ncc;
+    const int m = lane & 15, g = lane >> 4;
+    const int p = 4 * step + g;
+    const int tap = p / C8, c8 = p - tap * C8;
+    const int cie = cc * CK + c8 * 8 + j, coe = (chunk * MT + mt) * 16 + m;
+    float v = 0.f;
+    if (tap < 27 && cie < CinE && coe < CoutE) {
+      const int slot = mode ? 26 - tap : tap;
+      const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;
+      v = w[((int64_t)slot * Cin_total + ci) * Cout + co];
+    }
+    packed[idx] = (bf16_t)f2bf(v);
+  }
+}
+
+struct Bf16Plan {
+  int ck, ncc, mt, nchunks, nsteps;
+  int64_t count() const { return (int64_t)nchunks * ncc * nsteps * mt * 64 * 8; }
+};
+
+inline Bf16Plan plan_bf16(int CinE, int CoutE) {
+  Bf16Plan p;
+  p.ck = (CinE % 32 == 0) ? 32 : ((CinE % 24 == 0) ? 24 : 8);
+  p.ncc = (CinE + p.ck - 1) / p.ck;
+  const int mt_all = (CoutE + 15) / 16;
+  p.nchunks = (mt_all + 3) / 4;
+  p.mt = (mt_all + p.nchunks - 1) / p.nchunks;
+  p.nsteps = (27 * (p.ck / 8) + 3) / 4;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+struct FwdArgs {
+  const bf16_t* in;
+  const bf16_t* wp;
+  const float* bias;
+  bf16_t* out;
+  const bf16_t* below;   // act == 2: ELU output of the layer below, [vox][CoutE]
+  float* stats_partial;  // [gridDim.x * gridDim.y][2][16 * MT] per-workgroup sums / sums of squares, or null
+  int D0, D1, D2, Cin, Cout, ncc, tiles1, tiles2, ntiles, act;
+};
+
+template <int CK, int MT>
+__global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int C8 = CK / 8, ROWB = rowb_for(CK), NSTEP = (27 * C8 + 3) / 4;
+  constexpr int NPIECE = HVOX * C8, NLD = (NPIECE + 255) / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int chunk = blockIdx.y;
+  const int G = gridDim.x;
+  const int my_pos = (G % 8 == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout;
+
+  // per-lane LDS byte offset of the (tap, c8) pair of every K-step (relative to the voxel's halo row)
+  int koff[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int p = 4 * s + g;
+    const int tap = p / C8, c8 = p - tap * C8;
+    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+    koff[s] = (tap < 27) ? ((tz * HY + ty) * HX + tx) * ROWB + c8 * 16 : 0;  // beyond 27 taps: weights are zero
+  }
+  const int lbase = (wave * HY * HX + m) * ROWB;  // voxel (z = wave, y = 0, x = m) of the tile, tap (0, 0, 0)
+
+  // staging pieces of this thread: piece j -> halo voxel j / C8, 16-byte group j % C8
+  int prel[NLD], plds[NLD];
+  uint32_t pmask[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int j = tid + 256 * i;
+    const int v = j / C8, c8 = j - v * C8;
+    const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
+    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 2 + c8 * 16;
+    plds[i] = v * ROWB + c8 * 16;
+    pmask[i] = j < NPIECE ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;  // hx <= 17 -> bit 29
+  }
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 2), 0x00020000);
+  u32x4 stg[NLD];
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
+    const int t2 = t % a.tiles2, t1 = (t / a.tiles2) % a.tiles1, t0 = t / (a.tiles2 * a.tiles1);
+    z0 = t0 * TZ;
+    y0 = t1 * TY;
+    x0 = t2 * TX;
+  };
+  auto load_halo = [&](int t, int cc) {
+    int z0, y0, x0;
+    tile_origin(t, z0, y0, x0);
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * CK) * 2;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const uint32_t vo = (pmask[i] & bad) ? OOB : (uint32_t)(prel[i] + base);
+      stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0);
+    }
+  };
+
+  const bf16x8* __restrict__ wfrag = reinterpret_cast<const bf16x8*>(a.wp) + (int64_t)chunk * a.ncc * NSTEP * MT * 64 + lane;
+  float s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s1[mt][i] = s2[mt][i] = 0.f;
+
+  if (my_pos < a.ntiles) load_halo(my_pos, 0);
+  for (int t = my_pos; t < a.ntiles; t += G) {
+    f32x4 acc[TY][MT];
+#pragma unroll
+    for (int y = 0; y < TY; ++y)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < a.ncc; ++cc) {
+      __syncthreads();  // everyone is done reading the previous image
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        if (i < NLD - 1 || tid + 256 * i < NPIECE) *reinterpret_cast<u32x4*>(lds + plds[i]) = stg[i];
+      __syncthreads();
+      if (cc + 1 < a.ncc) {
+        load_halo(t, cc + 1);
+      } else if (t + G < a.ntiles) {
+        load_halo(t + G, 0);
+      }
+      const bf16x8* wf = wfrag + (int64_t)cc * NSTEP * MT * 64;
+      bf16x8 wa[2][MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) wa[0][mt] = wf[mt * 64];
+      sfor<0, NSTEP>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        if constexpr (s + 1 < NSTEP) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) wa[(s + 1) & 1][mt] = wf[((s + 1) * MT + mt) * 64];
+        }
+        bf16x8 xb[TY];
+#pragma unroll
+        for (int y = 0; y < TY; ++y)
+          xb[y] = *reinterpret_cast<const bf16x8*>(lds + lbase + koff[s] + y * (HX * ROWB));
+#pragma unroll
+        for (int y = 0; y < TY; ++y)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s & 1][mt], xb[y], acc[y][mt], 0, 0, 0);
+      });
+    }
+    // ---- epilogue: lane (m = x, g): channels (chunk*MT + mt)*16 + 4g + i of voxel (z0 + wave, y0 + y, x0 + m)
+    int z0, y0, x0;
+    tile_origin(t, z0, y0, x0);
+    const int gz = z0 + wave, gx = x0 + m;
+#pragma unroll
+    for (int y = 0; y < TY; ++y) {
+      const int gy = y0 + y;
+      const bool vok = gz < D0 && gy < D1 && gx < D2;
+      const int64_t vox = ((int64_t)gz * D1 + gy) * D2 + gx;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co = (chunk * MT + mt) * 16 + 4 * g;
+        if (!vok || co >= Cout) continue;  // Cout is a multiple of 4
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[y][mt][i] + (a.bias ? a.bias[co + i] : 0.f);
+        if (a.act == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
+        } else if (a.act == 2) {
+          const u32x2 b = *reinterpret_cast<const u32x2*>(a.below + vox * Cout + co);
+          v[0] *= elu_dy(bf2f(b.x & 0xffffu));
+          v[1] *= elu_dy(bf2f(b.x >> 16));
+          v[2] *= elu_dy(bf2f(b.y & 0xffffu));
+          v[3] *= elu_dy(bf2f(b.y >> 16));
+        }
+        u32x2 o;
+        o.x = pack2(v[0], v[1]);
+        o.y = pack2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(a.out + vox * Cout + co) = o;
+        if (a.stats_partial) {  // statistics of what the next layer will read (the bf16-rounded values)
+          const float r0 = bf2f(o.x & 0xffffu), r1 = bf2f(o.x >> 16), r2 = bf2f(o.y & 0xffffu), r3 = bf2f(o.y >> 16);
+          s1[mt][0] += r0; s1[mt][1] += r1; s1[mt][2] += r2; s1[mt][3] += r3;
+          s2[mt][0] += r0 * r0; s2[mt][1] += r1 * r1; s2[mt][2] += r2 * r2; s2[mt][3] += r3 * r3;
+        }
+      }
+    }
+  }
+  if (a.stats_partial) {
+    // reduce over the 16 voxel lanes of each g, then over the 4 waves through LDS
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);  // [wave][2][MT*16]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x1 = s1[mt][i], x2 = s2[mt][i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          x1 += __shfl_xor(x1, o, 64);
+          x2 += __shfl_xor(x2, o, 64);
+        }
+        if (m == 0) {
+          red[(wave * 2 + 0) * (MT * 16) + mt * 16 + 4 * g + i] = x1;
+          red[(wave * 2 + 1) * (MT * 16) + mt * 16 + 4 * g + i] = x2;
+        }
+      }
+    __syncthreads();
+    float* dst = a.stats_partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * MT * 16);
+    for (int e = tid; e < 2 * MT * 16; e += 256)
+      dst[e] = red[e] + red[2 * MT * 16 + e] + red[4 * MT * 16 + e] + red[6 * MT * 16 + e];
+  }
+}
+
+template <int CK, int MT>
+int launch_fwd(const FwdArgs& a0, int nchunks, hipStream_t st, int* wgs_out) {
+  FwdArgs a = a0;
+  int gx = 512;
+  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  if (a.ntiles < 8) gx = a.ntiles;
+  const size_t smem = (size_t)HVOX * rowb_for(CK);
+  auto kern = conv3d_bf16_fwd_kernel<CK, MT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  if (wgs_out) *wgs_out = gx * nchunks;
+  hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(256), smem, st, a);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+// per-workgroup partials [nwg][2][W] (W = 16*MT columns per co-chunk) -> stats[mean C | var C] (double accumulation)
+__global__ void bf16_stats_finalize_kernel(const float* __restrict__ partial, int gx, int nchunks, int W, int C,
+                                           float* __restrict__ stats, double inv_n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int chunk = c / W, col = c - chunk * W;
+  double s1 = 0.0, s2 = 0.0;
+  for (int w = 0; w < gx; ++w) {
+    const float* p = partial + ((int64_t)chunk * gx + w) * (2 * W);
+    s1 += (double)p[col];
+    s2 += (double)p[W + col];
+  }
+  const double mean = s1 * inv_n;
+  double var = s2 * inv_n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[c] = (float)mean;
+  stats[C + c] = (float)var;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// one transpose read with a compile-time offset: address VGPRs stay loop-invariant, the K-step / row part is the immediate
+template <int OFF>
+__device__ __forceinline__ u32x2 tr_read(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+// the compiler does not count inline-asm LDS reads in its own s_waitcnt bookkeeping: wait explicitly, then make every
+// consumer depend on a (no-op) volatile asm that is ordered after the wait
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void touch(u32x2& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ bf16x8 join8(u32x2 lo, u32x2 hi) {
+  u32x4 r = {lo.x, lo.y, hi.x, hi.y};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+struct WgArgs {
+  const bf16_t* in;    // x [vox][Cin]
+  const bf16_t* dout;  // dz [vox][Cout]
+  float* dw;           // [27][cin_total][Cout] fp32, accumulated with atomics
+  float* dbias;        // [Cout] or null
+  int D0, D1, D2, Cin, Cout, cin_total, ci_off, ncc, nco, tiles1, tiles2, ntiles;
+};
+
+// NT: 16-column tiles of output channels per workgroup pass (<= 3)
+template <int CK, int NT>
+__global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kernel(const WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int C8 = CK / 8, C4 = CK / 4, ROWB = rowb_for(CK);
+  constexpr int NBLK = 27 * C4 + 1;                 // (tap, quad) blocks + the constant-1 block (dbias)
+  constexpr int NMT = (NBLK + 3) / 4;               // 16-row tiles
+  constexpr int NW = 8, NTHR = 64 * NW;              // 8 waves: the row tiles' accumulators fit 128 VGPRs per wave
+  constexpr int MPW = (NMT + NW - 1) / NW;          // row tiles per wave
+  constexpr int DROWB = NT * 32 + 16;               // dz tile row stride (odd multiple of 16 B)
+  constexpr int XBYTES = HVOX * ROWB;
+  constexpr int NPIECE = HVOX * C8, NLD = (NPIECE + NTHR - 1) / NTHR;
+  constexpr int NDP = TZ * TY * TX * NT * 2, NDL = (NDP + NTHR - 1) / NTHR;  // 16-byte pieces of the dz tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15, lrow = li >> 2, lq = li & 3;
+  const int cc = blockIdx.y % a.ncc, oc = blockIdx.y / a.ncc;
+  const int G = gridDim.x;
+  const int my_pos = (G % 8 == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout;
+  unsigned char* ldz = lds + XBYTES;
+
+  // A addresses: lane i = (row lrow -> voxel 8g + lrow [+4], chunk lq -> block 4*mtile + lq)
+  int aoff[MPW];
+#pragma unroll
+  for (int q = 0; q < MPW; ++q) {
+    const int blk = (wave * MPW + q) * 4 + lq;
+    int off;
+    if (blk < 27 * C4) {
+      const int tap = blk / C4, quad = blk - tap * C4;
+      off = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * ROWB + quad * 8;
+    } else if (blk == 27 * C4) {
+      off = ((HY + 1) * HX + 1) * ROWB + CK * 2;      // centre tap, pad channels CK..CK+3 = (1, 0, 0, 0)
+    } else {
+      off = ((HY + 1) * HX + 1) * ROWB + CK * 2 + 8;  // unused slots: pad channels CK+4..CK+7 = 0
+    }
+    aoff[q] = off;
+  }
+  // voxel (8g + lrow) of a 32-voxel K-step: x = (8g + lrow) % 16, row (8g + lrow) / 16 of the step's row pair
+  const int vx = (8 * g + lrow) & 15, vr = (8 * g + lrow) >> 4;
+  const uint32_t ldsb = (uint32_t)(uintptr_t)lds;
+  const uint32_t abase = ldsb + (uint32_t)((vr * HX + vx) * ROWB);            // + aoff[q]; K-step rows / x + 4 as immediates
+  const uint32_t bbase = ldsb + (uint32_t)XBYTES + (uint32_t)((vr * TX + vx) * DROWB + lq * 8);
+
+  // pad channels of every halo row (never overwritten by the staging)
+  for (int v = tid; v < HVOX; v += NTHR) {
+    u32x4 one = {0x00003f80u, 0u, 0u, 0u};  // bf16 1.0 in channel CK
+    *reinterpret_cast<u32x4*>(lds + v * ROWB + CK * 2) = one;
+  }
+
+  int prel[NLD], plds[NLD];
+  uint32_t pmask[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int j = tid + NTHR * i;
+    const int v = j / C8, c8 = j - v * C8;
+    const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
+    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 2 + c8 * 16;
+    plds[i] = v * ROWB + c8 * 16;
+    pmask[i] = j < NPIECE ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;  // hx <= 17 -> bit 29
+  }
+  // dz pieces: piece j -> tile voxel j / (2 NT), 16-byte group j % (2 NT) (8 channels)
+  int drel[NDL], dlds[NDL], dvz[NDL], dvy[NDL], dvx[NDL];
+  bool dcok[NDL];
+#pragma unroll
+  for (int i = 0; i < NDL; ++i) {
+    const int j = tid + NTHR * i;
+    const int v = j / (2 * NT), c8 = j - v * (2 * NT);
+    dvz[i] = v / (TY * TX);
+    dvy[i] = (v / TX) % TY;
+    dvx[i] = v % TX;
+    const int co = oc * NT * 16 + c8 * 8;
+    dcok[i] = j < NDP && co < Cout;                     // Cout is a multiple of 8
+    drel[i] = ((dvz[i] * D1 + dvy[i]) * D2 + dvx[i]) * Cout * 2 + co * 2;
+    dlds[i] = v * DROWB + c8 * 16;
+  }
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(a.dout), 0, (int)((int64_t)D0 * D1 * D2 * Cout * 2), 0x00020000);
+  u32x4 stg[NLD], dst[NDL];
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
+    const int t2 = t % a.tiles2, t1 = (t / a.tiles2) % a.tiles1, t0 = t / (a.tiles2 * a.tiles1);
+    z0 = t0 * TZ;
+    y0 = t1 * TY;
+    x0 = t2 * TX;
+  };
+  auto load_tile = [&](int t) {
+    int z0, y0, x0;
+    tile_origin(t, z0, y0, x0);
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * CK) * 2;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const uint32_t vo = (pmask[i] & bad) ? OOB : (uint32_t)(prel[i] + base);
+      stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0);
+    }
+    const int dbase = ((z0 * D1 + y0) * D2 + x0) * Cout * 2;
+#pragma unroll
+    for (int i = 0; i < NDL; ++i) {
+      const bool ok = dcok[i] && z0 + dvz[i] < D0 && y0 + dvy[i] < D1 && x0 + dvx[i] < D2;
+      dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, ok ? drel[i] + dbase : (int)OOB, 0, 0);
+    }
+  };
+
+  f32x4 acc[MPW][NT];
+#pragma unroll
+  for (int q = 0; q < MPW; ++q)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (my_pos < a.ntiles) load_tile(my_pos);
+  for (int t = my_pos; t < a.ntiles; t += G) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (i < NLD - 1 || tid + NTHR * i < NPIECE) *reinterpret_cast<u32x4*>(lds + plds[i]) = stg[i];
+#pragma unroll
+    for (int i = 0; i < NDL; ++i)
+      if (i < NDL - 1 || tid + NTHR * i < NDP) *reinterpret_cast<u32x4*>(ldz + dlds[i]) = dst[i];
+    __syncthreads();
+    if (t + G < a.ntiles) load_tile(t + G);
+    // 8 K-steps of 32 voxels = 2 x-rows each: rows (z, y) = (ks >> 1, 2 (ks & 1) + vr)
+    sfor<0, 8>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      constexpr int z = ks >> 1, yb = 2 * (ks & 1);
+      constexpr int arow = ((z * HY + yb) * HX) * ROWB;     // halo row of voxel (z, yb, 0) with tap (0, 0, 0)
+      constexpr int brow = ((z * TY + yb) * TX) * DROWB;
+      // all transpose reads of the K-step first (B: 2 per column tile, A: 2 per row tile), one wait, then the MFMAs
+      u32x2 br[NT][2], ar[MPW][2];
+      sfor<0, NT>([&](auto N) {
+        constexpr int n = decltype(N)::value;
+        br[n][0] = tr_read<brow + n * 32>(bbase);
+        br[n][1] = tr_read<brow + n * 32 + 4 * DROWB>(bbase);
+      });
+      sfor<0, MPW>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        ar[q][0] = tr_read<arow>(abase + aoff[q]);
+        ar[q][1] = tr_read<arow + 4 * ROWB>(abase + aoff[q]);
+      });
+      lds_wait();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        touch(br[n][0]);
+        touch(br[n][1]);
+      }
+#pragma unroll
+      for (int q = 0; q < MPW; ++q) {
+        touch(ar[q][0]);
+        touch(ar[q][1]);
+      }
+#pragma unroll
+      for (int q = 0; q < MPW; ++q) {
+        if (wave * MPW + q >= NMT) continue;  // wave-uniform
+        const bf16x8 afr = join8(ar[q][0], ar[q][1]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, join8(br[n][0], br[n][1]), acc[q][n], 0, 0, 0);
+      }
+    });
+  }
+  // ---- flush: lane (n = li -> co, rows 4g + i -> block 4*mtile + g, element i)
+#pragma unroll
+  for (int q = 0; q < MPW; ++q) {
+    const int mtile = wave * MPW + q;
+    if (mtile >= NMT) continue;
+    const int blk = mtile * 4 + g;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = (oc * NT + n) * 16 + li;
+      if (co >= Cout) continue;
+      if (blk < 27 * C4) {
+        const int tap = blk / C4, quad = blk - tap * C4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ci = cc * CK + quad * 4 + i;
+          if (ci < Cin) atomicAdd(a.dw + ((int64_t)tap * a.cin_total + a.ci_off + ci) * Cout + co, acc[q][n][i]);
+        }
+      } else if (blk == 27 * C4 && a.dbias && cc == 0) {
+        atomicAdd(a.dbias + co, acc[q][n][0]);
+      }
+    }
+  }
+}
+
+template <int CK, int NT>
+int launch_wgrad(const WgArgs& a0, hipStream_t st) {
+  WgArgs a = a0;
+  int gx = 512 / (a.ncc * a.nco);
+  gx = (gx / 8) * 8;
+  if (gx < 8) gx = 8;
+  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  if (a.ntiles < 8) gx = a.ntiles;
+  const size_t smem = (size_t)HVOX * rowb_for(CK) + (size_t)TZ * TY * TX * (NT * 32 + 16);
+  auto kern = conv3d_bf16_wgrad_kernel<CK, NT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, a.ncc * a.nco), dim3(512), smem, st, a);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+// fp32 [n][Cs] -> bf16 [n][Cd] (Cd >= Cs, zero fill): the generator's image -> first-layer input (Cin 2 -> 8)
+__global__ void f32_to_bf16_pad_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n, int Cs, int Cd) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * Cd; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / Cd;
+    const int c = (int)(i - v * Cd);
+    dst[i] = (bf16_t)(c < Cs ? f2bf(src[v * Cs + c]) : 0u);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
+                                 synthsr_stream_t stream) {
+  if (Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1)) return SYNTHSR_EINVAL;
+  const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
+  if (CinE % 8 != 0 || CoutE % 4 != 0) return SYNTHSR_EINVAL;
+  const Bf16Plan pl = plan_bf16(CinE, CoutE);
+  const int64_t total = pl.count();
+  if (total >= (1ll << 31)) return SYNTHSR_EINVAL;
+  if (!packed) return total;
+  if (!w) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3(syn_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed,
+                     Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.mt, pl.nsteps, total);
+  return hipGetLastError() == hipSuccess ? total : (int64_t)SYNTHSR_ELAUNCH;
+}
+
+int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, void* out, const int shape[3], int Cin,
+                            int Cout, int act, const void* below, float* stats, float* scratch, int64_t scratch_floats,
+                            synthsr_stream_t stream) {
+  if (!in || !wp || !out || !shape || Cin % 8 != 0 || Cout % 4 != 0 || act < 0 || act > 2 || (act == 2 && !below))
+    return SYNTHSR_EINVAL;
+  const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
+  if (vox * Cin * 2 >= (1ll << 31) || vox * Cout * 2 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  const Bf16Plan pl = plan_bf16(Cin, Cout);
+  FwdArgs a;
+  a.in = (const bf16_t*)in;
+  a.wp = (const bf16_t*)wp;
+  a.bias = bias;
+  a.out = (bf16_t*)out;
+  a.below = (const bf16_t*)below;
+  a.D0 = shape[0];
+  a.D1 = shape[1];
+  a.D2 = shape[2];
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.ncc = pl.ncc;
+  a.tiles1 = (shape[1] + TY - 1) / TY;
+  a.tiles2 = (shape[2] + TX - 1) / TX;
+  a.ntiles = ((shape[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
+  a.act = act;
+  a.stats_partial = nullptr;
+  int gx = 512;
+  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  if (a.ntiles < 8) gx = a.ntiles;
+  const int W = 16 * pl.mt;
+  if (stats) {
+    if (!scratch || scratch_floats < (int64_t)gx * pl.nchunks * 2 * W) return SYNTHSR_EINVAL;
+    a.stats_partial = scratch;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = SYNTHSR_EINVAL, wgs = 0;
+#define SYN_FWD(CKV, MTV) rc = launch_fwd<CKV, MTV>(a, pl.nchunks, st, &wgs)
+  if (pl.ck == 8) {
+    if (pl.mt == 1) SYN_FWD(8, 1); else if (pl.mt == 2) SYN_FWD(8, 2); else if (pl.mt == 3) SYN_FWD(8, 3); else SYN_FWD(8, 4);
+  } else if (pl.ck == 24) {
+    if (pl.mt == 1) SYN_FWD(24, 1); else if (pl.mt == 2) SYN_FWD(24, 2); else if (pl.mt == 3) SYN_FWD(24, 3); else SYN_FWD(24, 4);
+  } else {
+    if (pl.mt == 1) SYN_FWD(32, 1); else if (pl.mt == 2) SYN_FWD(32, 2); else if (pl.mt == 3) SYN_FWD(32, 3); else SYN_FWD(32, 4);
+  }
+#undef SYN_FWD
+  if (rc != SYNTHSR_OK) return rc;
+  if (stats) {
+    hipLaunchKernelGGL(bf16_stats_finalize_kernel, dim3((Cout + 63) / 64), dim3(64), 0, st, scratch, gx, pl.nchunks, W, Cout,
+                       stats, 1.0 / (double)vox);
+    if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  }
+  return SYNTHSR_OK;
+}
+
+int64_t synthsr_conv3d_bf16_stats_scratch(const int shape[3], int Cin, int Cout) {
+  if (!shape) return SYNTHSR_EINVAL;
+  const Bf16Plan pl = plan_bf16(Cin, Cout);
+  return (int64_t)512 * pl.nchunks * 2 * 16 * pl.mt;
+}
+
+int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float* dbias, const int shape[3], int Cin_total,
+                              int ci_off, int Cin, int Cout, synthsr_stream_t stream) {
+  if (!in || !dout || !dw || !shape || Cin % 8 != 0 || Cout % 8 != 0 || ci_off != 0 || Cin != Cin_total)
+    return SYNTHSR_EINVAL;
+  const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
+  if (vox * Cin * 2 >= (1ll << 31) || vox * Cout * 2 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  WgArgs a;
+  a.in = (const bf16_t*)in;
+  a.dout = (const bf16_t*)dout;
+  a.dw = dw;
+  a.dbias = dbias;
+  a.D0 = shape[0];
+  a.D1 = shape[1];
+  a.D2 = shape[2];
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.cin_total = Cin_total;
+  a.ci_off = ci_off;
+  const int ck = (Cin % 32 == 0) ? 32 : ((Cin % 24 == 0) ? 24 : 8);
+  a.ncc = (Cin + ck - 1) / ck;
+  const int nt_all = (Cout + 15) / 16;
+  a.nco = (nt_all + 2) / 3;
+  const int nt = (nt_all + a.nco - 1) / a.nco;
+  a.tiles1 = (shape[1] + TY - 1) / TY;
+  a.tiles2 = (shape[2] + TX - 1) / TX;
+  a.ntiles = ((shape[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
+  hipStream_t st = (hipStream_t)stream;
+#define SYN_WG(CKV) \
+  (nt == 1 ? launch_wgrad<CKV, 1>(a, st) : (nt == 2 ? launch_wgrad<CKV, 2>(a, st) : launch_wgrad<CKV, 3>(a, st)))
+  if (ck == 8) return SYN_WG(8);
+  if (ck == 24) return SYN_WG(24);
+  return SYN_WG(32);
+#undef SYN_WG
+}
+
+int synthsr_f32_to_bf16_pad(const float* src, void* dst, int64_t n, int Cs, int Cd, synthsr_stream_t stream) {
+  if (!src || !dst || n < 0 || Cs < 1 || Cd < Cs) return SYNTHSR_EINVAL;
+  if (n == 0) return SYNTHSR_OK;
+  hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3(syn_grid(n * Cd, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t*)dst, n, Cs, Cd);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+}  // extern "C"

@@ -601,3 +601,69 @@ def lut_gather(labels, lut, out=None):
     _lib.check(_L().synthsr_lut_gather(_lib.ptr(labels), _lib.ptr(lut), lut.numel(), _lib.ptr(out), labels.numel(),
                                        _lib.stream()), 'lut_gather')
     return out
+
+
+# ---------------------------------------------------------------------- bf16 convolutions (csrc/conv_bf16.hip)
+_bf16_scratch = {}
+
+
+def pack_conv_weights_bf16(w, mode=0, ci_off=0, cin=None, out=None):
+    """fp32 Keras kernel w [3,3,3,Cin_total,Cout] -> bf16 MFMA fragments (mode 0 forward, 1 data gradient)"""
+    lib = _L()
+    cin_total, cout = int(w.shape[3]), int(w.shape[4])
+    cin = cin_total if cin is None else int(cin)
+    n = lib.synthsr_conv3d_bf16_pack(None, None, cin_total, int(ci_off), cin, cout, int(mode), None)
+    if n < 0:
+        _lib.check(int(n), 'conv3d_bf16_pack(size)')
+    if out is None:
+        out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    assert out.numel() == n and out.dtype == torch.bfloat16
+    r = lib.synthsr_conv3d_bf16_pack(_lib.ptr(w), _lib.ptr(out), cin_total, int(ci_off), cin, cout, int(mode), _lib.stream())
+    if r < 0:
+        _lib.check(int(r), 'conv3d_bf16_pack')
+    return out
+
+
+def conv3d_bf16(x, wpacked, bias, Cout, act=1, below=None, stats=None, out=None):
+    """act(conv3(x) + bias) on bf16 NDHWC tensors (fp32 accumulation); act 2: times ELU'(below); stats: fp32 [2*Cout]
+    receives the batch mean | variance of the output"""
+    lib = _L()
+    s = x.shape
+    assert x.dtype == torch.bfloat16 and wpacked.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty((s[0], s[1], s[2], Cout), dtype=torch.bfloat16, device=x.device)
+    scratch, nscr = None, 0
+    if stats is not None:
+        nscr = int(lib.synthsr_conv3d_bf16_stats_scratch(_lib.i3(s[:3]), int(s[3]), int(Cout)))
+        key = (x.device, nscr)
+        scratch = _bf16_scratch.get(key)
+        if scratch is None:
+            scratch = _bf16_scratch[key] = torch.empty(nscr, dtype=torch.float32, device=x.device)
+    with _Timed('conv3d_bf16', s[:3], s[3], Cout):
+        _lib.check(lib.synthsr_conv3d_bf16_fwd(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out), _lib.i3(s[:3]),
+                                               int(s[3]), int(Cout), int(act), _lib.ptr(below), _lib.ptr(stats),
+                                               _lib.ptr(scratch), nscr, _lib.stream()), 'conv3d_bf16_fwd')
+    return out
+
+
+def conv3d_wgrad_bf16(x, dz, dw, dbias=None):
+    """dw [3,3,3,Cin,Cout] fp32 += weight gradient of bf16 x / dz (dbias += column sums of dz)"""
+    lib = _L()
+    s = x.shape
+    assert x.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    with _Timed('conv3d_bf16_wgrad', s[:3], s[3], dz.shape[3]):
+        _lib.check(lib.synthsr_conv3d_bf16_wgrad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(dbias), _lib.i3(s[:3]),
+                                                 int(s[3]), 0, int(s[3]), int(dz.shape[3]), _lib.stream()),
+                   'conv3d_bf16_wgrad')
+    return dw
+
+
+def to_bf16_pad(x, Cd, out=None):
+    """fp32 [..., Cs] -> bf16 [..., Cd] with zero-filled extra channels"""
+    lib = _L()
+    Cs = int(x.shape[-1])
+    n = x.numel() // Cs
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (Cd,), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.synthsr_f32_to_bf16_pad(_lib.ptr(x), _lib.ptr(out), n, Cs, int(Cd), _lib.stream()), 'f32_to_bf16_pad')
+    return out
