@@ -205,13 +205,55 @@ int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* j
  * that change the launch geometry must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
 
+/* ---- bf16 twins of the HBM-bound U-Net kernels: same arguments and semantics as the float32 entry point of the same
+ * name (which cites the reference layers it replaces); activation / activation-gradient tensors are NDHWC bfloat16
+ * (void*), parameters, statistics, reductions, predictions and losses stay float32; all arithmetic is float32, stores
+ * round to nearest even ("bf16 with fp32 norm accum", BASELINE.json configs[3]) */
+int synthsr_elu_bwd_bf16(const void* dy, const void* dy2, const void* y, void* dz, float* dbias, int64_t nvox, int C,
+                         synthsr_stream_t stream);
+int synthsr_bn_elu_bwd_bf16(const void* dy, const void* dy2, const void* y, void* dz, float* dbias, int64_t nvox, int
+                            C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t
+                            stream);
+int synthsr_bn_elu_bwd_head_bf16(const float* dpred, const float* whead, const void* y, void* dz, float* dbias,
+                                 int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float*
+                                 sums, synthsr_stream_t stream);
+int synthsr_bn_stats_bf16(const void* x, int64_t nvox, int C, float* stats, double* ws, synthsr_stream_t stream);
+int synthsr_bn_maxpool_bf16(const void* x, void* y, const int shape[3], int C, const float* stats, const float* gamma,
+                            const float* beta, float eps, synthsr_stream_t stream);
+int synthsr_bn_maxpool_bwd_bf16(const void* dy, const void* x, void* dbn, const int shape[3], int C, const float*
+                                stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream);
+int synthsr_bn_maxpool_bwd_ex_bf16(const void* dy, const void* x, void* dbn, const int shape[3], int C, const float*
+                                   stats, const float* gamma, const float* beta, float eps, float* sums,
+                                   synthsr_stream_t stream);
+int synthsr_bn_bwd_reduce_bf16(const void* dy, const void* x, int64_t nvox, int C, const float* stats, float eps,
+                               float* sums, synthsr_stream_t stream);
+int synthsr_upsample_concat_bf16(const void* skip, const void* lo, void* out, const int shape[3], int Cs, int Cl,
+                                 const float* stats, const float* gamma, const float* beta, float eps,
+                                 synthsr_stream_t stream);
+int synthsr_upsample_concat_bwd_bf16(const void* dcat, void* dskip, void* dlo_bn, const int shape[3], int Cs, int Cl,
+                                     synthsr_stream_t stream);
+int synthsr_head_loss_fwd_bf16(const void* x, const int* shape, int C, const float* stats, const float* gamma, const
+                               float* beta, float eps, const float* w, const float* b, int K, const float* residual,
+                               int res_stride, const int* res_offs, const float* target, float* pred, float* dpred,
+                               float* loss, int kind, const int* crop, synthsr_stream_t stream);
+int synthsr_head_bwd_multi_bf16(const float* dpred, const void* x, int64_t nvox, int C, int K, const float* stats,
+                                const float* gamma, const float* beta, float eps, const float* w, void* dbn, float*
+                                dw, float* db, synthsr_stream_t stream);
+int synthsr_head_bwd_ex_bf16(const float* dpred, const void* x, int64_t nvox, int C, const float* stats, const float*
+                             gamma, const float* beta, float eps, const float* w, void* dbn, float* dw, float* db,
+                             float* bn_sums, synthsr_stream_t stream);
+int synthsr_head_bwd_bf16(const float* dpred, const void* x, int64_t nvox, int C, const float* stats, const float*
+                          gamma, const float* beta, float eps, const float* w, void* dbn, float* dw, float* db,
+                          synthsr_stream_t stream);
+
 /* ---- bf16 variants (BASELINE.json configs[3] / [4]: bf16 activations and weights, fp32 accumulation, fp32 BatchNorm
  * statistics; csrc/conv_bf16.hip).  Activation / gradient tensors are NDHWC bfloat16 (passed as void*), parameters,
  * parameter gradients and statistics stay float32 (fp32 master weights live in the optimizer's flat buffer).  They
  * replace the same Keras layers as the float32 entry points (ext/neuron/models.py:297-299,412-414; the reference has no
  * reduced-precision path: parity is stated against the float32 oracle with a bf16 tolerance).
  * pack: fp32 Keras kernel w [27][Cin_total][Cout] -> bf16 MFMA A-fragments of channels [ci_off, ci_off + Cin); mode 0
- * forward, 1 data gradient; returns the number of bf16 values (packed == NULL: size query).  CinE % 8 == 0, CoutE % 4 == 0 */
+ * forward, 1 data gradient; returns the number of bf16 values (packed == NULL: size query).  The tensor the layer reads
+ * has ceil(CinE / 8) * 8 channels (pad channels get zero weights); CoutE % 4 == 0 */
 int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
                                  synthsr_stream_t stream);
 /* out = act(conv3(in) + bias); act 0 linear, 1 ELU, 2 multiply by ELU'(below) (data gradient fused with the ELU backward
@@ -223,7 +265,8 @@ int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, v
                             synthsr_stream_t stream);
 int64_t synthsr_conv3d_bf16_stats_scratch(const int shape[3], int Cin, int Cout);
 /* dw[27][Cin][Cout] (fp32) += sum_v in[v + t - 1][ci] * dout[v][co];  dbias[Cout] += sum_v dout[v]  (may be NULL);
- * both zeroed by the caller.  Cin % 8 == 0, Cout % 8 == 0 */
+ * both zeroed by the caller.  `in` has Cin channels (Cin % 8 == 0), dw covers its first Cin_total <= Cin channels;
+ * Cout % 8 == 0 */
 int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float* dbias, const int shape[3],
                               int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream);
 /* float32 [n][Cs] -> bfloat16 [n][Cd], Cd >= Cs, zero fill (the generator's image -> first-layer input, Cin 2 -> 8) */

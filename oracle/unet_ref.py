@@ -47,10 +47,33 @@ def upsample2(x):
     return x.repeat_interleave(2, 0).repeat_interleave(2, 1).repeat_interleave(2, 2)
 
 
-def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, collect=None, softmax=False):
+class _RoundBF16(torch.autograd.Function):
+    """y = bf16(x) (round to nearest even) in the forward pass, the gradient is rounded the same way on its way back:
+    the storage roundings of the bf16 network (synthsr_amd UNet3D(dtype='bf16')) restated for the fp32 oracle"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def round_bf16(x):
+    return _RoundBF16.apply(x)
+
+
+def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, collect=None, softmax=False, quant=None):
     """P: dict name -> tensor with the Keras layer names (`<prefix>_conv_downarm_l_k/kernel`, ...).
-    Returns prediction [d0,d1,d2,1].  `collect` (dict) receives batch statistics per BN layer."""
+    Returns prediction [d0,d1,d2,1].  `collect` (dict) receives batch statistics per BN layer.
+    quant (optional, e.g. round_bf16): applied wherever the bf16 network stores a tensor -- the input, every conv kernel,
+    every conv + ELU output, every pooled tensor and every concatenated tensor (BatchNorm, head and loss stay fp32)."""
     L = nb_levels
+    if quant is not None:
+        x = quant(x)
+        P = {k: (quant(v) if k.endswith('/kernel') and 'likelihood' not in k else v) for k, v in P.items()}
+    q = (lambda t: t) if quant is None else quant
 
     def bn(t, name):
         if training:
@@ -66,17 +89,17 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
     for l in range(L):
         for k in range(nconv):
             nm = '%s_conv_downarm_%d_%d' % (prefix, l, k)
-            cur = F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias']))
+            cur = q(F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias'])))
         skips.append(cur)  # pre-BN skip (models.py:431-432)
         cur = bn(cur, '%s_bn_down_%d' % (prefix, l))
         if l < L - 1:
-            cur = maxpool2(cur)
+            cur = q(maxpool2(cur))
     for k in range(L - 1):
         l = L - 2 - k
-        cur = torch.cat([skips[l], upsample2(cur)], -1)  # concatenate([skip, up]) models.py:434
+        cur = q(torch.cat([skips[l], upsample2(cur)], -1))  # concatenate([skip, up]) models.py:434
         for j in range(nconv):
             nm = '%s_conv_uparm_%d_%d' % (prefix, L + k, j)
-            cur = F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias']))
+            cur = q(F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias'])))
         cur = bn(cur, '%s_bn_up_%d' % (prefix, k))
     w, b = P['%s_likelihood/kernel' % prefix], P['%s_likelihood/bias' % prefix]
     out = cur @ w.reshape(w.shape[-2], w.shape[-1]) + b

@@ -61,6 +61,20 @@ SIGNATURES = {
     'synthsr_conv3d_wgrad_bias': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad_ex': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_elu_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),
+    'synthsr_bn_elu_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
+    'synthsr_bn_elu_bwd_head_bf16': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
+    'synthsr_bn_stats_bf16': (c_int, [_P, c_int64, c_int, _P, _P, _S]),
+    'synthsr_bn_maxpool_bf16': (c_int, [_P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _S]),
+    'synthsr_bn_maxpool_bwd_bf16': (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _S]),
+    'synthsr_bn_maxpool_bwd_ex_bf16': (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _P, _S]),
+    'synthsr_bn_bwd_reduce_bf16': (c_int, [_P, _P, c_int64, c_int, _P, c_float, _P, _S]),
+    'synthsr_upsample_concat_bf16': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _P, _P, _P, c_float, _S]),
+    'synthsr_upsample_concat_bwd_bf16': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_head_loss_fwd_bf16': (c_int, [_P, POINTER(c_int), c_int, _P, _P, _P, c_float, _P, _P, c_int, _P, c_int, POINTER(c_int), _P, _P, _P, _P, c_int, POINTER(c_int), _S]),
+    'synthsr_head_bwd_multi_bf16': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
+    'synthsr_head_bwd_ex_bf16': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _S]),
+    'synthsr_head_bwd_bf16': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
     'synthsr_conv3d_bf16_pack': (c_int64, [_P, _P, c_int, c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_bf16_fwd': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _P, _P, _P, c_int64, _S]),
     'synthsr_conv3d_bf16_stats_scratch': (c_int64, [POINTER(c_int), c_int, c_int]),

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int ci = cc * CK + quad * 4 + i;
-          if (ci < Cin) atomicAdd(a.dw + ((int64_t)tap * a.cin_total + a.ci_off + ci) * Cout + co, acc[q][n][i]);
+          if (ci < a.cin_total) atomicAdd(a.dw + ((int64_t)tap * a.cin_total + a.ci_off + ci) * Cout + co, acc[q][n][i]);
         }
       } else if (blk == 27 * C4 && a.dbias && cc == 0) {
         atomicAdd(a.dbias + co, acc[q][n][0]);
@@ -582,8 +582,10 @@ extern "C" {
 int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
                                  synthsr_stream_t stream) {
   if (Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1)) return SYNTHSR_EINVAL;
-  const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
-  if (CinE % 8 != 0 || CoutE % 4 != 0) return SYNTHSR_EINVAL;
+  // the tensor a layer reads has its channel count padded to a multiple of 8 (the first layer's 2 -> 8): pad channels
+  // get zero weights.  The produced channel count must be a multiple of 4 (8-byte bf16x4 stores).
+  const int CinE = ((mode ? Cout : Cin) + 7) / 8 * 8, CoutE = mode ? Cin : Cout;
+  if (CoutE % 4 != 0) return SYNTHSR_EINVAL;
   const Bf16Plan pl = plan_bf16(CinE, CoutE);
   const int64_t total = pl.count();
   if (total >= (1ll << 31)) return SYNTHSR_EINVAL;
@@ -655,7 +657,8 @@ int64_t synthsr_conv3d_bf16_stats_scratch(const int shape[3], int Cin, int Cout)
 
 int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float* dbias, const int shape[3], int Cin_total,
                               int ci_off, int Cin, int Cout, synthsr_stream_t stream) {
-  if (!in || !dout || !dw || !shape || Cin % 8 != 0 || Cout % 8 != 0 || ci_off != 0 || Cin != Cin_total)
+  // `in` has Cin channels (a multiple of 8), dw covers its first Cin_total <= Cin channels (zero-padded first layer)
+  if (!in || !dout || !dw || !shape || Cin % 8 != 0 || Cout % 8 != 0 || ci_off != 0 || Cin_total > Cin || Cin_total < 1)
     return SYNTHSR_EINVAL;
   const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
   if (vox * Cin * 2 >= (1ll << 31) || vox * Cout * 2 >= (1ll << 31)) return SYNTHSR_EINVAL;

@@ -21,6 +21,28 @@ __device__ __forceinline__ float elu_grad_from_y(float y) { return y > 0.f ? 1.f
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// bf16 activations (BASELINE configs[3] / [4]): the same kernels instantiated on bf16_t move 4 values = 8 bytes per lane and
+// do all arithmetic (BatchNorm statistics, reductions, losses) in fp32; stores round to nearest even
+struct bf16_t {
+  uint16_t v;
+};
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf2f(u.x & 0xffffu), bf2f(u.x >> 16), bf2f(u.y & 0xffffu), bf2f(u.y >> 16));
+}
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+  uint2 u;
+  u.x = f2bf(v.x) | (f2bf(v.y) << 16);
+  u.y = f2bf(v.z) | (f2bf(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
 // block-level channel reduction of NV float4 partials held by threads with a fixed channel group
 template <int NV>
 __device__ __forceinline__ void block_channel_reduce(float4 (&part)[NV], int c4, int C4, bool fixed, float* smem) {
@@ -41,8 +63,9 @@ __device__ __forceinline__ void block_channel_reduce(float4 (&part)[NV], int c4,
 // dz = (dy [+ dy2]) * elu'(y); dbias[c] += sum dz
 // Optional fused BatchNorm backward (bn_sums != nullptr): the incoming gradient is w.r.t. the BN OUTPUT of y and is
 // first mapped to the BN input, g <- gamma*invstd*(g - sum_dy/n - xhat*sum_dyxhat/n), saving one full pass.
-__global__ __launch_bounds__(RB) void elu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
-                                                     const float* __restrict__ y, float* __restrict__ dz,
+template <typename T>
+__global__ __launch_bounds__(RB) void elu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                     const T* __restrict__ y, T* __restrict__ dz,
                                                      float* __restrict__ dbias, int64_t n4, int C4,
                                                      const float* __restrict__ bn_stats,
                                                      const float* __restrict__ bn_gamma,
@@ -106,7 +129,8 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const float* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------ BN statistics
-__global__ __launch_bounds__(RB) void bn_stats_kernel(const float* __restrict__ x, int64_t n4, int C4,
+template <typename T>
+__global__ __launch_bounds__(RB) void bn_stats_kernel(const T* __restrict__ x, int64_t n4, int C4,
                                                       double* __restrict__ ws) {
   extern __shared__ float smem[];  // [2][C4*4]
   const bool fixed = (RB % C4) == 0;
@@ -180,7 +204,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------ BN + max-pool 2^3
-__global__ __launch_bounds__(256) void bn_maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, Shape3 s,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, Shape3 s,
                                                          int C, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps) {
@@ -212,8 +237,9 @@ __global__ __launch_bounds__(256) void bn_maxpool_kernel(const float* __restrict
 }
 
 // gradient w.r.t. the BN output: routed to the FIRST maximum of each 2^3 window (raster order)
-__global__ __launch_bounds__(256) void bn_maxpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                             float* __restrict__ dbn, Shape3 s, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             T* __restrict__ dbn, Shape3 s, int C,
                                                              const float* __restrict__ stats,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps) {
@@ -252,8 +278,9 @@ __global__ __launch_bounds__(256) void bn_maxpool_bwd_kernel(const float* __rest
 // bn_maxpool_bwd + the channel sums of the NEXT BatchNorm backward (synthsr_bn_bwd_reduce of the routed gradient):
 // the routed gradient is 7/8 zeros, every non-zero and its xhat are in registers here, so the separate reduction pass
 // (a full read of dbn and x) is unnecessary.  RB threads so that each thread keeps a fixed channel group.
-__global__ __launch_bounds__(RB) void bn_maxpool_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                 float* __restrict__ dbn, Shape3 s, int C,
+template <typename T>
+__global__ __launch_bounds__(RB) void bn_maxpool_bwd_sums_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                 T* __restrict__ dbn, Shape3 s, int C,
                                                                  const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float eps,
@@ -314,7 +341,8 @@ __global__ __launch_bounds__(RB) void bn_maxpool_bwd_sums_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------ BN backward
-__global__ __launch_bounds__(RB) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(RB) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            int64_t n4, int C, const float* __restrict__ stats,
                                                            float eps, float* __restrict__ sums) {
   extern __shared__ float smem[];  // [2][C]
@@ -370,8 +398,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------ upsample + concat
-__global__ __launch_bounds__(256) void upsample_concat_kernel(const float* __restrict__ skip,
-                                                              const float* __restrict__ lo, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_concat_kernel(const T* __restrict__ skip,
+                                                              const T* __restrict__ lo, T* __restrict__ out,
                                                               Shape3 s, int Cs, int Cl,
                                                               const float* __restrict__ stats,
                                                               const float* __restrict__ gamma,
@@ -398,9 +427,10 @@ __global__ __launch_bounds__(256) void upsample_concat_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void upsample_concat_bwd_kernel(const float* __restrict__ dcat,
-                                                                  float* __restrict__ dskip,
-                                                                  float* __restrict__ dlo, Shape3 s, int Cs, int Cl) {
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_concat_bwd_kernel(const T* __restrict__ dcat,
+                                                                  T* __restrict__ dskip,
+                                                                  T* __restrict__ dlo, Shape3 s, int Cs, int Cl) {
   const int C = Cs + Cl;
   const int Cs4 = Cs / 4, Cl4 = Cl / 4;
   const int64_t nv = (int64_t)s.d[0] * s.d[1] * s.d[2];
@@ -448,8 +478,8 @@ struct HeadBox {
   int res_off[4];  // residual channel added to intensity channel k (work_with_residual_channel)
 };
 
-template <int K>
-__global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restrict__ x, int64_t nvox, int C,
+template <typename T, int K>
+__global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict__ x, int64_t nvox, int C,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
@@ -564,12 +594,12 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restr
 // K-channel head backward (K > 1, e.g. the intensity + spread channels of the 'laplace' loss): the gradient w.r.t. the
 // BatchNorm output, dbn[v][c] = sum_k g[v][k] w[c][k], is written out; dw[c][k] += gamma[c] A_k[c] + beta[c] B_k,
 // db[k] += B_k with A_k[c] = sum_v g_k xhat[v][c], B_k = sum_v g_k.
-template <int K>
-__global__ __launch_bounds__(RB) void head_multi_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ x,
+template <typename T, int K>
+__global__ __launch_bounds__(RB) void head_multi_bwd_kernel(const float* __restrict__ dpred, const T* __restrict__ x,
                                                             int64_t n4, int C, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
-                                                            const float* __restrict__ w, float* __restrict__ dbn,
+                                                            const float* __restrict__ w, T* __restrict__ dbn,
                                                             float* __restrict__ dw, float* __restrict__ db) {
   extern __shared__ float smem[];  // A[K][C], B[K]
   const int C4 = C / 4;
@@ -619,11 +649,12 @@ __global__ __launch_bounds__(RB) void head_multi_bwd_kernel(const float* __restr
   if (threadIdx.x < K) atomicAdd(&db[threadIdx.x], smem[K * C + threadIdx.x]);
 }
 
-__global__ __launch_bounds__(RB) void head_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(RB) void head_bwd_kernel(const float* __restrict__ dpred, const T* __restrict__ x,
                                                       int64_t n4, int C, const float* __restrict__ stats,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
-                                                      const float* __restrict__ w, float* __restrict__ dbn,
+                                                      const float* __restrict__ w, T* __restrict__ dbn,
                                                       float* __restrict__ dw, float* __restrict__ db,
                                                       float* __restrict__ sums) {
   // The gradient w.r.t. the BatchNorm output is rank-1, dbn[v][c] = g[v] w[c].  With A[c] = sum_v g xhat[v][c] and
@@ -815,53 +846,247 @@ inline bool odd_shape(const int s[3]) { return (s[0] | s[1] | s[2]) & 1; }
 
 }  // namespace
 
-extern "C" {
-
-int synthsr_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
-                    synthsr_stream_t stream) {
+// ---- entry-point bodies, templated on the activation type (float | bf16_t)
+template <typename T>
+int elu_bwd_t(const T* dy, const T* dy2, const T* y, T* dz, float* dbias, int64_t nvox, int C, synthsr_stream_t stream) {
   if (!dy || !y || !dz || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(elu_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
+  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
                      dy2, y, dz, dbias, n4, C / 4, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      0.f, 0.f, (const float*)nullptr, (const float*)nullptr);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }
 
-int synthsr_bn_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
-                       const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
+template <typename T>
+int bn_elu_bwd_t(const T* dy, const T* dy2, const T* y, T* dz, float* dbias, int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
   if (!dy || !y || !dz || !stats || !gamma || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(elu_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
+  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
                      dy2, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps, (float)(1.0 / (double)nvox),
                      (const float*)nullptr, (const float*)nullptr);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }
 
-int synthsr_bn_elu_bwd_head(const float* dpred, const float* whead, const float* y, float* dz, float* dbias, int64_t nvox,
-                            int C, const float* stats, const float* gamma, float eps, const float* sums,
-                            synthsr_stream_t stream) {
+template <typename T>
+int bn_elu_bwd_head_t(const float* dpred, const float* whead, const T* y, T* dz, float* dbias, int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
   if (!dpred || !whead || !y || !dz || !stats || !gamma || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(elu_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream,
-                     (const float*)nullptr, (const float*)nullptr, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps,
+  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream,
+                     (const T*)nullptr, (const T*)nullptr, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps,
                      (float)(1.0 / (double)nvox), dpred, whead);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }
 
-int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* ws, synthsr_stream_t stream) {
+template <typename T>
+int bn_stats_t(const T* x, int64_t nvox, int C, float* stats, double* ws, synthsr_stream_t stream) {
   if (!x || !stats || !ws || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   if (hipMemsetAsync(ws, 0, 2 * C * sizeof(double), (hipStream_t)stream) != hipSuccess) return SYNTHSR_ELAUNCH;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
+  hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
                      (hipStream_t)stream, x, n4, C / 4, ws);
   SYN_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, stats, C,
                      1.0 / (double)nvox);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
+}
+
+template <typename T>
+int bn_maxpool_t(const T* x, T* y, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  if (!x || !y || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C)) return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_maxpool_kernel<T>, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, s, C, stats,
+                     gamma, beta, eps);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int bn_maxpool_bwd_t(const T* dy, const T* x, T* dbn, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  if (!dy || !x || !dbn || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C))
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_maxpool_bwd_kernel<T>, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dbn, s,
+                     C, stats, gamma, beta, eps);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int bn_maxpool_bwd_ex_t(const T* dy, const T* x, T* dbn, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream) {
+  if (!sums) return bn_maxpool_bwd_t<T>(dy, x, dbn, shape, C, stats, gamma, beta, eps, stream);
+  if (!dy || !x || !dbn || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C))
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_maxpool_bwd_sums_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
+                     (hipStream_t)stream, dy, x, dbn, s, C, stats, gamma, beta, eps, sums);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int bn_bwd_reduce_t(const T* dy, const T* x, int64_t nvox, int C, const float* stats, float eps, float* sums, synthsr_stream_t stream) {
+  if (!dy || !x || !stats || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
+                     (hipStream_t)stream, dy, x, n4, C, stats, eps, sums);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int upsample_concat_t(const T* skip, const T* lo, T* out, const int shape[3], int Cs, int Cl, const float* stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  if (!skip || !lo || !out || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(Cs) ||
+      !ok_c4(Cl))
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n4 = (int64_t)s.d[0] * s.d[1] * s.d[2] * ((Cs + Cl) / 4);
+  hipLaunchKernelGGL(upsample_concat_kernel<T>, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, skip, lo, out,
+                     s, Cs, Cl, stats, gamma, beta, eps);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int upsample_concat_bwd_t(const T* dcat, T* dskip, T* dlo_bn, const int shape[3], int Cs, int Cl, synthsr_stream_t stream) {
+  if (!dcat || !dskip || !dlo_bn || bad_shape(shape) || odd_shape(shape) || !ok_c4(Cs) || !ok_c4(Cl))
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t nv = (int64_t)s.d[0] * s.d[1] * s.d[2];
+  const int64_t n4 = nv * (Cs / 4) + (nv / 8) * (Cl / 4);
+  hipLaunchKernelGGL(upsample_concat_bwd_kernel<T>, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, dcat,
+                     dskip, dlo_bn, s, Cs, Cl);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int head_loss_fwd_t(const T* x, const int* shape, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, const float* b, int K, const float* residual, int res_stride, const int* res_offs, const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, synthsr_stream_t stream) {
+  if (!x || !shape || !stats || !gamma || !beta || !w || !b || !target || !loss || !ok_c4(C)) return SYNTHSR_EINVAL;
+  if (shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
+  if (kind < 0 || kind > 2 || K < 1 || K > 4 || (kind == 2 && (K & 1))) return SYNTHSR_EINVAL;
+  const int NT = kind == 2 ? K / 2 : K;
+  if (C > 116) return SYNTHSR_EINVAL;  // LDS: (2 + K) C + 256 (C + 4) floats
+  const int64_t nvox = (int64_t)shape[0] * shape[1] * shape[2];
+  HeadBox box;
+  for (int k = 0; k < 4; ++k) box.res_off[k] = 0;
+  if (residual) {
+    if (res_stride < 1 || !res_offs) return SYNTHSR_EINVAL;
+    for (int k = 0; k < NT; ++k) {
+      if (res_offs[k] < 0 || res_offs[k] >= res_stride) return SYNTHSR_EINVAL;
+      box.res_off[k] = res_offs[k];
+    }
+  }
+  box.on = crop != nullptr;
+  box.d1 = shape[1];
+  box.d2 = shape[2];
+  int64_t n_in = nvox;
+  if (crop) {
+    n_in = 1;
+    for (int i = 0; i < 3; ++i) {
+      if (crop[i] < 0 || crop[3 + i] < 1 || crop[i] + crop[3 + i] > shape[i]) return SYNTHSR_EINVAL;
+      box.lo[i] = crop[i];
+      box.hi[i] = crop[i] + crop[3 + i];
+      n_in *= crop[3 + i];
+    }
+  } else {
+    for (int i = 0; i < 3; ++i) {
+      box.lo[i] = 0;
+      box.hi[i] = shape[i];
+    }
+  }
+  const size_t smem = ((2 + K) * C + 256 * (C + 4)) * sizeof(float);
+  const float inv_n = (float)(1.0 / ((double)n_in * NT));
+  const dim3 grid(syn_grid(nvox, 256, 1024));
+#define SYN_HEAD_FWD(KK)                                                                                                 \
+  hipLaunchKernelGGL((head_loss_fwd_kernel<T, KK>), grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta, \
+                     eps, w, b, residual, res_stride, target, pred, dpred, loss, inv_n, kind, box)
+  switch (K) {
+    case 1: SYN_HEAD_FWD(1); break;
+    case 2: SYN_HEAD_FWD(2); break;
+    case 3: SYN_HEAD_FWD(3); break;
+    default: SYN_HEAD_FWD(4); break;
+  }
+#undef SYN_HEAD_FWD
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int head_bwd_multi_t(const float* dpred, const T* x, int64_t nvox, int C, int K, const float* stats, const float* gamma, const float* beta, float eps, const float* w, T* dbn, float* dw, float* db, synthsr_stream_t stream) {
+  if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C) || K < 2 || K > 4)
+    return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  const dim3 grid(syn_grid(n4, RB, 1024));
+  const size_t smem = (K * C + K) * sizeof(float);
+#define SYN_HEAD_BWD(KK)                                                                                             \
+  hipLaunchKernelGGL((head_multi_bwd_kernel<T, KK>), grid, dim3(RB), smem, (hipStream_t)stream, dpred, x, n4, C, stats, gamma, \
+                     beta, eps, w, dbn, dw, db)
+  switch (K) {
+    case 2: SYN_HEAD_BWD(2); break;
+    case 3: SYN_HEAD_BWD(3); break;
+    default: SYN_HEAD_BWD(4); break;
+  }
+#undef SYN_HEAD_BWD
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int head_bwd_ex_t(const float* dpred, const T* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, T* dbn, float* dw, float* db, float* bn_sums, synthsr_stream_t stream) {
+  if (!dpred || !x || !stats || !gamma || !beta || !w || !dw || !db || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
+                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db, bn_sums);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int head_bwd_t(const float* dpred, const T* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, T* dbn, float* dw, float* db, synthsr_stream_t stream) {
+  if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C))
+    return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
+                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db, (float*)nullptr);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+extern "C" {
+
+int synthsr_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C, synthsr_stream_t stream) {
+  return elu_bwd_t<float>(dy, dy2, y, dz, dbias, nvox, C, stream);
+}
+int synthsr_elu_bwd_bf16(const void* dy, const void* dy2, const void* y, void* dz, float* dbias, int64_t nvox, int C, synthsr_stream_t stream) {
+  return elu_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (bf16_t*)dz, dbias, nvox, C, stream);
+}
+
+int synthsr_bn_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
+  return bn_elu_bwd_t<float>(dy, dy2, y, dz, dbias, nvox, C, stats, gamma, eps, sums, stream);
+}
+int synthsr_bn_elu_bwd_bf16(const void* dy, const void* dy2, const void* y, void* dz, float* dbias, int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
+  return bn_elu_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (bf16_t*)dz, dbias, nvox, C, stats, gamma, eps, sums, stream);
+}
+
+int synthsr_bn_elu_bwd_head(const float* dpred, const float* whead, const float* y, float* dz, float* dbias, int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
+  return bn_elu_bwd_head_t<float>(dpred, whead, y, dz, dbias, nvox, C, stats, gamma, eps, sums, stream);
+}
+int synthsr_bn_elu_bwd_head_bf16(const float* dpred, const float* whead, const void* y, void* dz, float* dbias, int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
+  return bn_elu_bwd_head_t<bf16_t>(dpred, whead, (const bf16_t*)y, (bf16_t*)dz, dbias, nvox, C, stats, gamma, eps, sums, stream);
+}
+
+int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* ws, synthsr_stream_t stream) {
+  return bn_stats_t<float>(x, nvox, C, stats, ws, stream);
+}
+int synthsr_bn_stats_bf16(const void* x, int64_t nvox, int C, float* stats, double* ws, synthsr_stream_t stream) {
+  return bn_stats_t<bf16_t>((const bf16_t*)x, nvox, C, stats, ws, stream);
 }
 
 // mean / variance from per-workgroup partial sums: partial[nwg][2C] (sum | sum of squares), accumulated in double
@@ -909,50 +1134,32 @@ int synthsr_bn_apply(const float* x, float* y, int64_t nvox, int C, const float*
   return SYNTHSR_OK;
 }
 
-int synthsr_bn_maxpool(const float* x, float* y, const int shape[3], int C, const float* stats, const float* gamma,
-                       const float* beta, float eps, synthsr_stream_t stream) {
-  if (!x || !y || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C)) return SYNTHSR_EINVAL;
-  Shape3 s{{shape[0], shape[1], shape[2]}};
-  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
-  hipLaunchKernelGGL(bn_maxpool_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, s, C, stats,
-                     gamma, beta, eps);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_bn_maxpool(const float* x, float* y, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  return bn_maxpool_t<float>(x, y, shape, C, stats, gamma, beta, eps, stream);
+}
+int synthsr_bn_maxpool_bf16(const void* x, void* y, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  return bn_maxpool_t<bf16_t>((const bf16_t*)x, (bf16_t*)y, shape, C, stats, gamma, beta, eps, stream);
 }
 
-int synthsr_bn_maxpool_bwd(const float* dy, const float* x, float* dbn, const int shape[3], int C, const float* stats,
-                           const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
-  if (!dy || !x || !dbn || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C))
-    return SYNTHSR_EINVAL;
-  Shape3 s{{shape[0], shape[1], shape[2]}};
-  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
-  hipLaunchKernelGGL(bn_maxpool_bwd_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dbn, s,
-                     C, stats, gamma, beta, eps);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_bn_maxpool_bwd(const float* dy, const float* x, float* dbn, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  return bn_maxpool_bwd_t<float>(dy, x, dbn, shape, C, stats, gamma, beta, eps, stream);
+}
+int synthsr_bn_maxpool_bwd_bf16(const void* dy, const void* x, void* dbn, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  return bn_maxpool_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dbn, shape, C, stats, gamma, beta, eps, stream);
 }
 
-int synthsr_bn_maxpool_bwd_ex(const float* dy, const float* x, float* dbn, const int shape[3], int C, const float* stats,
-                              const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream) {
-  if (!sums) return synthsr_bn_maxpool_bwd(dy, x, dbn, shape, C, stats, gamma, beta, eps, stream);
-  if (!dy || !x || !dbn || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C))
-    return SYNTHSR_EINVAL;
-  Shape3 s{{shape[0], shape[1], shape[2]}};
-  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
-  hipLaunchKernelGGL(bn_maxpool_bwd_sums_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
-                     (hipStream_t)stream, dy, x, dbn, s, C, stats, gamma, beta, eps, sums);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_bn_maxpool_bwd_ex(const float* dy, const float* x, float* dbn, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream) {
+  return bn_maxpool_bwd_ex_t<float>(dy, x, dbn, shape, C, stats, gamma, beta, eps, sums, stream);
+}
+int synthsr_bn_maxpool_bwd_ex_bf16(const void* dy, const void* x, void* dbn, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream) {
+  return bn_maxpool_bwd_ex_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dbn, shape, C, stats, gamma, beta, eps, sums, stream);
 }
 
-int synthsr_bn_bwd_reduce(const float* dy, const float* x, int64_t nvox, int C, const float* stats, float eps,
-                          float* sums, synthsr_stream_t stream) {
-  if (!dy || !x || !stats || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
-  const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
-                     (hipStream_t)stream, dy, x, n4, C, stats, eps, sums);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_bn_bwd_reduce(const float* dy, const float* x, int64_t nvox, int C, const float* stats, float eps, float* sums, synthsr_stream_t stream) {
+  return bn_bwd_reduce_t<float>(dy, x, nvox, C, stats, eps, sums, stream);
+}
+int synthsr_bn_bwd_reduce_bf16(const void* dy, const void* x, int64_t nvox, int C, const float* stats, float eps, float* sums, synthsr_stream_t stream) {
+  return bn_bwd_reduce_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, nvox, C, stats, eps, sums, stream);
 }
 
 int synthsr_bn_bwd_apply(const float* dy, const float* x, float* dx, int64_t nvox, int C, const float* stats,
@@ -965,85 +1172,25 @@ int synthsr_bn_bwd_apply(const float* dy, const float* x, float* dx, int64_t nvo
   return SYNTHSR_OK;
 }
 
-int synthsr_upsample_concat(const float* skip, const float* lo, float* out, const int shape[3], int Cs, int Cl,
-                            const float* stats, const float* gamma, const float* beta, float eps,
-                            synthsr_stream_t stream) {
-  if (!skip || !lo || !out || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(Cs) ||
-      !ok_c4(Cl))
-    return SYNTHSR_EINVAL;
-  Shape3 s{{shape[0], shape[1], shape[2]}};
-  const int64_t n4 = (int64_t)s.d[0] * s.d[1] * s.d[2] * ((Cs + Cl) / 4);
-  hipLaunchKernelGGL(upsample_concat_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, skip, lo, out,
-                     s, Cs, Cl, stats, gamma, beta, eps);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_upsample_concat(const float* skip, const float* lo, float* out, const int shape[3], int Cs, int Cl, const float* stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  return upsample_concat_t<float>(skip, lo, out, shape, Cs, Cl, stats, gamma, beta, eps, stream);
+}
+int synthsr_upsample_concat_bf16(const void* skip, const void* lo, void* out, const int shape[3], int Cs, int Cl, const float* stats, const float* gamma, const float* beta, float eps, synthsr_stream_t stream) {
+  return upsample_concat_t<bf16_t>((const bf16_t*)skip, (const bf16_t*)lo, (bf16_t*)out, shape, Cs, Cl, stats, gamma, beta, eps, stream);
 }
 
-int synthsr_upsample_concat_bwd(const float* dcat, float* dskip, float* dlo_bn, const int shape[3], int Cs, int Cl,
-                                synthsr_stream_t stream) {
-  if (!dcat || !dskip || !dlo_bn || bad_shape(shape) || odd_shape(shape) || !ok_c4(Cs) || !ok_c4(Cl))
-    return SYNTHSR_EINVAL;
-  Shape3 s{{shape[0], shape[1], shape[2]}};
-  const int64_t nv = (int64_t)s.d[0] * s.d[1] * s.d[2];
-  const int64_t n4 = nv * (Cs / 4) + (nv / 8) * (Cl / 4);
-  hipLaunchKernelGGL(upsample_concat_bwd_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, dcat,
-                     dskip, dlo_bn, s, Cs, Cl);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_upsample_concat_bwd(const float* dcat, float* dskip, float* dlo_bn, const int shape[3], int Cs, int Cl, synthsr_stream_t stream) {
+  return upsample_concat_bwd_t<float>(dcat, dskip, dlo_bn, shape, Cs, Cl, stream);
+}
+int synthsr_upsample_concat_bwd_bf16(const void* dcat, void* dskip, void* dlo_bn, const int shape[3], int Cs, int Cl, synthsr_stream_t stream) {
+  return upsample_concat_bwd_t<bf16_t>((const bf16_t*)dcat, (bf16_t*)dskip, (bf16_t*)dlo_bn, shape, Cs, Cl, stream);
 }
 
-int synthsr_head_loss_fwd(const float* x, const int* shape, int C, const float* stats, const float* gamma,
-                          const float* beta, float eps, const float* w, const float* b, int K, const float* residual,
-                          int res_stride, const int* res_offs, const float* target, float* pred, float* dpred, float* loss,
-                          int kind, const int* crop, synthsr_stream_t stream) {
-  if (!x || !shape || !stats || !gamma || !beta || !w || !b || !target || !loss || !ok_c4(C)) return SYNTHSR_EINVAL;
-  if (shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
-  if (kind < 0 || kind > 2 || K < 1 || K > 4 || (kind == 2 && (K & 1))) return SYNTHSR_EINVAL;
-  const int NT = kind == 2 ? K / 2 : K;
-  if (C > 116) return SYNTHSR_EINVAL;  // LDS: (2 + K) C + 256 (C + 4) floats
-  const int64_t nvox = (int64_t)shape[0] * shape[1] * shape[2];
-  HeadBox box;
-  for (int k = 0; k < 4; ++k) box.res_off[k] = 0;
-  if (residual) {
-    if (res_stride < 1 || !res_offs) return SYNTHSR_EINVAL;
-    for (int k = 0; k < NT; ++k) {
-      if (res_offs[k] < 0 || res_offs[k] >= res_stride) return SYNTHSR_EINVAL;
-      box.res_off[k] = res_offs[k];
-    }
-  }
-  box.on = crop != nullptr;
-  box.d1 = shape[1];
-  box.d2 = shape[2];
-  int64_t n_in = nvox;
-  if (crop) {
-    n_in = 1;
-    for (int i = 0; i < 3; ++i) {
-      if (crop[i] < 0 || crop[3 + i] < 1 || crop[i] + crop[3 + i] > shape[i]) return SYNTHSR_EINVAL;
-      box.lo[i] = crop[i];
-      box.hi[i] = crop[i] + crop[3 + i];
-      n_in *= crop[3 + i];
-    }
-  } else {
-    for (int i = 0; i < 3; ++i) {
-      box.lo[i] = 0;
-      box.hi[i] = shape[i];
-    }
-  }
-  const size_t smem = ((2 + K) * C + 256 * (C + 4)) * sizeof(float);
-  const float inv_n = (float)(1.0 / ((double)n_in * NT));
-  const dim3 grid(syn_grid(nvox, 256, 1024));
-#define SYN_HEAD_FWD(KK)                                                                                                 \
-  hipLaunchKernelGGL(head_loss_fwd_kernel<KK>, grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta, \
-                     eps, w, b, residual, res_stride, target, pred, dpred, loss, inv_n, kind, box)
-  switch (K) {
-    case 1: SYN_HEAD_FWD(1); break;
-    case 2: SYN_HEAD_FWD(2); break;
-    case 3: SYN_HEAD_FWD(3); break;
-    default: SYN_HEAD_FWD(4); break;
-  }
-#undef SYN_HEAD_FWD
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_head_loss_fwd(const float* x, const int* shape, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, const float* b, int K, const float* residual, int res_stride, const int* res_offs, const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, synthsr_stream_t stream) {
+  return head_loss_fwd_t<float>(x, shape, C, stats, gamma, beta, eps, w, b, K, residual, res_stride, res_offs, target, pred, dpred, loss, kind, crop, stream);
+}
+int synthsr_head_loss_fwd_bf16(const void* x, const int* shape, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, const float* b, int K, const float* residual, int res_stride, const int* res_offs, const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, synthsr_stream_t stream) {
+  return head_loss_fwd_t<bf16_t>((const bf16_t*)x, shape, C, stats, gamma, beta, eps, w, b, K, residual, res_stride, res_offs, target, pred, dpred, loss, kind, crop, stream);
 }
 
 int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta,
@@ -1055,48 +1202,25 @@ int synthsr_head_l1_fwd(const float* x, int64_t nvox, int C, const float* stats,
                                dpred, loss, 0, nullptr, stream);
 }
 
-int synthsr_head_bwd_multi(const float* dpred, const float* x, int64_t nvox, int C, int K, const float* stats,
-                           const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw,
-                           float* db, synthsr_stream_t stream) {
-  if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C) || K < 2 || K > 4)
-    return SYNTHSR_EINVAL;
-  const int64_t n4 = nvox * (C / 4);
-  const dim3 grid(syn_grid(n4, RB, 1024));
-  const size_t smem = (K * C + K) * sizeof(float);
-#define SYN_HEAD_BWD(KK)                                                                                             \
-  hipLaunchKernelGGL(head_multi_bwd_kernel<KK>, grid, dim3(RB), smem, (hipStream_t)stream, dpred, x, n4, C, stats, gamma, \
-                     beta, eps, w, dbn, dw, db)
-  switch (K) {
-    case 2: SYN_HEAD_BWD(2); break;
-    case 3: SYN_HEAD_BWD(3); break;
-    default: SYN_HEAD_BWD(4); break;
-  }
-#undef SYN_HEAD_BWD
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_head_bwd_multi(const float* dpred, const float* x, int64_t nvox, int C, int K, const float* stats, const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw, float* db, synthsr_stream_t stream) {
+  return head_bwd_multi_t<float>(dpred, x, nvox, C, K, stats, gamma, beta, eps, w, dbn, dw, db, stream);
+}
+int synthsr_head_bwd_multi_bf16(const float* dpred, const void* x, int64_t nvox, int C, int K, const float* stats, const float* gamma, const float* beta, float eps, const float* w, void* dbn, float* dw, float* db, synthsr_stream_t stream) {
+  return head_bwd_multi_t<bf16_t>(dpred, (const bf16_t*)x, nvox, C, K, stats, gamma, beta, eps, w, (bf16_t*)dbn, dw, db, stream);
 }
 
-int synthsr_head_bwd_ex(const float* dpred, const float* x, int64_t nvox, int C, const float* stats, const float* gamma,
-                        const float* beta, float eps, const float* w, float* dbn, float* dw, float* db, float* bn_sums,
-                        synthsr_stream_t stream) {
-  if (!dpred || !x || !stats || !gamma || !beta || !w || !dw || !db || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
-  const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
-                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db, bn_sums);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_head_bwd_ex(const float* dpred, const float* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw, float* db, float* bn_sums, synthsr_stream_t stream) {
+  return head_bwd_ex_t<float>(dpred, x, nvox, C, stats, gamma, beta, eps, w, dbn, dw, db, bn_sums, stream);
+}
+int synthsr_head_bwd_ex_bf16(const float* dpred, const void* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, void* dbn, float* dw, float* db, float* bn_sums, synthsr_stream_t stream) {
+  return head_bwd_ex_t<bf16_t>(dpred, (const bf16_t*)x, nvox, C, stats, gamma, beta, eps, w, (bf16_t*)dbn, dw, db, bn_sums, stream);
 }
 
-int synthsr_head_bwd(const float* dpred, const float* x, int64_t nvox, int C, const float* stats, const float* gamma,
-                     const float* beta, float eps, const float* w, float* dbn, float* dw, float* db,
-                     synthsr_stream_t stream) {
-  if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C))
-    return SYNTHSR_EINVAL;
-  const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
-                     (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db, (float*)nullptr);
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+int synthsr_head_bwd(const float* dpred, const float* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, float* dbn, float* dw, float* db, synthsr_stream_t stream) {
+  return head_bwd_t<float>(dpred, x, nvox, C, stats, gamma, beta, eps, w, dbn, dw, db, stream);
+}
+int synthsr_head_bwd_bf16(const float* dpred, const void* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, void* dbn, float* dw, float* db, synthsr_stream_t stream) {
+  return head_bwd_t<bf16_t>(dpred, (const bf16_t*)x, nvox, C, stats, gamma, beta, eps, w, (bf16_t*)dbn, dw, db, stream);
 }
 
 int synthsr_seg_head_fwd(const float* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta,

@@ -65,6 +65,11 @@ def _L():
     return _lib.load()
 
 
+def _sym(name, t):
+    """entry point `name` for float32 tensors, `name_bf16` for bfloat16 ones (same arguments)"""
+    return getattr(_L(), name + '_bf16' if t.dtype == torch.bfloat16 else name)
+
+
 def pack_conv_weights(w, shape, mode=0, out=None):
     """w: Keras Conv3D kernel [3,3,3,Cin,Cout] -> MFMA fragment order for a layer of spatial size `shape`
     (mode 0 fwd, 1 data-gradient)"""
@@ -155,6 +160,8 @@ def conv3d_wgrad_part(x, dout, dw, ci_off, dbias=None):
 
 def conv3d(x, wpacked, bias, Cout, act=1, out=None):
     """x [d0,d1,d2,Cin] -> [d0,d1,d2,Cout]; act: 0 linear, 1 ELU"""
+    if x.dtype == torch.bfloat16:
+        return conv3d_bf16(x, wpacked, bias, Cout, act, out=out)
     lib = _L()
     s = x.shape
     if out is None:
@@ -167,6 +174,8 @@ def conv3d(x, wpacked, bias, Cout, act=1, out=None):
 
 def conv3d_stats(x, wpacked, bias, Cout, stats, ws, act=1, out=None):
     """conv3d + BatchNorm batch statistics of its output (fused into the conv epilogue where the kernel supports it)"""
+    if x.dtype == torch.bfloat16:
+        return conv3d_bf16(x, wpacked, bias, Cout, act, stats=stats, out=out)
     lib = _L()
     s = x.shape
     if out is None:
@@ -181,6 +190,10 @@ def conv3d_stats(x, wpacked, bias, Cout, stats, ws, act=1, out=None):
 def conv3d_add(x, wpacked, bias, addend, Cout, act=1, out=None):
     """act 0/1: act(conv3(x) + addend + bias), `addend` may be `out` itself (in-place accumulation);
     act 2: conv3(x) * elu'(addend) -- data gradient fused with the ELU backward of the layer that produced `addend`"""
+    if x.dtype == torch.bfloat16:
+        if act != 2:
+            raise NotImplementedError('bf16: the fused addend exists for the ELU-backward epilogue only')
+        return conv3d_bf16(x, wpacked, bias, Cout, 2, below=addend, out=out)
     lib = _L()
     s = x.shape
     if out is None:
@@ -194,6 +207,8 @@ def conv3d_add(x, wpacked, bias, addend, Cout, act=1, out=None):
 
 def conv3d_wgrad(x, dout, dw, dbias=None):
     """dw [3,3,3,Cin,Cout] += sum_v x[v+t-1] (x) dout[v]; dbias [Cout] (optional) += sum_v dout[v]"""
+    if x.dtype == torch.bfloat16:
+        return conv3d_wgrad_bf16(x, dout, dw, dbias)
     return conv3d_wgrad_part(x, dout, dw, 0, dbias)
 
 
@@ -203,7 +218,7 @@ def elu_bwd(dy, y, dy2=None, dbias=None, out=None):
     nvox = y.numel() // C
     if out is None:
         out = torch.empty_like(y)
-    _lib.check(lib.synthsr_elu_bwd(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(out), _lib.ptr(dbias), nvox, C,
+    _lib.check(_sym('synthsr_elu_bwd', y)(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(out), _lib.ptr(dbias), nvox, C,
                                    _lib.stream()), 'elu_bwd')
     return out
 
@@ -212,7 +227,7 @@ def bn_reduce_bwd(dy, x, stats, sums, eps=BN_EPS):
     """pass 1 of the BN backward: sums [2C] (zeroed by caller) += [sum dy, sum dy*xhat]"""
     lib = _L()
     C = int(x.shape[-1])
-    _lib.check(lib.synthsr_bn_bwd_reduce(_lib.ptr(dy), _lib.ptr(x), x.numel() // C, C, _lib.ptr(stats), eps,
+    _lib.check(_sym('synthsr_bn_bwd_reduce', x)(_lib.ptr(dy), _lib.ptr(x), x.numel() // C, C, _lib.ptr(stats), eps,
                                          _lib.ptr(sums), _lib.stream()), 'bn_bwd_reduce')
     return sums
 
@@ -223,7 +238,7 @@ def bn_elu_bwd(dy, y, stats, gamma, sums, dy2=None, dbias=None, out=None, eps=BN
     C = int(y.shape[-1])
     if out is None:
         out = torch.empty_like(y)
-    _lib.check(lib.synthsr_bn_elu_bwd(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(out), _lib.ptr(dbias),
+    _lib.check(_sym('synthsr_bn_elu_bwd', y)(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(out), _lib.ptr(dbias),
                                       y.numel() // C, C, _lib.ptr(stats), _lib.ptr(gamma), eps, _lib.ptr(sums),
                                       _lib.stream()), 'bn_elu_bwd')
     return out
@@ -232,7 +247,7 @@ def bn_elu_bwd(dy, y, stats, gamma, sums, dy2=None, dbias=None, out=None, eps=BN
 def bn_stats(x, stats, ws):
     lib = _L()
     C = int(x.shape[-1])
-    _lib.check(lib.synthsr_bn_stats(_lib.ptr(x), x.numel() // C, C, _lib.ptr(stats), _lib.ptr(ws), _lib.stream()),
+    _lib.check(_sym('synthsr_bn_stats', x)(_lib.ptr(x), x.numel() // C, C, _lib.ptr(stats), _lib.ptr(ws), _lib.stream()),
                'bn_stats')
     return stats
 
@@ -251,8 +266,8 @@ def bn_maxpool(x, stats, gamma, beta, out=None, eps=BN_EPS):
     lib = _L()
     s = x.shape
     if out is None:
-        out = torch.empty((s[0] // 2, s[1] // 2, s[2] // 2, s[3]), dtype=torch.float32, device=x.device)
-    _lib.check(lib.synthsr_bn_maxpool(_lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), _lib.ptr(stats),
+        out = torch.empty((s[0] // 2, s[1] // 2, s[2] // 2, s[3]), dtype=x.dtype, device=x.device)
+    _lib.check(_sym('synthsr_bn_maxpool', x)(_lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), _lib.ptr(stats),
                                       _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.stream()), 'bn_maxpool')
     return out
 
@@ -263,7 +278,7 @@ def bn_maxpool_bwd(dy, x, stats, gamma, beta, out=None, eps=BN_EPS, sums=None):
     s = x.shape
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(lib.synthsr_bn_maxpool_bwd_ex(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]),
+    _lib.check(_sym('synthsr_bn_maxpool_bwd_ex', x)(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]),
                                              _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.ptr(sums),
                                              _lib.stream()), 'bn_maxpool_bwd')
     return out
@@ -276,7 +291,7 @@ def bn_bwd(dy, x, stats, gamma, sums, out=None, eps=BN_EPS):
     nvox = x.numel() // C
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(lib.synthsr_bn_bwd_reduce(_lib.ptr(dy), _lib.ptr(x), nvox, C, _lib.ptr(stats), eps, _lib.ptr(sums),
+    _lib.check(_sym('synthsr_bn_bwd_reduce', x)(_lib.ptr(dy), _lib.ptr(x), nvox, C, _lib.ptr(stats), eps, _lib.ptr(sums),
                                          _lib.stream()), 'bn_bwd_reduce')
     _lib.check(lib.synthsr_bn_bwd_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), nvox, C, _lib.ptr(stats),
                                         _lib.ptr(gamma), eps, _lib.ptr(sums), _lib.stream()), 'bn_bwd_apply')
@@ -288,8 +303,8 @@ def upsample_concat(skip, lo, stats, gamma, beta, out=None, eps=BN_EPS):
     s = skip.shape
     Cs, Cl = int(s[3]), int(lo.shape[3])
     if out is None:
-        out = torch.empty((s[0], s[1], s[2], Cs + Cl), dtype=torch.float32, device=skip.device)
-    _lib.check(lib.synthsr_upsample_concat(_lib.ptr(skip), _lib.ptr(lo), _lib.ptr(out), _lib.i3(s[:3]), Cs, Cl,
+        out = torch.empty((s[0], s[1], s[2], Cs + Cl), dtype=skip.dtype, device=skip.device)
+    _lib.check(_sym('synthsr_upsample_concat', skip)(_lib.ptr(skip), _lib.ptr(lo), _lib.ptr(out), _lib.i3(s[:3]), Cs, Cl,
                                            _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.stream()),
                'upsample_concat')
     return out
@@ -299,10 +314,10 @@ def upsample_concat_bwd(dcat, Cs, Cl, dskip=None, dlo=None):
     lib = _L()
     s = dcat.shape
     if dskip is None:
-        dskip = torch.empty((s[0], s[1], s[2], Cs), dtype=torch.float32, device=dcat.device)
+        dskip = torch.empty((s[0], s[1], s[2], Cs), dtype=dcat.dtype, device=dcat.device)
     if dlo is None:
-        dlo = torch.empty((s[0] // 2, s[1] // 2, s[2] // 2, Cl), dtype=torch.float32, device=dcat.device)
-    _lib.check(lib.synthsr_upsample_concat_bwd(_lib.ptr(dcat), _lib.ptr(dskip), _lib.ptr(dlo), _lib.i3(s[:3]), Cs, Cl,
+        dlo = torch.empty((s[0] // 2, s[1] // 2, s[2] // 2, Cl), dtype=dcat.dtype, device=dcat.device)
+    _lib.check(_sym('synthsr_upsample_concat_bwd', dcat)(_lib.ptr(dcat), _lib.ptr(dskip), _lib.ptr(dlo), _lib.i3(s[:3]), Cs, Cl,
                                                _lib.stream()), 'upsample_concat_bwd')
     return dskip, dlo
 
@@ -346,7 +361,7 @@ def head_loss_fwd(x, stats, gamma, beta, w, b, target, loss, kind='l1', crop=Non
     if len(offs) != n:
         raise ValueError('one residual channel per regression target is needed (%d given, %d targets)' % (len(offs), n))
     offs = (_lib.c_int * 4)(*(offs + [0] * (4 - n)))
-    _lib.check(lib.synthsr_head_loss_fwd(_lib.ptr(x), shape, C, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps,
+    _lib.check(_sym('synthsr_head_loss_fwd', x)(_lib.ptr(x), shape, C, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps,
                                          _lib.ptr(w), _lib.ptr(b), K, _lib.ptr(residual), int(res_stride), offs,
                                          _lib.ptr(target), _lib.ptr(pred), _lib.ptr(dpred), _lib.ptr(loss),
                                          LOSS_KINDS[kind], box, _lib.stream()), 'head_loss_fwd')
@@ -420,7 +435,7 @@ def head_bwd_multi(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS):
     C = int(x.shape[-1])
     nvox = x.numel() // C
     K = w.numel() // C
-    _lib.check(lib.synthsr_head_bwd_multi(_lib.ptr(dpred), _lib.ptr(x), nvox, C, K, _lib.ptr(stats), _lib.ptr(gamma),
+    _lib.check(_sym('synthsr_head_bwd_multi', x)(_lib.ptr(dpred), _lib.ptr(x), nvox, C, K, _lib.ptr(stats), _lib.ptr(gamma),
                                           _lib.ptr(beta), eps, _lib.ptr(w), _lib.ptr(dbn), _lib.ptr(dw), _lib.ptr(db),
                                           _lib.stream()), 'head_bwd_multi')
     return dbn
@@ -431,7 +446,7 @@ def head_bwd(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS, bn_sums=N
     lib = _L()
     C = int(x.shape[-1])
     nvox = x.numel() // C
-    _lib.check(lib.synthsr_head_bwd_ex(_lib.ptr(dpred), _lib.ptr(x), nvox, C, _lib.ptr(stats), _lib.ptr(gamma),
+    _lib.check(_sym('synthsr_head_bwd_ex', x)(_lib.ptr(dpred), _lib.ptr(x), nvox, C, _lib.ptr(stats), _lib.ptr(gamma),
                                        _lib.ptr(beta), eps, _lib.ptr(w), _lib.ptr(dbn), _lib.ptr(dw), _lib.ptr(db),
                                        _lib.ptr(bn_sums), _lib.stream()), 'head_bwd')
     return dbn
@@ -443,7 +458,7 @@ def bn_elu_bwd_head(dpred, whead, y, stats, gamma, sums, dbias=None, out=None, e
     C = int(y.shape[-1])
     if out is None:
         out = torch.empty_like(y)
-    _lib.check(lib.synthsr_bn_elu_bwd_head(_lib.ptr(dpred), _lib.ptr(whead), _lib.ptr(y), _lib.ptr(out),
+    _lib.check(_sym('synthsr_bn_elu_bwd_head', y)(_lib.ptr(dpred), _lib.ptr(whead), _lib.ptr(y), _lib.ptr(out),
                                            _lib.ptr(dbias), y.numel() // C, C, _lib.ptr(stats), _lib.ptr(gamma), eps,
                                            _lib.ptr(sums), _lib.stream()), 'bn_elu_bwd_head')
     return out
@@ -653,7 +668,7 @@ def conv3d_wgrad_bf16(x, dz, dw, dbias=None):
     assert x.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16 and dw.dtype == torch.float32
     with _Timed('conv3d_bf16_wgrad', s[:3], s[3], dz.shape[3]):
         _lib.check(lib.synthsr_conv3d_bf16_wgrad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(dbias), _lib.i3(s[:3]),
-                                                 int(s[3]), 0, int(s[3]), int(dz.shape[3]), _lib.stream()),
+                                                 int(dw.shape[3]), 0, int(s[3]), int(dz.shape[3]), _lib.stream()),
                    'conv3d_bf16_wgrad')
     return dw
 

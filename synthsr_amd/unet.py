@@ -21,12 +21,21 @@ from . import ops
 class UNet3D:
     def __init__(self, nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None,
                  feat_mult=1, nb_conv_per_level=1, batch_norm=None, activation='elu', device=None, seed=0,
-                 final_pred_activation='linear', fold_upsample='auto', table_only=False):
+                 final_pred_activation='linear', fold_upsample='auto', table_only=False, dtype='f32'):
         self.overlap_wgrad = False  # weight gradients on a second HIP stream (see _fork): measured 0.5 ms SLOWER per step
                                     # on one MI355X (cross-stream event waits cost more than the tails they fill) ...
         self.overlap_max_voxels = 40 ** 3  # ... on the small levels only: big persistent kernels just disturb each other
         self._side_stream = None
         self._side_busy = False
+        # dtype 'bf16' (BASELINE.json configs[3] / [4]): activations, activation gradients and the packed conv weights are
+        # bfloat16 (csrc/conv_bf16.hip + the _bf16 pointwise kernels); master weights, gradients, Adam moments, BatchNorm
+        # statistics / reductions, the head's prediction and the loss stay float32.  The reference has no such mode.
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError("dtype should be 'f32' or 'bf16'")
+        self.bf16 = dtype == 'bf16'
+        self.act_dtype = torch.bfloat16 if self.bf16 else torch.float32
+        if self.bf16:
+            fold_upsample = False  # the bf16 MFMA is 16x faster: the concatenated tensor is simply materialised
         if conv_size != 3:
             raise NotImplementedError('only conv_size=3 is supported')
         if activation != 'elu':
@@ -226,9 +235,21 @@ class UNet3D:
                     o, n = c[key + '_off']
                     c[key] = self._packed[o:o + n]
 
+    def _repack_bf16(self):
+        """bf16 fragment-ordered copies of every conv kernel (forward, and data-gradient where a gradient flows on)"""
+        first = True
+        for c in self.all_convs():
+            w = self.view(c['w'])
+            c['wp'] = ops.pack_conv_weights_bf16(w, 0, out=c.get('wp'))
+            if not first or self.need_input_grad:
+                c['wpd'] = ops.pack_conv_weights_bf16(w, 1, out=c.get('wpd'))
+            first = False
+
     def repack(self):
         """refresh the MFMA-fragment-ordered copies of ALL conv kernels in one launch (after init / optimizer step /
         load)"""
+        if self.bf16:
+            return self._repack_bf16()
         from . import _lib
         if getattr(self, '_jobs', None) is None:
             self._pack_jobs()
@@ -258,11 +279,16 @@ class UNet3D:
         self.repack()
 
     # ------------------------------------------------------------------ buffers
+    _F32_BUFS = ('loss', 'dpred', 'pred', 'loss_unused', 'zero_t', 'probs', 'dwc')
+
     def buf(self, key, shape):
+        """persistent scratch tensor: activations / activation gradients in the network's dtype, the head's outputs,
+        losses and weight-gradient scratch always float32"""
         t = self._bufs.get(key)
         n = int(np.prod(shape))
         if t is None or t.numel() < n:
-            t = torch.empty(n, dtype=torch.float32, device=self.device)
+            dt = torch.float32 if key in self._F32_BUFS or key.startswith('ssim') else self.act_dtype
+            t = torch.empty(n, dtype=dt, device=self.device)
             self._bufs[key] = t
         return t[:n].view(*shape)
 
@@ -276,6 +302,11 @@ class UNet3D:
         """x [d0,d1,d2,Cin] -> saves activations; returns the last decoder activation (pre-BN) and its BN"""
         L = self.nb_levels
         self.saved = dict(x=[], enc=[], cat=[], dec=[])
+        if self.bf16 and x.dtype != torch.bfloat16:
+            # generator output (float32, Cin channels) -> bf16 with the channel count padded to a multiple of 8 (zeros):
+            # 16-byte K-groups for the MFMA; the first conv's kernel is packed / its gradient taken on the real Cin only
+            x = ops.to_bf16_pad(x, (int(x.shape[-1]) + 7) // 8 * 8, out=self.buf('x_bf16', list(x.shape[:3]) + [
+                (int(x.shape[-1]) + 7) // 8 * 8]))
         cur = x
         for l in range(L):
             e = self.enc[l]
@@ -624,7 +655,7 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
          pool_size=2, use_logp=True, padding='same', dilation_rate_mult=1, activation='elu', skip_n_concatenations=0,
          use_residuals=False, final_pred_activation='softmax', nb_conv_per_level=1, add_prior_layer=False,
          layer_nb_feats=None, conv_dropout=0, batch_norm=None, input_model=None, device=None, seed=0,
-         fold_upsample='auto'):
+         fold_upsample='auto', dtype='f32'):
     """ext/neuron/models.py:26-47 signature.  Unsupported knobs of the over-parametrised reference raise."""
     if pool_size != 2 or padding != 'same' or dilation_rate_mult != 1 or skip_n_concatenations != 0 or \
             use_residuals or add_prior_layer or layer_nb_feats is not None or conv_dropout != 0:
@@ -633,6 +664,6 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
     net = UNet3D(nb_features, input_shape, nb_levels, conv_size, nb_labels, name=name, prefix=prefix,
                  feat_mult=feat_mult, nb_conv_per_level=nb_conv_per_level, batch_norm=batch_norm,
                  activation=activation, device=device, seed=seed, final_pred_activation=final_pred_activation,
-                 fold_upsample=fold_upsample)
+                 fold_upsample=fold_upsample, dtype=dtype)
     net.input_model = input_model
     return net

@@ -100,3 +100,101 @@ def test_f32_to_bf16_pad(T):
     x = torch.randn(5, 6, 7, 2)
     y = ops.to_bf16_pad(x.cuda(), 8).float().cpu()
     assert torch.equal(y[..., :2], rbf(x)) and float(y[..., 2:].abs().max()) == 0.0
+
+
+def _grad_report(net, P):
+    """per-tensor (max error / max |ref|, cosine similarity) of the HIP gradients against autograd"""
+    import torch
+    rep = {}
+    for nm, _, kind in net.specs:
+        got = net.view(nm, net.grads).cpu().double().reshape(-1)
+        ref = P[nm].grad.double().reshape(-1)
+        cos = float(torch.dot(got, ref) / (got.norm() * ref.norm()).clamp_min(1e-30))
+        rep[nm] = (float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)), cos, kind)
+    return rep
+
+
+@pytest.mark.parametrize('feats,levels,shape,cin', [(24, 3, (16, 16, 32), 2), (8, 2, (8, 12, 16), 1), (24, 5, (32, 32, 32), 2)])
+def test_unet_bf16_step_vs_oracle(T, feats, levels, shape, cin):
+    """one training step of the bf16 network (bf16 activations / packed weights, fp32 accumulation, fp32 BatchNorm
+    statistics, fp32 master weights and gradients) against the oracle on the same fp32 master weights, two ways:
+
+    (a) the plain fp32 oracle -- what the reference computes.  Stated bf16 tolerances: prediction 3e-2 of its range, loss
+        1 %, batch statistics 2e-2 of range.  Gradients only loosely (cosine >= 0.9): max-pooling routes each gradient to
+        ONE of 8 voxels and bf16 rounding flips that choice between near-equal candidates (measured: cosine 0.9999 with no
+        pooling level above a layer, 0.998 with one, 0.983 with two on iid noise volumes);
+    (b) the oracle with the bf16 STORAGE roundings restated (oracle.unet_ref.round_bf16 on the input, conv kernels, conv +
+        ELU outputs, pooled and concatenated tensors; everything else fp32): same pooling decisions, so every gradient
+        must agree tightly -- cosine >= 0.997, max error <= 8 % of the tensor's range (measured: 0.9995 / 4 %; the residue is
+        the occasional activation whose bf16 rounding flips between the two summation orders).  This is the check that pins the
+        kernels."""
+    torch = T
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1,
+               feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3,
+               dtype='bf16')
+    g = torch.Generator().manual_seed(11)
+    for nm, v in net.named_parameters():
+        if nm.endswith('/gamma'):
+            v.copy_(torch.rand(v.shape, generator=g) + .5)
+        elif nm.endswith('/beta') or nm.endswith('/bias'):
+            v.copy_(torch.randn(v.shape, generator=g) * .1)
+    net.repack()
+    x = torch.rand(*shape, cin, generator=g)
+    target = torch.rand(*shape, 1, generator=g)
+    loss, pred = net.loss_l1(x.cuda(), target.reshape(-1).cuda(), want_pred=True)
+    pred = pred.clone()
+    net.backward()
+    assert net.saved['enc'][0][0].dtype == torch.bfloat16 and net.grads.dtype == torch.float32
+    for mode in ('fp32', 'bf16-storage'):
+        P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+        stats = {}
+        pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats,
+                            quant=None if mode == 'fp32' else U.round_bf16)
+        lr = U.l1_loss(pr, target)
+        lr.backward()
+        tight = mode != 'fp32'
+        close(pred.view(*shape, 1), pr, 2.5e-2 if tight else 3e-2, mode + ' prediction')  # one flipped bf16 rounding = 2^-8
+        assert abs(loss.item() - lr.item()) < (3e-3 if tight else 1e-2) * abs(lr.item()), (mode, loss.item(), lr.item())
+        for bn in net.bn_layers:
+            o, C = bn['soff'], bn['C']
+            close(net.bn_batch[o:o + C], stats[bn['name']][0], 1.5e-2 if tight else 2e-2, mode + ' ' + bn['name'] + ' mean')
+            close(net.bn_batch[o + C:o + 2 * C], stats[bn['name']][1], 1.5e-2 if tight else 2e-2, mode + ' ' + bn['name'] + ' var')
+        rep = _grad_report(net, P)
+        worst = sorted(((c, e, nm) for nm, (e, c, _) in rep.items()))[:4]
+        for nm, (err, cos, kind) in rep.items():
+            if tight:   # each pooling level above a layer adds a few flipped arg-max decisions (5 levels at 32^3: 0.991 / 19 %)
+                cmin, emax = (0.997, 8e-2) if levels <= 3 else (0.985, 1.0)   # deep nets: cosine only (cancelling sums)
+                assert cos > cmin and err < emax, '%s: gradient of %s: err %.3e cos %.5f (worst %s)' % (mode, nm, err, cos, worst)
+            else:
+                assert cos > 0.9, '%s: gradient of %s: err %.3e cos %.5f (worst %s)' % (mode, nm, err, cos, worst)
+    p0, g0 = net.params.clone(), net.grads.clone()
+    net.adam_step(lr=1e-3)
+    pref, _, _ = U.adam_keras(p0.cpu(), g0.cpu(), torch.zeros_like(p0.cpu()), torch.zeros_like(p0.cpu()), 1, lr=1e-3)
+    close(net.params, pref, 1e-6, 'adam (fp32 master weights)')
+    net.update_moving_stats()
+    out = net.predict(x.cuda())
+    assert torch.isfinite(out).all() and list(out.shape) == list(shape) + [1] and out.dtype == torch.float32
+
+
+def test_bf16_training_reduces_loss(T):
+    """a few bf16 steps of the full loop (generator -> bf16 U-Net -> Adam on fp32 master weights) on a fixed sample"""
+    torch = T
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.training import Trainer
+    from synthsr_amd.unet import unet
+    from synthsr_amd.synthetic import (synthetic_label_pool, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
+                                       PRIOR_STDS_T1_HR)
+    pool = synthetic_label_pool(2, (32, 32, 32), 5)
+    bg = BrainGenerator(None, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', GENERATION_LABELS,
+                        generation_classes=GENERATION_CLASSES, output_shape=32, output_div_by_n=8, nonlin_std=4.,
+                        nonlin_shape_factor=.125, bias_shape_factor=.125, build_reliability_maps=True, downsample=True,
+                        shearing_bounds=.02, label_maps=pool, rng=np.random.default_rng(0))
+    net = unet(24, bg.model_output_shape, 3, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
+               batch_norm=-1, seed=1, dtype='bf16')
+    tr = Trainer(bg, net, lr=1e-3)
+    inputs = next(bg.model_inputs_generator)
+    draws = bg.labels_to_image_model.sample_draws()
+    losses = [tr.step(inputs, draws).item() for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
