@@ -258,8 +258,9 @@ int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, in
                                  synthsr_stream_t stream);
 /* out = act(conv3(in) + bias); act 0 linear, 1 ELU, 2 multiply by ELU'(below) (data gradient fused with the ELU backward
  * of the layer below; below = that layer's ELU output [vox][Cout]).  stats != NULL: BatchNorm batch statistics
- * [mean Cout | var Cout] of the (bf16-rounded) output, accumulated in fp32 / double through `scratch`
- * (>= synthsr_conv3d_bf16_stats_scratch floats) */
+ * [mean Cout | var Cout] of the (bf16-rounded) output, accumulated in fp32 / double.  `scratch` (>=
+ * synthsr_conv3d_bf16_stats_scratch floats; may be NULL when no statistics are wanted) also holds the fp32 partial sums
+ * of the split-K path that small volumes take */
 int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, void* out, const int shape[3], int Cin,
                             int Cout, int act, const void* below, float* stats, float* scratch, int64_t scratch_floats,
                             synthsr_stream_t stream);

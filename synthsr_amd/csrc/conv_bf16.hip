@@ -21,6 +21,7 @@
 //       blocks (+ one constant-1 block = dbias) fill the tiles to 99 %; the 4 waves split the row tiles and walk all 256
 //       voxels of the tile, 32 per MFMA; fp32 atomics flush once per workgroup.
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -35,7 +36,10 @@ typedef uint16_t bf16_t;
 constexpr int TZ = 4, TY = 4, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HVOX = HZ * HY * HX;
 constexpr uint32_t OOB = 0x80000000u;
 
-__host__ __device__ constexpr int rowb_for(int ck) { return ck == 8 ? 48 : 80; }  // LDS row stride: odd multiple of 16 B
+// LDS row strides (bytes), odd multiples of 16 B so that the 16 lanes of an x-row hit 16 different bank quads.
+// weight gradient: room for CK channels + the constant-1 pad block; forward: no pad needed (24 ch = 48 B = 3 quads)
+__host__ __device__ constexpr int rowb_for(int ck) { return ck == 8 ? 48 : 80; }
+__host__ __device__ constexpr int rowb_fwd(int ck) { return ck == 8 ? 16 : (ck == 24 ? 48 : 80); }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -119,13 +123,18 @@ struct FwdArgs {
   bf16_t* out;
   const bf16_t* below;   // act == 2: ELU output of the layer below, [vox][CoutE]
   float* stats_partial;  // [gridDim.x * gridDim.y][2][16 * MT] per-workgroup sums / sums of squares, or null
-  int D0, D1, D2, Cin, Cout, ncc, tiles1, tiles2, ntiles, act;
+  float* partial;        // split-K (small volumes): fp32 [vox][Cout] accumulated with atomics, epilogue in a second kernel
+  int D0, D1, D2, Cin, Cout, ncc, tiles1, tiles2, ntiles, act, ksplit;
 };
 
-template <int CK, int MT>
+// WLDS: the whole fragment-ordered weight set of this workgroup's (co-chunk, single ci-chunk) lives in LDS for the life of
+// the persistent workgroup (24 -> 24: 42 KB next to the 31 KB halo tile, 2 workgroups per CU) -- no global weight loads
+// in the K loop at all; otherwise fragments stream from L2 two K-steps ahead
+template <int CK, int MT, bool WLDS>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int C8 = CK / 8, ROWB = rowb_for(CK), NSTEP = (27 * C8 + 3) / 4;
+  constexpr int C8 = CK / 8, ROWB = rowb_fwd(CK), NSTEP = (27 * C8 + 3) / 4;
+  constexpr int HBYTES = (HVOX * ROWB + 1023) / 1024 * 1024;  // halo image, then (WLDS) the weight fragments
   constexpr int NPIECE = HVOX * C8, NLD = (NPIECE + 255) / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
@@ -185,50 +194,81 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
   };
 
   const bf16x8* __restrict__ wfrag = reinterpret_cast<const bf16x8*>(a.wp) + (int64_t)chunk * a.ncc * NSTEP * MT * 64 + lane;
+  if constexpr (WLDS) {  // ncc == 1 (checked by the launcher): one fragment set, copied once
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.wp) + (int64_t)chunk * NSTEP * MT * 64;
+    for (int i = tid; i < NSTEP * MT * 64; i += 256) *reinterpret_cast<u32x4*>(lds + HBYTES + i * 16) = src[i];
+  }
+  float bias_r[MT][4];  // this lane's 4 output channels per co-tile (tile-invariant)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = (chunk * MT + mt) * 16 + 4 * g + i;
+      bias_r[mt][i] = (a.bias && co < Cout) ? a.bias[co] : 0.f;
+    }
   float s1[MT][4], s2[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int i = 0; i < 4; ++i) s1[mt][i] = s2[mt][i] = 0.f;
 
-  if (my_pos < a.ntiles) load_halo(my_pos, 0);
+  // split-K: slice blockIdx.z of the input-channel chunks (ksplit == 1: all of them)
+  const int cc_lo = (int)(((int64_t)blockIdx.z * a.ncc) / a.ksplit), cc_hi = (int)(((int64_t)(blockIdx.z + 1) * a.ncc) / a.ksplit);
+  if (my_pos < a.ntiles) load_halo(my_pos, cc_lo);
   for (int t = my_pos; t < a.ntiles; t += G) {
     f32x4 acc[TY][MT];
 #pragma unroll
     for (int y = 0; y < TY; ++y)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cc = 0; cc < a.ncc; ++cc) {
+    for (int cc = cc_lo; cc < cc_hi; ++cc) {
       __syncthreads();  // everyone is done reading the previous image
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
         if (i < NLD - 1 || tid + 256 * i < NPIECE) *reinterpret_cast<u32x4*>(lds + plds[i]) = stg[i];
       __syncthreads();
-      if (cc + 1 < a.ncc) {
+      if (cc + 1 < cc_hi) {
         load_halo(t, cc + 1);
       } else if (t + G < a.ntiles) {
-        load_halo(t + G, 0);
+        load_halo(t + G, cc_lo);
       }
       const bf16x8* wf = wfrag + (int64_t)cc * NSTEP * MT * 64;
-      bf16x8 wa[2][MT];
+      // software pipeline, pinned with sched_barriers (left alone, the scheduler re-uses ONE register set and waits for
+      // every LDS read and every weight load right where it is issued): weights two K-steps ahead (global / L2 latency),
+      // the halo-tile reads one step ahead (LDS latency), the 4 x MT MFMAs of the current step in between
+      bf16x8 wa[3][MT], xb[2][TY];
+      auto wload = [&](auto SS, int mt) -> bf16x8 {
+        constexpr int ss = decltype(SS)::value;
+        if constexpr (WLDS) return *reinterpret_cast<const bf16x8*>(lds + HBYTES + ((ss * MT) * 64 + lane) * 16 + mt * 1024);
+        else return wf[(ss * MT + mt) * 64];
+      };
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) wa[0][mt] = wf[mt * 64];
+      for (int mt = 0; mt < MT; ++mt) {
+        wa[0][mt] = wload(std::integral_constant<int, 0>{}, mt);
+        if constexpr (NSTEP > 1) wa[1][mt] = wload(std::integral_constant<int, 1>{}, mt);
+      }
+#pragma unroll
+      for (int y = 0; y < TY; ++y) xb[0][y] = *reinterpret_cast<const bf16x8*>(lds + lbase + koff[0] + y * (HX * ROWB));
       sfor<0, NSTEP>([&](auto S) {
         constexpr int s = decltype(S)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s + 2 < NSTEP) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) wa[(s + 2) % 3][mt] = wload(std::integral_constant<int, s + 2>{}, mt);
+        }
         if constexpr (s + 1 < NSTEP) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) wa[(s + 1) & 1][mt] = wf[((s + 1) * MT + mt) * 64];
+          for (int y = 0; y < TY; ++y)
+            xb[(s + 1) & 1][y] = *reinterpret_cast<const bf16x8*>(lds + lbase + koff[s + 1] + y * (HX * ROWB));
         }
-        bf16x8 xb[TY];
-#pragma unroll
-        for (int y = 0; y < TY; ++y)
-          xb[y] = *reinterpret_cast<const bf16x8*>(lds + lbase + koff[s] + y * (HX * ROWB));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int y = 0; y < TY; ++y)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s & 1][mt], xb[y], acc[y][mt], 0, 0, 0);
+            acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s % 3][mt], xb[s & 1][y], acc[y][mt], 0, 0, 0);
       });
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue: lane (m = x, g): channels (chunk*MT + mt)*16 + 4g + i of voxel (z0 + wave, y0 + y, x0 + m)
     int z0, y0, x0;
@@ -243,9 +283,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
       for (int mt = 0; mt < MT; ++mt) {
         const int co = (chunk * MT + mt) * 16 + 4 * g;
         if (!vok || co >= Cout) continue;  // Cout is a multiple of 4
+        if (a.partial) {  // this K-slice's own fp32 plane: plain stores, summed by the epilogue kernel
+          *reinterpret_cast<f32x4*>(a.partial + ((int64_t)blockIdx.z * a.D0 * D1 * D2 + vox) * Cout + co) = acc[y][mt];
+          continue;
+        }
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = acc[y][mt][i] + (a.bias ? a.bias[co + i] : 0.f);
+        for (int i = 0; i < 4; ++i) v[i] = acc[y][mt][i] + bias_r[mt][i];
         if (a.act == 1) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
@@ -294,41 +338,117 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
   }
 }
 
-template <int CK, int MT>
-int launch_fwd(const FwdArgs& a0, int nchunks, hipStream_t st, int* wgs_out) {
-  FwdArgs a = a0;
+template <int CK, int MT, bool WLDS>
+int launch_fwd_w(const FwdArgs& a, int nchunks, hipStream_t st) {
   int gx = 512;
   while (gx > 8 && gx > a.ntiles) gx -= 8;
   if (a.ntiles < 8) gx = a.ntiles;
-  const size_t smem = (size_t)HVOX * rowb_for(CK);
-  auto kern = conv3d_bf16_fwd_kernel<CK, MT>;
+  constexpr int NSTEP = (27 * (CK / 8) + 3) / 4;
+  const size_t hbytes = ((size_t)HVOX * rowb_fwd(CK) + 1023) / 1024 * 1024;
+  const size_t smem = hbytes + (WLDS ? (size_t)NSTEP * MT * 1024 : 0);
+  auto kern = conv3d_bf16_fwd_kernel<CK, MT, WLDS>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  if (wgs_out) *wgs_out = gx * nchunks;
-  hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(gx, nchunks, a.ksplit), dim3(256), smem, st, a);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
+template <int CK, int MT>
+int launch_fwd(const FwdArgs& a, int nchunks, hipStream_t st, int* wgs_out) {
+  (void)wgs_out;
+  // weights in LDS when there is a single input-channel chunk and two workgroups still fit a CU (<= 80 KB each)
+  if constexpr (MT <= 2 && CK <= 24) {
+    if (a.ncc == 1 && a.ksplit == 1) return launch_fwd_w<CK, MT, true>(a, nchunks, st);
+  }
+  return launch_fwd_w<CK, MT, false>(a, nchunks, st);
+}
+
+// split-K epilogue: fp32 partial sums [n4 x 4] -> + bias, activation, bf16
+__global__ void bf16_epilogue_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                     const bf16_t* __restrict__ below, bf16_t* __restrict__ out, int64_t n4, int C4,
+                                     int act, int ksplit) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    float4 p = *reinterpret_cast<const float4*>(partial + i * 4);
+    for (int k = 1; k < ksplit; ++k) {  // fixed order: deterministic
+      const float4 q = *reinterpret_cast<const float4*>(partial + ((int64_t)k * n4 + i) * 4);
+      p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w;
+    }
+    float v[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += bias ? bias[c + k] : 0.f;
+    if (act == 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = elu_f(v[k]);
+    } else if (act == 2) {
+      const u32x2 b = *reinterpret_cast<const u32x2*>(below + i * 4);
+      v[0] *= elu_dy(bf2f(b.x & 0xffffu));
+      v[1] *= elu_dy(bf2f(b.x >> 16));
+      v[2] *= elu_dy(bf2f(b.y & 0xffffu));
+      v[3] *= elu_dy(bf2f(b.y >> 16));
+    }
+    u32x2 o;
+    o.x = pack2(v[0], v[1]);
+    o.y = pack2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(out + i * 4) = o;
+  }
+}
+
+// batch statistics of a small bf16 tensor [nvox][C]: one workgroup per channel (split-K path only)
+__global__ __launch_bounds__(256) void bf16_small_stats_kernel(const bf16_t* __restrict__ x, int64_t nvox, int C,
+                                                               float* __restrict__ stats) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t v = threadIdx.x; v < nvox; v += 256) {
+    const double t = (double)bf2f(x[v * C + c]);
+    s1 += t;
+    s2 += t * t;
+  }
+  __shared__ double r1[256], r2[256];
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      r1[threadIdx.x] += r1[threadIdx.x + o];
+      r2[threadIdx.x] += r2[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double m = r1[0] / (double)nvox;
+    double var = r2[0] / (double)nvox - m * m;
+    stats[c] = (float)m;
+    stats[C + c] = (float)(var < 0.0 ? 0.0 : var);
+  }
+}
+
 // per-workgroup partials [nwg][2][W] (W = 16*MT columns per co-chunk) -> stats[mean C | var C] (double accumulation)
-__global__ void bf16_stats_finalize_kernel(const float* __restrict__ partial, int gx, int nchunks, int W, int C,
-                                           float* __restrict__ stats, double inv_n) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void bf16_stats_finalize_kernel(const float* __restrict__ partial, int gx, int nchunks,
+                                                                 int W, int C, float* __restrict__ stats, double inv_n) {
+  const int c = blockIdx.x;  // one wave per channel
   const int chunk = c / W, col = c - chunk * W;
   double s1 = 0.0, s2 = 0.0;
-  for (int w = 0; w < gx; ++w) {
+  for (int w = threadIdx.x; w < gx; w += 64) {
     const float* p = partial + ((int64_t)chunk * gx + w) * (2 * W);
     s1 += (double)p[col];
     s2 += (double)p[W + col];
   }
-  const double mean = s1 * inv_n;
-  double var = s2 * inv_n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[c] = (float)mean;
-  stats[C + c] = (float)var;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (threadIdx.x == 0) {
+    const double mean = s1 * inv_n;
+    double var = s2 * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[c] = (float)mean;
+    stats[C + c] = (float)var;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -621,15 +741,24 @@ int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, v
   a.ntiles = ((shape[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
   a.act = act;
   a.stats_partial = nullptr;
+  a.partial = nullptr;
+  a.ksplit = 1;
   int gx = 512;
   while (gx > 8 && gx > a.ntiles) gx -= 8;
   if (a.ntiles < 8) gx = a.ntiles;
   const int W = 16 * pl.mt;
-  if (stats) {
+  hipStream_t st = (hipStream_t)stream;
+  // small deep levels (20^3, 10^3): a handful of tiles cannot fill 256 CUs and each workgroup would walk up to 18 channel
+  // chunks one after the other -> split the chunks over gridDim.z, accumulate in fp32, finish in a second tiny kernel
+  const int wgs_plain = gx * pl.nchunks;
+  int ks = std::min(pl.ncc, (512 + wgs_plain - 1) / std::max(wgs_plain, 1));
+  if (wgs_plain < 256 && ks >= 2 && scratch && scratch_floats >= (int64_t)ks * vox * Cout) {
+    a.ksplit = ks;
+    a.partial = scratch;
+  } else if (stats) {
     if (!scratch || scratch_floats < (int64_t)gx * pl.nchunks * 2 * W) return SYNTHSR_EINVAL;
     a.stats_partial = scratch;
   }
-  hipStream_t st = (hipStream_t)stream;
   int rc = SYNTHSR_EINVAL, wgs = 0;
 #define SYN_FWD(CKV, MTV) rc = launch_fwd<CKV, MTV>(a, pl.nchunks, st, &wgs)
   if (pl.ck == 8) {
@@ -641,9 +770,20 @@ int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, v
   }
 #undef SYN_FWD
   if (rc != SYNTHSR_OK) return rc;
+  if (a.partial) {
+    const int64_t n4 = vox * (Cout / 4);
+    hipLaunchKernelGGL(bf16_epilogue_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, st, scratch, bias, (const bf16_t*)below,
+                       (bf16_t*)out, n4, Cout / 4, act, a.ksplit);
+    if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+    if (stats) {
+      hipLaunchKernelGGL(bf16_small_stats_kernel, dim3(Cout), dim3(256), 0, st, (const bf16_t*)out, vox, Cout, stats);
+      if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+    }
+    return SYNTHSR_OK;
+  }
   if (stats) {
-    hipLaunchKernelGGL(bf16_stats_finalize_kernel, dim3((Cout + 63) / 64), dim3(64), 0, st, scratch, gx, pl.nchunks, W, Cout,
-                       stats, 1.0 / (double)vox);
+    hipLaunchKernelGGL(bf16_stats_finalize_kernel, dim3(Cout), dim3(64), 0, st, scratch, gx, pl.nchunks, W, Cout, stats,
+                       1.0 / (double)vox);
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   }
   return SYNTHSR_OK;
@@ -652,7 +792,12 @@ int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, v
 int64_t synthsr_conv3d_bf16_stats_scratch(const int shape[3], int Cin, int Cout) {
   if (!shape) return SYNTHSR_EINVAL;
   const Bf16Plan pl = plan_bf16(Cin, Cout);
-  return (int64_t)512 * pl.nchunks * 2 * 16 * pl.mt;
+  const int64_t stats = (int64_t)512 * pl.nchunks * 2 * 16 * pl.mt;
+  const int tiles = ((shape[0] + TZ - 1) / TZ) * ((shape[1] + TY - 1) / TY) * ((shape[2] + TX - 1) / TX);
+  const int wgs = std::min(tiles, 512) * pl.nchunks;
+  const int64_t ks = std::min(pl.ncc, (512 + wgs - 1) / std::max(wgs, 1));
+  const int64_t splitk = wgs < 256 ? ks * shape[0] * shape[1] * shape[2] * Cout : 0;  // fp32 partial planes
+  return stats > splitk ? stats : splitk;
 }
 
 int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float* dbias, const int shape[3], int Cin_total,

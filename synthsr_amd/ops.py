@@ -647,13 +647,11 @@ def conv3d_bf16(x, wpacked, bias, Cout, act=1, below=None, stats=None, out=None)
     assert x.dtype == torch.bfloat16 and wpacked.dtype == torch.bfloat16
     if out is None:
         out = torch.empty((s[0], s[1], s[2], Cout), dtype=torch.bfloat16, device=x.device)
-    scratch, nscr = None, 0
-    if stats is not None:
-        nscr = int(lib.synthsr_conv3d_bf16_stats_scratch(_lib.i3(s[:3]), int(s[3]), int(Cout)))
-        key = (x.device, nscr)
-        scratch = _bf16_scratch.get(key)
-        if scratch is None:
-            scratch = _bf16_scratch[key] = torch.empty(nscr, dtype=torch.float32, device=x.device)
+    nscr = int(lib.synthsr_conv3d_bf16_stats_scratch(_lib.i3(s[:3]), int(s[3]), int(Cout)))
+    scratch = _bf16_scratch.get(x.device)   # statistics partials / split-K partial sums (stream-ordered reuse)
+    if scratch is None or scratch.numel() < nscr:
+        scratch = _bf16_scratch[x.device] = torch.empty(max(nscr, 1 << 20), dtype=torch.float32, device=x.device)
+    nscr = scratch.numel()
     with _Timed('conv3d_bf16', s[:3], s[3], Cout):
         _lib.check(lib.synthsr_conv3d_bf16_fwd(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out), _lib.i3(s[:3]),
                                                int(s[3]), int(Cout), int(act), _lib.ptr(below), _lib.ptr(stats),
