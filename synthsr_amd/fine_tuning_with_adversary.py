@@ -129,8 +129,10 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
              lr_decay=0, epochs=100, steps_per_epoch=1000, work_with_residual_channel=None, loss_cropping=None,
              lr_generator=1e-4, lr_discriminator=1e-4, relative_weight_segmentation=0.25,
              relative_weight_discriminator=0.01, checkpoint_generator=None, gradient_penalty_weight=10,
-             first_training_ratio=100, training_ratio=10, labels_to_mask=None, seed=0, verbose=True):
-    """Parameters as documented in SynthSR/fine_tuning_with_adversary.py:92-283 (+ `seed`, `verbose`).
+             first_training_ratio=100, training_ratio=10, labels_to_mask=None, seed=0, verbose=True, dtype='f32'):
+    """Parameters as documented in SynthSR/fine_tuning_with_adversary.py:92-283 (+ `seed`, `verbose`, `dtype`: 'bf16' runs
+    the generator U-Net in bf16 (fp32 accumulation / statistics / master weights) next to the fp32 critic: the "mixed bf16" of
+    BASELINE.json configs[4]).
     Returns (generator U-Net, critic)."""
     import torch
     n_channels = len(hm.reformat_to_list(input_channels))
@@ -193,7 +195,7 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
                            conv_size=conv_size, nb_labels=n_output_channels, feat_mult=feat_multiplier,
                            nb_conv_per_level=nb_conv_per_level, conv_dropout=dropout, final_pred_activation='linear',
                            batch_norm=-1, activation=activation, input_model=brain_generator.labels_to_image_model,
-                           seed=seed)
+                           seed=seed, dtype=dtype)
     if checkpoint_generator is not None:
         if verbose:
             print('loading', checkpoint_generator)

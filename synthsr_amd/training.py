@@ -188,8 +188,10 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
              bias_shape_factor=0.03125, n_levels=5, nb_conv_per_level=2, conv_size=3, unet_feat_count=24,
              feat_multiplier=2, dropout=0, activation='elu', lr=1e-4, lr_decay=0, epochs=100, steps_per_epoch=1000,
              regression_metric='l1', work_with_residual_channel=None, loss_cropping=None, checkpoint=None,
-             model_file_has_different_lhood_layer=False, seed=0, verbose=True):
-    """Parameters as documented in SynthSR/training.py:90-240 (+ `seed`, `verbose`)."""
+             model_file_has_different_lhood_layer=False, seed=0, verbose=True, dtype='f32'):
+    """Parameters as documented in SynthSR/training.py:90-240 (+ `seed`, `verbose`, `dtype`: 'f32' like the reference, or
+    'bf16' = bf16 activations / packed weights with fp32 accumulation, BatchNorm statistics and master weights,
+    BASELINE.json configs[3])."""
     import torch
     # the launcher script hands `--input_channels` over as text (scripts/training.py:36 of the reference): 'True' / 'False'
     input_channels = [{'True': True, 'False': False}.get(c, c) if isinstance(c, str) else c
@@ -274,7 +276,7 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
                      feat_mult=feat_multiplier,
                      nb_conv_per_level=nb_conv_per_level, conv_dropout=dropout, final_pred_activation='linear',
                      batch_norm=-1, activation=activation, input_model=brain_generator.labels_to_image_model,
-                     seed=seed)
+                     seed=seed, dtype=dtype)
     init_epoch = 0
     if checkpoint is not None:
         if verbose and rank == 0:

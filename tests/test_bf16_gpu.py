@@ -198,3 +198,39 @@ def test_bf16_training_reduces_loss(T):
     draws = bg.labels_to_image_model.sample_draws()
     losses = [tr.step(inputs, draws).item() for _ in range(8)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_training_entry_points_in_bf16(tmp_path):
+    """training(dtype='bf16') and fine_tuning_with_adversary.training(dtype='bf16') (bf16 generator next to the fp32 critic:
+    the "mixed bf16" of BASELINE.json configs[4]) end to end on a tiny problem: finite, decreasing loss, checkpoints written"""
+    import os
+    from synthsr_amd.training import training
+    from synthsr_amd.fine_tuning_with_adversary import training as adv_training
+    from synthsr_amd.nifti import write_nifti
+    from synthsr_amd.synthetic import (GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR,
+                                       synthetic_label_map)
+    (tmp_path / 'labels').mkdir()
+    (tmp_path / 'images').mkdir()
+    rng = np.random.RandomState(0)
+    lut = rng.uniform(30, 220, 64)
+    for i in range(2):
+        lab = synthetic_label_map((40, 36, 48), 10 + i)
+        write_nifti(str(tmp_path / 'labels' / ('brain%d_labels.nii.gz' % i)), lab.astype(np.float32))
+        write_nifti(str(tmp_path / 'images' / ('brain%d.nii.gz' % i)), (lut[lab % 64] + rng.randn(*lab.shape)).astype(np.float32))
+    for nm, a in (('gl', GENERATION_LABELS), ('gc', GENERATION_CLASSES), ('pm', PRIOR_MEANS_T1_HR), ('ps', PRIOR_STDS_T1_HR)):
+        np.save(tmp_path / (nm + '.npy'), a)
+    model_dir = str(tmp_path / 'models')
+    net = training(str(tmp_path / 'labels'), model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'),
+                   str(tmp_path / 'gl.npy'), path_generation_classes=str(tmp_path / 'gc.npy'), output_shape=32, n_levels=3,
+                   unet_feat_count=24, nonlin_shape_factor=.125, bias_shape_factor=.125, steps_per_epoch=4, epochs=3,
+                   verbose=False, lr=1e-3, dtype='bf16')
+    assert net.bf16 and net.saved['enc'][0][0].dtype == __import__('torch').bfloat16
+    log = [float(l.split(',')[1]) for l in open(os.path.join(model_dir, 'logs', 'loss.csv')).read().strip().split('\n')]
+    assert len(log) == 3 and all(np.isfinite(log)) and log[-1] < log[0]
+    gen, critic = adv_training(str(tmp_path / 'labels'), str(tmp_path / 'images'), str(tmp_path / 'adv'), None, None,
+                               str(tmp_path / 'gl.npy'), output_shape=32, n_levels=3, nonlin_shape_factor=.125,
+                               bias_shape_factor=.125, epochs=1, steps_per_epoch=2, first_training_ratio=2,
+                               training_ratio=1, lr_generator=1e-3, lr_discriminator=1e-3, verbose=False, dtype='bf16')
+    assert gen.bf16 and gen.iterations == 2 and critic.iterations == 3
+    assert np.all(np.isfinite(np.load(tmp_path / 'adv' / 'logs' / 'generator_loss.npy')))
+    assert 'generator_1.h5' in os.listdir(tmp_path / 'adv')

@@ -91,6 +91,33 @@ def _run(S, hyperfine):
         got = net.view(nm, net.grads).cpu().double()
         ref = P[nm].grad.double()
         grads[nm] = (float((got - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), kind)
+    if hyperfine:
+        # configs[3] as BASELINE.json names it: the same step in bf16 (bf16 activations / packed weights, fp32 accumulation,
+        # fp32 BatchNorm statistics, fp32 master weights) against the SAME fp32 oracle result -- stated bf16 tolerances
+        sd = net.state_dict()
+        del net
+        torch.cuda.empty_cache()
+        nb = unet(24, bg.model_output_shape, 5, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
+                  batch_norm=-1, activation='elu', seed=0, dtype='bf16')
+        nb.load_state_dict(sd)
+        lb, pb = nb.loss(image, target.reshape(-1), 'l1', None, want_pred=True, **kw)
+        pb = pb.clone()
+        nb.backward()
+        rep['bf16_pred'] = float((pb.view(S, S, S, 1).cpu() - expect).abs().max()) / scale
+        rep['bf16_loss'] = abs(lb.item() - float(lr)) / abs(float(lr))
+        worst_bn = 0.0
+        for bn in nb.bn_layers:
+            o, C = bn['soff'], bn['C']
+            for got, ref in ((nb.bn_batch[o:o + C], stats[bn['name']][0]), (nb.bn_batch[o + C:o + 2 * C], stats[bn['name']][1])):
+                worst_bn = max(worst_bn, float((got.cpu() - ref).abs().max() / ref.abs().max()))
+        rep['bf16_bn'] = worst_bn
+        cos = {}
+        for nm, _, kind in nb.specs:
+            got = nb.view(nm, nb.grads).cpu().double().reshape(-1)
+            ref = P[nm].grad.double().reshape(-1)
+            cos[nm] = float(torch.dot(got, ref) / (got.norm() * ref.norm()).clamp_min(1e-30))
+        rep['bf16_min_cos'] = min(cos.values())
+        rep['bf16_min_cos_layer'] = min(cos, key=cos.get)
     return rep, grads, t_gpu, t_cpu
 
 
@@ -111,6 +138,8 @@ def test_one_training_step_at_baseline_shape_vs_oracle(S, hyperfine):
     assert rep['loss'] < 1e-4, rep
     assert rep['bn'] < 5e-4, rep
     assert rep['pred'] < 1e-3, rep
+    if hyperfine:   # bf16 vs the fp32 oracle (stated bf16 tolerances; gradients: see tests/test_bf16_gpu.py on pooling flips)
+        assert rep['bf16_loss'] < 1e-2 and rep['bf16_pred'] < 5e-2 and rep['bf16_bn'] < 3e-2 and rep['bf16_min_cos'] > 0.9, rep
     for nm, (err, kind) in grads.items():
         # biases of the conv right before a BatchNorm: BN's backward removes the mean of the signal, so their gradient is
         # a sum of cancelling terms over every voxel (like dbeta / dgamma); measured up to 1.3e-2 at 192^3
