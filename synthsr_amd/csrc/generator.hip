@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
   const float zf1 = p.has_field ? (float)((double)p.in_shape[1] / (double)p.half_shape[1]) : 1.f;
   const float zf2 = p.has_field ? (float)((double)p.in_shape[2] / (double)p.half_shape[2]) : 1.f;
 
-  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x) {
+  int64_t o_lo, o_hi;
+  syn_block_range(n, o_lo, o_hi);  // XCD-contiguous slabs: the label gather stays in one L2
+  for (int64_t o = o_lo + threadIdx.x; o < o_hi; o += blockDim.x) {
     const int o2 = (int)(o % p.out_shape[2]);
     const int o1 = (int)((o / p.out_shape[2]) % p.out_shape[1]);
     const int o0 = (int)(o / ((int64_t)p.out_shape[2] * p.out_shape[1]));
@@ -392,7 +394,9 @@ __global__ __launch_bounds__(256) void blur3d_kernel(const float* __restrict__ i
   __syncthreads();
   const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
   const int p0 = ks.d[0] / 2, p1 = ks.d[1] / 2, p2 = ks.d[2] / 2;
-  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+  int64_t v_lo, v_hi;
+  syn_block_range(n, v_lo, v_hi);  // XCD-contiguous slabs: the 27-tap stencil re-reads hit this XCD's L2
+  for (int64_t v = v_lo + threadIdx.x; v < v_hi; v += blockDim.x) {
     const int i2 = (int)(v % s.d[2]);
     const int i1 = (int)((v / s.d[2]) % s.d[1]);
     const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));

@@ -477,9 +477,18 @@ class LabelsToImageModel:
                            'blur(target)')
                 tgt_slot += 1
                 continue
+            # the blurred channel IS the regression target when there is a single, unresampled target channel: blur straight
+            # into the (then contiguous) target tensor and let the LR blur read it from there -- no staging copy
+            # (only when nothing downstream ping-pongs into the buffer: one LR-blur pass, no resampling / registration)
+            direct_target = (is_target and not self.resample_target and Ct == 1 and 'down' not in plan and 'T' not in plan
+                             and 'rr' not in plan and (plan.get('k_lr') is None or len(plan['k_lr']) == 1))
+            if direct_target:
+                t0 = fptr(self.d_target)
             with tk('gen:blur3d(.5)'):
                 _lib.check(lib.synthsr_blur3d(x, t0, cs, sm.dptr(off_k05), k3, 1, 0, -1, 0., st), 'blur(.5)')
-            if is_target:
+            if direct_target:
+                tgt_slot += 1
+            elif is_target:
                 if self.resample_target:
                     ko, ks = plan['k_tgt']
                     _lib.check(lib.synthsr_blur3d(t0, t1, cs, sm.dptr(ko), i3(ks), 1, 0, -1, 0., st), 'blur(tgt)')
