@@ -199,11 +199,8 @@ int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int kind, int64
 int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* jobs_dev, int njobs,
                             synthsr_stream_t stream);
 
-/* tuning / A-B switch, process-wide: option 0 = persistent forward kernel on the large levels (default 1),
- * 1 = diagnostic ablation mask, 2 = force MT, 3 = EXPERIMENTAL MFMA+VALU co-execution for Cout % 16 == 8 (default 0),
- * 4 = 4x4x1-MFMA kernels, 5 = split-K workgroup target, 6 = brick tiles, 7 = parity split of small up-conv data gradients.  Options
- * that change the launch geometry must be set before weights are packed. */
-int synthsr_conv3d_set_option(int option, int value);
+/* (the process-wide tuning switch of the conv kernels lives in synthsr_hip_tuning.h: it is a development hook for
+ * tools/, NOT part of this stateless boundary) */
 
 /* ---- bf16 twins of the HBM-bound U-Net kernels: same arguments and semantics as the float32 entry point of the same
  * name (which cites the reference layers it replaces); activation / activation-gradient tensors are NDHWC bfloat16
@@ -265,6 +262,17 @@ int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, v
                             int Cout, int act, const void* below, float* stats, float* scratch, int64_t scratch_floats,
                             synthsr_stream_t stream);
 int64_t synthsr_conv3d_bf16_stats_scratch(const int shape[3], int Cin, int Cout);
+/* same with the LeakyReLU epilogues of the WGAN-GP critic (SynthSR/fine_tuning_with_adversary.py:482-508):
+ * act 3 = LeakyReLU(alpha), act 4 = multiply by LeakyReLU'(below) (below = the layer's activation output) */
+int synthsr_conv3d_bf16_fwd_ex(const void* in, const void* wp, const float* bias, void* out, const int shape[3], int Cin,
+                               int Cout, int act, float alpha, const void* below, float* stats, float* scratch,
+                               int64_t scratch_floats, synthsr_stream_t stream);
+/* stride-2 'same' Conv3D of an even-sized volume (TensorFlow pads (0, 1)) = the stride-1 conv sampled at the odd positions:
+ * out[o] = in[2 o + 1] (optionally times LeakyReLU'(below[o])); zero_insert is its transpose (gradient w.r.t. the
+ * full-resolution tensor).  bf16 NDHWC, C % 4 == 0 */
+int synthsr_bf16_subsample_odd(const void* in, void* out, const void* below, const int out_shape[3], int C, float alpha,
+                               synthsr_stream_t stream);
+int synthsr_bf16_zero_insert_odd(const void* in, void* out, const int in_shape[3], int C, synthsr_stream_t stream);
 /* dw[27][Cin][Cout] (fp32) += sum_v in[v + t - 1][ci] * dout[v][co];  dbias[Cout] += sum_v dout[v]  (may be NULL);
  * both zeroed by the caller.  `in` has Cin channels (Cin % 8 == 0), dw covers its first Cin_total <= Cin channels;
  * Cout % 8 == 0 */

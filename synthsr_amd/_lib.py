@@ -77,6 +77,9 @@ SIGNATURES = {
     'synthsr_head_bwd_bf16': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
     'synthsr_conv3d_bf16_pack': (c_int64, [_P, _P, c_int, c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_bf16_fwd': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _P, _P, _P, c_int64, _S]),
+    'synthsr_conv3d_bf16_fwd_ex': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_float, _P, _P, _P, c_int64, _S]),
+    'synthsr_bf16_subsample_odd': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_float, _S]),
+    'synthsr_bf16_zero_insert_odd': (c_int, [_P, _P, POINTER(c_int), c_int, _S]),
     'synthsr_conv3d_bf16_stats_scratch': (c_int64, [POINTER(c_int), c_int, c_int]),
     'synthsr_conv3d_bf16_wgrad': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
     'synthsr_f32_to_bf16_pad': (c_int, [_P, _P, c_int64, c_int, c_int, _S]),

@@ -12,8 +12,12 @@ activations: with delta_l the back-propagated signals of grad_x D and u_0 = d pe
 u_l = mask_l * conv_l(u_{l-1}) gives  d penalty / d W_l = weight-gradient(u_{l-1}, delta_l)  (the backward pass is linear in
 every W_l); biases get no penalty gradient.
 
-Not optimised yet: the critic's channel counts (32 ... 256) are not multiples of 24, so every convolution takes the generic
-(CK = 8) kernels."""
+float32: the critic's channel counts (32 ... 256) are not multiples of 24, so every convolution takes the generic (CK = 8)
+kernels.  dtype='bf16' ("mixed bf16", BASELINE.json configs[4]): the conv stack runs on csrc/conv_bf16.hip, whose
+32-channel K-chunks fit these layers exactly -- bf16 activations / gradient signals / packed weights, fp32 accumulation,
+fp32 master weights, gradients, Dense layers, loss and penalty norm; LeakyReLU and its backward are conv epilogues; a
+stride-2 layer is the stride-1 conv sampled at the odd output positions (ops.subsample_odd_bf16), its backward goes through
+the zero-inserted full-resolution signal."""
 import numpy as np
 import torch
 
@@ -23,7 +27,10 @@ ALPHA = 0.2
 
 
 class Critic3D:
-    def __init__(self, input_shape, n_filters=32, n_levels=4, device=None, seed=0, name='discriminator'):
+    def __init__(self, input_shape, n_filters=32, n_levels=4, device=None, seed=0, name='discriminator', dtype='f32'):
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError("dtype should be 'f32' or 'bf16'")
+        self.bf16 = dtype == 'bf16'
         if len(input_shape) != 4:
             raise NotImplementedError('3-D volumes only')
         shape = [int(s) for s in input_shape[:3]]
@@ -76,15 +83,21 @@ class Critic3D:
         off, shp = self.offsets[name]
         return (self.params if buf is None else buf)[off:off + int(np.prod(shp))].view(*shp)
 
-    def buf(self, key, shape):
+    def buf(self, key, shape, dtype=torch.float32):
         n = int(np.prod(shape))
+        key = (key, dtype)
         t = self._bufs.get(key)
         if t is None or t.numel() < n:
-            t = torch.empty(n, dtype=torch.float32, device=self.device)
+            t = torch.empty(n, dtype=dtype, device=self.device)
             self._bufs[key] = t
         return t[:n].view(*shape)
 
     def repack(self):
+        if self.bf16:
+            for c in self.convs:
+                c['wp'] = ops.pack_conv_weights_bf16(self.view(c['w']), 0, out=c.get('wp'))
+                c['wpd'] = ops.pack_conv_weights_bf16(self.view(c['w']), 1, out=c.get('wpd'))
+            return
         for c in self.convs:
             if c['stride'] == 2:   # parity weight sets on the OUTPUT grid (ops.conv3d_stride2*)
                 lo = [v // 2 for v in c['shape']]
@@ -124,6 +137,8 @@ class Critic3D:
     # ------------------------------------------------------------------ forward / backward
     def forward(self, x, tag='a'):
         """x [d0,d1,d2,C] -> D(x) as a 1-element device tensor; the LeakyReLU outputs are kept under `tag`"""
+        if self.bf16:
+            return self._forward_bf16(x, tag)
         hs = [x]
         cur = x
         for i, c in enumerate(self.convs):
@@ -144,6 +159,8 @@ class Critic3D:
     def backward(self, dout=1.0, weight_grads=True, input_grad=False, keep_deltas=False):
         """back-propagates dD = dout through the pass stored by the last forward(): accumulates the weight gradients into
         self.grads (weight_grads), returns grad_x D * dout (input_grad), keeps the per-layer signals for the penalty"""
+        if self.bf16:
+            return self._backward_bf16(dout, weight_grads, input_grad, keep_deltas)
         hs, h9 = self._saved['hs'], self._saved['h9']
         d0, d1 = self.dense
         G = self.grads
@@ -214,6 +231,8 @@ class Critic3D:
 
     def _penalty_backward(self, g0, scale, mask=None):
         """adds d penalty / d W to self.grads: masked forward pass of u_0 = scale * grad_x D(x_hat)"""
+        if self.bf16:
+            return self._penalty_backward_bf16(g0, scale, mask)
         hs, h9 = self._saved['hs'], self._saved['h9']
         G = self.grads
         u = ops.axpby(g0, None, scale, 0.0, out=self.buf('u0', list(g0.shape)))
@@ -225,6 +244,104 @@ class Critic3D:
             u = ops.leaky_relu_bwd(v, hs[i + 1], ALPHA, out=self.buf('u%d' % ((i + 1) & 1), list(hs[i + 1].shape)))
         d0, d1 = self.dense
         uflat = u.reshape(-1)
+        ops.dense_bwd(uflat, self.view(d0['w']), self._delta9, dx=None, dW=self.view(d0['w'], G))
+        v9 = ops.dense_fwd(uflat, self.view(d0['w']), None, out=self.buf('v9', [d0['n_out']]))
+        self.view(d1['w'], G).view(-1).add_(ops.leaky_relu_bwd(v9, h9, ALPHA, out=self.buf('m9v9', [d0['n_out']])))
+
+    # ------------------------------------------------------------------ bf16 conv stack (dtype='bf16')
+    BF = torch.bfloat16
+
+    def _to_bf16_input(self, x, key):
+        """fp32 [d0,d1,d2,C] -> bf16 with the channels zero-padded to a multiple of 8 (16-byte K-groups of the MFMA)"""
+        C = int(x.shape[-1])
+        Cp = (C + 7) // 8 * 8
+        return ops.to_bf16_pad(x.contiguous(), Cp, out=self.buf(key, list(x.shape[:3]) + [Cp], self.BF))
+
+    def _conv_bf16(self, c, x, key, act, below=None, bias=True):
+        """layer c on bf16 x: act 3 = + bias, LeakyReLU; act 4 = * LeakyReLU'(below); act 0 linear.  A stride-2 layer is
+        evaluated at full resolution and sampled at the odd positions (TensorFlow's (0, 1) 'same' padding); with act 4 the
+        mask `below` lives on the low-resolution grid and is applied by the sampling kernel"""
+        b = self.view(c['b']) if bias else None
+        if c['stride'] == 1:
+            return ops.conv3d_bf16(x, c['wp'], b, c['cout'], act, below=below, alpha=ALPHA,
+                                   out=self.buf(key, c['shape'] + [c['cout']], self.BF))
+        full = ops.conv3d_bf16(x, c['wp'], b, c['cout'], 3 if act == 3 else 0, alpha=ALPHA,
+                               out=self.buf('full', c['shape'] + [c['cout']], self.BF))
+        return ops.subsample_odd_bf16(full, below=below if act == 4 else None, alpha=ALPHA,
+                                      out=self.buf(key, self._out_shape(c), self.BF))
+
+    def _full_delta(self, c, delta):
+        """the gradient signal of layer c on the grid its stride-1 conv runs on"""
+        if c['stride'] == 1:
+            return delta
+        return ops.zero_insert_odd_bf16(delta, out=self.buf('dfull', c['shape'] + [c['cout']], self.BF))
+
+    def _forward_bf16(self, x, tag):
+        hs = [self._to_bf16_input(x, 'x8' + tag)]
+        cur = hs[0]
+        for i, c in enumerate(self.convs):
+            cur = self._conv_bf16(c, cur, 'h%s%d' % (tag, i), 3)
+            hs.append(cur)
+        d0, d1 = self.dense
+        flat = self.buf('flat32' + tag, [d0['n_in']])
+        flat.copy_(cur.reshape(-1))                                        # bf16 -> fp32 for the Dense layers
+        h9 = ops.dense_fwd(flat, self.view(d0['w']), self.view(d0['b']), out=self.buf('h%s_d' % tag, [d0['n_out']]))
+        ops.leaky_relu(h9, ALPHA)
+        out = ops.dense_fwd(h9, self.view(d1['w']), self.view(d1['b']), out=self.buf('out' + tag, [1]))
+        self._saved = dict(hs=hs, h9=h9, tag=tag, flat=flat)
+        self.last_output = out
+        return out
+
+    def _backward_bf16(self, dout, weight_grads, input_grad, keep_deltas):
+        hs, h9, flat = self._saved['hs'], self._saved['h9'], self._saved['flat']
+        d0, d1 = self.dense
+        G = self.grads
+        dD = self.buf('dD', [1])
+        dD.fill_(float(dout))
+        dh9 = self.buf('dh9', [d1['n_in']])
+        ops.dense_bwd(h9, self.view(d1['w']), dD, dx=dh9, dW=self.view(d1['w'], G) if weight_grads else None)
+        delta9 = ops.leaky_relu_bwd(dh9, h9, ALPHA, out=self.buf('delta9', [d1['n_in']]))
+        dflat = self.buf('dflat', [d0['n_in']])
+        ops.dense_bwd(flat, self.view(d0['w']), delta9, dx=dflat, dW=self.view(d0['w'], G) if weight_grads else None)
+        if weight_grads:
+            self.view(d1['b'], G).add_(dD)
+            self.view(d0['b'], G).add_(delta9)
+        last = hs[-1]
+        delta = self.buf('delta%d' % (len(self.convs) - 1), list(last.shape), self.BF)
+        torch.mul(dflat.view(*last.shape), torch.where(last > 0, 1.0, ALPHA), out=self.buf('dlast32', list(last.shape)))
+        delta.copy_(self.buf('dlast32', list(last.shape)))
+        deltas = [None] * len(self.convs)
+        g = None
+        for i in range(len(self.convs) - 1, -1, -1):
+            c = self.convs[i]
+            deltas[i] = delta
+            dfull = self._full_delta(c, delta) if (weight_grads or i > 0 or input_grad) else None
+            if weight_grads:
+                ops.conv3d_wgrad_bf16(hs[i], dfull, self.view(c['w'], G), self.view(c['b'], G))
+            if i > 0:      # data gradient fused with the LeakyReLU backward of the layer below -> its delta
+                delta = ops.conv3d_bf16(dfull, c['wpd'], None, hs[i].shape[3], 4, below=hs[i], alpha=ALPHA,
+                                        out=self.buf('delta%d' % (i - 1), list(hs[i].shape), self.BF))
+            elif input_grad:
+                g8 = ops.conv3d_bf16(dfull, c['wpd'], None, hs[0].shape[3], 0, out=self.buf('g8', list(hs[0].shape), self.BF))
+                g = self.buf('g32', c['shape'] + [c['cin']])
+                g.copy_(g8[..., :c['cin']])
+        if keep_deltas:
+            self._deltas, self._delta9 = deltas, delta9
+        return g if input_grad else None
+
+    def _penalty_backward_bf16(self, g0, scale, mask):
+        hs, h9 = self._saved['hs'], self._saved['h9']
+        G = self.grads
+        u32 = ops.axpby(g0, None, scale, 0.0, out=self.buf('u0', list(g0.shape)))
+        if mask is not None:
+            ops.mul(u32, mask, out=u32)
+        u = self._to_bf16_input(u32, 'u8')
+        for i, c in enumerate(self.convs):
+            ops.conv3d_wgrad_bf16(u, self._full_delta(c, self._deltas[i]), self.view(c['w'], G), None)
+            u = self._conv_bf16(c, u, 'u%d' % (i & 1), 4, below=hs[i + 1], bias=False)
+        d0, d1 = self.dense
+        uflat = self.buf('uflat32', [d0['n_in']])
+        uflat.copy_(u.reshape(-1))
         ops.dense_bwd(uflat, self.view(d0['w']), self._delta9, dx=None, dW=self.view(d0['w'], G))
         v9 = ops.dense_fwd(uflat, self.view(d0['w']), None, out=self.buf('v9', [d0['n_out']]))
         self.view(d1['w'], G).view(-1).add_(ops.leaky_relu_bwd(v9, h9, ALPHA, out=self.buf('m9v9', [d0['n_out']])))

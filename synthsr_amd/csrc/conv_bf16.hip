@@ -125,6 +125,7 @@ struct FwdArgs {
   float* stats_partial;  // [gridDim.x * gridDim.y][2][16 * MT] per-workgroup sums / sums of squares, or null
   float* partial;        // split-K (small volumes): fp32 [vox][Cout] accumulated with atomics, epilogue in a second kernel
   int D0, D1, D2, Cin, Cout, ncc, tiles1, tiles2, ntiles, act, ksplit;
+  float alpha;           // LeakyReLU slope of act 3 / 4 (the WGAN-GP critic)
 };
 
 // WLDS: the whole fragment-ordered weight set of this workgroup's (co-chunk, single ci-chunk) lives in LDS for the life of
@@ -299,6 +300,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
           v[1] *= elu_dy(bf2f(b.x >> 16));
           v[2] *= elu_dy(bf2f(b.y & 0xffffu));
           v[3] *= elu_dy(bf2f(b.y >> 16));
+        } else if (a.act == 3) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : a.alpha * v[i];
+        } else if (a.act == 4) {
+          const u32x2 b = *reinterpret_cast<const u32x2*>(a.below + vox * Cout + co);
+          v[0] *= bf2f(b.x & 0xffffu) > 0.f ? 1.f : a.alpha;
+          v[1] *= bf2f(b.x >> 16) > 0.f ? 1.f : a.alpha;
+          v[2] *= bf2f(b.y & 0xffffu) > 0.f ? 1.f : a.alpha;
+          v[3] *= bf2f(b.y >> 16) > 0.f ? 1.f : a.alpha;
         }
         u32x2 o;
         o.x = pack2(v[0], v[1]);
@@ -369,7 +379,7 @@ int launch_fwd(const FwdArgs& a, int nchunks, hipStream_t st, int* wgs_out) {
 // split-K epilogue: fp32 partial sums [n4 x 4] -> + bias, activation, bf16
 __global__ void bf16_epilogue_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                      const bf16_t* __restrict__ below, bf16_t* __restrict__ out, int64_t n4, int C4,
-                                     int act, int ksplit) {
+                                     int act, int ksplit, float alpha) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
     float4 p = *reinterpret_cast<const float4*>(partial + i * 4);
@@ -389,11 +399,63 @@ __global__ void bf16_epilogue_kernel(const float* __restrict__ partial, const fl
       v[1] *= elu_dy(bf2f(b.x >> 16));
       v[2] *= elu_dy(bf2f(b.y & 0xffffu));
       v[3] *= elu_dy(bf2f(b.y >> 16));
+    } else if (act == 3) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : alpha * v[k];
+    } else if (act == 4) {
+      const u32x2 b = *reinterpret_cast<const u32x2*>(below + i * 4);
+      v[0] *= bf2f(b.x & 0xffffu) > 0.f ? 1.f : alpha;
+      v[1] *= bf2f(b.x >> 16) > 0.f ? 1.f : alpha;
+      v[2] *= bf2f(b.y & 0xffffu) > 0.f ? 1.f : alpha;
+      v[3] *= bf2f(b.y >> 16) > 0.f ? 1.f : alpha;
     }
     u32x2 o;
     o.x = pack2(v[0], v[1]);
     o.y = pack2(v[2], v[3]);
     *reinterpret_cast<u32x2*>(out + i * 4) = o;
+  }
+}
+
+// stride-2 'same' Conv3D of an even-sized volume (TensorFlow pads (0, 1): output o reads inputs 2o .. 2o+2) = the
+// stride-1 'same' conv sampled at the ODD positions 2o + 1.  out[o] = in[2o + 1] (* LeakyReLU'(below[o]) when below is
+// given: the masked forward pass of the gradient penalty); channels in 4-packs
+__global__ void bf16_subsample_odd_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                          const bf16_t* __restrict__ below, int o0, int o1, int o2, int C4, float alpha) {
+  const int64_t n4 = (int64_t)o0 * o1 * o2 * C4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    int64_t v = i / C4;
+    const int x = (int)(v % o2);
+    v /= o2;
+    const int y = (int)(v % o1), z = (int)(v / o1);
+    const int64_t src = (((int64_t)(2 * z + 1) * (2 * o1) + (2 * y + 1)) * (2 * o2) + (2 * x + 1)) * C4 + c4;
+    u32x2 r = *reinterpret_cast<const u32x2*>(in + src * 4);
+    if (below) {
+      const u32x2 b = *reinterpret_cast<const u32x2*>(below + i * 4);
+      const float f0 = bf2f(r.x & 0xffffu) * (bf2f(b.x & 0xffffu) > 0.f ? 1.f : alpha);
+      const float f1 = bf2f(r.x >> 16) * (bf2f(b.x >> 16) > 0.f ? 1.f : alpha);
+      const float f2 = bf2f(r.y & 0xffffu) * (bf2f(b.y & 0xffffu) > 0.f ? 1.f : alpha);
+      const float f3 = bf2f(r.y >> 16) * (bf2f(b.y >> 16) > 0.f ? 1.f : alpha);
+      r.x = pack2(f0, f1);
+      r.y = pack2(f2, f3);
+    }
+    *reinterpret_cast<u32x2*>(out + i * 4) = r;
+  }
+}
+
+// transpose of the above: out (full resolution, 2x) = in at the odd positions, zero elsewhere
+__global__ void bf16_zero_insert_odd_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int o0, int o1, int o2,
+                                            int C4) {
+  const int64_t n4 = (int64_t)8 * o0 * o1 * o2 * C4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    int64_t v = i / C4;
+    const int x = (int)(v % (2 * o2));
+    v /= (2 * o2);
+    const int y = (int)(v % (2 * o1)), z = (int)(v / (2 * o1));
+    u32x2 r = {0u, 0u};
+    if ((x & y & z) & 1) r = *reinterpret_cast<const u32x2*>(in + ((((int64_t)(z >> 1) * o1 + (y >> 1)) * o2 + (x >> 1)) * C4 + c4) * 4);
+    *reinterpret_cast<u32x2*>(out + i * 4) = r;
   }
 }
 
@@ -703,9 +765,9 @@ int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, in
                                  synthsr_stream_t stream) {
   if (Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1)) return SYNTHSR_EINVAL;
   // the tensor a layer reads has its channel count padded to a multiple of 8 (the first layer's 2 -> 8): pad channels
-  // get zero weights.  The produced channel count must be a multiple of 4 (8-byte bf16x4 stores).
+  // get zero weights.  The tensor it produces has its channel count padded the same way when CoutE is not a multiple
+  // of 4 (data gradient of a 1- or 2-channel first layer): the extra rows are zero, the tile count is the same.
   const int CinE = ((mode ? Cout : Cin) + 7) / 8 * 8, CoutE = mode ? Cin : Cout;
-  if (CoutE % 4 != 0) return SYNTHSR_EINVAL;
   const Bf16Plan pl = plan_bf16(CinE, CoutE);
   const int64_t total = pl.count();
   if (total >= (1ll << 31)) return SYNTHSR_EINVAL;
@@ -716,10 +778,11 @@ int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, in
   return hipGetLastError() == hipSuccess ? total : (int64_t)SYNTHSR_ELAUNCH;
 }
 
-int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, void* out, const int shape[3], int Cin,
-                            int Cout, int act, const void* below, float* stats, float* scratch, int64_t scratch_floats,
-                            synthsr_stream_t stream) {
-  if (!in || !wp || !out || !shape || Cin % 8 != 0 || Cout % 4 != 0 || act < 0 || act > 2 || (act == 2 && !below))
+int synthsr_conv3d_bf16_fwd_ex(const void* in, const void* wp, const float* bias, void* out, const int shape[3], int Cin,
+                               int Cout, int act, float alpha, const void* below, float* stats, float* scratch,
+                               int64_t scratch_floats, synthsr_stream_t stream) {
+  if (!in || !wp || !out || !shape || Cin % 8 != 0 || Cout % 4 != 0 || act < 0 || act > 4 ||
+      ((act == 2 || act == 4) && !below))
     return SYNTHSR_EINVAL;
   const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
   if (vox * Cin * 2 >= (1ll << 31) || vox * Cout * 2 >= (1ll << 31)) return SYNTHSR_EINVAL;
@@ -740,6 +803,7 @@ int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, v
   a.tiles2 = (shape[2] + TX - 1) / TX;
   a.ntiles = ((shape[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
   a.act = act;
+  a.alpha = alpha;
   a.stats_partial = nullptr;
   a.partial = nullptr;
   a.ksplit = 1;
@@ -773,7 +837,7 @@ int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, v
   if (a.partial) {
     const int64_t n4 = vox * (Cout / 4);
     hipLaunchKernelGGL(bf16_epilogue_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, st, scratch, bias, (const bf16_t*)below,
-                       (bf16_t*)out, n4, Cout / 4, act, a.ksplit);
+                       (bf16_t*)out, n4, Cout / 4, act, a.ksplit, a.alpha);
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
     if (stats) {
       hipLaunchKernelGGL(bf16_small_stats_kernel, dim3(Cout), dim3(256), 0, st, (const bf16_t*)out, vox, Cout, stats);
@@ -787,6 +851,33 @@ int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, v
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   }
   return SYNTHSR_OK;
+}
+
+int synthsr_conv3d_bf16_fwd(const void* in, const void* wp, const float* bias, void* out, const int shape[3], int Cin,
+                            int Cout, int act, const void* below, float* stats, float* scratch, int64_t scratch_floats,
+                            synthsr_stream_t stream) {
+  if (act > 2) return SYNTHSR_EINVAL;
+  return synthsr_conv3d_bf16_fwd_ex(in, wp, bias, out, shape, Cin, Cout, act, 0.f, below, stats, scratch, scratch_floats,
+                                    stream);
+}
+
+int synthsr_bf16_subsample_odd(const void* in, void* out, const void* below, const int out_shape[3], int C, float alpha,
+                               synthsr_stream_t stream) {
+  if (!in || !out || !out_shape || C < 4 || C % 4 != 0 || out_shape[0] < 1 || out_shape[1] < 1 || out_shape[2] < 1)
+    return SYNTHSR_EINVAL;
+  const int64_t n4 = (int64_t)out_shape[0] * out_shape[1] * out_shape[2] * (C / 4);
+  hipLaunchKernelGGL(bf16_subsample_odd_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
+                     (bf16_t*)out, (const bf16_t*)below, out_shape[0], out_shape[1], out_shape[2], C / 4, alpha);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+int synthsr_bf16_zero_insert_odd(const void* in, void* out, const int in_shape[3], int C, synthsr_stream_t stream) {
+  if (!in || !out || !in_shape || C < 4 || C % 4 != 0 || in_shape[0] < 1 || in_shape[1] < 1 || in_shape[2] < 1)
+    return SYNTHSR_EINVAL;
+  const int64_t n4 = (int64_t)8 * in_shape[0] * in_shape[1] * in_shape[2] * (C / 4);
+  hipLaunchKernelGGL(bf16_zero_insert_odd_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in, (bf16_t*)out, in_shape[0], in_shape[1], in_shape[2], C / 4);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
 int64_t synthsr_conv3d_bf16_stats_scratch(const int shape[3], int Cin, int Cout) {

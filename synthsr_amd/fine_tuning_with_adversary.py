@@ -22,10 +22,10 @@ from .training import load_checkpoint, save_checkpoint
 from .unet import unet as build_unet
 
 
-def make_discriminator(input_shape, n_filters=32, n_levels=4, mask_input=False, device=None, seed=0):
+def make_discriminator(input_shape, n_filters=32, n_levels=4, mask_input=False, device=None, seed=0, dtype='f32'):
     """the critic network of fine_tuning_with_adversary.py:482-502 as a `Critic3D`; with mask_input the volumes are
     multiplied by a mask before the first layer - pass it as `mask=` to the critic's methods"""
-    critic = Critic3D(input_shape, n_filters=n_filters, n_levels=n_levels, device=device, seed=seed)
+    critic = Critic3D(input_shape, n_filters=n_filters, n_levels=n_levels, device=device, seed=seed, dtype=dtype)
     critic.mask_input = bool(mask_input)
     return critic
 
@@ -131,8 +131,8 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
              relative_weight_discriminator=0.01, checkpoint_generator=None, gradient_penalty_weight=10,
              first_training_ratio=100, training_ratio=10, labels_to_mask=None, seed=0, verbose=True, dtype='f32'):
     """Parameters as documented in SynthSR/fine_tuning_with_adversary.py:92-283 (+ `seed`, `verbose`, `dtype`: 'bf16' runs
-    the generator U-Net in bf16 (fp32 accumulation / statistics / master weights) next to the fp32 critic: the "mixed bf16" of
-    BASELINE.json configs[4]).
+    the conv stacks of the generator U-Net AND the critic in bf16 (fp32 accumulation / statistics / master weights / Dense layers /
+    losses): the "mixed bf16" of BASELINE.json configs[4]).
     Returns (generator U-Net, critic)."""
     import torch
     n_channels = len(hm.reformat_to_list(input_channels))
@@ -204,7 +204,7 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
     if labels_to_mask is not None:
         mask_lut = hm.get_mapping_lut(generation_labels, hm.load_array_if_path(labels_to_mask))
     critic = make_discriminator(list(unet_input_shape[:-1]) + [n_output_channels], mask_input=mask_lut is not None,
-                                seed=seed + 2)
+                                seed=seed + 2, dtype=dtype)
     seg_reg = None
     if segmentation_model_file is not None:
         from .seg_loss import SegmentationRegulariser

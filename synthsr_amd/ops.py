@@ -639,9 +639,9 @@ def pack_conv_weights_bf16(w, mode=0, ci_off=0, cin=None, out=None):
     return out
 
 
-def conv3d_bf16(x, wpacked, bias, Cout, act=1, below=None, stats=None, out=None):
-    """act(conv3(x) + bias) on bf16 NDHWC tensors (fp32 accumulation); act 2: times ELU'(below); stats: fp32 [2*Cout]
-    receives the batch mean | variance of the output"""
+def conv3d_bf16(x, wpacked, bias, Cout, act=1, below=None, stats=None, out=None, alpha=0.0):
+    """act(conv3(x) + bias) on bf16 NDHWC tensors (fp32 accumulation); act 2: times ELU'(below); act 3: LeakyReLU(alpha);
+    act 4: times LeakyReLU'(below); stats: fp32 [2*Cout] receives the batch mean | variance of the output"""
     lib = _L()
     s = x.shape
     assert x.dtype == torch.bfloat16 and wpacked.dtype == torch.bfloat16
@@ -653,9 +653,31 @@ def conv3d_bf16(x, wpacked, bias, Cout, act=1, below=None, stats=None, out=None)
         scratch = _bf16_scratch[x.device] = torch.empty(max(nscr, 1 << 20), dtype=torch.float32, device=x.device)
     nscr = scratch.numel()
     with _Timed('conv3d_bf16', s[:3], s[3], Cout):
-        _lib.check(lib.synthsr_conv3d_bf16_fwd(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out), _lib.i3(s[:3]),
-                                               int(s[3]), int(Cout), int(act), _lib.ptr(below), _lib.ptr(stats),
-                                               _lib.ptr(scratch), nscr, _lib.stream()), 'conv3d_bf16_fwd')
+        _lib.check(lib.synthsr_conv3d_bf16_fwd_ex(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out),
+                                                  _lib.i3(s[:3]), int(s[3]), int(Cout), int(act), float(alpha),
+                                                  _lib.ptr(below), _lib.ptr(stats), _lib.ptr(scratch), nscr,
+                                                  _lib.stream()), 'conv3d_bf16_fwd')
+    return out
+
+
+def subsample_odd_bf16(x, below=None, alpha=0.0, out=None):
+    """out[o] = x[2 o + 1] (* LeakyReLU'(below[o])): a stride-2 'same' conv = the stride-1 conv at the odd positions"""
+    s = x.shape
+    lo = (s[0] // 2, s[1] // 2, s[2] // 2)
+    if out is None:
+        out = torch.empty(lo + (s[3],), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_L().synthsr_bf16_subsample_odd(_lib.ptr(x), _lib.ptr(out), _lib.ptr(below), _lib.i3(lo), int(s[3]),
+                                               float(alpha), _lib.stream()), 'bf16_subsample_odd')
+    return out
+
+
+def zero_insert_odd_bf16(x, out=None):
+    """transpose of subsample_odd_bf16: [2 d0, 2 d1, 2 d2, C] with x at the odd positions, zero elsewhere"""
+    s = x.shape
+    if out is None:
+        out = torch.empty((2 * s[0], 2 * s[1], 2 * s[2], s[3]), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_L().synthsr_bf16_zero_insert_odd(_lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), _lib.stream()),
+               'bf16_zero_insert_odd')
     return out
 
 

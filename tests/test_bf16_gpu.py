@@ -234,3 +234,54 @@ def test_training_entry_points_in_bf16(tmp_path):
     assert gen.bf16 and gen.iterations == 2 and critic.iterations == 3
     assert np.all(np.isfinite(np.load(tmp_path / 'adv' / 'logs' / 'generator_loss.npy')))
     assert 'generator_1.h5' in os.listdir(tmp_path / 'adv')
+
+
+@pytest.mark.parametrize('shape,n_filters,n_levels,masked', [((16, 16, 16), 8, 2, False), ((16, 16, 32), 32, 3, False),
+                                                          ((16, 16, 16), 8, 2, True)])
+def test_critic_bf16_vs_fp32_oracle(T, shape, n_filters, n_levels, masked):
+    """WGAN-GP critic with the conv stack in bf16 (Critic3D(dtype='bf16')): D(x), the gradient norm, the loss, every
+    parameter gradient (penalty term included) and the generator-side input gradient against the fp32 oracle under
+    autograd with create_graph.  bf16 tolerances: scalars 2 %, gradients cosine >= 0.98 (there is no pooling here, so no
+    arg-max flips: LeakyReLU masks flip only where a pre-activation is within bf16 rounding of zero)"""
+    torch = T
+    from synthsr_amd.critic import Critic3D
+    from oracle import unet_ref as U
+    net = Critic3D(list(shape) + [1], n_filters=n_filters, n_levels=n_levels, seed=1, dtype='bf16')
+    g = torch.Generator().manual_seed(7)
+    for nm, _ in net.specs:
+        v = net.view(nm)
+        v.copy_((torch.randn(v.shape, generator=g) * (0.1 if nm.endswith('bias') else 1.0)).to(v.device) *
+                (1.0 if nm.endswith('bias') else 3.0 * v.abs().max().item()))
+    net.repack()
+    real, fake = torch.rand(*shape, 1, generator=g), torch.rand(*shape, 1, generator=g)
+    u = 0.3
+    mask = dmask = None
+    if masked:
+        mask = (torch.rand(*shape, 1, generator=g) > 0.3).float()
+        dmask = mask.cuda()
+    loss, d_real, d_fake, norm = net.critic_loss_and_grads(real.cuda(), fake.cuda(), u, gp_weight=10.0, mask=dmask)
+    P = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    ref, nref = U.critic_loss(real, fake, u, P, net.name, n_levels, 10.0, mask=mask)
+    ref.backward()
+    nref, ref = float(nref.detach()), float(ref.detach())
+    assert abs(norm - nref) < 2e-2 * nref, (norm, nref)
+    assert abs(loss - ref) < 2e-2 * max(1.0, abs(ref)), (loss, ref)
+    assert abs(nref - 1.0) > 0.05
+    worst = []
+    for nm, _ in net.specs:
+        got, want = net.view(nm, net.grads).cpu().double().reshape(-1), P[nm].grad.double().reshape(-1)
+        if float(want.norm()) < 1e-12:          # dense_1/bias: -1 (real) + 1 (fake) + 0 (penalty) = 0 exactly
+            assert float(got.norm()) < 1e-6
+            continue
+        cos = float(torch.dot(got, want) / (got.norm() * want.norm()).clamp_min(1e-30))
+        worst.append((cos, nm))
+        assert cos > 0.98, (nm, cos, sorted(worst)[:3])   # measured >= 0.9898 (first-layer bias, 3 levels of 32..128 filters)
+    x = fake.clone().requires_grad_(True)
+    d = U.critic_forward(x if mask is None else x * mask, {k: v.detach() for k, v in P.items()}, net.name, n_levels)
+    gx, = torch.autograd.grad(d, x)
+    got = net.input_gradient(fake.cuda(), dout=-0.01, mask=dmask).cpu().double().reshape(-1)
+    want = (-0.01 * gx).double().reshape(-1)
+    assert float(torch.dot(got, want) / (got.norm() * want.norm())) > 0.99
+    before = net.forward(real.cuda()).item()
+    net.adam_step(lr=1e-3)
+    assert net.forward(real.cuda()).item() != before

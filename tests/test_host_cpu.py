@@ -120,8 +120,11 @@ def test_c_abi_exports_every_declared_symbol():
     if not os.path.exists(_lib.LIB_PATH):
         from synthsr_amd import build
         build.build(verbose=False)
-    hdr = open(os.path.join(REPO, 'include', 'synthsr_hip.h')).read()
+    import glob
+    hdr = ''.join(open(h).read() for h in sorted(glob.glob(os.path.join(REPO, 'include', '*.h'))))
     declared = set(re.findall(r'\b(synthsr_[a-z0-9_]+)\s*\(', hdr))
+    # the stateless boundary header must not declare the process-wide tuning switch (synthsr_hip_tuning.h does)
+    assert 'synthsr_conv3d_set_option(' not in open(os.path.join(REPO, 'include', 'synthsr_hip.h')).read()
     assert len(declared) >= 25
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
