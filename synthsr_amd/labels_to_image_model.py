@@ -146,7 +146,12 @@ class LabelsToImageModel:
         self.d_image = torch.empty(no * self.n_image_channels, dtype=f32, device=dev)
         self.d_target = torch.empty(no * self.n_target_channels, dtype=f32, device=dev)
         self.small_cap = 1 << 16  # floats of per-volume small parameters (SVF grid, bias grids, kernels, LUTs)
-        self.h_small = torch.empty(self.small_cap, dtype=f32).pin_memory()
+        # two pinned staging buffers used alternately + an event per buffer: with device-resident labels a step has no host
+        # sync, so the host could otherwise rewrite the parameters of step k+1 while the async copy of step k is pending
+        self.h_small_ring = [torch.empty(self.small_cap, dtype=f32).pin_memory() for _ in range(2)]
+        self.h_small_events = [None, None]
+        self.h_small_idx = 0
+        self.h_small = self.h_small_ring[0]
         self.d_small = torch.empty(self.small_cap, dtype=f32, device=dev)
         self.d_noise = None
         lut_size = int(self.generation_labels.max()) + 1
@@ -269,6 +274,11 @@ class LabelsToImageModel:
         def __init__(self, model):
             self.m = model
             self.pos = 0
+            model.h_small_idx ^= 1
+            ev = model.h_small_events[model.h_small_idx]
+            if ev is not None:
+                ev.synchronize()       # the copy that last used this buffer (two generate() calls ago) has completed
+            model.h_small = model.h_small_ring[model.h_small_idx]
             self.h = model.h_small.numpy()
 
         def put(self, arr):
@@ -284,6 +294,9 @@ class LabelsToImageModel:
         def flush(self):
             n = self.pos
             self.m.d_small[:n].copy_(self.m.h_small[:n], non_blocking=True)
+            ev = self.m.torch.cuda.Event()
+            ev.record()
+            self.m.h_small_events[self.m.h_small_idx] = ev
 
         def dptr(self, off):
             return ctypes.c_void_p(self.m.d_small.data_ptr() + 4 * off)

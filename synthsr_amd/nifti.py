@@ -71,7 +71,12 @@ def read_nifti(path):
     elif qform_code > 0:
         aff = _quat_to_affine(hdr)
     else:
-        aff = np.diag([pixdim[1], pixdim[2], pixdim[3], 1.0]).astype(np.float64)
+        # neither sform nor qform: nibabel's base affine (what the reference gets from nib.load): zooms on the diagonal with
+        # the first axis flipped, origin at the centre voxel
+        zooms = np.array([pixdim[1], pixdim[2], pixdim[3]], dtype=np.float64)
+        zooms[zooms == 0] = 1.0
+        aff = np.diag([-zooms[0], zooms[1], zooms[2], 1.0])
+        aff[:3, 3] = -aff[:3, :3] @ ((np.array(shape[:3], dtype=np.float64) - 1) / 2.0)
     return np.ascontiguousarray(data), aff, hdr
 
 

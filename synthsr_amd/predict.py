@@ -75,7 +75,13 @@ class Predictor:
             net = unet(nb_features=24, input_shape=list(key) + [self.n_inputs], nb_levels=5, conv_size=3, nb_labels=1, feat_mult=2,
                        nb_conv_per_level=2, conv_dropout=0, final_pred_activation='linear', batch_norm=-1,
                        activation='elu', input_model=None, device=self.device)
-            net.load_state_dict(self.state, strict=False)
+            # a weight file with another layer prefix / missing layers must not leave random weights in place silently
+            missing = [nm for nm, _, _ in net.specs if nm not in self.state]
+            missing += [b['name'] + '/moving_mean' for b in net.bn_layers if b['name'] + '/moving_mean' not in self.state]
+            if missing:
+                raise KeyError('the weight file lacks %d of the network\'s tensors (first: %s): wrong model file or layer '
+                               'prefix?' % (len(missing), missing[0]))
+            net.load_state_dict(self.state, strict=True)
             net.repack()
             self.nets[key] = net
         return self.nets[key]

@@ -207,7 +207,12 @@ def get_volume_info(path_volume, return_volume=False, aff_ref=None, max_channels
     im, aff, header = load_volume(path_volume, im_only=False)
     n_dims, n_channels = get_dims(list(im.shape), max_channels=max_channels)
     shape = np.array(im.shape[:n_dims])
-    res = np.array(header['pixdim'][1:n_dims + 1], dtype=np.float64) if '.nii' in path_volume else np.ones(n_dims)
+    if '.nii' in path_volume:
+        res = np.array(header['pixdim'][1:n_dims + 1], dtype=np.float64)
+    elif '.mgz' in path_volume:                     # ext/lab2im/utils.py:185: header['delta']
+        res = np.array(header['delta'][:n_dims], dtype=np.float64)
+    else:
+        res = np.ones(n_dims)
     if aff_ref is not None:
         here, there = get_ras_axes(aff, n_dims=n_dims), get_ras_axes(aff_ref, n_dims=n_dims)
         im = align_volume_to_ref(im, aff, aff_ref=aff_ref, n_dims=n_dims)

@@ -222,7 +222,8 @@ def test_three_channels_with_5cubed_bias_grids_vs_oracle(env):
     ref = R.labels_to_image(labels, means, stds, tape, GEN, len(GEN), input_channels=[True, True, True],
                             output_channel=[0], output_shape=40, **kw)
     # poison the staging buffer: a wrong offset must not be able to read zeros by luck
-    m.h_small.fill_(1e3)
+    for h in m.h_small_ring:
+        h.fill_(1e3)
     m.d_small.fill_(1e3)
     image, target, seg = m.generate(labels, means, stds, m.draws_from_tape(tape))
     np.testing.assert_array_equal(seg.cpu().numpy(), ref['seg'])

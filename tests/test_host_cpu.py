@@ -81,6 +81,25 @@ def test_nifti_roundtrip_and_orientation(tmp_path):
     np.testing.assert_allclose(res, [1.5, 1.2, 2.], atol=1e-6)
 
 
+def test_nifti_without_sform_qform_gets_the_centred_base_affine(tmp_path):
+    """sform_code = qform_code = 0: nibabel (what the reference loads volumes with) falls back to the base affine -- zooms on
+    the diagonal, first axis flipped, origin at the centre voxel"""
+    import gzip
+    from synthsr_amd.nifti import write_nifti, read_nifti
+    vol = np.arange(4 * 5 * 6, dtype=np.float32).reshape(4, 5, 6)
+    p = str(tmp_path / 'v.nii.gz')
+    write_nifti(p, vol, np.diag([2., 3., 4., 1.]))
+    raw = bytearray(gzip.open(p, 'rb').read())
+    raw[252:256] = b'\0' * 4                      # qform_code, sform_code (two int16)
+    with gzip.open(p, 'wb') as f:
+        f.write(bytes(raw))
+    d, aff, _ = read_nifti(p)
+    np.testing.assert_array_equal(d, vol)
+    exp = np.diag([-2., 3., 4., 1.])
+    exp[:3, 3] = [2. * 1.5, -3. * 2.0, -4. * 2.5]
+    np.testing.assert_allclose(aff, exp, atol=1e-6)
+
+
 def test_get_list_labels_fs_sort():
     from synthsr_amd import volumes
     from synthsr_amd.synthetic import GENERATION_LABELS

@@ -181,6 +181,11 @@ def test_mgz_volumes_layout_and_round_trip(tmp_path):
     back, aff2, hdr = V.load_volume(p, im_only=False)
     assert back.dtype == np.float64 and np.array_equal(back, vol) and np.allclose(aff2, aff, atol=1e-5)
     assert np.allclose(hdr['pixdim'][1:4], [1.0, 1.5, 2.5])
+    # voxel size of a .mgz from the header's delta (ext/lab2im/utils.py:185), in the axis order of the reference frame
+    _, _, _, _, _, res = V.get_volume_info(p, max_channels=3)           # (5, 7, 6): the last axis is spatial
+    assert np.allclose(res, [1.0, 1.5, 2.5])
+    _, _, _, _, _, res_ras = V.get_volume_info(p, aff_ref=np.eye(4), max_channels=3)
+    assert np.allclose(res_ras, [1.5, 2.5, 1.0])
     # same volume through NIfTI: identical data and affine, so predict/training treat both alike
     write_nifti(str(tmp_path / 'a.nii.gz'), vol, aff)
     d_n, a_n, _ = read_nifti(str(tmp_path / 'a.nii.gz'))
