@@ -21,6 +21,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+# the host driver only supports dmabuf IPC: without this RCCL's multi-process setup fails (hipIpcGetMemHandle)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, exact f32
 HBM_PEAK_GBS = 8000.0

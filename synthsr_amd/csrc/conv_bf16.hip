@@ -36,6 +36,42 @@ typedef uint16_t bf16_t;
 constexpr int TZ = 4, TY = 4, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HVOX = HZ * HY * HX;
 constexpr uint32_t OOB = 0x80000000u;
 
+// ---- tile schedule shared by the forward and the weight-gradient kernel -------------------------------------------------
+// Tiles are enumerated (z-slab of SLAB_Z tile planes, y, z within the slab, x): neighbours in all three directions are
+// close in the list.  The list is cut into 8 contiguous parts, one per XCD (consecutive workgroup ids are dealt round-robin
+// to the XCDs, each with a private L2), and the workgroups of an XCD walk their part with stride G / 8: the ~64 tiles an
+// XCD works on at any time form a compact block, so the halo voxels they share are fetched from HBM once (with the plain
+// z-major order every 4x4x16 tile pulled its 2.5x halo through on its own: FETCH ~2.5x the tensor).
+constexpr int SLAB_Z = 4;
+struct TileWalk {
+  int pos, end, stride;
+};
+__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
+  const int G = (int)gridDim.x, b = (int)blockIdx.x;
+  TileWalk w;
+  if (G % 8 == 0) {
+    const int per = (ntiles + 7) / 8, k = b & 7;
+    w.pos = k * per + (b >> 3);
+    w.end = min(ntiles, (k + 1) * per);
+    w.stride = G >> 3;
+  } else {
+    w.pos = b;
+    w.end = ntiles;
+    w.stride = G;
+  }
+  return w;
+}
+__device__ __forceinline__ void tile_decode(int p, int tiles0, int tiles1, int tiles2, int& z0, int& y0, int& x0) {
+  const int t12 = tiles1 * tiles2;
+  const int s = p / (SLAB_Z * t12), r = p - s * SLAB_Z * t12;
+  const int sz = min(SLAB_Z, tiles0 - s * SLAB_Z);
+  const int t1 = r / (sz * tiles2), rr = r - t1 * sz * tiles2;
+  const int zz = rr / tiles2, t2 = rr - zz * tiles2;
+  z0 = (s * SLAB_Z + zz) * TZ;
+  y0 = t1 * TY;
+  x0 = t2 * TX;
+}
+
 // LDS row strides (bytes), odd multiples of 16 B so that the 16 lanes of an x-row hit 16 different bank quads.
 // weight gradient: room for CK channels + the constant-1 pad block; forward: no pad needed (24 ch = 48 B = 3 quads)
 __host__ __device__ constexpr int rowb_for(int ck) { return ck == 8 ? 48 : 80; }
@@ -49,11 +85,12 @@ __device__ __forceinline__ void sfor(F&& f) {
   }
 }
 
+// ELU(alpha = 1) for a bf16 result: 2^(v log2 e) - 1 through v_exp_f32 has an ABSOLUTE error of ~6e-8 (the subtraction
+// cancels near 0), i.e. below half a bf16 ulp of the result for |v| > 3e-5 and negligible below -- no polynomial branch as
+// in the fp32 kernels: 4 vector-ALU instructions instead of 14 (the epilogue of a 24 -> 24 tile is 32 values per lane)
 __device__ __forceinline__ float elu_f(float v) {
   const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f;
-  const float p = v * fmaf(v, fmaf(v, fmaf(v, fmaf(v, 1.f / 120.f, 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
-  const float n = v > -0.125f ? p : e;
-  return v > 0.f ? v : n;
+  return v > 0.f ? v : e;
 }
 __device__ __forceinline__ float elu_dy(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
@@ -63,7 +100,12 @@ __device__ __forceinline__ uint32_t f2bf(float f) {  // round to nearest even (f
   return u >> 16;
 }
 __device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair, round to nearest even: the cast lowers to ONE v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
 
 // ------------------------------------------------------------------------------------------------ weight packing
 // forward layout (A fragments): [co-chunk][cc][step][mt][lane 64][8] bf16; lane = (m = lane & 15, g = lane >> 4):
@@ -140,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
   const int chunk = blockIdx.y;
-  const int G = gridDim.x;
-  const int my_pos = (G % 8 == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const TileWalk walk = tile_walk(a.ntiles);
+  const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
   const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout;
 
   // per-lane LDS byte offset of the (tap, c8) pair of every K-step (relative to the voxel's halo row)
@@ -170,12 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 2), 0x00020000);
   u32x4 stg[NLD];
-  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
-    const int t2 = t % a.tiles2, t1 = (t / a.tiles2) % a.tiles1, t0 = t / (a.tiles2 * a.tiles1);
-    z0 = t0 * TZ;
-    y0 = t1 * TY;
-    x0 = t2 * TX;
-  };
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) { tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0); };
   auto load_halo = [&](int t, int cc) {
     int z0, y0, x0;
     tile_origin(t, z0, y0, x0);
@@ -215,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
 
   // split-K: slice blockIdx.z of the input-channel chunks (ksplit == 1: all of them)
   const int cc_lo = (int)(((int64_t)blockIdx.z * a.ncc) / a.ksplit), cc_hi = (int)(((int64_t)(blockIdx.z + 1) * a.ncc) / a.ksplit);
-  if (my_pos < a.ntiles) load_halo(my_pos, cc_lo);
-  for (int t = my_pos; t < a.ntiles; t += G) {
+  if (walk.pos < walk.end) load_halo(walk.pos, cc_lo);
+  for (int t = walk.pos; t < walk.end; t += walk.stride) {
     f32x4 acc[TY][MT];
 #pragma unroll
     for (int y = 0; y < TY; ++y)
@@ -230,8 +267,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
       __syncthreads();
       if (cc + 1 < cc_hi) {
         load_halo(t, cc + 1);
-      } else if (t + G < a.ntiles) {
-        load_halo(t + G, cc_lo);
+      } else if (t + walk.stride < walk.end) {
+        load_halo(t + walk.stride, cc_lo);
       }
       const bf16x8* wf = wfrag + (int64_t)cc * NSTEP * MT * 64;
       // software pipeline, pinned with sched_barriers (left alone, the scheduler re-uses ONE register set and waits for
@@ -514,21 +551,16 @@ __global__ __launch_bounds__(64) void bf16_stats_finalize_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
-// one transpose read with a compile-time offset: address VGPRs stay loop-invariant, the K-step / row part is the immediate
-template <int OFF>
-__device__ __forceinline__ u32x2 tr_read(uint32_t addr) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
-  u32x2 r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-  return r;
-}
-// the compiler does not count inline-asm LDS reads in its own s_waitcnt bookkeeping: wait explicitly, then make every
-// consumer depend on a (no-op) volatile asm that is ordered after the wait
-__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void touch(u32x2& r) { asm volatile("" : "+v"(r)); }
-__device__ __forceinline__ bf16x8 join8(u32x2 lo, u32x2 hi) {
-  u32x4 r = {lo.x, lo.y, hi.x, hi.y};
-  return __builtin_bit_cast(bf16x8, r);
+// gfx950 transpose read (ds_read_b64_tr_b16) through the compiler builtin: the register allocator places the two 64-bit
+// halves of an MFMA operand in one aligned VGPR quad (inline asm needed 4 v_mov per operand), folds constant address parts
+// into the 16-bit offset field and keeps its own s_waitcnt bookkeeping
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* lds_base, uint32_t off_lo, uint32_t off_hi) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_base + off_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_base + off_hi));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 struct WgArgs {
@@ -555,8 +587,8 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15, lrow = li >> 2, lq = li & 3;
   const int cc = blockIdx.y % a.ncc, oc = blockIdx.y / a.ncc;
-  const int G = gridDim.x;
-  const int my_pos = (G % 8 == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const TileWalk walk = tile_walk(a.ntiles);
+  const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
   const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout;
   unsigned char* ldz = lds + XBYTES;
 
@@ -578,9 +610,8 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
   }
   // voxel (8g + lrow) of a 32-voxel K-step: x = (8g + lrow) % 16, row (8g + lrow) / 16 of the step's row pair
   const int vx = (8 * g + lrow) & 15, vr = (8 * g + lrow) >> 4;
-  const uint32_t ldsb = (uint32_t)(uintptr_t)lds;
-  const uint32_t abase = ldsb + (uint32_t)((vr * HX + vx) * ROWB);            // + aoff[q]; K-step rows / x + 4 as immediates
-  const uint32_t bbase = ldsb + (uint32_t)XBYTES + (uint32_t)((vr * TX + vx) * DROWB + lq * 8);
+  const uint32_t abase = (uint32_t)((vr * HX + vx) * ROWB);            // + aoff[q]; K-step rows / x + 4 as immediates
+  const uint32_t bbase = (uint32_t)XBYTES + (uint32_t)((vr * TX + vx) * DROWB + lq * 8);
 
   // pad channels of every halo row (never overwritten by the staging)
   for (int v = tid; v < HVOX; v += NTHR) {
@@ -619,12 +650,7 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
   const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(a.dout), 0, (int)((int64_t)D0 * D1 * D2 * Cout * 2), 0x00020000);
   u32x4 stg[NLD], dst[NDL];
-  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) {
-    const int t2 = t % a.tiles2, t1 = (t / a.tiles2) % a.tiles1, t0 = t / (a.tiles2 * a.tiles1);
-    z0 = t0 * TZ;
-    y0 = t1 * TY;
-    x0 = t2 * TX;
-  };
+  auto tile_origin = [&](int t, int& z0, int& y0, int& x0) { tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0); };
   auto load_tile = [&](int t) {
     int z0, y0, x0;
     tile_origin(t, z0, y0, x0);
@@ -655,8 +681,8 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (my_pos < a.ntiles) load_tile(my_pos);
-  for (int t = my_pos; t < a.ntiles; t += G) {
+  if (walk.pos < walk.end) load_tile(walk.pos);
+  for (int t = walk.pos; t < walk.end; t += walk.stride) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NLD; ++i)
@@ -665,44 +691,27 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
     for (int i = 0; i < NDL; ++i)
       if (i < NDL - 1 || tid + NTHR * i < NDP) *reinterpret_cast<u32x4*>(ldz + dlds[i]) = dst[i];
     __syncthreads();
-    if (t + G < a.ntiles) load_tile(t + G);
+    if (t + walk.stride < walk.end) load_tile(t + walk.stride);
     // 8 K-steps of 32 voxels = 2 x-rows each: rows (z, y) = (ks >> 1, 2 (ks & 1) + vr)
     sfor<0, 8>([&](auto KS) {
       constexpr int ks = decltype(KS)::value;
       constexpr int z = ks >> 1, yb = 2 * (ks & 1);
       constexpr int arow = ((z * HY + yb) * HX) * ROWB;     // halo row of voxel (z, yb, 0) with tap (0, 0, 0)
       constexpr int brow = ((z * TY + yb) * TX) * DROWB;
-      // all transpose reads of the K-step first (B: 2 per column tile, A: 2 per row tile), one wait, then the MFMAs
-      u32x2 br[NT][2], ar[MPW][2];
-      sfor<0, NT>([&](auto N) {
-        constexpr int n = decltype(N)::value;
-        br[n][0] = tr_read<brow + n * 32>(bbase);
-        br[n][1] = tr_read<brow + n * 32 + 4 * DROWB>(bbase);
-      });
-      sfor<0, MPW>([&](auto Q) {
-        constexpr int q = decltype(Q)::value;
-        ar[q][0] = tr_read<arow>(abase + aoff[q]);
-        ar[q][1] = tr_read<arow + 4 * ROWB>(abase + aoff[q]);
-      });
-      lds_wait();
+      // all transpose reads of the K-step first (B: 2 per column tile, A: 2 per row tile), then the MFMAs
+      bf16x8 bfr[NT], afr[MPW];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        touch(br[n][0]);
-        touch(br[n][1]);
-      }
+      for (int n = 0; n < NT; ++n) bfr[n] = tr_read8(lds, bbase + brow + n * 32, bbase + brow + n * 32 + 4 * DROWB);
 #pragma unroll
-      for (int q = 0; q < MPW; ++q) {
-        touch(ar[q][0]);
-        touch(ar[q][1]);
-      }
+      for (int q = 0; q < MPW; ++q) afr[q] = tr_read8(lds, abase + aoff[q] + arow, abase + aoff[q] + arow + 4 * ROWB);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < MPW; ++q) {
         if (wave * MPW + q >= NMT) continue;  // wave-uniform
-        const bf16x8 afr = join8(ar[q][0], ar[q][1]);
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, join8(br[n][0], br[n][1]), acc[q][n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[q], bfr[n], acc[q][n], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     });
   }
   // ---- flush: lane (n = li -> co, rows 4g + i -> block 4*mtile + g, element i)
