@@ -74,7 +74,8 @@ __device__ __forceinline__ void tile_decode(int p, int tiles0, int tiles1, int t
 
 // LDS row strides (bytes), odd multiples of 16 B so that the 16 lanes of an x-row hit 16 different bank quads.
 // weight gradient: room for CK channels + the constant-1 pad block; forward: no pad needed (24 ch = 48 B = 3 quads)
-__host__ __device__ constexpr int rowb_for(int ck) { return ck == 8 ? 48 : 80; }
+// (weight gradient: 32 B x odd -- the 8 consecutive x-voxels one LDS cycle serves then start in 8 different 32-byte bank groups)
+__host__ __device__ constexpr int rowb_for(int ck) { return ck == 8 ? 32 : 96; }
 __host__ __device__ constexpr int rowb_fwd(int ck) { return ck == 8 ? 16 : (ck == 24 ? 48 : 80); }
 
 template <int I, int N, class F>
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
   constexpr int NMT = (NBLK + 3) / 4;               // 16-row tiles
   constexpr int NW = 8, NTHR = 64 * NW;              // 8 waves: the row tiles' accumulators fit 128 VGPRs per wave
   constexpr int MPW = (NMT + NW - 1) / NW;          // row tiles per wave
-  constexpr int DROWB = NT * 32 + 16;               // dz tile row stride (odd multiple of 16 B)
+  constexpr int DROWB = (NT & 1) ? NT * 32 : NT * 32 + 32;  // dz tile row stride: 32 B x odd (see rowb_for)
   constexpr int XBYTES = HVOX * ROWB;
   constexpr int NPIECE = HVOX * C8, NLD = (NPIECE + NTHR - 1) / NTHR;
   constexpr int NDP = TZ * TY * TX * NT * 2, NDL = (NDP + NTHR - 1) / NTHR;  // 16-byte pieces of the dz tile
@@ -608,8 +609,11 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
     }
     aoff[q] = off;
   }
-  // voxel (8g + lrow) of a 32-voxel K-step: x = (8g + lrow) % 16, row (8g + lrow) / 16 of the step's row pair
-  const int vx = (8 * g + lrow) & 15, vr = (8 * g + lrow) >> 4;
+  // K index 8g + j of a 32-voxel K-step (2 x-rows) <-> voxel (row g >> 1, x = 8 (j >> 2) + 4 (g & 1) + (j & 3)): any
+  // bijection works as long as A and B agree, and with this one the 32 lanes an LDS cycle serves (g and g ^ 1) read 8
+  // CONSECUTIVE x-voxels -- with 96-byte rows their 32-byte pieces fall into 8 different bank groups (no conflicts when the
+  // 4 blocks of a row tile share a tap; with voxel 8g + j, x and x + 8 always met in the same banks)
+  const int vx = 4 * (g & 1) + lrow, vr = g >> 1;
   const uint32_t abase = (uint32_t)((vr * HX + vx) * ROWB);            // + aoff[q]; K-step rows / x + 4 as immediates
   const uint32_t bbase = (uint32_t)XBYTES + (uint32_t)((vr * TX + vx) * DROWB + lq * 8);
 
@@ -701,9 +705,9 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
       // all transpose reads of the K-step first (B: 2 per column tile, A: 2 per row tile), then the MFMAs
       bf16x8 bfr[NT], afr[MPW];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bfr[n] = tr_read8(lds, bbase + brow + n * 32, bbase + brow + n * 32 + 4 * DROWB);
+      for (int n = 0; n < NT; ++n) bfr[n] = tr_read8(lds, bbase + brow + n * 32, bbase + brow + n * 32 + 8 * DROWB);
 #pragma unroll
-      for (int q = 0; q < MPW; ++q) afr[q] = tr_read8(lds, abase + aoff[q] + arow, abase + aoff[q] + arow + 4 * ROWB);
+      for (int q = 0; q < MPW; ++q) afr[q] = tr_read8(lds, abase + aoff[q] + arow, abase + aoff[q] + arow + 8 * ROWB);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < MPW; ++q) {
@@ -746,7 +750,7 @@ int launch_wgrad(const WgArgs& a0, hipStream_t st) {
   if (gx < 8) gx = 8;
   while (gx > 8 && gx > a.ntiles) gx -= 8;
   if (a.ntiles < 8) gx = a.ntiles;
-  const size_t smem = (size_t)HVOX * rowb_for(CK) + (size_t)TZ * TY * TX * (NT * 32 + 16);
+  const size_t smem = (size_t)HVOX * rowb_for(CK) + (size_t)TZ * TY * TX * ((NT & 1) ? NT * 32 : NT * 32 + 32);
   auto kern = conv3d_bf16_wgrad_kernel<CK, NT>;
   static bool attr_done = false;
   if (!attr_done) {
