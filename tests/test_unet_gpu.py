@@ -247,14 +247,18 @@ def test_unet_loss_and_gradients_vs_autograd(T, feats, levels, shape, cin, fold)
     lr.backward()
     close(pred.view(*shape, 1), pr, 5e-4, 'prediction')
     assert abs(loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
-    worst = 0.0
-    for nm, _, _ in net.specs:
+    # per-tensor max error relative to the tensor's max-abs, bounded per layer type: conv / head kernels 2e-3 (fp32
+    # accumulation order over up to 4e6 voxels, float atomics); parameters whose gradient is a sum of cancelling terms over
+    # every voxel -- BatchNorm beta / gamma and the biases -- 5e-3.  The failure message lists the worst tensors.
+    errs = {}
+    for nm, _, kind in net.specs:
         got = net.view(nm, net.grads).cpu().double()
         ref = P[nm].grad.double()
-        scale = max(ref.abs().max().item(), 1e-12)
-        err = (got - ref).abs().max().item() / scale
-        worst = max(worst, err)
-        assert err < 5e-3, '%s grad rel err %.3e' % (nm, err)
+        errs[nm] = ((got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12), kind)
+    worst_list = sorted(((e, nm) for nm, (e, _) in errs.items()), reverse=True)[:5]
+    for nm, (err, kind) in errs.items():
+        bound = 2e-3 if kind in ('kernel', 'head_w') else 5e-3
+        assert err < bound, '%s (%s) grad rel err %.3e >= %.0e; worst: %s' % (nm, kind, err, bound, worst_list)
     # batch statistics
     for bn in net.bn_layers:
         o, C = bn['soff'], bn['C']
