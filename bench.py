@@ -120,10 +120,19 @@ def cpu_baseline(size_all=160, size_one=64, timed=3):
     nthreads_default = torch.get_num_threads()
     res = {}
     for tag, size, threads in (('all', size_all, nthreads_default), ('one', size_one, 1)):
-        torch.set_num_threads(threads)
-        step = _oracle_step_factory(size)
-        step()                                                   # warm-up (oneDNN primitive creation, page faults)
-        ts = [step() for _ in range(timed)]
+        if threads == 1:
+            # OpenMP's thread count is a per-thread setting and autograd runs the backward on its own thread: the only
+            # reliable way to pin the whole step to ONE core's worth of threads is a fresh process with OMP_NUM_THREADS=1
+            import subprocess
+            env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1')
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(size), str(timed)],
+                                 capture_output=True, text=True, env=env, timeout=1800)
+            ts = json.loads([l for l in out.stdout.splitlines() if l.startswith('[')][-1])
+        else:
+            torch.set_num_threads(threads)
+            step = _oracle_step_factory(size)
+            step()                                               # warm-up (oneDNN primitive creation, page faults)
+            ts = [step() for _ in range(timed)]
         scale = (size / 160.0) ** 3
         res[tag] = dict(volumes_per_s=round(scale / float(np.mean([t[0] for t in ts])), 5), threads=threads, size=size,
                         step_s=[round(t[0], 2) for t in ts], generator_s=round(float(np.mean([t[1] for t in ts])), 2))
@@ -142,7 +151,18 @@ def conv_flops(kind, shape, cin, cout):
     return 2.0 * 27 * cin * cout * float(np.prod(shape))
 
 
+def cpu_worker(size, timed):
+    """one-thread leg of cpu_baseline (run with OMP_NUM_THREADS=1): prints [[step_s, generator_s], ...]"""
+    import torch
+    torch.set_num_threads(1)
+    step = _oracle_step_factory(size)
+    step()
+    print(json.dumps([list(step()) for _ in range(timed)]))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == '--cpu-worker':
+        return cpu_worker(int(sys.argv[2]), int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
