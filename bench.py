@@ -39,6 +39,24 @@ def physical_cores():
         return os.cpu_count()
 
 
+def usable_cpus():
+    """CPUs this process may actually run on: the affinity mask, capped by a cgroup v2 / v1 CPU quota if one is set"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def _oracle_step_factory(size, seed=0):
     """one oracle training step (numpy generator + PyTorch-CPU U-Net fwd / bwd / Keras-Adam with live moments) on a
     size^3 volume of the benchmark configuration; returns a callable -> seconds"""
@@ -118,8 +136,9 @@ def cpu_baseline(size_all=160, size_one=64, timed=3):
     import torch
     cores = physical_cores()
     nthreads_default = torch.get_num_threads()
+    usable = usable_cpus()
     res = {}
-    for tag, size, threads in (('all', size_all, nthreads_default), ('one', size_one, 1)):
+    for tag, size, threads in (('all', size_all, min(nthreads_default, usable)), ('one', size_one, 1)):
         if threads == 1:
             # OpenMP's thread count is a per-thread setting and autograd runs the backward on its own thread: the only
             # reliable way to pin the whole step to ONE core's worth of threads is a fresh process with OMP_NUM_THREADS=1
@@ -138,7 +157,7 @@ def cpu_baseline(size_all=160, size_one=64, timed=3):
                         step_s=[round(t[0], 2) for t in ts], generator_s=round(float(np.mean([t[1] for t in ts])), 2))
     torch.set_num_threads(nthreads_default)
     return {'value': res['all']['volumes_per_s'], 'unit': 'volumes/s', 'cores': cores, 'kind': 'port',
-            'threads': res['all']['threads'], 'value_one_thread': res['one']['volumes_per_s'],
+            'threads': res['all']['threads'], 'usable_cpus': usable, 'value_one_thread': res['one']['volumes_per_s'],
             'sample': 'oracle (numpy generator + PyTorch-CPU U-Net fwd/bwd/Keras-Adam; CPU restatement, NOT TensorFlow): '
                       '1 warm-up + %d timed steps. all threads (%d on %d physical cores): %d^3 volumes, %s s per step '
                       '(generator %.2f s of it). one thread: %d^3 volumes (%.1f%% of the voxels of 160^3, volumes/s scaled '

@@ -64,11 +64,15 @@ def round_bf16(x):
     return _RoundBF16.apply(x)
 
 
-def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, collect=None, softmax=False, quant=None):
+def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, collect=None, softmax=False, quant=None,
+                 dropout=None):
     """P: dict name -> tensor with the Keras layer names (`<prefix>_conv_downarm_l_k/kernel`, ...).
     Returns prediction [d0,d1,d2,1].  `collect` (dict) receives batch statistics per BN layer.
     quant (optional, e.g. round_bf16): applied wherever the bf16 network stores a tensor -- the input, every conv kernel,
-    every conv + ELU output, every pooled tensor and every concatenated tensor (BatchNorm, head and loss stay fp32)."""
+    every conv + ELU output, every pooled tensor and every concatenated tensor (BatchNorm, head and loss stay fp32).
+    dropout (optional): conv layer name -> per-channel factor (0 or 1/(1-rate)) of the feature-wise KL.Dropout that
+    follows that conv (noise_shape [None,1,1,1,C], ext/neuron/models.py:320-324, 448-451); the skip connection reads the
+    conv layer's own output, i.e. the tensor BEFORE the dropout (models.py:431-432)."""
     L = nb_levels
     if quant is not None:
         x = quant(x)
@@ -89,8 +93,9 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
     for l in range(L):
         for k in range(nconv):
             nm = '%s_conv_downarm_%d_%d' % (prefix, l, k)
-            cur = q(F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias'])))
-        skips.append(cur)  # pre-BN skip (models.py:431-432)
+            pre = q(F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias'])))
+            cur = pre * dropout[nm] if dropout is not None else pre
+        skips.append(pre)  # pre-BN (and pre-dropout) skip: the conv layer's output (models.py:431-432)
         cur = bn(cur, '%s_bn_down_%d' % (prefix, l))
         if l < L - 1:
             cur = q(maxpool2(cur))
@@ -100,6 +105,8 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
         for j in range(nconv):
             nm = '%s_conv_uparm_%d_%d' % (prefix, L + k, j)
             cur = q(F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias'])))
+            if dropout is not None:
+                cur = cur * dropout[nm]
         cur = bn(cur, '%s_bn_up_%d' % (prefix, k))
     w, b = P['%s_likelihood/kernel' % prefix], P['%s_likelihood/bias' % prefix]
     out = cur @ w.reshape(w.shape[-2], w.shape[-1]) + b

@@ -152,8 +152,6 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
             raise Exception('The number or residual channels and output channels must be the same')
         if any(x >= n_channels for x in work_with_residual_channel):
             raise Exception('indices in work_with_residual_channel cannot be greater than the total number of channels')
-    if dropout != 0:
-        raise NotImplementedError('dropout is not supported')
     if batchsize != 1:
         raise NotImplementedError('batchsize 1 only')
     if n_output_channels != 1:

@@ -151,14 +151,26 @@ def uniform_f32(u, lo, hi):
     return _f(u) * (hi - lo) + lo
 
 
+def pick_bounds_block(b):
+    """build-time half of utils.draw_value_from_distribution for an array hyperparameter (ext/lab2im/utils.py:1011-1016):
+    a (2n, m) array is cut down to one of its n two-row blocks with np.random.randint (the reference's stream and call);
+    everything else passes through (paths are loaded)."""
+    b = load_array_if_path(b)
+    if isinstance(b, np.ndarray):
+        assert b.shape[0] % 2 == 0, 'number of rows of parameter_range should be divisible by 2'
+        block = 2 * np.random.randint(b.shape[0] // 2)
+        return b[block:block + 2, :]
+    return b
+
+
 def bounds_pair(b, centre, size):
     """hyperparameter -> (min[size], max[size]) — utils.draw_value_from_distribution (utils.py:1002-1016)"""
     b = load_array_if_path(b)
     if isinstance(b, np.ndarray):
         if b.shape[0] % 2 != 0:
             raise AssertionError('number of rows of parameter_range should be divisible by 2')
-        if b.shape[0] != 2:
-            raise NotImplementedError('multi-modality (2n, m) bounds are not supported on the device path yet')
+        if b.shape[0] != 2:  # direct callers; LabelsToImageModel resolves its arrays once with pick_bounds_block
+            b = pick_bounds_block(b)
         return b[0].astype(np.float64), b[1].astype(np.float64)
     if b is None:
         raise ValueError('None bounds have caller-specific defaults; pass a number')

@@ -99,10 +99,13 @@ class LabelsToImageModel:
                 # RandomFlip reverses the axis at POSITION 0 of flip_axes (F10); SynthSR always passes eye(4)
                 raise NotImplementedError('flipping is only supported for RAS-aligned label maps (aff=eye(4))')
         self.swap_lut = hm.flip_swap_lut(self.generation_labels, n_neutral_labels) if flipping else None
-        self.scaling_bounds = hm.load_array_if_path(scaling_bounds)
-        self.rotation_bounds = hm.load_array_if_path(rotation_bounds)
-        self.shearing_bounds = hm.load_array_if_path(shearing_bounds)
-        self.translation_bounds = hm.load_array_if_path(translation_bounds)
+        # a (2n, m) array of bounds: ONE of its n two-row blocks serves the whole model, picked with numpy's global stream
+        # while the graph is built (utils.draw_value_from_distribution, ext/lab2im/utils.py:1013-1016, called by
+        # sample_affine_transform in the order rotation, shearing, scaling, translation: utils.py:685-738)
+        self.rotation_bounds = hm.pick_bounds_block(rotation_bounds)
+        self.shearing_bounds = hm.pick_bounds_block(shearing_bounds)
+        self.scaling_bounds = hm.pick_bounds_block(scaling_bounds)
+        self.translation_bounds = hm.pick_bounds_block(translation_bounds)
         self.apply_affine = any(b is not False for b in (self.scaling_bounds, self.rotation_bounds,
                                                          self.shearing_bounds, self.translation_bounds))
         self.nonlin_std = nonlin_std

@@ -227,8 +227,6 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
                                  % len(work_with_residual_channel))
     if regression_metric not in ('l1', 'l2', 'laplace', 'ssim'):
         raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(regression_metric))
-    if dropout != 0:
-        raise NotImplementedError('dropout is not supported')
     if batchsize != 1:
         raise NotImplementedError('batchsize 1 per GPU (use more GPUs for a larger effective batch)')
 

@@ -21,7 +21,7 @@ from . import ops
 class UNet3D:
     def __init__(self, nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None,
                  feat_mult=1, nb_conv_per_level=1, batch_norm=None, activation='elu', device=None, seed=0,
-                 final_pred_activation='linear', fold_upsample='auto', table_only=False, dtype='f32'):
+                 final_pred_activation='linear', fold_upsample='auto', table_only=False, dtype='f32', conv_dropout=0):
         self.overlap_wgrad = False  # weight gradients on a second HIP stream (see _fork): measured 0.5 ms SLOWER per step
                                     # on one MI355X (cross-stream event waits cost more than the tails they fill) ...
         self.overlap_max_voxels = 40 ** 3  # ... on the small levels only: big persistent kernels just disturb each other
@@ -36,6 +36,21 @@ class UNet3D:
         self.act_dtype = torch.bfloat16 if self.bf16 else torch.float32
         if self.bf16:
             fold_upsample = False  # the bf16 MFMA is 16x faster: the concatenated tensor is simply materialised
+        # conv_dropout (ext/neuron/models.py:320-324, 448-451): KL.Dropout(rate, noise_shape=[None, 1, 1, 1, C]) after every
+        # conv + ELU, i.e. ONE factor per feature map and step (0, or 1/(1-rate)).  A per-channel factor never has to touch
+        # the activations: the factor of a conv that feeds another conv rides on that conv's input-channel weights
+        # (forward and data gradient use the scaled copy; its weight gradient is scaled back the same way), and the factor
+        # of a level's last conv is absorbed by the BatchNorm that follows it (see _dropout_bn).  The skip connection reads
+        # the conv layer's own output, before the dropout, in the reference too (models.py:431-432).
+        self.conv_dropout = float(conv_dropout)
+        if not 0.0 <= self.conv_dropout < 1.0:
+            raise ValueError('conv_dropout should be in [0, 1)')
+        self._drop_gen = torch.Generator(device='cpu')
+        self._drop_gen.manual_seed(int(seed) + 0x5eed)
+        self._drop_next = None      # scales for the next training forward (tests); None: drawn
+        self._drop = None           # conv name -> per-channel scale of the step in flight
+        self._mult = None
+        self._packed_scaled = False
         if conv_size != 3:
             raise NotImplementedError('only conv_size=3 is supported')
         if activation != 'elu':
@@ -235,25 +250,26 @@ class UNet3D:
                     o, n = c[key + '_off']
                     c[key] = self._packed[o:o + n]
 
-    def _repack_bf16(self):
+    def _repack_bf16(self, src=None):
         """bf16 fragment-ordered copies of every conv kernel (forward, and data-gradient where a gradient flows on)"""
         first = True
         for c in self.all_convs():
-            w = self.view(c['w'])
+            w = self.view(c['w'], src)
             c['wp'] = ops.pack_conv_weights_bf16(w, 0, out=c.get('wp'))
             if not first or self.need_input_grad:
                 c['wpd'] = ops.pack_conv_weights_bf16(w, 1, out=c.get('wpd'))
             first = False
 
-    def repack(self):
+    def repack(self, src=None):
         """refresh the MFMA-fragment-ordered copies of ALL conv kernels in one launch (after init / optimizer step /
-        load)"""
+        load); src: a flat buffer laid out like self.params to pack instead (the dropout-scaled copy)"""
+        self._packed_scaled = src is not None
         if self.bf16:
-            return self._repack_bf16()
+            return self._repack_bf16(src)
         from . import _lib
         if getattr(self, '_jobs', None) is None:
             self._pack_jobs()
-        _lib.check(_lib.load().synthsr_conv3d_pack_all(_lib.ptr(self.params), _lib.ptr(self._packed),
+        _lib.check(_lib.load().synthsr_conv3d_pack_all(_lib.ptr(self.params if src is None else src), _lib.ptr(self._packed),
                                                        _lib.ptr(self._jobs), int(self._jobs.shape[0]), _lib.stream()),
                    'conv3d_pack_all')
 
@@ -297,11 +313,58 @@ class UNet3D:
         src = self.bn_batch if self.training else self.bn_moving
         return src[o:o + 2 * C]
 
+    # ------------------------------------------------------------------ feature-wise dropout
+    def set_dropout_scales(self, scales):
+        """explicit per-channel factors {conv layer name: [Cout] of 0 | 1/(1-rate)} for the NEXT training forward (parity
+        tests against the oracle); None: drawn from the network's own generator"""
+        self._drop_next = scales
+
+    def _start_dropout(self):
+        p = self.conv_dropout
+        drop = {}
+        for c in self.all_convs():
+            if self._drop_next is not None:
+                v = torch.as_tensor(np.asarray(self._drop_next[c['name']], dtype=np.float32))
+            else:  # tf.nn.dropout: keep where uniform >= rate, scale the kept features by 1 / (1 - rate)
+                v = (torch.rand(c['cout'], generator=self._drop_gen) >= p).float() / (1.0 - p)
+            drop[c['name']] = v.to(self.device)
+        self._drop_next = None
+        self._drop = drop
+        if self._mult is None:
+            self._mult = torch.ones_like(self.params)
+            self._params_eff = torch.empty_like(self.params)
+            self.bn_true = torch.zeros_like(self.bn_batch)
+        self._mult.fill_(1.0)
+        for grp in self.enc + self.dec:
+            for k in range(1, len(grp['convs'])):
+                self.view(grp['convs'][k]['w'], self._mult).mul_(drop[grp['convs'][k - 1]['name']][None, None, None, :, None])
+        torch.mul(self.params, self._mult, out=self._params_eff)
+        self.repack(self._params_eff)
+
+    def _dropout_bn(self, bn, s):
+        """BatchNorm of x' = s * x (s per channel) written in terms of the stored x: xhat' = (x - mean_x) * r with
+        r = s / sqrt(s^2 var_x + eps) = 1 / sqrt(var_x + eps / s^2); the kernels form rsqrt(var + eps), so the batch-variance
+        slot gets var_x + eps (1/s^2 - 1) (inf for a dropped feature: xhat' = 0, the output is beta).  dr/dvar_x = -r^3/2
+        as for a plain BatchNorm, so the backward kernels hold unchanged.  The moving averages see the statistics of x'."""
+        o, C = bn['soff'], bn['C']
+        mean, var = self.bn_batch[o:o + C], self.bn_batch[o + C:o + 2 * C]
+        self.bn_true[o:o + C] = mean * s
+        self.bn_true[o + C:o + 2 * C] = var * s * s
+        inv2 = torch.where(s > 0, 1.0 / (s * s).clamp_min(1e-30), torch.full_like(s, float('inf')))
+        var.add_(ops.BN_EPS * (inv2 - 1.0))
+
     # ------------------------------------------------------------------ forward
     def forward(self, x):
         """x [d0,d1,d2,Cin] -> saves activations; returns the last decoder activation (pre-BN) and its BN"""
         L = self.nb_levels
         self.saved = dict(x=[], enc=[], cat=[], dec=[])
+        dropping = self.training and self.conv_dropout > 0
+        if dropping:
+            self._start_dropout()
+        else:
+            self._drop = None
+            if self._packed_scaled:  # a training forward without its optimizer step left scaled kernels behind
+                self.repack()
         if self.bf16 and x.dtype != torch.bfloat16:
             # generator output (float32, Cin channels) -> bf16 with the channel count padded to a multiple of 8 (zeros):
             # 16-byte K-groups for the MFMA; the first conv's kernel is packed / its gradient taken on the real Cin only
@@ -322,6 +385,8 @@ class UNet3D:
                     cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1, out=out)
                 acts.append(cur)
             self.saved['enc'].append(acts)
+            if dropping:
+                self._dropout_bn(e['bn'], self._drop[e['convs'][-1]['name']])
             if l < L - 1:
                 cur = ops.bn_maxpool(cur, self._stats(e['bn']), self.view(e['bn']['gamma']), self.view(e['bn']['beta']),
                                      out=self.buf('pool%d' % l, self.shapes[l + 1] + [e['bn']['C']]))
@@ -363,6 +428,8 @@ class UNet3D:
             self.saved['dec'].append(acts)
             if self.training and not stats_done:  # single-conv level whose only conv was the folded one
                 ops.bn_stats(cur, self._stats(d['bn']), self.bn_ws)
+            if dropping:
+                self._dropout_bn(d['bn'], self._drop[d['convs'][-1]['name']])
             low, low_bn = cur, d['bn']
         self.saved['last'] = (low, low_bn)
         return low, low_bn
@@ -470,6 +537,24 @@ class UNet3D:
         G = self.grads
         self._frozen = frozen
         self._pending_bn = None
+        if self._drop is not None and not frozen:
+            # the convs ran on W * diag(s_in): dL/dW = dL/d(W diag(s_in)) * diag(s_in), applied to each finished range
+            # of the flat gradient before it is handed on (bucketed all-reduce)
+            user, mult, done = on_grad_ready, self._mult, [G.numel()]
+
+            def on_grad_ready(lo):
+                G[lo:done[0]].mul_(mult[lo:done[0]])
+                done[0] = lo
+                if user is not None:
+                    user(lo)
+            out = self._backward_inner(on_grad_ready, g_last, frozen)
+            if done[0] > 0:
+                on_grad_ready(0)
+            return out
+        return self._backward_inner(on_grad_ready, g_last, frozen)
+
+    def _backward_inner(self, on_grad_ready, g_last, frozen):
+        G = self.grads
         low, bn = self.saved['last']
         C = low.shape[3]
         if frozen:
@@ -508,8 +593,12 @@ class UNet3D:
                 skip, lo_bn = self.saved['cat'][k]
                 Cl = lo_bn.shape[3]
                 # all convs but the first: regular; the first one through the folded kernels
-                dz = self._convs_backward(g, None, d['convs'][1:], acts[1:], acts[0], need_dx=True, tag='d%d' % k,
-                                          elu_below=acts[0])
+                if len(d['convs']) > 1:
+                    dz = self._convs_backward(g, None, d['convs'][1:], acts[1:], acts[0], need_dx=True, tag='d%d' % k,
+                                              elu_below=acts[0])
+                else:  # nb_conv_per_level = 1: the folded conv feeds the BatchNorm itself
+                    self._join()
+                    dz = self._elu_backward(g, acts[0], None, None)
                 c0 = d['convs'][0]
                 if not frozen:
                     dW = self.view(c0['w'], self.grads)
@@ -648,7 +737,8 @@ class UNet3D:
     def update_moving_stats(self):
         """K.moving_average_update with momentum .99; variance gets Keras' n/(n-(1+eps)) correction"""
         m = self.bn_momentum
-        self.bn_moving.mul_(m).add_(self.bn_batch * self.bn_corr, alpha=1.0 - m)
+        batch = self.bn_true if self._drop is not None else self.bn_batch  # dropout: statistics of the dropped-out tensor
+        self.bn_moving.mul_(m).add_(batch * self.bn_corr, alpha=1.0 - m)
 
 
 def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None, feat_mult=1,
@@ -658,12 +748,12 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
          fold_upsample='auto', dtype='f32'):
     """ext/neuron/models.py:26-47 signature.  Unsupported knobs of the over-parametrised reference raise."""
     if pool_size != 2 or padding != 'same' or dilation_rate_mult != 1 or skip_n_concatenations != 0 or \
-            use_residuals or add_prior_layer or layer_nb_feats is not None or conv_dropout != 0:
+            use_residuals or add_prior_layer or layer_nb_feats is not None:
         raise NotImplementedError('only the configuration SynthSR.training uses is supported '
-                                  '(pool 2, same padding, no dilation/residuals/dropout/prior)')
+                                  '(pool 2, same padding, no dilation/residuals/prior)')
     net = UNet3D(nb_features, input_shape, nb_levels, conv_size, nb_labels, name=name, prefix=prefix,
                  feat_mult=feat_mult, nb_conv_per_level=nb_conv_per_level, batch_norm=batch_norm,
                  activation=activation, device=device, seed=seed, final_pred_activation=final_pred_activation,
-                 fold_upsample=fold_upsample, dtype=dtype)
+                 fold_upsample=fold_upsample, dtype=dtype, conv_dropout=conv_dropout)
     net.input_model = input_model
     return net

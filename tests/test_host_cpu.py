@@ -318,3 +318,23 @@ def test_model_inputs_and_draws_match_reference_under_seeded_numpy():
                 ref = g['mi_%s_%d_%d' % (tag, it, j)]
                 assert np.asarray(a).shape == ref.shape, (tag, it, j)
                 np.testing.assert_array_equal(np.asarray(a), ref, err_msg='%s %d %d' % (tag, it, j))
+
+
+def test_multi_modality_affine_bounds_pick_one_block_at_build_time():
+    """(2n, m) bounds (ext/lab2im/utils.py:1011-1016): ONE block, drawn with np.random.randint like the reference's
+    draw_value_from_distribution (whose numpy branch is pinned by model_inputs.npz `arr2_u`), then used as min / max rows"""
+    b = np.arange(18, dtype=np.float64).reshape(6, 3)
+    np.random.seed(11)
+    want = 2 * np.random.randint(3)
+    np.random.seed(11)
+    got = hm.pick_bounds_block(b)
+    assert got.shape == (2, 3) and np.array_equal(got, b[want:want + 2])
+    lo, hi = hm.bounds_pair(got, 0., 3)
+    assert np.array_equal(lo, b[want]) and np.array_equal(hi, b[want + 1])
+    assert hm.pick_bounds_block(False) is False and hm.pick_bounds_block(.15) == .15
+    np.random.seed(11)
+    T = hm.sample_affine(dict(rot=np.full(3, .5, np.float32)), rotation_bounds=b)   # direct callers: picked on the spot
+    lo, hi = b[want], b[want + 1]
+    assert T.shape == (4, 4) and abs(np.linalg.det(T[:3, :3]) - 1) < 1e-5
+    with pytest.raises(AssertionError):
+        hm.pick_bounds_block(np.zeros((3, 3)))
