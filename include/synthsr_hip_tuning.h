@@ -17,6 +17,17 @@ extern "C" {
  * that change the launch geometry must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
 
+/* Deterministic mode (process-wide, single stream; synchronises the device).  on = 1: every cross-workgroup float
+ * accumulation (weight / bias / BatchNorm gradients, BatchNorm statistics, losses, the critic's dense layers) is flushed in
+ * workgroup-id order instead of arrival order, in-workgroup LDS float atomics are replaced by ordered sums, and the split-K /
+ * parity-split forward variants (partial sums meeting in atomics) are not selected: the same inputs give bit-identical
+ * results run after run.  Slower (flushes are serialised); the default (0) keeps plain atomics.  Not covered: channel counts
+ * C with 384 % (C / 4) != 0 and the Dice sums of the segmentation-regularised loss (data-indexed LDS atomics).
+ * Reference: SURVEY.md section 5 (determinism); the reference itself relies on TF's non-deterministic GPU reductions. */
+int synthsr_set_deterministic(int on);
+/* 0 = off, 1 = on and every ordered wait completed, 2 = on but a wait timed out (results may be unordered), -1 = error */
+int synthsr_deterministic_status(void);
+
 #ifdef __cplusplus
 }
 #endif

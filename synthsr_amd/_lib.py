@@ -51,6 +51,8 @@ SIGNATURES = {
     'synthsr_bn_stats_from_partials': (c_int, [_P, c_int, c_int64, c_int, _P, _S]),
     'synthsr_conv3d_fwd_add': (c_int, [_P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_conv3d_set_option': (c_int, [c_int, c_int]),
+    'synthsr_set_deterministic': (c_int, [c_int]),
+    'synthsr_deterministic_status': (c_int, []),
     'synthsr_conv3d_plan': (c_int, [POINTER(c_int), c_int, c_int, c_int, POINTER(c_int64)]),
     'synthsr_conv3d_pack_all': (c_int, [_P, _P, _P, c_int, _S]),
     'synthsr_conv3d_pack_ex': (c_int64, [_P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, _S]),

@@ -33,6 +33,109 @@ __device__ static inline void syn_block_range(int64_t n, int64_t& lo, int64_t& h
   lo = (int64_t)pos * chunk;
   hi = lo + chunk < n ? lo + chunk : n;
 }
+
+// ---- deterministic mode (synthsr_set_deterministic, include/synthsr_hip_tuning.h) ------------------------------------------
+// Every cross-workgroup float accumulation in the library is "reduce inside the workgroup in a fixed order, then ONE flush of
+// atomicAdd per workgroup onto the shared target": the only run-to-run freedom is the order in which the flushes land.
+// Deterministic mode removes it in one of two ways.
+//  * syn_det_gather (small partials: channel sums, losses): every workgroup parks its partial row in scratch; the workgroup
+//    that arrives LAST adds the rows up in workgroup-id order and alone performs the flush.  No serialisation.
+//  * syn_turn_begin / syn_turn_end (large partials: weight gradients): the workgroups that share target addresses form a chain
+//    and flush one after the other in chain position order -- a workgroup waits until the chain's ticket equals its position,
+//    flushes, fences, passes the ticket on (the last one resets it for the next launch).  Workgroups are dispatched in id
+//    order (per XCD as well) and every predecessor in a chain has a lower id, so the lowest unfinished id is always resident:
+//    no deadlock; the wait is bounded anyway (`timeout` is raised when it gives up).
+// One state block for the whole library: deterministic mode is for single-stream use.  g_syn_det == nullptr (the default)
+// costs one scalar load per workgroup.
+constexpr int SYN_DET_CHAINS = 8192;
+struct SynDet {
+  int arrivals;           // syn_det_gather: workgroups that parked their row
+  int timeout;            // raised when an ordered wait gave up (results may then be unordered)
+  long long scratch_floats;
+  float* scratch;
+  int chain[SYN_DET_CHAINS];  // tickets
+};
+static __device__ SynDet* g_syn_det = nullptr;  // one copy per translation unit, set through SYN_DET_SETTER(name)
+
+__device__ __forceinline__ int syn_wg_linear() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+__device__ __forceinline__ int syn_wg_count() { return gridDim.x * gridDim.y * gridDim.z; }
+__device__ __forceinline__ bool syn_tid0() { return threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0; }
+__device__ __forceinline__ bool syn_det_on() { return g_syn_det != nullptr; }
+
+// Ordered flush: chain = id of the group of workgroups that share target addresses, pos / len = this workgroup's place in it.
+// Call from workgroup-uniform control flow, by EVERY workgroup of the grid exactly once.
+__device__ __forceinline__ int* syn_turn_begin(int chain, int pos) {
+  SynDet* d = g_syn_det;
+  if (!d) return nullptr;
+  int* tk = &d->chain[chain % SYN_DET_CHAINS];
+  if (syn_tid0()) {
+    int spins = 0;
+    while (__hip_atomic_load(tk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != pos) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 24)) {  // ~1 s: report and go on unordered rather than hang the device
+        d->timeout = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  return tk;
+}
+
+__device__ __forceinline__ void syn_turn_end(int* tk, int pos, int len) {
+  if (tk) {
+    __threadfence();  // this workgroup's atomics are performed before the next workgroup starts its own
+    __syncthreads();
+    if (syn_tid0()) __hip_atomic_store(tk, pos + 1 == len ? 0 : pos + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// the weight-gradient kernels: grid (voxel split, slice [, slice]) -- workgroups with equal (y, z) accumulate the same slice
+__device__ __forceinline__ int* syn_turn_begin_x() { return syn_turn_begin(blockIdx.y + gridDim.y * blockIdx.z, blockIdx.x); }
+__device__ __forceinline__ void syn_turn_end_x(int* tk) { syn_turn_end(tk, blockIdx.x, gridDim.x); }
+
+// Small partials: part[0..n) is this workgroup's partial (LDS, complete and synchronised).  Default mode: returns true for
+// every workgroup (all of them flush with atomics).  Deterministic mode: returns true only in the workgroup that arrived last,
+// with part[] replaced by the sum over ALL workgroups in id order (double accumulation, one rounding).  Workgroup-uniform.
+__device__ __forceinline__ bool syn_det_gather(float* part, int n) {
+  SynDet* d = g_syn_det;
+  if (!d) return true;
+  const int wg = syn_wg_linear(), nwg = syn_wg_count();
+  const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z), nt = blockDim.x * blockDim.y * blockDim.z;
+  __shared__ int s_last;
+  if ((long long)nwg * n > d->scratch_floats) {  // does not fit: one chain over the whole grid instead
+    (void)syn_turn_begin(SYN_DET_CHAINS - 1, wg);
+    return true;  // the caller flushes with atomics; syn_det_gather_end passes the ticket on
+  }
+  float* row = d->scratch + (size_t)wg * n;
+  for (int i = tid; i < n; i += nt) row[i] = part[i];
+  __threadfence();
+  __syncthreads();
+  if (syn_tid0()) s_last = (atomicAdd(&d->arrivals, 1) == nwg - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return false;
+  __threadfence();
+  for (int i = tid; i < n; i += nt) {
+    double t = 0.0;
+    for (int w = 0; w < nwg; ++w) t += (double)__builtin_nontemporal_load(d->scratch + (size_t)w * n + i);
+    part[i] = (float)t;
+  }
+  if (syn_tid0()) d->arrivals = 0;
+  __syncthreads();
+  return true;
+}
+
+// after the flush that follows a `true` from syn_det_gather (no-op unless the oversize fallback took a ticket)
+__device__ __forceinline__ void syn_det_gather_end(int n) {
+  SynDet* d = g_syn_det;
+  if (d && (long long)syn_wg_count() * n > d->scratch_floats)
+    syn_turn_end(&d->chain[SYN_DET_CHAINS - 1], syn_wg_linear(), syn_wg_count());
+}
+
+#define SYN_DET_SETTER(name)                                                                              \
+  extern "C" __attribute__((visibility("hidden"))) int syn_det_set_##name(SynDet* p) {                   \
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_syn_det), &p, sizeof(p)) == hipSuccess ? 0 : 1;                 \
+  }
 #endif
 
 // monotone uint32 encoding of float (total order incl. negatives) for atomicMin/atomicMax

@@ -14,6 +14,9 @@
 // The data-gradient is the forward kernel on weights packed with flipped taps / swapped channels.
 #include "common.h"
 #include <algorithm>
+#include <cstddef>
+
+SYN_DET_SETTER(conv3d)
 
 namespace {
 
@@ -1924,6 +1927,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
   }
 
   // ---- flush: D row = (lane>>4)*4 + reg -> (tap, ci), col = lane&15 -> co
+  int* turn = syn_turn_begin_x();
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
 #pragma unroll
@@ -1943,6 +1947,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
       }
     }
   }
+  syn_turn_end_x(turn);
 }
 
 // ---- VALU-lean weight gradient (CK = 24, Cout % 4 == 0, tensors < 2 GiB).  Same tiling and LDS layout as
@@ -2142,6 +2147,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
 
   // ---- flush: D row = (lane>>4)*4 + reg -> (tap, ci), col = lane&15 -> co
   if (ext.dbg & 8) return;
+  int* turn = syn_turn_begin_x();
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
 #pragma unroll
@@ -2168,6 +2174,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
       }
     }
   }
+  syn_turn_end_x(turn);
 }
 
 // ---- weight gradient with small box tiles for the deep levels (40^3: 4x4x8 voxels, 20^3: 4x4x4) ---------------------
@@ -2337,6 +2344,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_box_kernel(const float* _
     }
   }
   if (ext.dbg & 8) return;
+  int* turn = syn_turn_begin_x();
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
 #pragma unroll
@@ -2361,6 +2369,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_box_kernel(const float* _
       }
     }
   }
+  syn_turn_end_x(turn);
 }
 
 // ---- first-layer weight gradient (Cin <= 2, Cout = 24) on the 4x4x1 MFMA -------------------------------------------
@@ -2511,18 +2520,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_c2_kernel(const float* __
 __global__ void rows_reduce_kernel(const float* __restrict__ partial, int nwg, float* __restrict__ dw,
                                    float* __restrict__ dbias, int nrow, int cin, int cin_total, int ci_off) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;  // row * 24 + c
-  if (j >= (nrow + 1) * 24) return;
+  const bool live = j < (nrow + 1) * 24;
   const int row = j / 24, c = j - row * 24;
   const int per = (nwg + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(nwg, b0 + per);
   float v = 0.f;
-  for (int b = b0; b < b1; ++b) v += partial[(size_t)b * 1536 + j];
-  if (row < nrow) {
-    const int tap = row / cin, ci = row - tap * cin;
-    atomicAdd(&dw[((size_t)tap * cin_total + ci_off + ci) * 24 + c], v);
-  } else if (dbias) {
-    atomicAdd(&dbias[c], v);
+  if (live)
+    for (int b = b0; b < b1; ++b) v += partial[(size_t)b * 1536 + j];
+  int* turn = syn_turn_begin(blockIdx.x, blockIdx.y);  // chain = address block (x), position = workgroup group (y)
+  if (live) {
+    if (row < nrow) {
+      const int tap = row / cin, ci = row - tap * cin;
+      atomicAdd(&dw[((size_t)tap * cin_total + ci_off + ci) * 24 + c], v);
+    } else if (dbias) {
+      atomicAdd(&dbias[c], v);
+    }
   }
+  syn_turn_end(turn, blockIdx.y, gridDim.y);
 }
 
 // ---- weight gradient of the forward parity convs (folded decoder conv, Cout = 24) on the 4x4x1 MFMA ----------------
@@ -2693,6 +2707,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
   if (dbg & 8) return;
   // ---- flush, one wave (= one parity) at a time through LDS: its [8 taps][24 ci][24 co] partial is laid out linearly so
   // that every global atomic instruction covers 64 consecutive floats
+  int* turn = syn_turn_begin_x();
   for (int w = 0; w < 4; ++w) {
     __syncthreads();
     if (wave == w) {
@@ -2714,6 +2729,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
       atomicAdd(dst + ((size_t)tap * Cin + cc * CK) * Cout + r, lds[e]);
     }
   }
+  syn_turn_end_x(turn);
 }
 
 // dbias fallback for the generic weight-gradient kernel: per-channel sum of dout [n][C]
@@ -2722,6 +2738,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   // threads run along the channels (coalesced rows of C floats), 256 / C voxel rows in flight per workgroup
   __shared__ float part[256];
   const int rows = C <= 256 ? 256 / C : 1;
+  int* turn = nullptr;
   for (int c0 = 0; c0 < C; c0 += 256) {  // one pass unless C > 256
     const int width = min(256, C - c0);
     const int r = threadIdx.x / width, c = threadIdx.x - r * width;
@@ -2730,6 +2747,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
       for (int64_t v = (int64_t)blockIdx.x * rows + r; v < n; v += (int64_t)gridDim.x * rows) acc += x[v * C + c0 + c];
     part[threadIdx.x] = acc;
     __syncthreads();
+    if (c0 == 0) turn = syn_turn_begin(0, blockIdx.x);  // deterministic mode: the whole flush of this workgroup is one turn
     if (threadIdx.x < width) {
       float t = 0.f;
       for (int k = 0; k < rows; ++k) t += part[k * width + threadIdx.x];
@@ -2737,6 +2755,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
     __syncthreads();
   }
+  syn_turn_end(turn, blockIdx.x, gridDim.x);
 }
 
 // library-owned device scratch (grown on demand, reused by later calls on the same stream order)
@@ -2753,6 +2772,7 @@ static float* lib_scratch(size_t bytes) {
   return buf;
 }
 
+static int g_det = 0;  // synthsr_set_deterministic: no split-K / parity-split forward (their partial sums meet in atomics)
 static int g_persist = 1;
 static int g_force_mt = 0;
 static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout % 16 == 8 remainder channels on the
@@ -2832,7 +2852,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
       int ks = (int)cdiv(g_ks_target, (int)w);
       if (ks > p.ncc) ks = p.ncc;
       if (ks > 16) ks = 16;
-      if (ks >= 2) p.ksplit = ks;
+      if (ks >= 2 && !g_det) p.ksplit = ks;
     }
     return p;
   }
@@ -2841,7 +2861,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
     int ks = (int)cdiv(g_ks_target, (int)w);
     if (ks > p.ncc / 2) ks = p.ncc / 2;
     if (ks > 8) ks = 8;
-    if (ks >= 2) p.ksplit = ks;
+    if (ks >= 2 && !g_det) p.ksplit = ks;
   }
   return p;
 }
@@ -2851,7 +2871,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
 // (20^3 / 10^3 levels: 120 workgroups ran at 16-34 % of the MFMA peak), then every workgroup adds its share atomically.
 static int g_psplit = 1;  // option 7: 0 disables
 inline int parity_split(int64_t workgroups, const float* bias, int act, const ConvExt& ext) {
-  if (!g_psplit || bias != nullptr || act != 0 || ext.addend != nullptr) return 1;
+  if (!g_psplit || g_det || bias != nullptr || act != 0 || ext.addend != nullptr) return 1;
   int ps = 1;
   while (ps < 8 && workgroups * ps < 400) ps *= 2;
   return ps;
@@ -3372,11 +3392,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_p4_kernel(const float* __
     for (int g = 0; g < 6; ++g) *reinterpret_cast<float4*>(d + 4 * g) = make_float4(acc[q][g][0], acc[q][g][1], acc[q][g][2], acc[q][g][3]);
   }
   __syncthreads();
+  int* turn = syn_turn_begin_x();
   for (int e = tid; e < 27 * CK * Cout; e += 256) {
     const int tap = e / (CK * Cout), r = e - tap * (CK * Cout);
     atomicAdd(dw + ((size_t)tap * cin_total + ci_off + cc * CK) * Cout + r, lds[e]);
   }
   if (dbias && cc == 0 && tid < Cout) atomicAdd(dbias + tid, lds[NBLK * 4 * Cout + tid]);
+  syn_turn_end_x(turn);
 }
 
 int launch_wgrad_c2(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int Cin, hipStream_t st,
@@ -3610,6 +3632,47 @@ int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo
   return dispatch_fwd<8>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);
 }
 
+
+// ---- deterministic mode (see common.h: syn_det_gather / syn_turn_begin) ------------------------------------------------
+extern "C" int syn_det_set_pointwise(SynDet*);
+extern "C" int syn_det_set_critic(SynDet*);
+extern "C" int syn_det_set_ssim(SynDet*);
+extern "C" int syn_det_set_conv_bf16(SynDet*);
+static SynDet* g_det_state = nullptr;
+constexpr long long DET_SCRATCH_FLOATS = 16ll << 20;  // 64 MB of partial rows (4096 workgroups x 4096 sums)
+
+int synthsr_set_deterministic(int on) {
+  if (hipDeviceSynchronize() != hipSuccess) return SYNTHSR_ELAUNCH;  // no kernel may see the switch mid-flight
+  if (on && !g_det_state) {
+    float* scratch = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&g_det_state), sizeof(SynDet)) != hipSuccess) return SYNTHSR_ELAUNCH;
+    if (hipMalloc(reinterpret_cast<void**>(&scratch), DET_SCRATCH_FLOATS * sizeof(float)) != hipSuccess) return SYNTHSR_ELAUNCH;
+    SynDet* h = new SynDet();
+    h->scratch_floats = DET_SCRATCH_FLOATS;
+    h->scratch = scratch;
+    const hipError_t e = hipMemcpy(g_det_state, h, sizeof(SynDet), hipMemcpyHostToDevice);
+    delete h;
+    if (e != hipSuccess) return SYNTHSR_ELAUNCH;
+  }
+  if (g_det_state) {  // fresh tickets / counters / timeout flag (scratch pointer and size stay)
+    if (hipMemset(g_det_state, 0, offsetof(SynDet, scratch_floats)) != hipSuccess) return SYNTHSR_ELAUNCH;
+    if (hipMemset(reinterpret_cast<char*>(g_det_state) + offsetof(SynDet, chain), 0, sizeof(int) * SYN_DET_CHAINS) != hipSuccess)
+      return SYNTHSR_ELAUNCH;
+  }
+  SynDet* p = on ? g_det_state : nullptr;
+  g_det = on ? 1 : 0;
+  if (syn_det_set_conv3d(p) || syn_det_set_pointwise(p) || syn_det_set_critic(p) || syn_det_set_ssim(p) ||
+      syn_det_set_conv_bf16(p))
+    return SYNTHSR_ELAUNCH;
+  return hipDeviceSynchronize() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+int synthsr_deterministic_status(void) {
+  if (!g_det) return 0;
+  int v[2] = {0, 0};
+  if (hipMemcpy(v, g_det_state, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return v[1] ? 2 : 1;  // 1: on and every ordered wait completed; 2: on, but a wait timed out (order not guaranteed)
+}
 
 int synthsr_conv3d_set_option(int option, int value) {
   if (option == 0) {

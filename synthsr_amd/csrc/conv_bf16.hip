@@ -25,6 +25,8 @@
 #include <type_traits>
 #include <utility>
 
+SYN_DET_SETTER(conv_bf16)
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -719,6 +721,7 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
     });
   }
   // ---- flush: lane (n = li -> co, rows 4g + i -> block 4*mtile + g, element i)
+  int* turn = syn_turn_begin_x();
 #pragma unroll
   for (int q = 0; q < MPW; ++q) {
     const int mtile = wave * MPW + q;
@@ -740,6 +743,7 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
       }
     }
   }
+  syn_turn_end_x(turn);
 }
 
 template <int CK, int NT>

@@ -4,6 +4,8 @@
 // All HBM-bound.
 #include "common.h"
 
+SYN_DET_SETTER(critic)
+
 namespace {
 
 // y = x > 0 ? x : alpha x (in place allowed); with dy: dx = dy * (y > 0 ? 1 : alpha), y being the layer OUTPUT (its sign is
@@ -30,6 +32,7 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
                                                           float* __restrict__ out) {
   __shared__ float part[256];
   const int rows = C <= 256 ? 256 / C : 1;
+  int* turn = nullptr;
   for (int c0 = 0; c0 < C; c0 += 256) {
     const int width = min(256, C - c0);
     const int r = threadIdx.x / width, c = threadIdx.x - r * width;
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
       for (int64_t v = (int64_t)blockIdx.x * rows + r; v < n; v += (int64_t)gridDim.x * rows) acc += x[v * C + c0 + c];
     part[threadIdx.x] = acc;
     __syncthreads();
+    if (c0 == 0) turn = syn_turn_begin(0, blockIdx.x);
     if (threadIdx.x < width) {
       float t = 0.f;
       for (int k = 0; k < rows; ++k) t += part[k * width + threadIdx.x];
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
     }
     __syncthreads();
   }
+  syn_turn_end(turn, blockIdx.x, gridDim.x);
 }
 
 // Dense layer y[j] = b[j] + sum_i x[i] W[i][j]  (W [n_in][n_out], Keras layout).  One workgroup per slab of rows, partial
@@ -62,7 +67,9 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict_
     acc[j] += s;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < n_out; j += 256) atomicAdd(&y[j], acc[j]);
+  if (syn_det_gather(acc, n_out))
+    for (int j = threadIdx.x; j < n_out; j += 256) atomicAdd(&y[j], acc[j]);
+  syn_det_gather_end(n_out);
 }
 
 // backward of the dense layer: dx[i] = sum_j W[i][j] dy[j] (optional), dW[i][j] += scale_w * x[i] dy[j] (optional)
@@ -115,7 +122,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   __shared__ float w[4];
   if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, w[0] + w[1] + w[2] + w[3]);
+  if (threadIdx.x == 0) w[0] = w[0] + w[1] + w[2] + w[3];
+  __syncthreads();
+  if (syn_det_gather(w, 1))
+    if (threadIdx.x == 0) atomicAdd(out, w[0]);
+  syn_det_gather_end(1);
 }
 
 }  // namespace

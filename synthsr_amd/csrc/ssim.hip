@@ -10,6 +10,8 @@
 // Everything is HBM-bound elementwise / 11-tap stencil work on 16 MB maps: separable 1-D passes, planar maps.
 #include "common.h"
 
+SYN_DET_SETTER(ssim)
+
 namespace {
 
 constexpr int SSIM_TAPS = 11;
@@ -87,7 +89,11 @@ __global__ __launch_bounds__(256) void ssim_point_kernel(const float* __restrict
   __shared__ float wsum[4];
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = lsum;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale);
+  if (threadIdx.x == 0) wsum[0] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale;
+  __syncthreads();
+  if (syn_det_gather(wsum, 1))
+    if (threadIdx.x == 0) atomicAdd(loss, wsum[0]);
+  syn_det_gather_end(1);
 }
 
 // dpred[v in box] += GA + y GB + 2 x GC  (GA, GB, GC: the three gradient maps filtered back onto the box)

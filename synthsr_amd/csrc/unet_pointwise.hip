@@ -8,6 +8,8 @@
 // global atomic per (block, channel).
 #include "common.h"
 
+SYN_DET_SETTER(pointwise)
+
 namespace {
 
 constexpr int RB = 384;  // reduction block size (6 waves)
@@ -48,6 +50,24 @@ template <int NV>
 __device__ __forceinline__ void block_channel_reduce(float4 (&part)[NV], int c4, int C4, bool fixed, float* smem) {
   // smem: NV * C4 * 4 floats, zeroed by the caller before accumulation started
   if (fixed) {
+    if (syn_det_on()) {
+      // deterministic mode: the blockDim / C4 threads of a channel group add one after the other (LDS float atomics land
+      // in arbitration order)
+      const int rounds = (int)blockDim.x / C4, mine = (int)threadIdx.x / C4;
+      for (int r = 0; r < rounds; ++r) {
+        if (mine == r) {
+#pragma unroll
+          for (int k = 0; k < NV; ++k) {
+            smem[(k * C4 + c4) * 4 + 0] += part[k].x;
+            smem[(k * C4 + c4) * 4 + 1] += part[k].y;
+            smem[(k * C4 + c4) * 4 + 2] += part[k].z;
+            smem[(k * C4 + c4) * 4 + 3] += part[k].w;
+          }
+        }
+        __syncthreads();
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       atomicAdd(&smem[(k * C4 + c4) * 4 + 0], part[k].x);
@@ -55,6 +75,25 @@ __device__ __forceinline__ void block_channel_reduce(float4 (&part)[NV], int c4,
       atomicAdd(&smem[(k * C4 + c4) * 4 + 2], part[k].z);
       atomicAdd(&smem[(k * C4 + c4) * 4 + 3], part[k].w);
     }
+  }
+  __syncthreads();
+}
+
+// one float per thread summed onto *slot (LDS; zeroed and synchronised by the caller).  Deterministic mode: wave butterflies,
+// then the waves in order.  Workgroup-uniform call sites only.
+__device__ __forceinline__ void block_scalar_add(float v, float* slot) {
+  if (!syn_det_on()) {
+    atomicAdd(slot, v);
+    return;
+  }
+  __shared__ float wave_part[16];
+  v = syn_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = *slot;
+    for (int w = 0; w < (int)(blockDim.x + 63) / 64; ++w) t += wave_part[w];
+    *slot = t;
   }
   __syncthreads();
 }
@@ -124,7 +163,9 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const T* __restrict__ dy, c
   }
   if (dbias) {
     block_channel_reduce<1>(part, threadIdx.x % C4, C4, fixed, smem);
-    for (int i = threadIdx.x; i < C4 * 4; i += RB) atomicAdd(&dbias[i], smem[i]);
+    if (syn_det_gather(smem, C4 * 4))
+      for (int i = threadIdx.x; i < C4 * 4; i += RB) atomicAdd(&dbias[i], smem[i]);
+    syn_det_gather_end(C4 * 4);
   }
 }
 
@@ -156,7 +197,9 @@ __global__ __launch_bounds__(RB) void bn_stats_kernel(const T* __restrict__ x, i
     }
   }
   block_channel_reduce<2>(part, threadIdx.x % C4, C4, fixed, smem);
-  for (int i = threadIdx.x; i < 2 * C4 * 4; i += RB) atomicAdd(&ws[i], (double)smem[i]);
+  if (syn_det_gather(smem, 2 * C4 * 4))
+    for (int i = threadIdx.x; i < 2 * C4 * 4; i += RB) atomicAdd(&ws[i], (double)smem[i]);
+  syn_det_gather_end(2 * C4 * 4);
 }
 
 __global__ void bn_stats_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats, int C, double inv_n) {
@@ -337,7 +380,9 @@ __global__ __launch_bounds__(RB) void bn_maxpool_bwd_sums_kernel(const T* __rest
     }
   }
   block_channel_reduce<2>(part, threadIdx.x % C4, C4, fixed, smem);
-  for (int i = threadIdx.x; i < 2 * C; i += RB) atomicAdd(&sums[i], smem[i]);
+  if (syn_det_gather(smem, 2 * C))
+    for (int i = threadIdx.x; i < 2 * C; i += RB) atomicAdd(&sums[i], smem[i]);
+  syn_det_gather_end(2 * C);
 }
 
 // ------------------------------------------------------------------------------------------ BN backward
@@ -372,7 +417,9 @@ __global__ __launch_bounds__(RB) void bn_bwd_reduce_kernel(const T* __restrict__
     }
   }
   block_channel_reduce<2>(part, threadIdx.x % C4, C4, fixed, smem);
-  for (int i = threadIdx.x; i < 2 * C; i += RB) atomicAdd(&sums[i], smem[i]);
+  if (syn_det_gather(smem, 2 * C))
+    for (int i = threadIdx.x; i < 2 * C; i += RB) atomicAdd(&sums[i], smem[i]);
+  syn_det_gather_end(2 * C);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -588,7 +635,11 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict_
   __shared__ float wsum[4];
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = lsum;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n);
+  if (threadIdx.x == 0) wsum[0] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n;
+  __syncthreads();
+  if (syn_det_gather(wsum, 1))
+    if (threadIdx.x == 0) atomicAdd(loss, wsum[0]);
+  syn_det_gather_end(1);
 }
 
 // K-channel head backward (K > 1, e.g. the intensity + spread channels of the 'laplace' loss): the gradient w.r.t. the
@@ -640,13 +691,16 @@ __global__ __launch_bounds__(RB) void head_multi_bwd_kernel(const float* __restr
     st4(dbn + i * 4, d);
   }
 #pragma unroll
-  for (int k = 0; k < K; ++k) atomicAdd(&smem[K * C + k], dbp[k]);
+  for (int k = 0; k < K; ++k) block_scalar_add(dbp[k], &smem[K * C + k]);
   block_channel_reduce<K>(part, threadIdx.x % C4, C4, fixed, smem);
-  for (int i = threadIdx.x; i < C * K; i += RB) {
-    const int c = i / K, k = i - c * K;
-    atomicAdd(&dw[i], gamma[c] * smem[k * C + c] + beta[c] * smem[K * C + k]);
+  if (syn_det_gather(smem, K * C + K)) {
+    for (int i = threadIdx.x; i < C * K; i += RB) {
+      const int c = i / K, k = i - c * K;
+      atomicAdd(&dw[i], gamma[c] * smem[k * C + c] + beta[c] * smem[K * C + k]);
+    }
+    if (threadIdx.x < K) atomicAdd(&db[threadIdx.x], smem[K * C + threadIdx.x]);
   }
-  if (threadIdx.x < K) atomicAdd(&db[threadIdx.x], smem[K * C + threadIdx.x]);
+  syn_det_gather_end(K * C + K);
 }
 
 template <typename T>
@@ -687,18 +741,21 @@ __global__ __launch_bounds__(RB) void head_bwd_kernel(const float* __restrict__ 
     }
     if (c == 0) dbp += g;
   }
-  atomicAdd(&smem[C], dbp);
+  block_scalar_add(dbp, &smem[C]);
   block_channel_reduce<1>(part, threadIdx.x % C4, C4, fixed, smem);
-  const float B = smem[C];
-  for (int i = threadIdx.x; i < C; i += RB) {
-    const float A = smem[i];
-    atomicAdd(&dw[i], gamma[i] * A + beta[i] * B);
-    if (sums) {
-      atomicAdd(&sums[i], w[i] * B);
-      atomicAdd(&sums[C + i], w[i] * A);
+  if (syn_det_gather(smem, C + 1)) {
+    const float B = smem[C];
+    for (int i = threadIdx.x; i < C; i += RB) {
+      const float A = smem[i];
+      atomicAdd(&dw[i], gamma[i] * A + beta[i] * B);
+      if (sums) {
+        atomicAdd(&sums[i], w[i] * B);
+        atomicAdd(&sums[C + i], w[i] * A);
+      }
     }
+    if (threadIdx.x == 0) atomicAdd(db, B);
   }
-  if (threadIdx.x == 0) atomicAdd(db, B);
+  syn_det_gather_end(C + 1);
 }
 
 // ------------------------------------------------------------------ segmentation-regularised loss (metrics_model.py:136-215)

@@ -16,6 +16,27 @@ BN_EPS = 1e-3  # keras.layers.BatchNormalization default epsilon (Keras 2.3.1)
 _prof = None
 
 
+def set_deterministic(on=True):
+    """process-wide switch (include/synthsr_hip_tuning.h: synthsr_set_deterministic): bit-identical results run after run on
+    the same inputs -- every cross-workgroup float accumulation is flushed in workgroup order, no split-K forward.  Slower;
+    single-stream use.  Returns the previous setting."""
+    global _deterministic
+    prev = _deterministic
+    torch.cuda.synchronize()
+    _lib.check(_L().synthsr_set_deterministic(int(bool(on))), 'set_deterministic')
+    _deterministic = bool(on)
+    return prev
+
+
+def deterministic_status():
+    """0 off; 1 on and every ordered flush completed in order; 2 on but a wait timed out (order not guaranteed)"""
+    torch.cuda.synchronize()
+    return int(_L().synthsr_deterministic_status())
+
+
+_deterministic = False
+
+
 def profile_start():
     global _prof
     _prof = []

@@ -537,6 +537,10 @@ class UNet3D:
         G = self.grads
         self._frozen = frozen
         self._pending_bn = None
+        if ops._deterministic:  # ordered in-workgroup sums need a fixed channel group per thread (unet_pointwise.hip)
+            bad = [c for c in set(self.feats) if c % 4 or 384 % (c // 4)]
+            if bad:
+                raise ValueError('deterministic mode: feature counts %s need 384 %% (C / 4) == 0' % bad)
         if self._drop is not None and not frozen:
             # the convs ran on W * diag(s_in): dL/dW = dL/d(W diag(s_in)) * diag(s_in), applied to each finished range
             # of the flat gradient before it is handed on (bucketed all-reduce)

@@ -1,0 +1,145 @@
+"""Deterministic mode (include/synthsr_hip_tuning.h: synthsr_set_deterministic): with the switch on, the
+same inputs give BIT-identical losses, gradients and updated weights run after run -- weight / bias / BatchNorm gradients,
+BatchNorm statistics and losses are accumulated across workgroups in workgroup-id order instead of arrival order.  The
+default path (plain float atomics) is left as it is; the tests only assert what the switch promises."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def det():
+    import torch
+    from synthsr_amd import ops
+    assert torch.cuda.is_available()
+    prev = ops.set_deterministic(True)
+    yield ops
+    assert ops.deterministic_status() == 1, 'an ordered wait timed out'
+    ops.set_deterministic(prev)
+    assert ops.deterministic_status() == 0
+
+
+def _net(dtype, feats, levels, shape, cin, seed=3, fold='auto'):
+    import torch
+    from synthsr_amd.unet import unet
+    net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1, feat_mult=2,
+               nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=seed,
+               fold_upsample=fold, dtype=dtype)
+    g = torch.Generator().manual_seed(11)
+    for nm, v in net.named_parameters():
+        if nm.endswith('/gamma'):
+            v.copy_(torch.rand(v.shape, generator=g) + .5)
+        elif nm.endswith('/beta') or nm.endswith('/bias'):
+            v.copy_(torch.randn(v.shape, generator=g) * .1)
+    net.repack()
+    return net
+
+
+def _step(net, x, t, kind='l1'):
+    import torch
+    loss = net.loss(x, t, kind=kind)[0]
+    net.backward()
+    g = net.grads.clone()
+    st = net.bn_batch.clone()
+    net.adam_step(lr=1e-3)
+    torch.cuda.synchronize()
+    return loss.clone(), g, st, net.params.clone()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('feats,levels,shape,cin,fold', [(24, 3, (48, 40, 64), 2, 'auto'), (24, 5, (32, 32, 32), 2, 'auto'),
+                                                         (24, 4, (64, 64, 64), 1, False)])
+def test_unet_step_is_bitwise_reproducible(det, dtype, feats, levels, shape, cin, fold):
+    import torch
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(*shape, cin, generator=g).cuda()
+    t = torch.rand(int(np.prod(shape)), generator=g).cuda()
+    runs = []
+    for rep in range(3):
+        net = _net(dtype, feats, levels, shape, cin, fold=fold)
+        out = [_step(net, x, t) for _ in range(2)]      # two consecutive steps: the second starts from updated weights
+        runs.append(out)
+    for rep in (1, 2):
+        for s in range(2):
+            for a, b, what in zip(runs[0][s], runs[rep][s], ('loss', 'grads', 'bn statistics', 'params')):
+                assert torch.equal(a, b), '%s differ between run 0 and run %d (step %d): max |d| %.3e' % (
+                    what, rep, s, (a.double() - b.double()).abs().max().item())
+
+
+def test_deterministic_results_match_the_default_path(det):
+    """the ordered flushes change the ORDER of the additions only: same numbers up to float32 rounding"""
+    import torch
+    shape, cin = (32, 32, 48), 2
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(*shape, cin, generator=g).cuda()
+    t = torch.rand(int(np.prod(shape)), generator=g).cuda()
+    l1, g1, s1, p1 = _step(_net('f32', 24, 3, shape, cin), x, t)
+    det.set_deterministic(False)
+    l0, g0, s0, p0 = _step(_net('f32', 24, 3, shape, cin), x, t)
+    det.set_deterministic(True)
+    assert abs(l1.item() - l0.item()) < 1e-6 * max(1.0, abs(l0.item()))
+    assert (g1 - g0).abs().max().item() < 2e-4 * g0.abs().max().item()
+    assert (s1 - s0).abs().max().item() < 1e-5 * s0.abs().max().item()
+
+
+@pytest.mark.parametrize('kind', ['l2', 'ssim'])
+def test_other_losses_reproducible(det, kind):
+    import torch
+    shape, cin = (32, 32, 32), 1
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(*shape, cin, generator=g).cuda()
+    t = torch.rand(int(np.prod(shape)), generator=g).cuda()
+    a = _step(_net('f32', 24, 3, shape, cin), x, t, kind)
+    b = _step(_net('f32', 24, 3, shape, cin), x, t, kind)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_critic_update_is_bitwise_reproducible(det, dtype):
+    import torch
+    from synthsr_amd.critic import Critic3D
+    shape = (32, 32, 32)
+    g = torch.Generator().manual_seed(8)
+    real = torch.rand(*shape, 1, generator=g).cuda()
+    fake = torch.rand(*shape, 1, generator=g).cuda()
+    u = 0.37
+    outs = []
+    for rep in range(2):
+        c = Critic3D(list(shape) + [1], n_levels=3, seed=2, dtype=dtype)
+        loss = c.critic_loss_and_grads(real, fake, u)[0]
+        gr = c.grads.clone()
+        c.adam_step(lr=1e-4)
+        torch.cuda.synchronize()
+        outs.append((torch.as_tensor(float(loss)), gr, c.params.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_trainer_step_reproducible_end_to_end(det):
+    """generator (already bitwise reproducible) -> U-Net -> Adam, twice from identical states: identical weights"""
+    import torch
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.training import Trainer
+    from synthsr_amd.unet import unet
+    from synthsr_amd.synthetic import (synthetic_label_pool, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
+                                       PRIOR_STDS_T1_HR)
+    pool = synthetic_label_pool(2, (32, 32, 32), 5)
+    res = []
+    for rep in range(2):
+        np.random.seed(0)
+        bg = BrainGenerator(None, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', GENERATION_LABELS,
+                            generation_classes=GENERATION_CLASSES, output_shape=32, output_div_by_n=8, nonlin_std=4.,
+                            nonlin_shape_factor=.125, bias_shape_factor=.125, build_reliability_maps=True, downsample=True,
+                            shearing_bounds=.02, label_maps=pool, rng=np.random.default_rng(0))
+        bg.labels_to_image_model.seed(0, 0)
+        net = unet(24, bg.model_output_shape, 3, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
+                   batch_norm=-1, seed=1)
+        tr = Trainer(bg, net, lr=1e-3)
+        tr.make_labels_resident(pool)
+        losses = [tr.step(label_index=i % 2).item() for i in range(4)]
+        torch.cuda.synchronize()
+        res.append((losses, net.params.clone(), net.bn_moving.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

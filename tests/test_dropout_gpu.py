@@ -66,7 +66,7 @@ def test_dropout_network_vs_oracle(feats, levels, shape, cin, nconv, rate, fold)
     for grp in net.enc + net.dec:
         for k in range(1, len(grp['convs'])):
             dead = np.flatnonzero(sc[grp['convs'][k - 1]['name']] == 0)
-            assert net.view(grp['convs'][k]['w'], net.grads)[:, :, :, dead, :].abs().max().item() == 0.0
+            assert dead.size == 0 or net.view(grp['convs'][k]['w'], net.grads)[:, :, :, dead, :].abs().max().item() == 0.0
     # the moving averages take the statistics of the dropped-out tensor (what the reference's BatchNormalization sees)
     mv0 = net.bn_moving.clone()
     net.update_moving_stats()
@@ -103,9 +103,10 @@ def test_dropout_draws_keep_rate_and_determinism():
     t = torch.rand(16 ** 3).cuda()
     kept, total = 0, 0
     for _ in range(6):
-        la = a.loss_l1(x, t)
-        lb = b.loss_l1(x, t)
-        assert la.item() == lb.item()            # same seed -> same masks
+        la = a.loss_l1(x, t)[0]
+        lb = b.loss_l1(x, t)[0]
+        assert abs(la.item() - lb.item()) < 1e-5 * max(1.0, abs(la.item()))   # same seed -> same masks
+        assert all(torch.equal(a._drop[k], b._drop[k]) for k in a._drop)
         for nm, s in a._drop.items():
             vals = set(np.round(s.cpu().numpy(), 5).tolist())
             assert vals <= {0.0, round(1 / .75, 5)}
@@ -131,7 +132,7 @@ def test_dropout_bf16_step_runs_and_matches_fp32_masks():
     t = torch.rand(16 * 16 * 32).cuda()
     f.set_dropout_scales(sc)
     h.set_dropout_scales(sc)
-    lf, lh = f.loss_l1(x, t), h.loss_l1(x, t)
+    lf, lh = f.loss_l1(x, t)[0], h.loss_l1(x, t)[0]
     assert abs(lf.item() - lh.item()) < 3e-2 * max(1.0, abs(lf.item()))
     f.backward()
     h.backward()
