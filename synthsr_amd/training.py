@@ -188,11 +188,17 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
              bias_shape_factor=0.03125, n_levels=5, nb_conv_per_level=2, conv_size=3, unet_feat_count=24,
              feat_multiplier=2, dropout=0, activation='elu', lr=1e-4, lr_decay=0, epochs=100, steps_per_epoch=1000,
              regression_metric='l1', work_with_residual_channel=None, loss_cropping=None, checkpoint=None,
-             model_file_has_different_lhood_layer=False, seed=0, verbose=True, dtype='f32'):
+             model_file_has_different_lhood_layer=False, seed=0, verbose=True, dtype='f32', deterministic=False):
     """Parameters as documented in SynthSR/training.py:90-240 (+ `seed`, `verbose`, `dtype`: 'f32' like the reference, or
     'bf16' = bf16 activations / packed weights with fp32 accumulation, BatchNorm statistics and master weights,
-    BASELINE.json configs[3])."""
+    BASELINE.json configs[3]; `deterministic`: bit-identical weights run after run for the same seed, ops.set_deterministic,
+    3-4x slower at 160^3 -- not with the segmentation-regularised loss)."""
     import torch
+    if deterministic:
+        if segmentation_model_file is not None:
+            raise NotImplementedError('deterministic mode does not cover the Dice sums of the segmentation-regularised loss')
+        from . import ops as _ops
+        _ops.set_deterministic(True)
     # the launcher script hands `--input_channels` over as text (scripts/training.py:36 of the reference): 'True' / 'False'
     input_channels = [{'True': True, 'False': False}.get(c, c) if isinstance(c, str) else c
                       for c in hm.reformat_to_list(input_channels)]
