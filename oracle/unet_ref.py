@@ -15,18 +15,19 @@ import torch.nn.functional as F
 BN_EPS = 1e-3
 
 
-def to_ncdhw(x):  # [d0,d1,d2,C] -> [1,C,d0,d1,d2]
-    return x.permute(3, 0, 1, 2).unsqueeze(0)
+def to_ncdhw(x):  # [d0,d1,d2,C] -> [1,C,d0,d1,d2];  a batch [B,d0,d1,d2,C] -> [B,C,d0,d1,d2]
+    return x.permute(0, 4, 1, 2, 3) if x.dim() == 5 else x.permute(3, 0, 1, 2).unsqueeze(0)
 
 
-def from_ncdhw(x):
-    return x[0].permute(1, 2, 3, 0).contiguous()
+def from_ncdhw(x, batched=False):
+    return x.permute(0, 2, 3, 4, 1).contiguous() if batched else x[0].permute(1, 2, 3, 0).contiguous()
 
 
 def conv3d_same(x, w, b=None):
-    """x [d0,d1,d2,Cin]; w Keras layout [3,3,3,Cin,Cout] (cross-correlation, zero 'same' padding)"""
+    """x [d0,d1,d2,Cin] (or a batch [B,d0,d1,d2,Cin]); w Keras layout [3,3,3,Cin,Cout] (cross-correlation, zero 'same'
+    padding)"""
     wt = w.permute(4, 3, 0, 1, 2)
-    return from_ncdhw(F.conv3d(to_ncdhw(x), wt, b, padding=1))
+    return from_ncdhw(F.conv3d(to_ncdhw(x), wt, b, padding=1), x.dim() == 5)
 
 
 def batchnorm_train(x, gamma, beta, eps=BN_EPS):
@@ -40,11 +41,12 @@ def batchnorm_train(x, gamma, beta, eps=BN_EPS):
 
 
 def maxpool2(x):
-    return from_ncdhw(F.max_pool3d(to_ncdhw(x), 2))
+    return from_ncdhw(F.max_pool3d(to_ncdhw(x), 2), x.dim() == 5)
 
 
 def upsample2(x):
-    return x.repeat_interleave(2, 0).repeat_interleave(2, 1).repeat_interleave(2, 2)
+    o = x.dim() - 4  # 1 for a batch
+    return x.repeat_interleave(2, o).repeat_interleave(2, o + 1).repeat_interleave(2, o + 2)
 
 
 class _RoundBF16(torch.autograd.Function):

@@ -93,6 +93,34 @@ class Trainer:
         self.reducer = GradBucketReducer(net.grads, bucket_elems, force=force_allreduce) if distributed else None
         self.resident_labels = None
 
+    def _generate_batch(self, model_inputs, draws, B):
+        """batchsize > 1 (SynthSR/training.py:52): the B items of the batch are generated one after the other (each with
+        its own label map, GMM parameters and draws -- the reference's batch-wise GMM LUT bug F9 is not reproduced) and
+        stacked along the first spatial axis, the layout UNet3D.set_batch works on"""
+        import torch
+        gen = self.gen
+        if self.seg is not None:
+            raise NotImplementedError('the segmentation loss is built for batchsize 1')
+        if draws is not None and len(draws) != B:
+            raise ValueError('one set of draws per batch item')
+        labels, means, stds = model_inputs[:3]
+        imgs, tgts = [], []
+        for b in range(B):
+            real = np.asarray(model_inputs[3])[b, ..., 0] if getattr(gen, 'use_real_image', False) else None
+            image, target, _ = gen.generate(np.asarray(labels)[b, ..., 0], np.asarray(means)[b], np.asarray(stds)[b],
+                                            None if draws is None else draws[b], real_image=real)
+            if b == 0:
+                key = (B,) + tuple(image.shape) + tuple(target.shape)
+                if getattr(self, '_batch_key', None) != key:
+                    self._batch_key = key
+                    self._img_b = torch.empty((B * image.shape[0],) + tuple(image.shape[1:]), dtype=image.dtype,
+                                              device=image.device)
+                    self._tgt_b = torch.empty((B * target.shape[0],) + tuple(target.shape[1:]), dtype=target.dtype,
+                                              device=target.device)
+            self._img_b.chunk(B, 0)[b].copy_(image)   # generate() re-uses its output buffers
+            self._tgt_b.chunk(B, 0)[b].copy_(target)
+        return self._img_b, self._tgt_b, None
+
     def make_labels_resident(self, label_maps):
         """upload a pool of int32 label maps once; steps then pick from the pool on the device"""
         import torch
@@ -105,15 +133,20 @@ class Trainer:
         if model_inputs is None:
             model_inputs = next(self.bg.model_inputs_generator)
         labels, means, stds = model_inputs[:3]
-        real = np.asarray(model_inputs[3])[0, ..., 0] if getattr(gen, 'use_real_image', False) else None
         from . import ops
-        with ops.timed('generator', gen.output_shape, gen.n_image_channels, gen.n_target_channels):
-            if label_index is not None and self.resident_labels is not None and real is None:
-                image, target, seg = gen.generate(self.resident_labels[label_index], np.asarray(means)[0],
-                                                  np.asarray(stds)[0], draws, labels_on_device=True)
-            else:
-                image, target, seg = gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0],
-                                                  np.asarray(stds)[0], draws, real_image=real)
+        B = int(np.asarray(means).shape[0])
+        if B > 1:
+            image, target, seg = self._generate_batch(model_inputs, draws, B)
+        else:
+            real = np.asarray(model_inputs[3])[0, ..., 0] if getattr(gen, 'use_real_image', False) else None
+            with ops.timed('generator', gen.output_shape, gen.n_image_channels, gen.n_target_channels):
+                if label_index is not None and self.resident_labels is not None and real is None:
+                    image, target, seg = gen.generate(self.resident_labels[label_index], np.asarray(means)[0],
+                                                      np.asarray(stds)[0], draws, labels_on_device=True)
+                else:
+                    image, target, seg = gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0],
+                                                      np.asarray(stds)[0], draws, real_image=real)
+        net.set_batch(B)
         residual, rs, ro = None, 1, 0
         if self.residual is not None:
             residual, rs, ro = image, image.shape[-1], [int(c) for c in self.residual]
@@ -233,8 +266,6 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
                                  % len(work_with_residual_channel))
     if regression_metric not in ('l1', 'l2', 'laplace', 'ssim'):
         raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(regression_metric))
-    if batchsize != 1:
-        raise NotImplementedError('batchsize 1 per GPU (use more GPUs for a larger effective batch)')
 
     dist_on = 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1
     rank, world = 0, 1

@@ -151,6 +151,7 @@ class UNet3D:
             o += 2 * C
         self.bn_momentum = 0.99
         self.training = True
+        self.batch = 1
         self._bufs = {}
         self.init_weights(seed)
 
@@ -313,6 +314,35 @@ class UNet3D:
         src = self.bn_batch if self.training else self.bn_moving
         return src[o:o + 2 * C]
 
+    # ------------------------------------------------------------------ batches of volumes (SynthSR/training.py: batchsize)
+    def set_batch(self, batch):
+        """B volumes per step: every activation tensor holds the B volumes stacked along the first spatial axis
+        ([B*d0, d1, d2, C]).  BatchNorm statistics / reductions, pooling, up-sampling + concatenation, the head and the
+        loss are per-voxel or per-channel-sum operations and run on the stack as one volume (d0 is even on every level that
+        is pooled, so no 2x2x2 window straddles two volumes); the 3x3x3 convolutions (zero padding at every volume's own
+        border) run volume by volume on slices of the stack, their weight gradients accumulate."""
+        batch = int(batch)
+        if batch < 1:
+            raise ValueError('batch should be >= 1')
+        if batch != self.batch:
+            self.batch = batch
+            lvl_of = [l for l in range(self.nb_levels)] + [d['level'] for d in self.dec]
+            for b, l in zip(self.bn_layers, lvl_of):
+                n = float(batch * np.prod(self.shapes[l]))
+                o, C = b['soff'], b['C']
+                self.bn_corr[o + C:o + 2 * C] = n / (n - (1.0 + ops.BN_EPS))
+
+    def _bshape(self, l):
+        s = self.shapes[l]
+        return [self.batch * s[0], s[1], s[2]]
+
+    def _pb(self, fn, *stacked):
+        """fn(*tensors) on each volume of the stack (tensors: stacked along axis 0, sliced without copies)"""
+        if self.batch == 1:
+            return fn(*stacked)
+        for parts in zip(*[t.chunk(self.batch, 0) for t in stacked]):
+            fn(*parts)
+
     # ------------------------------------------------------------------ feature-wise dropout
     def set_dropout_scales(self, scales):
         """explicit per-channel factors {conv layer name: [Cout] of 0 | 1/(1-rate)} for the NEXT training forward (parity
@@ -377,19 +407,22 @@ class UNet3D:
             acts = []
             nconv = len(e['convs'])
             for k, c in enumerate(e['convs']):
-                out = self.buf('enc%d_%d' % (l, k), self.shapes[l] + [c['cout']])
-                if self.training and k == nconv - 1:  # the level's BatchNorm statistics ride in the conv epilogue
+                out = self.buf('enc%d_%d' % (l, k), self._bshape(l) + [c['cout']])
+                if self.training and k == nconv - 1 and self.batch == 1:  # the BatchNorm statistics ride in the conv epilogue
                     cur = ops.conv3d_stats(cur, c['wp'], self.view(c['b']), c['cout'], self._stats(e['bn']), self.bn_ws,
                                            1, out=out)
                 else:
-                    cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1, out=out)
+                    self._pb(lambda x_, o_, c=c: ops.conv3d(x_, c['wp'], self.view(c['b']), c['cout'], 1, out=o_), cur, out)
+                    cur = out
+                    if self.training and k == nconv - 1:
+                        ops.bn_stats(cur, self._stats(e['bn']), self.bn_ws)
                 acts.append(cur)
             self.saved['enc'].append(acts)
             if dropping:
                 self._dropout_bn(e['bn'], self._drop[e['convs'][-1]['name']])
             if l < L - 1:
                 cur = ops.bn_maxpool(cur, self._stats(e['bn']), self.view(e['bn']['gamma']), self.view(e['bn']['beta']),
-                                     out=self.buf('pool%d' % l, self.shapes[l + 1] + [e['bn']['C']]))
+                                     out=self.buf('pool%d' % l, self._bshape(l + 1) + [e['bn']['C']]))
         low, low_bn = cur, self.enc[L - 1]['bn']
         for k, d in enumerate(self.dec):
             l = d['level']
@@ -402,14 +435,17 @@ class UNet3D:
                 self.saved['cat'].append((skip, lo_bn))
                 # the parity convs write the raw up-sampled part (strided stores), the skip-channel conv then adds it
                 # in place with coalesced reads and applies bias + ELU
-                cur = ops.conv3d_up(lo_bn, c0['wp_u'], None, None, c0['cout'], 0,
-                                    out=self.buf('dec%d_0' % k, self.shapes[l] + [c0['cout']]))
-                cur = ops.conv3d_add(skip, c0['wp_s'], self.view(c0['b']), cur, c0['cout'], 1, out=cur)
+                cur = self.buf('dec%d_0' % k, self._bshape(l) + [c0['cout']])
+
+                def folded(lo_, skip_, o_, c0=c0):
+                    ops.conv3d_up(lo_, c0['wp_u'], None, None, c0['cout'], 0, out=o_)
+                    ops.conv3d_add(skip_, c0['wp_s'], self.view(c0['b']), o_, c0['cout'], 1, out=o_)
+                self._pb(folded, lo_bn, skip, cur)
                 acts.append(cur)
             else:
                 cat = ops.upsample_concat(skip, low, self._stats(low_bn), self.view(low_bn['gamma']),
                                           self.view(low_bn['beta']),
-                                          out=self.buf('cat%d' % k, self.shapes[l] + [skip.shape[3] + low.shape[3]]))
+                                          out=self.buf('cat%d' % k, self._bshape(l) + [skip.shape[3] + low.shape[3]]))
                 self.saved['cat'].append(cat)
                 cur = cat
             nconv = len(d['convs'])
@@ -417,13 +453,14 @@ class UNet3D:
             for j, c in enumerate(d['convs']):
                 if d['fold'] and j == 0:
                     continue
-                out = self.buf('dec%d_%d' % (k, j), self.shapes[l] + [c['cout']])
-                if self.training and j == nconv - 1:
+                out = self.buf('dec%d_%d' % (k, j), self._bshape(l) + [c['cout']])
+                if self.training and j == nconv - 1 and self.batch == 1:
                     cur = ops.conv3d_stats(cur, c['wp'], self.view(c['b']), c['cout'], self._stats(d['bn']), self.bn_ws,
                                            1, out=out)
                     stats_done = True
                 else:
-                    cur = ops.conv3d(cur, c['wp'], self.view(c['b']), c['cout'], 1, out=out)
+                    self._pb(lambda x_, o_, c=c: ops.conv3d(x_, c['wp'], self.view(c['b']), c['cout'], 1, out=o_), cur, out)
+                    cur = out
                 acts.append(cur)
             self.saved['dec'].append(acts)
             if self.training and not stats_done:  # single-conv level whose only conv was the folded one
@@ -440,8 +477,10 @@ class UNet3D:
         loss_cropping = sizes of the centred box the loss is averaged over (metrics_model.py:70-90); residual
         [nvox, res_stride]: channel(s) res_off added to the intensities.  Returns (loss tensor[1], pred [nvox*K] | None)"""
         K = self.nb_labels
-        nvox_in = int(np.prod(self.input_shape[:3]))
+        nvox_in = self.batch * int(np.prod(self.input_shape[:3]))
         n = K // 2 if kind == 'laplace' else K
+        if self.batch > 1 and (kind == 'ssim' or loss_cropping is not None):
+            raise NotImplementedError('batches of several volumes: l1 / l2 / laplace without loss_cropping')
         if kind == 'ssim' and (K != 1 or target.numel() != nvox_in):
             raise Exception('SSIM metric does not currently support multiple channels')  # metrics_model.py:108-109
         if self.final_pred_activation != 'linear' or (kind == 'laplace' and K % 2) or target.numel() != nvox_in * n:
@@ -498,7 +537,7 @@ class UNet3D:
                               self.view(self.head['w']), self.view(self.head['b']), zero_t, loss, kind='l1', pred=pred)
         finally:
             self.training = was
-        return pred.view(*self.input_shape[:3], K)
+        return pred.view(self.batch * self.input_shape[0], self.input_shape[1], self.input_shape[2], K)
 
     # ------------------------------------------------------------------ frozen use (segmentation network)
     def enable_input_grad(self):
@@ -610,17 +649,24 @@ class UNet3D:
                     dwc = self.buf('dwc', [8, 27, Cl, c0['cout']])
 
                     def c0_wgrads(skip=skip, dz=dz, dW=dW, lo_bn=lo_bn, dwc=dwc, c0=c0, Cs=Cs):
-                        ops.conv3d_wgrad_part(skip, dz, dW, 0, dbias=self.view(c0['b'], self.grads))
-                        ops.conv3d_up_wgrad(lo_bn, dz, dwc, dW, Cs)
+                        def one(skip_, dz_, lo_):
+                            ops.conv3d_wgrad_part(skip_, dz_, dW, 0, dbias=self.view(c0['b'], self.grads))
+                            ops.conv3d_up_wgrad(lo_, dz_, dwc, dW, Cs)
+                        self._pb(one, skip, dz, lo_bn)
                     self._fork(c0_wgrads, skip[..., 0].numel())
-                dskips[l] = ops.conv3d(dz, c0['wpd_s'], None, Cs, 0, out=self.buf('dskip%d' % l, self.shapes[l] + [Cs]))
-                g = ops.conv3d_up_dgrad(dz, c0['wpd_u'], Cl, out=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
+                dskips[l] = self.buf('dskip%d' % l, self._bshape(l) + [Cs])
+                g = self.buf('dlo%d' % k, self._bshape(l + 1) + [Cl])
+
+                def c0_dgrads(dz_, ds_, dl_, c0=c0, Cs=Cs, Cl=Cl):
+                    ops.conv3d(dz_, c0['wpd_s'], None, Cs, 0, out=ds_)
+                    ops.conv3d_up_dgrad(dz_, c0['wpd_u'], Cl, out=dl_)
+                self._pb(c0_dgrads, dz, dskips[l], g)
             else:
                 g = self._convs_backward(g, None, d['convs'], acts, self.saved['cat'][k], need_dx=True, tag='d%d' % k)
                 # g = d(concat)
                 Cl = g.shape[3] - Cs
-                dskips[l], g = ops.upsample_concat_bwd(g, Cs, Cl, dskip=self.buf('dskip%d' % l, self.shapes[l] + [Cs]),
-                                                       dlo=self.buf('dlo%d' % k, self.shapes[l + 1] + [Cl]))
+                dskips[l], g = ops.upsample_concat_bwd(g, Cs, Cl, dskip=self.buf('dskip%d' % l, self._bshape(l) + [Cs]),
+                                                       dlo=self.buf('dlo%d' % k, self._bshape(l + 1) + [Cl]))
             if on_grad_ready is not None:
                 self._join()
                 on_grad_ready(self.offsets[d['convs'][0]['w']][0])
@@ -706,12 +752,14 @@ class UNet3D:
             if fused:
                 dz = g
                 if not frozen:
-                    self._fork(lambda: ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads),
-                                                        dbias=self.view(c['b'], self.grads)), xin[..., 0].numel())
+                    self._fork(lambda: self._pb(lambda x_, dz_: ops.conv3d_wgrad(
+                        x_, dz_, self.view(c['w'], self.grads), dbias=self.view(c['b'], self.grads)), xin, dz),
+                        xin[..., 0].numel())
             else:
                 dz = self._elu_backward(g, y, g2, None if frozen else self.view(c['b'], self.grads))
                 if not frozen:
-                    self._fork(lambda: ops.conv3d_wgrad(xin, dz, self.view(c['w'], self.grads)), xin[..., 0].numel())
+                    self._fork(lambda: self._pb(lambda x_, dz_: ops.conv3d_wgrad(x_, dz_, self.view(c['w'], self.grads)),
+                                                xin, dz), xin[..., 0].numel())
             g2 = None
             fused = False
             if j > 0 or need_dx:
@@ -720,10 +768,11 @@ class UNet3D:
                 # the activation instead of three; its dbias comes out of the weight-gradient GEMM
                 below = acts[j - 1] if j > 0 else elu_below
                 if below is not None:
-                    g = ops.conv3d_add(dz, c['wpd'], None, below, c['cin'], 2, out=out)
+                    self._pb(lambda dz_, b_, o_: ops.conv3d_add(dz_, c['wpd'], None, b_, c['cin'], 2, out=o_), dz, below, out)
                     fused = True
                 else:
-                    g = ops.conv3d(dz, c['wpd'], None, c['cin'], 0, out=out)
+                    self._pb(lambda dz_, o_: ops.conv3d(dz_, c['wpd'], None, c['cin'], 0, out=o_), dz, out)
+                g = out
             else:
                 g = None
         return g

@@ -1,0 +1,117 @@
+"""batchsize > 1 per GPU (SynthSR/training.py:52, 344): B volumes stacked along the first spatial axis; BatchNorm statistics
+and every reduction run over the whole stack, the convolutions volume by volume (synthsr_amd/unet.py: set_batch).  Checked
+against the oracle run on a real batch dimension ([B, d0, d1, d2, C] through torch's conv3d / autograd)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('fold', [False, True])
+@pytest.mark.parametrize('B,feats,levels,shape,cin', [(2, 24, 3, (16, 16, 32), 2), (3, 8, 2, (8, 12, 16), 1), (2, 24, 4, (32, 16, 16), 2)])
+def test_batched_unet_vs_oracle(B, feats, levels, shape, cin, fold):
+    import torch
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1, feat_mult=2,
+               nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3, fold_upsample=fold)
+    g = torch.Generator().manual_seed(11)
+    for nm, v in net.named_parameters():
+        if nm.endswith('/gamma'):
+            v.copy_(torch.rand(v.shape, generator=g) + .5)
+        elif nm.endswith('/beta') or nm.endswith('/bias'):
+            v.copy_(torch.randn(v.shape, generator=g) * .1)
+    net.repack()
+    net.set_batch(B)
+    x = torch.rand(B, *shape, cin, generator=g)
+    x[1] *= 1.7                                           # the volumes of a batch differ in scale: per-volume stats would show
+    target = torch.rand(B, *shape, 1, generator=g)
+    xs = x.reshape(B * shape[0], shape[1], shape[2], cin).cuda()
+    loss, pred = net.loss_l1(xs, target.reshape(-1).cuda(), want_pred=True)
+    pred = pred.clone()
+    net.backward()
+    P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+    stats = {}
+    pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats)
+    assert list(pr.shape) == [B] + list(shape) + [1]
+    lr = U.l1_loss(pr, target)
+    lr.backward()
+    err = (pred.view(B, *shape, 1).cpu() - pr).abs().max().item() / pr.abs().max().item()
+    assert err < 5e-4, err
+    assert abs(loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
+    for nm, _, kind in net.specs:
+        got = net.view(nm, net.grads).cpu().double()
+        ref = P[nm].grad.double()
+        e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert e < (2e-3 if kind in ('kernel', 'head_w') else 5e-3), (nm, e)
+    for bn in net.bn_layers:
+        o, C = bn['soff'], bn['C']
+        m, v = stats[bn['name']]
+        assert (net.bn_batch[o:o + C].cpu() - m).abs().max().item() < 1e-4 * max(1.0, m.abs().max().item())
+        assert (net.bn_batch[o + C:o + 2 * C].cpu() - v).abs().max().item() < 1e-4 * max(1.0, v.abs().max().item())
+    # Keras' sample-variance correction uses the number of values behind the statistics: B * voxels
+    l0 = float(B * np.prod(shape))
+    o, C = net.bn_layers[0]['soff'], net.bn_layers[0]['C']
+    assert abs(net.bn_corr[o + C].item() - l0 / (l0 - (1 + 1e-3))) < 1e-6
+    # back to single volumes: same network object, same weights
+    net.adam_step(lr=1e-3)
+    net.update_moving_stats()
+    net.set_batch(1)
+    net.training = False
+    assert torch.isfinite(net.predict(xs[:shape[0]].contiguous())).all()
+
+
+def test_batched_bf16_agrees_with_fp32():
+    import torch
+    from synthsr_amd.unet import unet
+    kw = dict(nb_features=24, input_shape=[16, 16, 32, 2], nb_levels=3, conv_size=3, nb_labels=1, feat_mult=2,
+              nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=4)
+    f, h = unet(**kw), unet(dtype='bf16', **kw)
+    f.set_batch(2)
+    h.set_batch(2)
+    x = torch.rand(32, 16, 32, 2).cuda()
+    t = torch.rand(32 * 16 * 32).cuda()
+    lf, lh = f.loss_l1(x, t)[0], h.loss_l1(x, t)[0]
+    assert abs(lf.item() - lh.item()) < 3e-2 * max(1.0, abs(lf.item()))
+    f.backward()
+    h.backward()
+    gf, gh = f.grads.double(), h.grads.double()
+    assert ((gf * gh).sum() / (gf.norm() * gh.norm())).item() > 0.97
+
+
+def test_trainer_and_training_entry_point_with_batchsize_2(tmp_path):
+    import os
+    import torch
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.nifti import write_nifti
+    from synthsr_amd.training import Trainer, training
+    from synthsr_amd.unet import unet
+    from synthsr_amd.synthetic import (synthetic_label_pool, synthetic_label_map, GENERATION_LABELS, GENERATION_CLASSES,
+                                       PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR)
+    pool = synthetic_label_pool(3, (32, 32, 32), 5)
+    bg = BrainGenerator(None, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', GENERATION_LABELS,
+                        generation_classes=GENERATION_CLASSES, output_shape=32, output_div_by_n=8, nonlin_std=4.,
+                        nonlin_shape_factor=.125, bias_shape_factor=.125, build_reliability_maps=True, downsample=True,
+                        shearing_bounds=.02, label_maps=pool, batchsize=2, rng=np.random.default_rng(0))
+    net = unet(24, bg.model_output_shape, 3, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
+               batch_norm=-1, seed=1)
+    tr = Trainer(bg, net, lr=1e-3)
+    inputs = next(bg.model_inputs_generator)
+    assert np.asarray(inputs[0]).shape[0] == 2
+    draws = [bg.labels_to_image_model.sample_draws() for _ in range(2)]
+    losses = [tr.step(inputs, draws).item() for _ in range(8)]
+    assert net.batch == 2 and all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert list(tr._img_b.shape) == [64, 32, 32, 2]
+    assert not torch.equal(tr._img_b[:32], tr._img_b[32:])          # two different volumes
+    # entry point
+    d = tmp_path / 'labels'
+    d.mkdir()
+    for i in range(2):
+        write_nifti(str(d / ('brain%d_labels.nii.gz' % i)), synthetic_label_map((40, 36, 48), 10 + i).astype(np.float32))
+    for nm, v in (('gl', GENERATION_LABELS), ('gc', GENERATION_CLASSES), ('pm', PRIOR_MEANS_T1_HR), ('ps', PRIOR_STDS_T1_HR)):
+        np.save(tmp_path / (nm + '.npy'), v)
+    model_dir = str(tmp_path / 'models')
+    net2 = training(str(d), model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'), str(tmp_path / 'gl.npy'),
+                    path_generation_classes=str(tmp_path / 'gc.npy'), output_shape=32, n_levels=3, unet_feat_count=24,
+                    nonlin_shape_factor=.125, bias_shape_factor=.125, steps_per_epoch=3, epochs=1, batchsize=2, verbose=False)
+    assert net2.batch == 2 and net2.iterations == 3 and os.path.exists(os.path.join(model_dir, '001.npz'))

@@ -60,3 +60,19 @@ def test_oracle_dropout_matches_keras_definition():
     c = U.unet_forward(x, P, net.prefix, 2, 2, training=True, dropout=drop)
     d = U.unet_forward(x * 2, P, net.prefix, 2, 2, training=True, dropout=drop)
     assert not torch.allclose(c, d) and not torch.allclose(a, c)
+
+
+def test_oracle_batch_dimension():
+    """the oracle on a batch [B, d0, d1, d2, C]: BatchNorm statistics run over batch and voxels (Keras axis=-1), the rest is
+    per volume -- a batch of two copies equals the single volume, and a batch of two DIFFERENT volumes does not"""
+    from synthsr_amd.unet import UNet3D
+    g = torch.Generator().manual_seed(3)
+    net = UNet3D(4, [8, 8, 8, 1], 2, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, table_only=True)
+    P = {nm: torch.randn(shp, generator=g) * .2 for nm, shp, _ in net.specs}
+    x = torch.randn(8, 8, 8, 1, generator=g)
+    one = U.unet_forward(x, P, net.prefix, 2, 2, training=True)
+    two = U.unet_forward(torch.stack([x, x]), P, net.prefix, 2, 2, training=True)
+    assert list(two.shape) == [2, 8, 8, 8, 1]
+    assert torch.allclose(two[0], one, atol=1e-5) and torch.allclose(two[1], one, atol=1e-5)
+    mixed = U.unet_forward(torch.stack([x, 3 * x + 1]), P, net.prefix, 2, 2, training=True)
+    assert not torch.allclose(mixed[0], one, atol=1e-3)
