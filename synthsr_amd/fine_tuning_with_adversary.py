@@ -133,6 +133,9 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
     """Parameters as documented in SynthSR/fine_tuning_with_adversary.py:92-283 (+ `seed`, `verbose`, `dtype`: 'bf16' runs
     the conv stacks of the generator U-Net AND the critic in bf16 (fp32 accumulation / statistics / master weights / Dense layers /
     losses): the "mixed bf16" of BASELINE.json configs[4]).
+    Deviation: `work_with_residual_channel` is APPLIED here (prediction = network output + that input channel, as in
+    SynthSR/training.py:260-271); the reference's adversarial script validates the argument (fine_tuning_with_adversary.py:
+    256-264) and then never uses it.  Pass None for the reference's behaviour.
     Returns (generator U-Net, critic)."""
     import torch
     n_channels = len(hm.reformat_to_list(input_channels))
