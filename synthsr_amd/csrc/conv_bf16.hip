@@ -27,6 +27,16 @@
 
 SYN_DET_SETTER(conv_bf16)
 
+#ifdef SYN_BF16_TIMING
+static __device__ long long* g_tm = nullptr;
+extern "C" int synthsr_bf16_timing_buffer(long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tm), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#define TM(i) do { if (g_tm && (blockIdx.x == 0 || blockIdx.x == 300) && blockIdx.y == 0 && tid == 0 && tix < 40) g_tm[((blockIdx.x ? 1 : 0) * 40 + tix) * 8 + (i)] = clock64(); } while (0)
+#else
+#define TM(i)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -256,7 +266,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
   // split-K: slice blockIdx.z of the input-channel chunks (ksplit == 1: all of them)
   const int cc_lo = (int)(((int64_t)blockIdx.z * a.ncc) / a.ksplit), cc_hi = (int)(((int64_t)(blockIdx.z + 1) * a.ncc) / a.ksplit);
   if (walk.pos < walk.end) load_halo(walk.pos, cc_lo);
+  int tix = -1;
+  (void)tix;
   for (int t = walk.pos; t < walk.end; t += walk.stride) {
+    ++tix;
+    TM(0);
     f32x4 acc[TY][MT];
 #pragma unroll
     for (int y = 0; y < TY; ++y)
@@ -264,15 +278,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
       for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int cc = cc_lo; cc < cc_hi; ++cc) {
       __syncthreads();  // everyone is done reading the previous image
+      TM(1);
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
         if (i < NLD - 1 || tid + 256 * i < NPIECE) *reinterpret_cast<u32x4*>(lds + plds[i]) = stg[i];
+      TM(2);
       __syncthreads();
+      TM(3);
       if (cc + 1 < cc_hi) {
         load_halo(t, cc + 1);
       } else if (t + walk.stride < walk.end) {
         load_halo(t + walk.stride, cc_lo);
       }
+      TM(4);
       const bf16x8* wf = wfrag + (int64_t)cc * NSTEP * MT * 64;
       // software pipeline, pinned with sched_barriers (left alone, the scheduler re-uses ONE register set and waits for
       // every LDS read and every weight load right where it is issued): weights two K-steps ahead (global / L2 latency),
@@ -310,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
             acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s % 3][mt], xb[s & 1][y], acc[y][mt], 0, 0, 0);
       });
       __builtin_amdgcn_sched_barrier(0);
+      TM(5);
     }
     // ---- epilogue: lane (m = x, g): channels (chunk*MT + mt)*16 + 4g + i of voxel (z0 + wave, y0 + y, x0 + m)
     int z0, y0, x0;
@@ -361,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
         }
       }
     }
+    TM(6);
   }
   if (a.stats_partial) {
     // reduce over the 16 voxel lanes of each g, then over the 4 waves through LDS
