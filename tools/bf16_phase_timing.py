@@ -8,12 +8,13 @@ import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from synthsr_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scratch', 'libsynthsr_hip_timing.so')
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scratch', os.environ.get('SYN_TIMING_LIB', 'libsynthsr_hip_timing.so'))
 from synthsr_amd import ops
 import numpy as np
 lib = _lib.load()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 raw.synthsr_bf16_timing_buffer.argtypes = [ctypes.c_void_p]
+ACT = int(os.environ.get('SYN_TIMING_ACT', '1'))
 for D, ci, co, stats in ((160, 24, 24, False), (160, 8, 24, False), (160, 72, 24, False), (80, 48, 48, False)):
     x = torch.randn(D, D, D, ci, device='cuda').bfloat16()
     w = torch.randn(3, 3, 3, ci, co, device='cuda') * .05
@@ -21,11 +22,11 @@ for D, ci, co, stats in ((160, 24, 24, False), (160, 8, 24, False), (160, 72, 24
     wp = ops.pack_conv_weights_bf16(w, 0)
     out = torch.empty(D, D, D, co, device='cuda', dtype=torch.bfloat16)
     for _ in range(3):
-        ops.conv3d_bf16(x, wp, b, co, 1, out=out)
+        ops.conv3d_bf16(x, wp, b, co, ACT, out=out)
     tm = torch.zeros(2 * 40 * 8, dtype=torch.int64, device='cuda')
     torch.cuda.synchronize()
     raw.synthsr_bf16_timing_buffer(ctypes.c_void_p(tm.data_ptr()))
-    ops.conv3d_bf16(x, wp, b, co, 1, out=out)
+    ops.conv3d_bf16(x, wp, b, co, ACT, out=out)
     torch.cuda.synchronize()
     raw.synthsr_bf16_timing_buffer(ctypes.c_void_p(0))
     t = tm.cpu().numpy().reshape(2, 40, 8)
