@@ -150,6 +150,18 @@ __host__ __device__ static inline float syn_ord2f(uint32_t u) {
   return c.f;
 }
 
+#ifdef __HIPCC__
+// running [min, max] pair (ordered-uint encoding) shared by the whole grid.  Thousands of atomics on the same two words
+// serialise at the memory-side atomic unit (8192 waves x 2: most of deform_gmm_kernel's 220 us); min / max only ever move
+// one way, so a plain (possibly stale) read filters out every wave that cannot improve them -- a stale value is only ever
+// LESS extreme than the current one, so nothing that matters is skipped and the result is exact.
+__device__ __forceinline__ void syn_minmax_update(uint32_t* mm, float mn, float mx) {
+  const uint32_t lo = syn_f2ord(mn), hi = syn_f2ord(mx);
+  if (lo < __hip_atomic_load(&mm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mm[0], lo);
+  if (hi > __hip_atomic_load(&mm[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[1], hi);
+}
+#endif
+
 // 64-lane wave reductions (CDNA wavefront = 64)
 __device__ static inline float syn_wave_sum(float v) {
 #pragma unroll

@@ -48,6 +48,44 @@ __device__ __forceinline__ float tri_accum(const Axis& a0, const Axis& a1, const
   return acc;
 }
 
+// the same for a 3-component field stored interleaved ([...][3]): ONE 12-byte load per corner instead of three 4-byte
+// gathers (the address unit handles a gather lane by lane: 8 instead of 24 gather instructions per voxel); per component
+// the arithmetic is tri_accum's, term by term
+struct F3 {
+  float x, y, z;
+};
+template <typename F>
+__device__ __forceinline__ void tri_accum3(const Axis& a0, const Axis& a1, const Axis& a2, F fetch, float& r0, float& r1,
+                                           float& r2) {
+  float c0, c1, c2;
+  {
+    const float w = (a0.w0 * a1.w0) * a2.w0;
+    const F3 f = fetch(a0.i0, a1.i0, a2.i0);
+    c0 = w * f.x;
+    c1 = w * f.y;
+    c2 = w * f.z;
+  }
+#define SYN_TRI3(W, I, J, K)          \
+  {                                   \
+    const float w = (W);              \
+    const F3 f = fetch((I), (J), (K)); \
+    c0 = c0 + w * f.x;                \
+    c1 = c1 + w * f.y;                \
+    c2 = c2 + w * f.z;                \
+  }
+  SYN_TRI3((a0.w0 * a1.w0) * a2.w1, a0.i0, a1.i0, a2.i1)
+  SYN_TRI3((a0.w0 * a1.w1) * a2.w0, a0.i0, a1.i1, a2.i0)
+  SYN_TRI3((a0.w0 * a1.w1) * a2.w1, a0.i0, a1.i1, a2.i1)
+  SYN_TRI3((a0.w1 * a1.w0) * a2.w0, a0.i1, a1.i0, a2.i0)
+  SYN_TRI3((a0.w1 * a1.w0) * a2.w1, a0.i1, a1.i0, a2.i1)
+  SYN_TRI3((a0.w1 * a1.w1) * a2.w0, a0.i1, a1.i1, a2.i0)
+  SYN_TRI3((a0.w1 * a1.w1) * a2.w1, a0.i1, a1.i1, a2.i1)
+#undef SYN_TRI3
+  r0 = c0;
+  r1 = c1;
+  r2 = c2;
+}
+
 // resize sample position: i + (i/zoom - i)  (utils.py:150 then :317)
 __device__ __forceinline__ float resize_pos(int i, float zoom) {
   const float g = (float)i;
@@ -58,14 +96,28 @@ struct Shape3 {
   int d[3];
 };
 
+// flat voxel index -> (i0, i1, i2).  Two 32-bit divisions (a 64-bit division by a run-time divisor is a ~100-instruction
+// sequence on gfx950 and every generator kernel did three per voxel); volumes of 2^31 voxels and more take the 64-bit path
+__device__ __forceinline__ void vox3(int64_t v, int d1, int d2, int& i0, int& i1, int& i2) {
+  if (v >> 31) {
+    i2 = (int)(v % d2);
+    i1 = (int)((v / d2) % d1);
+    i0 = (int)(v / ((int64_t)d2 * d1));
+    return;
+  }
+  const uint32_t u = (uint32_t)v, q = u / (uint32_t)d2, q1 = q / (uint32_t)d1;
+  i2 = (int)(u - q * (uint32_t)d2);
+  i1 = (int)(q - q1 * (uint32_t)d1);
+  i0 = (int)q1;
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void resize_kernel(const float* __restrict__ in, float* __restrict__ out, int C, Shape3 is, Shape3 os,
                               float z0, float z1, float z2, int method) {
   const int64_t n = (int64_t)os.d[0] * os.d[1] * os.d[2];
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
-    const int o2 = (int)(v % os.d[2]);
-    const int o1 = (int)((v / os.d[2]) % os.d[1]);
-    const int o0 = (int)(v / ((int64_t)os.d[2] * os.d[1]));
+    int o0, o1, o2;
+    vox3(v, os.d[1], os.d[2], o0, o1, o2);
     const float l0 = resize_pos(o0, z0), l1 = resize_pos(o1, z1), l2 = resize_pos(o2, z2);
     if (method == 1) {
       int r0 = (int)rintf(l0), r1 = (int)rintf(l1), r2 = (int)rintf(l2);
@@ -89,20 +141,17 @@ __global__ void resize_kernel(const float* __restrict__ in, float* __restrict__ 
 __global__ void svf_step_kernel(const float* __restrict__ in, float* __restrict__ out, Shape3 s, float scale) {
   const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
-    const int i2 = (int)(v % s.d[2]);
-    const int i1 = (int)((v / s.d[2]) % s.d[1]);
-    const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));
+    int i0, i1, i2;
+    vox3(v, s.d[1], s.d[2], i0, i1, i2);
     const float v0 = in[v * 3 + 0] * scale, v1 = in[v * 3 + 1] * scale, v2 = in[v * 3 + 2] * scale;
     const Axis a0 = axis_setup((float)i0 + v0, s.d[0]);
     const Axis a1 = axis_setup((float)i1 + v1, s.d[1]);
     const Axis a2 = axis_setup((float)i2 + v2, s.d[2]);
     float r[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      r[c] = tri_accum(a0, a1, a2, [&](int i, int j, int k) {
-        return in[(((int64_t)i * s.d[1] + j) * s.d[2] + k) * 3 + c] * scale;
-      });
-    }
+    tri_accum3(a0, a1, a2, [&](int i, int j, int k) {
+      const F3 f = *reinterpret_cast<const F3*>(in + (((int64_t)i * s.d[1] + j) * s.d[2] + k) * 3);
+      return F3{f.x * scale, f.y * scale, f.z * scale};
+    }, r[0], r[1], r[2]);
     out[v * 3 + 0] = v0 + r[0];
     out[v * 3 + 1] = v1 + r[1];
     out[v * 3 + 2] = v2 + r[2];
@@ -140,9 +189,8 @@ __global__ void affine_resample_kernel(const float* __restrict__ in, float* __re
                                        Aff A) {
   const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
-    const int i2 = (int)(v % s.d[2]);
-    const int i1 = (int)((v / s.d[2]) % s.d[1]);
-    const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));
+    int i0, i1, i2;
+    vox3(v, s.d[1], s.d[2], i0, i1, i2);
     float pos[3];
     affine_pos(A, s.d, i0, i1, i2, 0.f, 0.f, 0.f, false, true, pos);
     const Axis a0 = axis_setup(pos[0], s.d[0]), a1 = axis_setup(pos[1], s.d[1]), a2 = axis_setup(pos[2], s.d[2]);
@@ -174,10 +222,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 __device__ __forceinline__ void box_muller(uint32_t r0, uint32_t r1, float& n0, float& n1) {
   const float u1 = (float)((r0 >> 8) + 1u) * 5.9604644775390625e-08f;  // (0, 1]
   const float u2 = (float)(r1 >> 8) * 5.9604644775390625e-08f;         // [0, 1)
-  const float rad = sqrtf(-2.0f * logf(u1));
-  const float ang = 6.283185307179586f * u2;
-  n0 = rad * cosf(ang);
-  n1 = rad * sinf(ang);
+  // hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, i.e.
+  // u2 itself -- no 2 pi multiply, no range reduction (the precise libm sinf / cosf / logf were ~150 instructions per
+  // voxel).  This is the in-kernel sampling path (use_philox); parity runs feed the noise from a tape.
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln(u1) = -2 ln2 log2(u1)
+  n0 = rad * __builtin_amdgcn_cosf(u2);
+  n1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -212,9 +262,8 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
   int64_t o_lo, o_hi;
   syn_block_range(n, o_lo, o_hi);  // XCD-contiguous slabs: the label gather stays in one L2
   for (int64_t o = o_lo + threadIdx.x; o < o_hi; o += blockDim.x) {
-    const int o2 = (int)(o % p.out_shape[2]);
-    const int o1 = (int)((o / p.out_shape[2]) % p.out_shape[1]);
-    const int o0 = (int)(o / ((int64_t)p.out_shape[2] * p.out_shape[1]));
+    int o0, o1, o2;
+    vox3(o, p.out_shape[1], p.out_shape[2], o0, o1, o2);
     // undo flip (tf.reverse along axis 0), then crop offset -> voxel of the deformed full grid
     const int i0 = (p.flip ? (p.out_shape[0] - 1 - o0) : o0) + p.crop[0];
     const int i1 = o1 + p.crop[1];
@@ -225,9 +274,9 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
       const Axis a1 = axis_setup(resize_pos(i1, zf1), p.half_shape[1]);
       const Axis a2 = axis_setup(resize_pos(i2, zf2), p.half_shape[2]);
       const int h1 = p.half_shape[1], h2 = p.half_shape[2];
-      u0 = tri_accum(a0, a1, a2, [&](int i, int j, int k) { return field[(((int64_t)i * h1 + j) * h2 + k) * 3 + 0]; });
-      u1 = tri_accum(a0, a1, a2, [&](int i, int j, int k) { return field[(((int64_t)i * h1 + j) * h2 + k) * 3 + 1]; });
-      u2 = tri_accum(a0, a1, a2, [&](int i, int j, int k) { return field[(((int64_t)i * h1 + j) * h2 + k) * 3 + 2]; });
+      tri_accum3(a0, a1, a2, [&](int i, int j, int k) {
+        return *reinterpret_cast<const F3*>(field + ((i * h1 + j) * h2 + k) * 3);  // half-res field: < 2^31 elements
+      }, u0, u1, u2);
     }
     float pos[3];
     affine_pos(A, p.in_shape, i0, i1, i2, u0, u1, u2, p.has_field != 0, p.has_affine != 0, pos);
@@ -297,18 +346,12 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
   for (int c = 0; c < 4; ++c) {
     if (c < C) {
       const float mn = syn_wave_min(lmin[c]), mx = syn_wave_max(lmax[c]);
-      if ((threadIdx.x & 63) == 0) {
-        atomicMin(&minmax[2 * c + 0], syn_f2ord(mn));
-        atomicMax(&minmax[2 * c + 1], syn_f2ord(mx));
-      }
+      if ((threadIdx.x & 63) == 0) syn_minmax_update(&minmax[2 * c], mn, mx);
     }
   }
   if (real_in && real_minmax) {
     const float mn = syn_wave_min(rmin), mx = syn_wave_max(rmax);
-    if ((threadIdx.x & 63) == 0) {
-      atomicMin(&real_minmax[0], syn_f2ord(mn));
-      atomicMax(&real_minmax[1], syn_f2ord(mx));
-    }
+    if ((threadIdx.x & 63) == 0) syn_minmax_update(real_minmax, mn, mx);
   }
 }
 
@@ -324,9 +367,8 @@ __global__ __launch_bounds__(256) void mimic_acquisition_kernel(const float* __r
                                                                 MimicP p, int ostride, int ooff, int doff) {
   const int64_t n = (int64_t)p.R[0] * p.R[1] * p.R[2];
   for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x) {
-    const int o2 = (int)(o % p.R[2]);
-    const int o1 = (int)((o / p.R[2]) % p.R[1]);
-    const int o0 = (int)(o / ((int64_t)p.R[2] * p.R[1]));
+    int o0, o1, o2;
+    vox3(o, p.R[1], p.R[2], o0, o1, o2);
     const float u0 = (float)o0 / p.uz[0], u1 = (float)o1 / p.uz[1], u2 = (float)o2 / p.uz[2];
     const Axis a0 = axis_setup(u0, p.S[0]);
     const Axis a1 = axis_setup(u1, p.S[1]);
@@ -366,10 +408,7 @@ __global__ void minmax_reduce_kernel(const float* __restrict__ x, int64_t n, uin
   }
   mn = syn_wave_min(mn);
   mx = syn_wave_max(mx);
-  if ((threadIdx.x & 63) == 0) {
-    atomicMin(&mm[0], syn_f2ord(mn));
-    atomicMax(&mm[1], syn_f2ord(mx));
-  }
+  if ((threadIdx.x & 63) == 0) syn_minmax_update(mm, mn, mx);
 }
 
 __global__ void normalise_gamma_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
@@ -397,9 +436,8 @@ __global__ __launch_bounds__(256) void blur3d_kernel(const float* __restrict__ i
   int64_t v_lo, v_hi;
   syn_block_range(n, v_lo, v_hi);  // XCD-contiguous slabs: the 27-tap stencil re-reads hit this XCD's L2
   for (int64_t v = v_lo + threadIdx.x; v < v_hi; v += blockDim.x) {
-    const int i2 = (int)(v % s.d[2]);
-    const int i1 = (int)((v / s.d[2]) % s.d[1]);
-    const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));
+    int i0, i1, i2;
+    vox3(v, s.d[1], s.d[2], i0, i1, i2);
     float acc = 0.f;
     for (int a = 0; a < ks.d[0]; ++a) {
       const int z = i0 + a - p0;
@@ -421,9 +459,8 @@ __global__ __launch_bounds__(256) void blur3d_kernel(const float* __restrict__ i
 __global__ void outer3_kernel(const float* __restrict__ w, float* __restrict__ out, Shape3 s, int ostride, int ooff) {
   const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
-    const int i2 = (int)(v % s.d[2]);
-    const int i1 = (int)((v / s.d[2]) % s.d[1]);
-    const int i0 = (int)(v / ((int64_t)s.d[2] * s.d[1]));
+    int i0, i1, i2;
+    vox3(v, s.d[1], s.d[2], i0, i1, i2);
     // the reference multiplies the three 1-D maps in float64 and casts once (edit_tensors.py:326-328)
     const double r = ((double)w[i0] * (double)w[s.d[0] + i1]) * (double)w[s.d[0] + s.d[1] + i2];
     out[v * ostride + ooff] = (float)r;

@@ -10,6 +10,19 @@
 
 SYN_DET_SETTER(pointwise)
 
+#include <cstdlib>
+// workgroups of the channel-reduction kernels: every workgroup ends with one atomicAdd per channel sum on the SAME addresses,
+// and same-address atomics serialise at the memory-side unit (~14 ns each): with 2048 workgroups the tail cost 0.6 ms per fp32
+// step (29.36 -> 28.76 ms at 768 = 3 per CU; 512 and 1024 are within noise of it).  The grid-stride loops do the rest.
+static int red_grid() {
+  static const int g = getenv("SYN_RED_GRID") ? atoi(getenv("SYN_RED_GRID")) : 768;
+  return g;
+}
+static int head_grid() {
+  static const int g = getenv("SYN_HEAD_GRID") ? atoi(getenv("SYN_HEAD_GRID")) : 1024;
+  return g;
+}
+
 namespace {
 
 constexpr int RB = 384;  // reduction block size (6 waves)
@@ -908,7 +921,7 @@ template <typename T>
 int elu_bwd_t(const T* dy, const T* dy2, const T* y, T* dz, float* dbias, int64_t nvox, int C, synthsr_stream_t stream) {
   if (!dy || !y || !dz || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
+  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
                      dy2, y, dz, dbias, n4, C / 4, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      0.f, 0.f, (const float*)nullptr, (const float*)nullptr);
   SYN_CHECK_LAUNCH();
@@ -919,7 +932,7 @@ template <typename T>
 int bn_elu_bwd_t(const T* dy, const T* dy2, const T* y, T* dz, float* dbias, int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
   if (!dy || !y || !dz || !stats || !gamma || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
+  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), C * sizeof(float), (hipStream_t)stream, dy,
                      dy2, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps, (float)(1.0 / (double)nvox),
                      (const float*)nullptr, (const float*)nullptr);
   SYN_CHECK_LAUNCH();
@@ -930,7 +943,7 @@ template <typename T>
 int bn_elu_bwd_head_t(const float* dpred, const float* whead, const T* y, T* dz, float* dbias, int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
   if (!dpred || !whead || !y || !dz || !stats || !gamma || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), C * sizeof(float), (hipStream_t)stream,
+  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), C * sizeof(float), (hipStream_t)stream,
                      (const T*)nullptr, (const T*)nullptr, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps,
                      (float)(1.0 / (double)nvox), dpred, whead);
   SYN_CHECK_LAUNCH();
@@ -942,7 +955,7 @@ int bn_stats_t(const T* x, int64_t nvox, int C, float* stats, double* ws, synths
   if (!x || !stats || !ws || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   if (hipMemsetAsync(ws, 0, 2 * C * sizeof(double), (hipStream_t)stream) != hipSuccess) return SYNTHSR_ELAUNCH;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
+  hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), 2 * C * sizeof(float),
                      (hipStream_t)stream, x, n4, C / 4, ws);
   SYN_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, stats, C,
@@ -981,7 +994,7 @@ int bn_maxpool_bwd_ex_t(const T* dy, const T* x, T* dbn, const int shape[3], int
     return SYNTHSR_EINVAL;
   Shape3 s{{shape[0], shape[1], shape[2]}};
   const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
-  hipLaunchKernelGGL(bn_maxpool_bwd_sums_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
+  hipLaunchKernelGGL(bn_maxpool_bwd_sums_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), 2 * C * sizeof(float),
                      (hipStream_t)stream, dy, x, dbn, s, C, stats, gamma, beta, eps, sums);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
@@ -991,7 +1004,7 @@ template <typename T>
 int bn_bwd_reduce_t(const T* dy, const T* x, int64_t nvox, int C, const float* stats, float eps, float* sums, synthsr_stream_t stream) {
   if (!dy || !x || !stats || !sums || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), 2 * C * sizeof(float),
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), 2 * C * sizeof(float),
                      (hipStream_t)stream, dy, x, n4, C, stats, eps, sums);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
@@ -1060,7 +1073,7 @@ int head_loss_fwd_t(const T* x, const int* shape, int C, const float* stats, con
   }
   const size_t smem = ((2 + K) * C + 256 * (C + 4)) * sizeof(float);
   const float inv_n = (float)(1.0 / ((double)n_in * NT));
-  const dim3 grid(syn_grid(nvox, 256, 1024));
+  const dim3 grid(syn_grid(nvox, 256, head_grid()));
 #define SYN_HEAD_FWD(KK)                                                                                                 \
   hipLaunchKernelGGL((head_loss_fwd_kernel<T, KK>), grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta, \
                      eps, w, b, residual, res_stride, target, pred, dpred, loss, inv_n, kind, box)
@@ -1080,7 +1093,7 @@ int head_bwd_multi_t(const float* dpred, const T* x, int64_t nvox, int C, int K,
   if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C) || K < 2 || K > 4)
     return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  const dim3 grid(syn_grid(n4, RB, 1024));
+  const dim3 grid(syn_grid(n4, RB, head_grid()));
   const size_t smem = (K * C + K) * sizeof(float);
 #define SYN_HEAD_BWD(KK)                                                                                             \
   hipLaunchKernelGGL((head_multi_bwd_kernel<T, KK>), grid, dim3(RB), smem, (hipStream_t)stream, dpred, x, n4, C, stats, gamma, \
@@ -1099,7 +1112,7 @@ template <typename T>
 int head_bwd_ex_t(const float* dpred, const T* x, int64_t nvox, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, T* dbn, float* dw, float* db, float* bn_sums, synthsr_stream_t stream) {
   if (!dpred || !x || !stats || !gamma || !beta || !w || !dw || !db || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
+  hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), (C + 1) * sizeof(float),
                      (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db, bn_sums);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
@@ -1110,7 +1123,7 @@ int head_bwd_t(const float* dpred, const T* x, int64_t nvox, int C, const float*
   if (!dpred || !x || !stats || !gamma || !beta || !w || !dbn || !dw || !db || nvox < 1 || !ok_c4(C))
     return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(syn_grid(n4, RB, 2048)), dim3(RB), (C + 1) * sizeof(float),
+  hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), (C + 1) * sizeof(float),
                      (hipStream_t)stream, dpred, x, n4, C, stats, gamma, beta, eps, w, dbn, dw, db, (float*)nullptr);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
