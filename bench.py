@@ -156,10 +156,10 @@ def cpu_baseline(size_all=160, size_one=64, timed=3):
         res[tag] = dict(volumes_per_s=round(scale / float(np.mean([t[0] for t in ts])), 5), threads=threads, size=size,
                         step_s=[round(t[0], 2) for t in ts], generator_s=round(float(np.mean([t[1] for t in ts])), 2))
     torch.set_num_threads(nthreads_default)
-    return {'value': res['all']['volumes_per_s'], 'unit': 'volumes/s', 'cores': cores, 'kind': 'port',
-            'threads': res['all']['threads'], 'usable_cpus': usable, 'value_one_thread': res['one']['volumes_per_s'],
+    return {'value': res['all']['volumes_per_s'], 'unit': 'volumes/s', 'cores': res['all']['threads'], 'kind': 'port',
+            'threads': res['all']['threads'], 'usable_cpus': usable, 'physical_cores': cores, 'value_one_thread': res['one']['volumes_per_s'],
             'sample': 'oracle (numpy generator + PyTorch-CPU U-Net fwd/bwd/Keras-Adam; CPU restatement, NOT TensorFlow): '
-                      '1 warm-up + %d timed steps. all threads (%d on %d physical cores): %d^3 volumes, %s s per step '
+                      '1 warm-up + %d timed steps. all usable CPUs (%d threads; the host has %d physical cores, affinity / cgroup quota caps this process): %d^3 volumes, %s s per step '
                       '(generator %.2f s of it). one thread: %d^3 volumes (%.1f%% of the voxels of 160^3, volumes/s scaled '
                       'by voxel count), %s s per step'
                       % (timed, res['all']['threads'], cores, size_all, res['all']['step_s'], res['all']['generator_s'],
