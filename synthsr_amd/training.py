@@ -227,11 +227,19 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
     BASELINE.json configs[3]; `deterministic`: bit-identical weights run after run for the same seed, ops.set_deterministic,
     3-4x slower at 160^3 -- not with the segmentation-regularised loss)."""
     import torch
-    if deterministic:
+    if deterministic:  # process-wide switch: on for the duration of this call, previous setting restored on the way out
         if segmentation_model_file is not None:
             raise NotImplementedError('deterministic mode does not cover the Dice sums of the segmentation-regularised loss')
         from . import ops as _ops
-        _ops.set_deterministic(True)
+        kw = dict(locals())
+        kw.pop('torch', None)
+        kw.pop('_ops', None)
+        kw['deterministic'] = False
+        previous = _ops.set_deterministic(True)
+        try:
+            return training(**kw)
+        finally:
+            _ops.set_deterministic(previous)
     # the launcher script hands `--input_channels` over as text (scripts/training.py:36 of the reference): 'True' / 'False'
     input_channels = [{'True': True, 'False': False}.get(c, c) if isinstance(c, str) else c
                       for c in hm.reformat_to_list(input_channels)]

@@ -143,3 +143,34 @@ def test_trainer_step_reproducible_end_to_end(det):
         res.append((losses, net.params.clone(), net.bn_moving.clone()))
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_training_entry_point_deterministic_flag(tmp_path):
+    """training(..., deterministic=True): two runs from the same seed write identical checkpoints; the process-wide switch
+    is back to its previous setting afterwards"""
+    import os
+    from synthsr_amd import ops
+    from synthsr_amd.nifti import write_nifti
+    from synthsr_amd.synthetic import (synthetic_label_map, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
+                                       PRIOR_STDS_T1_HR)
+    from synthsr_amd.training import training
+    d = tmp_path / 'labels'
+    d.mkdir()
+    for i in range(2):
+        write_nifti(str(d / ('brain%d_labels.nii.gz' % i)), synthetic_label_map((40, 36, 48), 10 + i).astype(np.float32))
+    for nm, v in (('gl', GENERATION_LABELS), ('gc', GENERATION_CLASSES), ('pm', PRIOR_MEANS_T1_HR), ('ps', PRIOR_STDS_T1_HR)):
+        np.save(tmp_path / (nm + '.npy'), v)
+    out = []
+    for rep in range(2):
+        np.random.seed(3)
+        model_dir = str(tmp_path / ('models%d' % rep))
+        training(str(d), model_dir, str(tmp_path / 'pm.npy'), str(tmp_path / 'ps.npy'), str(tmp_path / 'gl.npy'),
+                 path_generation_classes=str(tmp_path / 'gc.npy'), output_shape=32, n_levels=3, unet_feat_count=24,
+                 nonlin_shape_factor=.125, bias_shape_factor=.125, steps_per_epoch=4, epochs=1, seed=5, verbose=False,
+                 deterministic=True)
+        assert ops.deterministic_status() == 0          # restored
+        z = np.load(os.path.join(model_dir, '001.npz'))
+        out.append({k: z[k] for k in z.files})
+    assert out[0].keys() == out[1].keys()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
