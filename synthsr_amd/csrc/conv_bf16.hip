@@ -263,6 +263,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
 #pragma unroll
     for (int i = 0; i < 4; ++i) s1[mt][i] = s2[mt][i] = 0.f;
 
+  // epilogue through buffer instructions when the output fits 32-bit byte offsets
+  const int64_t out_bytes = (int64_t)D0 * D1 * D2 * Cout * 2;
+  const bool fast_epi = !a.partial && out_bytes < (1ll << 31) && (!a.stats_partial || a.act <= 1);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(fast_epi ? out_bytes : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbelow = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(a.below ? a.below : a.out), 0, (int)(fast_epi ? out_bytes : 0), 0x00020000);
   // split-K: slice blockIdx.z of the input-channel chunks (ksplit == 1: all of them)
   const int cc_lo = (int)(((int64_t)blockIdx.z * a.ncc) / a.ksplit), cc_hi = (int)(((int64_t)(blockIdx.z + 1) * a.ncc) / a.ksplit);
   if (walk.pos < walk.end) load_halo(walk.pos, cc_lo);
@@ -333,6 +339,72 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
     // ---- epilogue: lane (m = x, g): channels (chunk*MT + mt)*16 + 4g + i of voxel (z0 + wave, y0 + y, x0 + m)
     int z0, y0, x0;
     tile_origin(t, z0, y0, x0);
+    if (fast_epi) {
+      // compile-time activation / statistics variants (no branch per piece), 32-bit offsets through buffer instructions
+      // whose out-of-range offset drops the store and returns 0 for the load: no bounds arithmetic on 64-bit addresses
+      const int gz = z0 + wave, gx = x0 + m;
+      const bool zx_ok = gz < D0 && gx < D2;
+      const uint32_t row0 = (uint32_t)((gz * D1 + y0) * D2 + gx) * (uint32_t)(Cout * 2);  // bytes
+      const uint32_t ystep = (uint32_t)(D2 * Cout * 2);
+      auto epi = [&](auto ACTC, auto STC) {
+        constexpr int ACT = decltype(ACTC)::value;
+        constexpr bool ST = decltype(STC)::value;
+#pragma unroll
+        for (int y = 0; y < TY; ++y) {
+          const bool vok = zx_ok && (y0 + y) < D1;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int co = (chunk * MT + mt) * 16 + 4 * g;
+            const uint32_t off = (vok && co < Cout) ? row0 + y * ystep + (uint32_t)(co * 2) : OOB;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[y][mt][i] + bias_r[mt][i];
+            if constexpr (ACT == 1) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
+            } else if constexpr (ACT == 2) {
+              const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rbelow, (int)off, 0, 0);
+              v[0] *= elu_dy(bf2f(b.x & 0xffffu));
+              v[1] *= elu_dy(bf2f(b.x >> 16));
+              v[2] *= elu_dy(bf2f(b.y & 0xffffu));
+              v[3] *= elu_dy(bf2f(b.y >> 16));
+            } else if constexpr (ACT == 3) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : a.alpha * v[i];
+            } else if constexpr (ACT == 4) {
+              const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rbelow, (int)off, 0, 0);
+              v[0] *= bf2f(b.x & 0xffffu) > 0.f ? 1.f : a.alpha;
+              v[1] *= bf2f(b.x >> 16) > 0.f ? 1.f : a.alpha;
+              v[2] *= bf2f(b.y & 0xffffu) > 0.f ? 1.f : a.alpha;
+              v[3] *= bf2f(b.y >> 16) > 0.f ? 1.f : a.alpha;
+            }
+            u32x2 o;
+            o.x = pack2(v[0], v[1]);
+            o.y = pack2(v[2], v[3]);
+            __builtin_amdgcn_raw_buffer_store_b64(o, rout, (int)off, 0, 0);
+            if constexpr (ST) {  // statistics of what the next layer will read (the bf16-rounded values)
+              const float w = off != OOB ? 1.f : 0.f;
+              const float r0 = w * bf2f(o.x & 0xffffu), r1 = w * bf2f(o.x >> 16), r2 = w * bf2f(o.y & 0xffffu),
+                          r3 = w * bf2f(o.y >> 16);
+              s1[mt][0] += r0; s1[mt][1] += r1; s1[mt][2] += r2; s1[mt][3] += r3;
+              s2[mt][0] += r0 * r0; s2[mt][1] += r1 * r1; s2[mt][2] += r2 * r2; s2[mt][3] += r3 * r3;
+            }
+          }
+        }
+      };
+      using T_ = std::true_type;
+      using F_ = std::false_type;
+      if (a.stats_partial) {
+        if (a.act == 1) epi(std::integral_constant<int, 1>{}, T_{});
+        else epi(std::integral_constant<int, 0>{}, T_{});
+      } else if (a.act == 0) epi(std::integral_constant<int, 0>{}, F_{});
+      else if (a.act == 1) epi(std::integral_constant<int, 1>{}, F_{});
+      else if (a.act == 2) epi(std::integral_constant<int, 2>{}, F_{});
+      else if (a.act == 3) epi(std::integral_constant<int, 3>{}, F_{});
+      else epi(std::integral_constant<int, 4>{}, F_{});
+      continue;
+    }
+    // generic path (split-K planes, statistics with other activations, tensors of 2 GiB and more)
     const int gz = z0 + wave, gx = x0 + m;
 #pragma unroll
     for (int y = 0; y < TY; ++y) {
