@@ -253,6 +253,13 @@ int synthsr_head_bwd_bf16(const float* dpred, const void* x, int64_t nvox, int C
  * has ceil(CinE / 8) * 8 channels (pad channels get zero weights); CoutE % 4 == 0 */
 int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
                                  synthsr_stream_t stream);
+/* One launch for every packed weight set of a network: jobs_dev[njobs][12] int64 = {w_off (floats into params), dst_off
+ * (bf16 elements into packed), then the 10 fields synthsr_conv3d_bf16_pack_job fills in}.  Replaces the per-layer Keras weight
+ * reads of the reference's Conv3D layers (ext/neuron/models.py:297-316) after every optimizer step. */
+int synthsr_conv3d_bf16_pack_job(int Cin_total, int ci_off, int Cin, int Cout, int mode, int64_t job[12]);
+int synthsr_conv3d_bf16_pack_all(const float* params, void* packed, const int64_t* jobs_dev, int njobs,
+                                 synthsr_stream_t stream);
+
 /* out = act(conv3(in) + bias); act 0 linear, 1 ELU, 2 multiply by ELU'(below) (data gradient fused with the ELU backward
  * of the layer below; below = that layer's ELU output [vox][Cout]).  stats != NULL: BatchNorm batch statistics
  * [mean Cout | var Cout] of the (bf16-rounded) output, accumulated in fp32 / double.  `scratch` (>=

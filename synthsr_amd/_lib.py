@@ -78,6 +78,8 @@ SIGNATURES = {
     'synthsr_head_bwd_ex_bf16': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _S]),
     'synthsr_head_bwd_bf16': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
     'synthsr_conv3d_bf16_pack': (c_int64, [_P, _P, c_int, c_int, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_bf16_pack_job': (c_int, [c_int, c_int, c_int, c_int, c_int, _P]),
+    'synthsr_conv3d_bf16_pack_all': (c_int, [_P, _P, _P, c_int, _S]),
     'synthsr_conv3d_bf16_fwd': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _P, _P, _P, c_int64, _S]),
     'synthsr_conv3d_bf16_fwd_ex': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_float, _P, _P, _P, c_int64, _S]),
     'synthsr_bf16_subsample_odd': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_float, _S]),

@@ -124,34 +124,52 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 // forward layout (A fragments): [co-chunk][cc][step][mt][lane 64][8] bf16; lane = (m = lane & 15, g = lane >> 4):
 //   pair p = 4 step + g -> tap = p / C8, c8 = p % C8;  value j: W_eff[tap][cc*CK + c8*8 + j][(chunk*MT + mt)*16 + m]
 // mode 0: W_eff = w[tap][ci_off + cie][coe]; mode 1 (data gradient): W_eff[tap][cie][coe] = w[26 - tap][ci_off + coe][cie]
-__global__ void pack_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ packed, int Cin_total, int ci_off,
-                                 int Cin, int Cout, int mode, int CK, int ncc, int MT, int nsteps, int64_t total) {
+__device__ __forceinline__ bf16_t pack_bf16_value(const float* __restrict__ w, uint32_t r, int Cin_total, int ci_off, int Cin,
+                                                  int Cout, int mode, int CK, int ncc, int MT, int nsteps) {
   const int C8 = CK / 8;
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t r = (uint32_t)idx;
-    const int j = r & 7;
-    r >>= 3;
-    const int lane = r & 63;
-    r >>= 6;
-    const int mt = r % MT;
-    r /= MT;
-    const int step = r % nsteps;
-    r /= nsteps;
-    const int cc = r % ncc;
-    const int chunk = r / ncc;
-    const int m = lane & 15, g = lane >> 4;
-    const int p = 4 * step + g;
-    const int tap = p / C8, c8 = p - tap * C8;
-    const int cie = cc * CK + c8 * 8 + j, coe = (chunk * MT + mt) * 16 + m;
-    float v = 0.f;
-    if (tap < 27 && cie < CinE && coe < CoutE) {
-      const int slot = mode ? 26 - tap : tap;
-      const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;
-      v = w[((int64_t)slot * Cin_total + ci) * Cout + co];
-    }
-    packed[idx] = (bf16_t)f2bf(v);
+  const int j = r & 7;
+  r >>= 3;
+  const int lane = r & 63;
+  r >>= 6;
+  const int mt = r % MT;
+  r /= MT;
+  const int step = r % nsteps;
+  r /= nsteps;
+  const int cc = r % ncc;
+  const int chunk = r / ncc;
+  const int m = lane & 15, g = lane >> 4;
+  const int p = 4 * step + g;
+  const int tap = p / C8, c8 = p - tap * C8;
+  const int cie = cc * CK + c8 * 8 + j, coe = (chunk * MT + mt) * 16 + m;
+  float v = 0.f;
+  if (tap < 27 && cie < CinE && coe < CoutE) {
+    const int slot = mode ? 26 - tap : tap;
+    const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;
+    v = w[((int64_t)slot * Cin_total + ci) * Cout + co];
   }
+  return (bf16_t)f2bf(v);
+}
+
+__global__ void pack_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ packed, int Cin_total, int ci_off,
+                                 int Cin, int Cout, int mode, int CK, int ncc, int MT, int nsteps, int64_t total) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+    packed[idx] = pack_bf16_value(w, (uint32_t)idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, MT, nsteps);
+}
+
+// every packed weight set of a network in ONE launch (38 launches of 5 us per training step otherwise): blockIdx.y = job,
+// jobs[j] = {w_off, dst_off, total, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, MT, nsteps} (int64 each, offsets in elements)
+constexpr int BF16_PACK_JOB_FIELDS = 12;
+__global__ void pack_bf16_all_kernel(const float* __restrict__ params, bf16_t* __restrict__ packed,
+                                     const int64_t* __restrict__ jobs) {
+  const int64_t* jb = jobs + (int64_t)blockIdx.y * BF16_PACK_JOB_FIELDS;
+  const float* w = params + jb[0];
+  bf16_t* dst = packed + jb[1];
+  const int64_t total = jb[2];
+  const int Cin_total = (int)jb[3], ci_off = (int)jb[4], Cin = (int)jb[5], Cout = (int)jb[6], mode = (int)jb[7], CK = (int)jb[8],
+            ncc = (int)jb[9], MT = (int)jb[10], nsteps = (int)jb[11];
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+    dst[idx] = pack_bf16_value(w, (uint32_t)idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, MT, nsteps);
 }
 
 struct Bf16Plan {
@@ -885,6 +903,33 @@ int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, in
   hipLaunchKernelGGL(pack_bf16_kernel, dim3(syn_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed,
                      Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.mt, pl.nsteps, total);
   return hipGetLastError() == hipSuccess ? total : (int64_t)SYNTHSR_ELAUNCH;
+}
+
+// job table row of synthsr_conv3d_bf16_pack_all for one weight set (host side; fields 0, 1 = w_off, dst_off are the caller's)
+int synthsr_conv3d_bf16_pack_job(int Cin_total, int ci_off, int Cin, int Cout, int mode, int64_t job[12]) {
+  if (!job || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1)) return SYNTHSR_EINVAL;
+  const int CinE = ((mode ? Cout : Cin) + 7) / 8 * 8, CoutE = mode ? Cin : Cout;
+  const Bf16Plan pl = plan_bf16(CinE, CoutE);
+  if (pl.count() >= (1ll << 31)) return SYNTHSR_EINVAL;
+  job[2] = pl.count();
+  job[3] = Cin_total;
+  job[4] = ci_off;
+  job[5] = Cin;
+  job[6] = Cout;
+  job[7] = mode;
+  job[8] = pl.ck;
+  job[9] = pl.ncc;
+  job[10] = pl.mt;
+  job[11] = pl.nsteps;
+  return SYNTHSR_OK;
+}
+
+int synthsr_conv3d_bf16_pack_all(const float* params, void* packed, const int64_t* jobs_dev, int njobs,
+                                 synthsr_stream_t stream) {
+  if (!params || !packed || !jobs_dev || njobs < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(pack_bf16_all_kernel, dim3(128, njobs), dim3(256), 0, (hipStream_t)stream, params, (bf16_t*)packed,
+                     jobs_dev);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
 int synthsr_conv3d_bf16_fwd_ex(const void* in, const void* wp, const float* bias, void* out, const int shape[3], int Cin,

@@ -251,15 +251,39 @@ class UNet3D:
                     o, n = c[key + '_off']
                     c[key] = self._packed[o:o + n]
 
-    def _repack_bf16(self, src=None):
-        """bf16 fragment-ordered copies of every conv kernel (forward, and data-gradient where a gradient flows on)"""
-        first = True
+    def _bf16_pack_jobs(self):
+        """job table of synthsr_conv3d_bf16_pack_all: bf16 fragment-ordered copies of every conv kernel (forward, and
+        data-gradient where a gradient flows on) in one flat buffer"""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        jobs, off, first = [], 0, True
         for c in self.all_convs():
-            w = self.view(c['w'], src)
-            c['wp'] = ops.pack_conv_weights_bf16(w, 0, out=c.get('wp'))
-            if not first or self.need_input_grad:
-                c['wpd'] = ops.pack_conv_weights_bf16(w, 1, out=c.get('wpd'))
+            for key, mode in (('wp', 0), ('wpd', 1)):
+                if mode == 1 and first and not self.need_input_grad:  # the first layer's input normally has no gradient
+                    continue
+                job = (ctypes.c_int64 * 12)()
+                _lib.check(lib.synthsr_conv3d_bf16_pack_job(c['cin'], 0, c['cin'], c['cout'], mode, job), 'bf16_pack_job')
+                job[0], job[1] = self.offsets[c['w']][0], off
+                c[key + '_off'] = (off, int(job[2]))
+                off += int(job[2])
+                jobs.append([int(v) for v in job])
             first = False
+        self._packed_bf16 = torch.empty(off, dtype=torch.bfloat16, device=self.device)
+        self._jobs_bf16 = torch.tensor(jobs, dtype=torch.int64, device=self.device)
+        for c in self.all_convs():
+            for key in ('wp', 'wpd'):
+                if key + '_off' in c:
+                    o, n = c[key + '_off']
+                    c[key] = self._packed_bf16[o:o + n]
+
+    def _repack_bf16(self, src=None):
+        from . import _lib
+        if getattr(self, '_jobs_bf16', None) is None:
+            self._bf16_pack_jobs()
+        _lib.check(_lib.load().synthsr_conv3d_bf16_pack_all(_lib.ptr(self.params if src is None else src),
+                                                            _lib.ptr(self._packed_bf16), _lib.ptr(self._jobs_bf16),
+                                                            int(self._jobs_bf16.shape[0]), _lib.stream()), 'bf16_pack_all')
 
     def repack(self, src=None):
         """refresh the MFMA-fragment-ordered copies of ALL conv kernels in one launch (after init / optimizer step /
@@ -545,6 +569,7 @@ class UNet3D:
         if not self.need_input_grad:
             self.need_input_grad = True
             self._jobs = None
+            self._jobs_bf16 = None
             self.repack()
 
     def predict_probs(self, x):
