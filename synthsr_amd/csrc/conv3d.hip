@@ -27,6 +27,9 @@ constexpr int MAX_NT = 6;  // n-tiles (of 16 output channels) per workgroup
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 inline int ck_for(int Cin) { return (Cin % 24 == 0) ? 24 : 8; }
+// forward / data-gradient kernels also take 32-channel chunks (the critic's 32 / 64 / 128 / 256 channels: four 8-channel
+// chunks re-staged the halo tile four times per tile and ran at 6 % of the MFMA peak)
+inline int ck_for_fwd(int Cin) { return (Cin % 24 == 0) ? 24 : ((Cin % 32 == 0) ? 32 : 8); }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {  // compile-time loop: f(std::integral_constant<int, I>) for I in [I, N)
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(const float* __restr
           const size_t off =
               ok ? ((((size_t)(gz * is + io0) * (D1 * is) + (gy * is + io1)) * (D2 * is) + (gx * is + io2)) * Cin + c) : 0;
           float4 v;
-          if constexpr (CK == 24) {  // Cin % 24 == 0: aligned float4, channel range always valid
+          if constexpr (CK != 8) {  // Cin % CK == 0: aligned float4, channel range always valid
             v = ld4(in + off);
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
           } else {
@@ -2800,13 +2803,13 @@ struct FwdPlan {
 inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
   const bool plain = kind == 1;
   FwdPlan p;
-  p.ck = ck_for(Cin);
+  p.ck = ck_for_fwd(Cin);
   p.ncc = cdiv(Cin, p.ck);
   const int ntiles = cdiv(Cout, 16);
   auto wgs = [&](int mt, int nt) { return (int64_t)cdiv(s[0], FT0) * cdiv(s[1], mt) * cdiv(s[2], FT2) * cdiv(ntiles, nt); };
   p.mt = 4;
   int max_nt = MAX_NT;
-  if (wgs(4, std::min(MAX_NT, ntiles)) < 768 || (g_force_mt == 2 && ntiles <= 3)) {
+  if (wgs(4, std::min(MAX_NT, ntiles)) < 768 || (g_force_mt == 2 && ntiles <= 3) || p.ck == 32) {  // ck 32: 62 KB halo tile
     p.mt = 2;
     max_nt = 3;
   }
@@ -3581,6 +3584,7 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   const ConvExt ext{0, nullptr, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
+  if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
 }
 
@@ -3592,6 +3596,7 @@ int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* b
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   const ConvExt ext{0, addend, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
+  if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
 }
 
@@ -3618,6 +3623,7 @@ int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* b
   const int64_t wstride = pl.count();
   const ConvExt ext{1, addend, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
+  if (pl.ck == 32) return dispatch_fwd<32>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
 }
 
@@ -3631,6 +3637,7 @@ int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo
   const int64_t wstride = pl.count();
   const ConvExt ext{2, nullptr, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);
+  if (pl.ck == 32) return dispatch_fwd<32>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);
 }
 
