@@ -4,11 +4,14 @@ against the oracle run on a real batch dimension ([B, d0, d1, d2, C] through tor
 import numpy as np
 import pytest
 
+from conftest import retry_pool_flips
+
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('fold', [False, True])
 @pytest.mark.parametrize('B,feats,levels,shape,cin', [(2, 24, 3, (16, 16, 32), 2), (3, 8, 2, (8, 12, 16), 1), (2, 24, 4, (32, 16, 16), 2)])
+@retry_pool_flips()
 def test_batched_unet_vs_oracle(B, feats, levels, shape, cin, fold):
     import torch
     from synthsr_amd.unet import unet

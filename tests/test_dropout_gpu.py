@@ -5,6 +5,8 @@ which applies the same factors the way the reference graph does (multiplying the
 import numpy as np
 import pytest
 
+from conftest import retry_pool_flips
+
 pytestmark = pytest.mark.gpu
 
 
@@ -24,6 +26,7 @@ def _scales(net, rate, seed, force_drop=True):
 @pytest.mark.parametrize('feats,levels,shape,cin,nconv,rate', [
     (24, 3, (16, 16, 32), 2, 2, .3), (8, 2, (8, 12, 16), 1, 2, .3), (8, 3, (16, 16, 16), 1, 1, .3), (8, 2, (8, 8, 16), 1, 3, .3),
     (8, 3, (16, 16, 16), 1, 1, 0.), (8, 2, (8, 8, 16), 2, 3, 0.)])   # rate 0: nb_conv_per_level 1 / 3 without dropout
+@retry_pool_flips()
 def test_dropout_network_vs_oracle(feats, levels, shape, cin, nconv, rate, fold):
     import torch
     from synthsr_amd.unet import unet

@@ -5,6 +5,8 @@ pointwise kernels 1e-5."""
 import numpy as np
 import pytest
 
+from conftest import retry_pool_flips
+
 pytestmark = pytest.mark.gpu
 
 
@@ -220,6 +222,7 @@ def _copy_params(net, torch):
 
 @pytest.mark.parametrize('fold', [False, True])
 @pytest.mark.parametrize('feats,levels,shape,cin', [(24, 3, (16, 16, 32), 2), (8, 2, (8, 12, 16), 1), (24, 5, (32, 32, 32), 2)])
+@retry_pool_flips()
 def test_unet_loss_and_gradients_vs_autograd(T, feats, levels, shape, cin, fold):
     torch = T
     from synthsr_amd.unet import unet
@@ -302,6 +305,7 @@ def test_training_reduces_loss(T):
 
 @pytest.mark.parametrize('fs_header,clip,crop', [(False, False, None), (True, True, None), (True, False, (12, 16, 20)),
                                                  (False, True, (8, 24, 12))])
+@retry_pool_flips()
 def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
     """SynthSR/metrics_model.py:136-215: L1 + w * Dice(frozen segmentation U-Net(prediction), label map).  Loss value and
     every gradient of the TRAINED network against torch autograd through the oracle (frozen net in inference mode)"""
