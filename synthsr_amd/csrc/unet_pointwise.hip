@@ -10,18 +10,12 @@
 
 SYN_DET_SETTER(pointwise)
 
-#include <cstdlib>
 // workgroups of the channel-reduction kernels: every workgroup ends with one atomicAdd per channel sum on the SAME addresses,
 // and same-address atomics serialise at the memory-side unit (~14 ns each): with 2048 workgroups the tail cost 0.6 ms per fp32
 // step (29.36 -> 28.76 ms at 768 = 3 per CU; 512 and 1024 are within noise of it).  The grid-stride loops do the rest.
-static int red_grid() {
-  static const int g = getenv("SYN_RED_GRID") ? atoi(getenv("SYN_RED_GRID")) : 768;
-  return g;
-}
-static int head_grid() {
-  static const int g = getenv("SYN_HEAD_GRID") ? atoi(getenv("SYN_HEAD_GRID")) : 1024;
-  return g;
-}
+// The head kernels (one atomic per workgroup on the loss word) are insensitive between 256 and 1024.
+static constexpr int red_grid() { return 768; }
+static constexpr int head_grid() { return 1024; }
 
 namespace {
 
