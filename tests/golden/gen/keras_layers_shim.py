@@ -41,7 +41,7 @@ def reset(seed=0, learning_phase=1):
     LAYERS.clear()
     PARAMS.clear()
     STATE.update(learning_phase=learning_phase, bn_batch={}, uid={}, rng=np.random.default_rng(seed),
-                 frozen_bn_inference=False)
+                 frozen_bn_inference=False, dropout={})
 
 
 def _uid(prefix):
@@ -350,14 +350,29 @@ class Dense(KerasLayer):
 
 
 class Dropout(KerasLayer):
+    """keras.layers.Dropout(rate, noise_shape): in the learning phase x * keep / (1 - rate) with a keep mask of shape
+    noise_shape (None -> the tensor's own extent), identity otherwise (documented Keras semantics, backend.dropout ->
+    tf.nn.dropout).  The mask is drawn from a generator seeded with the layer name; the per-feature factor is recorded in
+    STATE['dropout'][name] so that a golden can hand the same factors to the code under test."""
     prefix = 'dropout'
 
     def __init__(self, rate, noise_shape=None, name=None, **kw):
         super().__init__(name=name)
-        assert rate == 0
+        self.rate = float(rate)
+        self.noise_shape = noise_shape
 
     def forward(self, x):
-        return np.asarray(x)
+        x = np.asarray(x)
+        if self.rate == 0 or not STATE['learning_phase']:
+            return x
+        import zlib
+        shape = list(x.shape) if self.noise_shape is None else [x.shape[i] if d is None else int(d)
+                                                                 for i, d in enumerate(self.noise_shape)]
+        rng = np.random.default_rng(zlib.crc32(self.name.encode()))
+        keep = rng.random(shape) >= self.rate
+        scale = (keep / (1.0 - self.rate)).astype(np.float32)
+        STATE.setdefault('dropout', {})[self.name] = scale
+        return x * scale
 
 
 class Lambda:

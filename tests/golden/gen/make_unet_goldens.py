@@ -331,8 +331,42 @@ def golden_critic(out):
               'g_loss', out[tag + '_g_loss'], out[tag + '_g_loss_crop'], 'params', n_trainable())
 
 
+# ------------------------------------------------------------------------------------------------ 6. conv_dropout wiring
+def golden_dropout(out):
+    """the reference's unet(..., conv_dropout=.4) in the learning phase (ext/neuron/models.py:320-324, 448-451): where the
+    feature-wise Dropout layers sit, what the skip connections read (the conv layer's own output, models.py:431-432) and
+    that the inference phase ignores them.  Every layer output and every drawn per-feature factor is stored."""
+    rng = np.random.default_rng(8)
+    x = rng.uniform(0, 1, (1, 16, 8, 16, 2)).astype(np.float32)
+    for tag, phase in (('do_train', 1), ('do_infer', 0)):
+        ks.reset(seed=6, learning_phase=phase)
+        FEED[:] = [('unet_input', x)]
+        model = nrn_models.unet(nb_features=8, input_shape=[16, 8, 16, 2], nb_levels=3, conv_size=3, nb_labels=1,
+                                feat_mult=2, nb_conv_per_level=2, conv_dropout=.4, final_pred_activation='linear',
+                                batch_norm=-1, activation='elu', input_model=None)
+        out[tag + '_x'] = x
+        out.update(params_dict(tag + '_w:'))
+        out[tag + '_order'] = call_order()
+        for layer, _, o in ks.GRAPH:  # the concatenations only: what the skip connections carry
+            if 'merge' in str(layer.name) or 'concat' in str(layer.name):
+                out['%s_act:%s' % (tag, layer.name)] = np.asarray(o)[0]
+        out[tag + '_pred'] = np.asarray(model.output)[0]
+        for k, v in ks.STATE['dropout'].items():
+            assert v.shape[:4] == (1, 1, 1, 1), v.shape          # noise_shape [None, 1, 1, 1, C]: one factor per feature
+            out['%s_scale:%s' % (tag, k)] = v.reshape(-1)
+        for k, (m, v) in ks.STATE['bn_batch'].items():
+            out['%s_bnmean:%s' % (tag, k)] = m
+            out['%s_bnvar:%s' % (tag, k)] = v
+        print(tag, 'pred', out[tag + '_pred'].shape, 'dropout layers', len(ks.STATE['dropout']),
+              [n for n in call_order() if 'dropout' in n])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['wiring', 'graph', 'seg', 'critic']
+    which = sys.argv[1:] or ['wiring', 'graph', 'seg', 'critic', 'dropout']
+    if 'dropout' in which:
+        out = {}
+        golden_dropout(out)
+        np.savez_compressed(os.path.join(OUT, 'unet_dropout.npz'), **out)
     if 'wiring' in which:
         out = golden_param_count()
         golden_small_unet(out)

@@ -226,3 +226,53 @@ def test_oracle_critic_vs_reference(tag):
         lut = dict(zip(g[tag + '_gen_labels'].tolist(), g[tag + '_labels_to_mask'].tolist()))
         exp = np.vectorize(lut.get)(g[tag + '_seg'])
         np.testing.assert_array_equal(g[tag + '_mask'][..., 0], exp)
+
+
+def _dropout_scales(g, tag, nb_levels=3, nconv=2):
+    """the factors the shim's Dropout layers drew, keyed by the conv layer each one follows: Keras names
+    `unet_dropout_downarm_<l>_<k>` / `unet_dropout_uparm_<level>_<k>` (level counts the decoder stages from 0) ->
+    `unet_conv_downarm_<l>_<k>` / `unet_conv_uparm_<nb_levels + level>_<k>` (ext/neuron/models.py:322, 449)"""
+    sc = {}
+    for l in range(nb_levels):
+        for k in range(nconv):
+            sc['unet_conv_downarm_%d_%d' % (l, k)] = tt(g['%s_scale:unet_dropout_downarm_%d_%d' % (tag, l, k)])
+    for lvl in range(nb_levels - 1):
+        for k in range(nconv):
+            sc['unet_conv_uparm_%d_%d' % (nb_levels + lvl, k)] = tt(g['%s_scale:unet_dropout_uparm_%d_%d' % (tag, lvl, k)])
+    return sc
+
+
+def test_oracle_dropout_wiring_vs_reference():
+    """conv_dropout: the reference's unet(conv_dropout=.4) run on the Keras shim in the learning phase, with the drawn
+    per-feature factors recorded: the oracle given the same factors reproduces the prediction, the BatchNorm batch
+    statistics (of the dropped-out tensors) and the concatenated tensors -- whose skip halves must be the conv layers' own
+    outputs, NOT their dropped-out versions (ext/neuron/models.py:320-324, 431-434, 448-451).  Inference ignores dropout."""
+    g = load_golden('unet_dropout')
+    tag = 'do_train'
+    P = {k: tt(v) for k, v in golden_weights(g, tag + '_w:').items()}
+    P['unet_likelihood/kernel'] = P['unet_likelihood/kernel'].reshape(P['unet_likelihood/kernel'].shape[-2:])
+    x = tt(g[tag + '_x'][0])
+    sc = _dropout_scales(g, tag)
+    assert all(np.all((v.numpy() == 0) | np.isclose(v.numpy(), 1 / .6, rtol=1e-6)) for v in sc.values())
+    assert any((v == 0).any() for v in sc.values())
+    stats = {}
+    pred = U.unet_forward(x, P, 'unet', 3, 2, training=True, collect=stats, dropout=sc)
+    close(pred, g[tag + '_pred'], name='prediction with dropout')
+    for name, (m, v) in stats.items():
+        close(m, g['%s_bnmean:%s' % (tag, name)], name=name + ' mean')
+        close(v, g['%s_bnvar:%s' % (tag, name)], name=name + ' var')
+    # the skip half of the first merge = ELU(conv_downarm_1_1(...)) un-dropped: it has no exact zeros although features
+    # of that layer were dropped; the up-sampled half comes from a BatchNorm and has none either
+    merge3 = g[tag + '_act:unet_merge_3']
+    dropped = np.flatnonzero(sc['unet_conv_downarm_1_1'].numpy() == 0)
+    assert dropped.size > 0 and np.abs(merge3[..., dropped]).max() > 0
+    # without the factors the oracle must NOT match (the golden really exercises the dropout)
+    plain = U.unet_forward(x, P, 'unet', 3, 2, training=True)
+    assert float((plain - tt(g[tag + '_pred'])).abs().max()) > 1e-3
+    # inference phase: dropout layers are the identity
+    tag = 'do_infer'
+    P = {k: tt(v) for k, v in golden_weights(g, tag + '_w:').items()}
+    P['unet_likelihood/kernel'] = P['unet_likelihood/kernel'].reshape(P['unet_likelihood/kernel'].shape[-2:])
+    pred = U.unet_forward(tt(g[tag + '_x'][0]), P, 'unet', 3, 2, training=False, moving=P)
+    close(pred, g[tag + '_pred'], name='inference prediction')
+    assert not any(k.startswith('do_infer_scale:') for k in g.files)

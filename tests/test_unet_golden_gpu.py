@@ -63,6 +63,43 @@ def test_small_unet_vs_reference_wiring(T, fold):
     close(seg.predict_probs(x).view(16, 24, 8, 5), g['sm_softmax_pred'], name='softmax posteriors')
 
 
+@pytest.mark.parametrize('fold', [False, True])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_dropout_vs_reference_wiring(T, fold, dtype):
+    """conv_dropout: the reference's unet(conv_dropout=.4) on the shim in the learning phase, with the per-feature factors
+    its Dropout layers drew handed to the device path (which never scales an activation: factors ride on the next conv's
+    kernels and on the level's BatchNorm).  Prediction; the statistics the moving averages are fed = those of the dropped-out
+    tensors the reference's BatchNormalization layers saw; inference ignores dropout."""
+    torch = T
+    from synthsr_amd.unet import unet
+    g = load_golden('unet_dropout')
+    x = torch.as_tensor(g['do_train_x'][0]).cuda()
+    net = unet(nb_features=8, input_shape=[16, 8, 16, 2], nb_levels=3, conv_size=3, nb_labels=1, feat_mult=2,
+               nb_conv_per_level=2, batch_norm=-1, activation='elu', final_pred_activation='linear', fold_upsample=fold,
+               conv_dropout=.4, dtype=dtype)
+    net.load_state_dict(golden_weights(g, 'do_train_w:'))
+    sc = {}
+    for l in range(3):
+        for k in range(2):
+            sc['unet_conv_downarm_%d_%d' % (l, k)] = g['do_train_scale:unet_dropout_downarm_%d_%d' % (l, k)]
+    for lvl in range(2):
+        for k in range(2):
+            sc['unet_conv_uparm_%d_%d' % (3 + lvl, k)] = g['do_train_scale:unet_dropout_uparm_%d_%d' % (lvl, k)]
+    net.set_dropout_scales(sc)
+    zero = torch.zeros(16 * 8 * 16, device='cuda')
+    _, pred = net.loss_l1(x, zero, want_pred=True)
+    rel = 2e-4 if dtype == 'f32' else 4e-2
+    close(pred.view(16, 8, 16, 1), g['do_train_pred'], rel, name='training-phase prediction with dropout')
+    for bn in net.bn_layers:
+        o, C = bn['soff'], bn['C']
+        close(net.bn_true[o:o + C], g['do_train_bnmean:' + bn['name']], max(rel, 1e-3 if dtype == 'bf16' else rel),
+              name=bn['name'] + ' mean of the dropped-out tensor')
+        close(net.bn_true[o + C:o + 2 * C], g['do_train_bnvar:' + bn['name']], 5 * rel if dtype == 'bf16' else rel,
+              name=bn['name'] + ' var of the dropped-out tensor')
+    net.load_state_dict(golden_weights(g, 'do_infer_w:'))
+    close(net.predict(x), g['do_infer_pred'], rel, name='inference-phase prediction')
+
+
 def test_training_graph_vs_reference(T):
     """the graph training() compiles (labels_to_image_model -> unet -> metrics_model, SynthSR/training.py:319-347) at 32^3
     with the benchmark network: HIP generator from the golden's labels + tape, HIP U-Net, fused head + L1 loss; plain and
