@@ -361,8 +361,33 @@ def golden_dropout(out):
               [n for n in call_order() if 'dropout' in n])
 
 
+# ------------------------------------------------------------------------------------------------ 7. a batch of volumes
+def golden_batch(out):
+    """the reference's unet on a batch of TWO different volumes in the learning phase (training(batchsize=2)): the
+    BatchNormalization layers' statistics run over batch and voxels, everything else is per volume"""
+    rng = np.random.default_rng(9)
+    x = rng.uniform(0, 1, (2, 16, 8, 16, 2)).astype(np.float32)
+    x[1] *= 1.7
+    ks.reset(seed=7, learning_phase=1)
+    FEED[:] = [('unet_input', x)]
+    model = nrn_models.unet(nb_features=8, input_shape=[16, 8, 16, 2], nb_levels=3, conv_size=3, nb_labels=1, feat_mult=2,
+                            nb_conv_per_level=2, conv_dropout=0, final_pred_activation='linear', batch_norm=-1,
+                            activation='elu', input_model=None)
+    out['b2_x'] = x
+    out.update(params_dict('b2_w:'))
+    out['b2_pred'] = np.asarray(model.output)
+    for k, (m, v) in ks.STATE['bn_batch'].items():
+        out['b2_bnmean:%s' % k] = m
+        out['b2_bnvar:%s' % k] = v
+    print('batch pred', out['b2_pred'].shape)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['wiring', 'graph', 'seg', 'critic', 'dropout']
+    which = sys.argv[1:] or ['wiring', 'graph', 'seg', 'critic', 'dropout', 'batch']
+    if 'batch' in which:
+        out = {}
+        golden_batch(out)
+        np.savez_compressed(os.path.join(OUT, 'unet_batch.npz'), **out)
     if 'dropout' in which:
         out = {}
         golden_dropout(out)

@@ -276,3 +276,20 @@ def test_oracle_dropout_wiring_vs_reference():
     pred = U.unet_forward(tt(g[tag + '_x'][0]), P, 'unet', 3, 2, training=False, moving=P)
     close(pred, g[tag + '_pred'], name='inference prediction')
     assert not any(k.startswith('do_infer_scale:') for k in g.files)
+
+
+def test_oracle_batch_of_volumes_vs_reference():
+    """batchsize 2: the reference's unet on the shim with a batch of two different volumes, learning phase -- prediction of
+    both volumes and the BatchNorm statistics over batch and voxels"""
+    g = load_golden('unet_batch')
+    P = {k: tt(v) for k, v in golden_weights(g, 'b2_w:').items()}
+    P['unet_likelihood/kernel'] = P['unet_likelihood/kernel'].reshape(P['unet_likelihood/kernel'].shape[-2:])
+    stats = {}
+    pred = U.unet_forward(tt(g['b2_x']), P, 'unet', 3, 2, training=True, collect=stats)
+    close(pred, g['b2_pred'], name='prediction of the batch')
+    for name, (m, v) in stats.items():
+        close(m, g['b2_bnmean:' + name], name=name + ' mean')
+        close(v, g['b2_bnvar:' + name], name=name + ' var')
+    # per-volume statistics would differ: the second volume is 1.7x the first
+    solo = U.unet_forward(tt(g['b2_x'][0]), P, 'unet', 3, 2, training=True)
+    assert float((solo - tt(g['b2_pred'][0])).abs().max()) > 1e-3

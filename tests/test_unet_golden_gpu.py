@@ -100,6 +100,26 @@ def test_dropout_vs_reference_wiring(T, fold, dtype):
     close(net.predict(x), g['do_infer_pred'], rel, name='inference-phase prediction')
 
 
+@pytest.mark.parametrize('fold', [False, True])
+def test_batch_of_volumes_vs_reference(T, fold):
+    """batchsize 2 (UNet3D.set_batch: volumes stacked along the first axis) against the reference's unet run on a batch of
+    two different volumes: prediction of both, BatchNorm statistics over batch and voxels"""
+    torch = T
+    from synthsr_amd.unet import unet
+    g = load_golden('unet_batch')
+    net = unet(nb_features=8, input_shape=[16, 8, 16, 2], nb_levels=3, conv_size=3, nb_labels=1, feat_mult=2,
+               nb_conv_per_level=2, batch_norm=-1, activation='elu', final_pred_activation='linear', fold_upsample=fold)
+    net.load_state_dict(golden_weights(g, 'b2_w:'))
+    net.set_batch(2)
+    x = torch.as_tensor(g['b2_x']).reshape(32, 8, 16, 2).cuda()
+    _, pred = net.loss_l1(x, torch.zeros(2 * 16 * 8 * 16, device='cuda'), want_pred=True)
+    close(pred.view(2, 16, 8, 16, 1), g['b2_pred'], name='prediction of the batch')
+    for bn in net.bn_layers:
+        m, v = _bn_stats(net, bn['name'])
+        close(m, g['b2_bnmean:' + bn['name']], name=bn['name'] + ' mean')
+        close(v, g['b2_bnvar:' + bn['name']], name=bn['name'] + ' var')
+
+
 def test_training_graph_vs_reference(T):
     """the graph training() compiles (labels_to_image_model -> unet -> metrics_model, SynthSR/training.py:319-347) at 32^3
     with the benchmark network: HIP generator from the golden's labels + tape, HIP U-Net, fused head + L1 loss; plain and
