@@ -334,6 +334,7 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
         import torch.distributed as dist
         dist.broadcast(net.params, 0)  # identical initial weights on every rank
         net.repack()
+        net._drop_gen.manual_seed(int(seed) + 0x5eed + 7919 * rank)  # ... but its own dropout masks (as its own samples)
     # frozen segmentation CNN for the segmentation-regularised loss (training.py:371-409)
     seg_reg = None
     if segmentation_model_file is not None:
