@@ -4,56 +4,71 @@ against the oracle run on a real batch dimension ([B, d0, d1, d2, C] through tor
 import numpy as np
 import pytest
 
-from conftest import retry_pool_flips
+from conftest import single_shot_parity
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('fold', [False, True])
 @pytest.mark.parametrize('B,feats,levels,shape,cin', [(2, 24, 3, (16, 16, 32), 2), (3, 8, 2, (8, 12, 16), 1), (2, 24, 4, (32, 16, 16), 2)])
-@retry_pool_flips()
 def test_batched_unet_vs_oracle(B, feats, levels, shape, cin, fold):
     import torch
     from synthsr_amd.unet import unet
     from oracle import unet_ref as U
-    net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1, feat_mult=2,
-               nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3, fold_upsample=fold)
-    g = torch.Generator().manual_seed(11)
-    for nm, v in net.named_parameters():
-        if nm.endswith('/gamma'):
-            v.copy_(torch.rand(v.shape, generator=g) + .5)
-        elif nm.endswith('/beta') or nm.endswith('/bias'):
-            v.copy_(torch.randn(v.shape, generator=g) * .1)
-    net.repack()
-    net.set_batch(B)
-    x = torch.rand(B, *shape, cin, generator=g)
-    x[1] *= 1.7                                           # the volumes of a batch differ in scale: per-volume stats would show
-    target = torch.rand(B, *shape, 1, generator=g)
-    xs = x.reshape(B * shape[0], shape[1], shape[2], cin).cuda()
-    loss, pred = net.loss_l1(xs, target.reshape(-1).cuda(), want_pred=True)
-    pred = pred.clone()
-    net.backward()
-    P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
-    stats = {}
-    pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats)
-    assert list(pr.shape) == [B] + list(shape) + [1]
-    lr = U.l1_loss(pr, target)
-    lr.backward()
-    err = (pred.view(B, *shape, 1).cpu() - pr).abs().max().item() / pr.abs().max().item()
-    assert err < 5e-4, err
-    assert abs(loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
-    for nm, _, kind in net.specs:
-        got = net.view(nm, net.grads).cpu().double()
-        ref = P[nm].grad.double()
-        e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
-        # per-tensor max error relative to the tensor's max-abs; the sums run over B volumes here (more cancelling terms
-        # per weight than in the single-volume tests, whose bounds are 2e-3 / 5e-3)
-        assert e < (4e-3 if kind in ('kernel', 'head_w') else 8e-3), (nm, e)
-    for bn in net.bn_layers:
-        o, C = bn['soff'], bn['C']
-        m, v = stats[bn['name']]
-        assert (net.bn_batch[o:o + C].cpu() - m).abs().max().item() < 1e-4 * max(1.0, m.abs().max().item())
-        assert (net.bn_batch[o + C:o + 2 * C].cpu() - v).abs().max().item() < 1e-4 * max(1.0, v.abs().max().item())
+    g = torch.Generator()
+    tensors = {}
+
+    def run():
+        net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1, feat_mult=2,
+                   nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3,
+                   fold_upsample=fold)
+        g.manual_seed(11)
+        for nm, v in net.named_parameters():
+            if nm.endswith('/gamma'):
+                v.copy_(torch.rand(v.shape, generator=g) + .5)
+            elif nm.endswith('/beta') or nm.endswith('/bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * .1)
+        net.repack()
+        net.set_batch(B)
+        x = torch.rand(B, *shape, cin, generator=g)
+        x[1] *= 1.7                                       # the volumes of a batch differ in scale: per-volume stats would show
+        target = torch.rand(B, *shape, 1, generator=g)
+        xs = x.reshape(B * shape[0], shape[1], shape[2], cin).cuda()
+        loss, pred = net.loss_l1(xs, target.reshape(-1).cuda(), want_pred=True)
+        net.test_loss, net.test_pred = loss.clone(), pred.clone()
+        net.backward()
+        tensors.update(x=x, target=target, xs=xs)
+        return net
+
+    def check(net):
+        x, target = tensors['x'], tensors['target']
+        if 'ref' not in tensors:
+            P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+            stats = {}
+            pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats)
+            assert list(pr.shape) == [B] + list(shape) + [1]
+            lr = U.l1_loss(pr, target)
+            lr.backward()
+            tensors['ref'] = (P, stats, pr.detach(), lr.detach())
+        P, stats, pr, lr = tensors['ref']
+        err = (net.test_pred.view(B, *shape, 1).cpu() - pr).abs().max().item() / pr.abs().max().item()
+        assert err < 5e-4, err
+        assert abs(net.test_loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
+        for nm, _, kind in net.specs:
+            got = net.view(nm, net.grads).cpu().double()
+            ref = P[nm].grad.double()
+            e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            # per-tensor max error relative to the tensor's max-abs; the sums run over B volumes here (more cancelling terms
+            # per weight than in the single-volume tests, whose bounds are 2e-3 / 5e-3)
+            assert e < (4e-3 if kind in ('kernel', 'head_w') else 8e-3), (nm, e)
+        for bn in net.bn_layers:
+            o, C = bn['soff'], bn['C']
+            m, v = stats[bn['name']]
+            assert (net.bn_batch[o:o + C].cpu() - m).abs().max().item() < 1e-4 * max(1.0, m.abs().max().item())
+            assert (net.bn_batch[o + C:o + 2 * C].cpu() - v).abs().max().item() < 1e-4 * max(1.0, v.abs().max().item())
+
+    net, _ = single_shot_parity(run, check)
+    xs = tensors['xs']
     # Keras' sample-variance correction uses the number of values behind the statistics: B * voxels
     l0 = float(B * np.prod(shape))
     o, C = net.bn_layers[0]['soff'], net.bn_layers[0]['C']

@@ -5,7 +5,7 @@ which applies the same factors the way the reference graph does (multiplying the
 import numpy as np
 import pytest
 
-from conftest import retry_pool_flips
+from conftest import single_shot_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -26,45 +26,60 @@ def _scales(net, rate, seed, force_drop=True):
 @pytest.mark.parametrize('feats,levels,shape,cin,nconv,rate', [
     (24, 3, (16, 16, 32), 2, 2, .3), (8, 2, (8, 12, 16), 1, 2, .3), (8, 3, (16, 16, 16), 1, 1, .3), (8, 2, (8, 8, 16), 1, 3, .3),
     (8, 3, (16, 16, 16), 1, 1, 0.), (8, 2, (8, 8, 16), 2, 3, 0.)])   # rate 0: nb_conv_per_level 1 / 3 without dropout
-@retry_pool_flips()
 def test_dropout_network_vs_oracle(feats, levels, shape, cin, nconv, rate, fold):
     import torch
     from synthsr_amd.unet import unet
     from oracle import unet_ref as U
-    net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1,
-               feat_mult=2, nb_conv_per_level=nconv, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3,
-               fold_upsample=fold, conv_dropout=rate)
-    g = torch.Generator().manual_seed(11)
-    for nm, v in net.named_parameters():
-        if nm.endswith('/gamma'):
-            v.copy_(torch.rand(v.shape, generator=g) + .5)
-        elif nm.endswith('/beta') or nm.endswith('/bias'):
-            v.copy_(torch.randn(v.shape, generator=g) * .1)
-    net.repack()
-    x = torch.rand(*shape, cin, generator=g)
-    target = torch.rand(*shape, 1, generator=g)
-    sc = _scales(net, rate, 5, force_drop=rate > 0)
-    if rate > 0:
-        net.set_dropout_scales(sc)
-    loss, pred = net.loss_l1(x.cuda(), target.reshape(-1).cuda(), want_pred=True)
-    pred = pred.clone()
-    ready = []
-    net.backward(on_grad_ready=ready.append)
-    assert ready and ready == sorted(ready, reverse=True)          # the bucketing hook still fires, high offsets first
-    P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
-    stats = {}
-    pr = U.unet_forward(x, P, net.prefix, levels, nconv, training=True, collect=stats,
-                        dropout={k: torch.from_numpy(v) for k, v in sc.items()})
-    lr = U.l1_loss(pr, target)
-    lr.backward()
-    err = (pred.view(*shape, 1).cpu() - pr).abs().max().item() / pr.abs().max().item()
-    assert err < 5e-4, err
-    assert abs(loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
-    for nm, _, kind in net.specs:
-        got = net.view(nm, net.grads).cpu().double()
-        ref = P[nm].grad.double()
-        e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
-        assert e < (2e-3 if kind in ('kernel', 'head_w') else 5e-3), (nm, e)
+    g = torch.Generator()
+    tensors = {}
+
+    def run():
+        net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1,
+                   feat_mult=2, nb_conv_per_level=nconv, final_pred_activation='linear', batch_norm=-1, activation='elu',
+                   seed=3, fold_upsample=fold, conv_dropout=rate)
+        g.manual_seed(11)
+        for nm, v in net.named_parameters():
+            if nm.endswith('/gamma'):
+                v.copy_(torch.rand(v.shape, generator=g) + .5)
+            elif nm.endswith('/beta') or nm.endswith('/bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * .1)
+        net.repack()
+        x = torch.rand(*shape, cin, generator=g)
+        target = torch.rand(*shape, 1, generator=g)
+        sc = _scales(net, rate, 5, force_drop=rate > 0)
+        if rate > 0:
+            net.set_dropout_scales(sc)
+        loss, pred = net.loss_l1(x.cuda(), target.reshape(-1).cuda(), want_pred=True)
+        net.test_loss, net.test_pred = loss.clone(), pred.clone()
+        ready = []
+        net.backward(on_grad_ready=ready.append)
+        assert ready and ready == sorted(ready, reverse=True)      # the bucketing hook still fires, high offsets first
+        tensors.update(x=x, target=target, sc=sc)
+        return net
+
+    def check(net):
+        x, target, sc = tensors['x'], tensors['target'], tensors['sc']
+        if 'ref' not in tensors:
+            P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+            stats = {}
+            pr = U.unet_forward(x, P, net.prefix, levels, nconv, training=True, collect=stats,
+                                dropout={k: torch.from_numpy(v) for k, v in sc.items()})
+            lr = U.l1_loss(pr, target)
+            lr.backward()
+            tensors['ref'] = (P, stats, pr.detach(), lr.detach())
+        P, stats, pr, lr = tensors['ref']
+        err = (net.test_pred.view(*shape, 1).cpu() - pr).abs().max().item() / pr.abs().max().item()
+        assert err < 5e-4, err
+        assert abs(net.test_loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
+        for nm, _, kind in net.specs:
+            got = net.view(nm, net.grads).cpu().double()
+            ref = P[nm].grad.double()
+            e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            assert e < (2e-3 if kind in ('kernel', 'head_w') else 5e-3), (nm, e)
+
+    net, _ = single_shot_parity(run, check)
+    x, sc = tensors['x'], tensors['sc']
+    stats = tensors['ref'][1]
     # a dropped feature has NO gradient on the input-channel slice of the kernel that consumes it
     for grp in net.enc + net.dec:
         for k in range(1, len(grp['convs'])):

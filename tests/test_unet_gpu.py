@@ -5,7 +5,7 @@ pointwise kernels 1e-5."""
 import numpy as np
 import pytest
 
-from conftest import retry_pool_flips
+from conftest import single_shot_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -222,51 +222,66 @@ def _copy_params(net, torch):
 
 @pytest.mark.parametrize('fold', [False, True])
 @pytest.mark.parametrize('feats,levels,shape,cin', [(24, 3, (16, 16, 32), 2), (8, 2, (8, 12, 16), 1), (24, 5, (32, 32, 32), 2)])
-@retry_pool_flips()
 def test_unet_loss_and_gradients_vs_autograd(T, feats, levels, shape, cin, fold):
+    """one step of the whole network against the oracle under autograd; single shot in deterministic mode, then the default
+    atomics path with any max-pool tie flip identified (conftest.single_shot_parity)"""
     torch = T
     from synthsr_amd.unet import unet
     from oracle import unet_ref as U
-    net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1,
-               feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3,
-               fold_upsample=fold)
-    # make BN affine and biases non-trivial
     g = torch.Generator().manual_seed(11)
-    for nm, v in net.named_parameters():
-        if nm.endswith('/gamma'):
-            v.copy_(torch.rand(v.shape, generator=g) + .5)
-        elif nm.endswith('/beta') or nm.endswith('/bias'):
-            v.copy_(torch.randn(v.shape, generator=g) * .1)
-    net.repack()
-    x = torch.rand(*shape, cin, generator=g)
-    target = torch.rand(*shape, 1, generator=g)
-    loss, pred = net.loss_l1(x.cuda(), target.reshape(-1).cuda(), want_pred=True)
-    pred = pred.clone()
-    net.backward()
-    P = _copy_params(net, torch)
-    stats = {}
-    pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats)
-    lr = U.l1_loss(pr, target)
-    lr.backward()
-    close(pred.view(*shape, 1), pr, 5e-4, 'prediction')
-    assert abs(loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
-    # per-tensor max error relative to the tensor's max-abs, bounded per layer type: conv / head kernels 2e-3 (fp32
-    # accumulation order over up to 4e6 voxels, float atomics); parameters whose gradient is a sum of cancelling terms over
-    # every voxel -- BatchNorm beta / gamma and the biases -- 5e-3.  The failure message lists the worst tensors.
-    errs = {}
-    for nm, _, kind in net.specs:
-        got = net.view(nm, net.grads).cpu().double()
-        ref = P[nm].grad.double()
-        errs[nm] = ((got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12), kind)
-    worst_list = sorted(((e, nm) for nm, (e, _) in errs.items()), reverse=True)[:5]
-    for nm, (err, kind) in errs.items():
-        bound = 2e-3 if kind in ('kernel', 'head_w') else 5e-3
-        assert err < bound, '%s (%s) grad rel err %.3e >= %.0e; worst: %s' % (nm, kind, err, bound, worst_list)
-    # batch statistics
-    for bn in net.bn_layers:
-        o, C = bn['soff'], bn['C']
-        close(net.bn_batch[o:o + C], stats[bn['name']][0], 1e-4, bn['name'] + ' mean')
-        close(net.bn_batch[o + C:o + 2 * C], stats[bn['name']][1], 1e-4, bn['name'] + ' var')
+    tensors = {}
+
+    def run():
+        net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1,
+                   feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3,
+                   fold_upsample=fold)
+        # make BN affine and biases non-trivial
+        g.manual_seed(11)
+        for nm, v in net.named_parameters():
+            if nm.endswith('/gamma'):
+                v.copy_(torch.rand(v.shape, generator=g) + .5)
+            elif nm.endswith('/beta') or nm.endswith('/bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * .1)
+        net.repack()
+        tensors['x'] = torch.rand(*shape, cin, generator=g)
+        tensors['target'] = torch.rand(*shape, 1, generator=g)
+        loss, pred = net.loss_l1(tensors['x'].cuda(), tensors['target'].reshape(-1).cuda(), want_pred=True)
+        net.test_loss, net.test_pred = loss.clone(), pred.clone()
+        net.backward()
+        return net
+
+    def check(net):
+        x, target = tensors['x'], tensors['target']
+        if 'ref' not in tensors:  # the oracle step: once
+            P = _copy_params(net, torch)
+            stats = {}
+            pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats)
+            lr = U.l1_loss(pr, target)
+            lr.backward()
+            tensors['ref'] = (P, stats, pr.detach(), lr.detach())
+        P, stats, pr, lr = tensors['ref']
+        close(net.test_pred.view(*shape, 1), pr, 5e-4, 'prediction')
+        assert abs(net.test_loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
+        # per-tensor max error relative to the tensor's max-abs, bounded per layer type: conv / head kernels 2e-3 (fp32
+        # accumulation order over up to 4e6 voxels); parameters whose gradient is a sum of cancelling terms over
+        # every voxel -- BatchNorm beta / gamma and the biases -- 5e-3.  The failure message lists the worst tensors.
+        errs = {}
+        for nm, _, kind in net.specs:
+            got = net.view(nm, net.grads).cpu().double()
+            ref = P[nm].grad.double()
+            errs[nm] = ((got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12), kind)
+        worst_list = sorted(((e, nm) for nm, (e, _) in errs.items()), reverse=True)[:5]
+        for nm, (err, kind) in errs.items():
+            bound = 2e-3 if kind in ('kernel', 'head_w') else 5e-3
+            assert err < bound, '%s (%s) grad rel err %.3e >= %.0e; worst: %s' % (nm, kind, err, bound, worst_list)
+        # batch statistics
+        for bn in net.bn_layers:
+            o, C = bn['soff'], bn['C']
+            close(net.bn_batch[o:o + C], stats[bn['name']][0], 1e-4, bn['name'] + ' mean')
+            close(net.bn_batch[o + C:o + 2 * C], stats[bn['name']][1], 1e-4, bn['name'] + ' var')
+
+    net, _ = single_shot_parity(run, check)
+    x = tensors['x']
     # one Keras-Adam step
     p0 = net.params.clone()
     g0 = net.grads.clone()
@@ -305,10 +320,11 @@ def test_training_reduces_loss(T):
 
 @pytest.mark.parametrize('fs_header,clip,crop', [(False, False, None), (True, True, None), (True, False, (12, 16, 20)),
                                                  (False, True, (8, 24, 12))])
-@retry_pool_flips()
 def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
     """SynthSR/metrics_model.py:136-215: L1 + w * Dice(frozen segmentation U-Net(prediction), label map).  Loss value and
-    every gradient of the TRAINED network against torch autograd through the oracle (frozen net in inference mode)"""
+    every gradient of the TRAINED network against torch autograd through the oracle (frozen net in inference mode).
+    Single shot in deterministic mode; on the atomics path the pooling choices of BOTH networks are compared
+    (conftest.single_shot_parity)"""
     torch = T
     from synthsr_amd.unet import unet
     from synthsr_amd.seg_loss import SegmentationRegulariser
@@ -317,23 +333,25 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
     gen_labels = np.array([0, 14, 2, 3, 41, 42, 17])
     seg_labels = np.array([0, 2, 3, 4, 41, 42, 43, 17, 53])          # labels the segmentation net predicts
     equivalency = np.array([0, 2, 3, 3, 41, 42, 42, 17, 17])        # ... mapped onto generation-label VALUES (merges)
-    net = unet(24, list(shape) + [2], levels, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
-               final_pred_activation='linear', seed=3)
     segshape = (shape[0], shape[2], shape[1]) if fs_header else shape
-    segnet = unet(24, list(segshape) + [1], levels, 3, len(seg_labels), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
-                  activation='elu', final_pred_activation='softmax', seed=4)
     g = torch.Generator().manual_seed(0)
-    segnet.bn_moving.copy_((torch.rand(segnet.bn_moving.shape, generator=g) * 0.5 + 0.25).to(segnet.device))
+    moving = None
     m, M = (0.1, 0.7) if clip else (None, None)
     w = 0.25
-    reg = SegmentationRegulariser(segnet, gen_labels, equivalency, w, m=m, M=M, fs_header=fs_header)
+
+    def nets():
+        net = unet(24, list(shape) + [2], levels, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
+                   final_pred_activation='linear', seed=3)
+        segnet = unet(24, list(segshape) + [1], levels, 3, len(seg_labels), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
+                      activation='elu', final_pred_activation='softmax', seed=4)
+        return net, segnet
+
+    net, segnet = nets()
+    moving = torch.rand(segnet.bn_moving.shape, generator=g) * 0.5 + 0.25
     x = torch.rand(*shape, 2, generator=g)
     target = torch.rand(*shape, generator=g)
     seg_target = torch.randint(0, len(gen_labels), shape, generator=g, dtype=torch.int32)  # indices, cf. the module docstring
-    # ---- HIP
-    loss, pred = net.loss_l1(x.cuda(), target.cuda().reshape(-1), want_pred=True)
-    dice = reg(pred, seg_target.cuda(), net.dpred, crop)
-    net.backward()
+    segnet.bn_moving.copy_(moving.to(segnet.device))
     # ---- oracle / autograd
     P = {k: v.clone().float().requires_grad_(True) for k, v in net.state_dict().items() if 'moving' not in k}
     Pseg = {k: v.clone().float() for k, v in segnet.state_dict().items()}
@@ -343,22 +361,41 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
                                 fs_header=fs_header, loss_cropping=crop)
     g_dice = torch.autograd.grad(dref, [P[nm] for nm, _, _ in net.specs], retain_graph=True)
     (l1 + w * dref).backward()
-    assert abs(float(loss.detach().item()) - float(l1.detach())) < 1e-5
-    assert abs(float(dice.item()) - float(dref.detach())) < 2e-5, (float(dice.item()), float(dref.detach()))
-    for nm, _, _ in net.specs:
-        close(net.view(nm, net.grads), P[nm].grad, 2e-3, 'grad ' + nm)
-    # the Dice term alone (it is ~1 % of the total gradient here): image-loss gradient zeroed, weight 1
-    reg.rel_weight = 1.0
-    loss, pred = net.loss_l1(x.cuda(), target.cuda().reshape(-1), want_pred=True)
-    net.dpred.zero_()
-    reg(pred, seg_target.cuda(), net.dpred, crop)
-    net.backward()
-    for (nm, _, _), gd in zip(net.specs, g_dice):
-        if nm.endswith('likelihood/bias'):
-            continue  # a sum of cancelling contributions: compared absolutely below
-        close(net.view(nm, net.grads), gd, 3e-3, 'dice-only grad ' + nm)
-    hb = net.view(net.head['b'], net.grads).cpu()
-    assert float((hb - g_dice[-1]).abs().max()) < 1e-5
+    del net, segnet
+
+    def make_run(rel_weight, dice_only):
+        def run():
+            net, segnet = nets()
+            segnet.bn_moving.copy_(moving.to(segnet.device))
+            reg = SegmentationRegulariser(segnet, gen_labels, equivalency, rel_weight, m=m, M=M, fs_header=fs_header)
+            loss, pred = net.loss_l1(x.cuda(), target.cuda().reshape(-1), want_pred=True)
+            if dice_only:  # image-loss gradient zeroed
+                net.dpred.zero_()
+            net.test_loss = loss.clone()
+            net.test_dice = reg(pred, seg_target.cuda(), net.dpred, crop).clone()
+            net.backward()
+            net.test_segnet = segnet
+            return net
+        return run
+
+    def check_total(net):
+        assert abs(float(net.test_loss.item()) - float(l1.detach())) < 1e-5
+        assert abs(float(net.test_dice.item()) - float(dref.detach())) < 2e-5, (float(net.test_dice.item()), float(dref.detach()))
+        for nm, _, _ in net.specs:
+            close(net.view(nm, net.grads), P[nm].grad, 2e-3, 'grad ' + nm)
+
+    def check_dice(net):
+        for (nm, _, _), gd in zip(net.specs, g_dice):
+            if nm.endswith('likelihood/bias'):
+                continue  # a sum of cancelling contributions: compared absolutely below
+            close(net.view(nm, net.grads), gd, 3e-3, 'dice-only grad ' + nm)
+        hb = net.view(net.head['b'], net.grads).cpu()
+        assert float((hb - g_dice[-1]).abs().max()) < 1e-5
+
+    both = lambda net: [net, net.test_segnet]
+    single_shot_parity(make_run(w, False), check_total, pool_nets=both)
+    # the Dice term alone (it is ~1 % of the total gradient here): weight 1
+    single_shot_parity(make_run(1.0, True), check_dice, pool_nets=both, atomics_tol=3e-3)
 
 
 @pytest.mark.gpu
