@@ -156,8 +156,13 @@ def cpu_baseline(size_all=160, size_one=64, timed=3):
         res[tag] = dict(volumes_per_s=round(scale / float(np.mean([t[0] for t in ts])), 5), threads=threads, size=size,
                         step_s=[round(t[0], 2) for t in ts], generator_s=round(float(np.mean([t[1] for t in ts])), 2))
     torch.set_num_threads(nthreads_default)
+    par = [l.strip() for l in torch.__config__.parallel_info().splitlines() if l.strip() and ('threads' in l.lower() or
+           'openmp' in l.lower() or 'mkl' in l.lower() or 'ATen parallel backend' in l)]
+    aff = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
     return {'value': res['all']['volumes_per_s'], 'unit': 'volumes/s', 'cores': res['all']['threads'], 'kind': 'port',
             'threads': res['all']['threads'], 'usable_cpus': usable, 'physical_cores': cores, 'value_one_thread': res['one']['volumes_per_s'],
+            'affinity_mask': aff, 'torch_parallel_info': par,
+            'omp_env': {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'GOMP_CPU_AFFINITY')},
             'sample': 'oracle (numpy generator + PyTorch-CPU U-Net fwd/bwd/Keras-Adam; CPU restatement, NOT TensorFlow): '
                       '1 warm-up + %d timed steps. all usable CPUs (%d threads; the host has %d physical cores, affinity / cgroup quota caps this process): %d^3 volumes, %s s per step '
                       '(generator %.2f s of it). one thread: %d^3 volumes (%.1f%% of the voxels of 160^3, volumes/s scaled '
@@ -184,13 +189,15 @@ def main():
         return cpu_worker(int(sys.argv[2]), int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--size', type=int, default=160)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-size', type=int, default=160, help='volume size of the all-threads CPU baseline')
     ap.add_argument('--overlap', action='store_true', help='weight gradients on a second stream (A/B switch; slower)')
     ap.add_argument('--fold', default='auto', help="nearest-upsample folding of the decoder convs: auto | all | none")
+    ap.add_argument('--log-clocks', action='store_true',
+                    help='sample rocm-smi clocks / power every 2 s during the timed region (sustained runs: --steps 1000)')
     ap.add_argument('--force-allreduce', action='store_true',
                     help='initialise RCCL and run the bucketed gradient all-reduce even at world size 1 (path test)')
     args = ap.parse_args()
@@ -240,25 +247,64 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    if tr.reducer is not None:
+        tr.comm_events = []
+    clocks, stop_clocks = [], None
+    if args.log_clocks and rank == 0:
+        import subprocess
+        import threading
+        stop_clocks = threading.Event()
+
+        def sample():
+            while not stop_clocks.is_set():
+                try:
+                    txt = subprocess.run(['rocm-smi', '-d', str(local), '-c', '-P', '--json'], capture_output=True, text=True,
+                                         timeout=10).stdout
+                    clocks.append((round(time.perf_counter(), 2), json.loads(txt[txt.index('{'):])))
+                except Exception as ex:  # noqa: BLE001 -- the log is a diagnostic
+                    clocks.append((round(time.perf_counter(), 2), repr(ex)))
+                stop_clocks.wait(2.0)
+        threading.Thread(target=sample, daemon=True).start()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     ops.profile_start()
+    # one HIP event per step boundary on the launch stream (= torch's current stream, which every kernel of the step is
+    # launched on): per-step device times without a host sync inside the timed region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     loss = None
+    marks[0].record()
     for i in range(args.steps):
         if i == min(3, args.steps):  # per-launch HIP events on the first 3 timed steps only (0.5 ms of host/event overhead each)
             ops.profile_pause()
         loss = one_step()
+        marks[i + 1].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = ops.profile_stop()
+    if stop_clocks is not None:
+        stop_clocks.set()
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
+    comm_ms = np.array([a.elapsed_time(b) for a, b in (tr.comm_events or [])]) if tr.comm_events else np.zeros(0)
+    dt_rank = dt
+    per_rank = None
     if world > 1:
         tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # every rank's own clock: wall time of the K steps, mean / median step (HIP events) and the time its compute
+        # stream spent waiting for the gradient all-reduce at the end of each backward -- what a scaling loss is made of
+        mine = torch.tensor([dt_rank * 1e3 / args.steps, float(np.mean(step_ms)), float(np.median(step_ms)),
+                             float(np.mean(comm_ms)) if comm_ms.size else 0.0,
+                             float(np.max(comm_ms)) if comm_ms.size else 0.0], device='cuda', dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(rank=r, wall_ms_per_step=round(float(v[0]), 3), step_ms_mean=round(float(v[1]), 3),
+                         step_ms_median=round(float(v[2]), 3), allreduce_wait_ms_mean=round(float(v[3]), 3),
+                         allreduce_wait_ms_max=round(float(v[4]), 3)) for r, v in enumerate(allr)]
     final_loss = float(loss.item())
     if not np.isfinite(final_loss):  # tf.debugging.check_numerics of the reference's IdentityLoss
         raise FloatingPointError('non-finite loss after %d steps: the measurement is invalid' % args.steps)
@@ -292,11 +338,15 @@ def main():
                     'conv_ms_per_step': round(conv_total / min(3, args.steps), 3), 'profiled_steps': min(3, args.steps)}
         # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes (bench.py cannot host the
         # profiler), committed under profiles/pmc_traffic.json; algorithmic bytes = the tensors one launch must touch
+        roofline['traffic_source'] = None
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as f:
-                pmc = json.load(f).get(roofline['kernel'])
+                pmc_all = json.load(f)
+            pmc = pmc_all.get(roofline['kernel'])
             if pmc and S == 160:
                 roofline['traffic'] = pmc['bytes']
+                roofline['traffic_source'] = ('NOT measured in this run: read from profiles/pmc_traffic.json (%s); FETCH_SIZE '
+                                              'doubled for 16-byte loads per the gfx950 note' % pmc_all.get('_source', '?'))
         except (OSError, ValueError):
             pass
         vox = dom['shape'][0] * dom['shape'][1] * dom['shape'][2]
@@ -321,7 +371,16 @@ def main():
                                           'traffic per kernel: profiles/pmc_traffic.json'}
         out = {'metric': 'training volumes/sec (160^3 fp32, 5-level U-Net)', 'value': round(world * args.steps / dt, 4),
                'unit': 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-               'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+               'ms_per_step': round(1e3 * dt / args.steps, 3),
+               # per-step device times of rank 0 (HIP events at the step boundaries; the first `profiled_steps` steps carry the
+               # per-launch events of the roofline measurement): value stays K steps / wall time of the whole region
+               'step_ms': {'mean': round(float(step_ms.mean()), 3), 'median': round(float(np.median(step_ms)), 3),
+                           'min': round(float(step_ms.min()), 3), 'max': round(float(step_ms.max()), 3),
+                           'p95': round(float(np.percentile(step_ms, 95)), 3),
+                           'first_tenth_median': round(float(np.median(step_ms[:max(1, len(step_ms) // 10)])), 3),
+                           'last_tenth_median': round(float(np.median(step_ms[-max(1, len(step_ms) // 10):])), 3)},
+               'value_median_step': round(world * 1e3 / float(np.median(step_ms)), 4),
+               'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': 'configs[1]: brain_generator %d^3 batch=1 (training() defaults) + 5-level 3-D U-Net '
                                       '(24..384 features, Cin=2) fwd/bwd + Adam, fp32, random-init' % S,
@@ -330,6 +389,12 @@ def main():
                'n_ranks_seen': dist.get_world_size() if dist.is_initialized() else 1,
                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if dist.is_initialized() else None,
                'top_kernels': [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]}
+        if per_rank is not None:
+            out['per_rank'] = per_rank
+        elif comm_ms.size:
+            out['allreduce_wait_ms'] = {'mean': round(float(comm_ms.mean()), 3), 'max': round(float(comm_ms.max()), 3)}
+        if clocks:
+            out['clock_log'] = clocks
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.cpu_size)

@@ -222,7 +222,7 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
         dist.broadcast(generator.params, 0)
         dist.broadcast(generator.bn_moving, 0)
         dist.broadcast(critic.params, 0)
-        generator._drop_gen.manual_seed(int(seed) + 0x5eed + 7919 * rank)  # per-rank dropout masks
+        generator.set_dropout_seed(int(seed) + 0x5eed + 7919 * rank)  # per-rank dropout masks
         generator.repack()
         critic.repack()
     trainer = AdversarialTrainer(brain_generator, generator, critic, lr_generator, lr_discriminator, lr_decay,

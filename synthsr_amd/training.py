@@ -92,6 +92,7 @@ class Trainer:
         self.residual = work_with_residual_channel
         self.reducer = GradBucketReducer(net.grads, bucket_elems, force=force_allreduce) if distributed else None
         self.resident_labels = None
+        self.comm_events = None  # a list: (start, end) HIP events around reducer.finish() of every step (bench.py --gpus N)
 
     def _generate_batch(self, model_inputs, draws, B):
         """batchsize > 1 (SynthSR/training.py:52): the B items of the batch are generated one after the other (each with
@@ -135,6 +136,8 @@ class Trainer:
         labels, means, stds = model_inputs[:3]
         from . import ops
         B = int(np.asarray(means).shape[0])
+        if B > 1 and label_index is not None:
+            raise ValueError('label_index (device-resident label pool) picks ONE map: not available with batchsize > 1')
         if B > 1:
             image, target, seg = self._generate_batch(model_inputs, draws, B)
         else:
@@ -159,7 +162,15 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.start()
             net.backward(on_grad_ready=self.reducer.ready)
-            scale = self.reducer.finish()
+            if self.comm_events is not None:  # how long the compute stream waits for the collectives still in flight
+                import torch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                scale = self.reducer.finish()
+                e1.record()
+                self.comm_events.append((e0, e1))
+            else:
+                scale = self.reducer.finish()
         else:
             net.backward()
             scale = 1.0
@@ -274,6 +285,15 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
                                  % len(work_with_residual_channel))
     if regression_metric not in ('l1', 'l2', 'laplace', 'ssim'):
         raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(regression_metric))
+    # combinations this build does not cover are refused HERE, before the dataset, generator and network are built (the
+    # reference has no such restriction, SynthSR/training.py:52)
+    if int(batchsize) > 1:
+        for bad, what in ((segmentation_model_file is not None, 'the segmentation-regularised loss'),
+                          (regression_metric == 'ssim', "regression_metric='ssim'"),
+                          (loss_cropping not in (None, 0), 'loss_cropping'),
+                          (dropout > 0, 'dropout > 0 (per-sample feature masks)')):
+            if bad:
+                raise NotImplementedError('batchsize > 1 together with %s is not supported' % what)
 
     dist_on = 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1
     rank, world = 0, 1
@@ -334,7 +354,7 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
         import torch.distributed as dist
         dist.broadcast(net.params, 0)  # identical initial weights on every rank
         net.repack()
-        net._drop_gen.manual_seed(int(seed) + 0x5eed + 7919 * rank)  # ... but its own dropout masks (as its own samples)
+        net.set_dropout_seed(int(seed) + 0x5eed + 7919 * rank)  # ... but its own dropout masks (as its own samples)
     # frozen segmentation CNN for the segmentation-regularised loss (training.py:371-409)
     seg_reg = None
     if segmentation_model_file is not None:

@@ -45,8 +45,10 @@ class UNet3D:
         self.conv_dropout = float(conv_dropout)
         if not 0.0 <= self.conv_dropout < 1.0:
             raise ValueError('conv_dropout should be in [0, 1)')
+        # the masks of optimizer step t are a function of (dropout seed, t) alone: a run resumed from a checkpoint (which
+        # restores `iterations`) continues the exact mask sequence of an uninterrupted one, on every rank
         self._drop_gen = torch.Generator(device='cpu')
-        self._drop_gen.manual_seed(int(seed) + 0x5eed)
+        self._drop_seed = int(seed) + 0x5eed
         self._drop_next = None      # scales for the next training forward (tests); None: drawn
         self._drop = None           # conv name -> per-channel scale of the step in flight
         self._mult = None
@@ -368,6 +370,9 @@ class UNet3D:
             fn(*parts)
 
     # ------------------------------------------------------------------ feature-wise dropout
+    def set_dropout_seed(self, seed):
+        self._drop_seed = int(seed)
+
     def set_dropout_scales(self, scales):
         """explicit per-channel factors {conv layer name: [Cout] of 0 | 1/(1-rate)} for the NEXT training forward (parity
         tests against the oracle); None: drawn from the network's own generator"""
@@ -375,13 +380,27 @@ class UNet3D:
 
     def _start_dropout(self):
         p = self.conv_dropout
-        drop = {}
-        for c in self.all_convs():
-            if self._drop_next is not None:
-                v = torch.as_tensor(np.asarray(self._drop_next[c['name']], dtype=np.float32))
-            else:  # tf.nn.dropout: keep where uniform >= rate, scale the kept features by 1 / (1 - rate)
-                v = (torch.rand(c['cout'], generator=self._drop_gen) >= p).float() / (1.0 - p)
-            drop[c['name']] = v.to(self.device)
+        convs = list(self.all_convs())
+        total = sum(c['cout'] for c in convs)
+        if getattr(self, '_drop_host', None) is None:  # one pinned staging buffer + one device buffer for all masks
+            self._drop_host = torch.empty(total, dtype=torch.float32).pin_memory()
+            self._drop_dev = torch.empty(total, dtype=torch.float32, device=self.device)
+            self._drop_event = None
+        if self._drop_event is not None:
+            self._drop_event.synchronize()  # the previous step's upload has left the staging buffer
+        if self._drop_next is not None:
+            flat = torch.cat([torch.as_tensor(np.asarray(self._drop_next[c['name']], dtype=np.float32)) for c in convs])
+        else:  # tf.nn.dropout: keep where uniform >= rate, scale the kept features by 1 / (1 - rate); ONE draw for all layers
+            self._drop_gen.manual_seed((self._drop_seed * 1000003 + self.iterations) & 0x7fffffffffffffff)
+            flat = (torch.rand(total, generator=self._drop_gen) >= p).float() / (1.0 - p)
+        self._drop_host.copy_(flat)
+        self._drop_dev.copy_(self._drop_host, non_blocking=True)
+        self._drop_event = torch.cuda.Event()
+        self._drop_event.record()
+        drop, o = {}, 0
+        for c in convs:
+            drop[c['name']] = self._drop_dev[o:o + c['cout']]
+            o += c['cout']
         self._drop_next = None
         self._drop = drop
         if self._mult is None:
@@ -413,6 +432,11 @@ class UNet3D:
         L = self.nb_levels
         self.saved = dict(x=[], enc=[], cat=[], dec=[])
         dropping = self.training and self.conv_dropout > 0
+        if dropping and self.batch > 1:
+            # KL.Dropout(noise_shape=[None, 1, 1, 1, C]) draws one mask PER SAMPLE of the batch (ext/neuron/models.py:320-324);
+            # the per-feature factors here ride on the shared conv kernels and on the BatchNorm of the whole stack, which
+            # can only express ONE mask per step: refuse rather than train with a different regularisation
+            raise NotImplementedError('conv_dropout > 0 with batchsize > 1 (per-sample feature masks) is not supported')
         if dropping:
             self._start_dropout()
         else:

@@ -1,6 +1,7 @@
-"""Worker of tests/test_ddp_gpu.py: one rank of a 2-rank data-parallel Trainer.step (both ranks share cuda:0 on the
-one-GPU test box; `gloo` carries the collectives so that two processes on one device can talk -- on a multi-GPU node
-the same code path runs over RCCL, cf. bench.py).  Saves, per rank, the single-rank gradient of ITS sample, then the
+"""Worker of tests/test_ddp_gpu.py: one rank of a 2-rank data-parallel Trainer.step.  On a box with at least as many GPUs as
+ranks every rank takes its own GPU and the collectives run over RCCL (backend `nccl`) -- the production path; on the
+one-GPU test box both ranks share cuda:0 and `gloo` carries the collectives (two processes on one device cannot form an
+RCCL communicator).  The choice is automatic (`_init`) and recorded in the output files.  Saves, per rank, the single-rank gradient of ITS sample, then the
 all-reduced gradient sum and the weights after the distributed step."""
 import os
 import sys
@@ -10,14 +11,27 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
+def _init():
+    """backend / device of this rank: RCCL with one GPU per rank whenever the box has enough GPUs, else gloo on cuda:0"""
+    import torch
+    import torch.distributed as dist
+    world, local = int(os.environ['WORLD_SIZE']), int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.device_count() >= world and os.environ.get('SYNTHSR_TEST_BACKEND', '') != 'gloo':
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        return 'nccl'
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo')
+    return 'gloo'
+
+
 def adversarial(out_dir):
     """fine_tuning_with_adversary.training() data-parallel on 2 ranks (gloo, both on cuda:0)"""
     import torch
     import torch.distributed as dist
     from synthsr_amd.fine_tuning_with_adversary import training
     rank = int(os.environ['RANK'])
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo')
+    backend = _init()
     gen, critic = training(os.path.join(out_dir, 'labels'), os.path.join(out_dir, 'images'), os.path.join(out_dir, 'models'),
                            None, None, os.path.join(out_dir, 'gl.npy'), output_shape=32, n_levels=3,
                            nonlin_shape_factor=.125, bias_shape_factor=.125, epochs=1, steps_per_epoch=2,
@@ -25,7 +39,7 @@ def adversarial(out_dir):
                            verbose=False)
     np.savez(os.path.join(out_dir, 'adv_rank%d.npz' % rank), gen=gen.params.detach().cpu().numpy(),
              critic=critic.params.detach().cpu().numpy(), gen_iter=gen.iterations, critic_iter=critic.iterations,
-             bn=gen.bn_moving.detach().cpu().numpy())
+             bn=gen.bn_moving.detach().cpu().numpy(), backend=backend)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -42,8 +56,7 @@ def main():
     from synthsr_amd.synthetic import (synthetic_label_pool, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
                                        PRIOR_STDS_T1_HR)
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo')
+    backend = _init()
     S = 32
     pool = synthetic_label_pool(2, (S, S, S), 5)
     bg = BrainGenerator(None, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', GENERATION_LABELS,
@@ -72,7 +85,7 @@ def main():
     n_buckets = getattr(tr.reducer, 'n_launched', -1)
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), g_solo=g_solo, g_sum=net.grads.detach().cpu().numpy(), w0=w0,
              w1=net.params.detach().cpu().numpy(), loss=float(loss.item()), n_buckets=n_buckets,
-             adam_m=net.adam_m.detach().cpu().numpy())
+             adam_m=net.adam_m.detach().cpu().numpy(), backend=backend)
     dist.barrier()
     dist.destroy_process_group()
 

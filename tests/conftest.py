@@ -100,6 +100,37 @@ def random_tape(m, rng):
     return t
 
 
+def tape_from_draws(m, d, gmm_noise):
+    """the tape (reference call order) equivalent to a Draws object `d` of model `m`; `gmm_noise` [ncrop * C] stands in
+    for the in-kernel Philox stream (oracle.philox_ref.normals of d.philox_key / d.philox_offset)"""
+    f = lambda a: np.asarray(a, dtype=np.float32).reshape(-1)
+    t = []
+    for kind, v in (('u', d.u_rot), ('u', d.u_shear), ('u', d.u_scale), ('u', d.u_trans)):
+        if v is not None:
+            t.append((kind, f(v)))
+    if m.apply_elastic:
+        t += [('u', f(d.u_svf_std)), ('n', f(d.n_svf))]
+    if m.crop_shape != m.labels_shape:
+        t.append(('u', f(d.u_crop)))
+    if m.flipping:
+        t.append(('u', f(d.u_flip)))
+    t.append(('n', f(gmm_noise)))
+    for i in range(m.n_channels):
+        c = d.channels[i]
+        if 'u_bias_std' in c:
+            t += [('u', f(c['u_bias_std'])), ('n', f(c['n_bias'])), ('u', f(c['u_bias_gate']))]
+        t.append(('n', f(c['n_gamma'])))
+        if 'u_regT' in c:
+            t += [('u', f(c['u_regT'][0])), ('u', f(c['u_regT'][1]))]
+        if 'u_rr' in c:
+            t += [('u', f(v)) for v in c['u_rr']]
+        if 'u_blur' in c:
+            t.append(('u', f(c['u_blur'])))
+        if 'u_regE' in c:
+            t += [('u', f(c['u_regE'][0])), ('u', f(c['u_regE'][1]))]
+    return t
+
+
 def _pool_choices(net):
     """the device's OWN arg-max choice of every 2x2x2 max-pool of the step in flight: bn_maxpool_bwd routes a gradient of ones
     to the winner of each window, so the non-zeros of its output ARE the arg-max mask the backward pass used.  Returns

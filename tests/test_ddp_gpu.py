@@ -2,8 +2,9 @@
 single-rank gradients in the flat buffer (the optimizer applies 1/world), identical gradients on both ranks, and
 bit-identical weights afterwards -- starting from deliberately different initial weights that the rank-0 broadcast
 must override.  The hook offsets that `unet._backward_body` hands to GradBucketReducer are exercised with several
-buckets in flight.  Both ranks run on cuda:0 (one-GPU box), collectives over gloo; the RCCL flavour of the same path is
-covered by test_training_gpu.py::test_bench_under_torchrun_with_forced_allreduce and bench.py --gpus N."""
+buckets in flight.  On a box with >= 2 GPUs each rank takes its own GPU and the collectives run over RCCL; on the one-GPU
+test box both ranks share cuda:0 and gloo carries them (tests/_ddp_worker.py: _init picks automatically; the backend used
+is printed).  RCCL at world size 1: test_training_gpu.py::test_bench_under_torchrun_with_forced_allreduce."""
 import os
 import subprocess
 import sys
@@ -21,6 +22,7 @@ def test_two_rank_trainer_step_averages_gradients_and_keeps_weights_identical(tm
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     a, b = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+    print('collectives over', str(a['backend']))
     np.testing.assert_array_equal(a['w0'], b['w0'])                     # broadcast from rank 0
     np.testing.assert_array_equal(a['g_sum'], b['g_sum'])               # same reduced gradients everywhere
     np.testing.assert_array_equal(a['w1'], b['w1'])                     # ... hence bit-identical weights after Adam

@@ -338,3 +338,13 @@ def test_multi_modality_affine_bounds_pick_one_block_at_build_time():
     assert T.shape == (4, 4) and abs(np.linalg.det(T[:3, :3]) - 1) < 1e-5
     with pytest.raises(AssertionError):
         hm.pick_bounds_block(np.zeros((3, 3)))
+
+
+@pytest.mark.parametrize('extra', [dict(dropout=.2), dict(regression_metric='ssim'), dict(loss_cropping=16),
+                                   dict(segmentation_model_file='seg.h5')])
+def test_training_refuses_unsupported_batch_combinations_up_front(extra):
+    """batchsize > 1 together with dropout / SSIM / loss_cropping / the segmentation loss is refused at the top of
+    training(), before any dataset, generator or network is built (no GPU, no file access needed to get the error)"""
+    from synthsr_amd.training import training
+    with pytest.raises(NotImplementedError, match='batchsize > 1'):
+        training('/nonexistent/labels', '/nonexistent/models', None, None, '/nonexistent/gl.npy', batchsize=2, **extra)

@@ -83,6 +83,70 @@ def test_brain_generator_generate_brain(tmp_path):
     assert set(np.unique(np.round(im2[..., 1], 6)).tolist()) != {1.0}  # channel 0 is down-sampled in z: sparse map
 
 
+def test_generate_brain_native_orientation_vs_oracle(tmp_path):
+    """H19 (SynthSR/brain_generator.py:317-330): label maps stored in a NON-RAS orientation (axes permuted and two of them
+    reversed).  The generator works in the RAS frame and generate_brain() re-orients every item back to the native frame of
+    the label maps (`align_volume_to_ref(aff_ref=self.aff)`).  Checked end to end against the oracle: the same host draws
+    (the model's numpy Philox stream replayed) and the in-kernel noise stream (oracle/philox_ref) go into
+    oracle.generator_ref.labels_to_image on the RAS label map; its outputs are brought to the native frame by EXPLICIT index
+    arithmetic written out for this affine (not by the product's align_volume_to_ref).  Also .mgz: the same volume stored as
+    MGZ goes through the same path."""
+    from conftest import tape_from_draws
+    from oracle import generator_ref as R
+    from oracle import philox_ref
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.mgh import write_mgh
+    from synthsr_amd.model_inputs import build_model_inputs
+    from synthsr_amd.nifti import write_nifti
+    from synthsr_amd.synthetic import GENERATION_LABELS, GENERATION_CLASSES, synthetic_label_map
+    ras_shape = (40, 36, 48)
+    lab_ras = synthetic_label_map(ras_shape, 21)
+    nx, ny, nz = ras_shape
+    # native voxel (i, j, k) sits at world (x, y, z) = (nx-1-k, i, nz-1-j): native axis 0 runs along +y (A), axis 1 along -z
+    # (I), axis 2 along -x (L)  =>  N[i, j, k] = R[nx-1-k, i, nz-1-j]
+    to_native = lambda r: np.ascontiguousarray(np.moveaxis(r, (0, 1, 2), (2, 0, 1))[:, ::-1, ::-1])
+    native = to_native(lab_ras)
+    assert native.shape == (ny, nz, nx) and native[3, 5, 7] == lab_ras[nx - 1 - 7, 3, nz - 1 - 5]
+    aff = np.array([[0., 0., -1., nx - 1.], [1., 0., 0., 0.], [0., -1., 0., nz - 1.], [0., 0., 0., 1.]])
+    kw = dict(output_shape=[32, 24, 40], output_div_by_n=8, build_reliability_maps=True, bias_shape_factor=.125,
+              nonlin_shape_factor=.125, generation_classes=GENERATION_CLASSES)
+    out = {}
+    for ext in ('nii.gz', 'mgz'):
+        d = tmp_path / ('labels_' + ext.replace('.', '_'))
+        d.mkdir()
+        path = str(d / ('brain_labels.' + ext))
+        if ext == 'mgz':
+            write_mgh(path, native.astype(np.int32), aff)
+        else:
+            write_nifti(path, native.astype(np.float32), aff)
+        bg = BrainGenerator(str(d), None, None, 'uniform', GENERATION_LABELS, rng=np.random.default_rng(3), **kw)
+        assert bg.labels_shape == list(ras_shape) and np.allclose(bg.aff, aff) and bg.n_dims == 3
+        m = bg.labels_to_image_model
+        m.seed(11)
+        dr = m.sample_draws()
+        m.seed(11)                                   # generate_brain() will draw exactly `dr` again
+        twin = build_model_inputs([path], len(GENERATION_LABELS), None, None, 'uniform', n_channels=1,
+                                  generation_classes=GENERATION_CLASSES, rng=np.random.default_rng(3))
+        labels_in, means, stds = next(twin)
+        assert np.array_equal(labels_in[0, ..., 0], lab_ras)      # loading re-oriented the stored map to RAS
+        image, target = bg.generate_brain()
+        out[ext] = (image, target)
+        if ext == 'mgz':
+            continue
+        noise = philox_ref.normals(m.ncrop, 1, dr.philox_key, dr.philox_offset)
+        ref = R.labels_to_image(lab_ras, means[0], stds[0], tape_from_draws(m, dr, noise), GENERATION_LABELS,
+                                len(GENERATION_LABELS), input_channels=[True], output_channel=[0], output_shape=[32, 24, 40],
+                                output_div_by_n=8, build_reliability_maps=True, bias_shape_factor=.125,
+                                nonlin_shape_factor=.125, translation_bounds=5)
+        want_image, want_target = to_native(ref['image']), to_native(ref['target'])[..., 0]
+        assert image.shape == want_image.shape == (24, 40, 32, 2) and target.shape == (24, 40, 32)
+        assert np.abs(image - want_image).max() < 3e-5, np.abs(image - want_image).max()
+        assert np.abs(target - want_target).max() < 3e-5, np.abs(target - want_target).max()
+        assert np.abs(image - ref['image'].transpose(1, 2, 0, 3)).max() > 1e-2   # the flips matter: a bare transpose is wrong
+    # the MGZ copy of the same map (different container, same geometry) generates the same sample
+    assert np.array_equal(out['mgz'][0], out['nii.gz'][0]) and np.array_equal(out['mgz'][1], out['nii.gz'][1])
+
+
 def test_real_image_targets_images_dir(tmp_path):
     """images_dir: BrainGenerator / training() with real scans as regression targets"""
     from synthsr_amd.brain_generator import BrainGenerator
