@@ -1,10 +1,15 @@
-/* Development hooks of libsynthsr_hip.so -- NOT part of the drop-in boundary (include/synthsr_hip.h).
+/* Process-wide switches of libsynthsr_hip.so -- NOT part of the drop-in boundary (include/synthsr_hip.h).
  *
  * The boundary contract is stateless and re-entrant: every entry point of synthsr_hip.h depends only on its
- * arguments.  The one exception is kept out of that header on purpose: a PROCESS-WIDE A/B switch that the profiling
- * scripts under tools/ (ab.py, conv_ablate.py, persist_check.py, ...) use to time kernel variants against each other.
- * Nothing in synthsr_amd/, scripts/ or bench.py calls it; it is not thread-safe; options that change the launch geometry
- * must be set before weights are packed (a packed weight set is only valid for the plan it was packed under). */
+ * arguments.  The two exceptions are kept out of that header on purpose:
+ *  - synthsr_conv3d_set_option: an A/B switch that the profiling scripts under tools/ (ab.py, conv_ablate.py, ...) use to
+ *    time kernel variants against each other.  Nothing in synthsr_amd/, scripts/ or bench.py calls it.
+ *  - synthsr_set_deterministic: called by synthsr_amd.ops.set_deterministic, training(deterministic=True) and the parity
+ *    tests.  Its state (a device block holding scratch for ordered reductions, installed in every translation unit's
+ *    g_syn_det symbol) is per PROCESS and per CURRENT DEVICE and assumes ONE stream: every network, critic and predictor
+ *    of the process is switched together, and kernels of two streams must not overlap while it is on.
+ * Neither is thread-safe; options that change the launch geometry must be set before weights are packed (a packed weight
+ * set is only valid for the plan it was packed under). */
 #ifndef SYNTHSR_HIP_TUNING_H
 #define SYNTHSR_HIP_TUNING_H
 #ifdef __cplusplus
@@ -17,12 +22,15 @@ extern "C" {
  * that change the launch geometry must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
 
-/* Deterministic mode (process-wide, single stream; synchronises the device).  on = 1: every cross-workgroup float
- * accumulation (weight / bias / BatchNorm gradients, BatchNorm statistics, losses, the critic's dense layers) is flushed in
- * workgroup-id order instead of arrival order, in-workgroup LDS float atomics are replaced by ordered sums, and the split-K /
- * parity-split forward variants (partial sums meeting in atomics) are not selected: the same inputs give bit-identical
- * results run after run.  Slower (flushes are serialised); the default (0) keeps plain atomics.  Not covered: channel counts
- * C with 384 % (C / 4) != 0 and the Dice sums of the segmentation-regularised loss (data-indexed LDS atomics).
+/* Deterministic mode (process-wide, per current device, single stream; synchronises the device).  on = 1: every
+ * cross-workgroup float accumulation is performed in a fixed order -- small partials (channel sums, BatchNorm statistics,
+ * losses, the critic's dense outputs) are parked per workgroup and added up in workgroup-id order by the workgroup that
+ * arrives last; weight gradients go to one private copy of dW per workgroup column which a second kernel sums in column
+ * order (no serialisation: ~1.1x the default step time at 160^3); in-workgroup LDS float atomics are replaced by ordered
+ * sums, and the split-K / parity-split forward variants (partial sums meeting in atomics) are not selected: the same
+ * inputs give bit-identical results run after run.  The default (0) keeps plain atomics.  Not covered: channel counts
+ * C with 384 % (C / 4) != 0 and the Dice sums of the segmentation-regularised loss (data-indexed LDS atomics).  An
+ * allocation failure leaves the mode off and nothing half-installed.
  * Reference: SURVEY.md section 5 (determinism); the reference itself relies on TF's non-deterministic GPU reductions. */
 int synthsr_set_deterministic(int on);
 /* 0 = off, 1 = on and every ordered wait completed, 2 = on but a wait timed out (results may be unordered), -1 = error */

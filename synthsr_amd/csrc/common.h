@@ -132,6 +132,19 @@ __device__ __forceinline__ void syn_det_gather_end(int n) {
     syn_turn_end(&d->chain[SYN_DET_CHAINS - 1], syn_wg_linear(), syn_wg_count());
 }
 
+// host side of the deterministic WEIGHT-GRADIENT flush (conv3d.hip: det_prepare / det_finish): private planes per workgroup
+// column + an ordered reduction; shared by the fp32 and the bf16 weight-gradient launchers
+struct DetRun {
+  float* planes = nullptr;
+  float* dw = nullptr;
+  float* dbias = nullptr;
+  int64_t dw_elems = 0, stride = 0;
+  int cout = 0, gx = 0;
+};
+extern "C" int syn_det_enabled();
+extern "C" int syn_det_prepare(DetRun* d, float** dw, float** dbias, int64_t dw_elems, int cout, int gx, hipStream_t st);
+extern "C" int syn_det_finish(const DetRun* d, hipStream_t st);
+
 #define SYN_DET_SETTER(name)                                                                              \
   extern "C" __attribute__((visibility("hidden"))) int syn_det_set_##name(SynDet* p) {                   \
     return hipMemcpyToSymbol(HIP_SYMBOL(g_syn_det), &p, sizeof(p)) == hipSuccess ? 0 : 1;                 \

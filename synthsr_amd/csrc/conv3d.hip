@@ -1733,6 +1733,8 @@ struct WgExt {
   int64_t dwstride;
   int dbg;         // timing experiments: 8 = skip the flush
   float* dbias;    // optional: += sum over voxels of dout (a constant-1 GEMM row), else nullptr
+  int64_t det_stride;  // deterministic mode: dw / dbias point at per-workgroup-column planes, plane blockIdx.x = + det_stride
+                       // floats (0 otherwise: every workgroup adds into the one dw); see det_prepare / det_finish
 };
 
 template <int CK, int NT, int MS, int NTAPS>
@@ -1929,8 +1931,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
     }
   }
 
-  // ---- flush: D row = (lane>>4)*4 + reg -> (tap, ci), col = lane&15 -> co
-  int* turn = syn_turn_begin_x();
+  // ---- flush: D row = (lane>>4)*4 + reg -> (tap, ci), col = lane&15 -> co.  Every address is touched by ONE lane of the
+  // workgroup; deterministic mode gives each workgroup column (blockIdx.x) its own plane (det_stride), summed in order later
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
 #pragma unroll
@@ -1942,7 +1944,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
       const int tap = nth_tap(ti);
       const int ci = cc * CK + cil;
       if (ci >= Cin) continue;
-      float* dwp = dw + (size_t)par * ext.dwstride;
+      float* dwp = dw + (size_t)par * ext.dwstride + (size_t)blockIdx.x * ext.det_stride;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = co0 + n * 16 + li;
@@ -1950,7 +1952,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float* __res
       }
     }
   }
-  syn_turn_end_x(turn);
 }
 
 // ---- VALU-lean weight gradient (CK = 24, Cout % 4 == 0, tensors < 2 GiB).  Same tiling and LDS layout as
@@ -2150,7 +2151,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
 
   // ---- flush: D row = (lane>>4)*4 + reg -> (tap, ci), col = lane&15 -> co
   if (ext.dbg & 8) return;
-  int* turn = syn_turn_begin_x();
+  const size_t detoff = (size_t)blockIdx.x * ext.det_stride;  // deterministic mode: this workgroup column's own plane
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
 #pragma unroll
@@ -2161,7 +2162,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int co = co0 + n * 16 + li;
-          if (co < Cout) atomicAdd(&ext.dbias[co], acc[m][n][r]);
+          if (co < Cout) atomicAdd(&ext.dbias[detoff + co], acc[m][n][r]);
         }
       }
       if (row >= MR) continue;
@@ -2169,7 +2170,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
       const int tap = nth_tap(ti);
       const int ci = cc * CK + cil;
       if (ci >= Cin) continue;
-      float* dwp = dw + (size_t)par * ext.dwstride;
+      float* dwp = dw + (size_t)par * ext.dwstride + detoff;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = co0 + n * 16 + li;
@@ -2177,7 +2178,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lean_kernel(const float* 
       }
     }
   }
-  syn_turn_end_x(turn);
 }
 
 // ---- weight gradient with small box tiles for the deep levels (40^3: 4x4x8 voxels, 20^3: 4x4x4) ---------------------
@@ -2347,7 +2347,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_box_kernel(const float* _
     }
   }
   if (ext.dbg & 8) return;
-  int* turn = syn_turn_begin_x();
+  const size_t detoff = (size_t)blockIdx.x * ext.det_stride;  // deterministic mode: this workgroup column's own plane
 #pragma unroll
   for (int m = 0; m < MTW; ++m) {
 #pragma unroll
@@ -2358,7 +2358,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_box_kernel(const float* _
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int co = co0 + n * 16 + li;
-          if (co < Cout) atomicAdd(&ext.dbias[co], acc[m][n][r]);
+          if (co < Cout) atomicAdd(&ext.dbias[detoff + co], acc[m][n][r]);
         }
       }
       if (row >= MR) continue;
@@ -2368,11 +2368,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_box_kernel(const float* _
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = co0 + n * 16 + li;
-        if (co < Cout) atomicAdd(&dw[((size_t)tap * ext.cin_total + ext.ci_off + ci) * Cout + co], acc[m][n][r]);
+        if (co < Cout) atomicAdd(&dw[detoff + ((size_t)tap * ext.cin_total + ext.ci_off + ci) * Cout + co], acc[m][n][r]);
       }
     }
   }
-  syn_turn_end_x(turn);
 }
 
 // ---- first-layer weight gradient (Cin <= 2, Cout = 24) on the 4x4x1 MFMA -------------------------------------------
@@ -2553,7 +2552,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
                                                                     const float* __restrict__ dout,
                                                                     float* __restrict__ dwc, int D0, int D1, int D2,
                                                                     int Cin, int tiles1, int tiles2, int ntiles,
-                                                                    int64_t dwstride, int dbg) {
+                                                                    int64_t dwstride, int dbg, int64_t det_stride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CK = 24, MT = 4, Cout = 24;
   constexpr int FT1 = MT, FH1 = MT + 2, CKP = CK + 4, C4 = CK / 4, NQ = 3;
@@ -2710,7 +2709,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
   if (dbg & 8) return;
   // ---- flush, one wave (= one parity) at a time through LDS: its [8 taps][24 ci][24 co] partial is laid out linearly so
   // that every global atomic instruction covers 64 consecutive floats
-  int* turn = syn_turn_begin_x();
+  dwc += (size_t)blockIdx.x * det_stride;  // deterministic mode: this workgroup column's own plane (0 otherwise)
   for (int w = 0; w < 4; ++w) {
     __syncthreads();
     if (wave == w) {
@@ -2732,7 +2731,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_wgrad_p4_kernel(const float*
       atomicAdd(dst + ((size_t)tap * Cin + cc * CK) * Cout + r, lds[e]);
     }
   }
-  syn_turn_end_x(turn);
 }
 
 // dbias fallback for the generic weight-gradient kernel: per-channel sum of dout [n][C]
@@ -3140,9 +3138,72 @@ int dispatch_fwd(const float* in, const float* wp, const float* bias, float* out
   return SYNTHSR_EINVAL;
 }
 
+// ---- deterministic weight gradients: private planes + ordered reduction ------------------------------------------------
+// Every weight-gradient kernel accumulates, per workgroup, a partial dW whose addresses are each touched by exactly ONE lane
+// of the workgroup; what differs from run to run in the default mode is only the order in which the workgroups' atomic adds
+// land on the shared dW.  Deterministic mode (synthsr_set_deterministic) gives every workgroup COLUMN (blockIdx.x = the voxel
+// split; the other grid dimensions split dW itself) its own zeroed copy of dW (+ dbias) -- "plane" x -- and a second kernel
+// adds the planes up in x order.  No serialisation: the chained-ticket flush this replaces cost ~3 us per hand-over,
+// 98 instead of 29 ms per 160^3 step; the planes cost one memset + one read of gx * |dW| floats per launch.
+static float* g_det_planes = nullptr;
+static size_t g_det_planes_floats = 0;
+static float* det_planes(size_t floats) {
+  if (floats > g_det_planes_floats) {
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;  // the old buffer may still be read by a queued reduction
+    if (g_det_planes) (void)hipFree(g_det_planes);
+    g_det_planes = nullptr;
+    g_det_planes_floats = 0;
+    const size_t want = std::max(floats + floats / 4, (size_t)16 << 20);
+    if (hipMalloc(reinterpret_cast<void**>(&g_det_planes), want * sizeof(float)) != hipSuccess) {
+      g_det_planes = nullptr;
+      return nullptr;
+    }
+    g_det_planes_floats = want;
+  }
+  return g_det_planes;
+}
+__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ planes, int64_t stride, int gx,
+                                                         float* __restrict__ dw, int64_t dw_elems,
+                                                         float* __restrict__ dbias, int cout) {
+  const int64_t n = dw_elems + (dbias ? cout : 0);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int x = 0; x < gx; ++x) t += planes[(int64_t)x * stride + i];  // fixed order
+    if (i < dw_elems) dw[i] += t;
+    else dbias[i - dw_elems] += t;
+  }
+}
+// before the launch: redirects dw / dbias to the planes (no-op unless deterministic mode is on)
+static int det_prepare_impl(DetRun* d, float** dw, float** dbias, int64_t dw_elems, int cout, int gx, hipStream_t st) {
+  d->stride = 0;
+  if (!g_det) return SYNTHSR_OK;
+  d->dw = *dw;
+  d->dbias = *dbias;
+  d->dw_elems = dw_elems;
+  d->cout = cout;
+  d->gx = gx;
+  d->stride = (dw_elems + cout + 3) / 4 * 4;
+  d->planes = det_planes((size_t)gx * (size_t)d->stride);
+  if (!d->planes) return SYNTHSR_ELAUNCH;
+  if (hipMemsetAsync(d->planes, 0, (size_t)gx * (size_t)d->stride * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
+  *dw = d->planes;
+  if (*dbias) *dbias = d->planes + dw_elems;
+  return SYNTHSR_OK;
+}
+static int det_finish_impl(const DetRun* d, hipStream_t st) {
+  if (!d->stride) return SYNTHSR_OK;
+  const int64_t n = d->dw_elems + (d->dbias ? d->cout : 0);
+  hipLaunchKernelGGL(det_reduce_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, st, d->planes, d->stride, d->gx, d->dw,
+                     d->dw_elems, d->dbias, d->cout);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
 template <int CK, int NT, int MS, int NTAPS>
 int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], int Cin, int Cout, hipStream_t st,
-                 const WgExt& ext) {
+                 const WgExt& ext0) {
+  WgExt ext = ext0;
+  DetRun det;
+  const int64_t dw_elems = (NTAPS == 8) ? 8 * ext.dwstride : (int64_t)27 * ext.cin_total * Cout;
   const int tiles0 = cdiv(s[0], WT0), tiles1 = cdiv(s[1], WT1), tiles2 = cdiv(s[2], WT2);
   const int ntiles = tiles0 * tiles1 * tiles2;
   const int ncc = cdiv(Cin, CK), nco = cdiv(Cout, NT * 16);
@@ -3169,6 +3230,8 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
         const int hv = 6 * 6 * (tx + 2), tv = 16 * tx;
         const int vpx = hv + ((hv / 2) % 2 == 0 ? 2 : 0) + (hv % 2);
         const size_t bsmem = ((size_t)(CK + 1) * vpx + (size_t)NT * 16 * (tv + 2)) * sizeof(float);
+        if (syn_det_prepare(&det, &dw, &ext.dbias, dw_elems, Cout, bgx, st) != SYNTHSR_OK) return SYNTHSR_ELAUNCH;
+        ext.det_stride = det.stride;
         if (x8) {
           hipLaunchKernelGGL((conv3d_wgrad_box_kernel<NT, MS, 4, 4, 8>), dim3(bgx, ncc * ymul, nco), dim3(256), bsmem, st, in,
                              dout, dw, s[0], s[1], s[2], Cin, Cout, bt0, bt1, bt2, ext);
@@ -3176,7 +3239,8 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
           hipLaunchKernelGGL((conv3d_wgrad_box_kernel<NT, MS, 4, 4, 4>), dim3(bgx, ncc * ymul, nco), dim3(256), bsmem, st, in,
                              dout, dw, s[0], s[1], s[2], Cin, Cout, bt0, bt1, bt2, ext);
         }
-        return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+        if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+        return syn_det_finish(&det, st);
       }
     }
     if ((Cout % 4) == 0 && xbytes < (1ll << 31) && dbytes < (1ll << 31) && !(g_dbg & 16)) {
@@ -3187,9 +3251,12 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
                                   (int)smem);
         lean_attr_done = true;
       }
+      if (syn_det_prepare(&det, &dw, &ext.dbias, dw_elems, Cout, gx, st) != SYNTHSR_OK) return SYNTHSR_ELAUNCH;
+      ext.det_stride = det.stride;
       hipLaunchKernelGGL(lkern, dim3(gx, ncc * ymul, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout,
                          tiles0, tiles1, tiles2, ext);
-      return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+      if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+      return syn_det_finish(&det, st);
     }
   }
   static bool attr_done = false;
@@ -3202,9 +3269,13 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
     hipLaunchKernelGGL(colsum_kernel, dim3(1024), dim3(256), 0, st, dout, (int64_t)s[0] * s[1] * s[2], Cout, ext.dbias);
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   }
+  float* no_dbias = nullptr;
+  if (syn_det_prepare(&det, &dw, &no_dbias, dw_elems, Cout, gx, st) != SYNTHSR_OK) return SYNTHSR_ELAUNCH;
+  ext.det_stride = det.stride;
   hipLaunchKernelGGL(kern, dim3(gx, ncc * ymul, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout,
                      tiles0, tiles1, tiles2, ext);
-  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  return syn_det_finish(&det, st);
 }
 
 // ---- weight gradient of a 24-input-channel chunk with Cout = 24 on the 4x4x1 MFMA ----------------------------------
@@ -3221,7 +3292,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_p4_kernel(const float* __
                                                                  const float* __restrict__ dout, float* __restrict__ dw,
                                                                  int D0, int D1, int D2, int Cin, int tiles1, int tiles2,
                                                                  int ntiles, int cin_total, int ci_off, int dbg,
-                                                                 float* __restrict__ dbias) {
+                                                                 float* __restrict__ dbias, int64_t det_stride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CK = 24, MT = 4, Cout = 24;
   constexpr int FT1 = MT, FH1 = MT + 2, CKP = CK + 4, C4 = CK / 4;
@@ -3395,13 +3466,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_p4_kernel(const float* __
     for (int g = 0; g < 6; ++g) *reinterpret_cast<float4*>(d + 4 * g) = make_float4(acc[q][g][0], acc[q][g][1], acc[q][g][2], acc[q][g][3]);
   }
   __syncthreads();
-  int* turn = syn_turn_begin_x();
+  const size_t detoff = (size_t)blockIdx.x * det_stride;  // deterministic mode: this workgroup column's own plane (0 otherwise)
   for (int e = tid; e < 27 * CK * Cout; e += 256) {
     const int tap = e / (CK * Cout), r = e - tap * (CK * Cout);
-    atomicAdd(dw + ((size_t)tap * cin_total + ci_off + cc * CK) * Cout + r, lds[e]);
+    atomicAdd(dw + detoff + ((size_t)tap * cin_total + ci_off + cc * CK) * Cout + r, lds[e]);
   }
-  if (dbias && cc == 0 && tid < Cout) atomicAdd(dbias + tid, lds[NBLK * 4 * Cout + tid]);
-  syn_turn_end_x(turn);
+  if (dbias && cc == 0 && tid < Cout) atomicAdd(dbias + detoff + tid, lds[NBLK * 4 * Cout + tid]);
 }
 
 int launch_wgrad_c2(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int Cin, hipStream_t st,
@@ -3443,9 +3513,13 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
       }
       int gx = std::max(8, ((512 / (ncc * 2)) / 8) * 8);  // each workgroup carries 4 of the 8 parities (one per wave)
       while (gx > 8 && gx > ntiles) gx -= 8;
+      DetRun det;
+      float* no_dbias = nullptr;
+      if (syn_det_prepare(&det, &dw, &no_dbias, 8 * ext.dwstride, Cout, gx, st) != SYNTHSR_OK) return SYNTHSR_ELAUNCH;
       hipLaunchKernelGGL(conv3d_up_wgrad_p4_kernel, dim3(gx, ncc * 2), dim3(256), smem, st, in, dout, dw, shape[0], shape[1],
-                         shape[2], Cin, tiles1, tiles2, ntiles, ext.dwstride, ext.dbg);
-      return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+                         shape[2], Cin, tiles1, tiles2, ntiles, ext.dwstride, ext.dbg, det.stride);
+      if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+      return syn_det_finish(&det, st);
     }
   }
   if constexpr (NTAPS == 27) {
@@ -3467,9 +3541,14 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
       }
       int gx = std::max(8, ((512 / ncc) / 8) * 8);
       while (gx > 8 && gx > ntiles) gx -= 8;
+      DetRun det;
+      float* dbias = ext.dbias;
+      if (syn_det_prepare(&det, &dw, &dbias, (int64_t)27 * ext.cin_total * Cout, Cout, gx, st) != SYNTHSR_OK)
+        return SYNTHSR_ELAUNCH;
       hipLaunchKernelGGL(conv3d_wgrad_p4_kernel, dim3(gx, ncc), dim3(256), smem, st, in, dout, dw, shape[0], shape[1],
-                         shape[2], Cin, tiles1, tiles2, ntiles, ext.cin_total, ext.ci_off, ext.dbg, ext.dbias);
-      return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+                         shape[2], Cin, tiles1, tiles2, ntiles, ext.cin_total, ext.ci_off, ext.dbg, dbias, det.stride);
+      if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+      return syn_det_finish(&det, st);
     }
   }
   const int CK = ck_for(Cin);
@@ -3643,6 +3722,14 @@ int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo
 
 
 // ---- deterministic mode (see common.h: syn_det_gather / syn_turn_begin) ------------------------------------------------
+extern "C" __attribute__((visibility("hidden"))) int syn_det_enabled() { return g_det; }
+extern "C" __attribute__((visibility("hidden"))) int syn_det_prepare(DetRun* d, float** dw, float** dbias, int64_t dw_elems,
+                                                                      int cout, int gx, hipStream_t st) {
+  return det_prepare_impl(d, dw, dbias, dw_elems, cout, gx, st);
+}
+extern "C" __attribute__((visibility("hidden"))) int syn_det_finish(const DetRun* d, hipStream_t st) {
+  return det_finish_impl(d, st);
+}
 extern "C" int syn_det_set_pointwise(SynDet*);
 extern "C" int syn_det_set_critic(SynDet*);
 extern "C" int syn_det_set_ssim(SynDet*);
@@ -3653,15 +3740,24 @@ constexpr long long DET_SCRATCH_FLOATS = 16ll << 20;  // 64 MB of partial rows (
 int synthsr_set_deterministic(int on) {
   if (hipDeviceSynchronize() != hipSuccess) return SYNTHSR_ELAUNCH;  // no kernel may see the switch mid-flight
   if (on && !g_det_state) {
+    // all-or-nothing: a half-built state block (struct allocated, scratch not) must never be installed by a later call
+    SynDet* state = nullptr;
     float* scratch = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&g_det_state), sizeof(SynDet)) != hipSuccess) return SYNTHSR_ELAUNCH;
-    if (hipMalloc(reinterpret_cast<void**>(&scratch), DET_SCRATCH_FLOATS * sizeof(float)) != hipSuccess) return SYNTHSR_ELAUNCH;
-    SynDet* h = new SynDet();
-    h->scratch_floats = DET_SCRATCH_FLOATS;
-    h->scratch = scratch;
-    const hipError_t e = hipMemcpy(g_det_state, h, sizeof(SynDet), hipMemcpyHostToDevice);
-    delete h;
-    if (e != hipSuccess) return SYNTHSR_ELAUNCH;
+    if (hipMalloc(reinterpret_cast<void**>(&state), sizeof(SynDet)) != hipSuccess) return SYNTHSR_ELAUNCH;
+    bool ok = hipMalloc(reinterpret_cast<void**>(&scratch), DET_SCRATCH_FLOATS * sizeof(float)) == hipSuccess;
+    if (ok) {
+      SynDet* h = new SynDet();
+      h->scratch_floats = DET_SCRATCH_FLOATS;
+      h->scratch = scratch;
+      ok = hipMemcpy(state, h, sizeof(SynDet), hipMemcpyHostToDevice) == hipSuccess;
+      delete h;
+    }
+    if (!ok) {
+      if (scratch) (void)hipFree(scratch);
+      (void)hipFree(state);
+      return SYNTHSR_ELAUNCH;
+    }
+    g_det_state = state;
   }
   if (g_det_state) {  // fresh tickets / counters / timeout flag (scratch pointer and size stay)
     if (hipMemset(g_det_state, 0, offsetof(SynDet, scratch_floats)) != hipSuccess) return SYNTHSR_ELAUNCH;

@@ -682,6 +682,7 @@ struct WgArgs {
   float* dw;           // [27][cin_total][Cout] fp32, accumulated with atomics
   float* dbias;        // [Cout] or null
   int D0, D1, D2, Cin, Cout, cin_total, ci_off, ncc, nco, tiles1, tiles2, ntiles;
+  int64_t det_stride;  // deterministic mode: dw / dbias are per-workgroup-column planes (common.h: DetRun), else 0
 };
 
 // NT: 16-column tiles of output channels per workgroup pass (<= 3)
@@ -830,8 +831,9 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
       __builtin_amdgcn_sched_barrier(0);
     });
   }
-  // ---- flush: lane (n = li -> co, rows 4g + i -> block 4*mtile + g, element i)
-  int* turn = syn_turn_begin_x();
+  // ---- flush: lane (n = li -> co, rows 4g + i -> block 4*mtile + g, element i); every address belongs to one lane of the
+  // workgroup, deterministic mode gives each workgroup column its own plane (a.det_stride)
+  const size_t detoff = (size_t)blockIdx.x * a.det_stride;
 #pragma unroll
   for (int q = 0; q < MPW; ++q) {
     const int mtile = wave * MPW + q;
@@ -846,14 +848,13 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int ci = cc * CK + quad * 4 + i;
-          if (ci < a.cin_total) atomicAdd(a.dw + ((int64_t)tap * a.cin_total + a.ci_off + ci) * Cout + co, acc[q][n][i]);
+          if (ci < a.cin_total) atomicAdd(a.dw + detoff + ((int64_t)tap * a.cin_total + a.ci_off + ci) * Cout + co, acc[q][n][i]);
         }
       } else if (blk == 27 * C4 && a.dbias && cc == 0) {
-        atomicAdd(a.dbias + co, acc[q][n][0]);
+        atomicAdd(a.dbias + detoff + co, acc[q][n][0]);
       }
     }
   }
-  syn_turn_end_x(turn);
 }
 
 template <int CK, int NT>
@@ -871,8 +872,13 @@ int launch_wgrad(const WgArgs& a0, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
+  DetRun det;
+  if (syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)
+    return SYNTHSR_ELAUNCH;
+  a.det_stride = det.stride;
   hipLaunchKernelGGL(kern, dim3(gx, a.ncc * a.nco), dim3(512), smem, st, a);
-  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  return syn_det_finish(&det, st);
 }
 
 // fp32 [n][Cs] -> bf16 [n][Cd] (Cd >= Cs, zero fill): the generator's image -> first-layer input (Cin 2 -> 8)

@@ -18,8 +18,9 @@ _prof = None
 
 def set_deterministic(on=True):
     """process-wide switch (include/synthsr_hip_tuning.h: synthsr_set_deterministic): bit-identical results run after run on
-    the same inputs -- every cross-workgroup float accumulation is flushed in workgroup order, no split-K forward.  Slower;
-    single-stream use.  Returns the previous setting."""
+    the same inputs -- every cross-workgroup float accumulation happens in a fixed order, no split-K forward.  Scope: the
+    whole PROCESS on the CURRENT device (every network, critic and predictor is switched together) and ONE stream (kernels
+    of two streams must not overlap while it is on).  Returns the previous setting."""
     global _deterministic
     prev = _deterministic
     torch.cuda.synchronize()

@@ -139,9 +139,84 @@ def test_one_training_step_at_baseline_shape_vs_oracle(S, hyperfine):
     assert rep['bn'] < 5e-4, rep
     assert rep['pred'] < 1e-3, rep
     if hyperfine:   # bf16 vs the fp32 oracle (stated bf16 tolerances; gradients: see tests/test_bf16_gpu.py on pooling flips)
-        assert rep['bf16_loss'] < 1e-2 and rep['bf16_pred'] < 5e-2 and rep['bf16_bn'] < 3e-2 and rep['bf16_min_cos'] > 0.9, rep
+        assert rep['bf16_loss'] < 1e-2 and rep['bf16_pred'] < 5e-2 and rep['bf16_bn'] < 3e-2 and rep['bf16_min_cos'] > 0.98, rep   # measured 0.991
     for nm, (err, kind) in grads.items():
         # biases of the conv right before a BatchNorm: BN's backward removes the mean of the signal, so their gradient is
         # a sum of cancelling terms over every voxel (like dbeta / dgamma); measured up to 1.3e-2 at 192^3
         bound = 3e-2 if (kind in ('beta', 'gamma') or nm.endswith('_1/bias')) else 3e-3
         assert err < bound, 'gradient of %s: %.3e of its range (worst: %s)' % (nm, err, worst)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_critic_update_at_160_vs_oracle(dtype):
+    """BASELINE.json configs[4] at size: ONE critic update and the critic's share of ONE generator update of the adversarial
+    fine-tuning (SynthSR/fine_tuning_with_adversary.py:482-508 make_discriminator, :579-595 build_discriminator_loss with
+    the gradient penalty's double backward, :541-560 the generator's -D(G) term) at 160^3 -- 134.6 M critic parameters, 131 M
+    of them in Dense(512) -- against oracle/unet_ref.critic_loss in float32 under autograd (create_graph).  Compared:
+    D(real), D(fake), ||grad_x D(x_hat)||, the loss, EVERY parameter gradient (fp32: 2e-3 of the tensor's range; bf16 =
+    'mixed bf16' of configs[4], bf16 conv stack with fp32 accumulation / Dense / master weights: cosine > 0.98 and norm
+    within 5 %), the norm of the Dense(512) weight gradient, and the input gradient the generator update receives.
+    Oracle time: about 25 s on 16 host cores (the whole loss incl. the double backward)."""
+    import torch
+    from synthsr_amd.critic import Critic3D
+    from oracle import unet_ref as U
+    S, n_levels = 160, 4
+    net = Critic3D([S, S, S, 1], seed=1, dtype=dtype)
+    assert net.n_params > 134e6 and net.dense[0]['n_in'] == 256000 and net.dense[0]['n_out'] == 512
+    g = torch.Generator().manual_seed(7)
+    for nm, _ in net.specs:       # non-zero biases, larger weights: |D| = O(1) and an active gradient penalty
+        v = net.view(nm)
+        scale = 0.1 if nm.endswith('bias') else 3.0 * v.abs().max().item()
+        v.copy_(torch.randn(v.shape, generator=g) * scale)
+    net.repack()
+    real, fake = torch.rand(S, S, S, 1, generator=g), torch.rand(S, S, S, 1, generator=g)
+    u = 0.3
+    t0 = time.time()
+    loss, d_real, d_fake, norm = net.critic_loss_and_grads(real.cuda(), fake.cuda(), u, gp_weight=10.0)
+    torch.cuda.synchronize()
+    t_gpu = time.time() - t0
+    P = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    t0 = time.time()
+    ref, nref = U.critic_loss(real, fake, u, P, net.name, n_levels, 10.0)
+    ref.backward()
+    t_cpu = time.time() - t0
+    with torch.no_grad():
+        Pd = {k: v.detach() for k, v in P.items()}
+        dr_ref = float(U.critic_forward(real, Pd, net.name, n_levels))
+        df_ref = float(U.critic_forward(fake, Pd, net.name, n_levels))
+    nref, ref = float(nref.detach()), float(ref.detach())
+    tol = 2e-4 if dtype == 'f32' else 3e-2
+    dscale = max(1.0, abs(dr_ref), abs(df_ref))
+    rep = dict(d_real=(d_real, dr_ref), d_fake=(d_fake, df_ref), norm=(norm, nref), loss=(loss, ref))
+    worst_cos, worst_rel, worst_max = (2.0, ''), (0.0, ''), (0.0, '')
+    for nm, _ in net.specs:
+        a, b = net.view(nm, net.grads).cpu().double().reshape(-1), P[nm].grad.double().reshape(-1)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300))
+        rel = abs(float(a.norm() / b.norm().clamp_min(1e-300)) - 1.0)
+        mx = float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+        worst_cos, worst_rel, worst_max = min(worst_cos, (cos, nm)), max(worst_rel, (rel, nm)), max(worst_max, (mx, nm))
+    dn = net.view(net.dense[0]['w'], net.grads).double().norm().item()
+    dn_ref = P[net.dense[0]['w']].grad.double().norm().item()
+    print('\ncritic 160^3 %s: HIP loss + gradients %.2fs (first call), oracle %.1fs; %r; Dense(512) dW norm %.6g vs %.6g; '
+          'gradients: min cosine %.5f (%s), worst norm error %.2e (%s), worst max error %.2e of range (%s)'
+          % (dtype, t_gpu, t_cpu, rep, dn, dn_ref, worst_cos[0], worst_cos[1], worst_rel[0], worst_rel[1], worst_max[0],
+             worst_max[1]))
+    assert abs(nref - 1.0) > 0.05                                     # the penalty contributes
+    assert abs(d_real - dr_ref) < tol * dscale and abs(d_fake - df_ref) < tol * dscale, rep
+    assert abs(norm - nref) < tol * nref, rep
+    assert abs(loss - ref) < tol * max(1.0, abs(ref)), rep
+    assert abs(dn - dn_ref) < (2e-3 if dtype == 'f32' else 5e-2) * dn_ref, (dn, dn_ref)
+    if dtype == 'f32':
+        assert worst_max[0] < 2e-3, worst_max
+    else:
+        assert worst_cos[0] > 0.98 and worst_rel[0] < 5e-2, (worst_cos, worst_rel)
+    # generator side (build_generator_loss: w * mean(-D(G(x)))): the gradient the U-Net's prediction receives
+    x = fake.clone().requires_grad_(True)
+    gx, = torch.autograd.grad(U.critic_forward(x, Pd, net.name, n_levels), x)
+    got = net.input_gradient(fake.cuda(), dout=-0.01).cpu().double().reshape(-1)
+    want = (-0.01 * gx).double().reshape(-1)
+    if dtype == 'f32':
+        assert float((got - want).abs().max() / want.abs().max()) < 2e-3
+    else:
+        assert float(torch.dot(got, want) / (got.norm() * want.norm())) > 0.98
+        assert abs(float(got.norm() / want.norm()) - 1.0) < 5e-2

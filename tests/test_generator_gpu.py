@@ -309,9 +309,9 @@ def test_philox_noise_per_voxel(env, shape, C):
     oracle/philox_ref: synthsr_deform_gmm called through the C ABI with identity deformation, mu = 0, sigma = 1, no bias, no
     clip, so that its planar channel output IS the noise (sd * nz + mu).  The Philox4x32-10 integers are exact by
     construction of this comparison (a single wrong bit moves a normal by O(1)); the Box-Muller transcendentals are the
-    hardware v_log / v_sqrt / v_sin / v_cos: the device value is compared with the float64 value of the same uniforms (5e-6
-    absolute: 1-2 ulp of the radius <= 5.8) and with the float32 oracle stream (whose own rounding of 2 pi u2 costs
-    up to 1.5e-6).  Reference: ext/lab2im/layers.py:480-498 (tf.random.normal inside SampleConditionalGMM; TF's stream is
+    hardware v_log / v_sqrt / v_sin / v_cos: the device value is compared with the float64 value of the same uniforms (1e-6
+    absolute on values up to 5.8; measured 5.7e-7) and with the float32 oracle stream (3e-6: the oracle's own float32
+    rounding of 2 pi u2 costs up to 1.8e-6 against the float64 value).  Reference: ext/lab2im/layers.py:480-498 (tf.random.normal inside SampleConditionalGMM; TF's stream is
     unseeded, so the stream is this build's convention -- SURVEY F4)."""
     torch, _lib, lib = env
     import ctypes
@@ -357,10 +357,11 @@ def test_philox_noise_per_voxel(env, shape, C):
     e32 = np.abs(got - want32)
     print('philox per-voxel: max |device - float64| %.2e (mean %.2e), max |device - float32 oracle| %.2e'
           % (e64.max(), e64.mean(), e32.max()))
-    assert e64.max() < 2e-5 and e64.mean() < 1e-6, (e64.max(), e64.mean())
-    assert e32.max() < 2e-5, e32.max()
+    assert e64.max() < 1e-6 and e64.mean() < 1e-7, (e64.max(), e64.mean())   # measured 5.7e-7 / 4.3e-8
+    assert e32.max() < 3e-6, e32.max()                                         # measured 1.4e-6
     # the running min / max the kernel leaves behind are the extremes of exactly this stream
-    dec = lambda u: np.array([(~u if not (u & 0x80000000) else (u & 0x7fffffff))], dtype=np.uint32).view(np.float32)[0]
+    dec = lambda u: np.array([((~u) & 0xffffffff if not (u & 0x80000000) else (u & 0x7fffffff))],
+                             dtype=np.uint32).view(np.float32)[0]  # common.h: syn_ord2f
     mmh = mm.cpu().numpy().view(np.uint32)
     for c in range(C):
         assert dec(int(mmh[2 * c])) == got[:, c].min() and dec(int(mmh[2 * c + 1])) == got[:, c].max()
