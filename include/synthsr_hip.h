@@ -115,6 +115,18 @@ int synthsr_normalise_gamma(const float* x, float* out, int64_t n, const uint32_
 int synthsr_blur3d(const float* in, float* out, const int shape[3], const float* kernel, const int ksize[3],
                    int out_stride, int out_offset, int fill_offset, float fill_value, synthsr_stream_t stream);
 
+/* One channel of the common case of SynthSR/labels_to_image_model.py:184-228 in a single pass over HBM:
+ * IntensityAugmentation's min-max normalisation + gamma (ext/lab2im/layers.py:1227-1242; x = the clipped channel, minmax =
+ * its running extremes as left by synthsr_deform_gmm, gexp = exp(.5 z)) -> GaussianBlur(.5) (:186, kernel1 3x3x3) written to
+ * `target` (one contiguous channel: the regression-target tap, :189-196) -> the acquisition blur (:223, kernel2 3x3x3) written
+ * to image[v * image_stride + image_offset], with image[v * image_stride + fill_offset] = fill_value (the all-ones
+ * reliability map of a channel that is not down-sampled, :228) when fill_offset >= 0.  Same arithmetic, tap order and zero
+ * padding as synthsr_normalise_gamma followed by two synthsr_blur3d calls (bit-identical results); x must not alias the
+ * outputs. */
+int synthsr_normalise_blur2(const float* x, const int shape[3], const uint32_t* minmax, float gexp, const float* kernel1,
+                            const float* kernel2, float* target, float* image, int image_stride, int image_offset,
+                            int fill_offset, float fill_value, synthsr_stream_t stream);
+
 /* MimicAcquisition (ext/lab2im/layers.py:927-990; randomise_res path, labels_to_image_model.py:220) with
  * min_subsample_res = volume_res: nearest down-sampling by down_zoom then linear up-sampling by up_zoom (both as the
  * reference computes them from the sampled resolution, passed in as float32), fused per output voxel.
@@ -253,15 +265,23 @@ int synthsr_head_bwd_bf16(const float* dpred, const void* x, int64_t nvox, int C
  * has ceil(CinE / 8) * 8 channels (pad channels get zero weights); CoutE % 4 == 0 */
 int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
                                  synthsr_stream_t stream);
-/* One launch for every packed weight set of a network: jobs_dev[njobs][12] int64 = {w_off (floats into params), dst_off
- * (bf16 elements into packed), then the 10 fields synthsr_conv3d_bf16_pack_job fills in}.  Replaces the per-layer Keras weight
+/* parity -1: as synthsr_conv3d_bf16_pack.  parity 0..7 (= 4 pz + 2 py + px): one of the 8 weight sets of the
+ * nearest-upsample folding of a decoder's first conv (UpSampling3D(2) -> concatenate -> Conv3D, ext/neuron/models.py:
+ * 426-444): 8 taps on the LOW-resolution tensor, each the sum of the original taps that fall on it under that output
+ * parity (p = 0: low-res offsets {-1, 0} <- taps {0}, {1, 2}; p = 1: offsets {0, +1} <- {0, 1}, {2}); mode 0 = the parity
+ * conv itself (synthsr_conv3d_bf16_up_fwd), mode 1 = its data gradient (synthsr_conv3d_bf16_up_dgrad). */
+int64_t synthsr_conv3d_bf16_pack_ex(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
+                                    int parity, synthsr_stream_t stream);
+/* One launch for every packed weight set of a network: jobs_dev[njobs][13] int64 = {w_off (floats into params), dst_off
+ * (bf16 elements into packed), then the 11 fields synthsr_conv3d_bf16_pack_job fills in}.  Replaces the per-layer Keras weight
  * reads of the reference's Conv3D layers (ext/neuron/models.py:297-316) after every optimizer step. */
-int synthsr_conv3d_bf16_pack_job(int Cin_total, int ci_off, int Cin, int Cout, int mode, int64_t job[12]);
+int synthsr_conv3d_bf16_pack_job(int Cin_total, int ci_off, int Cin, int Cout, int mode, int parity, int64_t job[13]);
 int synthsr_conv3d_bf16_pack_all(const float* params, void* packed, const int64_t* jobs_dev, int njobs,
                                  synthsr_stream_t stream);
 
 /* out = act(conv3(in) + bias); act 0 linear, 1 ELU, 2 multiply by ELU'(below) (data gradient fused with the ELU backward
- * of the layer below; below = that layer's ELU output [vox][Cout]).  stats != NULL: BatchNorm batch statistics
+ * of the layer below; below = that layer's ELU output [vox][Cout]), 5 ELU(conv3(in) + bias + below) (below = partial sums
+ * of another input-channel range, may be `out` itself: the skip-channel half of a folded decoder conv).  stats != NULL: BatchNorm batch statistics
  * [mean Cout | var Cout] of the (bf16-rounded) output, accumulated in fp32 / double.  `scratch` (>=
  * synthsr_conv3d_bf16_stats_scratch floats; may be NULL when no statistics are wanted) also holds the fp32 partial sums
  * of the split-K path that small volumes take */
@@ -285,6 +305,26 @@ int synthsr_bf16_zero_insert_odd(const void* in, void* out, const int in_shape[3
  * Cout % 8 == 0 */
 int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float* dbias, const int shape[3],
                               int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream);
+/* the same for the input-channel range [ci_off, ci_off + Cin) of a layer with Cin_total input channels (`in` = that
+ * range as its own tensor, Cin % 8 == 0): the skip-channel half of a folded decoder conv (SynthSR/../models.py:434:
+ * concatenate([skip, up]) is never materialised) */
+int synthsr_conv3d_bf16_wgrad_part(const void* in, const void* dout, float* dw, float* dbias, const int shape[3],
+                                   int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream);
+/* Nearest-upsample folding in bf16 (the float32 versions: synthsr_conv3d_up_fwd / _up_dgrad / _up_wgrad): the part of a
+ * decoder's first conv that reads UpSampling3D(2)(lo) is evaluated on the low-resolution tensor lo [lo_shape][Cl] as 8
+ * parity convs with 2x2x2 taps (3.4x fewer FLOPs, no up-sampled / concatenated tensor).
+ *  up_fwd:   out [2 lo_shape][Cout] = the raw partial sums (bf16-rounded; bias / activation come with the skip-channel
+ *            conv, synthsr_conv3d_bf16_fwd act 5); wpacked8 = the 8 parity sets (pack_ex mode 0), back to back;
+ *  up_dgrad: dlo [lo_shape][Cl] = gradient w.r.t. lo of dout [2 lo_shape][Cout]; wpacked8 = pack_ex mode 1 sets; scratch:
+ *            fp32 partial planes of the split-K path of small volumes (may be NULL);
+ *  up_wgrad: dwc [8][27][Cl][Cout] fp32 (zeroed by the caller) += per-parity gradients in 27-slot form;
+ *            synthsr_conv3d_up_unpack then folds them onto dw[27][Cin_total][Cout]. */
+int synthsr_conv3d_bf16_up_fwd(const void* lo, const void* wpacked8, void* out, const int lo_shape[3], int Cl, int Cout,
+                               synthsr_stream_t stream);
+int synthsr_conv3d_bf16_up_dgrad(const void* dout, const void* wpacked8, void* dlo, const int lo_shape[3], int Cl, int Cout,
+                                 float* scratch, int64_t scratch_floats, synthsr_stream_t stream);
+int synthsr_conv3d_bf16_up_wgrad(const void* lo, const void* dout, float* dwc, const int lo_shape[3], int Cl, int Cout,
+                                 synthsr_stream_t stream);
 /* float32 [n][Cs] -> bfloat16 [n][Cd], Cd >= Cs, zero fill (the generator's image -> first-layer input, Cin 2 -> 8) */
 int synthsr_f32_to_bf16_pad(const float* src, void* dst, int64_t n, int Cs, int Cd, synthsr_stream_t stream);
 
@@ -318,6 +358,8 @@ int synthsr_bn_stats_from_partials(const float* partial, int nwg, int64_t nvox, 
 /* y = gamma*(x-mean)*rsqrt(var+eps)+beta */
 int synthsr_bn_apply(const float* x, float* y, int64_t nvox, int C, const float* stats, const float* gamma,
                      const float* beta, float eps, synthsr_stream_t stream);
+int synthsr_bn_apply_bf16(const void* x, void* y, int64_t nvox, int C, const float* stats, const float* gamma,
+                          const float* beta, float eps, synthsr_stream_t stream);
 /* fused BN apply + MaxPooling3D(2) (models.py:356): x [d0,d1,d2,C] -> y [d0/2,d1/2,d2/2,C] */
 int synthsr_bn_maxpool(const float* x, float* y, const int shape[3], int C, const float* stats, const float* gamma,
                        const float* beta, float eps, synthsr_stream_t stream);

@@ -67,14 +67,19 @@ def round_bf16(x):
 
 
 def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, collect=None, softmax=False, quant=None,
-                 dropout=None):
+                 dropout=None, pool_inputs=None, pool_nudge=None):
     """P: dict name -> tensor with the Keras layer names (`<prefix>_conv_downarm_l_k/kernel`, ...).
     Returns prediction [d0,d1,d2,1].  `collect` (dict) receives batch statistics per BN layer.
     quant (optional, e.g. round_bf16): applied wherever the bf16 network stores a tensor -- the input, every conv kernel,
     every conv + ELU output, every pooled tensor and every concatenated tensor (BatchNorm, head and loss stay fp32).
     dropout (optional): conv layer name -> per-channel factor (0 or 1/(1-rate)) of the feature-wise KL.Dropout that
     follows that conv (noise_shape [None,1,1,1,C], ext/neuron/models.py:320-324, 448-451); the skip connection reads the
-    conv layer's own output, i.e. the tensor BEFORE the dropout (models.py:431-432)."""
+    conv layer's own output, i.e. the tensor BEFORE the dropout (models.py:431-432).
+    pool_inputs (optional list): receives the tensor each MaxPooling3D reads (detached).  pool_nudge (optional list, one
+    entry per pooled level, None or a constant tensor of that shape) is ADDED to that tensor before the pooling: the parity
+    tests use it to make this oracle break an exact-rounding TIE between two candidates of a 2x2x2 window the way the device
+    did (a few ulp on one element of an identified window; tests/conftest.py: align_pool_ties) -- max-pooling is
+    discontinuous, and which of two values within float32 rounding of each other wins is not a property of the algorithm."""
     L = nb_levels
     if quant is not None:
         x = quant(x)
@@ -100,6 +105,10 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
         skips.append(pre)  # pre-BN (and pre-dropout) skip: the conv layer's output (models.py:431-432)
         cur = bn(cur, '%s_bn_down_%d' % (prefix, l))
         if l < L - 1:
+            if pool_inputs is not None:
+                pool_inputs.append(cur.detach())
+            if pool_nudge is not None and pool_nudge[l] is not None:
+                cur = cur + pool_nudge[l]
             cur = q(maxpool2(cur))
     for k in range(L - 1):
         l = L - 2 - k
@@ -125,7 +134,7 @@ def dice_loss(gt, pred, eps=1e-7):
 
 
 def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, generation_labels, label_equivalency,
-                       m=None, M=None, fs_header=False, loss_cropping=None):
+                       m=None, M=None, fs_header=False, loss_cropping=None, pool_inputs=None, pool_nudge=None):
     """SynthSR/metrics_model.py:136-215 (add_seg_loss_to_model) for one volume: the predicted image [d0,d1,d2] is
     normalised (:152-155), optionally permuted / flipped to the FreeSurfer orientation (:158-163), pushed through the
     FROZEN segmentation U-Net (softmax head, inference-mode BatchNorm -- third-party Keras semantics, unpinned) and
@@ -138,7 +147,8 @@ def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, g
     x = x[..., None]
     if fs_header:
         x = torch.flip(x.permute(0, 2, 1, 3), dims=[1])
-    probs = unet_forward(x, Pseg, prefix, nb_levels, nconv, training=False, moving=Pseg, softmax=True)
+    probs = unet_forward(x, Pseg, prefix, nb_levels, nconv, training=False, moving=Pseg, softmax=True,
+                         pool_inputs=pool_inputs, pool_nudge=pool_nudge)
     if fs_header:
         probs = torch.flip(probs, dims=[1]).permute(0, 2, 1, 3)
     if loss_cropping is not None:  # :166-183: posteriors and label map cropped to the centred box

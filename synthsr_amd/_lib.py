@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsynthsr_hip.so')
+# SYNTHSR_HIP_LIB: another build of the same library (A/B timing of kernel variants, tools/); never a different backend
+LIB_PATH = os.environ.get('SYNTHSR_HIP_LIB') or os.path.join(_HERE, 'libsynthsr_hip.so')
 
 _lib = None
 
@@ -43,6 +44,7 @@ SIGNATURES = {
     'synthsr_minmax_reduce': (c_int, [_P, c_int64, _P, _S]),
     'synthsr_normalise_gamma': (c_int, [_P, _P, c_int64, _P, c_float, _S]),
     'synthsr_blur3d': (c_int, [_P, _P, POINTER(c_int), _P, POINTER(c_int), c_int, c_int, c_int, c_float, _S]),
+    'synthsr_normalise_blur2': (c_int, [_P, POINTER(c_int), _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _S]),
     'synthsr_outer3': (c_int, [_P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_copy_strided': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_pack': (c_int64, [_P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
@@ -78,7 +80,12 @@ SIGNATURES = {
     'synthsr_head_bwd_ex_bf16': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _S]),
     'synthsr_head_bwd_bf16': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
     'synthsr_conv3d_bf16_pack': (c_int64, [_P, _P, c_int, c_int, c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_bf16_pack_job': (c_int, [c_int, c_int, c_int, c_int, c_int, _P]),
+    'synthsr_conv3d_bf16_pack_ex': (c_int64, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_bf16_pack_job': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'synthsr_conv3d_bf16_wgrad_part': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_bf16_up_fwd': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_conv3d_bf16_up_dgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _P, c_int64, _S]),
+    'synthsr_conv3d_bf16_up_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_conv3d_bf16_pack_all': (c_int, [_P, _P, _P, c_int, _S]),
     'synthsr_conv3d_bf16_fwd': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _P, _P, _P, c_int64, _S]),
     'synthsr_conv3d_bf16_fwd_ex': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_float, _P, _P, _P, c_int64, _S]),
@@ -91,6 +98,7 @@ SIGNATURES = {
     'synthsr_bn_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
     'synthsr_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P, _S]),
     'synthsr_bn_apply': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _S]),
+    'synthsr_bn_apply_bf16': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _S]),
     'synthsr_bn_maxpool': (c_int, [_P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _S]),
     'synthsr_bn_maxpool_bwd': (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _S]),
     'synthsr_bn_maxpool_bwd_ex': (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _P, _S]),

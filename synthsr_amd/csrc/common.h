@@ -115,10 +115,45 @@ __device__ __forceinline__ bool syn_det_gather(float* part, int n) {
   __syncthreads();
   if (!s_last) return false;
   __threadfence();
-  for (int i = tid; i < n; i += nt) {
-    double t = 0.0;
-    for (int w = 0; w < nwg; ++w) t += (double)__builtin_nontemporal_load(d->scratch + (size_t)w * n + i);
-    part[i] = (float)t;
+  // the last workgroup adds the rows up.  One thread per column walking all nwg rows is a chain of ~1000 dependent
+  // load + add steps with most of the workgroup idle (0.3-0.5 ms per reduction launch, 10 ms per 160^3 step); instead
+  // P = nt / n threads share a column, thread p takes rows p, p + P, ... and the P partial sums are added in p order:
+  // the grouping depends on the launch geometry only, so the result is still the same run after run.
+  __shared__ double s_col[1024];
+  const int P = (n <= nt) ? min(nt / n, 1024 / n) : 0;
+  if (P >= 2) {
+    if (tid < n * P) {
+      const int col = tid % n, p = tid / n;
+      // four independent accumulators (rows p, p + P, p + 2P, p + 3P of every group of 4 P): the loads of a group are in
+      // flight together instead of one row's latency after the other; combined in a fixed order
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+      const float* base = d->scratch + col;
+      int w = p;
+      for (; w + 3 * P < nwg; w += 4 * P) {
+        const float a0 = __builtin_nontemporal_load(base + (size_t)w * n);
+        const float a1 = __builtin_nontemporal_load(base + (size_t)(w + P) * n);
+        const float a2 = __builtin_nontemporal_load(base + (size_t)(w + 2 * P) * n);
+        const float a3 = __builtin_nontemporal_load(base + (size_t)(w + 3 * P) * n);
+        t0 += (double)a0;
+        t1 += (double)a1;
+        t2 += (double)a2;
+        t3 += (double)a3;
+      }
+      for (; w < nwg; w += P) t0 += (double)__builtin_nontemporal_load(base + (size_t)w * n);
+      s_col[tid] = (t0 + t1) + (t2 + t3);
+    }
+    __syncthreads();
+    if (tid < n) {
+      double t = 0.0;
+      for (int p = 0; p < P; ++p) t += s_col[p * n + tid];
+      part[tid] = (float)t;
+    }
+  } else {
+    for (int i = tid; i < n; i += nt) {
+      double t = 0.0;
+      for (int w = 0; w < nwg; ++w) t += (double)__builtin_nontemporal_load(d->scratch + (size_t)w * n + i);
+      part[i] = (float)t;
+    }
   }
   if (syn_tid0()) d->arrivals = 0;
   __syncthreads();
@@ -150,6 +185,20 @@ extern "C" int syn_det_finish(const DetRun* d, hipStream_t st);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_syn_det), &p, sizeof(p)) == hipSuccess ? 0 : 1;                 \
   }
 #endif
+
+// Nearest-upsample folding (conv3d.hip: weight_value; conv_bf16.hip: pack_bf16_value): a 3-tap axis of a conv applied to
+// UpSampling(2)(x) acts, for output parity p, on x through a 2-tap window -- low-res slot s (offset s - 1) collects the
+// original taps t[0 .. n): p = 0: slot 0 <- {0}, slot 1 <- {1, 2};  p = 1: slot 1 <- {0, 1}, slot 2 <- {2}.
+__host__ __device__ static inline int syn_up_axis_taps(int p, int s, int t[2]) {
+  if (p == 0) {
+    if (s == 0) { t[0] = 0; return 1; }
+    if (s == 1) { t[0] = 1; t[1] = 2; return 2; }
+    return 0;
+  }
+  if (s == 1) { t[0] = 0; t[1] = 1; return 2; }
+  if (s == 2) { t[0] = 2; return 1; }
+  return 0;
+}
 
 // monotone uint32 encoding of float (total order incl. negatives) for atomicMin/atomicMax
 __host__ __device__ static inline uint32_t syn_f2ord(float f) {

@@ -124,8 +124,12 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 // forward layout (A fragments): [co-chunk][cc][step][mt][lane 64][8] bf16; lane = (m = lane & 15, g = lane >> 4):
 //   pair p = 4 step + g -> tap = p / C8, c8 = p % C8;  value j: W_eff[tap][cc*CK + c8*8 + j][(chunk*MT + mt)*16 + m]
 // mode 0: W_eff = w[tap][ci_off + cie][coe]; mode 1 (data gradient): W_eff[tap][cie][coe] = w[26 - tap][ci_off + coe][cie]
+// parity >= 0 (0..7 = 4 pz + 2 py + px): one of the 8 weight sets of the nearest-upsample folding, 8 taps (a, b, c) in {0, 1}^3
+// (tap = 4a + 2b + c) on the LOW-resolution grid: forward (mode 0) tap (a, b, c) reads halo offset a + p per axis and carries
+// the sum of the original taps behind low-res slot s = a + p (syn_up_axis_taps); data gradient (mode 1, channels transposed)
+// tap (a, b, c) reads the parity-p sub-lattice of dz at halo offset (1 - p) + a and carries slot s = 1 + p - a.
 __device__ __forceinline__ bf16_t pack_bf16_value(const float* __restrict__ w, uint32_t r, int Cin_total, int ci_off, int Cin,
-                                                  int Cout, int mode, int CK, int ncc, int MT, int nsteps) {
+                                                  int Cout, int mode, int CK, int ncc, int MT, int nsteps, int parity) {
   const int C8 = CK / 8;
   const int CinE = mode ? Cout : Cin, CoutE = mode ? Cin : Cout;
   const int j = r & 7;
@@ -143,23 +147,35 @@ __device__ __forceinline__ bf16_t pack_bf16_value(const float* __restrict__ w, u
   const int tap = p / C8, c8 = p - tap * C8;
   const int cie = cc * CK + c8 * 8 + j, coe = (chunk * MT + mt) * 16 + m;
   float v = 0.f;
-  if (tap < 27 && cie < CinE && coe < CoutE) {
-    const int slot = mode ? 26 - tap : tap;
+  if (tap < (parity < 0 ? 27 : 8) && cie < CinE && coe < CoutE) {
     const int ci = (mode ? coe : cie) + ci_off, co = mode ? cie : coe;
-    v = w[((int64_t)slot * Cin_total + ci) * Cout + co];
+    if (parity < 0) {
+      const int slot = mode ? 26 - tap : tap;
+      v = w[((int64_t)slot * Cin_total + ci) * Cout + co];
+    } else {
+      const int ab[3] = {tap >> 2, (tap >> 1) & 1, tap & 1}, pp[3] = {(parity >> 2) & 1, (parity >> 1) & 1, parity & 1};
+      int t[3][2], n[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) n[i] = syn_up_axis_taps(pp[i], mode ? 1 + pp[i] - ab[i] : ab[i] + pp[i], t[i]);
+      for (int a = 0; a < n[0]; ++a)
+        for (int b = 0; b < n[1]; ++b)
+          for (int c = 0; c < n[2]; ++c)
+            v += w[((int64_t)((t[0][a] * 3 + t[1][b]) * 3 + t[2][c]) * Cin_total + ci) * Cout + co];
+    }
   }
   return (bf16_t)f2bf(v);
 }
 
 __global__ void pack_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ packed, int Cin_total, int ci_off,
-                                 int Cin, int Cout, int mode, int CK, int ncc, int MT, int nsteps, int64_t total) {
+                                 int Cin, int Cout, int mode, int CK, int ncc, int MT, int nsteps, int parity, int64_t total) {
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
-    packed[idx] = pack_bf16_value(w, (uint32_t)idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, MT, nsteps);
+    packed[idx] = pack_bf16_value(w, (uint32_t)idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, MT, nsteps, parity);
 }
 
 // every packed weight set of a network in ONE launch (38 launches of 5 us per training step otherwise): blockIdx.y = job,
-// jobs[j] = {w_off, dst_off, total, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, MT, nsteps} (int64 each, offsets in elements)
-constexpr int BF16_PACK_JOB_FIELDS = 12;
+// jobs[j] = {w_off, dst_off, total, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, MT, nsteps, parity} (int64 each, offsets in
+// elements; parity -1 = plain 27-tap set)
+constexpr int BF16_PACK_JOB_FIELDS = 13;
 __global__ void pack_bf16_all_kernel(const float* __restrict__ params, bf16_t* __restrict__ packed,
                                      const int64_t* __restrict__ jobs) {
   const int64_t* jb = jobs + (int64_t)blockIdx.y * BF16_PACK_JOB_FIELDS;
@@ -167,9 +183,9 @@ __global__ void pack_bf16_all_kernel(const float* __restrict__ params, bf16_t* _
   bf16_t* dst = packed + jb[1];
   const int64_t total = jb[2];
   const int Cin_total = (int)jb[3], ci_off = (int)jb[4], Cin = (int)jb[5], Cout = (int)jb[6], mode = (int)jb[7], CK = (int)jb[8],
-            ncc = (int)jb[9], MT = (int)jb[10], nsteps = (int)jb[11];
+            ncc = (int)jb[9], MT = (int)jb[10], nsteps = (int)jb[11], parity = (int)jb[12];
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
-    dst[idx] = pack_bf16_value(w, (uint32_t)idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, MT, nsteps);
+    dst[idx] = pack_bf16_value(w, (uint32_t)idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, MT, nsteps, parity);
 }
 
 struct Bf16Plan {
@@ -177,14 +193,14 @@ struct Bf16Plan {
   int64_t count() const { return (int64_t)nchunks * ncc * nsteps * mt * 64 * 8; }
 };
 
-inline Bf16Plan plan_bf16(int CinE, int CoutE) {
+inline Bf16Plan plan_bf16(int CinE, int CoutE, int ntaps = 27) {
   Bf16Plan p;
   p.ck = (CinE % 32 == 0) ? 32 : ((CinE % 24 == 0) ? 24 : 8);
   p.ncc = (CinE + p.ck - 1) / p.ck;
   const int mt_all = (CoutE + 15) / 16;
   p.nchunks = (mt_all + 3) / 4;
   p.mt = (mt_all + p.nchunks - 1) / p.nchunks;
-  p.nsteps = (27 * (p.ck / 8) + 3) / 4;
+  p.nsteps = (ntaps * (p.ck / 8) + 3) / 4;  // ntaps = 8: one parity set of the nearest-upsample folding
   return p;
 }
 
@@ -199,15 +215,24 @@ struct FwdArgs {
   float* partial;        // split-K (small volumes): fp32 [vox][Cout] accumulated with atomics, epilogue in a second kernel
   int D0, D1, D2, Cin, Cout, ncc, tiles1, tiles2, ntiles, act, ksplit;
   float alpha;           // LeakyReLU slope of act 3 / 4 (the WGAN-GP critic)
+  int ncc_real;          // UPM == 2: input-channel chunks of dz per parity (ncc = 8 * ncc_real: the 8 parities are K chunks)
 };
 
 // WLDS: the whole fragment-ordered weight set of this workgroup's (co-chunk, single ci-chunk) lives in LDS for the life of
 // the persistent workgroup (24 -> 24: 42 KB next to the 31 KB halo tile, 2 workgroups per CU) -- no global weight loads
 // in the K loop at all; otherwise fragments stream from L2 two K-steps ahead
-template <int CK, int MT, bool WLDS>
+// UPM: nearest-upsample folding of a decoder's first conv (unet.py; ext/neuron/models.py:426-444 UpSampling3D -> concatenate
+// -> Conv3D): the up-sampled channels never exist at full resolution.
+//   UPM 1 (forward): D0..D2 = the LOW-resolution grid; blockIdx.z = output parity (pz, py, px); 8-tap parity weights; the
+//         tile's outputs go to the voxels 2 v + p of the 2x tensor `out` (raw fp32-accumulated sums rounded to bf16: the
+//         skip-channel conv then adds them in its epilogue, act 5);
+//   UPM 2 (data gradient): `in` = dz on the 2x grid; the 8 parities are K chunks (cc = parity * ncc_real + chunk): parity p
+//         stages the sub-lattice dz[2 v + p] and multiplies by its transposed 8-tap set; output = d(lo) on the low-res grid.
+template <int CK, int MT, bool WLDS, int UPM = 0>
 __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int C8 = CK / 8, ROWB = rowb_fwd(CK), NSTEP = (27 * C8 + 3) / 4;
+  constexpr int C8 = CK / 8, ROWB = rowb_fwd(CK), NTAPS = UPM ? 8 : 27, NSTEP = (NTAPS * C8 + 3) / 4;
+  static_assert(!(WLDS && UPM), "the folded variants stream their weights");
   constexpr int HBYTES = (HVOX * ROWB + 1023) / 1024 * 1024;  // halo image, then (WLDS) the weight fragments
   constexpr int NPIECE = HVOX * C8, NLD = (NPIECE + 255) / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -223,10 +248,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
   for (int s = 0; s < NSTEP; ++s) {
     const int p = 4 * s + g;
     const int tap = p / C8, c8 = p - tap * C8;
-    const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-    koff[s] = (tap < 27) ? ((tz * HY + ty) * HX + tx) * ROWB + c8 * 16 : 0;  // beyond 27 taps: weights are zero
+    const int tz = UPM ? (tap >> 2) : tap / 9, ty = UPM ? ((tap >> 1) & 1) : (tap / 3) % 3, tx = UPM ? (tap & 1) : tap % 3;
+    koff[s] = (tap < NTAPS) ? ((tz * HY + ty) * HX + tx) * ROWB + c8 * 16 : 0;  // beyond the taps: weights are zero
   }
-  const int lbase = (wave * HY * HX + m) * ROWB;  // voxel (z = wave, y = 0, x = m) of the tile, tap (0, 0, 0)
+  // folded variants: the 2x2x2 window of parity p starts at halo offset p (forward) / 1 - p (data gradient) per axis
+  auto par_shift = [&](int par) {
+    const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+    return UPM == 1 ? ((pz * HY + py) * HX + px) * ROWB : (((1 - pz) * HY + (1 - py)) * HX + (1 - px)) * ROWB;
+  };
+  const int par1 = UPM == 1 ? (int)blockIdx.z : 0;  // forward: this workgroup's output parity
+  const int lbase0 = (wave * HY * HX + m) * ROWB;  // voxel (z = wave, y = 0, x = m) of the tile, tap (0, 0, 0)
+  int lbase = lbase0 + (UPM == 1 ? par_shift(par1) : 0);
 
   // staging pieces of this thread: piece j -> halo voxel j / C8, 16-byte group j % C8
   int prel[NLD], plds[NLD];
@@ -236,17 +268,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
     const int j = tid + 256 * i;
     const int v = j / C8, c8 = j - v * C8;
     const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
-    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 2 + c8 * 16;
+    // UPM 2: the staged tensor lives on the 2x grid, halo voxel h of the low-res tile = voxel 2 h + p of it
+    prel[i] = UPM == 2 ? ((2 * hz * (2 * D1) + 2 * hy) * (2 * D2) + 2 * hx) * Cin * 2 + c8 * 16
+                       : ((hz * D1 + hy) * D2 + hx) * Cin * 2 + c8 * 16;
     plds[i] = v * ROWB + c8 * 16;
     pmask[i] = j < NPIECE ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;  // hx <= 17 -> bit 29
   }
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 2), 0x00020000);
+      const_cast<bf16_t*>(a.in), 0, (int)((int64_t)(UPM == 2 ? 8 : 1) * D0 * D1 * D2 * Cin * 2), 0x00020000);
   u32x4 stg[NLD];
   auto tile_origin = [&](int t, int& z0, int& y0, int& x0) { tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0); };
-  auto load_halo = [&](int t, int cc) {
+  auto load_halo = [&](int t, int cc_) {
     int z0, y0, x0;
     tile_origin(t, z0, y0, x0);
+    const int par = UPM == 2 ? cc_ / a.ncc_real : 0;
+    const int cc = UPM == 2 ? cc_ - par * a.ncc_real : cc_;
     uint32_t bad = 0x80000000u;
 #pragma unroll
     for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
@@ -254,7 +290,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
     for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
 #pragma unroll
     for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
-    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * CK) * 2;
+    const int base = UPM == 2
+        ? ((((2 * (z0 - 1) + ((par >> 2) & 1)) * (2 * D1) + (2 * (y0 - 1) + ((par >> 1) & 1))) * (2 * D2) +
+            (2 * (x0 - 1) + (par & 1))) * Cin + cc * CK) * 2
+        : ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * CK) * 2;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const uint32_t vo = (pmask[i] & bad) ? OOB : (uint32_t)(prel[i] + base);
@@ -262,7 +301,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
     }
   };
 
-  const bf16x8* __restrict__ wfrag = reinterpret_cast<const bf16x8*>(a.wp) + (int64_t)chunk * a.ncc * NSTEP * MT * 64 + lane;
+  // plain: [co-chunk][cc]; UPM 1: 8 such sets back to back, this workgroup uses the one of its parity; UPM 2: per parity
+  // [co-chunk][ncc_real] (indexed in the K loop)
+  const bf16x8* __restrict__ wfrag = reinterpret_cast<const bf16x8*>(a.wp) +
+      (UPM == 2 ? (int64_t)0 : ((int64_t)par1 * gridDim.y + chunk) * a.ncc * NSTEP * MT * 64) + lane;
   if constexpr (WLDS) {  // ncc == 1 (checked by the launcher): one fragment set, copied once
     const u32x4* src = reinterpret_cast<const u32x4*>(a.wp) + (int64_t)chunk * NSTEP * MT * 64;
     for (int i = tid; i < NSTEP * MT * 64; i += 256) *reinterpret_cast<u32x4*>(lds + HBYTES + i * 16) = src[i];
@@ -282,13 +324,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
     for (int i = 0; i < 4; ++i) s1[mt][i] = s2[mt][i] = 0.f;
 
   // epilogue through buffer instructions when the output fits 32-bit byte offsets
-  const int64_t out_bytes = (int64_t)D0 * D1 * D2 * Cout * 2;
+  const int64_t out_bytes = (int64_t)(UPM == 1 ? 8 : 1) * D0 * D1 * D2 * Cout * 2;
   const bool fast_epi = !a.partial && out_bytes < (1ll << 31) && (!a.stats_partial || a.act <= 1);
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(fast_epi ? out_bytes : 0), 0x00020000);
   const __amdgpu_buffer_rsrc_t rbelow = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(a.below ? a.below : a.out), 0, (int)(fast_epi ? out_bytes : 0), 0x00020000);
   // split-K: slice blockIdx.z of the input-channel chunks (ksplit == 1: all of them)
-  const int cc_lo = (int)(((int64_t)blockIdx.z * a.ncc) / a.ksplit), cc_hi = (int)(((int64_t)(blockIdx.z + 1) * a.ncc) / a.ksplit);
+  const int kz = UPM == 1 ? 0 : (int)blockIdx.z;  // UPM 1: blockIdx.z is the output parity (no split-K)
+  const int cc_lo = (int)(((int64_t)kz * a.ncc) / a.ksplit), cc_hi = (int)(((int64_t)(kz + 1) * a.ncc) / a.ksplit);
   if (walk.pos < walk.end) load_halo(walk.pos, cc_lo);
   int tix = -1;
   (void)tix;
@@ -315,7 +358,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
         load_halo(t + walk.stride, cc_lo);
       }
       TM(4);
-      const bf16x8* wf = wfrag + (int64_t)cc * NSTEP * MT * 64;
+      const bf16x8* wf;
+      if constexpr (UPM == 2) {
+        const int par = cc / a.ncc_real, c = cc - par * a.ncc_real;
+        wf = wfrag + (((int64_t)par * gridDim.y + chunk) * a.ncc_real + c) * NSTEP * MT * 64;
+        lbase = lbase0 + par_shift(par);
+      } else {
+        wf = wfrag + (int64_t)cc * NSTEP * MT * 64;
+      }
       // software pipeline, pinned with sched_barriers (left alone, the scheduler re-uses ONE register set and waits for
       // every LDS read and every weight load right where it is issued): weights two K-steps ahead (global / L2 latency),
       // the halo-tile reads one step ahead (LDS latency), the 4 x MT MFMAs of the current step in between
@@ -362,8 +412,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
       // whose out-of-range offset drops the store and returns 0 for the load: no bounds arithmetic on 64-bit addresses
       const int gz = z0 + wave, gx = x0 + m;
       const bool zx_ok = gz < D0 && gx < D2;
-      const uint32_t row0 = (uint32_t)((gz * D1 + y0) * D2 + gx) * (uint32_t)(Cout * 2);  // bytes
-      const uint32_t ystep = (uint32_t)(D2 * Cout * 2);
+      // UPM 1: low-res voxel v of parity p -> voxel 2 v + p of the 2x output
+      const uint32_t row0 = UPM == 1
+          ? (uint32_t)(((2 * gz + ((par1 >> 2) & 1)) * (2 * D1) + (2 * y0 + ((par1 >> 1) & 1))) * (2 * D2) + (2 * gx + (par1 & 1))) *
+                (uint32_t)(Cout * 2)
+          : (uint32_t)((gz * D1 + y0) * D2 + gx) * (uint32_t)(Cout * 2);  // bytes
+      const uint32_t ystep = (uint32_t)((UPM == 1 ? 4 : 1) * D2 * Cout * 2);
       auto epi = [&](auto ACTC, auto STC) {
         constexpr int ACT = decltype(ACTC)::value;
         constexpr bool ST = decltype(STC)::value;
@@ -395,6 +449,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
               v[1] *= bf2f(b.x >> 16) > 0.f ? 1.f : a.alpha;
               v[2] *= bf2f(b.y & 0xffffu) > 0.f ? 1.f : a.alpha;
               v[3] *= bf2f(b.y >> 16) > 0.f ? 1.f : a.alpha;
+            } else if constexpr (ACT == 5) {  // ELU(conv + bias + addend): the other channel range's partial sums (folding)
+              const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rbelow, (int)off, 0, 0);
+              v[0] = elu_f(v[0] + bf2f(b.x & 0xffffu));
+              v[1] = elu_f(v[1] + bf2f(b.x >> 16));
+              v[2] = elu_f(v[2] + bf2f(b.y & 0xffffu));
+              v[3] = elu_f(v[3] + bf2f(b.y >> 16));
             }
             u32x2 o;
             o.x = pack2(v[0], v[1]);
@@ -419,7 +479,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
       else if (a.act == 1) epi(std::integral_constant<int, 1>{}, F_{});
       else if (a.act == 2) epi(std::integral_constant<int, 2>{}, F_{});
       else if (a.act == 3) epi(std::integral_constant<int, 3>{}, F_{});
-      else epi(std::integral_constant<int, 4>{}, F_{});
+      else if (a.act == 4) epi(std::integral_constant<int, 4>{}, F_{});
+      else epi(std::integral_constant<int, 5>{}, F_{});
       continue;
     }
     // generic path (split-K planes, statistics with other activations, tensors of 2 GiB and more)
@@ -434,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
         const int co = (chunk * MT + mt) * 16 + 4 * g;
         if (!vok || co >= Cout) continue;  // Cout is a multiple of 4
         if (a.partial) {  // this K-slice's own fp32 plane: plain stores, summed by the epilogue kernel
-          *reinterpret_cast<f32x4*>(a.partial + ((int64_t)blockIdx.z * a.D0 * D1 * D2 + vox) * Cout + co) = acc[y][mt];
+          *reinterpret_cast<f32x4*>(a.partial + ((int64_t)kz * a.D0 * D1 * D2 + vox) * Cout + co) = acc[y][mt];
           continue;
         }
         float v[4];
@@ -458,6 +519,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
           v[1] *= bf2f(b.x >> 16) > 0.f ? 1.f : a.alpha;
           v[2] *= bf2f(b.y & 0xffffu) > 0.f ? 1.f : a.alpha;
           v[3] *= bf2f(b.y >> 16) > 0.f ? 1.f : a.alpha;
+        } else if (a.act == 5) {
+          const u32x2 b = *reinterpret_cast<const u32x2*>(a.below + vox * Cout + co);
+          v[0] = elu_f(v[0] + bf2f(b.x & 0xffffu));
+          v[1] = elu_f(v[1] + bf2f(b.x >> 16));
+          v[2] = elu_f(v[2] + bf2f(b.y & 0xffffu));
+          v[3] = elu_f(v[3] + bf2f(b.y >> 16));
         }
         u32x2 o;
         o.x = pack2(v[0], v[1]);
@@ -516,6 +583,35 @@ int launch_fwd_w(const FwdArgs& a, int nchunks, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
+// folded variants (UPM 1: gridDim.z = 8 output parities; UPM 2: gridDim.z = K slices over the 8 x ncc_real chunks)
+template <int CK, int MT, int UPM>
+int launch_fwd_up(const FwdArgs& a, int nchunks, hipStream_t st) {
+  int gx = UPM == 1 ? 64 : 512;  // UPM 1: 8 parities x 64 x chunks workgroups
+  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  if (a.ntiles < 8) gx = a.ntiles;
+  const size_t smem = ((size_t)HVOX * rowb_fwd(CK) + 1023) / 1024 * 1024;
+  auto kern = conv3d_bf16_fwd_kernel<CK, MT, false, UPM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, nchunks, UPM == 1 ? 8 : a.ksplit), dim3(256), smem, st, a);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+template <int UPM>
+int dispatch_fwd_up(const FwdArgs& a, const Bf16Plan& pl, hipStream_t st) {
+#define SYN_UP(CKV, MTV) return launch_fwd_up<CKV, MTV, UPM>(a, pl.nchunks, st)
+  if (pl.ck == 8) {
+    if (pl.mt == 1) SYN_UP(8, 1); else if (pl.mt == 2) SYN_UP(8, 2); else if (pl.mt == 3) SYN_UP(8, 3); else SYN_UP(8, 4);
+  } else if (pl.ck == 24) {
+    if (pl.mt == 1) SYN_UP(24, 1); else if (pl.mt == 2) SYN_UP(24, 2); else if (pl.mt == 3) SYN_UP(24, 3); else SYN_UP(24, 4);
+  } else {
+    if (pl.mt == 1) SYN_UP(32, 1); else if (pl.mt == 2) SYN_UP(32, 2); else if (pl.mt == 3) SYN_UP(32, 3); else SYN_UP(32, 4);
+  }
+#undef SYN_UP
+}
+
 template <int CK, int MT>
 int launch_fwd(const FwdArgs& a, int nchunks, hipStream_t st, int* wgs_out) {
   (void)wgs_out;
@@ -558,6 +654,12 @@ __global__ void bf16_epilogue_kernel(const float* __restrict__ partial, const fl
       v[1] *= bf2f(b.x >> 16) > 0.f ? 1.f : alpha;
       v[2] *= bf2f(b.y & 0xffffu) > 0.f ? 1.f : alpha;
       v[3] *= bf2f(b.y >> 16) > 0.f ? 1.f : alpha;
+    } else if (act == 5) {
+      const u32x2 b = *reinterpret_cast<const u32x2*>(below + i * 4);
+      v[0] = elu_f(v[0] + bf2f(b.x & 0xffffu));
+      v[1] = elu_f(v[1] + bf2f(b.x >> 16));
+      v[2] = elu_f(v[2] + bf2f(b.y & 0xffffu));
+      v[3] = elu_f(v[3] + bf2f(b.y >> 16));
     }
     u32x2 o;
     o.x = pack2(v[0], v[1]);
@@ -678,19 +780,25 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* lds_base, uint32
 
 struct WgArgs {
   const bf16_t* in;    // x [vox][Cin]
-  const bf16_t* dout;  // dz [vox][Cout]
-  float* dw;           // [27][cin_total][Cout] fp32, accumulated with atomics
+  const bf16_t* dout;  // dz [vox][Cout] (UP: on the 2x grid)
+  float* dw;           // [27][cin_total][Cout] fp32, accumulated with atomics (UP: [8 parities][27 slots][cin_total][Cout])
   float* dbias;        // [Cout] or null
   int D0, D1, D2, Cin, Cout, cin_total, ci_off, ncc, nco, tiles1, tiles2, ntiles;
+  int cin_valid;       // channels [0, cin_valid) of `in` have a row in dw (the zero-padded first layer: 2 of 8)
   int64_t det_stride;  // deterministic mode: dw / dbias are per-workgroup-column planes (common.h: DetRun), else 0
 };
 
 // NT: 16-column tiles of output channels per workgroup pass (<= 3)
-template <int CK, int NT>
+// UP: weight gradient of the up-sampled channel range of a folded decoder conv: x = lo on the LOW-resolution grid (D0..D2),
+// dz on the 2x grid; blockIdx.z = parity p: rows = the 8 taps (a, b, c) of the parity's 2x2x2 window (halo offset a + p per
+// axis), dz is read on the sub-lattice 2 v + p; the partial goes to slot (a + p) of the 27-slot set of parity p in dwc
+// (synthsr_conv3d_up_unpack folds the 8 sets back onto the 27 taps).
+template <int CK, int NT, bool UP = false>
 __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kernel(const WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int C8 = CK / 8, C4 = CK / 4, ROWB = rowb_for(CK);
-  constexpr int NBLK = 27 * C4 + 1;                 // (tap, quad) blocks + the constant-1 block (dbias)
+  constexpr int NTAPS = UP ? 8 : 27;
+  constexpr int NBLK = NTAPS * C4 + 1;              // (tap, quad) blocks + the constant-1 block (dbias)
   constexpr int NMT = (NBLK + 3) / 4;               // 16-row tiles
   constexpr int NW = 8, NTHR = 64 * NW;              // 8 waves: the row tiles' accumulators fit 128 VGPRs per wave
   constexpr int MPW = (NMT + NW - 1) / NW;          // row tiles per wave
@@ -712,10 +820,13 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
   for (int q = 0; q < MPW; ++q) {
     const int blk = (wave * MPW + q) * 4 + lq;
     int off;
-    if (blk < 27 * C4) {
+    if (blk < NTAPS * C4) {
       const int tap = blk / C4, quad = blk - tap * C4;
-      off = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * ROWB + quad * 8;
-    } else if (blk == 27 * C4) {
+      const int par = UP ? (int)blockIdx.z : 0;
+      const int hz = UP ? (tap >> 2) + ((par >> 2) & 1) : tap / 9, hy = UP ? ((tap >> 1) & 1) + ((par >> 1) & 1) : (tap / 3) % 3,
+                hx = UP ? (tap & 1) + (par & 1) : tap % 3;
+      off = ((hz * HY + hy) * HX + hx) * ROWB + quad * 8;
+    } else if (blk == NTAPS * C4) {
       off = ((HY + 1) * HX + 1) * ROWB + CK * 2;      // centre tap, pad channels CK..CK+3 = (1, 0, 0, 0)
     } else {
       off = ((HY + 1) * HX + 1) * ROWB + CK * 2 + 8;  // unused slots: pad channels CK+4..CK+7 = 0
@@ -759,13 +870,14 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
     dvx[i] = v % TX;
     const int co = oc * NT * 16 + c8 * 8;
     dcok[i] = j < NDP && co < Cout;                     // Cout is a multiple of 8
-    drel[i] = ((dvz[i] * D1 + dvy[i]) * D2 + dvx[i]) * Cout * 2 + co * 2;
+    drel[i] = UP ? ((2 * dvz[i] * (2 * D1) + 2 * dvy[i]) * (2 * D2) + 2 * dvx[i]) * Cout * 2 + co * 2
+                 : ((dvz[i] * D1 + dvy[i]) * D2 + dvx[i]) * Cout * 2 + co * 2;
     dlds[i] = v * DROWB + c8 * 16;
   }
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(a.dout), 0, (int)((int64_t)D0 * D1 * D2 * Cout * 2), 0x00020000);
+      const_cast<bf16_t*>(a.dout), 0, (int)((int64_t)(UP ? 8 : 1) * D0 * D1 * D2 * Cout * 2), 0x00020000);
   u32x4 stg[NLD], dst[NDL];
   auto tile_origin = [&](int t, int& z0, int& y0, int& x0) { tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0); };
   auto load_tile = [&](int t) {
@@ -784,7 +896,10 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
       const uint32_t vo = (pmask[i] & bad) ? OOB : (uint32_t)(prel[i] + base);
       stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0);
     }
-    const int dbase = ((z0 * D1 + y0) * D2 + x0) * Cout * 2;
+    const int dpar = UP ? (int)blockIdx.z : 0;
+    const int dbase = UP ? (((2 * z0 + ((dpar >> 2) & 1)) * (2 * D1) + (2 * y0 + ((dpar >> 1) & 1))) * (2 * D2) +
+                            (2 * x0 + (dpar & 1))) * Cout * 2
+                         : ((z0 * D1 + y0) * D2 + x0) * Cout * 2;
 #pragma unroll
     for (int i = 0; i < NDL; ++i) {
       const bool ok = dcok[i] && z0 + dvz[i] < D0 && y0 + dvy[i] < D1 && x0 + dvx[i] < D2;
@@ -834,6 +949,8 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
   // ---- flush: lane (n = li -> co, rows 4g + i -> block 4*mtile + g, element i); every address belongs to one lane of the
   // workgroup, deterministic mode gives each workgroup column its own plane (a.det_stride)
   const size_t detoff = (size_t)blockIdx.x * a.det_stride;
+  const int fpar = UP ? (int)blockIdx.z : 0;
+  float* dwp = a.dw + detoff + (UP ? (int64_t)fpar * 27 * a.cin_total * Cout : (int64_t)0);
 #pragma unroll
   for (int q = 0; q < MPW; ++q) {
     const int mtile = wave * MPW + q;
@@ -843,40 +960,44 @@ __global__ __launch_bounds__(512, (NT <= 2 ? 2 : 1)) void conv3d_bf16_wgrad_kern
     for (int n = 0; n < NT; ++n) {
       const int co = (oc * NT + n) * 16 + li;
       if (co >= Cout) continue;
-      if (blk < 27 * C4) {
-        const int tap = blk / C4, quad = blk - tap * C4;
+      if (blk < NTAPS * C4) {
+        const int tap8 = blk / C4, quad = blk - tap8 * C4;
+        // UP: tap (a, b, c) of parity p is slot (a + pz, b + py, c + px) of that parity's 27-slot set
+        const int tap = UP ? (((tap8 >> 2) + ((fpar >> 2) & 1)) * 3 + (((tap8 >> 1) & 1) + ((fpar >> 1) & 1))) * 3 +
+                                 ((tap8 & 1) + (fpar & 1))
+                           : tap8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int ci = cc * CK + quad * 4 + i;
-          if (ci < a.cin_total) atomicAdd(a.dw + detoff + ((int64_t)tap * a.cin_total + a.ci_off + ci) * Cout + co, acc[q][n][i]);
+          if (ci < a.cin_valid) atomicAdd(dwp + ((int64_t)tap * a.cin_total + a.ci_off + ci) * Cout + co, acc[q][n][i]);
         }
-      } else if (blk == 27 * C4 && a.dbias && cc == 0) {
+      } else if (blk == NTAPS * C4 && a.dbias && cc == 0) {
         atomicAdd(a.dbias + detoff + co, acc[q][n][0]);
       }
     }
   }
 }
 
-template <int CK, int NT>
+template <int CK, int NT, bool UP = false>
 int launch_wgrad(const WgArgs& a0, hipStream_t st) {
   WgArgs a = a0;
-  int gx = 512 / (a.ncc * a.nco);
+  int gx = 512 / (a.ncc * a.nco * (UP ? 8 : 1));
   gx = (gx / 8) * 8;
   if (gx < 8) gx = 8;
   while (gx > 8 && gx > a.ntiles) gx -= 8;
   if (a.ntiles < 8) gx = a.ntiles;
   const size_t smem = (size_t)HVOX * rowb_for(CK) + (size_t)TZ * TY * TX * ((NT & 1) ? NT * 32 : NT * 32 + 32);
-  auto kern = conv3d_bf16_wgrad_kernel<CK, NT>;
+  auto kern = conv3d_bf16_wgrad_kernel<CK, NT, UP>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   DetRun det;
-  if (syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)
+  if (syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)(UP ? 8 : 1) * 27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)
     return SYNTHSR_ELAUNCH;
   a.det_stride = det.stride;
-  hipLaunchKernelGGL(kern, dim3(gx, a.ncc * a.nco), dim3(512), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(gx, a.ncc * a.nco, UP ? 8 : 1), dim3(512), smem, st, a);
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   return syn_det_finish(&det, st);
 }
@@ -894,28 +1015,37 @@ __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ src, bf16_t* __
 
 extern "C" {
 
-int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
-                                 synthsr_stream_t stream) {
-  if (Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1)) return SYNTHSR_EINVAL;
+int64_t synthsr_conv3d_bf16_pack_ex(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
+                                    int parity, synthsr_stream_t stream) {
+  if (Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1) || parity < -1 || parity > 7)
+    return SYNTHSR_EINVAL;
   // the tensor a layer reads has its channel count padded to a multiple of 8 (the first layer's 2 -> 8): pad channels
   // get zero weights.  The tensor it produces has its channel count padded the same way when CoutE is not a multiple
   // of 4 (data gradient of a 1- or 2-channel first layer): the extra rows are zero, the tile count is the same.
   const int CinE = ((mode ? Cout : Cin) + 7) / 8 * 8, CoutE = mode ? Cin : Cout;
-  const Bf16Plan pl = plan_bf16(CinE, CoutE);
+  const Bf16Plan pl = plan_bf16(CinE, CoutE, parity < 0 ? 27 : 8);
   const int64_t total = pl.count();
   if (total >= (1ll << 31)) return SYNTHSR_EINVAL;
   if (!packed) return total;
   if (!w) return SYNTHSR_EINVAL;
   hipLaunchKernelGGL(pack_bf16_kernel, dim3(syn_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed,
-                     Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.mt, pl.nsteps, total);
+                     Cin_total, ci_off, Cin, Cout, mode, pl.ck, pl.ncc, pl.mt, pl.nsteps, parity, total);
   return hipGetLastError() == hipSuccess ? total : (int64_t)SYNTHSR_ELAUNCH;
 }
 
-// job table row of synthsr_conv3d_bf16_pack_all for one weight set (host side; fields 0, 1 = w_off, dst_off are the caller's)
-int synthsr_conv3d_bf16_pack_job(int Cin_total, int ci_off, int Cin, int Cout, int mode, int64_t job[12]) {
-  if (!job || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1)) return SYNTHSR_EINVAL;
+int64_t synthsr_conv3d_bf16_pack(const float* w, void* packed, int Cin_total, int ci_off, int Cin, int Cout, int mode,
+                                 synthsr_stream_t stream) {
+  return synthsr_conv3d_bf16_pack_ex(w, packed, Cin_total, ci_off, Cin, Cout, mode, -1, stream);
+}
+
+// job table row of synthsr_conv3d_bf16_pack_all for one weight set (host side; fields 0, 1 = w_off, dst_off are the caller's);
+// parity -1: the plain 27-tap set, 0..7: one parity set of the nearest-upsample folding
+int synthsr_conv3d_bf16_pack_job(int Cin_total, int ci_off, int Cin, int Cout, int mode, int parity, int64_t job[13]) {
+  if (!job || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1) || parity < -1 ||
+      parity > 7)
+    return SYNTHSR_EINVAL;
   const int CinE = ((mode ? Cout : Cin) + 7) / 8 * 8, CoutE = mode ? Cin : Cout;
-  const Bf16Plan pl = plan_bf16(CinE, CoutE);
+  const Bf16Plan pl = plan_bf16(CinE, CoutE, parity < 0 ? 27 : 8);
   if (pl.count() >= (1ll << 31)) return SYNTHSR_EINVAL;
   job[2] = pl.count();
   job[3] = Cin_total;
@@ -927,6 +1057,7 @@ int synthsr_conv3d_bf16_pack_job(int Cin_total, int ci_off, int Cin, int Cout, i
   job[9] = pl.ncc;
   job[10] = pl.mt;
   job[11] = pl.nsteps;
+  job[12] = parity;
   return SYNTHSR_OK;
 }
 
@@ -941,8 +1072,8 @@ int synthsr_conv3d_bf16_pack_all(const float* params, void* packed, const int64_
 int synthsr_conv3d_bf16_fwd_ex(const void* in, const void* wp, const float* bias, void* out, const int shape[3], int Cin,
                                int Cout, int act, float alpha, const void* below, float* stats, float* scratch,
                                int64_t scratch_floats, synthsr_stream_t stream) {
-  if (!in || !wp || !out || !shape || Cin % 8 != 0 || Cout % 4 != 0 || act < 0 || act > 4 ||
-      ((act == 2 || act == 4) && !below))
+  if (!in || !wp || !out || !shape || Cin % 8 != 0 || Cout % 4 != 0 || act < 0 || act > 5 ||
+      ((act == 2 || act == 4 || act == 5) && !below) || (act == 5 && stats))
     return SYNTHSR_EINVAL;
   const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
   if (vox * Cin * 2 >= (1ll << 31) || vox * Cout * 2 >= (1ll << 31)) return SYNTHSR_EINVAL;
@@ -967,6 +1098,7 @@ int synthsr_conv3d_bf16_fwd_ex(const void* in, const void* wp, const float* bias
   a.stats_partial = nullptr;
   a.partial = nullptr;
   a.ksplit = 1;
+  a.ncc_real = pl.ncc;
   int gx = 512;
   while (gx > 8 && gx > a.ntiles) gx -= 8;
   if (a.ntiles < 8) gx = a.ntiles;
@@ -1051,13 +1183,10 @@ int64_t synthsr_conv3d_bf16_stats_scratch(const int shape[3], int Cin, int Cout)
   return stats > splitk ? stats : splitk;
 }
 
-int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float* dbias, const int shape[3], int Cin_total,
-                              int ci_off, int Cin, int Cout, synthsr_stream_t stream) {
-  // `in` has Cin channels (a multiple of 8), dw covers its first Cin_total <= Cin channels (zero-padded first layer)
-  if (!in || !dout || !dw || !shape || Cin % 8 != 0 || Cout % 8 != 0 || ci_off != 0 || Cin_total > Cin || Cin_total < 1)
-    return SYNTHSR_EINVAL;
+static int bf16_wgrad_common(const void* in, const void* dout, float* dw, float* dbias, const int shape[3], int dw_cin_total,
+                             int ci_off, int Cin, int cin_valid, int Cout, bool up, hipStream_t st) {
   const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
-  if (vox * Cin * 2 >= (1ll << 31) || vox * Cout * 2 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  if (vox * Cin * 2 >= (1ll << 31) || (up ? 8 : 1) * vox * Cout * 2 >= (1ll << 31)) return SYNTHSR_EINVAL;
   WgArgs a;
   a.in = (const bf16_t*)in;
   a.dout = (const bf16_t*)dout;
@@ -1068,8 +1197,10 @@ int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float
   a.D2 = shape[2];
   a.Cin = Cin;
   a.Cout = Cout;
-  a.cin_total = Cin_total;
+  a.cin_total = dw_cin_total;
   a.ci_off = ci_off;
+  a.cin_valid = cin_valid;
+  a.det_stride = 0;
   const int ck = (Cin % 32 == 0) ? 32 : ((Cin % 24 == 0) ? 24 : 8);
   a.ncc = (Cin + ck - 1) / ck;
   const int nt_all = (Cout + 15) / 16;
@@ -1078,13 +1209,106 @@ int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float
   a.tiles1 = (shape[1] + TY - 1) / TY;
   a.tiles2 = (shape[2] + TX - 1) / TX;
   a.ntiles = ((shape[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
-  hipStream_t st = (hipStream_t)stream;
-#define SYN_WG(CKV) \
-  (nt == 1 ? launch_wgrad<CKV, 1>(a, st) : (nt == 2 ? launch_wgrad<CKV, 2>(a, st) : launch_wgrad<CKV, 3>(a, st)))
-  if (ck == 8) return SYN_WG(8);
-  if (ck == 24) return SYN_WG(24);
-  return SYN_WG(32);
+#define SYN_WG(CKV, UPV) \
+  (nt == 1 ? launch_wgrad<CKV, 1, UPV>(a, st) : (nt == 2 ? launch_wgrad<CKV, 2, UPV>(a, st) : launch_wgrad<CKV, 3, UPV>(a, st)))
+  if (up) {
+    if (ck == 8) return SYN_WG(8, true);
+    if (ck == 24) return SYN_WG(24, true);
+    return SYN_WG(32, true);
+  }
+  if (ck == 8) return SYN_WG(8, false);
+  if (ck == 24) return SYN_WG(24, false);
+  return SYN_WG(32, false);
 #undef SYN_WG
+}
+
+int synthsr_conv3d_bf16_wgrad(const void* in, const void* dout, float* dw, float* dbias, const int shape[3], int Cin_total,
+                              int ci_off, int Cin, int Cout, synthsr_stream_t stream) {
+  // `in` has Cin channels (a multiple of 8), dw covers its first Cin_total <= Cin channels (zero-padded first layer)
+  if (!in || !dout || !dw || !shape || Cin % 8 != 0 || Cout % 8 != 0 || ci_off != 0 || Cin_total > Cin || Cin_total < 1)
+    return SYNTHSR_EINVAL;
+  return bf16_wgrad_common(in, dout, dw, dbias, shape, Cin_total, 0, Cin, Cin_total, Cout, false, (hipStream_t)stream);
+}
+
+int synthsr_conv3d_bf16_wgrad_part(const void* in, const void* dout, float* dw, float* dbias, const int shape[3],
+                                   int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream) {
+  // the Cin channels of `in` are the input-channel range [ci_off, ci_off + Cin) of a layer with Cin_total input channels
+  if (!in || !dout || !dw || !shape || Cin % 8 != 0 || Cout % 8 != 0 || ci_off < 0 || ci_off + Cin > Cin_total)
+    return SYNTHSR_EINVAL;
+  return bf16_wgrad_common(in, dout, dw, dbias, shape, Cin_total, ci_off, Cin, Cin, Cout, false, (hipStream_t)stream);
+}
+
+int synthsr_conv3d_bf16_up_wgrad(const void* lo, const void* dout, float* dwc, const int lo_shape[3], int Cl, int Cout,
+                                 synthsr_stream_t stream) {
+  if (!lo || !dout || !dwc || !lo_shape || Cl % 8 != 0 || Cout % 8 != 0 || Cl < 8 || Cout < 8) return SYNTHSR_EINVAL;
+  return bf16_wgrad_common(lo, dout, dwc, nullptr, lo_shape, Cl, 0, Cl, Cl, Cout, true, (hipStream_t)stream);
+}
+
+static int bf16_up_args(FwdArgs& a, const void* in, const void* wp, void* out, const int lo_shape[3], int Cin, int Cout) {
+  a.in = (const bf16_t*)in;
+  a.wp = (const bf16_t*)wp;
+  a.bias = nullptr;
+  a.out = (bf16_t*)out;
+  a.below = nullptr;
+  a.D0 = lo_shape[0];
+  a.D1 = lo_shape[1];
+  a.D2 = lo_shape[2];
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.tiles1 = (lo_shape[1] + TY - 1) / TY;
+  a.tiles2 = (lo_shape[2] + TX - 1) / TX;
+  a.ntiles = ((lo_shape[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
+  a.act = 0;
+  a.alpha = 0.f;
+  a.stats_partial = nullptr;
+  a.partial = nullptr;
+  a.ksplit = 1;
+  return SYNTHSR_OK;
+}
+
+int synthsr_conv3d_bf16_up_fwd(const void* lo, const void* wpacked8, void* out, const int lo_shape[3], int Cl, int Cout,
+                               synthsr_stream_t stream) {
+  if (!lo || !wpacked8 || !out || !lo_shape || Cl % 8 != 0 || Cout % 4 != 0 || Cl < 8 || Cout < 4) return SYNTHSR_EINVAL;
+  const int64_t vox = (int64_t)lo_shape[0] * lo_shape[1] * lo_shape[2];
+  if (vox * Cl * 2 >= (1ll << 31) || 8 * vox * Cout * 2 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  const Bf16Plan pl = plan_bf16(Cl, Cout, 8);
+  FwdArgs a;
+  bf16_up_args(a, lo, wpacked8, out, lo_shape, Cl, Cout);
+  a.ncc = pl.ncc;
+  a.ncc_real = pl.ncc;
+  return dispatch_fwd_up<1>(a, pl, (hipStream_t)stream);
+}
+
+int synthsr_conv3d_bf16_up_dgrad(const void* dout, const void* wpacked8, void* dlo, const int lo_shape[3], int Cl, int Cout,
+                                 float* scratch, int64_t scratch_floats, synthsr_stream_t stream) {
+  if (!dout || !wpacked8 || !dlo || !lo_shape || Cl % 4 != 0 || Cout % 8 != 0 || Cl < 4 || Cout < 8) return SYNTHSR_EINVAL;
+  const int64_t vox = (int64_t)lo_shape[0] * lo_shape[1] * lo_shape[2];
+  if (8 * vox * Cout * 2 >= (1ll << 31) || vox * Cl * 2 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  const Bf16Plan pl = plan_bf16(Cout, Cl, 8);  // K = dz channels (Cout of the layer), output = lo channels
+  FwdArgs a;
+  bf16_up_args(a, dout, wpacked8, dlo, lo_shape, Cout, Cl);
+  a.ncc_real = pl.ncc;
+  a.ncc = 8 * pl.ncc;
+  hipStream_t st = (hipStream_t)stream;
+  // small deep levels: split the 8 x ncc K chunks over gridDim.z, fp32 partial planes + the split-K epilogue
+  int gx = 512;
+  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  if (a.ntiles < 8) gx = a.ntiles;
+  const int wgs_plain = gx * pl.nchunks;
+  const int ks = std::min(a.ncc, (512 + wgs_plain - 1) / std::max(wgs_plain, 1));
+  if (wgs_plain < 256 && ks >= 2 && scratch && scratch_floats >= (int64_t)ks * vox * Cl) {
+    a.ksplit = ks;
+    a.partial = scratch;
+  }
+  const int rc = dispatch_fwd_up<2>(a, pl, st);
+  if (rc != SYNTHSR_OK) return rc;
+  if (a.partial) {
+    const int64_t n4 = vox * (Cl / 4);
+    hipLaunchKernelGGL(bf16_epilogue_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, st, scratch, (const float*)nullptr,
+                       (const bf16_t*)nullptr, (bf16_t*)dlo, n4, Cl / 4, 0, a.ksplit, 0.f);
+    if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  }
+  return SYNTHSR_OK;
 }
 
 int synthsr_f32_to_bf16_pad(const float* src, void* dst, int64_t n, int Cs, int Cd, synthsr_stream_t stream) {

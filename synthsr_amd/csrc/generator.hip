@@ -456,6 +456,82 @@ __global__ __launch_bounds__(256) void blur3d_kernel(const float* __restrict__ i
   }
 }
 
+// IntensityAugmentation's normalise + gamma (layers.py:1227-1242), GaussianBlur(sigma = .5) (labels_to_image_model.py:186:
+// the regression-target tap) and the acquisition blur (:223) of ONE channel in a single pass: the clipped channel is read once
+// with a 2-voxel halo into LDS (normalised on the way in), the sigma = .5 blur is evaluated on the tile + 1-voxel halo (its
+// interior goes to the target tensor), the second blur on the tile itself (interleaved image + optional all-ones reliability
+// map).  The three separate kernels moved 28 B / voxel through HBM (write + re-read of two intermediates), this one 16.
+// Arithmetic is exactly that of normalise_gamma_kernel and blur3d_kernel: zero padding outside the VOLUME for both blurs (the
+// sigma = .5 result outside the volume counts as 0 for the second blur, it is not evaluated there), taps accumulated in
+// (z, y, x) raster order, float32, no contraction (this file is built with -ffp-contract=off).
+constexpr int NB_TZ = 8, NB_TY = 16, NB_TX = 32;
+__global__ __launch_bounds__(256) void normalise_blur2_kernel(const float* __restrict__ x, Shape3 s,
+                                                              const uint32_t* __restrict__ mm, float gexp,
+                                                              const float* __restrict__ k1, const float* __restrict__ k2,
+                                                              float* __restrict__ target, float* __restrict__ image,
+                                                              int istride, int ioff, int foff, float fval, int t1, int t2) {
+  constexpr int AZ = NB_TZ + 4, AY = NB_TY + 4, AX = NB_TX + 4, BZ = NB_TZ + 2, BY = NB_TY + 2, BX = NB_TX + 2;
+  __shared__ float A[AZ * AY * AX];
+  __shared__ float B[BZ * BY * BX];
+  __shared__ float kw[54];
+  const int tid = threadIdx.x;
+  if (tid < 54) kw[tid] = tid < 27 ? k1[tid] : k2[tid - 27];
+  const float m = syn_ord2f(mm[0]), M = syn_ord2f(mm[1]);
+  const float den = (M - m) + 1e-7f;  // K.epsilon(), layers.py:1236
+  // XCD-contiguous tile order (consecutive workgroup ids are dealt to the 8 XCDs): each XCD walks a compact slab
+  const int G = (int)gridDim.x, b = (int)blockIdx.x;
+  const int tile = (G % 8 == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
+  const int tz = tile / (t1 * t2), r = tile - tz * (t1 * t2), ty = r / t2, tx = r - ty * t2;
+  const int z0 = tz * NB_TZ, y0 = ty * NB_TY, x0 = tx * NB_TX;
+  const int D0 = s.d[0], D1 = s.d[1], D2 = s.d[2];
+  for (int i = tid; i < AZ * AY * AX; i += 256) {
+    const int az = i / (AY * AX), q = i - az * (AY * AX), ay = q / AX, ax = q - ay * AX;
+    const int z = z0 - 2 + az, y = y0 - 2 + ay, xx = x0 - 2 + ax;
+    float v = 0.f;
+    if ((unsigned)z < (unsigned)D0 && (unsigned)y < (unsigned)D1 && (unsigned)xx < (unsigned)D2) {
+      v = fminf(fmaxf(x[((int64_t)z * D1 + y) * D2 + xx], m), M);
+      v = (v - m) / den;
+      if (gexp > 0.f) v = powf(v, gexp);
+    }
+    A[i] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < BZ * BY * BX; i += 256) {
+    const int bz = i / (BY * BX), q = i - bz * (BY * BX), by = q / BX, bx = q - by * BX;
+    const int z = z0 - 1 + bz, y = y0 - 1 + by, xx = x0 - 1 + bx;
+    float acc = 0.f;
+    const bool inside = (unsigned)z < (unsigned)D0 && (unsigned)y < (unsigned)D1 && (unsigned)xx < (unsigned)D2;
+    if (inside) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) acc = acc + A[((bz + a) * AY + (by + c)) * AX + (bx + d)] * kw[(a * 3 + c) * 3 + d];
+      if (bz >= 1 && bz <= NB_TZ && by >= 1 && by <= NB_TY && bx >= 1 && bx <= NB_TX)
+        target[((int64_t)z * D1 + y) * D2 + xx] = acc;
+    }
+    B[i] = acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < NB_TZ * NB_TY * NB_TX; i += 256) {
+    const int cz = i / (NB_TY * NB_TX), q = i - cz * (NB_TY * NB_TX), cy = q / NB_TX, cx = q - cy * NB_TX;
+    const int z = z0 + cz, y = y0 + cy, xx = x0 + cx;
+    if (z < D0 && y < D1 && xx < D2) {
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) acc = acc + B[((cz + a) * BY + (cy + c)) * BX + (cx + d)] * kw[27 + (a * 3 + c) * 3 + d];
+      const int64_t v = ((int64_t)z * D1 + y) * D2 + xx;
+      image[v * istride + ioff] = acc;
+      if (foff >= 0) image[v * istride + foff] = fval;
+    }
+  }
+}
+
 __global__ void outer3_kernel(const float* __restrict__ w, float* __restrict__ out, Shape3 s, int ostride, int ooff) {
   const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
@@ -620,6 +696,23 @@ int synthsr_blur3d(const float* in, float* out, const int shape[3], const float*
   const int64_t n = (int64_t)s.d[0] * s.d[1] * s.d[2];
   hipLaunchKernelGGL(blur3d_kernel, dim3(syn_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, s, kernel, ks,
                      out_stride, out_offset, fill_offset, fill_value);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_normalise_blur2(const float* x, const int shape[3], const uint32_t* minmax, float gexp, const float* kernel1,
+                            const float* kernel2, float* target, float* image, int image_stride, int image_offset,
+                            int fill_offset, float fill_value, synthsr_stream_t stream) {
+  if (!x || !minmax || !kernel1 || !kernel2 || !target || !image || bad_shape(shape)) return SYNTHSR_EINVAL;
+  if (image_stride < 1 || image_offset < 0 || image_offset >= image_stride || fill_offset >= image_stride ||
+      fill_offset == image_offset || x == target || x == image)
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int t0 = (shape[0] + NB_TZ - 1) / NB_TZ, t1 = (shape[1] + NB_TY - 1) / NB_TY, t2 = (shape[2] + NB_TX - 1) / NB_TX;
+  const int64_t tiles = (int64_t)t0 * t1 * t2;
+  if (tiles >= (1ll << 31)) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(normalise_blur2_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, s, minmax, gexp,
+                     kernel1, kernel2, target, image, image_stride, image_offset, fill_offset, fill_value, t1, t2);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

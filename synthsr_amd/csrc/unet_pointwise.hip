@@ -240,7 +240,8 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 s, float4 h) {
   return make_float4(a.x * s.x + h.x, a.y * s.y + h.y, a.z * s.z + h.z, a.w * s.w + h.w);
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n4,
                                                        int C, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps) {
@@ -1192,8 +1193,17 @@ int synthsr_bn_apply(const float* x, float* y, int64_t nvox, int C, const float*
                      const float* beta, float eps, synthsr_stream_t stream) {
   if (!x || !y || !stats || !gamma || !beta || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n4, C, stats,
+  hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n4, C, stats,
                      gamma, beta, eps);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+int synthsr_bn_apply_bf16(const void* x, void* y, int64_t nvox, int C, const float* stats, const float* gamma,
+                          const float* beta, float eps, synthsr_stream_t stream) {
+  if (!x || !y || !stats || !gamma || !beta || nvox < 1 || !ok_c4(C)) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)y, n4, C, stats, gamma, beta, eps);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }

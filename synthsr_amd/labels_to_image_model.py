@@ -163,6 +163,7 @@ class LabelsToImageModel:
             self.d_swap = torch.from_numpy(self.swap_lut.astype(np.int32)).to(dev)
         else:
             self.d_swap = None
+        self.fuse_blur = True  # one-pass normalise -> blur -> blur kernel where it applies (generate()); False: separate kernels
         self.host_rng = np.random.Generator(np.random.Philox(key=0))
         self.philox_counter = 0
         self.seed(0)
@@ -484,9 +485,23 @@ class LabelsToImageModel:
             x = fptr(self.d_chan, i * nc)
             mm = ctypes.c_void_p(self.d_minmax.data_ptr() + 8 * i)
             t0, t1, t2 = (fptr(t) for t in self.d_tmp)
+            is_target = i in self.output_channel
+            # the common case (training() defaults: the channel is the single regression target AND a network input, nothing
+            # is resampled): normalise + gamma -> blur(.5) -> target -> acquisition blur -> image (+ all-ones map) in ONE pass
+            if (self.fuse_blur and is_target and self.input_channels[i] and not self.resample_target and Ct == 1
+                    and 'down' not in plan and 'T' not in plan and 'rr' not in plan and plan.get('k_lr') is not None
+                    and len(plan['k_lr']) == 1 and list(plan['k_lr'][0][1]) == [3, 3, 3] and list(k05.shape) == [3, 3, 3]):
+                fill = img_slot + 1 if self.build_reliability_maps else -1
+                with tk('gen:normalise+blur(.5)+blur(lr)+map'):
+                    _lib.check(lib.synthsr_normalise_blur2(x, cs, mm, plan['gexp'], sm.dptr(off_k05),
+                                                           sm.dptr(plan['k_lr'][0][0]), fptr(self.d_target),
+                                                           fptr(self.d_image), Ci, img_slot, fill, 1.0, st),
+                               'normalise_blur2')
+                tgt_slot += 1
+                img_slot += 2 if self.build_reliability_maps else 1
+                continue
             with tk('gen:normalise_gamma'):
                 _lib.check(lib.synthsr_normalise_gamma(x, x, nc, mm, plan['gexp'], st), 'normalise_gamma')
-            is_target = i in self.output_channel
             # GaussianBlur(sigma=.5): target tap (labels_to_image_model.py:186-196)
             if is_target and not self.resample_target and not self.input_channels[i]:
                 _lib.check(lib.synthsr_blur3d(x, fptr(self.d_target), cs, sm.dptr(off_k05), k3, Ct, tgt_slot, -1, 0., st),

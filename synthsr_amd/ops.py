@@ -130,9 +130,18 @@ def pack_conv_weights_ex(w, shape, ci_off, cin, mode=0, up=False, out=None):
 
 
 def conv3d_up(lo, wpacked8, bias, addend, Cout, act=1, out=None):
-    """act(conv3(UpSampling3D(2)(lo)) + addend + bias) evaluated on the low-res tensor (8 parity convs)"""
+    """act(conv3(UpSampling3D(2)(lo)) + addend + bias) evaluated on the low-res tensor (8 parity convs); bf16: the raw
+    partial sums only (bias / addend / activation come with the skip-channel conv, conv3d_add)"""
     lib = _L()
     s = lo.shape
+    if lo.dtype == torch.bfloat16:
+        assert bias is None and addend is None and act == 0
+        if out is None:
+            out = torch.empty((2 * s[0], 2 * s[1], 2 * s[2], Cout), dtype=torch.bfloat16, device=lo.device)
+        with _Timed('conv3d_bf16_up_fwd', s[:3], s[3], Cout):
+            _lib.check(lib.synthsr_conv3d_bf16_up_fwd(_lib.ptr(lo), _lib.ptr(wpacked8), _lib.ptr(out), _lib.i3(s[:3]),
+                                                      int(s[3]), int(Cout), _lib.stream()), 'conv3d_bf16_up_fwd')
+        return out
     if out is None:
         out = torch.empty((2 * s[0], 2 * s[1], 2 * s[2], Cout), dtype=torch.float32, device=lo.device)
     with _Timed('conv3d_up_fwd', s[:3], s[3], Cout):
@@ -147,6 +156,18 @@ def conv3d_up_dgrad(dout, wpacked8, Cl, out=None):
     lib = _L()
     s = dout.shape
     lo_shape = (s[0] // 2, s[1] // 2, s[2] // 2)
+    if dout.dtype == torch.bfloat16:
+        if out is None:
+            out = torch.empty(lo_shape + (Cl,), dtype=torch.bfloat16, device=dout.device)
+        scratch = _bf16_scratch.get(dout.device)   # fp32 partial planes of the split-K path (small levels)
+        need = 8 * lo_shape[0] * lo_shape[1] * lo_shape[2] * int(Cl) if lo_shape[0] * lo_shape[1] * lo_shape[2] <= 32 ** 3 else 0
+        if scratch is None or scratch.numel() < need:
+            scratch = _bf16_scratch[dout.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=dout.device)
+        with _Timed('conv3d_bf16_up_dgrad', lo_shape, Cl, s[3]):
+            _lib.check(lib.synthsr_conv3d_bf16_up_dgrad(_lib.ptr(dout), _lib.ptr(wpacked8), _lib.ptr(out), _lib.i3(lo_shape),
+                                                        int(Cl), int(s[3]), _lib.ptr(scratch), scratch.numel(),
+                                                        _lib.stream()), 'conv3d_bf16_up_dgrad')
+        return out
     if out is None:
         out = torch.empty(lo_shape + (Cl,), dtype=torch.float32, device=dout.device)
     with _Timed('conv3d_up_dgrad', lo_shape, Cl, s[3]):
@@ -160,6 +181,13 @@ def conv3d_up_wgrad(lo, dout, dwc, dw, ci_off):
     lib = _L()
     s = lo.shape
     dwc.zero_()
+    if lo.dtype == torch.bfloat16:
+        with _Timed('conv3d_bf16_up_wgrad', s[:3], s[3], dout.shape[3]):
+            _lib.check(lib.synthsr_conv3d_bf16_up_wgrad(_lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]), int(s[3]),
+                                                        int(dout.shape[3]), _lib.stream()), 'conv3d_bf16_up_wgrad')
+        _lib.check(lib.synthsr_conv3d_up_unpack(_lib.ptr(dwc), _lib.ptr(dw), int(dw.shape[3]), int(ci_off), int(s[3]),
+                                                int(dout.shape[3]), _lib.stream()), 'conv3d_up_unpack')
+        return dw
     with _Timed('conv3d_up_wgrad', s[:3], s[3], dout.shape[3]):
         _lib.check(lib.synthsr_conv3d_up_wgrad(_lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]), int(s[3]),
                                                int(dout.shape[3]), _lib.stream()), 'conv3d_up_wgrad')
@@ -173,6 +201,12 @@ def conv3d_wgrad_part(x, dout, dw, ci_off, dbias=None):
     dbias [Cout] (optional) += sum over voxels of dout"""
     lib = _L()
     s = x.shape
+    if x.dtype == torch.bfloat16:
+        with _Timed('conv3d_bf16_wgrad', s[:3], s[3], dout.shape[3]):
+            _lib.check(lib.synthsr_conv3d_bf16_wgrad_part(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.ptr(dbias),
+                                                          _lib.i3(s[:3]), int(dw.shape[3]), int(ci_off), int(s[3]),
+                                                          int(dout.shape[3]), _lib.stream()), 'conv3d_bf16_wgrad_part')
+        return dw
     with _Timed('conv3d_wgrad', s[:3], s[3], dout.shape[3]):
         _lib.check(lib.synthsr_conv3d_wgrad_bias(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.ptr(dbias),
                                                  _lib.i3(s[:3]), int(dw.shape[3]), int(ci_off), int(s[3]),
@@ -213,9 +247,9 @@ def conv3d_add(x, wpacked, bias, addend, Cout, act=1, out=None):
     """act 0/1: act(conv3(x) + addend + bias), `addend` may be `out` itself (in-place accumulation);
     act 2: conv3(x) * elu'(addend) -- data gradient fused with the ELU backward of the layer that produced `addend`"""
     if x.dtype == torch.bfloat16:
-        if act != 2:
-            raise NotImplementedError('bf16: the fused addend exists for the ELU-backward epilogue only')
-        return conv3d_bf16(x, wpacked, bias, Cout, 2, below=addend, out=out)
+        if act == 0:
+            raise NotImplementedError('bf16: addend epilogues are ELU(conv + bias + addend) (act 1) and conv * ELU\'(addend) (act 2)')
+        return conv3d_bf16(x, wpacked, bias, Cout, 5 if act == 1 else 2, below=addend, out=out)
     lib = _L()
     s = x.shape
     if out is None:
@@ -279,8 +313,8 @@ def bn_apply(x, stats, gamma, beta, out=None, eps=BN_EPS):
     C = int(x.shape[-1])
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(lib.synthsr_bn_apply(_lib.ptr(x), _lib.ptr(out), x.numel() // C, C, _lib.ptr(stats), _lib.ptr(gamma),
-                                    _lib.ptr(beta), eps, _lib.stream()), 'bn_apply')
+    _lib.check(_sym('synthsr_bn_apply', x)(_lib.ptr(x), _lib.ptr(out), x.numel() // C, C, _lib.ptr(stats), _lib.ptr(gamma),
+                                           _lib.ptr(beta), eps, _lib.stream()), 'bn_apply')
     return out
 
 
@@ -644,20 +678,24 @@ def lut_gather(labels, lut, out=None):
 _bf16_scratch = {}
 
 
-def pack_conv_weights_bf16(w, mode=0, ci_off=0, cin=None, out=None):
-    """fp32 Keras kernel w [3,3,3,Cin_total,Cout] -> bf16 MFMA fragments (mode 0 forward, 1 data gradient)"""
+def pack_conv_weights_bf16(w, mode=0, ci_off=0, cin=None, out=None, up=False):
+    """fp32 Keras kernel w [3,3,3,Cin_total,Cout] -> bf16 MFMA fragments (mode 0 forward, 1 data gradient); up: the 8 parity
+    sets of the nearest-upsample folding, back to back (conv3d_up / conv3d_up_dgrad)"""
     lib = _L()
     cin_total, cout = int(w.shape[3]), int(w.shape[4])
     cin = cin_total if cin is None else int(cin)
-    n = lib.synthsr_conv3d_bf16_pack(None, None, cin_total, int(ci_off), cin, cout, int(mode), None)
+    parities = list(range(8)) if up else [-1]
+    n = lib.synthsr_conv3d_bf16_pack_ex(None, None, cin_total, int(ci_off), cin, cout, int(mode), parities[0], None)
     if n < 0:
         _lib.check(int(n), 'conv3d_bf16_pack(size)')
     if out is None:
-        out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
-    assert out.numel() == n and out.dtype == torch.bfloat16
-    r = lib.synthsr_conv3d_bf16_pack(_lib.ptr(w), _lib.ptr(out), cin_total, int(ci_off), cin, cout, int(mode), _lib.stream())
-    if r < 0:
-        _lib.check(int(r), 'conv3d_bf16_pack')
+        out = torch.empty(n * len(parities), dtype=torch.bfloat16, device=w.device)
+    assert out.numel() == n * len(parities) and out.dtype == torch.bfloat16
+    for k, par in enumerate(parities):
+        r = lib.synthsr_conv3d_bf16_pack_ex(_lib.ptr(w), _lib.ptr(out[k * n:(k + 1) * n]), cin_total, int(ci_off), cin, cout,
+                                            int(mode), par, _lib.stream())
+        if r < 0:
+            _lib.check(int(r), 'conv3d_bf16_pack')
     return out
 
 

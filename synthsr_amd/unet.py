@@ -34,8 +34,6 @@ class UNet3D:
             raise ValueError("dtype should be 'f32' or 'bf16'")
         self.bf16 = dtype == 'bf16'
         self.act_dtype = torch.bfloat16 if self.bf16 else torch.float32
-        if self.bf16:
-            fold_upsample = False  # the bf16 MFMA is 16x faster: the concatenated tensor is simply materialised
         # conv_dropout (ext/neuron/models.py:320-324, 448-451): KL.Dropout(rate, noise_shape=[None, 1, 1, 1, C]) after every
         # conv + ELU, i.e. ONE factor per feature map and step (0, or 1/(1-rate)).  A per-channel factor never has to touch
         # the activations: the factor of a conv that feeds another conv rides on that conv's input-channel weights
@@ -260,21 +258,34 @@ class UNet3D:
         from . import _lib
         lib = _lib.load()
         jobs, off, first = [], 0, True
-        for c in self.all_convs():
-            for key, mode in (('wp', 0), ('wpd', 1)):
-                if mode == 1 and first and not self.need_input_grad:  # the first layer's input normally has no gradient
-                    continue
-                job = (ctypes.c_int64 * 12)()
-                _lib.check(lib.synthsr_conv3d_bf16_pack_job(c['cin'], 0, c['cin'], c['cout'], mode, job), 'bf16_pack_job')
+
+        def add(c, key, ci_off, cin, mode, up):
+            nonlocal off
+            start = off
+            for par in (range(8) if up else (-1,)):
+                job = (ctypes.c_int64 * 13)()
+                _lib.check(lib.synthsr_conv3d_bf16_pack_job(c['cin'], ci_off, cin, c['cout'], mode, par, job), 'bf16_pack_job')
                 job[0], job[1] = self.offsets[c['w']][0], off
-                c[key + '_off'] = (off, int(job[2]))
                 off += int(job[2])
                 jobs.append([int(v) for v in job])
+            c[key + '_off'] = (start, off - start)
+
+        for c in self.all_convs():
+            if c.get('fold'):   # skip-channel half at full resolution + the 8 parity sets of the up-sampled half (conv_bf16.hip)
+                cs, cl = c['cs'], c['cin'] - c['cs']
+                add(c, 'wp_s', 0, cs, 0, False)
+                add(c, 'wpd_s', 0, cs, 1, False)
+                add(c, 'wp_u', cs, cl, 0, True)
+                add(c, 'wpd_u', cs, cl, 1, True)
+            else:
+                add(c, 'wp', 0, c['cin'], 0, False)
+                if not first or self.need_input_grad:  # the first layer's input normally has no gradient
+                    add(c, 'wpd', 0, c['cin'], 1, False)
             first = False
         self._packed_bf16 = torch.empty(off, dtype=torch.bfloat16, device=self.device)
         self._jobs_bf16 = torch.tensor(jobs, dtype=torch.int64, device=self.device)
         for c in self.all_convs():
-            for key in ('wp', 'wpd'):
+            for key in ('wp', 'wpd', 'wp_s', 'wpd_s', 'wp_u', 'wpd_u'):
                 if key + '_off' in c:
                     o, n = c[key + '_off']
                     c[key] = self._packed_bf16[o:o + n]
@@ -485,7 +496,7 @@ class UNet3D:
                 # in place with coalesced reads and applies bias + ELU
                 cur = self.buf('dec%d_0' % k, self._bshape(l) + [c0['cout']])
 
-                def folded(lo_, skip_, o_, c0=c0):
+                def folded(lo_, skip_, o_, c0=c0):   # (bf16: the partial sums are rounded to bf16 once before the addition)
                     ops.conv3d_up(lo_, c0['wp_u'], None, None, c0['cout'], 0, out=o_)
                     ops.conv3d_add(skip_, c0['wp_s'], self.view(c0['b']), o_, c0['cout'], 1, out=o_)
                 self._pb(folded, lo_bn, skip, cur)

@@ -40,24 +40,25 @@ def test_batched_unet_vs_oracle(B, feats, levels, shape, cin, fold):
         tensors.update(x=x, target=target, xs=xs)
         return net
 
-    def check(net):
-        x, target = tensors['x'], tensors['target']
-        if 'ref' not in tensors:
-            P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
-            stats = {}
-            pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats)
-            assert list(pr.shape) == [B] + list(shape) + [1]
-            lr = U.l1_loss(pr, target)
-            lr.backward()
-            tensors['ref'] = (P, stats, pr.detach(), lr.detach())
-        P, stats, pr, lr = tensors['ref']
+    def oracle(net, nudge):
+        P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+        stats, pin = {}, []
+        pr = U.unet_forward(tensors['x'], P, net.prefix, levels, 2, training=True, collect=stats, pool_inputs=pin,
+                            pool_nudge=nudge)
+        assert list(pr.shape) == [B] + list(shape) + [1]
+        lr = U.l1_loss(pr, tensors['target'])
+        lr.backward()
+        return (P, stats, pr.detach(), lr.detach()), pin
+
+    def compare(net, ref):
+        P, stats, pr, lr = ref
         err = (net.test_pred.view(B, *shape, 1).cpu() - pr).abs().max().item() / pr.abs().max().item()
         assert err < 5e-4, err
         assert abs(net.test_loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
         for nm, _, kind in net.specs:
             got = net.view(nm, net.grads).cpu().double()
-            ref = P[nm].grad.double()
-            e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            ref_g = P[nm].grad.double()
+            e = (got - ref_g).abs().max().item() / max(ref_g.abs().max().item(), 1e-12)
             # per-tensor max error relative to the tensor's max-abs; the sums run over B volumes here (more cancelling terms
             # per weight than in the single-volume tests, whose bounds are 2e-3 / 5e-3)
             assert e < (4e-3 if kind in ('kernel', 'head_w') else 8e-3), (nm, e)
@@ -67,7 +68,7 @@ def test_batched_unet_vs_oracle(B, feats, levels, shape, cin, fold):
             assert (net.bn_batch[o:o + C].cpu() - m).abs().max().item() < 1e-4 * max(1.0, m.abs().max().item())
             assert (net.bn_batch[o + C:o + 2 * C].cpu() - v).abs().max().item() < 1e-4 * max(1.0, v.abs().max().item())
 
-    net, _ = single_shot_parity(run, check)
+    net, _ = single_shot_parity(run, oracle, compare)
     xs = tensors['xs']
     # Keras' sample-variance correction uses the number of values behind the statistics: B * voxels
     l0 = float(B * np.prod(shape))

@@ -94,6 +94,69 @@ def test_conv3d_bf16_transpose_detecting(T):
     assert torch.equal(dw.cpu(), exp)
 
 
+@pytest.mark.parametrize('lo_shape,Cs,Cl,Cout', [((6, 5, 9), 24, 48, 24), ((4, 4, 8), 48, 96, 48), ((3, 2, 3), 24, 24, 48),
+                                                 ((5, 5, 5), 192, 384, 192), ((20, 20, 24), 24, 48, 24),
+                                                 ((10, 12, 20), 96, 192, 96), ((40, 40, 48), 24, 48, 24)])
+def test_upsample_folded_conv_bf16(T, lo_shape, Cs, Cl, Cout):
+    """bf16 nearest-upsample folding (synthsr_conv3d_bf16_up_fwd / _up_dgrad / _up_wgrad, _wgrad_part, the act-5 epilogue):
+    conv on concatenate([skip, UpSampling3D(2)(lo)]) = conv3(skip) + 8 parity convs on lo.  Forward, both data gradients
+    and the full weight gradient against float32 autograd on the materialised concat of the SAME bf16-rounded operands.
+    Tolerances: the up-sampled half's partial sums are rounded to bf16 once before the skip half adds them, and the 8
+    parity weight sets are bf16 roundings of SUMS of taps (the unfolded conv sums products of rounded taps): 1.5e-2 of range
+    forward / data gradients (1e-2 for the plain bf16 convs), 4e-3 weight gradient (fp32 accumulation of exact bf16 products)."""
+    torch = T
+    from synthsr_amd import ops
+    from oracle import unet_ref as U
+    g = torch.Generator().manual_seed(Cs + 7 * Cl)
+    full = tuple(2 * s for s in lo_shape)
+    skip = rbf(torch.randn(*full, Cs, generator=g))
+    lo = rbf(torch.randn(*lo_shape, Cl, generator=g))
+    w = rbf(torch.randn(3, 3, 3, Cs + Cl, Cout, generator=g) / np.sqrt(27 * (Cs + Cl)))
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(*full, Cout, generator=g)
+    sr, lr, wr = skip.clone().requires_grad_(True), lo.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = torch.nn.functional.elu(U.conv3d_same(torch.cat([sr, U.upsample2(lr)], -1), wr, b))
+    dz = rbf(dy * torch.where(yr.detach() > 0, torch.ones_like(dy), yr.detach() + 1))
+    # autograd from the (rounded) pre-activation gradient: d/dz of sum(z * dz)
+    zr = U.conv3d_same(torch.cat([sr, U.upsample2(lr)], -1), wr, b)
+    (zr * dz).sum().backward()
+    wd, sd, ld, dzd = w.cuda(), skip.cuda().bfloat16(), lo.cuda().bfloat16(), dz.cuda().bfloat16()
+    wp_s = ops.pack_conv_weights_bf16(wd, 0, 0, Cs)
+    wp_u = ops.pack_conv_weights_bf16(wd, 0, Cs, Cl, up=True)
+    y = ops.conv3d_up(ld, wp_u, None, None, Cout, act=0)
+    up_ref = U.conv3d_same(U.upsample2(lo), w[..., Cs:, :])
+    close(y.float(), up_ref, 1e-2, 'parity convs (raw partial sums)')
+    y = ops.conv3d_add(sd, wp_s, b.cuda(), y, Cout, act=1, out=y)
+    close(y.float(), yr, 1.5e-2, 'folded forward')
+    wpd_s = ops.pack_conv_weights_bf16(wd, 1, 0, Cs)
+    wpd_u = ops.pack_conv_weights_bf16(wd, 1, Cs, Cl, up=True)
+    close(ops.conv3d(dzd, wpd_s, None, Cs, act=0).float(), sr.grad, 1e-2, 'dskip')
+    close(ops.conv3d_up_dgrad(dzd, wpd_u, Cl).float(), lr.grad, 1.5e-2, 'dlo')
+    dw, db = torch.zeros(3, 3, 3, Cs + Cl, Cout, device='cuda'), torch.zeros(Cout, device='cuda')
+    ops.conv3d_wgrad_part(sd, dzd, dw, 0, dbias=db)
+    dwc = torch.empty(8, 27, Cl, Cout, device='cuda')
+    ops.conv3d_up_wgrad(ld, dzd, dwc, dw, Cs)
+    close(dw[..., :Cs, :], wr.grad[..., :Cs, :], 4e-3, 'dW (skip channels)')
+    close(dw[..., Cs:, :], wr.grad[..., Cs:, :], 4e-3, 'dW (up-sampled channels)')
+    close(db, dz.reshape(-1, Cout).sum(0), 4e-3, 'dbias')
+
+
+def test_upsample_folded_bf16_one_hot(T):
+    """asymmetric one-hot kernels through the parity convs: a swapped parity / tap / channel mapping cannot hide (exact)"""
+    torch = T
+    from synthsr_amd import ops
+    from oracle import unet_ref as U
+    lo_shape, Cl, Cout = (5, 6, 9), 24, 24
+    lo = rbf(torch.randn(*lo_shape, Cl))
+    for tap, ci, co in [((0, 1, 2), 3, 17), ((2, 0, 1), 23, 0), ((1, 1, 1), 5, 5), ((2, 2, 0), 8, 23), ((0, 0, 0), 0, 1)]:
+        w = torch.zeros(3, 3, 3, Cl, Cout)
+        w[tap[0], tap[1], tap[2], ci, co] = 1.0
+        y = ops.conv3d_up(lo.cuda().bfloat16(), ops.pack_conv_weights_bf16(w.cuda(), 0, 0, Cl, up=True), None, None, Cout,
+                          act=0).float().cpu()
+        exp = U.conv3d_same(U.upsample2(lo), w)
+        assert torch.equal(y, exp), (tap, ci, co, float((y - exp).abs().max()))
+
+
 def test_f32_to_bf16_pad(T):
     torch = T
     from synthsr_amd import ops
@@ -114,8 +177,9 @@ def _grad_report(net, P):
     return rep
 
 
+@pytest.mark.parametrize('fold', [False, True])
 @pytest.mark.parametrize('feats,levels,shape,cin', [(24, 3, (16, 16, 32), 2), (8, 2, (8, 12, 16), 1), (24, 5, (32, 32, 32), 2)])
-def test_unet_bf16_step_vs_oracle(T, feats, levels, shape, cin):
+def test_unet_bf16_step_vs_oracle(T, feats, levels, shape, cin, fold):
     """one training step of the bf16 network (bf16 activations / packed weights, fp32 accumulation, fp32 BatchNorm
     statistics, fp32 master weights and gradients) against the oracle on the same fp32 master weights, two ways:
 
@@ -133,7 +197,7 @@ def test_unet_bf16_step_vs_oracle(T, feats, levels, shape, cin):
     from oracle import unet_ref as U
     net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1,
                feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3,
-               dtype='bf16')
+               dtype='bf16', fold_upsample=fold)   # fold: nearest-upsample folding of every decoder level (no concat tensors)
     g = torch.Generator().manual_seed(11)
     for nm, v in net.named_parameters():
         if nm.endswith('/gamma'):
@@ -166,6 +230,10 @@ def test_unet_bf16_step_vs_oracle(T, feats, levels, shape, cin):
         for nm, (err, cos, kind) in rep.items():
             if tight:   # each pooling level above a layer adds a few flipped arg-max decisions (5 levels at 32^3: 0.991 / 19 %)
                 cmin, emax = (0.997, 8e-2) if levels <= 3 else (0.985, 1.0)   # deep nets: cosine only (cancelling sums)
+                if fold:   # the folded decoder convs round differently from what `quant` restates (the up-sampled half's
+                    # partial sums are rounded to bf16 before the skip half adds them; parity weights = bf16(sum of taps)):
+                    # measured 0.9909 / 11 % on the 8-feature 2-level net, 0.996+ on the 24-feature ones
+                    cmin, emax = min(cmin, 0.985), max(emax, 0.15)
                 assert cos > cmin and err < emax, '%s: gradient of %s: err %.3e cos %.5f (worst %s)' % (mode, nm, err, cos, worst)
             else:
                 assert cos > 0.9, '%s: gradient of %s: err %.3e cos %.5f (worst %s)' % (mode, nm, err, cos, worst)

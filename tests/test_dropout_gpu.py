@@ -57,29 +57,31 @@ def test_dropout_network_vs_oracle(feats, levels, shape, cin, nconv, rate, fold)
         tensors.update(x=x, target=target, sc=sc)
         return net
 
-    def check(net):
-        x, target, sc = tensors['x'], tensors['target'], tensors['sc']
-        if 'ref' not in tensors:
-            P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
-            stats = {}
-            pr = U.unet_forward(x, P, net.prefix, levels, nconv, training=True, collect=stats,
-                                dropout={k: torch.from_numpy(v) for k, v in sc.items()})
-            lr = U.l1_loss(pr, target)
-            lr.backward()
-            tensors['ref'] = (P, stats, pr.detach(), lr.detach())
-        P, stats, pr, lr = tensors['ref']
+    def oracle(net, nudge):
+        P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+        stats, pin = {}, []
+        pr = U.unet_forward(tensors['x'], P, net.prefix, levels, nconv, training=True, collect=stats,
+                            dropout={k: torch.from_numpy(v) for k, v in tensors['sc'].items()}, pool_inputs=pin,
+                            pool_nudge=nudge)
+        lr = U.l1_loss(pr, tensors['target'])
+        lr.backward()
+        tensors['stats'] = stats
+        return (P, stats, pr.detach(), lr.detach()), pin
+
+    def compare(net, ref):
+        P, stats, pr, lr = ref
         err = (net.test_pred.view(*shape, 1).cpu() - pr).abs().max().item() / pr.abs().max().item()
         assert err < 5e-4, err
         assert abs(net.test_loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
         for nm, _, kind in net.specs:
             got = net.view(nm, net.grads).cpu().double()
-            ref = P[nm].grad.double()
-            e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            ref_g = P[nm].grad.double()
+            e = (got - ref_g).abs().max().item() / max(ref_g.abs().max().item(), 1e-12)
             assert e < (2e-3 if kind in ('kernel', 'head_w') else 5e-3), (nm, e)
 
-    net, _ = single_shot_parity(run, check)
+    net, _ = single_shot_parity(run, oracle, compare)
     x, sc = tensors['x'], tensors['sc']
-    stats = tensors['ref'][1]
+    stats = tensors['stats']
     # a dropped feature has NO gradient on the input-channel slice of the kernel that consumes it
     for grp in net.enc + net.dec:
         for k in range(1, len(grp['convs'])):

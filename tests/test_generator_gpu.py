@@ -471,3 +471,32 @@ def test_abi_rejects_bad_arguments(env):
     assert lib.synthsr_resize_f32(_lib.ptr(x), _lib.ptr(x), 1, _lib.i3([2, 2, 2]), _lib.i3([2, 2, 2]), 7, None) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, 'x')
+
+
+@pytest.mark.parametrize('shape', [(32, 32, 32), (40, 24, 72), (13, 21, 35)])
+def test_fused_normalise_blur_blur_is_bit_identical(env, shape):
+    """synthsr_normalise_blur2 (one pass: normalise + gamma -> blur(.5) -> target -> acquisition blur -> image + map) against
+    the three separate kernels it replaces, through the whole generator (same draws): bit-identical image and target.
+    Shapes: tile multiples and ragged ones (tile 8 x 16 x 32)."""
+    torch, _lib, lib = env
+    from conftest import random_tape
+    from synthsr_amd.labels_to_image_model import labels_to_image_model
+    rng = np.random.default_rng(sum(shape))
+    labels = np.asarray(GEN)[rng.integers(0, len(GEN), shape)].astype(np.int32)
+    kw = dict(C2_KW)
+    kw.update(output_div_by_n=None)
+    m = labels_to_image_model(labels_shape=list(shape), input_channels=[True], output_channel=[0], generation_labels=GEN,
+                              n_neutral_labels=len(GEN), aff=np.eye(4), output_shape=None, **kw)
+    assert list(m.output_shape) == list(shape)
+    means = rng.uniform(20, 220, (len(GEN), 1)).astype(np.float32)
+    stds = rng.uniform(2, 20, (len(GEN), 1)).astype(np.float32)
+    tape = random_tape(m, rng)
+    outs = []
+    for fuse in (True, False):
+        m.fuse_blur = fuse
+        image, target, seg = m.generate(labels, means, stds, m.draws_from_tape(tape))
+        outs.append((image.clone(), target.clone(), seg.clone()))
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][1], outs[1][1]), (outs[0][1] - outs[1][1]).abs().max().item()
+    assert torch.equal(outs[0][0], outs[1][0]), (outs[0][0] - outs[1][0]).abs().max().item()
+    assert (outs[0][0][..., 1] == 1).all()

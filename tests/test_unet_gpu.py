@@ -250,16 +250,17 @@ def test_unet_loss_and_gradients_vs_autograd(T, feats, levels, shape, cin, fold)
         net.backward()
         return net
 
-    def check(net):
-        x, target = tensors['x'], tensors['target']
-        if 'ref' not in tensors:  # the oracle step: once
-            P = _copy_params(net, torch)
-            stats = {}
-            pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats)
-            lr = U.l1_loss(pr, target)
-            lr.backward()
-            tensors['ref'] = (P, stats, pr.detach(), lr.detach())
-        P, stats, pr, lr = tensors['ref']
+    def oracle(net, nudge):
+        P = _copy_params(net, torch)
+        stats, pin = {}, []
+        pr = U.unet_forward(tensors['x'], P, net.prefix, levels, 2, training=True, collect=stats, pool_inputs=pin,
+                            pool_nudge=nudge)
+        lr = U.l1_loss(pr, tensors['target'])
+        lr.backward()
+        return (P, stats, pr.detach(), lr.detach()), pin
+
+    def compare(net, ref):
+        P, stats, pr, lr = ref
         close(net.test_pred.view(*shape, 1), pr, 5e-4, 'prediction')
         assert abs(net.test_loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
         # per-tensor max error relative to the tensor's max-abs, bounded per layer type: conv / head kernels 2e-3 (fp32
@@ -268,8 +269,8 @@ def test_unet_loss_and_gradients_vs_autograd(T, feats, levels, shape, cin, fold)
         errs = {}
         for nm, _, kind in net.specs:
             got = net.view(nm, net.grads).cpu().double()
-            ref = P[nm].grad.double()
-            errs[nm] = ((got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12), kind)
+            ref_g = P[nm].grad.double()
+            errs[nm] = ((got - ref_g).abs().max().item() / max(ref_g.abs().max().item(), 1e-12), kind)
         worst_list = sorted(((e, nm) for nm, (e, _) in errs.items()), reverse=True)[:5]
         for nm, (err, kind) in errs.items():
             bound = 2e-3 if kind in ('kernel', 'head_w') else 5e-3
@@ -280,7 +281,7 @@ def test_unet_loss_and_gradients_vs_autograd(T, feats, levels, shape, cin, fold)
             close(net.bn_batch[o:o + C], stats[bn['name']][0], 1e-4, bn['name'] + ' mean')
             close(net.bn_batch[o + C:o + 2 * C], stats[bn['name']][1], 1e-4, bn['name'] + ' var')
 
-    net, _ = single_shot_parity(run, check)
+    net, _ = single_shot_parity(run, oracle, compare)
     x = tensors['x']
     # one Keras-Adam step
     p0 = net.params.clone()
@@ -351,16 +352,6 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
     x = torch.rand(*shape, 2, generator=g)
     target = torch.rand(*shape, generator=g)
     seg_target = torch.randint(0, len(gen_labels), shape, generator=g, dtype=torch.int32)  # indices, cf. the module docstring
-    segnet.bn_moving.copy_(moving.to(segnet.device))
-    # ---- oracle / autograd
-    P = {k: v.clone().float().requires_grad_(True) for k, v in net.state_dict().items() if 'moving' not in k}
-    Pseg = {k: v.clone().float() for k, v in segnet.state_dict().items()}
-    pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True)[..., 0]
-    l1 = (pr - target).abs().mean()
-    dref = U.seg_regularisation(pr, seg_target, Pseg, segnet.prefix, levels, 2, gen_labels, equivalency, m=m, M=M,
-                                fs_header=fs_header, loss_cropping=crop)
-    g_dice = torch.autograd.grad(dref, [P[nm] for nm, _, _ in net.specs], retain_graph=True)
-    (l1 + w * dref).backward()
     del net, segnet
 
     def make_run(rel_weight, dice_only):
@@ -378,24 +369,42 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
             return net
         return run
 
-    def check_total(net):
-        assert abs(float(net.test_loss.item()) - float(l1.detach())) < 1e-5
-        assert abs(float(net.test_dice.item()) - float(dref.detach())) < 2e-5, (float(net.test_dice.item()), float(dref.detach()))
+    def make_oracle(dice_only):
+        def oracle(net, nudge):          # nudge / pool inputs: the pooled levels of the trained net, then of the frozen one
+            P = {k: v.clone().float().requires_grad_(True) for k, v in net.state_dict().items() if 'moving' not in k}
+            Pseg = {k: v.clone().float() for k, v in net.test_segnet.state_dict().items()}
+            pin, pin_seg = [], []
+            n1 = levels - 1
+            pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, pool_inputs=pin,
+                                pool_nudge=None if nudge is None else nudge[:n1])[..., 0]
+            l1 = (pr - target).abs().mean()
+            dref = U.seg_regularisation(pr, seg_target, Pseg, net.test_segnet.prefix, levels, 2, gen_labels, equivalency, m=m,
+                                        M=M, fs_header=fs_header, loss_cropping=crop, pool_inputs=pin_seg,
+                                        pool_nudge=None if nudge is None else nudge[n1:])
+            (dref if dice_only else l1 + w * dref).backward()
+            return (P, l1.detach(), dref.detach()), pin + pin_seg
+        return oracle
+
+    def compare_total(net, ref):
+        P, l1, dref = ref
+        assert abs(float(net.test_loss.item()) - float(l1)) < 1e-5
+        assert abs(float(net.test_dice.item()) - float(dref)) < 2e-5, (float(net.test_dice.item()), float(dref))
         for nm, _, _ in net.specs:
             close(net.view(nm, net.grads), P[nm].grad, 2e-3, 'grad ' + nm)
 
-    def check_dice(net):
-        for (nm, _, _), gd in zip(net.specs, g_dice):
+    def compare_dice(net, ref):
+        P = ref[0]
+        for nm, _, _ in net.specs:
             if nm.endswith('likelihood/bias'):
                 continue  # a sum of cancelling contributions: compared absolutely below
-            close(net.view(nm, net.grads), gd, 3e-3, 'dice-only grad ' + nm)
+            close(net.view(nm, net.grads), P[nm].grad, 3e-3, 'dice-only grad ' + nm)
         hb = net.view(net.head['b'], net.grads).cpu()
-        assert float((hb - g_dice[-1]).abs().max()) < 1e-5
+        assert float((hb - P[net.head['b']].grad).abs().max()) < 1e-5
 
     both = lambda net: [net, net.test_segnet]
-    single_shot_parity(make_run(w, False), check_total, pool_nets=both)
+    single_shot_parity(make_run(w, False), make_oracle(False), compare_total, pool_nets=both)
     # the Dice term alone (it is ~1 % of the total gradient here): weight 1
-    single_shot_parity(make_run(1.0, True), check_dice, pool_nets=both, atomics_tol=3e-3)
+    single_shot_parity(make_run(1.0, True), make_oracle(True), compare_dice, pool_nets=both, atomics_tol=3e-3)
 
 
 @pytest.mark.gpu
