@@ -29,7 +29,8 @@ def per_kernel(path):
 
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 out = {'_note': __doc__.split('bench.py reads')[1].strip().replace('\n', ' '),
-       '_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3 --warmup 1 --no-cpu-baseline`'}
+       '_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3 --warmup 1 --no-cpu-baseline`, round %s'
+                  % (sys.argv[3] if len(sys.argv) > 3 else '?')}
 # the 160^3 24 -> 24 layers are the LARGEST dispatches of their kernels (the same kernels also run smaller layers)
 for key, kern, wide in (('conv3d_wgrad 160x160x160 Cin=24 Cout=24', 'conv3d_wgrad_p4_kernel', True),
                         ('conv3d_fwd 160x160x160 Cin=24 Cout=24', 'conv3d_fwd_p4_kernel', True),
@@ -37,8 +38,8 @@ for key, kern, wide in (('conv3d_wgrad 160x160x160 Cin=24 Cout=24', 'conv3d_wgra
     f, w = max(fetch[kern]), max(write[kern])
     out[key] = {'kernel': kern, 'fetch_kb': round(f, 1), 'write_kb': round(w, 1), 'bytes': int((2 if wide else 1) * f * 1024 + w * 1024)}
 nvox = 160 ** 3
-for kern, alg in (('deform_gmm_kernel', 12), ('normalise_gamma_kernel', 8), ('blur3d_kernel', None), ('copy_strided_kernel', 8),
-                  ('svf_step_kernel', None), ('resize_kernel', None)):
+for kern, alg in (('deform_gmm_kernel', 12), ('normalise_blur2_kernel', 16), ('normalise_gamma_kernel', 8), ('blur3d_kernel', None),
+                  ('copy_strided_kernel', 8), ('svf_step_kernel', None), ('resize_kernel', None)):
     if kern not in fetch and kern not in write:
         continue
     f = sum(fetch.get(kern, [0])) / max(len(fetch.get(kern, [0])), 1)
