@@ -159,6 +159,14 @@ def cpu_baseline(size_all=160, size_one=64, timed=3):
     par = [l.strip() for l in torch.__config__.parallel_info().splitlines() if l.strip() and ('threads' in l.lower() or
            'openmp' in l.lower() or 'mkl' in l.lower() or 'ATen parallel backend' in l)]
     aff = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
+    runs, i = [], 0                      # "0-15,32-47": the mask as ranges
+    while i < len(aff):
+        j = i
+        while j + 1 < len(aff) and aff[j + 1] == aff[j] + 1:
+            j += 1
+        runs.append('%d' % aff[i] if i == j else '%d-%d' % (aff[i], aff[j]))
+        i = j + 1
+    aff = ','.join(runs)
     return {'value': res['all']['volumes_per_s'], 'unit': 'volumes/s', 'cores': res['all']['threads'], 'kind': 'port',
             'threads': res['all']['threads'], 'usable_cpus': usable, 'physical_cores': cores, 'value_one_thread': res['one']['volumes_per_s'],
             'affinity_mask': aff, 'torch_parallel_info': par,
@@ -367,8 +375,11 @@ def main():
                                   'ms_per_volume': round(ms, 4),
                                   'kernels_ms': {k[0][4:]: round(float(np.sum(v)) / nsteps_prof, 4)
                                                  for k, v in gen_agg.items() if k[0].startswith('gen:')},
-                                  'note': 'region time includes the host-side launch gaps of ~10 small kernels; '
-                                          'traffic per kernel: profiles/pmc_traffic.json'}
+                                  'kernel_ms_sum': round(float(sum(np.sum(v) for k, v in gen_agg.items()
+                                                                   if k[0].startswith('gen:'))) / nsteps_prof, 4),
+                                  'note': 'ms_per_volume = HIP events around the whole generator call on the first profiled steps '
+                                          '(the host has just synchronised, so the ~11 launches arrive one host round trip apart);'
+                                          ' kernel_ms_sum = the kernels alone; traffic per kernel: profiles/pmc_traffic.json'}
         out = {'metric': 'training volumes/sec (160^3 fp32, 5-level U-Net)', 'value': round(world * args.steps / dt, 4),
                'unit': 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(1e3 * dt / args.steps, 3),

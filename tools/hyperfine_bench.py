@@ -115,7 +115,7 @@ def main():
                       'global_batch': 1, 'parallelism': 'dp1', 'volume': [S, S, S]},
            'roofline': roof, 'final_loss': round(float(loss.item()), 6),
            'top_kernels': [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
-                            if k not in ('flops', 'bytes')} for r in rows[:8]]}
+                            if k not in ('flops', 'bytes')} for r in rows[:24]]}
     print(json.dumps(out))
 
 
