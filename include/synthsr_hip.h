@@ -371,6 +371,18 @@ int synthsr_bn_maxpool_bwd(const float* dy, const float* x, float* dbn, const in
  * (sum dbn | sum dbn*xhat): the routed gradient is 7/8 zeros and already in registers here.  sums == NULL: plain. */
 int synthsr_bn_maxpool_bwd_ex(const float* dy, const float* x, float* dbn, const int shape[3], int C, const float* stats,
                               const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream);
+/* dbn == NULL in synthsr_bn_maxpool_bwd_ex: only the sums are produced.  synthsr_bn_pool_elu_bwd then does MaxPooling3D
+ * backward + BatchNormalization backward + ELU backward of an encoder level in one pass (ext/neuron/models.py:316-356):
+ * dz = (BN'(route(dpool)) + dy2) * ELU'(y) with y [shape][C] the conv + ELU output the BatchNorm read, dpool [shape/2][C] the
+ * gradient w.r.t. the pooled tensor, dy2 (optional) the skip connection's gradient w.r.t. y, sums as above; dbias[C]
+ * (optional) += sum over voxels of dz.  Bit-identical to bn_maxpool_bwd_ex + bn_elu_bwd, without writing and re-reading the
+ * 7/8-zero routed gradient. */
+int synthsr_bn_pool_elu_bwd(const float* dpool, const float* y, const float* dy2, float* dz, float* dbias, const int shape[3],
+                            int C, const float* stats, const float* gamma, const float* beta, const float* sums, float eps,
+                            synthsr_stream_t stream);
+int synthsr_bn_pool_elu_bwd_bf16(const void* dpool, const void* y, const void* dy2, void* dz, float* dbias, const int shape[3],
+                                 int C, const float* stats, const float* gamma, const float* beta, const float* sums, float eps,
+                                 synthsr_stream_t stream);
 /* BN backward, pass 1: sums[0..C) = sum dy, sums[C..2C) = sum dy*xhat (zeroed by caller) */
 int synthsr_bn_bwd_reduce(const float* dy, const float* x, int64_t nvox, int C, const float* stats, float eps,
                           float* sums, synthsr_stream_t stream);

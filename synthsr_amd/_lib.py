@@ -102,6 +102,8 @@ SIGNATURES = {
     'synthsr_bn_maxpool': (c_int, [_P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _S]),
     'synthsr_bn_maxpool_bwd': (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _S]),
     'synthsr_bn_maxpool_bwd_ex': (c_int, [_P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, c_float, _P, _S]),
+    'synthsr_bn_pool_elu_bwd': (c_int, [_P, _P, _P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, _P, c_float, _S]),
+    'synthsr_bn_pool_elu_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, POINTER(c_int), c_int, _P, _P, _P, _P, c_float, _S]),
     'synthsr_bn_bwd_reduce': (c_int, [_P, _P, c_int64, c_int, _P, c_float, _P, _S]),
     'synthsr_bn_bwd_apply': (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
     'synthsr_upsample_concat': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _P, _P, _P, c_float, _S]),

@@ -367,10 +367,12 @@ __global__ __launch_bounds__(RB) void bn_maxpool_bwd_sums_kernel(const T* __rest
       if (t.w > m.w) { m.w = t.w; aw = k; xa.w = r.w; }
     }
     const float4 g = ld4(dy + i * 4);
+    if (dbn) {  // nullptr: the sums only -- the routed gradient is re-derived by bn_pool_elu_bwd_kernel
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int64_t vi = ((int64_t)(2 * p0 + (k >> 2)) * s.d[1] + (2 * p1 + ((k >> 1) & 1))) * s.d[2] + (2 * p2 + (k & 1));
-      st4(dbn + vi * C + c, make_float4(ax == k ? g.x : 0.f, ay == k ? g.y : 0.f, az == k ? g.z : 0.f, aw == k ? g.w : 0.f));
+      for (int k = 0; k < 8; ++k) {
+        const int64_t vi = ((int64_t)(2 * p0 + (k >> 2)) * s.d[1] + (2 * p1 + ((k >> 1) & 1))) * s.d[2] + (2 * p2 + (k & 1));
+        st4(dbn + vi * C + c, make_float4(ax == k ? g.x : 0.f, ay == k ? g.y : 0.f, az == k ? g.z : 0.f, aw == k ? g.w : 0.f));
+      }
     }
     float4 gx;  // g * xhat(arg-max)
     gx.x = g.x * (xa.x - stats[c + 0]) * rsqrtf(stats[C + c + 0] + eps);
@@ -391,6 +393,103 @@ __global__ __launch_bounds__(RB) void bn_maxpool_bwd_sums_kernel(const T* __rest
   if (syn_det_gather(smem, 2 * C))
     for (int i = threadIdx.x; i < 2 * C; i += RB) atomicAdd(&sums[i], smem[i]);
   syn_det_gather_end(2 * C);
+}
+
+// MaxPooling3D backward + BatchNormalization backward (pass 2) + ELU backward of an encoder level in ONE pass
+// (ext/neuron/models.py:316-356: conv + ELU -> BatchNormalization -> MaxPooling3D): dz = (BN'(route(dpool)) + dy2) * ELU'(y).
+// The gradient routed to the arg-max of every 2x2x2 window is 7/8 zeros; writing it out (bn_maxpool_bwd) and reading it back
+// (elu_bwd) cost one write + one read of the level's largest tensor (2 x 393 MB at 160^3 x 24).  Here each thread owns a
+// pooling window x 4 channels: it re-derives the arg-max from y (same arithmetic as bn_maxpool_kernel: first maximum in
+// raster order of y * sc + sh), applies g <- gamma * invstd * (g - sum_dy / n - xhat * sum_dyxhat / n) to all 8 voxels
+// (sums from bn_maxpool_bwd_sums_kernel with dbn = nullptr), adds the skip connection's gradient dy2 and multiplies by
+// ELU'(y); dbias += sum dz.
+template <typename T>
+__global__ __launch_bounds__(RB) void bn_pool_elu_bwd_kernel(const T* __restrict__ dpool, const T* __restrict__ y,
+                                                             const T* __restrict__ dy2, T* __restrict__ dz,
+                                                             float* __restrict__ dbias, Shape3 s, int C,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ sums, float eps, float inv_n) {
+  extern __shared__ float smem[];  // [C]
+  const int C4 = C / 4;
+  const bool fixed = (RB % C4) == 0;
+  if (dbias)
+    for (int i = threadIdx.x; i < C; i += RB) smem[i] = 0.f;
+  __syncthreads();
+  float4 part[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+  const int o0 = s.d[0] / 2, o1 = s.d[1] / 2, o2 = s.d[2] / 2;
+  const int64_t n4 = (int64_t)o0 * o1 * o2 * C4;
+  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RB) {
+    const int c = (int)(i % C4) * 4;
+    int64_t v = i / C4;
+    const int p2 = (int)(v % o2);
+    v /= o2;
+    const int p1 = (int)(v % o1);
+    const int p0 = (int)(v / o1);
+    float4 sc, sh;
+    bn_coeff4(stats, gamma, beta, eps, C, c, sc, sh);
+    float mean[4], inv[4], gam[4], s0[4], s1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mean[k] = stats[c + k];
+      inv[k] = rsqrtf(stats[C + c + k] + eps);
+      gam[k] = gamma[c + k];
+      s0[k] = sums[c + k];
+      s1[k] = sums[C + c + k];
+    }
+    float4 r[8];
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int ax = 0, ay = 0, az = 0, aw = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t vi = ((int64_t)(2 * p0 + (k >> 2)) * s.d[1] + (2 * p1 + ((k >> 1) & 1))) * s.d[2] + (2 * p2 + (k & 1));
+      r[k] = ld4(y + vi * C + c);
+      const float4 t = fma4(r[k], sc, sh);
+      if (t.x > m.x) { m.x = t.x; ax = k; }
+      if (t.y > m.y) { m.y = t.y; ay = k; }
+      if (t.z > m.z) { m.z = t.z; az = k; }
+      if (t.w > m.w) { m.w = t.w; aw = k; }
+    }
+    const float4 g = ld4(dpool + i * 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t vi = ((int64_t)(2 * p0 + (k >> 2)) * s.d[1] + (2 * p1 + ((k >> 1) & 1))) * s.d[2] + (2 * p2 + (k & 1));
+      float gg[4] = {ax == k ? g.x : 0.f, ay == k ? g.y : 0.f, az == k ? g.z : 0.f, aw == k ? g.w : 0.f};
+      const float aa[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (aa[q] - mean[q]) * inv[q];
+        gg[q] = gam[q] * inv[q] * (gg[q] - s0[q] * inv_n - xh * s1[q] * inv_n);  // the expression of elu_bwd_kernel, bit for bit
+      }
+      if (dy2) {
+        const float4 g2 = ld4(dy2 + vi * C + c);
+        gg[0] += g2.x; gg[1] += g2.y; gg[2] += g2.z; gg[3] += g2.w;
+      }
+      float4 o;
+      o.x = gg[0] * elu_grad_from_y(aa[0]);
+      o.y = gg[1] * elu_grad_from_y(aa[1]);
+      o.z = gg[2] * elu_grad_from_y(aa[2]);
+      o.w = gg[3] * elu_grad_from_y(aa[3]);
+      st4(dz + vi * C + c, o);
+      if (dbias) {
+        if (fixed) {
+          part[0].x += o.x; part[0].y += o.y; part[0].z += o.z; part[0].w += o.w;
+        } else {
+          atomicAdd(&smem[c + 0], o.x);
+          atomicAdd(&smem[c + 1], o.y);
+          atomicAdd(&smem[c + 2], o.z);
+          atomicAdd(&smem[c + 3], o.w);
+        }
+      }
+    }
+  }
+  if (dbias) {
+    block_channel_reduce<1>(part, threadIdx.x % C4, C4, fixed, smem);
+    if (syn_det_gather(smem, C))
+      for (int i = threadIdx.x; i < C; i += RB) atomicAdd(&dbias[i], smem[i]);
+    syn_det_gather_end(C);
+  }
 }
 
 // ------------------------------------------------------------------------------------------ BN backward
@@ -985,12 +1084,27 @@ int bn_maxpool_bwd_t(const T* dy, const T* x, T* dbn, const int shape[3], int C,
 template <typename T>
 int bn_maxpool_bwd_ex_t(const T* dy, const T* x, T* dbn, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream) {
   if (!sums) return bn_maxpool_bwd_t<T>(dy, x, dbn, shape, C, stats, gamma, beta, eps, stream);
-  if (!dy || !x || !dbn || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C))
+  if (!dy || !x || !stats || !gamma || !beta || bad_shape(shape) || odd_shape(shape) || !ok_c4(C))  // dbn may be NULL: sums only
     return SYNTHSR_EINVAL;
   Shape3 s{{shape[0], shape[1], shape[2]}};
   const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
   hipLaunchKernelGGL(bn_maxpool_bwd_sums_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), 2 * C * sizeof(float),
                      (hipStream_t)stream, dy, x, dbn, s, C, stats, gamma, beta, eps, sums);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+template <typename T>
+int bn_pool_elu_bwd_t(const T* dpool, const T* y, const T* dy2, T* dz, float* dbias, const int shape[3], int C,
+                      const float* stats, const float* gamma, const float* beta, const float* sums, float eps,
+                      synthsr_stream_t stream) {
+  if (!dpool || !y || !dz || !stats || !gamma || !beta || !sums || bad_shape(shape) || odd_shape(shape) || !ok_c4(C))
+    return SYNTHSR_EINVAL;
+  Shape3 s{{shape[0], shape[1], shape[2]}};
+  const int64_t n4 = (int64_t)(s.d[0] / 2) * (s.d[1] / 2) * (s.d[2] / 2) * (C / 4);
+  const float inv_n = 1.0f / (float)((int64_t)s.d[0] * s.d[1] * s.d[2]);
+  hipLaunchKernelGGL(bn_pool_elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), C * sizeof(float),
+                     (hipStream_t)stream, dpool, y, dy2, dz, dbias, s, C, stats, gamma, beta, sums, eps, inv_n);
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }
@@ -1224,6 +1338,17 @@ int synthsr_bn_maxpool_bwd_bf16(const void* dy, const void* x, void* dbn, const 
 
 int synthsr_bn_maxpool_bwd_ex(const float* dy, const float* x, float* dbn, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream) {
   return bn_maxpool_bwd_ex_t<float>(dy, x, dbn, shape, C, stats, gamma, beta, eps, sums, stream);
+}
+int synthsr_bn_pool_elu_bwd(const float* dpool, const float* y, const float* dy2, float* dz, float* dbias, const int shape[3],
+                            int C, const float* stats, const float* gamma, const float* beta, const float* sums, float eps,
+                            synthsr_stream_t stream) {
+  return bn_pool_elu_bwd_t<float>(dpool, y, dy2, dz, dbias, shape, C, stats, gamma, beta, sums, eps, stream);
+}
+int synthsr_bn_pool_elu_bwd_bf16(const void* dpool, const void* y, const void* dy2, void* dz, float* dbias, const int shape[3],
+                                 int C, const float* stats, const float* gamma, const float* beta, const float* sums, float eps,
+                                 synthsr_stream_t stream) {
+  return bn_pool_elu_bwd_t<bf16_t>((const bf16_t*)dpool, (const bf16_t*)y, (const bf16_t*)dy2, (bf16_t*)dz, dbias, shape, C, stats,
+                                   gamma, beta, sums, eps, stream);
 }
 int synthsr_bn_maxpool_bwd_ex_bf16(const void* dy, const void* x, void* dbn, const int shape[3], int C, const float* stats, const float* gamma, const float* beta, float eps, float* sums, synthsr_stream_t stream) {
   return bn_maxpool_bwd_ex_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dbn, shape, C, stats, gamma, beta, eps, sums, stream);

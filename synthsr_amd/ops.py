@@ -300,6 +300,18 @@ def bn_elu_bwd(dy, y, stats, gamma, sums, dy2=None, dbias=None, out=None, eps=BN
     return out
 
 
+def bn_pool_elu_bwd(dpool, y, stats, gamma, beta, sums, dy2=None, dbias=None, out=None, eps=BN_EPS):
+    """MaxPooling3D backward + BN backward (pass 2) + ELU backward of an encoder level in one pass: dpool = gradient w.r.t.
+    maxpool(BN(y)), sums from bn_maxpool_bwd(..., out=False, sums=sums); bit-identical to bn_maxpool_bwd + bn_elu_bwd"""
+    s = y.shape
+    if out is None:
+        out = torch.empty_like(y)
+    _lib.check(_sym('synthsr_bn_pool_elu_bwd', y)(_lib.ptr(dpool), _lib.ptr(y), _lib.ptr(dy2), _lib.ptr(out), _lib.ptr(dbias),
+                                                  _lib.i3(s[:3]), int(s[3]), _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta),
+                                                  _lib.ptr(sums), eps, _lib.stream()), 'bn_pool_elu_bwd')
+    return out
+
+
 def bn_stats(x, stats, ws):
     lib = _L()
     C = int(x.shape[-1])
@@ -329,10 +341,14 @@ def bn_maxpool(x, stats, gamma, beta, out=None, eps=BN_EPS):
 
 
 def bn_maxpool_bwd(dy, x, stats, gamma, beta, out=None, eps=BN_EPS, sums=None):
-    """gradient of maxpool(BN(x)) w.r.t. BN(x); sums [2C] (optional, += ) = bn_reduce_bwd(result, x) for free"""
+    """gradient of maxpool(BN(x)) w.r.t. BN(x); sums [2C] (optional, += ) = bn_reduce_bwd(result, x) for free;
+    out=False (with sums): the sums only, the routed gradient is not written (bn_pool_elu_bwd re-derives it)"""
     lib = _L()
     s = x.shape
-    if out is None:
+    if out is False:
+        assert sums is not None
+        out = None
+    elif out is None:
         out = torch.empty_like(x)
     _lib.check(_sym('synthsr_bn_maxpool_bwd_ex', x)(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), _lib.i3(s[:3]), int(s[3]),
                                              _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.ptr(sums),

@@ -25,6 +25,7 @@ class UNet3D:
         self.overlap_wgrad = False  # weight gradients on a second HIP stream (see _fork): measured 0.5 ms SLOWER per step
                                     # on one MI355X (cross-stream event waits cost more than the tails they fill) ...
         self.overlap_max_voxels = 40 ** 3  # ... on the small levels only: big persistent kernels just disturb each other
+        self.fuse_pool_bwd = True  # encoder levels: max-pool + BatchNorm + ELU backward in one pass (False: separate kernels)
         self._side_stream = None
         self._side_busy = False
         # dtype 'bf16' (BASELINE.json configs[3] / [4]): activations, activation gradients and the packed conv weights are
@@ -110,8 +111,11 @@ class UNet3D:
             bn = self._add_bn('%s_bn_up_%d' % (self.prefix, k), c)
             # nearest-upsample folding of the first conv of the stage (ops.conv3d_up): 3.4x fewer FLOPs on the up-sampled
             # channels; measured faster on every level of the 160^3 network (parity = grid.z keeps the GPU filled)
+            # bf16: the folded kernels of the small deep levels are launch / latency-bound (8 parities x a handful of
+            # tiles): measured at 160^3, folding pays from a 40^3 low-res grid up (level 1: -0.2 ms, level 0: -1.3 ms per
+            # step), is neutral at 20^3 and costs 0.1 ms at 10^3 (profiles/r03_bf16_c1_bench.json.log)
             lo_vox = int(np.prod(self.shapes[l + 1]))
-            fold = (lo_vox >= 512) if fold_upsample == 'auto' else bool(fold_upsample)
+            fold = (lo_vox >= (32768 if self.bf16 else 512)) if fold_upsample == 'auto' else bool(fold_upsample)
             convs[0]['fold'] = fold
             convs[0]['cs'] = self.feats[l]
             self.dec.append(dict(convs=convs, bn=bn, level=l, fold=fold))
@@ -738,10 +742,17 @@ class UNet3D:
                 # gradient): no separate reduction pass
                 off = self.offsets[e['bn']['beta']][0]
                 sums = None if frozen else self.grads[off:off + 2 * e['bn']['C']]
-                g = ops.bn_maxpool_bwd(g, acts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
-                                       self.view(e['bn']['beta']), out=self.buf('gpool%d' % l, list(acts[-1].shape)),
-                                       sums=sums)
-                self._pending_bn = (e['bn'], self._zero_sums[:2 * e['bn']['C']] if frozen else sums)
+                if self.fuse_pool_bwd and not frozen:
+                    # only the BatchNorm-backward sums now; the routed gradient (7/8 zeros) is never written: the fused
+                    # pool + BatchNorm + ELU backward re-derives it from the pooled gradient (ops.bn_pool_elu_bwd)
+                    ops.bn_maxpool_bwd(g, acts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
+                                       self.view(e['bn']['beta']), out=False, sums=sums)
+                    self._pending_bn = (e['bn'], sums, 'pooled')
+                else:
+                    g = ops.bn_maxpool_bwd(g, acts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
+                                           self.view(e['bn']['beta']), out=self.buf('gpool%d' % l, list(acts[-1].shape)),
+                                           sums=sums)
+                    self._pending_bn = (e['bn'], self._zero_sums[:2 * e['bn']['C']] if frozen else sums)
             else:
                 g = self._bn_backward(g, acts[-1], e['bn'])
             g = self._convs_backward(g, dskips[l], e['convs'], acts, self.saved['x'][l], need_dx=(l > 0) or frozen,
@@ -790,7 +801,10 @@ class UNet3D:
         out = self.buf('dz', list(y.shape))
         pend, self._pending_bn = self._pending_bn, None
         if pend is not None:
-            bn, sums = pend
+            bn, sums = pend[:2]
+            if len(pend) > 2:  # g is the gradient w.r.t. the POOLED tensor: pool + BatchNorm + ELU backward in one pass
+                return ops.bn_pool_elu_bwd(g, y, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']), sums,
+                                           dy2=dy2, dbias=dbias, out=out)
             if g is None:  # rank-1 gradient of the head
                 dpred, whead = self._rank1
                 assert dy2 is None
