@@ -206,6 +206,8 @@ def main():
     ap.add_argument('--fold', default='auto', help="nearest-upsample folding of the decoder convs: auto | all | none")
     ap.add_argument('--log-clocks', action='store_true',
                     help='sample rocm-smi clocks / power every 2 s during the timed region (sustained runs: --steps 1000)')
+    ap.add_argument('--no-fuse-pool-bwd', action='store_true', help='A/B switch: separate max-pool / BatchNorm+ELU backward kernels')
+    ap.add_argument('--no-fuse-head-bwd', action='store_true', help='A/B switch: separate head backward pass')
     ap.add_argument('--force-allreduce', action='store_true',
                     help='initialise RCCL and run the bucketed gradient all-reduce even at world size 1 (path test)')
     args = ap.parse_args()
@@ -243,11 +245,13 @@ def main():
                batch_norm=-1, activation='elu', seed=0,
                fold_upsample={'auto': 'auto', 'all': True, 'none': False}[args.fold])
     net.overlap_wgrad = args.overlap
+    net.fuse_pool_bwd = not args.no_fuse_pool_bwd
     if world > 1:
         dist.broadcast(net.params, 0)
         net.repack()
     tr = Trainer(bg, net, lr=1e-4, distributed=world > 1 or args.force_allreduce, force_allreduce=args.force_allreduce)
     tr.make_labels_resident(pool)
+    tr.fuse_head_bwd = not args.no_fuse_head_bwd
     pick = np.random.default_rng(rank)
 
     def one_step():

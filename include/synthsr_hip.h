@@ -423,6 +423,21 @@ int synthsr_head_loss_fwd(const float* x, const int shape[3], int C, const float
                           const float* beta, float eps, const float* w, const float* b, int K, const float* residual,
                           int res_stride, const int* res_offs, const float* target, float* pred, float* dpred,
                           float* loss, int kind, const int* crop, synthsr_stream_t stream);
+/* synthsr_head_loss_fwd for ONE regression target with an l1 / l2 loss (kind 0 / 1), which also accumulates the two sums its
+ * backward pass needs: ab[0 .. C) += sum_v g[v] xhat[v][c], ab[C] += sum_v g[v] (g = dpred; ab zeroed by the caller).  The
+ * gradient w.r.t. the last BatchNorm's output is rank-1 (g[v] w[c]), so synthsr_head_bwd_from_sums(ab) yields dw (+=), db (+=)
+ * and that BatchNorm's backward sums bn_sums [2C] (+=, may be NULL) without another pass over the feature map
+ * (= synthsr_head_bwd_ex with dbn == NULL).  Only valid while dpred is not modified between the two calls. */
+int synthsr_head_loss_fwd_ab(const float* x, const int shape[3], int C, const float* stats, const float* gamma, const float* beta,
+                             float eps, const float* w, const float* b, const float* residual, int res_stride, int res_off,
+                             const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, float* ab,
+                             synthsr_stream_t stream);
+int synthsr_head_loss_fwd_ab_bf16(const void* x, const int shape[3], int C, const float* stats, const float* gamma,
+                                  const float* beta, float eps, const float* w, const float* b, const float* residual,
+                                  int res_stride, int res_off, const float* target, float* pred, float* dpred, float* loss,
+                                  int kind, const int* crop, float* ab, synthsr_stream_t stream);
+int synthsr_head_bwd_from_sums(const float* ab, int C, const float* gamma, const float* beta, const float* w, float* dw,
+                               float* db, float* bn_sums, synthsr_stream_t stream);
 /* regression_metric='ssim' (SynthSR/metrics_model.py:105-125; tf.image.ssim(max_val=1): 11x11 Gaussian window sigma 1.5,
  * 'VALID', k1 .01, k2 .03).  Building blocks, orchestrated by synthsr_amd/ops.py:ssim_loss; all volumes planar float32.
  *   products: maps [4][box] = pred, target, pred*target, pred^2 + target^2 over the (loss_cropping) box `crop`

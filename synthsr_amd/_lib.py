@@ -75,6 +75,9 @@ SIGNATURES = {
     'synthsr_bn_bwd_reduce_bf16': (c_int, [_P, _P, c_int64, c_int, _P, c_float, _P, _S]),
     'synthsr_upsample_concat_bf16': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _P, _P, _P, c_float, _S]),
     'synthsr_upsample_concat_bwd_bf16': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_head_loss_fwd_ab': (c_int, [_P, POINTER(c_int), c_int, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, POINTER(c_int), _P, _S]),
+    'synthsr_head_loss_fwd_ab_bf16': (c_int, [_P, POINTER(c_int), c_int, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, POINTER(c_int), _P, _S]),
+    'synthsr_head_bwd_from_sums': (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _S]),
     'synthsr_head_loss_fwd_bf16': (c_int, [_P, POINTER(c_int), c_int, _P, _P, _P, c_float, _P, _P, c_int, _P, c_int, POINTER(c_int), _P, _P, _P, _P, c_int, POINTER(c_int), _S]),
     'synthsr_head_bwd_multi_bf16': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _S]),
     'synthsr_head_bwd_ex_bf16': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _S]),

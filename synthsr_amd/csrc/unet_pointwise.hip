@@ -641,7 +641,11 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict_
                                                             const float* __restrict__ residual, int rs,
                                                             const float* __restrict__ target, float* __restrict__ pred,
                                                             float* __restrict__ dpred, float* __restrict__ loss,
-                                                            float inv_n, int kind, HeadBox box) {
+                                                            float inv_n, int kind, HeadBox box, float* __restrict__ ab) {
+  // ab != nullptr (K == 1): also the two sums the backward pass of this head needs, A[c] = sum_v g[v] xhat[v][c] and
+  // B = sum_v g[v] with g = d loss / d pred (ab[0 .. C) += A, ab[C] += B): the gradient w.r.t. the BatchNorm output is rank-1
+  // (g[v] w[c]), so head-weight gradients and that BatchNorm's backward sums are linear in (A, B) (head_ab_finish_kernel) and
+  // the separate pass over the last feature map (head_bwd_kernel, 393 MB at 160^3) is not needed.
   constexpr int NTMAX = K;
   const int NT = kind == 2 ? K / 2 : K;  // regression targets
   extern __shared__ float smem[];  // scale[C], shift[C], w[C][K], then the voxel tile
@@ -656,6 +660,20 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict_
   }
   __syncthreads();
   float lsum = 0.f;
+  // second phase of a pass (ab): thread = (channel quad qa, voxel lane la); la walks the tile's voxels with stride LA
+  __shared__ float gl[256];
+  const int C4h = C / 4, LA = 256 / C4h;
+  const int qa = (int)threadIdx.x % C4h, la = (int)threadIdx.x / C4h;
+  float4 apart[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+  float bsum = 0.f;
+  float amean[4] = {0.f, 0.f, 0.f, 0.f}, ainv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ab) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      amean[k] = stats[qa * 4 + k];
+      ainv[k] = rsqrtf(stats[C + qa * 4 + k] + eps);
+    }
+  }
   // 256 voxels per pass: the [256][C] slab is contiguous in memory -> coalesced float4 loads into an LDS tile with rows
   // padded to C+4 floats (conflict-free 16-byte reads), then one thread per voxel (thread-per-voxel global loads touch 48
   // cache lines per instruction and ran at 1.7 TB/s)
@@ -734,6 +752,23 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict_
 #pragma unroll
         for (int k = 0; k < K; ++k) dpred[v * K + k] = g[k];
       }
+      if (ab) {
+        gl[threadIdx.x] = g[0];
+        bsum += g[0];
+      }
+    }
+    if (ab) {
+      __syncthreads();
+      if (la < LA) {
+        for (int vl = la; vl < nv; vl += LA) {
+          const float gv = gl[vl];
+          const float4 a = *reinterpret_cast<const float4*>(tile + vl * CP + qa * 4);
+          apart[0].x += gv * ((a.x - amean[0]) * ainv[0]);
+          apart[0].y += gv * ((a.y - amean[1]) * ainv[1]);
+          apart[0].z += gv * ((a.z - amean[2]) * ainv[2]);
+          apart[0].w += gv * ((a.w - amean[3]) * ainv[3]);
+        }
+      }
     }
   }
   // one atomic per BLOCK on the single loss word: 16k same-address atomics (one per wave of a 4096-block grid) used to
@@ -744,9 +779,43 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict_
   __syncthreads();
   if (threadIdx.x == 0) wsum[0] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n;
   __syncthreads();
-  if (syn_det_gather(wsum, 1))
-    if (threadIdx.x == 0) atomicAdd(loss, wsum[0]);
-  syn_det_gather_end(1);
+  if (!ab) {
+    if (syn_det_gather(wsum, 1))
+      if (threadIdx.x == 0) atomicAdd(loss, wsum[0]);
+    syn_det_gather_end(1);
+    return;
+  }
+  // one row [A (C) | B | loss] per workgroup: ONE gather (two in a row would mix their arrival counts)
+  __shared__ float row[128];
+  for (int i = threadIdx.x; i < C + 2; i += 256) row[i] = 0.f;
+  __syncthreads();
+  block_scalar_add(bsum, &row[C]);
+  if (la >= LA) apart[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  block_channel_reduce<1>(apart, qa, C4h, true, row);
+  if (threadIdx.x == 0) row[C + 1] = wsum[0];
+  __syncthreads();
+  if (syn_det_gather(row, C + 2)) {
+    for (int i = threadIdx.x; i < C + 1; i += 256) atomicAdd(&ab[i], row[i]);
+    if (threadIdx.x == 0) atomicAdd(loss, row[C + 1]);
+  }
+  syn_det_gather_end(C + 2);
+}
+
+// backward of the 1-channel head from the sums of head_loss_fwd_kernel (see there): dw = gamma A + beta B, db = B, and the
+// BatchNorm-backward sums of the rank-1 gradient g[v] w[c]: sum = w B, sum * xhat = w A
+__global__ void head_ab_finish_kernel(const float* __restrict__ ab, int C, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ w, float* __restrict__ dw,
+                                      float* __restrict__ db, float* __restrict__ sums) {
+  const float B = ab[C];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    const float A = ab[i];
+    dw[i] += gamma[i] * A + beta[i] * B;
+    if (sums) {
+      sums[i] += w[i] * B;
+      sums[C + i] += w[i] * A;
+    }
+  }
+  if (threadIdx.x == 0) *db += B;
 }
 
 // K-channel head backward (K > 1, e.g. the intensity + spread channels of the 'laplace' loss): the gradient w.r.t. the
@@ -1146,8 +1215,9 @@ int upsample_concat_bwd_t(const T* dcat, T* dskip, T* dlo_bn, const int shape[3]
 }
 
 template <typename T>
-int head_loss_fwd_t(const T* x, const int* shape, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, const float* b, int K, const float* residual, int res_stride, const int* res_offs, const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, synthsr_stream_t stream) {
+int head_loss_fwd_t(const T* x, const int* shape, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, const float* b, int K, const float* residual, int res_stride, const int* res_offs, const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, synthsr_stream_t stream, float* ab = nullptr) {
   if (!x || !shape || !stats || !gamma || !beta || !w || !b || !target || !loss || !ok_c4(C)) return SYNTHSR_EINVAL;
+  if (ab && (K != 1 || kind == 2 || C > 120)) return SYNTHSR_EINVAL;  // the fused backward sums exist for the 1-channel l1 / l2 head
   if (shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
   if (kind < 0 || kind > 2 || K < 1 || K > 4 || (kind == 2 && (K & 1))) return SYNTHSR_EINVAL;
   const int NT = kind == 2 ? K / 2 : K;
@@ -1185,7 +1255,7 @@ int head_loss_fwd_t(const T* x, const int* shape, int C, const float* stats, con
   const dim3 grid(syn_grid(nvox, 256, head_grid()));
 #define SYN_HEAD_FWD(KK)                                                                                                 \
   hipLaunchKernelGGL((head_loss_fwd_kernel<T, KK>), grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta, \
-                     eps, w, b, residual, res_stride, target, pred, dpred, loss, inv_n, kind, box)
+                     eps, w, b, residual, res_stride, target, pred, dpred, loss, inv_n, kind, box, ab)
   switch (K) {
     case 1: SYN_HEAD_FWD(1); break;
     case 2: SYN_HEAD_FWD(2); break;
@@ -1387,6 +1457,20 @@ int synthsr_upsample_concat_bwd_bf16(const void* dcat, void* dskip, void* dlo_bn
 
 int synthsr_head_loss_fwd(const float* x, const int* shape, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, const float* b, int K, const float* residual, int res_stride, const int* res_offs, const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, synthsr_stream_t stream) {
   return head_loss_fwd_t<float>(x, shape, C, stats, gamma, beta, eps, w, b, K, residual, res_stride, res_offs, target, pred, dpred, loss, kind, crop, stream);
+}
+int synthsr_head_loss_fwd_ab(const float* x, const int* shape, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, const float* b, const float* residual, int res_stride, int res_off, const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, float* ab, synthsr_stream_t stream) {
+  if (!ab) return SYNTHSR_EINVAL;
+  return head_loss_fwd_t<float>(x, shape, C, stats, gamma, beta, eps, w, b, 1, residual, res_stride, &res_off, target, pred, dpred, loss, kind, crop, stream, ab);
+}
+int synthsr_head_loss_fwd_ab_bf16(const void* x, const int* shape, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, const float* b, const float* residual, int res_stride, int res_off, const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, float* ab, synthsr_stream_t stream) {
+  if (!ab) return SYNTHSR_EINVAL;
+  return head_loss_fwd_t<bf16_t>((const bf16_t*)x, shape, C, stats, gamma, beta, eps, w, b, 1, residual, res_stride, &res_off, target, pred, dpred, loss, kind, crop, stream, ab);
+}
+int synthsr_head_bwd_from_sums(const float* ab, int C, const float* gamma, const float* beta, const float* w, float* dw, float* db, float* bn_sums, synthsr_stream_t stream) {
+  if (!ab || !gamma || !beta || !w || !dw || !db || C < 1) return SYNTHSR_EINVAL;
+  hipLaunchKernelGGL(head_ab_finish_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, ab, C, gamma, beta, w, dw, db, bn_sums);
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
 }
 int synthsr_head_loss_fwd_bf16(const void* x, const int* shape, int C, const float* stats, const float* gamma, const float* beta, float eps, const float* w, const float* b, int K, const float* residual, int res_stride, const int* res_offs, const float* target, float* pred, float* dpred, float* loss, int kind, const int* crop, synthsr_stream_t stream) {
   return head_loss_fwd_t<bf16_t>((const bf16_t*)x, shape, C, stats, gamma, beta, eps, w, b, K, residual, res_stride, res_offs, target, pred, dpred, loss, kind, crop, stream);

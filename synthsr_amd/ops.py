@@ -410,7 +410,7 @@ LOSS_KINDS = {'l1': 0, 'l2': 1, 'laplace': 2}
 
 
 def head_loss_fwd(x, stats, gamma, beta, w, b, target, loss, kind='l1', crop=None, pred=None, dpred=None, residual=None,
-                  res_stride=1, res_off=0, eps=BN_EPS):
+                  res_stride=1, res_off=0, eps=BN_EPS, ab=None):
     """unet_likelihood + regression loss (metrics_model.py:30-132).  x [d0,d1,d2,C]; w [C,K]; target [nvox*n] for n
     regression targets: K = n ('l1', 'l2') or 2n ('laplace': intensities then spreads); crop = (begin[3], size[3]) of the
     loss_cropping box or None; residual [nvox, res_stride] with res_off = the channel (or one per target) added to the
@@ -432,6 +432,14 @@ def head_loss_fwd(x, stats, gamma, beta, w, b, target, loss, kind='l1', crop=Non
     offs = [int(res_off)] * n if np.ndim(res_off) == 0 else [int(v) for v in res_off]
     if len(offs) != n:
         raise ValueError('one residual channel per regression target is needed (%d given, %d targets)' % (len(offs), n))
+    if ab is not None:   # one l1 / l2 target: also the sums head_bwd_from_sums needs, ab [C + 1] (zeroed by the caller)
+        if K != 1 or kind == 'laplace' or ab.numel() < C + 1:
+            raise ValueError('the fused backward sums exist for the 1-channel l1 / l2 head')
+        _lib.check(_sym('synthsr_head_loss_fwd_ab', x)(_lib.ptr(x), shape, C, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps,
+                                                      _lib.ptr(w), _lib.ptr(b), _lib.ptr(residual), int(res_stride), offs[0],
+                                                      _lib.ptr(target), _lib.ptr(pred), _lib.ptr(dpred), _lib.ptr(loss),
+                                                      LOSS_KINDS[kind], box, _lib.ptr(ab), _lib.stream()), 'head_loss_fwd_ab')
+        return loss
     offs = (_lib.c_int * 4)(*(offs + [0] * (4 - n)))
     _lib.check(_sym('synthsr_head_loss_fwd', x)(_lib.ptr(x), shape, C, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps,
                                          _lib.ptr(w), _lib.ptr(b), K, _lib.ptr(residual), int(res_stride), offs,
@@ -499,6 +507,13 @@ def ssim_loss(pred, target, shape, loss, dpred, crop=None, scratch=None):
         _lib.check(lib.synthsr_ssim_combine(_lib.ptr(t1), _lib.ptr(pred), _lib.ptr(target), sh3, box, _lib.ptr(dpred), st),
                    'ssim_combine')
     return loss
+
+
+def head_bwd_from_sums(ab, gamma, beta, w, dw, db, bn_sums=None):
+    """head_bwd (dbn not materialised) from the sums head_loss_fwd(..., ab=...) accumulated: dw, db, bn_sums (+=)"""
+    C = int(gamma.numel())
+    _lib.check(_L().synthsr_head_bwd_from_sums(_lib.ptr(ab), C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(w), _lib.ptr(dw),
+                                               _lib.ptr(db), _lib.ptr(bn_sums), _lib.stream()), 'head_bwd_from_sums')
 
 
 def head_bwd_multi(dpred, x, stats, gamma, beta, w, dbn, dw, db, eps=BN_EPS):

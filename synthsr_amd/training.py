@@ -92,6 +92,7 @@ class Trainer:
         self.residual = work_with_residual_channel
         self.reducer = GradBucketReducer(net.grads, bucket_elems, force=force_allreduce) if distributed else None
         self.resident_labels = None
+        self.fuse_head_bwd = True  # the head kernel also accumulates the sums of its backward pass (UNet3D.loss)
         self.comm_events = None  # a list: (start, end) HIP events around reducer.finish() of every step (bench.py --gpus N)
 
     def _generate_batch(self, model_inputs, draws, B):
@@ -153,8 +154,10 @@ class Trainer:
         residual, rs, ro = None, 1, 0
         if self.residual is not None:
             residual, rs, ro = image, image.shape[-1], [int(c) for c in self.residual]
+        # fuse_head_bwd: nothing touches net.dpred between the loss and the backward pass unless the segmentation loss adds to it
         loss, pred = net.loss(image, target.reshape(-1), self.metric, self.loss_cropping, residual=residual,
-                              res_stride=rs, res_off=ro, want_pred=self.seg is not None)
+                              res_stride=rs, res_off=ro, want_pred=self.seg is not None,
+                              fuse_head_bwd=self.fuse_head_bwd and self.seg is None)
         if self.seg is not None:  # total = image loss + w * Dice(frozen segmentation net(prediction), labels)
             if list(seg.shape) != list(image.shape[:3]):
                 raise NotImplementedError('segmentation loss with a target resolution different from the label maps')

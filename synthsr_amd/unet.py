@@ -337,7 +337,7 @@ class UNet3D:
         self.repack()
 
     # ------------------------------------------------------------------ buffers
-    _F32_BUFS = ('loss', 'dpred', 'pred', 'loss_unused', 'zero_t', 'probs', 'dwc')
+    _F32_BUFS = ('loss', 'dpred', 'pred', 'loss_unused', 'zero_t', 'probs', 'dwc', 'head_ab')
 
     def buf(self, key, shape):
         """persistent scratch tensor: activations / activation gradients in the network's dtype, the head's outputs,
@@ -534,11 +534,15 @@ class UNet3D:
         self.saved['last'] = (low, low_bn)
         return low, low_bn
 
-    def loss(self, x, target, kind='l1', loss_cropping=None, residual=None, res_stride=1, res_off=0, want_pred=False):
+    def loss(self, x, target, kind='l1', loss_cropping=None, residual=None, res_stride=1, res_off=0, want_pred=False,
+             fuse_head_bwd=False):
         """forward + unet_likelihood + regression loss (SynthSR/metrics_model.py:30-132): kind 'l1' | 'l2' | 'laplace' | 'ssim'
         with n = target.numel() / nvox regression targets (head channels: n, or 2n for laplace = intensities, spreads);
         loss_cropping = sizes of the centred box the loss is averaged over (metrics_model.py:70-90); residual
-        [nvox, res_stride]: channel(s) res_off added to the intensities.  Returns (loss tensor[1], pred [nvox*K] | None)"""
+        [nvox, res_stride]: channel(s) res_off added to the intensities.  fuse_head_bwd (one l1 / l2 target): the head kernel
+        also accumulates the two sums backward() needs, saving its pass over the last feature map -- only valid if
+        self.dpred is NOT modified between loss() and backward() (the segmentation-regularised loss adds to it).
+        Returns (loss tensor[1], pred [nvox*K] | None)"""
         K = self.nb_labels
         nvox_in = self.batch * int(np.prod(self.input_shape[:3]))
         n = K // 2 if kind == 'laplace' else K
@@ -552,6 +556,8 @@ class UNet3D:
                                                       (target.numel() // nvox_in), K, self.final_pred_activation))
         low, bn = self.forward(x)
         nvox = low.numel() // low.shape[3]
+        C_last = int(low.shape[3])
+        self._head_ab = None
         crop = None
         if loss_cropping is not None:
             size = [int(loss_cropping)] * 3 if np.ndim(loss_cropping) == 0 else [int(v) for v in loss_cropping]
@@ -571,9 +577,13 @@ class UNet3D:
             ops.ssim_loss(pred, target, low.shape[:3], self.loss_buf, self.dpred, crop=crop,
                           scratch=lambda key, numel: self.buf(key, [numel]))
             return self.loss_buf, pred
+        self._head_ab = None
+        if fuse_head_bwd and self.training and K == 1 and kind in ('l1', 'l2') and C_last <= 120:
+            self._head_ab = self.buf('head_ab', [C_last + 1])
+            self._head_ab.zero_()
         ops.head_loss_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']), self.view(self.head['w']),
                           self.view(self.head['b']), target, self.loss_buf, kind=kind, crop=crop, pred=pred,
-                          dpred=self.dpred, residual=residual, res_stride=res_stride, res_off=res_off)
+                          dpred=self.dpred, residual=residual, res_stride=res_stride, res_off=res_off, ab=self._head_ab)
         return self.loss_buf, pred
 
     def loss_l1(self, x, target, residual=None, res_stride=1, res_off=0, want_pred=False):
@@ -678,9 +688,13 @@ class UNet3D:
             return self._backward_body(dbn, on_grad_ready)
         off = self.offsets[bn['beta']][0]
         sums = self.grads[off:off + 2 * bn['C']]
-        ops.head_bwd(self.dpred, low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
-                     self.view(self.head['w']), None, self.view(self.head['w'], G), self.view(self.head['b'], G),
-                     bn_sums=sums)
+        if getattr(self, '_head_ab', None) is not None:  # the head kernel of loss() already holds the sums (fuse_head_bwd)
+            ops.head_bwd_from_sums(self._head_ab, self.view(bn['gamma']), self.view(bn['beta']), self.view(self.head['w']),
+                                   self.view(self.head['w'], G), self.view(self.head['b'], G), bn_sums=sums)
+        else:
+            ops.head_bwd(self.dpred, low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),
+                         self.view(self.head['w']), None, self.view(self.head['w'], G), self.view(self.head['b'], G),
+                         bn_sums=sums)
         self._pending_bn = (bn, sums)
         self._rank1 = (self.dpred, self.view(self.head['w']))
         return self._backward_body(None, on_grad_ready)

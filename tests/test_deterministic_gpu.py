@@ -198,3 +198,32 @@ def test_fused_pool_bn_elu_backward_is_bit_identical(det, dtype):
     # dz is the same bit for bit; the bias gradients (sums of dz over all voxels) are added up in a different order
     d = (outs[0][1] - outs[1][1]).abs().max().item()
     assert d <= 1e-6 * outs[1][1].abs().max().item(), d
+
+
+@pytest.mark.parametrize('dtype,kind,crop', [('f32', 'l1', None), ('f32', 'l2', (20, 32, 16)), ('bf16', 'l1', None)])
+def test_fused_head_backward_sums_match_the_separate_pass(det, dtype, kind, crop):
+    """loss(..., fuse_head_bwd=True): the head kernel accumulates A[c] = sum g xhat and B = sum g on the fly and backward() takes
+    the head's gradients and the last BatchNorm's backward sums from them (synthsr_head_loss_fwd_ab + synthsr_head_bwd_from_sums)
+    instead of a second pass over the last feature map (synthsr_head_bwd_ex).  Deterministic mode: same loss bit for bit, every
+    gradient to 2e-5 of its tensor's range in fp32 (different summation order of the same 49 k terms per channel; bf16: 2e-3)."""
+    import torch
+    shape, cin = (32, 48, 32), 2
+    g = torch.Generator().manual_seed(10)
+    x = torch.rand(*shape, cin, generator=g).cuda()
+    t = torch.rand(int(np.prod(shape)), generator=g).cuda()
+    res = torch.rand(int(np.prod(shape)), 3, generator=g).cuda()
+    outs = []
+    for fuse in (True, False):
+        net = _net(dtype, 24, 3, shape, cin)
+        loss = net.loss(x, t, kind=kind, loss_cropping=crop, residual=res, res_stride=3, res_off=1, fuse_head_bwd=fuse)[0]
+        assert (net._head_ab is not None) == fuse
+        net.backward()
+        torch.cuda.synchronize()
+        outs.append((loss.clone(), net.grads.clone(), net))
+    assert torch.equal(outs[0][0], outs[1][0])
+    worst = (0.0, '')
+    for nm, _, _ in outs[0][2].specs:
+        a, b = outs[0][2].view(nm, outs[0][1]), outs[1][2].view(nm, outs[1][1])
+        worst = max(worst, (float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30), nm))
+    print('fused head sums: worst gradient difference %.2e of the range (%s)' % worst)
+    assert worst[0] <= (2e-5 if dtype == 'f32' else 2e-3), worst
