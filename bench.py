@@ -280,7 +280,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.profile_start()
+    # per-launch HIP events on the LAST 3 timed steps only (0.5 ms of host / event overhead each): by then the host runs ahead of
+    # the GPU, so a region's time is what its kernels cost in a full queue, not the host's launch cadence right after a sync
+    nprof = min(3, args.steps)
     # one HIP event per step boundary on the launch stream (= torch's current stream, which every kernel of the step is
     # launched on): per-step device times without a host sync inside the timed region
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -288,8 +290,8 @@ def main():
     loss = None
     marks[0].record()
     for i in range(args.steps):
-        if i == min(3, args.steps):  # per-launch HIP events on the first 3 timed steps only (0.5 ms of host/event overhead each)
-            ops.profile_pause()
+        if i == args.steps - nprof:
+            ops.profile_start()
         loss = one_step()
         marks[i + 1].record()
     if world > 1:
@@ -381,13 +383,13 @@ def main():
                                                  for k, v in gen_agg.items() if k[0].startswith('gen:')},
                                   'kernel_ms_sum': round(float(sum(np.sum(v) for k, v in gen_agg.items()
                                                                    if k[0].startswith('gen:'))) / nsteps_prof, 4),
-                                  'note': 'ms_per_volume = HIP events around the whole generator call on the first profiled steps '
-                                          '(the host has just synchronised, so the ~11 launches arrive one host round trip apart);'
-                                          ' kernel_ms_sum = the kernels alone; traffic per kernel: profiles/pmc_traffic.json'}
+                                  'note': 'ms_per_volume = HIP events around the whole generator call (11 launches incl. dispatch gaps) '
+                                          'on the last profiled steps; kernel_ms_sum = the kernels alone; traffic per kernel: '
+                                          'profiles/pmc_traffic.json'}
         out = {'metric': 'training volumes/sec (160^3 fp32, 5-level U-Net)', 'value': round(world * args.steps / dt, 4),
                'unit': 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(1e3 * dt / args.steps, 3),
-               # per-step device times of rank 0 (HIP events at the step boundaries; the first `profiled_steps` steps carry the
+               # per-step device times of rank 0 (HIP events at the step boundaries; the last `profiled_steps` steps carry the
                # per-launch events of the roofline measurement): value stays K steps / wall time of the whole region
                'step_ms': {'mean': round(float(step_ms.mean()), 3), 'median': round(float(np.median(step_ms)), 3),
                            'min': round(float(step_ms.min()), 3), 'max': round(float(step_ms.max()), 3),
