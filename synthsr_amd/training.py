@@ -292,8 +292,6 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
     # reference has no such restriction, SynthSR/training.py:52)
     if int(batchsize) > 1:
         for bad, what in ((segmentation_model_file is not None, 'the segmentation-regularised loss'),
-                          (regression_metric == 'ssim', "regression_metric='ssim'"),
-                          (loss_cropping not in (None, 0), 'loss_cropping'),
                           (dropout > 0, 'dropout > 0 (per-sample feature masks)')):
             if bad:
                 raise NotImplementedError('batchsize > 1 together with %s is not supported' % what)

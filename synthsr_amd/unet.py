@@ -546,8 +546,6 @@ class UNet3D:
         K = self.nb_labels
         nvox_in = self.batch * int(np.prod(self.input_shape[:3]))
         n = K // 2 if kind == 'laplace' else K
-        if self.batch > 1 and (kind == 'ssim' or loss_cropping is not None):
-            raise NotImplementedError('batches of several volumes: l1 / l2 / laplace without loss_cropping')
         if kind == 'ssim' and (K != 1 or target.numel() != nvox_in):
             raise Exception('SSIM metric does not currently support multiple channels')  # metrics_model.py:108-109
         if self.final_pred_activation != 'linear' or (kind == 'laplace' and K % 2) or target.numel() != nvox_in * n:
@@ -561,7 +559,7 @@ class UNet3D:
         crop = None
         if loss_cropping is not None:
             size = [int(loss_cropping)] * 3 if np.ndim(loss_cropping) == 0 else [int(v) for v in loss_cropping]
-            shape = [int(v) for v in low.shape[:3]]
+            shape = [int(low.shape[0]) // self.batch, int(low.shape[1]), int(low.shape[2])]   # of ONE volume of the stack
             if len(size) != 3 or any(c < 1 or c > s for c, s in zip(size, shape)):
                 raise ValueError('loss_cropping %s does not fit the output shape %s' % (size, shape))
             crop = ([int((s - c) / 2) for s, c in zip(shape, size)], size)
@@ -569,6 +567,29 @@ class UNet3D:
         self.loss_buf.zero_()
         self.dpred = self.buf('dpred', [nvox * K])
         pred = self.buf('pred', [nvox * K]) if want_pred else None
+        if self.batch > 1 and (kind == 'ssim' or crop is not None):
+            # a loss defined per volume (the centred loss_cropping box, the slice-wise SSIM windows) on a batch: volume by
+            # volume on slices of the stack -- BatchNorm statistics stay those of the whole batch -- then the mean over the
+            # batch (the reference's K.mean over [B, ...], metrics_model.py:100-125): loss and gradient times 1 / B
+            B, nvb = self.batch, nvox // self.batch
+            pred = self.buf('pred', [nvox * K])
+            stats, gam, bet = self._stats(bn), self.view(bn['gamma']), self.view(bn['beta'])
+            hw, hb = self.view(self.head['w']), self.view(self.head['b'])
+            for b_, lo_b in enumerate(low.chunk(B, 0)):
+                tgt_b = target.reshape(B, -1)[b_]
+                res_b = None if residual is None else residual.reshape(B, nvb, -1)[b_]
+                pred_b, dpred_b = pred.view(B, nvb * K)[b_], self.dpred.view(B, nvb * K)[b_]
+                if kind == 'ssim':
+                    ops.head_loss_fwd(lo_b, stats, gam, bet, hw, hb, tgt_b, self.buf('loss_unused', [1]), kind='l1', pred=pred_b,
+                                      residual=res_b, res_stride=res_stride, res_off=res_off)
+                    ops.ssim_loss(pred_b, tgt_b, lo_b.shape[:3], self.loss_buf, dpred_b, crop=crop,
+                                  scratch=lambda key, numel: self.buf(key, [numel]))
+                else:
+                    ops.head_loss_fwd(lo_b, stats, gam, bet, hw, hb, tgt_b, self.loss_buf, kind=kind, crop=crop, pred=pred_b,
+                                      dpred=dpred_b, residual=res_b, res_stride=res_stride, res_off=res_off)
+            self.loss_buf.mul_(1.0 / B)
+            self.dpred.mul_(1.0 / B)
+            return self.loss_buf, pred
         if kind == 'ssim':  # the head kernel only produces the prediction; loss and gradient come from the SSIM kernels
             pred = self.buf('pred', [nvox])
             ops.head_loss_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']),

@@ -136,3 +136,48 @@ def test_trainer_and_training_entry_point_with_batchsize_2(tmp_path):
                     path_generation_classes=str(tmp_path / 'gc.npy'), output_shape=32, n_levels=3, unet_feat_count=24,
                     nonlin_shape_factor=.125, bias_shape_factor=.125, steps_per_epoch=3, epochs=1, batchsize=2, verbose=False)
     assert net2.batch == 2 and net2.iterations == 3 and os.path.exists(os.path.join(model_dir, '001.npz'))
+
+
+@pytest.mark.parametrize('kind,crop', [('l1', (12, 10, 24)), ('l2', (16, 8, 20)), ('ssim', None), ('ssim', (14, 16, 24)),
+                                       ('laplace', (12, 10, 24))])
+def test_batched_per_volume_losses_vs_oracle(kind, crop):
+    """batchsize > 1 (SynthSR/training.py:52) with the losses that are defined per volume: loss_cropping (the centred box of
+    EVERY volume, metrics_model.py:70-90) and the slice-wise SSIM (:105-125).  Loss = mean over the batch of the per-volume
+    oracle losses; every gradient against autograd through the batched oracle network (deterministic mode, single shot)."""
+    import torch
+    from synthsr_amd import ops
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    B, shape, levels, cin = 2, (16, 16, 32), 2, 2
+    K = 2 if kind == 'laplace' else 1
+    prev = ops.set_deterministic(True)
+    try:
+        net = unet(nb_features=8, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=K, feat_mult=2,
+                   nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3)
+        g = torch.Generator().manual_seed(13)
+        for nm, v in net.named_parameters():
+            if nm.endswith('/gamma'):
+                v.copy_(torch.rand(v.shape, generator=g) + .5)
+            elif nm.endswith('/beta') or nm.endswith('/bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * .1)
+        net.repack()
+        net.set_batch(B)
+        x = torch.rand(B, *shape, cin, generator=g)
+        target = torch.rand(B, *shape, 1, generator=g)
+        xs = x.reshape(B * shape[0], shape[1], shape[2], cin).cuda()
+        loss, pred = net.loss(xs, target.reshape(-1).cuda(), kind, crop, want_pred=True)
+        loss, pred = loss.clone(), pred.clone()
+        net.backward()
+        P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+        pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True)
+        lr = sum(U.regression_loss(pr[b], target[b], kind, crop) for b in range(B)) / B
+        lr.backward()
+        assert (pred.view(B, *shape, K).cpu() - pr.detach()).abs().max().item() < 5e-4 * pr.abs().max().item()
+        assert abs(loss.item() - lr.item()) < 3e-5 * max(1.0, abs(lr.item())), (loss.item(), lr.item())
+        for nm, _, kind_ in net.specs:
+            got = net.view(nm, net.grads).cpu().double()
+            ref = P[nm].grad.double()
+            e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            assert e < (4e-3 if kind_ in ('kernel', 'head_w') else 8e-3), (nm, e)
+    finally:
+        ops.set_deterministic(prev)
