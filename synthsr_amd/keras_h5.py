@@ -479,8 +479,7 @@ def _string_list(attrs, name):
 
 def load_keras_weights(path):
     """{'<layer>/<weight>': float32 ndarray} of a Keras `save_weights()` file or of a full `model.save()` /
-    `ModelCheckpoint` file (weights under /model_weights; optimizer slots are not converted: their naming depends on
-    the Keras/TF version, and `training(checkpoint=...)` of the reference restores weights only, `by_name=True`)."""
+    `ModelCheckpoint` file (weights under /model_weights; the optimizer slots: load_keras_optimizer)."""
     f = H5File(path)
     g = f.root
     if 'layer_names' not in g.attrs and 'layer_names0' not in g.attrs and 'model_weights' in g:
@@ -497,6 +496,28 @@ def load_keras_weights(path):
                 key = layer + '/' + key
             out[key] = np.ascontiguousarray(arr, dtype=np.float32)
     return out
+
+
+def load_keras_optimizer(path):
+    """Adam slots of a full-model Keras file (`model.save()` / `ModelCheckpoint`, what SynthSR/training.py:429-439 resumes from
+    with `models.load_model`): -> (iterations, [m_i], [v_i]) or None if the file has no /optimizer_weights.  Keras 2.3.1's
+    `Adam.weights` is [iterations] + ms + vs + vhats with one entry per trainable weight of the model, IN THE ORDER OF
+    `model.trainable_weights` (keras/optimizers.py, third party: restated); the variable names differ between Keras / TF
+    versions, so the slots are taken by position and the caller checks them against its own shapes."""
+    f = H5File(path)
+    if 'optimizer_weights' not in f.root:
+        return None
+    og = f.root['optimizer_weights']
+    names = _string_list(og.attrs, 'weight_names')
+    if not names or (len(names) - 1) % 3 not in (0,) and (len(names) - 1) % 2 != 0:
+        raise H5FormatError('%s: /optimizer_weights does not look like Adam slots (%d entries)' % (path, len(names)))
+    arrays = [np.asarray(og[n].read()) for n in names]
+    it = int(np.asarray(arrays[0]).reshape(-1)[0])
+    rest = arrays[1:]
+    n = len(rest) // 3 if len(rest) % 3 == 0 else len(rest) // 2     # with / without the vhat placeholders
+    ms = [np.ascontiguousarray(a, dtype=np.float32) for a in rest[:n]]
+    vs = [np.ascontiguousarray(a, dtype=np.float32) for a in rest[n:2 * n]]
+    return it, ms, vs
 
 
 def convert(path_h5, path_npz):

@@ -208,9 +208,50 @@ def read_weights(path):
     return {k: z[k] for k in z.files}
 
 
+def keras_trainable_order(net):
+    """names of the network's trainable weights in the order of Keras' `model.trainable_weights` (layer order; Conv3D: kernel,
+    bias; BatchNormalization: gamma, beta -- this build stores beta before gamma): the order of the Adam slots in a Keras file"""
+    out = []
+    specs = [nm for nm, _, _ in net.specs]
+    i = 0
+    while i < len(specs):
+        if specs[i].endswith('/beta') and i + 1 < len(specs) and specs[i + 1].endswith('/gamma'):
+            out += [specs[i + 1], specs[i]]
+            i += 2
+        else:
+            out.append(specs[i])
+            i += 1
+    return out
+
+
+def restore_keras_optimizer(path, net):
+    """Adam moments + iteration count from a full-model Keras .h5 (SynthSR/training.py:434-439 resumes with
+    `models.load_model`, "momentum is comprised in checkpoints").  Slots are matched by position and verified by shape;
+    returns True if restored, False if the file carries none, raises if they do not fit this network."""
+    import torch
+    from .keras_h5 import load_keras_optimizer
+    slots = load_keras_optimizer(path)
+    if slots is None:
+        return False
+    it, ms, vs = slots
+    order = keras_trainable_order(net)
+    if len(ms) != len(order):
+        raise ValueError('%s: %d Adam slots for %d trainable weights' % (path, len(ms), len(order)))
+    for nm, m, v in zip(order, ms, vs):
+        shp = tuple(net.offsets[nm][1])
+        want = (1, 1, 1) + shp if nm.endswith('likelihood/kernel') and m.ndim == 5 else shp   # Keras keeps the 1x1x1 head 5-D
+        if tuple(m.shape) != want or tuple(v.shape) != want:
+            raise ValueError('%s: Adam slot of %s has shape %s, the network expects %s' % (path, nm, tuple(m.shape), want))
+        net.view(nm, net.adam_m).copy_(torch.from_numpy(m.reshape(shp)))
+        net.view(nm, net.adam_v).copy_(torch.from_numpy(v.reshape(shp)))
+    net.iterations = it
+    return True
+
+
 def load_checkpoint(path, net, by_name=True, skip=()):
-    """model.load_weights(checkpoint, by_name=True) of SynthSR/training.py:363; Adam state is restored only from our
-    own .npz checkpoints (the reference's load_weights does not restore it either)"""
+    """weights by layer name (model.load_weights(checkpoint, by_name=True), SynthSR/training.py:363) + the Adam state: from
+    our own .npz checkpoints, or from a full-model Keras .h5 (what the reference's ModelCheckpoint writes and its resume
+    path `models.load_model` restores, training.py:429-439)"""
     import torch
     z = read_weights(path)
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in z.items() if not k.startswith('optimizer/') and
@@ -222,6 +263,8 @@ def load_checkpoint(path, net, by_name=True, skip=()):
         net.adam_m.copy_(torch.from_numpy(z['optimizer/m']))
         net.adam_v.copy_(torch.from_numpy(z['optimizer/v']))
         net.iterations = int(z['optimizer/iterations'])
+    elif str(path).lower().endswith(('.h5', '.hdf5')) and not skip:
+        restore_keras_optimizer(path, net)
 
 
 def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_labels, segmentation_label_list=None,

@@ -129,6 +129,36 @@ def main():
         for n_ in names[1:]:
             og.create_dataset(n_, (5,), dtype='float32')[:] = 0.5
 
+    # 2b) a full-model file whose /optimizer_weights holds what Keras 2.3.1's Adam serialises (keras/optimizers.py, Adam.weights
+    #     = [iterations] + ms + vs + vhats; one m / v per entry of model.trainable_weights -- Conv3D: kernel, bias;
+    #     BatchNormalization: gamma, beta -- and a (1,)-shaped vhat placeholder each when amsgrad is off); variable names as
+    #     the TensorFlow backend of that version spells them ('training/Adam/m_<i>:0').  Expected slots by OUR weight names.
+    with h5py.File(os.path.join(OUT, 'keras_model_tiny_opt.h5'), 'w') as f:
+        f.attrs['keras_version'] = '2.3.1'.encode('utf8')
+        f.attrs['backend'] = 'tensorflow'.encode('utf8')
+        f.attrs['model_config'] = json.dumps({'class_name': 'Model', 'config': {'name': 'unet', 'layers': [
+            {'name': ln, 'class_name': 'Layer'} for ln, _ in layers]}}).encode('utf8')
+        f.attrs['training_config'] = json.dumps({'optimizer_config': {'class_name': 'Adam', 'config': {'lr': 1e-4}},
+                                                 'loss': 'l1'}).encode('utf8')
+        save_weights_group(f.create_group('model_weights'), layers, values)
+        trainable = [(wn, shp) for ln, ws in layers for wn, shp in ws if 'moving' not in wn]
+        og = f.create_group('optimizer_weights')
+        n = len(trainable)
+        names = (['training/Adam/iterations:0'] + ['training/Adam/m_%d:0' % i for i in range(n)] +
+                 ['training/Adam/v_%d:0' % i for i in range(n)] + ['training/Adam/vhat_%d:0' % i for i in range(n)])
+        save_attributes(og, 'weight_names', names)
+        og.create_dataset(names[0], (), dtype='int64')[()] = 4321
+        expect = {'iterations': np.array(4321)}
+        for i, (wn, shp) in enumerate(trainable):
+            m = rng.standard_normal(shp).astype(np.float32) * 1e-3
+            v = (rng.random_sample(shp).astype(np.float32) + .1) * 1e-6
+            og.create_dataset(names[1 + i], data=m)
+            og.create_dataset(names[1 + n + i], data=v)
+            og.create_dataset(names[1 + 2 * n + i], data=np.zeros(1, np.float32))
+            expect['m/' + wn[:-2]] = m
+            expect['v/' + wn[:-2]] = v
+        np.savez(os.path.join(OUT, 'keras_h5_opt_expected.npz'), **expect)
+
     # 3) the same weights through the storage features Keras does not use by default but other writers do:
     #    chunked + shuffle + gzip, chunked without filters, fletcher32, float64 / big-endian / int datasets, a str
     #    (variable-length UTF-8) attribute, a scalar numeric attribute, and chunked attribute lists

@@ -173,3 +173,47 @@ def test_unet_loads_and_saves_keras_h5(tmp_path):
                      nb_conv_per_level=2, batch_norm=-1, activation='elu', device='cuda', name='segunet',
                      final_pred_activation='linear')
         load_checkpoint(path, other)
+
+
+def test_adam_slots_of_a_full_model_file():
+    """load_keras_optimizer on a `model.save()`-layout file written by the real HDF5 library with the slot list Keras 2.3.1's
+    Adam serialises ([iterations] + ms + vs + vhats, tests/golden/gen/make_keras_h5.py): slots come back by position, and
+    training.keras_trainable_order maps them onto this build's parameter table (BatchNormalization: gamma before beta in
+    Keras, beta before gamma here).  Reference: SynthSR/training.py:429-439 (ModelCheckpoint + models.load_model)."""
+    from synthsr_amd.training import keras_trainable_order
+    from synthsr_amd.unet import UNet3D
+    it, ms, vs = keras_h5.load_keras_optimizer(os.path.join(GOLD, 'keras_model_tiny_opt.h5'))
+    exp = np.load(os.path.join(GOLD, 'keras_h5_opt_expected.npz'))
+    assert it == 4321 == int(exp['iterations'])
+    net = UNet3D(4, [16, 16, 16, 1], 3, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, table_only=True)
+    order = keras_trainable_order(net)
+    assert len(order) == len(ms) == len(vs) == len(net.specs)
+    assert order[4:6] == ['unet_bn_down_0/gamma', 'unet_bn_down_0/beta']
+    shapes = {nm: shp for nm, shp, _ in net.specs}
+    for nm, m, v in zip(order, ms, vs):
+        want = (1, 1, 1) + tuple(shapes[nm]) if nm == 'unet_likelihood/kernel' else tuple(shapes[nm])
+        assert tuple(m.shape) == want == tuple(v.shape), nm
+        assert np.array_equal(m, exp['m/' + nm]) and np.array_equal(v, exp['v/' + nm]), nm
+    assert keras_h5.load_keras_optimizer(os.path.join(GOLD, 'keras_weights_tiny.h5')) is None   # save_weights(): no slots
+
+
+@pytest.mark.gpu
+def test_resume_from_a_full_model_h5_restores_the_adam_state():
+    """training(checkpoint='NNN.h5') on a file the reference's ModelCheckpoint wrote (full model): weights by layer name AND the
+    Adam moments / iteration count, like the reference's resume path `models.load_model` (SynthSR/training.py:434-439:
+    "momentum is comprised in checkpoints")"""
+    import torch
+    from synthsr_amd.training import load_checkpoint
+    from synthsr_amd.unet import unet
+    net = unet(4, [16, 16, 16, 1], 3, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1)
+    load_checkpoint(os.path.join(GOLD, 'keras_model_tiny_opt.h5'), net)
+    exp = np.load(os.path.join(GOLD, 'keras_h5_opt_expected.npz'))
+    w = np.load(os.path.join(GOLD, 'keras_h5_expected.npz'))
+    assert net.iterations == 4321
+    for nm, shp, _ in net.specs:
+        assert np.array_equal(net.view(nm, net.adam_m).cpu().numpy(), exp['m/' + nm].reshape(shp)), nm
+        assert np.array_equal(net.view(nm, net.adam_v).cpu().numpy(), exp['v/' + nm].reshape(shp)), nm
+        assert np.array_equal(net.view(nm).cpu().numpy(), w[nm].reshape(shp)), nm
+    net.grads.fill_(1e-3)
+    net.adam_step(1e-4)
+    assert net.iterations == 4322 and torch.isfinite(net.params).all()
