@@ -134,10 +134,11 @@ def dice_loss(gt, pred, eps=1e-7):
 
 
 def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, generation_labels, label_equivalency,
-                       m=None, M=None, fs_header=False, loss_cropping=None, pool_inputs=None, pool_nudge=None):
+                       m=None, M=None, fs_header=False, loss_cropping=None, pool_inputs=None, pool_nudge=None,
+                       bn_batch_stats=False):
     """SynthSR/metrics_model.py:136-215 (add_seg_loss_to_model) for one volume: the predicted image [d0,d1,d2] is
     normalised (:152-155), optionally permuted / flipped to the FreeSurfer orientation (:158-163), pushed through the
-    FROZEN segmentation U-Net (softmax head, inference-mode BatchNorm -- third-party Keras semantics, unpinned) and
+    FROZEN segmentation U-Net (softmax head; BatchNorm on its moving averages, or with bn_batch_stats on batch statistics) and
     compared with the generator's label map by the soft Dice over the generation labels that have an equivalent
     (:187-207).  NB the reference builds the ground-truth one-hot as `segmentation_target == i` with i the INDEX of the
     generation label (:191), not its value; mirrored here.  Returns the Dice loss (scalar tensor)."""
@@ -147,7 +148,9 @@ def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, g
     x = x[..., None]
     if fs_header:
         x = torch.flip(x.permute(0, 2, 1, 3), dims=[1])
-    probs = unet_forward(x, Pseg, prefix, nb_levels, nconv, training=False, moving=Pseg, softmax=True,
+    # bn_batch_stats: the frozen network's BatchNormalization layers use the statistics of the current activations (Keras
+    # 2.3.1 with the learning phase set, `trainable = False` notwithstanding) instead of their moving averages
+    probs = unet_forward(x, Pseg, prefix, nb_levels, nconv, training=bool(bn_batch_stats), moving=Pseg, softmax=True,
                          pool_inputs=pool_inputs, pool_nudge=pool_nudge)
     if fs_header:
         probs = torch.flip(probs, dims=[1]).permute(0, 2, 1, 3)

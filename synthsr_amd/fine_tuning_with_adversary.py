@@ -129,10 +129,11 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
              lr_decay=0, epochs=100, steps_per_epoch=1000, work_with_residual_channel=None, loss_cropping=None,
              lr_generator=1e-4, lr_discriminator=1e-4, relative_weight_segmentation=0.25,
              relative_weight_discriminator=0.01, checkpoint_generator=None, gradient_penalty_weight=10,
-             first_training_ratio=100, training_ratio=10, labels_to_mask=None, seed=0, verbose=True, dtype='f32'):
+             first_training_ratio=100, training_ratio=10, labels_to_mask=None, seed=0, verbose=True, dtype='f32',
+             segnet_frozen_bn='batch'):
     """Parameters as documented in SynthSR/fine_tuning_with_adversary.py:92-283 (+ `seed`, `verbose`, `dtype`: 'bf16' runs
     the conv stacks of the generator U-Net AND the critic in bf16 (fp32 accumulation / statistics / master weights / Dense layers /
-    losses): the "mixed bf16" of BASELINE.json configs[4]).
+    losses): the "mixed bf16" of BASELINE.json configs[4]; `segnet_frozen_bn` as in synthsr_amd.training.training).
     Deviation: `work_with_residual_channel` is APPLIED here (prediction = network output + that input channel, as in
     SynthSR/training.py:260-271); the reference's adversarial script validates the argument (fine_tuning_with_adversary.py:
     256-264) and then never uses it.  Pass None for the reference's behaviour.
@@ -217,7 +218,8 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
         load_checkpoint(segmentation_model_file, seg_net)
         im = volumes.load_volume(volumes.list_images_in_folder(images_dir)[0], im_only=True)   # :378-380
         seg_reg = SegmentationRegulariser(seg_net, brain_generator.generation_labels, equivalency,
-                                          relative_weight_segmentation, m=np.percentile(im, 2), M=np.percentile(im, 98))
+                                          relative_weight_segmentation, m=np.percentile(im, 2), M=np.percentile(im, 98),
+                                          frozen_bn=segnet_frozen_bn)
     if dist_on:                       # identical replicas: rank 0's initial / loaded weights everywhere
         dist.broadcast(generator.params, 0)
         dist.broadcast(generator.bn_moving, 0)

@@ -4,10 +4,10 @@ posteriors and the generator's label map is added to the image loss with weight 
 (total = image_loss + rel_weight * dice, metrics_model.py:209).
 
 Everything runs on the device: U-Net forward / data-gradient backward through the HIP conv kernels
-(`UNet3D.predict_probs` / `backward_input`: inference-mode BatchNorm, no weight gradients), head softmax, Dice sums and
+(`UNet3D.predict_probs` / `backward_input`: no weight gradients; BatchNorm on batch statistics like Keras' learning phase, or
+on the moving averages: `frozen_bn`), head softmax, Dice sums and
 their backward in `csrc/unet_pointwise.hip`.  The reference's quirk is kept: the ground-truth one-hot of generation
 label number i is `segmentation_target == i` (the INDEX, metrics_model.py:191), not `== generation_labels[i]`.
-Keras semantics of the frozen network's BatchNorm (inference statistics) are third-party and unpinned.
 """
 import numpy as np
 
@@ -16,8 +16,16 @@ from . import ops
 
 class SegmentationRegulariser:
     def __init__(self, seg_net, generation_labels, segmentation_label_equivalency, rel_weight, m=None, M=None,
-                 fs_header=False):
+                 fs_header=False, frozen_bn='batch'):
+        """frozen_bn: what the frozen network's BatchNormalization layers normalise with.  'batch' (default): the statistics
+        of the current activations -- Keras 2.3.1 semantics of a non-trainable BatchNormalization inside a model being fitted
+        (learning phase 1; `trainable = False` only stops the updates), i.e. what SynthSR/training.py:371-409 +
+        metrics_model.py:136-215 compute; 'inference': the moving averages stored in the segmentation model.  Both are pinned by
+        the reference graph executed on the shim (tests/golden/unet_seg_loss.npz: `*_bnbatch_*`, `*_bninf_*`)."""
         import torch
+        if frozen_bn not in ('batch', 'inference'):
+            raise ValueError("frozen_bn should be 'batch' or 'inference'")
+        self.batch_stats = frozen_bn == 'batch'
         self.torch = torch
         self.net = seg_net
         seg_net.training = False
@@ -70,7 +78,7 @@ class SegmentationRegulariser:
         net = self.net
         if list(xs.shape) != net.input_shape[:3]:
             raise ValueError('segmentation network built for %s, prediction is %s' % (net.input_shape[:3], list(xs.shape)))
-        probs = net.predict_probs(xs[..., None].contiguous())
+        probs = net.predict_probs(xs[..., None].contiguous(), batch_stats=self.batch_stats)
         if loss_cropping is not None:
             # outside the box: no ground-truth class (label -1) and zero posteriors, which removes those voxels from both
             # Dice sums and - the softmax Jacobian p_i (delta_ij - p_j) vanishing with p - from the gradient

@@ -278,11 +278,14 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
              bias_shape_factor=0.03125, n_levels=5, nb_conv_per_level=2, conv_size=3, unet_feat_count=24,
              feat_multiplier=2, dropout=0, activation='elu', lr=1e-4, lr_decay=0, epochs=100, steps_per_epoch=1000,
              regression_metric='l1', work_with_residual_channel=None, loss_cropping=None, checkpoint=None,
-             model_file_has_different_lhood_layer=False, seed=0, verbose=True, dtype='f32', deterministic=False):
+             model_file_has_different_lhood_layer=False, seed=0, verbose=True, dtype='f32', deterministic=False,
+             segnet_frozen_bn='batch'):
     """Parameters as documented in SynthSR/training.py:90-240 (+ `seed`, `verbose`, `dtype`: 'f32' like the reference, or
     'bf16' = bf16 activations / packed weights with fp32 accumulation, BatchNorm statistics and master weights,
     BASELINE.json configs[3]; `deterministic`: bit-identical weights run after run for the same seed, ops.set_deterministic,
-    3-4x slower at 160^3 -- not with the segmentation-regularised loss)."""
+    1.2x (fp32) / 1.4x (bf16) slower at 160^3 -- not with the segmentation-regularised loss; `segnet_frozen_bn`: what the frozen
+    segmentation network's BatchNormalization normalises with, 'batch' = the statistics of its own activations, which is what
+    Keras 2.3.1 does to a trainable=False BatchNormalization under fit(), or 'inference' = its moving averages)."""
     import torch
     if deterministic:  # process-wide switch: on for the duration of this call, previous setting restored on the way out
         if segmentation_model_file is not None:
@@ -419,7 +422,8 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
             m, M = np.percentile(im, 2), np.percentile(im, 98)
         seg_reg = SegmentationRegulariser(seg_net, brain_generator.generation_labels,
                                           hm.load_array_if_path(segmentation_label_equivalency),
-                                          relative_weight_segmentation, m=m, M=M, fs_header=fs_header_segnet)
+                                          relative_weight_segmentation, m=m, M=M, fs_header=fs_header_segnet,
+                                          frozen_bn=segnet_frozen_bn)
     if loss_cropping == 0:
         loss_cropping = None
     trainer = Trainer(brain_generator, net, lr, lr_decay, work_with_residual_channel, distributed=dist_on,

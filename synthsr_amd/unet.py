@@ -25,6 +25,10 @@ class UNet3D:
         self.overlap_wgrad = False  # weight gradients on a second HIP stream (see _fork): measured 0.5 ms SLOWER per step
                                     # on one MI355X (cross-stream event waits cost more than the tails they fill) ...
         self.overlap_max_voxels = 40 ** 3  # ... on the small levels only: big persistent kernels just disturb each other
+        # frozen use (segmentation network of the segmentation-regularised loss) with BatchNorm on BATCH statistics: what Keras
+        # 2.3.1 does with a non-trainable BatchNormalization while the learning phase is 1 (`trainable` only stops the
+        # weight / moving-average updates, keras/layers/normalization.py) -- predict_probs(batch_stats=True)
+        self.frozen_batch_stats = False
         self.fuse_pool_bwd = True  # encoder levels: max-pool + BatchNorm + ELU backward in one pass (False: separate kernels)
         self._side_stream = None
         self._side_busy = False
@@ -352,7 +356,7 @@ class UNet3D:
 
     def _stats(self, bn):
         o, C = bn['soff'], bn['C']
-        src = self.bn_batch if self.training else self.bn_moving
+        src = self.bn_batch if (self.training or self.frozen_batch_stats) else self.bn_moving
         return src[o:o + 2 * C]
 
     # ------------------------------------------------------------------ batches of volumes (SynthSR/training.py: batchsize)
@@ -642,12 +646,23 @@ class UNet3D:
             self._jobs_bf16 = None
             self.repack()
 
-    def predict_probs(self, x):
-        """inference forward of a softmax-headed network: x [d0,d1,d2,Cin] -> probs [nvox, nb_labels] (activations are kept
-        for backward_input)"""
+    def predict_probs(self, x, batch_stats=False):
+        """forward of a (frozen) softmax-headed network: x [d0,d1,d2,Cin] -> probs [nvox, nb_labels] (activations are kept
+        for backward_input).  batch_stats: BatchNorm normalises with the statistics of x's own activations (a frozen Keras
+        network inside a model that is being fitted) instead of the moving averages; nothing is updated either way"""
         assert self.nb_labels > 1
-        self.training = False
-        low, bn = self.forward(x)
+        self.frozen_batch_stats = bool(batch_stats)
+        if batch_stats:
+            if self.conv_dropout > 0:
+                raise NotImplementedError('a frozen network with batch statistics and dropout')
+            self.training = True      # the forward pass gathers the batch statistics (conv epilogues / bn_stats)
+            try:
+                low, bn = self.forward(x)
+            finally:
+                self.training = False
+        else:
+            self.training = False
+            low, bn = self.forward(x)
         nvox = low.numel() // low.shape[3]
         probs = self.buf('probs', [nvox, self.nb_labels])
         ops.seg_head_fwd(low, self._stats(bn), self.view(bn['gamma']), self.view(bn['beta']), self.view(self.head['w']),
@@ -658,7 +673,7 @@ class UNet3D:
         """gradient w.r.t. the network input of a loss whose gradient w.r.t. the LAST BatchNorm output is `dbn`
         [d0,d1,d2,C]; the network is frozen: inference-mode BatchNorm (moving statistics), no weight gradients"""
         assert self.need_input_grad and not self.training
-        return self.backward(g_last=dbn, frozen=True)
+        return self.backward(g_last=dbn, frozen=True)   # BatchNorm as in the forward pass (predict_probs: batch_stats)
 
     # ------------------------------------------------------------------ backward
     def backward(self, on_grad_ready=None, g_last=None, frozen=False):
@@ -698,6 +713,7 @@ class UNet3D:
         if frozen:
             if getattr(self, '_zero_sums', None) is None:
                 self._zero_sums = torch.zeros(2 * max(b['C'] for b in self.bn_layers), device=self.device)
+                self._frozen_sums = torch.zeros_like(self._zero_sums)
             return self._backward_body(g_last, on_grad_ready)
         G.zero_()
         # the gradient w.r.t. the last BatchNorm output is rank-1 (dpred[v] * w_head[c]): it is neither stored nor
@@ -777,6 +793,9 @@ class UNet3D:
                 # gradient): no separate reduction pass
                 off = self.offsets[e['bn']['beta']][0]
                 sums = None if frozen else self.grads[off:off + 2 * e['bn']['C']]
+                if frozen and self.frozen_batch_stats:  # batch-statistics BatchNorm: its backward needs the two sums
+                    sums = self._frozen_sums[:2 * e['bn']['C']]
+                    sums.zero_()
                 if self.fuse_pool_bwd and not frozen:
                     # only the BatchNorm-backward sums now; the routed gradient (7/8 zeros) is never written: the fused
                     # pool + BatchNorm + ELU backward re-derives it from the pooled gradient (ops.bn_pool_elu_bwd)
@@ -787,7 +806,7 @@ class UNet3D:
                     g = ops.bn_maxpool_bwd(g, acts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
                                            self.view(e['bn']['beta']), out=self.buf('gpool%d' % l, list(acts[-1].shape)),
                                            sums=sums)
-                    self._pending_bn = (e['bn'], self._zero_sums[:2 * e['bn']['C']] if frozen else sums)
+                    self._pending_bn = (e['bn'], self._zero_sums[:2 * e['bn']['C']] if (frozen and sums is None) else sums)
             else:
                 g = self._bn_backward(g, acts[-1], e['bn'])
             g = self._convs_backward(g, dskips[l], e['convs'], acts, self.saved['x'][l], need_dx=(l > 0) or frozen,
@@ -822,7 +841,14 @@ class UNet3D:
         """pass 1 (channel sums = dbeta | dgamma); pass 2 is fused into the ELU backward of the conv that produced x"""
         if g is None:  # rank-1 head gradient: head_bwd already produced the sums (backward())
             return None
-        if getattr(self, '_frozen', False):  # inference-mode BatchNorm: dx = gamma * invstd * dy, i.e. zero batch sums
+        if getattr(self, '_frozen', False):
+            if self.frozen_batch_stats:     # batch-statistics BatchNorm of a frozen network: the full backward, no parameter gradients
+                sums = self._frozen_sums[:2 * bn['C']]
+                sums.zero_()
+                ops.bn_reduce_bwd(g, x, self._stats(bn), sums)
+                self._pending_bn = (bn, sums)
+                return g
+            # inference-mode BatchNorm: dx = gamma * invstd * dy, i.e. zero batch sums
             self._pending_bn = (bn, self._zero_sums[:2 * bn['C']])
             return g
         off = self.offsets[bn['beta']][0]

@@ -143,7 +143,7 @@ def test_oracle_training_graph_vs_reference(gen_labels):
 def test_oracle_segmentation_loss_vs_reference():
     """metrics_model + add_seg_loss_to_model (metrics_model.py:136-215) with DiceLoss (layers.py:1264-1379): plain,
     clipped / normalised, FreeSurfer orientation, loss cropping.  'bninf' = the frozen network's BatchNorm uses its
-    moving statistics (what synthsr_amd implements); 'bnbatch' (batch statistics) is recorded for reference"""
+    moving statistics; 'bnbatch' = batch statistics (Keras 2.3.1 under fit; the default of SegmentationRegulariser)"""
     g = load_golden('unet_seg_loss')
     P = {k: tt(v) for k, v in golden_weights(g, 'sg_w:').items()}
     P['unet_likelihood/kernel'] = P['unet_likelihood/kernel'].reshape(P['unet_likelihood/kernel'].shape[-2:])
@@ -163,6 +163,11 @@ def test_oracle_segmentation_loss_vs_reference():
         total = float(image_loss) + .25 * float(dice)
         assert abs(total - float(g[tag + '_bninf_total'])) < 5e-6, (tag, total, float(g[tag + '_bninf_total']))
         assert abs(float(g[tag + '_bnbatch_total']) - float(g[tag + '_bninf_total'])) > 1e-3   # the two modes differ
+        # Keras' learning phase: the frozen network normalises with the statistics of its own activations
+        dice_b = U.seg_regularisation(pred[..., 0], seg, Ps, 'unet', 2, 2, g['sg_gen_labels'], g['sg_seg_labels'],
+                                      m=m, M=M, fs_header=bool(g['sg_fs'][i]), loss_cropping=crop, bn_batch_stats=True)
+        total_b = float(image_loss) + .25 * float(dice_b)
+        assert abs(total_b - float(g[tag + '_bnbatch_total'])) < 5e-6, (tag, total_b, float(g[tag + '_bnbatch_total']))
 
 
 def _critic_params(g, tag):

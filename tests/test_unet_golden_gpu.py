@@ -174,14 +174,15 @@ def test_segmentation_loss_vs_reference(T):
         m = None if np.isnan(g['sg_m'][i]) else float(g['sg_m'][i])
         M = None if np.isnan(g['sg_M'][i]) else float(g['sg_M'][i])
         crop = None if not g['sg_crop'][i].any() else [int(v) for v in g['sg_crop'][i]]
-        reg = SegmentationRegulariser(segnet, g['sg_gen_labels'], g['sg_seg_labels'], .25, m=m, M=M,
-                                      fs_header=bool(g['sg_fs'][i]))
-        loss, pred = net.loss(image, target, 'l1', crop, want_pred=True)
-        close(pred.view(*S, 1), g[tag + '_bninf_pred'], name=tag + ' prediction')
-        assert abs(loss.item() - float(g[tag + '_bninf_image_loss'])) < 1e-5
-        dice = reg(pred, seg, net.dpred, crop)
-        total = loss.item() + .25 * float(dice.item())
-        assert abs(total - float(g[tag + '_bninf_total'])) < 2e-5, (tag, total, float(g[tag + '_bninf_total']))
+        for mode, key in (('inference', 'bninf'), ('batch', 'bnbatch')):   # the frozen network's BatchNorm: both Keras readings
+            reg = SegmentationRegulariser(segnet, g['sg_gen_labels'], g['sg_seg_labels'], .25, m=m, M=M,
+                                          fs_header=bool(g['sg_fs'][i]), frozen_bn=mode)
+            loss, pred = net.loss(image, target, 'l1', crop, want_pred=True)
+            close(pred.view(*S, 1), g[tag + '_bninf_pred'], name=tag + ' prediction')
+            assert abs(loss.item() - float(g[tag + '_bninf_image_loss'])) < 1e-5
+            dice = reg(pred, seg, net.dpred, crop)
+            total = loss.item() + .25 * float(dice.item())
+            assert abs(total - float(g[tag + '_%s_total' % key])) < 2e-5, (tag, mode, total, float(g[tag + '_%s_total' % key]))
 
 
 @pytest.mark.parametrize('tag', ['cr_l4', 'cr_small', 'cr_mask'])

@@ -319,11 +319,14 @@ def test_training_reduces_loss(T):
     assert losses[-1] < losses[0]
 
 
-@pytest.mark.parametrize('fs_header,clip,crop', [(False, False, None), (True, True, None), (True, False, (12, 16, 20)),
-                                                 (False, True, (8, 24, 12))])
-def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
+@pytest.mark.parametrize('fs_header,clip,crop,frozen_bn', [(False, False, None, 'batch'), (True, True, None, 'inference'),
+                                                           (True, False, (12, 16, 20), 'batch'),
+                                                           (False, True, (8, 24, 12), 'inference'),
+                                                           (True, True, (8, 24, 12), 'batch')])
+def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop, frozen_bn):
     """SynthSR/metrics_model.py:136-215: L1 + w * Dice(frozen segmentation U-Net(prediction), label map).  Loss value and
-    every gradient of the TRAINED network against torch autograd through the oracle (frozen net in inference mode).
+    every gradient of the TRAINED network against torch autograd through the oracle; the frozen network's BatchNorm on batch
+    statistics (Keras' learning phase, the default) or on its moving averages.
     Single shot in deterministic mode; on the atomics path the pooling choices of BOTH networks are compared
     (conftest.single_shot_parity)"""
     torch = T
@@ -358,7 +361,8 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
         def run():
             net, segnet = nets()
             segnet.bn_moving.copy_(moving.to(segnet.device))
-            reg = SegmentationRegulariser(segnet, gen_labels, equivalency, rel_weight, m=m, M=M, fs_header=fs_header)
+            reg = SegmentationRegulariser(segnet, gen_labels, equivalency, rel_weight, m=m, M=M, fs_header=fs_header,
+                                          frozen_bn=frozen_bn)
             loss, pred = net.loss_l1(x.cuda(), target.cuda().reshape(-1), want_pred=True)
             if dice_only:  # image-loss gradient zeroed
                 net.dpred.zero_()
@@ -380,7 +384,8 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop):
             l1 = (pr - target).abs().mean()
             dref = U.seg_regularisation(pr, seg_target, Pseg, net.test_segnet.prefix, levels, 2, gen_labels, equivalency, m=m,
                                         M=M, fs_header=fs_header, loss_cropping=crop, pool_inputs=pin_seg,
-                                        pool_nudge=None if nudge is None else nudge[n1:])
+                                        pool_nudge=None if nudge is None else nudge[n1:],
+                                        bn_batch_stats=frozen_bn == 'batch')
             (dref if dice_only else l1 + w * dref).backward()
             return (P, l1.detach(), dref.detach()), pin + pin_seg
         return oracle
