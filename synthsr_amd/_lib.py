@@ -157,6 +157,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get('SYNTHSR_CONV_SPLIT') == '1':   # TEMPORARY switch while the split path is being brought up
+        lib.synthsr_conv3d_set_option(8, 1)
     _lib = lib
     return lib
 

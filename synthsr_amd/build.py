@@ -18,6 +18,7 @@ SOURCES = [('generator.hip', ['-ffp-contract=off']),
            ('ssim.hip', []),
            ('critic.hip', []),
            ('conv_bf16.hip', []),
+           ('conv_split.hip', []),
            ('conv3d.hip', [])]
 
 

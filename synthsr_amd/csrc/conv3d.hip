@@ -110,6 +110,33 @@ __device__ __forceinline__ float weight_value(const float* __restrict__ w, int t
 __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
                                             int Cout, int mode, int CK, int ncc, int NT, int parity, int NV,
                                             int64_t mfma_count) {
+  if (NT <= -100) {
+    // split layout (conv_split.hip): bf16 A fragments of the three pieces of every weight, two bf16 per float slot --
+    // [piece 3][co-chunk][cc][step 7][mt][lane 64][8]; lane = (m = lane & 15 -> output channel, g = lane >> 4 -> tap syn_split_tap(4 step + g)),
+    // value j -> input channel cc*8 + j.  `mfma_count` carries the number of co-chunks.
+    const int MT = -100 - NT, nchunks = (int)mfma_count;
+    uint32_t r = (uint32_t)idx * 2u;
+    const int j = (int)(r & 7);
+    r >>= 3;
+    const int lane = (int)(r & 63);
+    r >>= 6;
+    const int mt = (int)(r % MT);
+    r /= MT;
+    const int step = (int)(r % 7);
+    r /= 7;
+    const int cc = (int)(r % ncc);
+    r /= ncc;
+    const int chunk = (int)(r % nchunks), piece = (int)(r / nchunks);
+    const int tap = syn_split_tap(4 * step + (lane >> 4)), coe = (chunk * MT + mt) * 16 + (lane & 15);
+    float v0 = 0.f, v1 = 0.f;
+    if (tap >= 0) {
+      v0 = weight_value(w, tap, cc * 8 + j, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
+      v1 = weight_value(w, tap, cc * 8 + j + 1, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
+    }
+    uint32_t pc[3];
+    syn_split3(v0, v1, pc[0], pc[1], pc[2]);
+    return __uint_as_float(pc[piece]);
+  }
   if (NT < 0) {
     // first-layer layout (conv3d_fwd_c2_kernel, Cin = -NT <= 2, Cout = 24): [r][lane 64], G = r*16 + (lane >> 2) =
     // k*6 + g with k = tap*Cin + ci; output channels 4g + (lane & 3); zero beyond k = 27*Cin
@@ -2784,13 +2811,20 @@ static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
 static int g_ks_target = 1024;  // option 5: workgroup target of the split-K heuristic
 static int g_brick = 1;  // option 6: brick tiles (4x4 voxels per MFMA row block) on the small deep levels
 static int g_p4 = 1;  // option 4: 4x4x1-MFMA kernel for the Cout = 24 layers (no padding to 32 columns)
+static int g_split = 0;  // option 8: fp32 convs through 3 x bf16 operand pieces on the bf16 matrix cores (conv_split.hip)
+extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias, const float* addend, float* out,
+                             const int s[3], int Cin, int Cout, int mt, int nchunks, int act, hipStream_t st);
 
 struct FwdPlan {
-  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2, brick, wn, wm;
-  // NT = 0 selects the 4x4x1 weight layout in pack_value, NT = -Cin the first-layer layout
-  int pack_nt() const { return c2 ? -c2 : (p4 ? 0 : nt); }
-  int64_t mfma_count() const { return (p4 || c2) ? 0 : (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128; }
+  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2, brick, wn, wm, split;
+  // NT = 0 selects the 4x4x1 weight layout in pack_value, NT = -Cin the first-layer layout, NT = -100 - MT the split layout
+  int pack_nt() const { return split ? -100 - mt : (c2 ? -c2 : (p4 ? 0 : nt)); }
+  int64_t mfma_count() const {
+    if (split) return nchunks;  // what pack_value needs to decode the split layout
+    return (p4 || c2) ? 0 : (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128;
+  }
   int64_t count() const {
+    if (split) return (int64_t)3 * nchunks * ncc * 7 * mt * 64 * 4;  // floats (= pairs of bf16)
     if (c2) return (int64_t)((27 * c2 * 6 + 15) / 16) * 64;
     return p4 ? (int64_t)ncc * 27 * 9 * 64 : mfma_count() + (int64_t)ncc * 27 * ck * nv;
   }
@@ -2801,6 +2835,27 @@ struct FwdPlan {
 inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
   const bool plain = kind == 1;
   FwdPlan p;
+  p.split = 0;
+  if (g_split && plain && (Cin % 8) == 0 && (Cout % 8) == 0) {
+    // fp32 through three bf16 pieces per operand on the bf16 matrix cores (conv_split.hip): layers with enough 4x4x16 tiles
+    const int64_t vox = (int64_t)s[0] * s[1] * s[2];
+    const int ntiles = cdiv(Cout, 16);
+    const int mt = ntiles <= 3 ? ntiles : ((ntiles % 3) == 0 ? 3 : ((ntiles % 2) == 0 ? 2 : 1));
+    const int nchunks = cdiv(ntiles, mt);
+    const int64_t wgs = (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) * nchunks;
+    if (wgs >= 256 && vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31)) {
+      p.split = 1;
+      p.ck = 8;
+      p.ncc = Cin / 8;
+      p.mt = mt;
+      p.nt = mt;
+      p.nchunks = nchunks;
+      p.ksplit = 1;
+      p.nv = p.persist = p.p4 = p.c2 = p.brick = 0;
+      p.wn = p.wm = 1;
+      return p;
+    }
+  }
   p.ck = ck_for_fwd(Cin);
   p.ncc = cdiv(Cin, p.ck);
   const int ntiles = cdiv(Cout, 16);
@@ -3661,6 +3716,7 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
       (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
+  if (pl.split) return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, (hipStream_t)stream);
   const ConvExt ext{0, nullptr, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
@@ -3673,6 +3729,7 @@ int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* b
       (act != 0 && act != 1 && act != 2) || (act == 2 && (!addend || addend == out)))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
+  if (pl.split) return syn_split_fwd(in, wpacked, bias, addend, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, (hipStream_t)stream);
   const ConvExt ext{0, addend, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
@@ -3810,6 +3867,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 7) {
     g_psplit = value ? 1 : 0;
+    return SYNTHSR_OK;
+  }
+  if (option == 8) {
+    g_split = value ? 1 : 0;
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;

@@ -1,0 +1,399 @@
+// 3x3x3 'same' Conv3D on NDHWC **fp32** activations / weights evaluated on the bf16 matrix cores by operand splitting
+// (gfx950, v_mfma_f32_16x16x32_bf16, fp32 accumulation).  SynthSR's U-Net is fp32 Keras (ext/neuron/models.py:256-498,
+// SynthSR/training.py:330-341); gfx950 multiplies bf16 16x faster than fp32 (2.5 PFLOP/s vs 157 TFLOP/s dense), so every
+// fp32 operand is written as the exact sum of three bf16 numbers
+//       a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = a - a0 - a1      (round to nearest even; 3 x 8 significand
+//                                                                                  bits cover the 24 of fp32: a2 is exact)
+// and a product a b is accumulated as the six partial products a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0, each EXACT in the
+// matrix core's fp32 accumulator (8 x 8 significand bits).  The three products left out are bounded by
+// |a1 b2 + a2 b1 + a2 b2| <= (2^-9 2^-18 + 2^-18 2^-9 + 2^-36) |a b| < 2^-26 |a b|: a quarter of the rounding error fp32 commits
+// on the product itself, so the result is as close to the exact convolution as the fp32-MFMA kernels of conv3d.hip are
+// (tests/test_split_gpu.py measures both against float64).  Six bf16 MFMAs per fp32 MFMA's worth of work = 2.6x the fp32
+// matrix rate; activations stay fp32 in HBM (the split happens on the way into LDS), weights are split when they are packed.
+//
+//   forward / data gradient:  D[co][voxel] += sum over the 6 (i, j) of  A_i[co][(tap, ci)] * B_j[(tap, ci)][voxel]
+//       geometry of conv_bf16.hip's forward kernel: M = output channels (A = packed weight fragments, streamed from L2),
+//       N = 16 voxels of an x-row, K = 4 taps x 8 channels per MFMA; 4x4x16-voxel tiles, 4 waves (wave = z plane),
+//       persistent workgroups walking the tiles XCD-contiguously.  Input channels go through LDS 8 at a time as three bf16
+//       planes [piece][halo voxel][8 ch] (3 x 10 KB), double buffered: while the 6 x 4 x MT MFMAs of a K step run on one
+//       buffer, the next 8-channel chunk is converted and written to the other -- one barrier per chunk.
+#include "common.h"
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TZ = 4, TY = 4, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HVOX = HZ * HY * HX;
+constexpr uint32_t OOB = 0x80000000u;
+constexpr int PLANE = HVOX * 16;   // one bf16 piece of an 8-channel halo image
+constexpr int BUF = 3 * PLANE;     // the three pieces
+constexpr int NSTEP = 7;           // 27 taps, 4 per MFMA (the 28th slot carries zero weights)
+constexpr int SLAB_Z = 4;
+
+// tile schedule: see conv_bf16.hip (tiles enumerated slab by slab, the list cut into 8 contiguous parts, one per XCD)
+struct TileWalk {
+  int pos, end, stride;
+};
+__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
+  const int G = (int)gridDim.x, b = (int)blockIdx.x;
+  TileWalk w;
+  if (G % 8 == 0) {
+    const int per = (ntiles + 7) / 8, k = b & 7;
+    w.pos = k * per + (b >> 3);
+    w.end = min(ntiles, (k + 1) * per);
+    w.stride = G >> 3;
+  } else {
+    w.pos = b;
+    w.end = ntiles;
+    w.stride = G;
+  }
+  return w;
+}
+__device__ __forceinline__ void tile_decode(int p, int tiles0, int tiles1, int tiles2, int& z0, int& y0, int& x0) {
+  const int t12 = tiles1 * tiles2;
+  const int s = p / (SLAB_Z * t12), r = p - s * SLAB_Z * t12;
+  const int sz = min(SLAB_Z, tiles0 - s * SLAB_Z);
+  const int t1 = r / (sz * tiles2), rr = r - t1 * sz * tiles2;
+  const int zz = rr / tiles2, t2 = rr - zz * tiles2;
+  z0 = (s * SLAB_Z + zz) * TZ;
+  y0 = t1 * TY;
+  x0 = t2 * TX;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+
+// ELU(alpha = 1), fp32 accuracy (same function as conv3d.hip: exp2 away from 0, degree-5 Taylor on (-1/8, 0])
+__device__ __forceinline__ float elu_f(float v) {
+  const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f;
+  const float p = v * fmaf(v, fmaf(v, fmaf(v, fmaf(v, 1.f / 120.f, 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
+  const float n = v > -0.125f ? p : e;
+  return v > 0.f ? v : n;
+}
+__device__ __forceinline__ float elu_dy(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+struct SplitFwdArgs {
+  const float* in;
+  const u32x4* wp;      // [piece 3][co-chunk][cc][step 7][mt][lane 64] x 8 bf16
+  const float* bias;
+  const float* addend;  // act 0 / 1: added before the activation (may be `out`); act 2: ELU output of the layer below
+  float* out;
+  float* stats_partial;  // [gridDim.y][gridDim.x][2][16 MT] per-workgroup sums / sums of squares of the output, or null
+  int D0, D1, D2, Cin, Cout, ncc, tiles1, tiles2, ntiles, act;
+};
+
+template <int MT, bool ST>
+__global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int NV = (HVOX + 255) / 256;  // halo voxels per thread (3; the last one only for tid < 136)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int chunk = blockIdx.y, nchunks = gridDim.y;
+  const TileWalk walk = tile_walk(a.ntiles);
+  const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
+  const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout, ncc = a.ncc;
+
+  // per-lane LDS byte offset of the tap of K slot 4 s + g (relative to the voxel's place in a piece); the spare slot (zero
+  // weights) reads what its pair partner reads.  Lane m holds x-voxel syn_split_voxel(m): see syn_split_tap (bank conflicts)
+  int koff[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    int tap = syn_split_tap(4 * s + g);
+    if (tap < 0) tap = syn_split_tap((4 * s + g) ^ 1);
+    koff[s] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * 16;
+  }
+  const int xv = syn_split_voxel(m);
+  const int lbase = (wave * HY * HX + xv) * 16;  // voxel (z = wave, y = 0, x = xv) of the tile, tap (0, 0, 0)
+
+  // staging: thread -> halo voxels tid, tid + 256, tid + 512 (8 channels = 32 B each)
+  int prel[NV];
+  uint32_t pmask[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + 256 * i;
+    const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
+    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4;
+    pmask[i] = v < HVOX ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+  }
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  f32x4 stg[NV][2];
+  auto load_halo = [&](int t, int cc) {
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bool skip = (pmask[i] & bad) != 0;
+      const uint32_t vo = skip ? OOB : (uint32_t)(prel[i] + base);
+      stg[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
+      stg[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(skip ? OOB : vo + 16u), 0, 0));
+    }
+  };
+  auto store_halo = [&](int buf) {  // split the staged voxels into their three bf16 pieces
+    unsigned char* dst = lds + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i == NV - 1 && tid + 256 * i >= HVOX) continue;
+      u32x4 p[3];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t a0, a1, a2, b0, b1, b2;
+        syn_split3(stg[i][h][0], stg[i][h][1], a0, a1, a2);
+        syn_split3(stg[i][h][2], stg[i][h][3], b0, b1, b2);
+        p[0][2 * h] = a0; p[0][2 * h + 1] = b0;
+        p[1][2 * h] = a1; p[1][2 * h + 1] = b1;
+        p[2][2 * h] = a2; p[2][2 * h + 1] = b2;
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(dst + q * PLANE + (tid + 256 * i) * 16) = p[q];
+    }
+  };
+
+  // weight fragments of this co-chunk: piece q at wq[q]; fragment (cc, step, mt) at ((cc * NSTEP + step) * MT + mt) * 64
+  const int64_t piece_stride = (int64_t)nchunks * ncc * NSTEP * MT * 64;
+  const u32x4* __restrict__ wbase = a.wp + (int64_t)chunk * ncc * NSTEP * MT * 64 + lane;
+
+  float s1[ST ? MT : 1][4], s2[ST ? MT : 1][4];  // BatchNorm partial sums of this lane's channels (ST only)
+#pragma unroll
+  for (int mt = 0; mt < (ST ? MT : 1); ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s1[mt][i] = s2[mt][i] = 0.f;
+
+  const int64_t out_bytes = (int64_t)D0 * D1 * D2 * Cout * 4;
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t radd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.addend ? a.addend : a.out), 0, (int)out_bytes, 0x00020000);
+
+  // Register budget (2 workgroups per CU: 256 VGPRs): ONE set of weight fragments and ONE set of activation fragments.  The six
+  // products of a K step are ordered so that every piece's registers can be re-loaded for the next step right after their last
+  // use and are not needed again for as long as possible:
+  //     (w0,x2) (w0,x1) (w0,x0) | reload w0   (w1,x0) (w1,x1) | reload w1, x1   (w2,x0) | reload w2, x0      [x2 after its product]
+  // weights (L2 latency) get >= 3 products = 12 MT MFMAs of cover, activations (LDS) >= 2; the weight stream runs on across
+  // chunk and tile boundaries (the next chunk's first fragments are requested during the last step of this one).
+  u32x4 wa[3][MT], xb[3][TY];
+  auto wload = [&](const u32x4* wf, int s, int q) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wa[q][mt] = wf[q * piece_stride + (s * MT + mt) * 64];
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  int buf = 0;
+  if (walk.pos < walk.end) {
+    load_halo(walk.pos, 0);
+    store_halo(0);
+    wload(wbase, 0, 0);
+    wload(wbase, 0, 1);
+    wload(wbase, 0, 2);
+  }
+  for (int t = walk.pos; t < walk.end; t += walk.stride) {
+    f32x4 acc[TY][MT];
+#pragma unroll
+    for (int y = 0; y < TY; ++y)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < ncc; ++cc) {
+      __syncthreads();  // image `buf` is complete; nobody reads the other one any more
+      const bool more = cc + 1 < ncc || t + walk.stride < walk.end;
+      if (cc + 1 < ncc) load_halo(t, cc + 1);
+      else if (t + walk.stride < walk.end) load_halo(t + walk.stride, 0);
+      const u32x4* wf = wbase + (int64_t)cc * NSTEP * MT * 64;
+      const u32x4* wf_next = cc + 1 < ncc ? wf + NSTEP * MT * 64 : wbase;  // step 0 of the chunk that follows
+      const unsigned char* img = lds + buf * BUF + lbase;
+      auto xload = [&](int s, int q) {  // piece q of the four x-rows at the taps of step s
+#pragma unroll
+        for (int y = 0; y < TY; ++y) xb[q][y] = *reinterpret_cast<const u32x4*>(img + q * PLANE + koff[s] + y * (HX * 16));
+      };
+      auto mma = [&](auto QA, auto QB) {  // acc += (weight piece QA) x (activation piece QB)
+        constexpr int qa = decltype(QA)::value, qb = decltype(QB)::value;
+#pragma unroll
+        for (int y = 0; y < TY; ++y)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[qa][mt]),
+                                                                 __builtin_bit_cast(bf16x8, xb[qb][y]), acc[y][mt], 0, 0, 0);
+      };
+      xload(0, 2);
+      xload(0, 1);
+      xload(0, 0);
+      sfor<0, NSTEP>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        constexpr bool last = s + 1 == NSTEP;
+        const u32x4* wn = last ? wf_next : wf;
+        constexpr int sn = last ? 0 : s + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I0{}, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!last) xload(sn, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I0{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I0{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        wload(wn, sn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I1{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I1{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        wload(wn, sn, 1);
+        if constexpr (!last) xload(sn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I2{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        wload(wn, sn, 2);
+        if constexpr (!last) xload(sn, 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) store_halo(buf ^ 1);
+      buf ^= 1;
+    }
+    // ---- epilogue: lane (m, g): channels (chunk*MT + mt)*16 + 4g + i of voxel (z0 + wave, y0 + y, x0 + xv)
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    const int gz = z0 + wave, gx = x0 + xv;
+    const bool zx_ok = gz < D0 && gx < D2;
+    const uint32_t row0 = (uint32_t)((gz * D1 + y0) * D2 + gx) * (uint32_t)(Cout * 4);
+    const uint32_t ystep = (uint32_t)(D2 * Cout * 4);
+    auto epi = [&](auto ACTC, auto ADDC) {
+      constexpr int ACT = decltype(ACTC)::value;
+      constexpr bool ADD = decltype(ADDC)::value;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co = (chunk * MT + mt) * 16 + 4 * g;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias && co < Cout) bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int y = 0; y < TY; ++y) {
+          const bool vok = zx_ok && (y0 + y) < D1;
+          const uint32_t off = (vok && co < Cout) ? row0 + y * ystep + (uint32_t)(co * 4) : OOB;
+          f32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[y][mt][i] + bias[i];
+          if constexpr (ADD || ACT == 2) {
+            const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)off, 0, 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ACT == 2 ? v[i] * elu_dy(b[i]) : v[i] + b[i];
+          }
+          if constexpr (ACT == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)off, 0, 0);
+          if constexpr (ST) {
+            const float w = off != OOB ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float r = w * v[i];
+              s1[mt][i] += r;
+              s2[mt][i] += r * r;
+            }
+          }
+        }
+      }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if constexpr (ST) {  // forward layers in front of a BatchNorm: no addend
+      if (a.act == 1) epi(std::integral_constant<int, 1>{}, F_{});
+      else epi(std::integral_constant<int, 0>{}, F_{});
+    } else {
+      if (a.act == 2) epi(std::integral_constant<int, 2>{}, F_{});
+      else if (a.addend) {
+        if (a.act == 1) epi(std::integral_constant<int, 1>{}, T_{});
+        else epi(std::integral_constant<int, 0>{}, T_{});
+      } else if (a.act == 1) epi(std::integral_constant<int, 1>{}, F_{});
+      else epi(std::integral_constant<int, 0>{}, F_{});
+    }
+  }
+  if constexpr (ST) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);  // [wave][2][MT*16]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x1 = s1[mt][i], x2 = s2[mt][i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          x1 += __shfl_xor(x1, o, 64);
+          x2 += __shfl_xor(x2, o, 64);
+        }
+        if (m == 0) {
+          red[(wave * 2 + 0) * (MT * 16) + mt * 16 + 4 * g + i] = x1;
+          red[(wave * 2 + 1) * (MT * 16) + mt * 16 + 4 * g + i] = x2;
+        }
+      }
+    __syncthreads();
+    float* dst = a.stats_partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * MT * 16);
+    for (int e = tid; e < 2 * MT * 16; e += 256)
+      dst[e] = red[e] + red[2 * MT * 16 + e] + red[4 * MT * 16 + e] + red[6 * MT * 16 + e];
+  }
+}
+
+template <int MT, bool ST>
+int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
+  const size_t smem = 2 * BUF;
+  auto kern = conv3d_split_fwd_kernel<MT, ST>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(256), smem, st, a);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+inline int split_grid_x(int ntiles, int nchunks) {
+  int gx = std::max(8, ((512 / nchunks) / 8) * 8);  // 2 workgroups per CU in total
+  while (gx > 8 && gx > ntiles) gx -= 8;
+  if (ntiles < 8) gx = ntiles;
+  return gx;
+}
+
+}  // namespace
+
+// called by conv3d.hip's dispatcher when the plan of the layer says `split` (weights packed in the split layout by pack_value)
+extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* in, const float* wp, const float* bias,
+                                                                    const float* addend, float* out, const int s[3], int Cin,
+                                                                    int Cout, int mt, int nchunks, int act, hipStream_t st) {
+  if ((Cin % 8) != 0 || (Cout % 4) != 0 || mt < 1 || mt > 3 || nchunks < 1) return SYNTHSR_EINVAL;
+  const int64_t vox = (int64_t)s[0] * s[1] * s[2];
+  if (vox * Cin * 4 >= (1ll << 31) || vox * Cout * 4 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  SplitFwdArgs a;
+  a.in = in;
+  a.wp = reinterpret_cast<const u32x4*>(wp);
+  a.bias = bias;
+  a.addend = addend;
+  a.out = out;
+  a.stats_partial = nullptr;
+  a.D0 = s[0]; a.D1 = s[1]; a.D2 = s[2];
+  a.Cin = Cin; a.Cout = Cout; a.ncc = Cin / 8;
+  a.tiles1 = (s[1] + TY - 1) / TY;
+  a.tiles2 = (s[2] + TX - 1) / TX;
+  a.ntiles = ((s[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
+  a.act = act;
+  const int gx = split_grid_x(a.ntiles, nchunks);
+  if (mt == 1) return launch_split_fwd<1, false>(a, gx, nchunks, st);
+  if (mt == 2) return launch_split_fwd<2, false>(a, gx, nchunks, st);
+  return launch_split_fwd<3, false>(a, gx, nchunks, st);
+}

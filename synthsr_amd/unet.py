@@ -229,7 +229,8 @@ class UNet3D:
             cin_e, cout_e = (cout, cin) if mode else (cin, cout)
             # kind: 1 plain conv, 2 forward parity convs of a folded decoder conv, 0 their data gradient
             ck, ncc, nt, nchunks, _, _, nv, per = plan(shape, cin_e, cout_e, ((2 if mode == 0 else 0) if up else 1))
-            mfma_count = nchunks * ncc * 27 * (ck // 8) * nt * 128
+            # last job field: size of the MFMA section of a mixed layout; the split layout (nt <= -100) wants its co-chunk count
+            mfma_count = nchunks if nt <= -100 else nchunks * ncc * 27 * (ck // 8) * nt * 128
             w_off = self.offsets[c['w']][0]
             c[key + '_off'] = (off, per * (8 if up else 1))
             for p in range(8 if up else 1):
