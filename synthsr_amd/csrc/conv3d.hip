@@ -2812,6 +2812,8 @@ static int g_ks_target = 1024;  // option 5: workgroup target of the split-K heu
 static int g_brick = 1;  // option 6: brick tiles (4x4 voxels per MFMA row block) on the small deep levels
 static int g_p4 = 1;  // option 4: 4x4x1-MFMA kernel for the Cout = 24 layers (no padding to 32 columns)
 static int g_split = 0;  // option 8: fp32 convs through 3 x bf16 operand pieces on the bf16 matrix cores (conv_split.hip)
+extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, const int s[3], int cin_total, int ci_off,
+                               int Cin, int Cout, hipStream_t st);
 extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias, const float* addend, float* out,
                              const int s[3], int Cin, int Cout, int mt, int nchunks, int act, hipStream_t st);
 
@@ -3580,6 +3582,11 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
   if constexpr (NTAPS == 27) {
     if (Cin <= 2 && Cout == 24 && g_p4 && (int64_t)shape[0] * shape[1] * shape[2] * Cout * 4 < (1ll << 31))
       return launch_wgrad_c2(in, dout, dw, ext.dbias, shape, Cin, st, ext);
+    // fp32 through three bf16 pieces per operand (conv_split.hip): layers with enough 4x4x16 tiles and no fused dbias
+    if (g_split && !ext.dbias && (int64_t)cdiv(shape[0], 4) * cdiv(shape[1], 4) * cdiv(shape[2], 16) >= 256) {
+      const int rc = syn_split_wgrad(in, dout, dw, shape, ext.cin_total, ext.ci_off, Cin, Cout, st);
+      if (rc != SYNTHSR_EINVAL) return rc;  // EINVAL: channel counts the split kernel does not cover
+    }
   }
   if constexpr (NTAPS == 27) {
     const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];

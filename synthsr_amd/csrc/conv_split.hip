@@ -370,6 +370,278 @@ inline int split_grid_x(int ntiles, int nchunks) {
   return gx;
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+//   dW[tap][ci][co] = sum over voxels v of x[v + tap - 1][ci] * dz[v][co]:  D[(tap, ci)][co] += sum over the 6 (i, j) of
+//   A_i[(tap, ci)][voxel] * B_j[voxel][co], both operands activations: both go through LDS as three bf16 pieces in their
+//   natural [voxel][channel] layout and are read K(voxel)-major with the transpose read ds_read_b64_tr_b16 (as conv_bf16.hip's
+//   weight-gradient kernel).  LDS bandwidth is what bounds this kernel (an operand fragment is 1 KB = 8 LDS cycles of a CU,
+//   an MFMA 16 cycles of a SIMD), so the decomposition maximises fragment re-use:
+//     * a workgroup owns 8 input channels (blockIdx.y) x COW output channels and ALL 27 taps [RT = 14 row tiles of 16 =
+//       (2 taps) x (2 channel quads) x 4 channels; COW = 48: 7 row tiles, the other half in the next workgroup];
+//     * its 8 waves split the tile's 256 voxels (one 32-voxel K step each): a wave loads the 3 x NT dz fragments of its K step
+//       once and streams the 3 x RT x fragments past them -- 6 NT MFMAs per 3 KB of LDS reads;
+//     * accumulators stay in registers over the workgroup's whole tile range; at the end the 8 waves' partial sums are added
+//       through LDS and flushed with one atomic per element (deterministic mode: private planes, common.h DetRun).
+//   8 waves x 1 workgroup per CU; LDS double buffered when it fits (COW = 24: 2 x 68 KB): one barrier per tile.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ u32x4 tr_read8(const unsigned char* p_lo, const unsigned char* p_hi) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p_lo);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p_hi);
+  return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+struct SplitWgArgs {
+  const float* in;    // x [vox][Cin]
+  const float* dout;  // dz [vox][Cout]
+  float* dw;          // [27][cin_total][Cout], accumulated with atomics
+  int D0, D1, D2, Cin, Cout, cin_total, ci_off, ncc, nco, tiles1, tiles2, ntiles;
+  int64_t det_stride;
+};
+
+constexpr int WG_XPLANE = HVOX * 16;
+template <int COW>
+struct WgCfg {
+  static constexpr int NT = (COW + 15) / 16, DROWB = COW * 2, DPLANE = TZ * TY * TX * DROWB;
+  static constexpr int RT = COW <= 24 ? 14 : 7;                 // row tiles per workgroup
+  static constexpr int BUFB = 3 * WG_XPLANE + 3 * DPLANE + 64;  // + slack: the last column tile reads past a 24-channel row
+  static constexpr bool DBUF = 2 * BUFB <= 160 * 1024;
+  static constexpr int NBUF = DBUF ? 2 : 1;
+};
+
+template <int COW>
+__global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitWgArgs a) {
+  using C = WgCfg<COW>;
+  constexpr int NT = C::NT, DROWB = C::DROWB, DPLANE = C::DPLANE, RT = C::RT, NW = 8, NTHR = 512;
+  constexpr int NXP = HVOX * 2, NXL = (NXP + NTHR - 1) / NTHR;             // 16-byte pieces of the 8-channel x halo image
+  constexpr int DQ = COW / 4, NDP = TZ * TY * TX * DQ, NDL = NDP / NTHR;   // 16-byte pieces (4 channels) of the dz tile
+  static_assert(NDP % NTHR == 0, "dz pieces divide among the threads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15, lrow = li >> 2, lq = li & 3;
+  const int halves = 14 / RT;
+  int by = blockIdx.y;
+  const int rh = by % halves;  // which half of the row tiles (COW = 48)
+  by /= halves;
+  const int cc = by % a.ncc, oc = by / a.ncc;
+  const TileWalk walk = tile_walk(a.ntiles);
+  const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
+  const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout;
+
+  // A addresses: lane i = (voxel row lrow, block lq) of the row tile: tap = 2 (rh RT + q) + (lq >> 1), channel quad lq & 1
+  int aoff[RT];
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    int tap = 2 * (rh * RT + q) + (lq >> 1);
+    if (tap > 26) tap = 26;  // the spare slot of the last pair: its rows are not flushed
+    aoff[q] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * 16 + (lq & 1) * 8;
+  }
+  // this wave's K step: 32 voxels = x-rows (z, yb) and (z, yb + 1); K index 8 g + j <-> voxel (row g >> 1, x = 8 (j >> 2) +
+  // 4 (g & 1) + (j & 3)) -- the same bijection for both operands (conv_bf16.hip)
+  const int kz = wave >> 1, kyb = 2 * (wave & 1);
+  const int vx = 4 * (g & 1) + lrow, vr = g >> 1;
+  const uint32_t abase = (uint32_t)((((kz * HY + kyb + vr) * HX) + vx) * 16);
+  const uint32_t bbase = (uint32_t)(3 * WG_XPLANE) + (uint32_t)((((kz * TY + kyb + vr) * TX) + vx) * DROWB + lq * 8);
+
+  // staging: x piece j -> halo voxel j >> 1, channels 4 (j & 1) .. + 3 of the chunk; dz piece j -> voxel j / DQ, quad j % DQ
+  int xrel[NXL], xlds[NXL];
+  uint32_t xmask[NXL];
+#pragma unroll
+  for (int i = 0; i < NXL; ++i) {
+    const int j = tid + NTHR * i;
+    const int v = j >> 1, h = j & 1;
+    const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
+    xrel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4 + h * 16;
+    xlds[i] = v * 16 + h * 8;
+    xmask[i] = j < NXP ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+  }
+  int drel[NDL], dlds[NDL], dvz[NDL], dvy[NDL], dvx[NDL];
+  bool dcok[NDL];
+#pragma unroll
+  for (int i = 0; i < NDL; ++i) {
+    const int j = tid + NTHR * i;
+    const int v = j / DQ, c4 = j - v * DQ;
+    dvz[i] = v / (TY * TX);
+    dvy[i] = (v / TX) % TY;
+    dvx[i] = v % TX;
+    const int co = oc * COW + c4 * 4;
+    dcok[i] = co < Cout;
+    drel[i] = ((dvz[i] * D1 + dvy[i]) * D2 + dvx[i]) * Cout * 4 + co * 4;
+    dlds[i] = v * DROWB + c4 * 8;
+  }
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, (int)((int64_t)D0 * D1 * D2 * Cout * 4), 0x00020000);
+  f32x4 xst[NXL], dst[NDL];
+  auto load_tile = [&](int t) {
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const uint32_t vo = (xmask[i] & bad) ? OOB : (uint32_t)(xrel[i] + base);
+      xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
+    }
+    const int dbase = ((z0 * D1 + y0) * D2 + x0) * Cout * 4;
+#pragma unroll
+    for (int i = 0; i < NDL; ++i) {
+      const bool ok = dcok[i] && z0 + dvz[i] < D0 && y0 + dvy[i] < D1 && x0 + dvx[i] < D2;
+      dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, ok ? drel[i] + dbase : (int)OOB, 0, 0));
+    }
+  };
+  auto store_tile = [&](int buf) {  // four fp32 -> 3 x (four bf16 = 8 bytes)
+    unsigned char* xd = lds + buf * C::BUFB;
+    unsigned char* dd = xd + 3 * WG_XPLANE;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      if (i == NXL - 1 && tid + NTHR * i >= NXP) continue;
+      uint32_t p0, p1, p2, q0, q1, q2;
+      syn_split3(xst[i][0], xst[i][1], p0, p1, p2);
+      syn_split3(xst[i][2], xst[i][3], q0, q1, q2);
+      *reinterpret_cast<u32x2*>(xd + xlds[i]) = (u32x2){p0, q0};
+      *reinterpret_cast<u32x2*>(xd + WG_XPLANE + xlds[i]) = (u32x2){p1, q1};
+      *reinterpret_cast<u32x2*>(xd + 2 * WG_XPLANE + xlds[i]) = (u32x2){p2, q2};
+    }
+#pragma unroll
+    for (int i = 0; i < NDL; ++i) {
+      uint32_t p0, p1, p2, q0, q1, q2;
+      syn_split3(dst[i][0], dst[i][1], p0, p1, p2);
+      syn_split3(dst[i][2], dst[i][3], q0, q1, q2);
+      *reinterpret_cast<u32x2*>(dd + dlds[i]) = (u32x2){p0, q0};
+      *reinterpret_cast<u32x2*>(dd + DPLANE + dlds[i]) = (u32x2){p1, q1};
+      *reinterpret_cast<u32x2*>(dd + 2 * DPLANE + dlds[i]) = (u32x2){p2, q2};
+    }
+  };
+
+  f32x4 acc[RT][NT];
+#pragma unroll
+  for (int q = 0; q < RT; ++q)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int buf = 0;
+  if (walk.pos < walk.end) {
+    load_tile(walk.pos);
+    store_tile(0);
+  }
+  for (int t = walk.pos; t < walk.end; t += walk.stride) {
+    __syncthreads();  // image `buf` is complete (double buffered: and nobody reads the other one any more)
+    const bool more = t + walk.stride < walk.end;
+    if (more) load_tile(t + walk.stride);
+    const unsigned char* img = lds + buf * C::BUFB;
+    u32x4 bfr[3][NT], afr[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        bfr[p][n] = tr_read8(img + bbase + p * DPLANE + n * 32, img + bbase + p * DPLANE + n * 32 + 8 * DROWB);
+    auto aload = [&](int q, int slot) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        afr[slot][p] = tr_read8(img + abase + aoff[q] + p * WG_XPLANE, img + abase + aoff[q] + p * WG_XPLANE + 8 * 16);
+    };
+    aload(0, 0);
+    sfor<0, RT>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (q + 1 < RT) aload(q + 1, (q + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      sfor<0, 6>([&](auto CC) {
+        constexpr int c = decltype(CC)::value;
+        constexpr int qa = c == 0 ? 2 : ((c == 2 || c == 3) ? 1 : 0), qb = c == 1 ? 2 : ((c == 2 || c == 4) ? 1 : 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][qa]),
+                                                               __builtin_bit_cast(bf16x8, bfr[qb][n]), acc[q][n], 0, 0, 0);
+      });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!C::DBUF) __syncthreads();  // single buffer: everyone is done reading before the next image is written
+    if (more) store_tile(C::DBUF ? buf ^ 1 : 0);
+    if constexpr (C::DBUF) buf ^= 1;
+  }
+  // ---- add the 8 waves' partial sums through LDS (4 -> 2 -> 1), wave 0 flushes
+  float* red = reinterpret_cast<float*>(lds);  // [wave slot][RT][NT][4][64]
+  constexpr int WSZ = RT * NT * 4 * 64;
+#pragma unroll
+  for (int half = 4; half >= 1; half >>= 1) {
+    __syncthreads();
+    if (wave >= half && wave < 2 * half) {
+      float* dstw = red + (size_t)(wave - half) * WSZ;
+#pragma unroll
+      for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dstw[((q * NT + n) * 4 + i) * 64 + lane] = acc[q][n][i];
+    }
+    __syncthreads();
+    if (wave < half) {
+      const float* srcw = red + (size_t)wave * WSZ;
+#pragma unroll
+      for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[q][n][i] += srcw[((q * NT + n) * 4 + i) * 64 + lane];
+    }
+  }
+  if (wave != 0) return;
+  // lane (li -> co, rows 4 g + i -> block g of the row tile: tap 2 (rh RT + q) + (g >> 1), channel 4 (g & 1) + i of the chunk)
+  float* dwp = a.dw + (size_t)blockIdx.x * a.det_stride;
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    const int tap = 2 * (rh * RT + q) + (g >> 1);
+    if (tap > 26) continue;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = n * 16 + li, co = oc * COW + col;
+      if (col >= COW || co >= Cout) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ci = a.ci_off + cc * 8 + 4 * (g & 1) + i;
+        atomicAdd(dwp + ((int64_t)tap * a.cin_total + ci) * Cout + co, acc[q][n][i]);
+      }
+    }
+  }
+}
+
+template <int COW>
+int launch_split_wgrad(const SplitWgArgs& a0, hipStream_t st) {
+  using C = WgCfg<COW>;
+  SplitWgArgs a = a0;
+  const int gy = a.ncc * a.nco * (14 / C::RT);
+  int gx = ((256 / gy) / 8) * 8;  // one workgroup per CU
+  if (gx < 8) gx = 8;
+  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  if (a.ntiles < 8) gx = a.ntiles;
+  const size_t smem = (size_t)C::NBUF * C::BUFB;
+  auto kern = conv3d_split_wgrad_kernel<COW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  DetRun det;
+  float* no_dbias = nullptr;
+  if (syn_det_prepare(&det, &a.dw, &no_dbias, (int64_t)27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)
+    return SYNTHSR_ELAUNCH;
+  a.det_stride = det.stride;
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(512), smem, st, a);
+  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  return syn_det_finish(&det, st);
+}
+
 }  // namespace
 
 // called by conv3d.hip's dispatcher when the plan of the layer says `split` (weights packed in the split layout by pack_value)
@@ -396,4 +668,27 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
   if (mt == 1) return launch_split_fwd<1, false>(a, gx, nchunks, st);
   if (mt == 2) return launch_split_fwd<2, false>(a, gx, nchunks, st);
   return launch_split_fwd<3, false>(a, gx, nchunks, st);
+}
+
+// weight gradient of the input-channel range [ci_off, ci_off + Cin) of a layer with cin_total input channels (no dbias: the
+// U-Net's ELU / BatchNorm backward kernels produce it); SYNTHSR_EINVAL = shape not covered, the caller takes the fp32-MFMA path
+extern "C" __attribute__((visibility("hidden"))) int syn_split_wgrad(const float* in, const float* dout, float* dw,
+                                                                      const int s[3], int cin_total, int ci_off, int Cin,
+                                                                      int Cout, hipStream_t st) {
+  if ((Cin % 8) != 0 || (Cout != 24 && (Cout % 48) != 0)) return SYNTHSR_EINVAL;
+  const int64_t vox = (int64_t)s[0] * s[1] * s[2];
+  if (vox * Cin * 4 >= (1ll << 31) || vox * Cout * 4 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  SplitWgArgs a;
+  a.in = in;
+  a.dout = dout;
+  a.dw = dw;
+  a.D0 = s[0]; a.D1 = s[1]; a.D2 = s[2];
+  a.Cin = Cin; a.Cout = Cout; a.cin_total = cin_total; a.ci_off = ci_off;
+  a.ncc = Cin / 8;
+  a.nco = Cout == 24 ? 1 : Cout / 48;
+  a.tiles1 = (s[1] + TY - 1) / TY;
+  a.tiles2 = (s[2] + TX - 1) / TX;
+  a.ntiles = ((s[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
+  a.det_stride = 0;
+  return Cout == 24 ? launch_split_wgrad<24>(a, st) : launch_split_wgrad<48>(a, st);
 }
