@@ -1,7 +1,8 @@
 /* Process-wide switches of libsynthsr_hip.so -- NOT part of the drop-in boundary (include/synthsr_hip.h).
  *
  * The boundary contract is stateless and re-entrant: every entry point of synthsr_hip.h depends only on its
- * arguments.  The two exceptions are kept out of that header on purpose:
+ * arguments.  The exceptions are kept out of that header on purpose:
+ *  - synthsr_set_conv_arithmetic: which matrix instructions evaluate the fp32 convolutions (below).
  *  - synthsr_conv3d_set_option: an A/B switch that the profiling scripts under tools/ (ab.py, conv_ablate.py, ...) use to
  *    time kernel variants against each other.  Nothing in synthsr_amd/, scripts/ or bench.py calls it.
  *  - synthsr_set_deterministic: called by synthsr_amd.ops.set_deterministic, training(deterministic=True) and the parity
@@ -21,6 +22,20 @@ extern "C" {
  * 4 = 4x4x1-MFMA kernels, 5 = split-K workgroup target, 6 = brick tiles, 7 = parity split of small up-conv data gradients.  Options
  * that change the launch geometry must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
+
+/* Arithmetic of the fp32 3x3x3 convolutions (process-wide; set it BEFORE weights are packed: a packed weight set is only valid
+ * for the arithmetic it was packed under -- synthsr_amd.unet re-packs when the mode changed).
+ *   1 (default) "split": every fp32 operand is the exact sum of three bf16 numbers (round to nearest even on what the previous
+ *      pieces left); a product a*b is accumulated as a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0 on v_mfma_f32_16x16x32_bf16,
+ *      each partial product exact in the fp32 accumulator; what is left out is < 2^-26 |a b|, a quarter of the rounding error
+ *      of an fp32 multiply.  Inputs, outputs, accumulation, BatchNorm statistics, gradients and weights stay fp32; against a
+ *      float64 convolution the result is as accurate as the fp32-MFMA kernels' (tests/test_split_gpu.py).  Used for the
+ *      layers with >= 256 tiles of 4x4x16 voxels and channel counts that are multiples of 8 (csrc/conv_split.hip); the rest
+ *      (first layer, deep levels, folded decoder convs) runs on the fp32 matrix instructions in either mode.
+ *   0 "fp32_mfma": v_mfma_f32_4x4x1 / 16x16x4 kernels everywhere (csrc/conv3d.hip), the round-1/2 path.
+ * The reference computes in fp32 on TensorFlow (SynthSR/training.py:330-341); both modes are fp32 computations of it. */
+int synthsr_set_conv_arithmetic(int mode);
+int synthsr_conv_arithmetic(void);
 
 /* Deterministic mode (process-wide, per current device, single stream; synchronises the device).  on = 1: every
  * cross-workgroup float accumulation is performed in a fixed order -- small partials (channel sums, BatchNorm statistics,

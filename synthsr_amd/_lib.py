@@ -53,6 +53,8 @@ SIGNATURES = {
     'synthsr_bn_stats_from_partials': (c_int, [_P, c_int, c_int64, c_int, _P, _S]),
     'synthsr_conv3d_fwd_add': (c_int, [_P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_conv3d_set_option': (c_int, [c_int, c_int]),
+    'synthsr_set_conv_arithmetic': (c_int, [c_int]),
+    'synthsr_conv_arithmetic': (c_int, []),
     'synthsr_set_deterministic': (c_int, [c_int]),
     'synthsr_deterministic_status': (c_int, []),
     'synthsr_conv3d_plan': (c_int, [POINTER(c_int), c_int, c_int, c_int, POINTER(c_int64)]),
@@ -140,6 +142,9 @@ SIGNATURES = {
 }
 
 
+CONV_ARITHMETICS = ('fp32_mfma', 'split')   # include/synthsr_hip_tuning.h: synthsr_set_conv_arithmetic(index)
+
+
 class SynthSRHipError(RuntimeError):
     pass
 
@@ -157,8 +162,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if os.environ.get('SYNTHSR_CONV_SPLIT') == '1':   # TEMPORARY switch while the split path is being brought up
-        lib.synthsr_conv3d_set_option(8, 1)
+    arith = os.environ.get('SYNTHSR_CONV_ARITH')   # 'fp32_mfma' | 'split' (default): ops.set_conv_arithmetic
+    if arith:
+        if arith not in CONV_ARITHMETICS:
+            raise ValueError('SYNTHSR_CONV_ARITH should be one of %s' % (CONV_ARITHMETICS,))
+        lib.synthsr_set_conv_arithmetic(CONV_ARITHMETICS.index(arith))
     _lib = lib
     return lib
 

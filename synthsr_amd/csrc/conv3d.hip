@@ -2811,11 +2811,13 @@ static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
 static int g_ks_target = 1024;  // option 5: workgroup target of the split-K heuristic
 static int g_brick = 1;  // option 6: brick tiles (4x4 voxels per MFMA row block) on the small deep levels
 static int g_p4 = 1;  // option 4: 4x4x1-MFMA kernel for the Cout = 24 layers (no padding to 32 columns)
-static int g_split = 0;  // option 8: fp32 convs through 3 x bf16 operand pieces on the bf16 matrix cores (conv_split.hip)
-extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, const int s[3], int cin_total, int ci_off,
-                               int Cin, int Cout, hipStream_t st);
+static int g_split = 1;  // synthsr_set_conv_arithmetic: fp32 convs through 3 x bf16 operand pieces on the bf16 matrix cores
+                         // (conv_split.hip) where the layer has enough tiles; 0 = fp32 MFMA kernels everywhere
+extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int cin_total,
+                               int ci_off, int Cin, int Cout, hipStream_t st);
 extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias, const float* addend, float* out,
-                             const int s[3], int Cin, int Cout, int mt, int nchunks, int act, hipStream_t st);
+                             const int s[3], int Cin, int Cout, int mt, int nchunks, int act, float* stats, float* partial,
+                             hipStream_t st);
 
 struct FwdPlan {
   int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2, brick, wn, wm, split;
@@ -3582,9 +3584,9 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
   if constexpr (NTAPS == 27) {
     if (Cin <= 2 && Cout == 24 && g_p4 && (int64_t)shape[0] * shape[1] * shape[2] * Cout * 4 < (1ll << 31))
       return launch_wgrad_c2(in, dout, dw, ext.dbias, shape, Cin, st, ext);
-    // fp32 through three bf16 pieces per operand (conv_split.hip): layers with enough 4x4x16 tiles and no fused dbias
-    if (g_split && !ext.dbias && (int64_t)cdiv(shape[0], 4) * cdiv(shape[1], 4) * cdiv(shape[2], 16) >= 256) {
-      const int rc = syn_split_wgrad(in, dout, dw, shape, ext.cin_total, ext.ci_off, Cin, Cout, st);
+    // fp32 through three bf16 pieces per operand (conv_split.hip): layers with enough 4x4x16 tiles
+    if (g_split && (int64_t)cdiv(shape[0], 4) * cdiv(shape[1], 4) * cdiv(shape[2], 16) >= 256) {
+      const int rc = syn_split_wgrad(in, dout, dw, ext.dbias, shape, ext.cin_total, ext.ci_off, Cin, Cout, st);
       if (rc != SYNTHSR_EINVAL) return rc;  // EINVAL: channel counts the split kernel does not cover
     }
   }
@@ -3723,7 +3725,9 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
       (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
-  if (pl.split) return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, (hipStream_t)stream);
+  if (pl.split)
+    return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr,
+                         (hipStream_t)stream);
   const ConvExt ext{0, nullptr, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
@@ -3736,7 +3740,9 @@ int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* b
       (act != 0 && act != 1 && act != 2) || (act == 2 && (!addend || addend == out)))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
-  if (pl.split) return syn_split_fwd(in, wpacked, bias, addend, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, (hipStream_t)stream);
+  if (pl.split)
+    return syn_split_fwd(in, wpacked, bias, addend, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr,
+                         (hipStream_t)stream);
   const ConvExt ext{0, addend, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
@@ -3750,6 +3756,12 @@ int synthsr_conv3d_fwd_stats(const float* in, const float* wpacked, const float*
     return SYNTHSR_EINVAL;
   const int64_t nvox = (int64_t)shape[0] * shape[1] * shape[2];
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
+  if (pl.split) {  // statistics accumulated in the conv epilogue (conv_split.hip)
+    float* partial = lib_scratch((size_t)512 * 2 * Cout * sizeof(float));
+    if (!partial) return SYNTHSR_ELAUNCH;
+    return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, stats, partial,
+                         (hipStream_t)stream);
+  }
   if (pl.p4 && nvox * Cin * 4 < (1ll << 31))  // statistics accumulated in the conv epilogue
     return launch_fwd_p4(in, wpacked, bias, out, shape, Cin, pl, act, (hipStream_t)stream, nullptr, stats);
   const int rc = synthsr_conv3d_fwd(in, wpacked, bias, out, shape, Cin, Cout, act, stream);
@@ -3843,6 +3855,14 @@ int synthsr_deterministic_status(void) {
   return v[1] ? 2 : 1;  // 1: on and every ordered wait completed; 2: on, but a wait timed out (order not guaranteed)
 }
 
+int synthsr_set_conv_arithmetic(int mode) {
+  if (mode != 0 && mode != 1) return SYNTHSR_EINVAL;
+  g_split = mode;
+  return SYNTHSR_OK;
+}
+
+int synthsr_conv_arithmetic(void) { return g_split; }
+
 int synthsr_conv3d_set_option(int option, int value) {
   if (option == 0) {
     g_persist = value ? 1 : 0;
@@ -3874,10 +3894,6 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 7) {
     g_psplit = value ? 1 : 0;
-    return SYNTHSR_OK;
-  }
-  if (option == 8) {
-    g_split = value ? 1 : 0;
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;

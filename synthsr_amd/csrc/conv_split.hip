@@ -88,14 +88,13 @@ struct SplitFwdArgs {
   const float* bias;
   const float* addend;  // act 0 / 1: added before the activation (may be `out`); act 2: ELU output of the layer below
   float* out;
-  float* stats_partial;  // [gridDim.y][gridDim.x][2][16 MT] per-workgroup sums / sums of squares of the output, or null
+  float* stats_partial;  // [gridDim.x][2 Cout] per-workgroup-column sums | sums of squares of the output (ST), or null
   int D0, D1, D2, Cin, Cout, ncc, tiles1, tiles2, ntiles, act;
 };
 
 template <int MT, bool ST>
 __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int NV = (HVOX + 255) / 256;  // halo voxels per thread (3; the last one only for tid < 136)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
   const int chunk = blockIdx.y, nchunks = gridDim.y;
@@ -115,19 +114,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
   const int xv = syn_split_voxel(m);
   const int lbase = (wave * HY * HX + xv) * 16;  // voxel (z = wave, y = 0, x = xv) of the tile, tap (0, 0, 0)
 
-  // staging: thread -> halo voxels tid, tid + 256, tid + 512 (8 channels = 32 B each)
-  int prel[NV];
-  uint32_t pmask[NV];
+  // staging: 16-byte piece j = tid + 256 i of the 8-channel halo image -> halo voxel j >> 1, channels 4 (j & 1) .. + 3: the two
+  // lanes of a voxel sit in ONE load instruction, which then touches 32 cache lines instead of 64 (the vector memory pipe's
+  // tag rate, not bandwidth, is what these 96-byte-strided reads cost)
+  constexpr int NP = HVOX * 2, NL = (NP + 255) / 256;  // 1296 pieces, 6 per thread (the last one only for tid < 16)
+  int prel[NL], plds[NL];
+  uint32_t pmask[NL];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int v = tid + 256 * i;
+  for (int i = 0; i < NL; ++i) {
+    const int j = tid + 256 * i;
+    const int v = j >> 1, h = j & 1;
     const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
-    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4;
-    pmask[i] = v < HVOX ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4 + h * 16;
+    plds[i] = v * 16 + h * 8;
+    pmask[i] = j < NP ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
   }
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
-  f32x4 stg[NV][2];
+  f32x4 stg[NL];
   auto load_halo = [&](int t, int cc) {
     int z0, y0, x0;
     tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
@@ -140,30 +144,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
     for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
     const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const bool skip = (pmask[i] & bad) != 0;
-      const uint32_t vo = skip ? OOB : (uint32_t)(prel[i] + base);
-      stg[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
-      stg[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(skip ? OOB : vo + 16u), 0, 0));
+    for (int i = 0; i < NL; ++i) {
+      const uint32_t vo = (pmask[i] & bad) ? OOB : (uint32_t)(prel[i] + base);
+      stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
     }
   };
-  auto store_halo = [&](int buf) {  // split the staged voxels into their three bf16 pieces
+  auto store_halo = [&](int buf) {  // four fp32 -> 3 x (four bf16 = 8 bytes)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     unsigned char* dst = lds + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      if (i == NV - 1 && tid + 256 * i >= HVOX) continue;
-      u32x4 p[3];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        uint32_t a0, a1, a2, b0, b1, b2;
-        syn_split3(stg[i][h][0], stg[i][h][1], a0, a1, a2);
-        syn_split3(stg[i][h][2], stg[i][h][3], b0, b1, b2);
-        p[0][2 * h] = a0; p[0][2 * h + 1] = b0;
-        p[1][2 * h] = a1; p[1][2 * h + 1] = b1;
-        p[2][2 * h] = a2; p[2][2 * h + 1] = b2;
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(dst + q * PLANE + (tid + 256 * i) * 16) = p[q];
+    for (int i = 0; i < NL; ++i) {
+      if (i == NL - 1 && tid + 256 * i >= NP) continue;
+      uint32_t p0, p1, p2, q0, q1, q2;
+      syn_split3(stg[i][0], stg[i][1], p0, p1, p2);
+      syn_split3(stg[i][2], stg[i][3], q0, q1, q2);
+      *reinterpret_cast<u32x2*>(dst + plds[i]) = (u32x2){p0, q0};
+      *reinterpret_cast<u32x2*>(dst + PLANE + plds[i]) = (u32x2){p1, q1};
+      *reinterpret_cast<u32x2*>(dst + 2 * PLANE + plds[i]) = (u32x2){p2, q2};
     }
   };
 
@@ -344,9 +341,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
         }
       }
     __syncthreads();
-    float* dst = a.stats_partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * MT * 16);
-    for (int e = tid; e < 2 * MT * 16; e += 256)
-      dst[e] = red[e] + red[2 * MT * 16 + e] + red[4 * MT * 16 + e] + red[6 * MT * 16 + e];
+    // partial[workgroup column][2 Cout] (sums | sums of squares), the layout of synthsr_bn_stats_from_partials
+    float* dst = a.stats_partial + (int64_t)blockIdx.x * (2 * Cout);
+    for (int e = tid; e < MT * 16; e += 256) {
+      const int c = chunk * MT * 16 + e;
+      if (c < Cout) {
+        dst[c] = red[e] + red[2 * MT * 16 + e] + red[4 * MT * 16 + e] + red[6 * MT * 16 + e];
+        dst[Cout + c] = red[MT * 16 + e] + red[3 * MT * 16 + e] + red[5 * MT * 16 + e] + red[7 * MT * 16 + e];
+      }
+    }
   }
 }
 
@@ -396,6 +399,7 @@ struct SplitWgArgs {
   const float* in;    // x [vox][Cin]
   const float* dout;  // dz [vox][Cout]
   float* dw;          // [27][cin_total][Cout], accumulated with atomics
+  float* dbias;       // [Cout] += sum over voxels of dz, or null
   int D0, D1, D2, Cin, Cout, cin_total, ci_off, ncc, nco, tiles1, tiles2, ntiles;
   int64_t det_stride;
 };
@@ -523,9 +527,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     }
   };
 
-  f32x4 acc[RT][NT];
+  // row tile RT: the bias gradient = (a row of ones) x dz, in the workgroups of the first input-channel chunk / row half only
+  const bool want_db = a.dbias != nullptr && cc == 0 && rh == 0;
+  const uint32_t one2 = li == 0 ? 0x3f803f80u : 0u;  // A fragment whose row 0 is all ones (bf16 1.0), exact in piece 0
+  const u32x4 ones = {one2, one2, one2, one2};
+  f32x4 acc[RT + 1][NT];
 #pragma unroll
-  for (int q = 0; q < RT; ++q)
+  for (int q = 0; q <= RT; ++q)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -551,6 +559,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
         afr[slot][p] = tr_read8(img + abase + aoff[q] + p * WG_XPLANE, img + abase + aoff[q] + p * WG_XPLANE + 8 * 16);
     };
     aload(0, 0);
+    if (want_db) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[RT][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
+                                                                __builtin_bit_cast(bf16x8, bfr[p][n]), acc[RT][n], 0, 0, 0);
+    }
     sfor<0, RT>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
       __builtin_amdgcn_sched_barrier(0);
@@ -571,15 +587,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     if constexpr (C::DBUF) buf ^= 1;
   }
   // ---- add the 8 waves' partial sums through LDS (4 -> 2 -> 1), wave 0 flushes
-  float* red = reinterpret_cast<float*>(lds);  // [wave slot][RT][NT][4][64]
-  constexpr int WSZ = RT * NT * 4 * 64;
+  float* red = reinterpret_cast<float*>(lds);  // [wave slot][RT + 1][NT][4][64]
+  constexpr int WSZ = (RT + 1) * NT * 4 * 64;
 #pragma unroll
   for (int half = 4; half >= 1; half >>= 1) {
     __syncthreads();
     if (wave >= half && wave < 2 * half) {
       float* dstw = red + (size_t)(wave - half) * WSZ;
 #pragma unroll
-      for (int q = 0; q < RT; ++q)
+      for (int q = 0; q <= RT; ++q)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -589,7 +605,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     if (wave < half) {
       const float* srcw = red + (size_t)wave * WSZ;
 #pragma unroll
-      for (int q = 0; q < RT; ++q)
+      for (int q = 0; q <= RT; ++q)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -599,6 +615,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   if (wave != 0) return;
   // lane (li -> co, rows 4 g + i -> block g of the row tile: tap 2 (rh RT + q) + (g >> 1), channel 4 (g & 1) + i of the chunk)
   float* dwp = a.dw + (size_t)blockIdx.x * a.det_stride;
+  if (want_db && g == 0) {  // row 0 of the ones tile
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = n * 16 + li, co = oc * COW + col;
+      if (col < COW && co < Cout) atomicAdd(a.dbias + (size_t)blockIdx.x * a.det_stride + co, acc[RT][n][0]);
+    }
+  }
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
     const int tap = 2 * (rh * RT + q) + (g >> 1);
@@ -633,8 +656,7 @@ int launch_split_wgrad(const SplitWgArgs& a0, hipStream_t st) {
     attr_done = true;
   }
   DetRun det;
-  float* no_dbias = nullptr;
-  if (syn_det_prepare(&det, &a.dw, &no_dbias, (int64_t)27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)
+  if (syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)
     return SYNTHSR_ELAUNCH;
   a.det_stride = det.stride;
   hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(512), smem, st, a);
@@ -644,11 +666,15 @@ int launch_split_wgrad(const SplitWgArgs& a0, hipStream_t st) {
 
 }  // namespace
 
-// called by conv3d.hip's dispatcher when the plan of the layer says `split` (weights packed in the split layout by pack_value)
+// called by conv3d.hip's dispatcher when the plan of the layer says `split` (weights packed in the split layout by pack_value).
+// stats != null: BatchNorm batch statistics (mean | biased variance) of the output, from per-workgroup sums in `partial`
+// (room for 512 x 2 Cout floats)
 extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* in, const float* wp, const float* bias,
                                                                     const float* addend, float* out, const int s[3], int Cin,
-                                                                    int Cout, int mt, int nchunks, int act, hipStream_t st) {
+                                                                    int Cout, int mt, int nchunks, int act, float* stats,
+                                                                    float* partial, hipStream_t st) {
   if ((Cin % 8) != 0 || (Cout % 4) != 0 || mt < 1 || mt > 3 || nchunks < 1) return SYNTHSR_EINVAL;
+  if (stats && (!partial || addend || act == 2)) return SYNTHSR_EINVAL;
   const int64_t vox = (int64_t)s[0] * s[1] * s[2];
   if (vox * Cin * 4 >= (1ll << 31) || vox * Cout * 4 >= (1ll << 31)) return SYNTHSR_EINVAL;
   SplitFwdArgs a;
@@ -657,7 +683,7 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
   a.bias = bias;
   a.addend = addend;
   a.out = out;
-  a.stats_partial = nullptr;
+  a.stats_partial = stats ? partial : nullptr;
   a.D0 = s[0]; a.D1 = s[1]; a.D2 = s[2];
   a.Cin = Cin; a.Cout = Cout; a.ncc = Cin / 8;
   a.tiles1 = (s[1] + TY - 1) / TY;
@@ -665,14 +691,21 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
   a.ntiles = ((s[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
   a.act = act;
   const int gx = split_grid_x(a.ntiles, nchunks);
-  if (mt == 1) return launch_split_fwd<1, false>(a, gx, nchunks, st);
-  if (mt == 2) return launch_split_fwd<2, false>(a, gx, nchunks, st);
-  return launch_split_fwd<3, false>(a, gx, nchunks, st);
+  int rc;
+  if (stats) {
+    rc = mt == 1 ? launch_split_fwd<1, true>(a, gx, nchunks, st)
+                 : (mt == 2 ? launch_split_fwd<2, true>(a, gx, nchunks, st) : launch_split_fwd<3, true>(a, gx, nchunks, st));
+    if (rc != SYNTHSR_OK) return rc;
+    return synthsr_bn_stats_from_partials(partial, gx, vox, Cout, stats, (synthsr_stream_t)st);
+  }
+  rc = mt == 1 ? launch_split_fwd<1, false>(a, gx, nchunks, st)
+               : (mt == 2 ? launch_split_fwd<2, false>(a, gx, nchunks, st) : launch_split_fwd<3, false>(a, gx, nchunks, st));
+  return rc;
 }
 
-// weight gradient of the input-channel range [ci_off, ci_off + Cin) of a layer with cin_total input channels (no dbias: the
-// U-Net's ELU / BatchNorm backward kernels produce it); SYNTHSR_EINVAL = shape not covered, the caller takes the fp32-MFMA path
-extern "C" __attribute__((visibility("hidden"))) int syn_split_wgrad(const float* in, const float* dout, float* dw,
+// weight gradient of the input-channel range [ci_off, ci_off + Cin) of a layer with cin_total input channels (+ optionally the
+// bias gradient); SYNTHSR_EINVAL = shape not covered, the caller takes the fp32-MFMA path
+extern "C" __attribute__((visibility("hidden"))) int syn_split_wgrad(const float* in, const float* dout, float* dw, float* dbias,
                                                                       const int s[3], int cin_total, int ci_off, int Cin,
                                                                       int Cout, hipStream_t st) {
   if ((Cin % 8) != 0 || (Cout != 24 && (Cout % 48) != 0)) return SYNTHSR_EINVAL;
@@ -682,6 +715,7 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_wgrad(const float
   a.in = in;
   a.dout = dout;
   a.dw = dw;
+  a.dbias = dbias;
   a.D0 = s[0]; a.D1 = s[1]; a.D2 = s[2];
   a.Cin = Cin; a.Cout = Cout; a.cin_total = cin_total; a.ci_off = ci_off;
   a.ncc = Cin / 8;

@@ -16,6 +16,22 @@ BN_EPS = 1e-3  # keras.layers.BatchNormalization default epsilon (Keras 2.3.1)
 _prof = None
 
 
+def set_conv_arithmetic(name):
+    """process-wide (include/synthsr_hip_tuning.h: synthsr_set_conv_arithmetic): 'split' (default) = fp32 convolutions on the
+    bf16 matrix cores through three bf16 pieces per operand and six exact partial products (fp32 accumulation, as accurate as
+    the fp32 matrix instructions: tests/test_split_gpu.py); 'fp32_mfma' = fp32 matrix instructions everywhere.  Networks
+    re-pack their weights at the next `repack()` when the mode changed.  Returns the previous setting."""
+    if name not in _lib.CONV_ARITHMETICS:
+        raise ValueError('conv arithmetic should be one of %s' % (_lib.CONV_ARITHMETICS,))
+    prev = conv_arithmetic()
+    _lib.check(_L().synthsr_set_conv_arithmetic(_lib.CONV_ARITHMETICS.index(name)), 'set_conv_arithmetic')
+    return prev
+
+
+def conv_arithmetic():
+    return _lib.CONV_ARITHMETICS[int(_L().synthsr_conv_arithmetic())]
+
+
 def set_deterministic(on=True):
     """process-wide switch (include/synthsr_hip_tuning.h: synthsr_set_deterministic): bit-identical results run after run on
     the same inputs -- every cross-workgroup float accumulation happens in a fixed order, no split-K forward.  Scope: the

@@ -314,7 +314,8 @@ class UNet3D:
         if self.bf16:
             return self._repack_bf16(src)
         from . import _lib
-        if getattr(self, '_jobs', None) is None:
+        if getattr(self, '_jobs', None) is None or getattr(self, '_jobs_arith', None) != ops.conv_arithmetic():
+            self._jobs_arith = ops.conv_arithmetic()   # the packed layouts depend on it (ops.set_conv_arithmetic)
             self._pack_jobs()
         _lib.check(_lib.load().synthsr_conv3d_pack_all(_lib.ptr(self.params if src is None else src), _lib.ptr(self._packed),
                                                        _lib.ptr(self._jobs), int(self._jobs.shape[0]), _lib.stream()),

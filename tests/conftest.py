@@ -166,7 +166,9 @@ def align_pool_ties(dev_choices, oracle_inputs, max_ties=8):
     device and the CPU oracle may legitimately differ there, and the level's gradients then differ by a few 1e-3 of their
     range although both are correct.  This function compares the device's own arg-max choices (`_pool_choices`) with the
     oracle's pre-pooling tensors (oracle.unet_ref.unet_forward(pool_inputs=...)), window by window.  Every disagreement must
-    be a TIE -- the oracle's value at the device's choice within 4 ulp of the oracle's maximum -- and there may be at most
+    be a TIE -- the oracle's value at the device's choice within 4 ulp of the oracle's maximum, an ulp being taken of the larger
+    of the two candidates and the tensor's rms (the candidates are BatchNorm outputs (x - mean) / std: their rounding error is
+    set by the magnitude of x and mean, i.e. by the tensor's scale, not by how close to zero the difference lands) -- and there may be at most
     `max_ties`; anything else raises.  Returns (nudges, n_ties): per pooled level None or a tensor (oracle layout) that, added
     before the oracle's pooling (pool_nudge=...), makes it break exactly those ties the way the device did."""
     import torch
@@ -183,7 +185,7 @@ def align_pool_ties(dev_choices, oracle_inputs, max_ties=8):
             nudges.append(None)
             continue
         a, b = w[diff, idx_dev[diff]], w[diff, idx_or[diff]]
-        ulp = eps * torch.maximum(a.abs(), b.abs()).clamp_min(1e-30)
+        ulp = eps * torch.maximum(a.abs(), b.abs()).clamp_min(float(w.pow(2).mean().sqrt()))
         worst = float(((b - a) / ulp).max())
         assert worst <= 4.0, 'pooled level %d: device and oracle pick different maxima in %d windows whose candidates are up ' \
             'to %.1f ulp apart: not a rounding tie' % (l, diff.numel(), worst)
@@ -241,10 +243,12 @@ def single_shot_parity(run, oracle, compare, max_flips=8, atomics_tol=1e-3, loss
         diff = (_windows(m0) != _windows(m1)).any(1)
         n = int(diff.sum())
         if n:
-            w = _windows(t1)[diff]
+            wall = _windows(t1)
+            w = wall[diff]
             a = (w * _windows(m0)[diff]).sum(1)
             b = (w * _windows(m1)[diff]).sum(1)
-            ulp = torch.finfo(torch.float32).eps * torch.maximum(a.abs(), b.abs()).clamp_min(1e-30)
+            # an ulp of the larger of (candidate, rms of the tensor): see align_pool_ties
+            ulp = torch.finfo(torch.float32).eps * torch.maximum(a.abs(), b.abs()).clamp_min(float(wall.float().pow(2).mean().sqrt()))
             worst = float(((a - b).abs() / ulp).max())
             assert worst <= 4.0, 'level %d: %d pooling windows changed their arg-max between the deterministic and the ' \
                 'atomics run, candidates up to %.1f ulp apart: not a rounding tie' % (l, n, worst)

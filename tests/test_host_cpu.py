@@ -154,10 +154,18 @@ def test_c_abi_exports_every_declared_symbol():
     # argument validation happens before any HIP call: usable without a GPU
     _lib.load()
     big = _lib.i3([160, 160, 160])
-    # packed sizes (query mode): Cout = 24 uses the unpadded 4x4x1-MFMA layout, 48 -> 48 the 16x16x4 B-fragment layout
+    # packed sizes (query mode).  split arithmetic (the default): 3 pieces x [co-chunk][8-channel chunk][7 K steps][co tiles]
+    # fragments of 64 lanes x 8 bf16 (= 4 floats)
+    assert _lib.load().synthsr_conv_arithmetic() == 1
+    assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 3 * 3 * 7 * 2 * 64 * 4
+    assert _lib.load().synthsr_conv3d_pack(None, None, _lib.i3([80, 80, 80]), 48, 48, 0, None) == 3 * 6 * 7 * 3 * 64 * 4
+    assert _lib.load().synthsr_set_conv_arithmetic(2) == -1
+    assert _lib.load().synthsr_set_conv_arithmetic(0) == 0
+    # fp32 MFMA: Cout = 24 uses the unpadded 4x4x1-MFMA layout, 48 -> 48 the 16x16x4 B-fragment layout
     assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 27 * 24 * 24
     assert _lib.load().synthsr_conv3d_pack(None, None, _lib.i3([80, 80, 80]), 48, 48, 0, None) == 2 * 27 * 3 * 3 * 128
     assert _lib.load().synthsr_conv3d_pack(None, None, big, 0, 24, 0, None) == -1
+    assert _lib.load().synthsr_set_conv_arithmetic(1) == 0   # process-wide: back to the default for the tests that follow
 
 
 def test_product_fails_loudly_without_the_library(monkeypatch, tmp_path):

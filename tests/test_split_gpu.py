@@ -1,0 +1,162 @@
+"""fp32 convolutions through three bf16 pieces per operand (csrc/conv_split.hip, ops.set_conv_arithmetic('split'), the default)
+are fp32 computations: measured against a FLOAT64 convolution of the same fp32 inputs they are as accurate as the fp32 matrix
+instructions (csrc/conv3d.hip), on benign data and on data chosen to expose a bf16 short-cut (large common offsets, a wide
+dynamic range, exact cancellation).  The reference computes these layers in fp32 on TensorFlow (ext/neuron/models.py:256-498);
+float64 is the common yardstick, the tolerance of every assertion is written next to it."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref64(x, w, b=None):
+    xi = x.double().cpu().permute(3, 0, 1, 2)[None]
+    wi = w.double().cpu().permute(4, 3, 0, 1, 2)
+    return F.conv3d(xi, wi, None if b is None else b.double().cpu(), padding=1)[0].permute(1, 2, 3, 0)
+
+
+def _wgrad64(x, dy):
+    xi = x.double().cpu().permute(3, 0, 1, 2)[None]
+    g = dy.double().cpu().permute(3, 0, 1, 2)[None]
+    w = torch.zeros(dy.shape[3], x.shape[3], 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(xi, w, None, padding=1).backward(g)
+    return w.grad.permute(2, 3, 4, 1, 0)
+
+
+def _err(y, ref):
+    d = y.double().cpu() - ref
+    scale = float(ref.pow(2).mean().sqrt())
+    return float(d.abs().max()) / scale, float(d.pow(2).mean().sqrt()) / scale
+
+
+def _is_split(shape, cin, cout):
+    import ctypes
+    from synthsr_amd import _lib
+    out = (ctypes.c_int64 * 8)()
+    _lib.check(_lib.load().synthsr_conv3d_plan(_lib.i3(shape), cin, cout, 1, out), 'plan')
+    return int(out[2]) <= -100
+
+
+def _data(kind, D, ci, co, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = torch.randn(D, D, D, ci, generator=g)
+    dy = torch.randn(D, D, D, co, generator=g)
+    w = torch.randn(3, 3, 3, ci, co, generator=g) * 0.05
+    if kind == 'offset':      # a large common offset: bf16 alone would lose the signal (8 significand bits of 100 + noise)
+        x = x * 0.01 + 100.0
+        dy = dy * 0.01 - 37.0
+    elif kind == 'range':     # seven decades of magnitude between channels
+        x = x * torch.logspace(-3, 4, ci)
+        dy = dy * torch.logspace(-2, 3, co)
+        w = w * torch.logspace(-2, 2, ci)[:, None]
+    elif kind == 'cancel':    # weights that sum to ~0 over the taps on a nearly constant input: the result is all rounding
+        x = 1.0 + 1e-4 * x
+        w = w - w.mean((0, 1, 2), keepdim=True)
+    return x.cuda(), dy.cuda(), w.cuda(), (torch.randn(co, generator=g) * 0.1).cuda()
+
+
+@pytest.mark.parametrize('kind', ['normal', 'offset', 'range', 'cancel'])
+@pytest.mark.parametrize('D,ci,co', [(48, 24, 24), (48, 24, 48), (40, 48, 48), (40, 96, 48)])
+def test_split_conv_is_as_accurate_as_the_fp32_mfma_kernels(D, ci, co, kind):
+    from synthsr_amd import ops
+    shape = (D, D, D)
+    x, dy, w, b = _data(kind, D, ci, co, seed=D + ci + co)
+    refs = (_ref64(x, w, b), _ref64(dy, torch.flip(w, (0, 1, 2)).transpose(3, 4)), _wgrad64(x, dy), dy.double().cpu().sum((0, 1, 2)))
+    res = {}
+    prev = ops.conv_arithmetic()
+    try:
+        for mode in ('fp32_mfma', 'split'):
+            ops.set_conv_arithmetic(mode)
+            assert _is_split(shape, ci, co) == (mode == 'split')
+            wp, wpd = ops.pack_conv_weights(w, shape, 0), ops.pack_conv_weights(w, shape, 1)
+            y = ops.conv3d(x, wp, b, co, 0)
+            dx = ops.conv3d(dy, wpd, None, ci, 0)
+            dw, db = torch.zeros_like(w), torch.zeros_like(b)
+            ops.conv3d_wgrad(x, dy, dw, db)
+            res[mode] = [_err(t, r) for t, r in zip((y, dx, dw, db), refs)]
+    finally:
+        ops.set_conv_arithmetic(prev)
+    for k, name in enumerate(('forward', 'data gradient', 'weight gradient', 'bias gradient')):
+        (nmax, nrms), (smax, srms) = res['fp32_mfma'][k], res['split'][k]
+        # (1) not less accurate than the fp32 matrix instructions: rms error within 1.25x (+ 1e-8 for the cases where both are
+        #     ~0), worst element within 2x;  (2) an fp32 result in absolute terms: rms error below 4e-6 of the result's rms even
+        #     on the cancellation-dominated inputs (bf16 inputs alone would be at 4e-3)
+        assert srms <= 1.25 * nrms + 1e-8, (name, kind, res)
+        assert smax <= 2.0 * nmax + 1e-7, (name, kind, res)
+        assert srms < 4e-6 or kind in ('cancel', 'offset'), (name, kind, res)
+
+
+def test_split_pieces_reconstruct_fp32_exactly():
+    """a = a0 + a1 + a2 with every piece a bf16 number: checked through the conv itself -- a 1-tap identity kernel must return
+    its input to the last bit (x * 1.0 is exact in every partial product, the three pieces add up in the fp32 accumulator)"""
+    from synthsr_amd import ops
+    D, C = 48, 24
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = (torch.randn(D, D, D, C, generator=g) * torch.logspace(-6, 6, C)).cuda()
+    w = torch.zeros(3, 3, 3, C, C, device='cuda')
+    w[1, 1, 1] = torch.eye(C)
+    assert ops.conv_arithmetic() == 'split' and _is_split((D, D, D), C, C)
+    y = ops.conv3d(x, ops.pack_conv_weights(w, (D, D, D), 0), None, C, 0)
+    assert torch.equal(y, x)
+
+
+@pytest.mark.parametrize('act', [0, 1])
+def test_split_forward_epilogues_and_fused_statistics(act):
+    """bias + ELU, the addend / ELU'-gating epilogues and the BatchNorm statistics of the output, against torch on the device"""
+    from synthsr_amd import ops
+    D, ci, co = 48, 24, 24
+    x, dy, w, b = _data('normal', D, ci, co, seed=11)
+    shape = (D, D, D)
+    wp = ops.pack_conv_weights(w, shape, 0)
+    lin = _ref64(x, w, b)
+    want = (F.elu(lin) if act else lin)
+    y = ops.conv3d(x, wp, b, co, act)
+    assert _err(y, want)[0] < 2e-6
+    add = torch.randn(D, D, D, co, device='cuda')
+    ya = ops.conv3d_add(x, wp, b, add, co, act)
+    wa = lin + add.double().cpu()
+    assert _err(ya, F.elu(wa) if act else wa)[0] < 2e-6
+    below = F.elu(torch.randn(D, D, D, co, device='cuda'))
+    yg = ops.conv3d_add(x, wp, None, below, co, 2)   # conv * ELU'(below), ELU' through its output
+    wg = _ref64(x, w) * torch.where(below > 0, torch.ones_like(below), below + 1).double().cpu()
+    assert _err(yg, wg)[0] < 2e-6
+    stats, ws = torch.zeros(2 * co, device='cuda'), torch.zeros(2 * co, dtype=torch.float64, device='cuda')
+    ys = ops.conv3d_stats(x, wp, b, co, stats, ws, act)
+    assert torch.equal(ys, y)
+    flat = want.reshape(-1, co)
+    assert float((stats[:co].double().cpu() - flat.mean(0)).abs().max()) < 2e-6
+    assert float((stats[co:].double().cpu() - flat.var(0, unbiased=False)).abs().max()) < 2e-6 * float(flat.var(0).max())
+
+
+def test_network_step_agrees_between_the_two_arithmetics():
+    """one training step of a small U-Net under both arithmetics: same loss and gradients to fp32 accuracy (and the packed
+    weights follow the mode switch)"""
+    from synthsr_amd import ops
+    from synthsr_amd.unet import unet
+    shape = (64, 64, 64)
+    res = {}
+    prev = ops.conv_arithmetic()
+    try:
+        for mode in ('fp32_mfma', 'split'):
+            ops.set_conv_arithmetic(mode)
+            net = unet(nb_features=24, input_shape=list(shape) + [2], nb_levels=3, conv_size=3, nb_labels=1, feat_mult=2,
+                       nb_conv_per_level=2, batch_norm=-1, activation='elu', final_pred_activation='linear', seed=5)
+            g = torch.Generator(device='cpu').manual_seed(9)
+            x = torch.randn(*shape, 2, generator=g).cuda()
+            target = torch.randn(*shape, 1, generator=g).cuda()
+            prev_det = ops.set_deterministic(True)
+            try:
+                loss = net.loss_l1(x, target.reshape(-1)).clone()
+                net.backward()
+            finally:
+                ops.set_deterministic(prev_det)
+            res[mode] = (float(loss.item()), net.grads.clone())
+    finally:
+        ops.set_conv_arithmetic(prev)
+    (l0, g0), (l1, g1) = res['fp32_mfma'], res['split']
+    assert abs(l0 - l1) < 2e-6 * abs(l0)
+    cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
+    assert cos > 1 - 1e-6, cos
+    assert float((g0 - g1).abs().max()) < 2e-3 * float(g0.abs().max())   # max-pool ties may route a few gradients differently

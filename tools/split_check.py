@@ -14,11 +14,8 @@ import torch.nn.functional as F  # noqa: E402
 
 from synthsr_amd import _lib, ops  # noqa: E402
 
-SPLIT_OPTION = 8
-
-
 def set_split(on):
-    _lib.check(_lib.load().synthsr_conv3d_set_option(SPLIT_OPTION, int(on)), 'set_option')
+    ops.set_conv_arithmetic('split' if on else 'fp32_mfma')
 
 
 def plan_is_split(shape, cin, cout):
