@@ -22,6 +22,16 @@
 #include <type_traits>
 #include <utility>
 
+#ifdef SYN_SPLIT_TIMING  // per-phase shader-clock stamps of wave 0 of workgroups 0 and 300 (tools/split_phase_timing.py)
+static __device__ long long* g_tm = nullptr;
+extern "C" int synthsr_split_timing_buffer(long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tm), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#define TM(i) do { if (g_tm && (blockIdx.x == 0 || blockIdx.x == 300) && blockIdx.y == 0 && tid == 0 && tix < 120) g_tm[((blockIdx.x ? 1 : 0) * 120 + tix) * 8 + (i)] = clock64(); } while (0)
+#else
+#define TM(i)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -202,6 +212,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
     wload(wbase, 0, 1);
     wload(wbase, 0, 2);
   }
+  int tix = -1;
+  (void)tix;
   for (int t = walk.pos; t < walk.end; t += walk.stride) {
     f32x4 acc[TY][MT];
 #pragma unroll
@@ -209,10 +221,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int cc = 0; cc < ncc; ++cc) {
+      ++tix;
+      TM(0);
       __syncthreads();  // image `buf` is complete; nobody reads the other one any more
+      TM(1);
       const bool more = cc + 1 < ncc || t + walk.stride < walk.end;
       if (cc + 1 < ncc) load_halo(t, cc + 1);
       else if (t + walk.stride < walk.end) load_halo(t + walk.stride, 0);
+      TM(2);
       const u32x4* wf = wbase + (int64_t)cc * NSTEP * MT * 64;
       const u32x4* wf_next = cc + 1 < ncc ? wf + NSTEP * MT * 64 : wbase;  // step 0 of the chunk that follows
       const unsigned char* img = lds + buf * BUF + lbase;
@@ -261,7 +277,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
         if constexpr (!last) xload(sn, 0);
       });
       __builtin_amdgcn_sched_barrier(0);
+      TM(3);
       if (more) store_halo(buf ^ 1);
+      TM(4);
       buf ^= 1;
     }
     // ---- epilogue: lane (m, g): channels (chunk*MT + mt)*16 + 4g + i of voxel (z0 + wave, y0 + y, x0 + xv)
@@ -321,6 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
       } else if (a.act == 1) epi(std::integral_constant<int, 1>{}, F_{});
       else epi(std::integral_constant<int, 0>{}, F_{});
     }
+    TM(5);
   }
   if constexpr (ST) {
     __syncthreads();

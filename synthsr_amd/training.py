@@ -226,8 +226,11 @@ def keras_trainable_order(net):
 
 def restore_keras_optimizer(path, net):
     """Adam moments + iteration count from a full-model Keras .h5 (SynthSR/training.py:434-439 resumes with
-    `models.load_model`, "momentum is comprised in checkpoints").  Slots are matched by position and verified by shape;
-    returns True if restored, False if the file carries none, raises if they do not fit this network."""
+    `models.load_model`, "momentum is comprised in checkpoints").  Slots are matched by position and verified by shape.
+    Returns True if restored; False if the file carries none, or carries the optimizer of a DIFFERENT model (weights are
+    loaded by layer name, so a file of another architecture is a legitimate source of weights: its optimizer state is then
+    left alone, with a warning, and Adam restarts)."""
+    import warnings
     import torch
     from .keras_h5 import load_keras_optimizer
     slots = load_keras_optimizer(path)
@@ -235,13 +238,18 @@ def restore_keras_optimizer(path, net):
         return False
     it, ms, vs = slots
     order = keras_trainable_order(net)
-    if len(ms) != len(order):
-        raise ValueError('%s: %d Adam slots for %d trainable weights' % (path, len(ms), len(order)))
-    for nm, m, v in zip(order, ms, vs):
+
+    def fits(nm, m, v):
         shp = tuple(net.offsets[nm][1])
         want = (1, 1, 1) + shp if nm.endswith('likelihood/kernel') and m.ndim == 5 else shp   # Keras keeps the 1x1x1 head 5-D
-        if tuple(m.shape) != want or tuple(v.shape) != want:
-            raise ValueError('%s: Adam slot of %s has shape %s, the network expects %s' % (path, nm, tuple(m.shape), want))
+        return tuple(m.shape) == want and tuple(v.shape) == want
+
+    if len(ms) != len(order) or not all(fits(nm, m, v) for nm, m, v in zip(order, ms, vs)):
+        warnings.warn('%s: its optimizer state (%d slots) does not belong to this network (%d trainable weights): weights '
+                      'loaded by name, Adam restarts' % (path, len(ms), len(order)))
+        return False
+    for nm, m, v in zip(order, ms, vs):
+        shp = tuple(net.offsets[nm][1])
         net.view(nm, net.adam_m).copy_(torch.from_numpy(m.reshape(shp)))
         net.view(nm, net.adam_v).copy_(torch.from_numpy(v.reshape(shp)))
     net.iterations = it
