@@ -278,6 +278,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
       });
       __builtin_amdgcn_sched_barrier(0);
       TM(3);
+#ifdef SYN_SPLIT_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TM(6);
+#endif
       if (more) store_halo(buf ^ 1);
       TM(4);
       buf ^= 1;

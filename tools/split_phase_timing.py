@@ -35,12 +35,12 @@ for D, ci, co in ((160, 24, 24), (80, 48, 48)):
     for wg in range(2):
         rows = t[wg]
         n = int((rows[:, 0] > 0).sum())
-        names = ['barrier', 'issue-halo-loads', 'K-loop', 'convert+lds-write', 'to-next (epilogue on last chunk)']
+        names = ['barrier', 'issue-halo-loads', 'K-loop', 'wait-for-loads', 'convert+lds-write', 'to-next (epilogue on last chunk)']
         d, last = [], []
         for j in range(2, n - 1):
             r = rows[j]
             nxt = rows[j + 1][0]
-            row = [r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], nxt - r[4]]
+            row = [r[1] - r[0], r[2] - r[1], r[3] - r[2], r[6] - r[3], r[4] - r[6], nxt - r[4]]
             (last if (j % ncc) == ncc - 1 else d).append(row)
         for nm, arr in (('inner chunks', d), ('last chunk of a tile', last)):
             arr = np.array(arr, dtype=np.float64)
