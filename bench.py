@@ -25,6 +25,7 @@ sys.path.insert(0, HERE)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, exact f32
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16, dense
 HBM_PEAK_GBS = 8000.0
 
 
@@ -192,6 +193,14 @@ def cpu_worker(size, timed):
     print(json.dumps([list(step()) for _ in range(timed)]))
 
 
+CONV_ARITH_NOTE = {
+    'split': 'fp32 tensors, weights, accumulation, BatchNorm statistics and optimizer throughout; inside the 3x3x3 convs of the '
+             'levels with >= 256 tiles every fp32 operand is split EXACTLY into three bf16 numbers and a product is accumulated as '
+             'six exact partial products on v_mfma_f32_16x16x32_bf16 (omitted terms < 2^-26 |a b|): as accurate against a float64 '
+             'convolution as the fp32 matrix instructions (tests/test_split_gpu.py); other layers on fp32 MFMA',
+    'fp32_mfma': 'every convolution on the fp32 matrix instructions (v_mfma_f32_4x4x1 / 16x16x4)'}
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == '--cpu-worker':
         return cpu_worker(int(sys.argv[2]), int(sys.argv[3]))
@@ -208,6 +217,12 @@ def main():
                     help='sample rocm-smi clocks / power every 2 s during the timed region (sustained runs: --steps 1000)')
     ap.add_argument('--no-fuse-pool-bwd', action='store_true', help='A/B switch: separate max-pool / BatchNorm+ELU backward kernels')
     ap.add_argument('--no-fuse-head-bwd', action='store_true', help='A/B switch: separate head backward pass')
+    ap.add_argument('--conv-arith', default='split', choices=['split', 'fp32_mfma'],
+                    help='arithmetic of the fp32 convolutions (ops.set_conv_arithmetic): split = three bf16 pieces per fp32 '
+                         'operand, six exact partial products on the bf16 matrix cores, fp32 accumulation; fp32_mfma = fp32 '
+                         'matrix instructions everywhere')
+    ap.add_argument('--no-arith-compare', action='store_true',
+                    help='skip the short second measurement under the other conv arithmetic (N = 1 only, 20 steps)')
     ap.add_argument('--force-allreduce', action='store_true',
                     help='initialise RCCL and run the bucketed gradient all-reduce even at world size 1 (path test)')
     args = ap.parse_args()
@@ -231,6 +246,7 @@ def main():
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
+    ops.set_conv_arithmetic(args.conv_arith)
     S = args.size
     pool = synthetic_label_pool(8, (S, S, S), 1234)
     rng = np.random.Generator(np.random.Philox(key=1000 + rank))
@@ -320,6 +336,25 @@ def main():
                          step_ms_median=round(float(v[2]), 3), allreduce_wait_ms_mean=round(float(v[3]), 3),
                          allreduce_wait_ms_max=round(float(v[4]), 3)) for r, v in enumerate(allr)]
     final_loss = float(loss.item())
+    # the same steps under the OTHER conv arithmetic, same process / box / clocks (N = 1): what the split arithmetic buys
+    other = None
+    if world == 1 and not args.no_arith_compare:
+        other_name = 'fp32_mfma' if args.conv_arith == 'split' else 'split'
+        ops.set_conv_arithmetic(other_name)
+        net.repack()   # re-plans and re-packs every weight set for the new arithmetic
+        for _ in range(3):
+            one_step()
+        k2 = min(20, args.steps)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(k2 + 1)]
+        ev[0].record()
+        for i in range(k2):
+            one_step()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ms2 = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(k2)])
+        other = {'conv_arithmetic': other_name, 'steps': k2, 'ms_per_step_median': round(float(np.median(ms2)), 3),
+                 'value_median_step': round(1e3 / float(np.median(ms2)), 4)}
+        ops.set_conv_arithmetic(args.conv_arith)
     if not np.isfinite(final_loss):  # tf.debugging.check_numerics of the reference's IdentityLoss
         raise FloatingPointError('non-finite loss after %d steps: the measurement is invalid' % args.steps)
 
@@ -342,10 +377,18 @@ def main():
         conv_total = sum(r['total_ms'] for r in rows)
         dom = rows[0]
         flops_launch = conv_flops(dom['kernel'], dom['shape'], dom['cin'], dom['cout'])
+        # the peak the dominant kernel is priced against: layers on the split arithmetic issue 6 bf16 MFMAs per fp32 MFMA's
+        # worth of algorithmic work -> dense bf16 peak / 6; layers on the fp32 matrix instructions -> the fp32 MFMA peak
+        dom_split = args.conv_arith == 'split' and ops.conv_runs_split(dom['kernel'], dom['shape'], dom['cin'], dom['cout'])
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if dom_split else FP32_MFMA_PEAK_TFLOPS
         roofline = {'bound': 'mfma', 'kernel': '%s %s Cin=%d Cout=%d' % (dom['kernel'], 'x'.join(map(str, dom['shape'])),
                                                                           dom['cin'], dom['cout']),
-                    'achieved': round(dom['tflops'], 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                    'achieved': round(dom['tflops'], 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                    'frac': round(dom['tflops'] / peak, 4),
+                    'peak_basis': ('dense bf16 MFMA peak %.0f TFLOP/s / 6 partial products per fp32 product (split arithmetic); '
+                                   'achieved = ALGORITHMIC fp32 flops / time' % BF16_MFMA_PEAK_TFLOPS) if dom_split else
+                                  'dense fp32 MFMA peak',
+                    'frac_of_fp32_mfma_peak': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                     'flops_per_launch': flops_launch, 'avg_launch_ms': round(dom['avg_ms'], 4),
                     'all_conv_tflops': round(sum(conv_flops(r['kernel'], r['shape'], r['cin'], r['cout']) * r['launches']
                                                  for r in rows) / (conv_total * 1e-3) / 1e12, 2),
@@ -401,7 +444,10 @@ def main():
                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': 'configs[1]: brain_generator %d^3 batch=1 (training() defaults) + 5-level 3-D U-Net '
                                       '(24..384 features, Cin=2) fwd/bwd + Adam, fp32, random-init' % S,
-                          'global_batch': world, 'parallelism': 'dp%d' % world, 'volume': [S, S, S]},
+                          'global_batch': world, 'parallelism': 'dp%d' % world, 'volume': [S, S, S],
+                          'conv_arithmetic': args.conv_arith,
+                          'conv_arithmetic_note': CONV_ARITH_NOTE[args.conv_arith]},
+               'other_conv_arithmetic': other,
                'roofline': roofline, 'roofline_generator': roofline_generator, 'final_loss': round(final_loss, 6),
                'n_ranks_seen': dist.get_world_size() if dist.is_initialized() else 1,
                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if dist.is_initialized() else None,

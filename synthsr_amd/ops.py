@@ -32,6 +32,22 @@ def conv_arithmetic():
     return _lib.CONV_ARITHMETICS[int(_L().synthsr_conv_arithmetic())]
 
 
+def conv_runs_split(kind, shape, cin, cout):
+    """whether a plain 3x3x3 conv launch of this kind ('conv3d_fwd' | 'conv3d_dgrad' | 'conv3d_wgrad', the names of the profile
+    records) runs on the split kernels under the CURRENT arithmetic (mirrors the dispatcher: csrc/conv3d.hip plan_fwd /
+    dispatch_wgrad); used by the benchmarks to price a kernel against the right peak"""
+    import ctypes
+    if conv_arithmetic() != 'split' or kind not in ('conv3d_fwd', 'conv3d_dgrad', 'conv3d_wgrad'):
+        return False
+    d0, d1, d2 = [int(v) for v in shape[:3]]
+    if kind == 'conv3d_wgrad':
+        tiles = -(-d0 // 4) * -(-d1 // 4) * -(-d2 // 16)
+        return tiles >= 256 and cin % 8 == 0 and (cout == 24 or cout % 48 == 0)
+    out = (ctypes.c_int64 * 8)()
+    _lib.check(_L().synthsr_conv3d_plan(_lib.i3((d0, d1, d2)), int(cin), int(cout), 1, out), 'conv3d_plan')
+    return int(out[2]) <= -100
+
+
 def set_deterministic(on=True):
     """process-wide switch (include/synthsr_hip_tuning.h: synthsr_set_deterministic): bit-identical results run after run on
     the same inputs -- every cross-workgroup float accumulation happens in a fixed order, no split-K forward.  Scope: the

@@ -58,7 +58,7 @@ def _data(kind, D, ci, co, seed):
 
 
 @pytest.mark.parametrize('kind', ['normal', 'offset', 'range', 'cancel'])
-@pytest.mark.parametrize('D,ci,co', [(48, 24, 24), (48, 24, 48), (40, 48, 48), (40, 96, 48)])
+@pytest.mark.parametrize('D,ci,co', [(48, 24, 24), (48, 24, 48), (40, 48, 48), (40, 96, 48), (40, 96, 96)])
 def test_split_conv_is_as_accurate_as_the_fp32_mfma_kernels(D, ci, co, kind):
     from synthsr_amd import ops
     shape = (D, D, D)

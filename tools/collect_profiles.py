@@ -94,6 +94,7 @@ def main():
         print('pmc_traffic_json failed:', tj.stderr[-2000:])
     for src, dst in (('bench_default.json', T + '_bench_default.json.log'),
                      ('bench_sustained_1000.json', T + '_bench_sustained_1000.json.log'),
+                     ('bench_fp32_mfma.json', T + '_bench_fp32_mfma_same_box.json.log'),
                      ('bf16_c1_bench.json', T + '_bf16_c1_bench.json.log'), ('bf16_hf_bench.json', T + '_bf16_hf_bench.json.log'),
                      ('f32_hf_bench.json', T + '_f32_hf_bench.json.log'),
                      ('adversarial_bf16.json', T + '_adversarial_bf16_bench.json.log'),
@@ -102,6 +103,7 @@ def main():
         if d:
             print('%-40s %s %s  %s ms/step' % (dst, d.get('value'), d.get('unit'), d.get('ms_per_step')))
     for src, dst in (('conv_bf16_bench.txt', T + '_conv_bf16_bench.txt'), ('det_f32.txt', T + '_deterministic_mode_f32.txt'),
+                     ('split_check.txt', T + '_split_vs_fp32_mfma_accuracy_and_time.txt'),
                      ('det_bf16.txt', T + '_deterministic_mode_bf16.txt')):
         if os.path.exists(os.path.join(O, src)):
             shutil.copy(os.path.join(O, src), os.path.join(P, dst))

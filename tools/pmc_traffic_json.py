@@ -32,9 +32,13 @@ out = {'_note': __doc__.split('bench.py reads')[1].strip().replace('\n', ' '),
        '_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3 --warmup 1 --no-cpu-baseline`, round %s'
                   % (sys.argv[3] if len(sys.argv) > 3 else '?')}
 # the 160^3 24 -> 24 layers are the LARGEST dispatches of their kernels (the same kernels also run smaller layers)
-for key, kern, wide in (('conv3d_wgrad 160x160x160 Cin=24 Cout=24', 'conv3d_wgrad_p4_kernel', True),
-                        ('conv3d_fwd 160x160x160 Cin=24 Cout=24', 'conv3d_fwd_p4_kernel', True),
-                        ('conv3d_dgrad 160x160x160 Cin=24 Cout=24', 'conv3d_fwd_p4_kernel', True)):
+# (split arithmetic, the default: conv_split.hip kernels; fp32_mfma: the 4x4x1-MFMA kernels of conv3d.hip)
+for key, kerns, wide in (('conv3d_wgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_wgrad_kernel<24>', 'conv3d_wgrad_p4_kernel'), True),
+                         ('conv3d_fwd 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd_kernel<2, false>', 'conv3d_fwd_p4_kernel'), True),
+                         ('conv3d_dgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd_kernel<2, false>', 'conv3d_fwd_p4_kernel'), True)):
+    kern = next((k for k in kerns if k in fetch and k in write), None)
+    if kern is None:
+        continue
     f, w = max(fetch[kern]), max(write[kern])
     out[key] = {'kernel': kern, 'fetch_kb': round(f, 1), 'write_kb': round(w, 1), 'bytes': int((2 if wide else 1) * f * 1024 + w * 1024)}
 nvox = 160 ** 3

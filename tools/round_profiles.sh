@@ -10,6 +10,7 @@ mkdir -p $O
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 1000 --warmup 10 --no-cpu-baseline --log-clocks > $O/bench_sustained_1000.json 2> $O/bench_sustained_1000.err
+python bench.py --conv-arith fp32_mfma --steps 50 --warmup 5 --no-cpu-baseline --no-arith-compare > $O/bench_fp32_mfma.json 2> $O/bench_fp32_mfma.err
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/kstats -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/kstats.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_util -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_util.log 2>&1
@@ -22,6 +23,7 @@ python tools/hyperfine_bench.py --dtype f32 --steps 20 --warmup 3 > $O/f32_hf_be
 python tools/adversarial_bench.py --dtype bf16 --steps 10 > $O/adversarial_bf16.json 2> $O/adversarial_bf16.err
 python tools/adversarial_bench.py --dtype f32 --steps 5 > $O/adversarial_f32.json 2> $O/adversarial_f32.err
 python tools/conv_bf16_bench.py 160 > $O/conv_bf16_bench.txt 2>&1
+python tools/split_check.py --acc --time > $O/split_check.txt 2>&1
 python tools/det_bench.py --dtype f32 > $O/det_f32.txt 2>&1
 python tools/det_bench.py --dtype bf16 > $O/det_bf16.txt 2>&1
 ls $O
