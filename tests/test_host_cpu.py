@@ -168,6 +168,30 @@ def test_c_abi_exports_every_declared_symbol():
     assert _lib.load().synthsr_set_conv_arithmetic(1) == 0   # process-wide: back to the default for the tests that follow
 
 
+def test_conv_arithmetic_switch_and_layer_plans():
+    """ops.set_conv_arithmetic / conv_runs_split (host logic, no GPU): the split arithmetic is the default and covers the
+    layers with >= 256 tiles of 4x4x16 voxels and channel counts that are multiples of 8"""
+    from synthsr_amd import ops
+    assert ops.conv_arithmetic() == 'split'
+    with pytest.raises(ValueError):
+        ops.set_conv_arithmetic('bf16')
+    big = (160, 160, 160)
+    assert ops.conv_runs_split('conv3d_fwd', big, 24, 24) and ops.conv_runs_split('conv3d_dgrad', big, 24, 24)
+    assert ops.conv_runs_split('conv3d_wgrad', big, 24, 24) and ops.conv_runs_split('conv3d_wgrad', (80, 80, 80), 48, 48)
+    assert ops.conv_runs_split('conv3d_fwd', (40, 40, 40), 96, 96)
+    assert not ops.conv_runs_split('conv3d_fwd', big, 2, 24)              # first layer: 2 input channels
+    assert not ops.conv_runs_split('conv3d_fwd', (20, 20, 20), 192, 192)  # too few tiles: fp32 MFMA kernels
+    assert not ops.conv_runs_split('conv3d_wgrad', (20, 20, 20), 192, 192)
+    assert not ops.conv_runs_split('conv3d_up_fwd', big, 48, 24)          # folded decoder convs stay on fp32 MFMA
+    prev = ops.set_conv_arithmetic('fp32_mfma')
+    try:
+        assert prev == 'split' and ops.conv_arithmetic() == 'fp32_mfma'
+        assert not ops.conv_runs_split('conv3d_fwd', big, 24, 24)
+    finally:
+        ops.set_conv_arithmetic(prev)
+    assert ops.conv_arithmetic() == 'split'
+
+
 def test_product_fails_loudly_without_the_library(monkeypatch, tmp_path):
     from synthsr_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)

@@ -72,8 +72,18 @@ def copy_json_line(name, dst):
 def main():
     os.makedirs(P, exist_ok=True)
     kernel_stats(os.path.join(O, 'kstats', 'p_kernel_stats.csv'), os.path.join(P, T + '_kernel_stats_final.txt'),
-                 '# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline (1x MI355X, round %s; '
+                 '# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-arith-compare (1x MI355X, round %s; '
                  '23 steps + set-up)' % T)
+    if os.path.exists(os.path.join(O, 'kstats_fp32_mfma', 'p_kernel_stats.csv')):
+        kernel_stats(os.path.join(O, 'kstats_fp32_mfma', 'p_kernel_stats.csv'), os.path.join(P, T + '_kernel_stats_fp32_mfma_same_box.txt'),
+                     '# rocprofv3 --kernel-trace --stats -- python bench.py --conv-arith fp32_mfma --steps 20 --warmup 3 --no-cpu-baseline '
+                     '(1x MI355X, round %s; 23 steps + set-up)' % T)
+    if os.path.exists(os.path.join(O, 'pmc_lds', 'p_counter_collection.csv')):
+        lds = subprocess.run([sys.executable, os.path.join(R, 'tools', 'pmc_raw.py'),
+                              os.path.join(O, 'pmc_lds', 'p_counter_collection.csv'), 'conv3d'], capture_output=True, text=True).stdout
+        with open(os.path.join(P, T + '_pmc_lds_valu.txt'), 'w') as f:
+            f.write('# rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python bench.py '
+                    '--steps 3 --warmup 1 --no-cpu-baseline (tools/pmc_raw.py: per call and per CU-cycle; round %s)\n' % T + lds)
     out = subprocess.run([sys.executable, os.path.join(R, 'tools', 'pmc_mfma_util.py'),
                           os.path.join(O, 'pmc_util', 'p_counter_collection.csv')], capture_output=True, text=True).stdout
     with open(os.path.join(P, T + '_pmc_mfma_util.txt'), 'w') as f:

@@ -8,15 +8,19 @@ T=${1:-rXX}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
-python bench.py --steps 1000 --warmup 10 --no-cpu-baseline --log-clocks > $O/bench_sustained_1000.json 2> $O/bench_sustained_1000.err
-python bench.py --conv-arith fp32_mfma --steps 50 --warmup 5 --no-cpu-baseline --no-arith-compare > $O/bench_fp32_mfma.json 2> $O/bench_fp32_mfma.err
+# counter passes first: profiles/pmc_traffic.json (read by bench.py for roofline.traffic) is rebuilt from THIS code's kernels
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/kstats -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/kstats.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_util -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_util.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-arith-compare > $O/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-arith-compare > $O/pmc_w.log 2>&1
+python $R/tools/pmc_traffic_json.py $O/pmc_f/p_counter_collection.csv $O/pmc_w/p_counter_collection.csv $T > $O/pmc_traffic.json && cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
+rocprofv3 --kernel-trace --stats -d $O/kstats -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-arith-compare > $O/kstats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kstats_fp32_mfma -o p --output-format csv -- python $R/bench.py --conv-arith fp32_mfma --steps 20 --warmup 3 --no-cpu-baseline --no-arith-compare > $O/kstats_fp32_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_util -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-arith-compare > $O/pmc_util.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $O/pmc_lds -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-arith-compare > $O/pmc_lds.log 2>&1
 cd $R
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --steps 1000 --warmup 10 --no-cpu-baseline --no-arith-compare --log-clocks > $O/bench_sustained_1000.json 2> $O/bench_sustained_1000.err
+python bench.py --conv-arith fp32_mfma --steps 50 --warmup 5 --no-cpu-baseline --no-arith-compare > $O/bench_fp32_mfma.json 2> $O/bench_fp32_mfma.err
 python tools/hyperfine_bench.py --dtype bf16 --config c1 --size 160 --steps 50 --warmup 5 > $O/bf16_c1_bench.json 2> $O/bf16_c1_bench.err
 python tools/hyperfine_bench.py --dtype bf16 --steps 50 --warmup 5 > $O/bf16_hf_bench.json 2> $O/bf16_hf_bench.err
 python tools/hyperfine_bench.py --dtype f32 --steps 20 --warmup 3 > $O/f32_hf_bench.json 2> $O/f32_hf_bench.err
