@@ -404,10 +404,12 @@ inline int split_grid_x(int ntiles, int nchunks) {
 //   natural [voxel][channel] layout and are read K(voxel)-major with the transpose read ds_read_b64_tr_b16 (as conv_bf16.hip's
 //   weight-gradient kernel).  LDS bandwidth is what bounds this kernel (an operand fragment is 1 KB = 8 LDS cycles of a CU,
 //   an MFMA 16 cycles of a SIMD), so the decomposition maximises fragment re-use:
-//     * a workgroup owns 8 input channels (blockIdx.y) x COW output channels and ALL 27 taps [RT = 14 row tiles of 16 =
-//       (2 taps) x (2 channel quads) x 4 channels; COW = 48: 7 row tiles, the other half in the next workgroup];
-//     * its 8 waves split the tile's 256 voxels (one 32-voxel K step each): a wave loads the 3 x NT dz fragments of its K step
-//       once and streams the 3 x RT x fragments past them -- 6 NT MFMAs per 3 KB of LDS reads;
+//     * a workgroup owns 8 input channels (blockIdx.y) x COW output channels and ALL 27 taps = 14 row tiles of 16 rows =
+//       (2 taps) x (2 channel quads) x 4 channels;
+//     * COW = 24: its 8 waves split the tile's 256 voxels (one 32-voxel K step each) and every wave holds all 14 row tiles;
+//       COW = 48 (3 column tiles: 14 x 3 accumulator tiles do not fit a wave): waves 0-3 hold row tiles 0-6, waves 4-7 row
+//       tiles 7-13, each wave two K steps -- in both cases a wave loads the 3 x NT dz fragments of a K step once and streams
+//       the 3 x RT x fragments past them: 6 NT MFMAs per 3 KB of LDS reads, and a staged (converted) tile serves all 27 taps;
 //     * accumulators stay in registers over the workgroup's whole tile range; at the end the 8 waves' partial sums are added
 //       through LDS and flushed with one atomic per element (deterministic mode: private planes, common.h DetRun).
 //   8 waves x 1 workgroup per CU; LDS double buffered when it fits (COW = 24: 2 x 68 KB): one barrier per tile.
@@ -448,11 +450,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15, lrow = li >> 2, lq = li & 3;
-  const int halves = 14 / RT;
-  int by = blockIdx.y;
-  const int rh = by % halves;  // which half of the row tiles (COW = 48)
-  by /= halves;
-  const int cc = by % a.ncc, oc = by / a.ncc;
+  constexpr int GROUPS = 14 / RT, WPG = NW / GROUPS, KPW = 8 / WPG;  // row groups, waves per group, K steps per wave
+  const int rh = wave / WPG, wg = wave % WPG;                          // this wave's row group and its place in it
+  const int cc = blockIdx.y % a.ncc, oc = blockIdx.y / a.ncc;
   const TileWalk walk = tile_walk(a.ntiles);
   const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
   const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout;
@@ -467,7 +467,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   }
   // this wave's K step: 32 voxels = x-rows (z, yb) and (z, yb + 1); K index 8 g + j <-> voxel (row g >> 1, x = 8 (j >> 2) +
   // 4 (g & 1) + (j & 3)) -- the same bijection for both operands (conv_bf16.hip)
-  const int kz = wave >> 1, kyb = 2 * (wave & 1);
+  // (KPW = 2: K steps 2 wg and 2 wg + 1 = the four x-rows of z plane wg; the second one sits 2 rows further down)
+  const int ks0 = wg * KPW, kz = ks0 >> 1, kyb = 2 * (ks0 & 1);
+  constexpr uint32_t AK = 2 * HX * 16, BK = 2 * TX * DROWB;  // address step from one K step of a wave to its next
   const int vx = 4 * (g & 1) + lrow, vr = g >> 1;
   const uint32_t abase = (uint32_t)((((kz * HY + kyb + vr) * HX) + vx) * 16);
   const uint32_t bbase = (uint32_t)(3 * WG_XPLANE) + (uint32_t)((((kz * TY + kyb + vr) * TX) + vx) * DROWB + lq * 8);
@@ -571,53 +573,58 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     const bool more = t + walk.stride < walk.end;
     if (more) load_tile(t + walk.stride);
     const unsigned char* img = lds + buf * C::BUFB;
-    u32x4 bfr[3][NT], afr[2][3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-        bfr[p][n] = tr_read8(img + bbase + p * DPLANE + n * 32, img + bbase + p * DPLANE + n * 32 + 8 * DROWB);
-    auto aload = [&](int q, int slot) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        afr[slot][p] = tr_read8(img + abase + aoff[q] + p * WG_XPLANE, img + abase + aoff[q] + p * WG_XPLANE + 8 * 16);
-    };
-    aload(0, 0);
-    if (want_db) {
+    sfor<0, KPW>([&](auto KJ) {
+      constexpr int kj = decltype(KJ)::value;
+      u32x4 bfr[3][NT], afr[2][3];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[RT][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
-                                                                __builtin_bit_cast(bf16x8, bfr[p][n]), acc[RT][n], 0, 0, 0);
-    }
-    sfor<0, RT>([&](auto Q) {
-      constexpr int q = decltype(Q)::value;
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (q + 1 < RT) aload(q + 1, (q + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      sfor<0, 6>([&](auto CC) {
-        constexpr int c = decltype(CC)::value;
-        constexpr int qa = c == 0 ? 2 : ((c == 2 || c == 3) ? 1 : 0), qb = c == 1 ? 2 : ((c == 2 || c == 4) ? 1 : 0);
+          bfr[p][n] = tr_read8(img + bbase + kj * BK + p * DPLANE + n * 32, img + bbase + kj * BK + p * DPLANE + n * 32 + 8 * DROWB);
+      auto aload = [&](int q, int slot) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][qa]),
-                                                               __builtin_bit_cast(bf16x8, bfr[qb][n]), acc[q][n], 0, 0, 0);
+        for (int p = 0; p < 3; ++p)
+          afr[slot][p] = tr_read8(img + abase + kj * AK + aoff[q] + p * WG_XPLANE,
+                                  img + abase + kj * AK + aoff[q] + p * WG_XPLANE + 8 * 16);
+      };
+      aload(0, 0);
+      if (want_db) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[RT][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
+                                                                  __builtin_bit_cast(bf16x8, bfr[p][n]), acc[RT][n], 0, 0, 0);
+      }
+      sfor<0, RT>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (q + 1 < RT) aload(q + 1, (q + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        sfor<0, 6>([&](auto CC) {
+          constexpr int c = decltype(CC)::value;
+          constexpr int qa = c == 0 ? 2 : ((c == 2 || c == 3) ? 1 : 0), qb = c == 1 ? 2 : ((c == 2 || c == 4) ? 1 : 0);
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][qa]),
+                                                                 __builtin_bit_cast(bf16x8, bfr[qb][n]), acc[q][n], 0, 0, 0);
+        });
       });
+      __builtin_amdgcn_sched_barrier(0);
     });
-    __builtin_amdgcn_sched_barrier(0);
     if constexpr (!C::DBUF) __syncthreads();  // single buffer: everyone is done reading before the next image is written
     if (more) store_tile(C::DBUF ? buf ^ 1 : 0);
     if constexpr (C::DBUF) buf ^= 1;
   }
-  // ---- add the 8 waves' partial sums through LDS (4 -> 2 -> 1), wave 0 flushes
-  float* red = reinterpret_cast<float*>(lds);  // [wave slot][RT + 1][NT][4][64]
+  // ---- add the partial sums of the WPG waves of a row group through LDS (halving), the group's first wave flushes
+  float* red = reinterpret_cast<float*>(lds);  // [row group][wave slot][RT + 1][NT][4][64]
   constexpr int WSZ = (RT + 1) * NT * 4 * 64;
+  static_assert((size_t)GROUPS * (WPG / 2) * WSZ * 4 <= (size_t)C::NBUF * C::BUFB, "the reduction slots fit the LDS images");
 #pragma unroll
-  for (int half = 4; half >= 1; half >>= 1) {
+  for (int half = WPG / 2; half >= 1; half >>= 1) {
     __syncthreads();
-    if (wave >= half && wave < 2 * half) {
-      float* dstw = red + (size_t)(wave - half) * WSZ;
+    if (wg >= half && wg < 2 * half) {
+      float* dstw = red + (size_t)(rh * (WPG / 2) + wg - half) * WSZ;
 #pragma unroll
       for (int q = 0; q <= RT; ++q)
 #pragma unroll
@@ -626,8 +633,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
           for (int i = 0; i < 4; ++i) dstw[((q * NT + n) * 4 + i) * 64 + lane] = acc[q][n][i];
     }
     __syncthreads();
-    if (wave < half) {
-      const float* srcw = red + (size_t)wave * WSZ;
+    if (wg < half) {
+      const float* srcw = red + (size_t)(rh * (WPG / 2) + wg) * WSZ;
 #pragma unroll
       for (int q = 0; q <= RT; ++q)
 #pragma unroll
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
           for (int i = 0; i < 4; ++i) acc[q][n][i] += srcw[((q * NT + n) * 4 + i) * 64 + lane];
     }
   }
-  if (wave != 0) return;
+  if (wg != 0) return;
   // lane (li -> co, rows 4 g + i -> block g of the row tile: tap 2 (rh RT + q) + (g >> 1), channel 4 (g & 1) + i of the chunk)
   float* dwp = a.dw + (size_t)blockIdx.x * a.det_stride;
   if (want_db && g == 0) {  // row 0 of the ones tile
@@ -667,7 +674,7 @@ template <int COW>
 int launch_split_wgrad(const SplitWgArgs& a0, hipStream_t st) {
   using C = WgCfg<COW>;
   SplitWgArgs a = a0;
-  const int gy = a.ncc * a.nco * (14 / C::RT);
+  const int gy = a.ncc * a.nco;
   int gx = std::max(1, 256 / gy);  // one workgroup per CU
   if (gx > a.ntiles) gx = a.ntiles;
   const size_t smem = (size_t)C::NBUF * C::BUFB;
