@@ -28,6 +28,7 @@ python tools/adversarial_bench.py --dtype bf16 --steps 10 > $O/adversarial_bf16.
 python tools/adversarial_bench.py --dtype f32 --steps 5 > $O/adversarial_f32.json 2> $O/adversarial_f32.err
 python tools/conv_bf16_bench.py 160 > $O/conv_bf16_bench.txt 2>&1
 python tools/split_check.py --acc --time > $O/split_check.txt 2>&1
+python tools/predict_bench.py 160 > $O/predict_bench.txt 2>&1
 python tools/det_bench.py --dtype f32 > $O/det_f32.txt 2>&1
 python tools/det_bench.py --dtype bf16 > $O/det_bf16.txt 2>&1
 ls $O
