@@ -41,8 +41,9 @@ def _is_split(shape, cin, cout):
 
 def _data(kind, D, ci, co, seed):
     g = torch.Generator(device='cpu').manual_seed(seed)
-    x = torch.randn(D, D, D, ci, generator=g)
-    dy = torch.randn(D, D, D, co, generator=g)
+    S = (D, D, D) if isinstance(D, int) else tuple(D)
+    x = torch.randn(*S, ci, generator=g)
+    dy = torch.randn(*S, co, generator=g)
     w = torch.randn(3, 3, 3, ci, co, generator=g) * 0.05
     if kind == 'offset':      # a large common offset: bf16 alone would lose the signal (8 significand bits of 100 + noise)
         x = x * 0.01 + 100.0
@@ -58,11 +59,13 @@ def _data(kind, D, ci, co, seed):
 
 
 @pytest.mark.parametrize('kind', ['normal', 'offset', 'range', 'cancel'])
-@pytest.mark.parametrize('D,ci,co', [(48, 24, 24), (48, 24, 48), (40, 48, 48), (40, 96, 48), (40, 96, 96)])
+@pytest.mark.parametrize('D,ci,co', [(48, 24, 24), (48, 24, 48), (40, 48, 48), (40, 96, 48), (40, 96, 96), (48, 16, 16),
+                                     ((42, 38, 50), 24, 24), ((38, 42, 50), 48, 48)])
 def test_split_conv_is_as_accurate_as_the_fp32_mfma_kernels(D, ci, co, kind):
+    """(cubes, a one-column-tile layer, and volumes whose sizes are no multiples of the 4x4x16 tile: masked loads / stores)"""
     from synthsr_amd import ops
-    shape = (D, D, D)
-    x, dy, w, b = _data(kind, D, ci, co, seed=D + ci + co)
+    shape = (D, D, D) if isinstance(D, int) else tuple(D)
+    x, dy, w, b = _data(kind, D, ci, co, seed=sum(shape) + ci + co)
     refs = (_ref64(x, w, b), _ref64(dy, torch.flip(w, (0, 1, 2)).transpose(3, 4)), _wgrad64(x, dy), dy.double().cpu().sum((0, 1, 2)))
     res = {}
     prev = ops.conv_arithmetic()
