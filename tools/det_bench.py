@@ -46,12 +46,13 @@ def main():
             same = torch.equal(res['det'][1], net.params)
             print('deterministic rerun: %.2f ms per step, weights bit-identical to the first deterministic run: %s' % (ms, same))
             assert same
+            res['det_warm'] = ms   # the first run also grows the library's private gradient planes (hipMalloc + sync)
         else:
             res[key] = (ms, net.params.clone())
             print('%s %d^3 %s: %.2f ms per U-Net step (status %d)' % (key, S, a.dtype, ms, ops.deterministic_status()))
         del net
     ops.set_deterministic(False)
-    print('deterministic / default = %.2fx' % (res['det'][0] / res['default'][0]))
+    print('deterministic / default = %.2fx (steady state: the rerun)' % (res.get('det_warm', res['det'][0]) / res['default'][0]))
 
 
 if __name__ == '__main__':
