@@ -253,6 +253,13 @@ __host__ __device__ constexpr int syn_split_tap(int slot) {
   const int i = 2 * (p - 9) + h;
   return i < 9 ? i * 3 + 1 : -1;
 }
+// K order of the folded (nearest-upsample) variants: K slot 4 * step + g of the 2 steps of a parity -> tap (a, b, c) in {0, 1}^3
+// of the parity's 2x2x2 window as 4 a + 2 b + c; the two slots of a pair differ in b (one halo row apart: an even number of
+// voxels, see syn_split_tap)
+__host__ __device__ constexpr int syn_split_tap8(int slot) {
+  const int p = slot >> 1, h = slot & 1;
+  return 4 * (p & 1) + 2 * h + (p >> 1);
+}
 // x-voxel of lane m (= lane & 15) of a 16-voxel row under that scheme
 __host__ __device__ constexpr int syn_split_voxel(int m) { return m < 4 ? 2 * m : (m >= 12 ? 2 * m - 16 : 2 * m - 7); }
 

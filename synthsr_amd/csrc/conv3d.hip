@@ -110,6 +110,34 @@ __device__ __forceinline__ float weight_value(const float* __restrict__ w, int t
 __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
                                             int Cout, int mode, int CK, int ncc, int NT, int parity, int NV,
                                             int64_t mfma_count) {
+  if (NT <= -200) {
+    // split layout of ONE parity set of a folded decoder conv (conv_split.hip, UPM): as below with 2 K steps whose slots are
+    // the 8 taps (a, b, c) of the parity's 2x2x2 window (syn_split_tap8).  `mfma_count` carries the number of co-chunks.
+    const int MT = -200 - NT, nchunks = (int)mfma_count;
+    uint32_t r = (uint32_t)idx * 2u;
+    const int j = (int)(r & 7);
+    r >>= 3;
+    const int lane = (int)(r & 63);
+    r >>= 6;
+    const int mt = (int)(r % MT);
+    r /= MT;
+    const int step = (int)(r % 2);
+    r /= 2;
+    const int cc = (int)(r % ncc);
+    r /= ncc;
+    const int chunk = (int)(r % nchunks), piece = (int)(r / nchunks);
+    const int t8 = syn_split_tap8(4 * step + (lane >> 4)), coe = (chunk * MT + mt) * 16 + (lane & 15);
+    const int pz = (parity >> 2) & 1, py = (parity >> 1) & 1, px = parity & 1;
+    // the kernel (UPM 2) reads tap (a, b, c) at halo offset (1 - p) + a per axis: that offset IS the 27-slot index weight_value
+    // wants, whatever the orientation (`mode`) of the set -- folded data gradient (mode 1) or a stride-2 forward (mode 0, 8 + p)
+    const int hz = 1 - pz + (t8 >> 2), hy = 1 - py + ((t8 >> 1) & 1), hx = 1 - px + (t8 & 1);
+    const int tap = (hz * 3 + hy) * 3 + hx;
+    const float v0 = weight_value(w, tap, cc * 8 + j, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
+    const float v1 = weight_value(w, tap, cc * 8 + j + 1, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
+    uint32_t pc[3];
+    syn_split3(v0, v1, pc[0], pc[1], pc[2]);
+    return __uint_as_float(pc[piece]);
+  }
   if (NT <= -100) {
     // split layout (conv_split.hip): bf16 A fragments of the three pieces of every weight, two bf16 per float slot --
     // [piece 3][co-chunk][cc][step 7][mt][lane 64][8]; lane = (m = lane & 15 -> output channel, g = lane >> 4 -> tap syn_split_tap(4 step + g)),
@@ -2817,18 +2845,19 @@ extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, fl
                                int ci_off, int Cin, int Cout, hipStream_t st);
 extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias, const float* addend, float* out,
                              const int s[3], int Cin, int Cout, int mt, int nchunks, int act, float* stats, float* partial,
-                             hipStream_t st);
+                             int upm, hipStream_t st);
 
 struct FwdPlan {
   int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2, brick, wn, wm, split;
-  // NT = 0 selects the 4x4x1 weight layout in pack_value, NT = -Cin the first-layer layout, NT = -100 - MT the split layout
-  int pack_nt() const { return split ? -100 - mt : (c2 ? -c2 : (p4 ? 0 : nt)); }
+  // NT = 0 selects the 4x4x1 weight layout in pack_value, NT = -Cin the first-layer layout, NT = -100 - MT the split layout,
+  // NT = -200 - MT the split layout of a folded conv's parity set; split: 0 no, 1 plain conv, 2 folded data gradient
+  int pack_nt() const { return split == 2 ? -200 - mt : (split ? -100 - mt : (c2 ? -c2 : (p4 ? 0 : nt))); }
   int64_t mfma_count() const {
     if (split) return nchunks;  // what pack_value needs to decode the split layout
     return (p4 || c2) ? 0 : (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128;
   }
   int64_t count() const {
-    if (split) return (int64_t)3 * nchunks * ncc * 7 * mt * 64 * 4;  // floats (= pairs of bf16)
+    if (split) return (int64_t)3 * nchunks * ncc * (split == 2 ? 2 : 7) * mt * 64 * 4;  // floats (= pairs of bf16)
     if (c2) return (int64_t)((27 * c2 * 6 + 15) / 16) * 64;
     return p4 ? (int64_t)ncc * 27 * 9 * 64 : mfma_count() + (int64_t)ncc * 27 * ck * nv;
   }
@@ -2840,15 +2869,16 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
   const bool plain = kind == 1;
   FwdPlan p;
   p.split = 0;
-  if (g_split && plain && (Cin % 8) == 0 && (Cout % 8) == 0) {
+  if (g_split && (plain || kind == 0) && (Cin % 8) == 0 && (Cout % 8) == 0) {
     // fp32 through three bf16 pieces per operand on the bf16 matrix cores (conv_split.hip): layers with enough 4x4x16 tiles
     const int64_t vox = (int64_t)s[0] * s[1] * s[2];
     const int ntiles = cdiv(Cout, 16);
     const int mt = ntiles <= 3 ? ntiles : ((ntiles % 3) == 0 ? 3 : ((ntiles % 2) == 0 ? 2 : 1));
     const int nchunks = cdiv(ntiles, mt);
     const int64_t wgs = (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) * nchunks;
-    if (wgs >= 256 && vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31)) {
-      p.split = 1;
+    // (kind 0 = data gradient of a folded decoder conv: s is the low-resolution grid, the input lives on the 2x grid)
+    if (wgs >= 256 && (plain ? 1 : 8) * vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31)) {
+      p.split = plain ? 1 : 2;
       p.ck = 8;
       p.ncc = Cin / 8;
       p.mt = mt;
@@ -3726,7 +3756,7 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   if (pl.split)
-    return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr,
+    return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr, 0,
                          (hipStream_t)stream);
   const ConvExt ext{0, nullptr, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
@@ -3741,7 +3771,7 @@ int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* b
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   if (pl.split)
-    return syn_split_fwd(in, wpacked, bias, addend, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr,
+    return syn_split_fwd(in, wpacked, bias, addend, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr, 0,
                          (hipStream_t)stream);
   const ConvExt ext{0, addend, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
@@ -3759,7 +3789,7 @@ int synthsr_conv3d_fwd_stats(const float* in, const float* wpacked, const float*
   if (pl.split) {  // statistics accumulated in the conv epilogue (conv_split.hip)
     float* partial = lib_scratch((size_t)512 * 2 * Cout * sizeof(float));
     if (!partial) return SYNTHSR_ELAUNCH;
-    return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, stats, partial,
+    return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, stats, partial, 0,
                          (hipStream_t)stream);
   }
   if (pl.p4 && nvox * Cin * 4 < (1ll << 31))  // statistics accumulated in the conv epilogue
@@ -3789,6 +3819,9 @@ int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo
     return SYNTHSR_EINVAL;
   // effective conv: input channels = Cout (of the forward layer), output channels = Cl
   const FwdPlan pl = plan_fwd(lo_shape, Cout, Cl, 0);
+  if (pl.split)  // the 8 parities as K chunks of one split-arithmetic launch (conv_split.hip, UPM 2)
+    return syn_split_fwd(dout, wpacked8, nullptr, nullptr, dlo, lo_shape, Cout, Cl, pl.mt, pl.nchunks, 0, nullptr, nullptr, 2,
+                         (hipStream_t)stream);
   const int64_t wstride = pl.count();
   const ConvExt ext{2, nullptr, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);

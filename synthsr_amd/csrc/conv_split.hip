@@ -42,7 +42,7 @@ constexpr int TZ = 4, TY = 4, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV
 constexpr uint32_t OOB = 0x80000000u;
 constexpr int PLANE = HVOX * 16;   // one bf16 piece of an 8-channel halo image
 constexpr int BUF = 3 * PLANE;     // the three pieces
-constexpr int NSTEP = 7;           // 27 taps, 4 per MFMA (the 28th slot carries zero weights)
+constexpr int NSTEP27 = 7;         // 27 taps, 4 per MFMA (the 28th slot carries zero weights)
 constexpr int SLAB_Z = 4;
 
 // tile schedule: see conv_bf16.hip (tiles enumerated slab by slab, the list cut into 8 contiguous parts, one per XCD)
@@ -103,8 +103,17 @@ struct SplitFwdArgs {
   int D0, D1, D2, Cin, Cout, ncc, tiles1, tiles2, ntiles, act;
 };
 
-template <int MT, bool ST>
+// UPM = 2: data gradient of the up-sampled channel range of a folded decoder conv (unet.py; ext/neuron/models.py:426-444
+// UpSampling3D -> concatenate -> Conv3D).  `in` = dz on the 2x grid, D0..D2 = the LOW-resolution grid, output = d(lo).  The 8
+// output parities are K chunks (chunk = parity * ncc + input-channel chunk): parity p stages the sub-lattice dz[2 v + p] and
+// multiplies by its transposed 8-tap set (2 K steps, taps syn_split_tap8), whose 2x2x2 window starts at halo offset 1 - p per
+// axis.  wp = 8 parity sets [piece][co-chunk][cc][step 2][mt][lane], back to back.
+template <int MT, bool ST, int UPM = 0>
 __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwdArgs a) {
+  static_assert(UPM == 0 || UPM == 2, "the folded forward pass has its own kernel");
+  static_assert(!(UPM && ST), "statistics belong to plain forward convs");
+  constexpr int NSTEP = UPM ? 2 : NSTEP27;
+  constexpr int UPS = UPM == 2 ? 2 : 1;  // the staged tensor lives on the 2x grid
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
@@ -118,9 +127,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
   int koff[NSTEP];
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-    int tap = syn_split_tap(4 * s + g);
-    if (tap < 0) tap = syn_split_tap((4 * s + g) ^ 1);
-    koff[s] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * 16;
+    if constexpr (UPM) {
+      const int t8 = syn_split_tap8(4 * s + g);
+      koff[s] = (((t8 >> 2) * HY + ((t8 >> 1) & 1)) * HX + (t8 & 1)) * 16;  // + the parity's window origin, per chunk
+    } else {
+      int tap = syn_split_tap(4 * s + g);
+      if (tap < 0) tap = syn_split_tap((4 * s + g) ^ 1);
+      koff[s] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * 16;
+    }
   }
   const int xv = syn_split_voxel(m);
   const int lbase = (wave * HY * HX + xv) * 16;  // voxel (z = wave, y = 0, x = xv) of the tile, tap (0, 0, 0)
@@ -136,14 +150,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
     const int j = tid + 256 * i;
     const int v = j >> 1, h = j & 1;
     const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
-    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4 + h * 16;
+    prel[i] = ((UPS * hz * (UPS * D1) + UPS * hy) * (UPS * D2) + UPS * hx) * Cin * 4 + h * 16;
     plds[i] = v * 16 + h * 8;
     pmask[i] = j < NP ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
   }
   const __amdgpu_buffer_rsrc_t rin =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)(UPM ? 8 : 1) * D0 * D1 * D2 * Cin * 4), 0x00020000);
   f32x4 stg[NL];
-  auto load_halo = [&](int t, int cc) {
+  auto load_halo = [&](int t, int cc_) {
+    const int par = UPM ? cc_ / ncc : 0, cc = UPM ? cc_ - par * ncc : cc_;
     int z0, y0, x0;
     tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
     uint32_t bad = 0x80000000u;
@@ -153,7 +168,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
     for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
 #pragma unroll
     for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
-    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
+    const int base = UPM ? ((((2 * (z0 - 1) + ((par >> 2) & 1)) * (2 * D1) + (2 * (y0 - 1) + ((par >> 1) & 1))) * (2 * D2) +
+                             (2 * (x0 - 1) + (par & 1))) * Cin + cc * 8) * 4
+                         : ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const uint32_t vo = (pmask[i] & bad) ? OOB : (uint32_t)(prel[i] + base);
@@ -177,7 +194,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
 
   // weight fragments of this co-chunk: piece q at wq[q]; fragment (cc, step, mt) at ((cc * NSTEP + step) * MT + mt) * 64
   const int64_t piece_stride = (int64_t)nchunks * ncc * NSTEP * MT * 64;
+  const int64_t par_stride = 3 * piece_stride;  // UPM: one parity's weight set
   const u32x4* __restrict__ wbase = a.wp + (int64_t)chunk * ncc * NSTEP * MT * 64 + lane;
+  const int nck = UPM ? 8 * ncc : ncc;          // K chunks per tile
 
   float s1[ST ? MT : 1][4], s2[ST ? MT : 1][4];  // BatchNorm partial sums of this lane's channels (ST only)
 #pragma unroll
@@ -221,18 +240,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
     for (int y = 0; y < TY; ++y)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cc = 0; cc < ncc; ++cc) {
+    for (int cc = 0; cc < nck; ++cc) {
       ++tix;
       TM(0);
       __syncthreads();  // image `buf` is complete; nobody reads the other one any more
       TM(1);
-      const bool more = cc + 1 < ncc || t + walk.stride < walk.end;
-      if (cc + 1 < ncc) load_halo(t, cc + 1);
+      const bool more = cc + 1 < nck || t + walk.stride < walk.end;
+      if (cc + 1 < nck) load_halo(t, cc + 1);
       else if (t + walk.stride < walk.end) load_halo(t + walk.stride, 0);
       TM(2);
-      const u32x4* wf = wbase + (int64_t)cc * NSTEP * MT * 64;
-      const u32x4* wf_next = cc + 1 < ncc ? wf + NSTEP * MT * 64 : wbase;  // step 0 of the chunk that follows
-      const unsigned char* img = lds + buf * BUF + lbase;
+      // fragments of this K chunk and step 0 of the one that follows (UPM: chunk = parity * ncc + c)
+      auto wchunk = [&](int c_) {
+        const int par = UPM ? c_ / ncc : 0;
+        return wbase + (int64_t)par * par_stride + (int64_t)(c_ - par * ncc) * NSTEP * MT * 64;
+      };
+      const u32x4* wf = wchunk(cc);
+      const u32x4* wf_next = wchunk(cc + 1 < nck ? cc + 1 : 0);
+      int win = 0;  // UPM: the parity's 2x2x2 window starts at halo offset 1 - p per axis
+      if constexpr (UPM) {
+        const int par = cc / ncc;
+        win = (((1 - ((par >> 2) & 1)) * HY + (1 - ((par >> 1) & 1))) * HX + (1 - (par & 1))) * 16;
+      }
+      const unsigned char* img = lds + buf * BUF + lbase + win;
       auto xload = [&](int s, int q) {  // piece q of the four x-rows at the taps of step s
 #pragma unroll
         for (int y = 0; y < TY; ++y) xb[q][y] = *reinterpret_cast<const u32x4*>(img + q * PLANE + koff[s] + y * (HX * 16));
@@ -377,10 +406,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
   }
 }
 
-template <int MT, bool ST>
+template <int MT, bool ST, int UPM = 0>
 int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
   const size_t smem = 2 * BUF;
-  auto kern = conv3d_split_fwd_kernel<MT, ST>;
+  auto kern = conv3d_split_fwd_kernel<MT, ST, UPM>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -698,14 +727,16 @@ int launch_split_wgrad(const SplitWgArgs& a0, hipStream_t st) {
 // called by conv3d.hip's dispatcher when the plan of the layer says `split` (weights packed in the split layout by pack_value).
 // stats != null: BatchNorm batch statistics (mean | biased variance) of the output, from per-workgroup sums in `partial`
 // (room for 512 x 2 Cout floats)
+// upm = 2: the data gradient of a folded decoder conv (`in` = dz on the 2x grid, s = the low-resolution grid, wp = 8 parity sets)
 extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* in, const float* wp, const float* bias,
                                                                     const float* addend, float* out, const int s[3], int Cin,
                                                                     int Cout, int mt, int nchunks, int act, float* stats,
-                                                                    float* partial, hipStream_t st) {
-  if ((Cin % 8) != 0 || (Cout % 4) != 0 || mt < 1 || mt > 3 || nchunks < 1) return SYNTHSR_EINVAL;
-  if (stats && (!partial || addend || act == 2)) return SYNTHSR_EINVAL;
+                                                                    float* partial, int upm, hipStream_t st) {
+  if ((Cin % 8) != 0 || (Cout % 4) != 0 || mt < 1 || mt > 3 || nchunks < 1 || (upm != 0 && upm != 2)) return SYNTHSR_EINVAL;
+  if (stats && (!partial || addend || act == 2 || upm)) return SYNTHSR_EINVAL;
+  if (upm && (bias || addend || act != 0)) return SYNTHSR_EINVAL;
   const int64_t vox = (int64_t)s[0] * s[1] * s[2];
-  if (vox * Cin * 4 >= (1ll << 31) || vox * Cout * 4 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  if ((upm ? 8 : 1) * vox * Cin * 4 >= (1ll << 31) || vox * Cout * 4 >= (1ll << 31)) return SYNTHSR_EINVAL;
   SplitFwdArgs a;
   a.in = in;
   a.wp = reinterpret_cast<const u32x4*>(wp);
@@ -727,6 +758,9 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
     if (rc != SYNTHSR_OK) return rc;
     return synthsr_bn_stats_from_partials(partial, gx, vox, Cout, stats, (synthsr_stream_t)st);
   }
+  if (upm == 2)
+    return mt == 1 ? launch_split_fwd<1, false, 2>(a, gx, nchunks, st)
+                   : (mt == 2 ? launch_split_fwd<2, false, 2>(a, gx, nchunks, st) : launch_split_fwd<3, false, 2>(a, gx, nchunks, st));
   rc = mt == 1 ? launch_split_fwd<1, false>(a, gx, nchunks, st)
                : (mt == 2 ? launch_split_fwd<2, false>(a, gx, nchunks, st) : launch_split_fwd<3, false>(a, gx, nchunks, st));
   return rc;

@@ -113,13 +113,68 @@ def timing(reps, only=''):
               '   split TF: ' + ' '.join('%6.1f' % (fl / t[1][k]) for k in range(3)))
 
 
+def folded(reps):
+    """the up-sampled channel range of a folded decoder conv (ops.conv3d_up / conv3d_up_dgrad / conv3d_up_wgrad): split vs fp32
+    MFMA, error against a float64 evaluation of conv3(UpSampling3D(2)(lo)) at a small size, time at the U-Net's sizes"""
+    torch.manual_seed(1)
+    print('folded decoder conv, up-sampled channels: error vs float64 (max / rms of the result rms), fp32 MFMA | split')
+    for D, cs, cl, co in [(48, 24, 48, 24), (40, 48, 96, 48)]:
+        lo_shape = (D, D, D)
+        lo = torch.randn(D, D, D, cl, device='cuda')
+        dz = torch.randn(2 * D, 2 * D, 2 * D, co, device='cuda')
+        w = torch.randn(3, 3, 3, cs + cl, co, device='cuda') * 0.05
+        up = lo.double().cpu().repeat_interleave(2, 0).repeat_interleave(2, 1).repeat_interleave(2, 2).requires_grad_(True)
+        wu = w[:, :, :, cs:].double().cpu().requires_grad_(True)
+        y = F.conv3d(up.permute(3, 0, 1, 2)[None], wu.permute(4, 3, 0, 1, 2), None, padding=1)[0].permute(1, 2, 3, 0)
+        y.backward(dz.double().cpu())
+        dlo_ref = up.grad.reshape(D, 2, D, 2, D, 2, cl).sum((1, 3, 5))
+        res = {}
+        for mode in (0, 1):
+            set_split(mode)
+            wp_u = ops.pack_conv_weights_ex(w, lo_shape, cs, cl, 0, up=True)
+            wpd_u = ops.pack_conv_weights_ex(w, lo_shape, cs, cl, 1, up=True)
+            yu = ops.conv3d_up(lo, wp_u, None, None, co, 0)
+            dlo = ops.conv3d_up_dgrad(dz, wpd_u, cl)
+            dW = torch.zeros_like(w)
+            dwc = torch.zeros(8, 27, cl, co, device='cuda')
+            ops.conv3d_up_wgrad(lo, dz, dwc, dW, cs)
+            res[mode] = (errs(yu, y.detach()), errs(dlo, dlo_ref), errs(dW[:, :, :, cs:], wu.grad))
+        set_split(0)
+        for k, nm in enumerate(('up fwd', 'up dgrad', 'up wgrad')):
+            print('lo %2d^3 %3d->%-3d %-9s %.3e / %.3e | %.3e / %.3e' % (D, cl, co, nm, res[0][k][0], res[0][k][1], res[1][k][0], res[1][k][1]))
+    print('%-22s %12s %12s %12s   (ms: fp32 MFMA -> split)' % ('layer (low-res grid)', 'up fwd', 'up dgrad', 'up wgrad'))
+    for D, cs, cl, co in [(80, 24, 48, 24), (40, 48, 96, 48), (20, 96, 192, 96)]:
+        lo_shape = (D, D, D)
+        lo = torch.randn(D, D, D, cl, device='cuda')
+        dz = torch.randn(2 * D, 2 * D, 2 * D, co, device='cuda')
+        w = torch.randn(3, 3, 3, cs + cl, co, device='cuda') * 0.05
+        out = torch.empty(2 * D, 2 * D, 2 * D, co, device='cuda')
+        dlo = torch.empty(D, D, D, cl, device='cuda')
+        dW = torch.zeros_like(w)
+        dwc = torch.zeros(8, 27, cl, co, device='cuda')
+        t = {}
+        for mode in (0, 1):
+            set_split(mode)
+            wp_u = ops.pack_conv_weights_ex(w, lo_shape, cs, cl, 0, up=True)
+            wpd_u = ops.pack_conv_weights_ex(w, lo_shape, cs, cl, 1, up=True)
+            t[mode] = (timeit(lambda: ops.conv3d_up(lo, wp_u, None, None, co, 0, out=out), reps),
+                       timeit(lambda: ops.conv3d_up_dgrad(dz, wpd_u, cl, out=dlo), reps),
+                       timeit(lambda: ops.conv3d_up_wgrad(lo, dz, dwc, dW, cs), reps))
+        set_split(0)
+        print('%4d^3 %4d->%-4d      ' % (D, cl, co) + ' '.join('%5.3f->%5.3f' % (t[0][k], t[1][k]) for k in range(3)))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--acc', action='store_true')
     ap.add_argument('--time', action='store_true')
+    ap.add_argument('--folded', action='store_true', help='only the folded decoder conv comparison')
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--only', default='', help='comma-separated D_cin_cout of the timing table')
     a = ap.parse_args()
+    if a.folded:
+        folded(a.reps)
+        sys.exit(0)
     if a.acc or not a.time:
         accuracy()
     if a.time or not a.acc:
