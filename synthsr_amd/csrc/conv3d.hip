@@ -113,7 +113,8 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t
   if (NT <= -200) {
     // split layout of ONE parity set of a folded decoder conv (conv_split.hip, UPM): as below with 2 K steps whose slots are
     // the 8 taps (a, b, c) of the parity's 2x2x2 window (syn_split_tap8).  `mfma_count` carries the number of co-chunks.
-    const int MT = -200 - NT, nchunks = (int)mfma_count;
+    const bool fwdwin = NT <= -300;  // -300 - MT: the forward kernel's window (halo offset a + p), -200 - MT: the data gradient's
+    const int MT = fwdwin ? -300 - NT : -200 - NT, nchunks = (int)mfma_count;
     uint32_t r = (uint32_t)idx * 2u;
     const int j = (int)(r & 7);
     r >>= 3;
@@ -130,7 +131,9 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t
     const int pz = (parity >> 2) & 1, py = (parity >> 1) & 1, px = parity & 1;
     // the kernel (UPM 2) reads tap (a, b, c) at halo offset (1 - p) + a per axis: that offset IS the 27-slot index weight_value
     // wants, whatever the orientation (`mode`) of the set -- folded data gradient (mode 1) or a stride-2 forward (mode 0, 8 + p)
-    const int hz = 1 - pz + (t8 >> 2), hy = 1 - py + ((t8 >> 1) & 1), hx = 1 - px + (t8 & 1);
+    // (the forward kernel, conv3d_split_upfwd_kernel, reads it at halo offset a + p)
+    const int hz = (fwdwin ? pz : 1 - pz) + (t8 >> 2), hy = (fwdwin ? py : 1 - py) + ((t8 >> 1) & 1),
+              hx = (fwdwin ? px : 1 - px) + (t8 & 1);
     const int tap = (hz * 3 + hy) * 3 + hx;
     const float v0 = weight_value(w, tap, cc * 8 + j, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
     const float v1 = weight_value(w, tap, cc * 8 + j + 1, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
@@ -2843,6 +2846,8 @@ static int g_split = 1;  // synthsr_set_conv_arithmetic: fp32 convs through 3 x 
                          // (conv_split.hip) where the layer has enough tiles; 0 = fp32 MFMA kernels everywhere
 extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int cin_total,
                                int ci_off, int Cin, int Cout, hipStream_t st);
+extern "C" int syn_split_upfwd(const float* lo, const float* wp, const float* bias, const float* addend, float* out,
+                               const int s[3], int Cin, int Cout, int mt, int act, hipStream_t st);
 extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias, const float* addend, float* out,
                              const int s[3], int Cin, int Cout, int mt, int nchunks, int act, float* stats, float* partial,
                              int upm, hipStream_t st);
@@ -2850,14 +2855,15 @@ extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias
 struct FwdPlan {
   int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2, brick, wn, wm, split;
   // NT = 0 selects the 4x4x1 weight layout in pack_value, NT = -Cin the first-layer layout, NT = -100 - MT the split layout,
-  // NT = -200 - MT the split layout of a folded conv's parity set; split: 0 no, 1 plain conv, 2 folded data gradient
-  int pack_nt() const { return split == 2 ? -200 - mt : (split ? -100 - mt : (c2 ? -c2 : (p4 ? 0 : nt))); }
+  // NT = -200 - MT / -300 - MT the split layout of a folded conv's parity set (data gradient / forward window);
+  // split: 0 no, 1 plain conv, 2 folded data gradient, 3 folded forward
+  int pack_nt() const { return split == 3 ? -300 - mt : (split == 2 ? -200 - mt : (split ? -100 - mt : (c2 ? -c2 : (p4 ? 0 : nt)))); }
   int64_t mfma_count() const {
     if (split) return nchunks;  // what pack_value needs to decode the split layout
     return (p4 || c2) ? 0 : (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128;
   }
   int64_t count() const {
-    if (split) return (int64_t)3 * nchunks * ncc * (split == 2 ? 2 : 7) * mt * 64 * 4;  // floats (= pairs of bf16)
+    if (split) return (int64_t)3 * nchunks * ncc * (split >= 2 ? 2 : 7) * mt * 64 * 4;  // floats (= pairs of bf16)
     if (c2) return (int64_t)((27 * c2 * 6 + 15) / 16) * 64;
     return p4 ? (int64_t)ncc * 27 * 9 * 64 : mfma_count() + (int64_t)ncc * 27 * ck * nv;
   }
@@ -2869,7 +2875,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
   const bool plain = kind == 1;
   FwdPlan p;
   p.split = 0;
-  if (g_split && (plain || kind == 0) && (Cin % 8) == 0 && (Cout % 8) == 0) {
+  if (g_split && (Cin % 8) == 0 && (Cout % 8) == 0) {
     // fp32 through three bf16 pieces per operand on the bf16 matrix cores (conv_split.hip): layers with enough 4x4x16 tiles
     const int64_t vox = (int64_t)s[0] * s[1] * s[2];
     const int ntiles = cdiv(Cout, 16);
@@ -2877,8 +2883,10 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
     const int nchunks = cdiv(ntiles, mt);
     const int64_t wgs = (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) * nchunks;
     // (kind 0 = data gradient of a folded decoder conv: s is the low-resolution grid, the input lives on the 2x grid)
-    if (wgs >= 256 && (plain ? 1 : 8) * vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31)) {
-      p.split = plain ? 1 : 2;
+    // (kind 2 = their forward pass: the OUTPUT lives on the 2x grid, one co-chunk of <= 48 channels)
+    if (wgs >= 256 && (kind == 0 ? 8 : 1) * vox * Cin * 4 < (1ll << 31) && (kind == 2 ? 8 : 1) * vox * Cout * 4 < (1ll << 31) &&
+        (kind != 2 || nchunks == 1)) {
+      p.split = plain ? 1 : (kind == 0 ? 2 : 3);
       p.ck = 8;
       p.ncc = Cin / 8;
       p.mt = mt;
@@ -3805,6 +3813,8 @@ int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* b
       lo_shape[2] < 1 || (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(lo_shape, Cl, Cout, 2);
+  if (pl.split)  // all parities from one converted low-resolution halo (conv_split.hip: conv3d_split_upfwd_kernel)
+    return syn_split_upfwd(lo, wpacked8, bias, addend, out, lo_shape, Cl, Cout, pl.mt, act, (hipStream_t)stream);
   const int64_t wstride = pl.count();
   const ConvExt ext{1, addend, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);

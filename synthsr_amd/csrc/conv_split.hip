@@ -52,7 +52,7 @@ struct TileWalk {
 __device__ __forceinline__ TileWalk tile_walk(int ntiles) {
   // workgroup (x, y) has linear id x + G y and runs on XCD id % 8; the workgroups of one XCD and one y are x, x + 8, ...
   const int G = (int)gridDim.x, b = (int)blockIdx.x;
-  const int per = (ntiles + 7) / 8, k = (b + G * (int)blockIdx.y) & 7;
+  const int per = (ntiles + 7) / 8, k = (b + G * (int)(blockIdx.y + gridDim.y * blockIdx.z)) & 7;
   TileWalk w;
   if (G >= 8) {
     w.pos = k * per + (b >> 3);
@@ -404,6 +404,202 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
       }
     }
   }
+}
+
+// Forward pass of the up-sampled channel range of a folded decoder conv: out[2 v + p] (+)= sum over the 8 taps (a, b, c) of parity
+// p's 2x2x2 window of W_p[(a, b, c)] . lo[v + (a, b, c) + p - 1], for all parities p from ONE staged (converted) low-resolution
+// halo image -- a converted element feeds 8 parities x 8 taps instead of 27 taps.  512 threads: wave = (z plane, y half) of the
+// 4x4x16 low-resolution tile, two x-rows per wave; accumulators for NPAR parities x 2 rows x MT co-tiles stay in registers over
+// the input-channel chunks (register budget: NPAR = 4, or 2 for MT = 3; blockIdx.z = parity group).  Per chunk 2 NPAR K steps (parity, step) of
+// 6 x 2 x MT MFMAs, weights one step ahead (two register sets), activations re-loaded per step.  D0..D2 = the low-res grid.
+template <int MT, int NPAR>
+__global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int NTHR = 512, RW = 2, NS = 2 * NPAR;  // rows per wave, K steps per chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4, zw = wave & 3, yh = wave >> 2;
+  const int pg = blockIdx.z;  // parity group: parities pg * NPAR + q
+  const TileWalk walk = tile_walk(a.ntiles);
+  const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
+  const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout, ncc = a.ncc;
+
+  int koff[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t8 = syn_split_tap8(4 * s + g);
+    koff[s] = (((t8 >> 2) * HY + ((t8 >> 1) & 1)) * HX + (t8 & 1)) * 16;
+  }
+  const int xv = syn_split_voxel(m);
+  // window origin of parity pg * NPAR + q: halo offset p per axis; the group part at run time, the rest at compile time
+  const int gpar = pg * NPAR;
+  const int lbase = ((zw * HY + RW * yh) * HX + xv) * 16 +
+                    ((((gpar >> 2) & 1) * HY + ((gpar >> 1) & 1)) * HX + (gpar & 1)) * 16;
+
+  constexpr int NP = HVOX * 2, NL = (NP + NTHR - 1) / NTHR;
+  int prel[NL], plds[NL];
+  uint32_t pmask[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int j = tid + NTHR * i;
+    const int v = j >> 1, h = j & 1;
+    const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
+    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4 + h * 16;
+    plds[i] = v * 16 + h * 8;
+    pmask[i] = j < NP ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+  }
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  f32x4 stg[NL];
+  auto load_halo = [&](int t, int cc) {
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const uint32_t vo = (pmask[i] & bad) ? OOB : (uint32_t)(prel[i] + base);
+      stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
+    }
+  };
+  auto store_halo = [&](int buf) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    unsigned char* dst = lds + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if (i == NL - 1 && tid + NTHR * i >= NP) continue;
+      uint32_t p0, p1, p2, q0, q1, q2;
+      syn_split3(stg[i][0], stg[i][1], p0, p1, p2);
+      syn_split3(stg[i][2], stg[i][3], q0, q1, q2);
+      *reinterpret_cast<u32x2*>(dst + plds[i]) = (u32x2){p0, q0};
+      *reinterpret_cast<u32x2*>(dst + PLANE + plds[i]) = (u32x2){p1, q1};
+      *reinterpret_cast<u32x2*>(dst + 2 * PLANE + plds[i]) = (u32x2){p2, q2};
+    }
+  };
+
+  // weights: 8 parity sets [piece 3][cc][step 2][mt][lane] back to back (one co-chunk: Cout <= 16 MT)
+  const int64_t piece_stride = (int64_t)ncc * 2 * MT * 64, par_stride = 3 * piece_stride;
+  const u32x4* __restrict__ wbase = a.wp + (int64_t)gpar * par_stride + lane;
+  u32x4 wa[2][3][MT], xb[3][RW];
+  auto wload = [&](int cc, int q, int s, int slot) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        wa[slot][pc][mt] = wbase[(int64_t)q * par_stride + pc * piece_stride + ((cc * 2 + s) * MT + mt) * 64];
+  };
+
+  const int64_t out_bytes = (int64_t)8 * D0 * D1 * D2 * Cout * 4;
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t radd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.addend ? a.addend : a.out), 0, (int)out_bytes, 0x00020000);
+
+  int buf = 0;
+  if (walk.pos < walk.end) {
+    load_halo(walk.pos, 0);
+    store_halo(0);
+    wload(0, 0, 0, 0);
+  }
+  for (int t = walk.pos; t < walk.end; t += walk.stride) {
+    f32x4 acc[NPAR][RW][MT];
+#pragma unroll
+    for (int q = 0; q < NPAR; ++q)
+#pragma unroll
+      for (int y = 0; y < RW; ++y)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[q][y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < ncc; ++cc) {
+      __syncthreads();
+      const bool more = cc + 1 < ncc || t + walk.stride < walk.end;
+      if (cc + 1 < ncc) load_halo(t, cc + 1);
+      else if (t + walk.stride < walk.end) load_halo(t + walk.stride, 0);
+      const unsigned char* img = lds + buf * BUF + lbase;
+      const int cc_next = cc + 1 < ncc ? cc + 1 : 0;
+      sfor<0, NS>([&](auto N) {
+        constexpr int n = decltype(N)::value, q = n >> 1, s = n & 1, slot = n & 1;
+        constexpr int win = ((((q >> 2) & 1) * HY + ((q >> 1) & 1)) * HX + (q & 1)) * 16;  // parity q's part of the window origin
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+          for (int y = 0; y < RW; ++y)
+            xb[pc][y] = *reinterpret_cast<const u32x4*>(img + win + pc * PLANE + koff[s] + y * (HX * 16));
+        if constexpr (n + 1 < NS) wload(cc, (n + 1) >> 1, (n + 1) & 1, slot ^ 1);
+        else wload(cc_next, 0, 0, slot ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        sfor<0, 6>([&](auto CC) {
+          constexpr int c = decltype(CC)::value;
+          constexpr int qa = c == 0 ? 2 : ((c == 2 || c == 3) ? 1 : 0), qb = c == 1 ? 2 : ((c == 2 || c == 4) ? 1 : 0);
+#pragma unroll
+          for (int y = 0; y < RW; ++y)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[q][y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[slot][qa][mt]),
+                                                                      __builtin_bit_cast(bf16x8, xb[qb][y]), acc[q][y][mt], 0, 0, 0);
+        });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) store_halo(buf ^ 1);
+      buf ^= 1;
+    }
+    // ---- epilogue: lane (m, g): channels mt*16 + 4g + i of voxel 2 (z0 + zw, y0 + 2 yh + y, x0 + xv) + parity
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    const int gz = z0 + zw, gx = x0 + xv, gy0 = y0 + RW * yh;
+    const bool zx_ok = gz < D0 && gx < D2;
+#pragma unroll
+    for (int q = 0; q < NPAR; ++q) {
+      const int par = gpar + q, pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co = mt * 16 + 4 * g;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias && co < Cout) bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int y = 0; y < RW; ++y) {
+          const bool vok = zx_ok && (gy0 + y) < D1 && co < Cout;
+          const uint32_t off = vok ? (uint32_t)(((2 * gz + pz) * (2 * D1) + (2 * (gy0 + y) + py)) * (2 * D2) + (2 * gx + px)) *
+                                         (uint32_t)(Cout * 4) + (uint32_t)(co * 4)
+                                   : OOB;
+          f32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[q][y][mt][i] + bias[i];
+          if (a.addend) {
+            const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)off, 0, 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += b[i];
+          }
+          if (a.act == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)off, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int NPAR>
+int launch_split_upfwd(const SplitFwdArgs& a, hipStream_t st) {
+  constexpr int NG = 8 / NPAR;
+  int gx = std::max(8, ((256 / NG) / 8) * 8);  // one workgroup per CU
+  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  if (a.ntiles < 8) gx = a.ntiles;
+  const size_t smem = 2 * BUF;
+  auto kern = conv3d_split_upfwd_kernel<MT, NPAR>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, 1, NG), dim3(512), smem, st, a);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
 template <int MT, bool ST, int UPM = 0>
@@ -764,6 +960,32 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
   rc = mt == 1 ? launch_split_fwd<1, false>(a, gx, nchunks, st)
                : (mt == 2 ? launch_split_fwd<2, false>(a, gx, nchunks, st) : launch_split_fwd<3, false>(a, gx, nchunks, st));
   return rc;
+}
+
+// forward pass of the up-sampled channel range of a folded decoder conv: lo [s][Cin] -> out [2 s][Cout] (Cout <= 48: one co-chunk),
+// wp = 8 parity sets in the split layout; act 0 / 1, optional bias and addend (indexed like the output)
+extern "C" __attribute__((visibility("hidden"))) int syn_split_upfwd(const float* lo, const float* wp, const float* bias,
+                                                                      const float* addend, float* out, const int s[3], int Cin,
+                                                                      int Cout, int mt, int act, hipStream_t st) {
+  if ((Cin % 8) != 0 || (Cout % 4) != 0 || mt < 1 || mt > 3 || Cout > 16 * mt || (act != 0 && act != 1)) return SYNTHSR_EINVAL;
+  const int64_t vox = (int64_t)s[0] * s[1] * s[2];
+  if (vox * Cin * 4 >= (1ll << 31) || 8 * vox * Cout * 4 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  SplitFwdArgs a;
+  a.in = lo;
+  a.wp = reinterpret_cast<const u32x4*>(wp);
+  a.bias = bias;
+  a.addend = addend;
+  a.out = out;
+  a.stats_partial = nullptr;
+  a.D0 = s[0]; a.D1 = s[1]; a.D2 = s[2];
+  a.Cin = Cin; a.Cout = Cout; a.ncc = Cin / 8;
+  a.tiles1 = (s[1] + TY - 1) / TY;
+  a.tiles2 = (s[2] + TX - 1) / TX;
+  a.ntiles = ((s[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
+  a.act = act;
+  if (mt == 1) return launch_split_upfwd<1, 4>(a, st);
+  if (mt == 2) return launch_split_upfwd<2, 4>(a, st);
+  return launch_split_upfwd<3, 2>(a, st);
 }
 
 // weight gradient of the input-channel range [ci_off, ci_off + Cin) of a layer with cin_total input channels (+ optionally the
