@@ -105,68 +105,64 @@ __device__ __forceinline__ float weight_value(const float* __restrict__ w, int t
   return v;
 }
 
+// ---- split layouts (conv_split.hip): bf16 A fragments of the three pieces of every weight, two bf16 per float slot --
+// [piece 3][co-chunk][cc][step][mt][lane 64][8]; lane = (m = lane & 15 -> output channel, g = lane >> 4 -> K slot 4 step + g),
+// value j -> input channel cc*8 + j.  NT = -100 - MT: plain conv, 7 K steps, slot -> tap by syn_split_tap (one spare slot:
+// zero).  NT = -200 - MT / -300 - MT: ONE parity set of a folded decoder conv, 2 K steps whose slots are the 8 taps (a, b, c)
+// of the parity's 2x2x2 window (syn_split_tap8); the kernel reads tap (a, b, c) at halo offset (1 - p) + a per axis (UPM 2:
+// folded data gradient, or a stride-2 forward, parity code 8 + p) or a + p (the forward kernel conv3d_split_upfwd_kernel) --
+// that offset IS the 27-slot index weight_value folds the original taps onto, whatever the orientation (`mode`) of the set.
+// `nchunks` (the job's mfma_count field) = number of co-chunks.
+__host__ __device__ inline int64_t split_plane_floats(int NT, int ncc, int nchunks) {  // floats of one piece plane
+  const int MT = NT <= -300 ? -300 - NT : (NT <= -200 ? -200 - NT : -100 - NT);
+  return (int64_t)nchunks * ncc * (NT <= -200 ? 2 : 7) * MT * 64 * 4;
+}
+// the three pieces (packed bf16 pairs) of float slot i of a piece plane
+__device__ __forceinline__ void split_pack_pair(const float* __restrict__ w, int64_t i, int Cin_total, int ci_off, int Cin, int Cout,
+                                                int mode, int ncc, int NT, int parity, int nchunks, uint32_t pc[3]) {
+  const bool up = NT <= -200, fwdwin = NT <= -300;
+  const int MT = fwdwin ? -300 - NT : (up ? -200 - NT : -100 - NT), nstep = up ? 2 : 7;
+  uint32_t r = (uint32_t)i * 2u;
+  const int j = (int)(r & 7);
+  r >>= 3;
+  const int lane = (int)(r & 63);
+  r >>= 6;
+  const int mt = (int)(r % MT);
+  r /= MT;
+  const int step = (int)(r % nstep);
+  r /= nstep;
+  const int cc = (int)(r % ncc);
+  const int chunk = (int)(r / ncc);
+  (void)nchunks;
+  const int coe = (chunk * MT + mt) * 16 + (lane & 15);
+  int tap;
+  if (up) {
+    const int t8 = syn_split_tap8(4 * step + (lane >> 4));
+    const int pz = (parity >> 2) & 1, py = (parity >> 1) & 1, px = parity & 1;
+    const int hz = (fwdwin ? pz : 1 - pz) + (t8 >> 2), hy = (fwdwin ? py : 1 - py) + ((t8 >> 1) & 1),
+              hx = (fwdwin ? px : 1 - px) + (t8 & 1);
+    tap = (hz * 3 + hy) * 3 + hx;
+  } else {
+    tap = syn_split_tap(4 * step + (lane >> 4));
+  }
+  float v0 = 0.f, v1 = 0.f;
+  if (tap >= 0) {
+    v0 = weight_value(w, tap, cc * 8 + j, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
+    v1 = weight_value(w, tap, cc * 8 + j + 1, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
+  }
+  syn_split3(v0, v1, pc[0], pc[1], pc[2]);
+}
+
 // packed layout of one weight set: MFMA section [nc][cc][tap][cg][nt][lane][2] (B fragments), followed — when the layer
 // keeps NV output channels on the vector ALUs — by the VALU section [cc][tap][ci (CK)][NV] (wave-uniform scalar loads)
 __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
                                             int Cout, int mode, int CK, int ncc, int NT, int parity, int NV,
                                             int64_t mfma_count) {
-  if (NT <= -200) {
-    // split layout of ONE parity set of a folded decoder conv (conv_split.hip, UPM): as below with 2 K steps whose slots are
-    // the 8 taps (a, b, c) of the parity's 2x2x2 window (syn_split_tap8).  `mfma_count` carries the number of co-chunks.
-    const bool fwdwin = NT <= -300;  // -300 - MT: the forward kernel's window (halo offset a + p), -200 - MT: the data gradient's
-    const int MT = fwdwin ? -300 - NT : -200 - NT, nchunks = (int)mfma_count;
-    uint32_t r = (uint32_t)idx * 2u;
-    const int j = (int)(r & 7);
-    r >>= 3;
-    const int lane = (int)(r & 63);
-    r >>= 6;
-    const int mt = (int)(r % MT);
-    r /= MT;
-    const int step = (int)(r % 2);
-    r /= 2;
-    const int cc = (int)(r % ncc);
-    r /= ncc;
-    const int chunk = (int)(r % nchunks), piece = (int)(r / nchunks);
-    const int t8 = syn_split_tap8(4 * step + (lane >> 4)), coe = (chunk * MT + mt) * 16 + (lane & 15);
-    const int pz = (parity >> 2) & 1, py = (parity >> 1) & 1, px = parity & 1;
-    // the kernel (UPM 2) reads tap (a, b, c) at halo offset (1 - p) + a per axis: that offset IS the 27-slot index weight_value
-    // wants, whatever the orientation (`mode`) of the set -- folded data gradient (mode 1) or a stride-2 forward (mode 0, 8 + p)
-    // (the forward kernel, conv3d_split_upfwd_kernel, reads it at halo offset a + p)
-    const int hz = (fwdwin ? pz : 1 - pz) + (t8 >> 2), hy = (fwdwin ? py : 1 - py) + ((t8 >> 1) & 1),
-              hx = (fwdwin ? px : 1 - px) + (t8 & 1);
-    const int tap = (hz * 3 + hy) * 3 + hx;
-    const float v0 = weight_value(w, tap, cc * 8 + j, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
-    const float v1 = weight_value(w, tap, cc * 8 + j + 1, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
+  if (NT <= -100) {  // split layouts: one piece of split_pack_pair
+    const int64_t n3 = split_plane_floats(NT, ncc, (int)mfma_count);
     uint32_t pc[3];
-    syn_split3(v0, v1, pc[0], pc[1], pc[2]);
-    return __uint_as_float(pc[piece]);
-  }
-  if (NT <= -100) {
-    // split layout (conv_split.hip): bf16 A fragments of the three pieces of every weight, two bf16 per float slot --
-    // [piece 3][co-chunk][cc][step 7][mt][lane 64][8]; lane = (m = lane & 15 -> output channel, g = lane >> 4 -> tap syn_split_tap(4 step + g)),
-    // value j -> input channel cc*8 + j.  `mfma_count` carries the number of co-chunks.
-    const int MT = -100 - NT, nchunks = (int)mfma_count;
-    uint32_t r = (uint32_t)idx * 2u;
-    const int j = (int)(r & 7);
-    r >>= 3;
-    const int lane = (int)(r & 63);
-    r >>= 6;
-    const int mt = (int)(r % MT);
-    r /= MT;
-    const int step = (int)(r % 7);
-    r /= 7;
-    const int cc = (int)(r % ncc);
-    r /= ncc;
-    const int chunk = (int)(r % nchunks), piece = (int)(r / nchunks);
-    const int tap = syn_split_tap(4 * step + (lane >> 4)), coe = (chunk * MT + mt) * 16 + (lane & 15);
-    float v0 = 0.f, v1 = 0.f;
-    if (tap >= 0) {
-      v0 = weight_value(w, tap, cc * 8 + j, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
-      v1 = weight_value(w, tap, cc * 8 + j + 1, coe, Cin_total, ci_off, Cin, Cout, mode, parity);
-    }
-    uint32_t pc[3];
-    syn_split3(v0, v1, pc[0], pc[1], pc[2]);
-    return __uint_as_float(pc[piece]);
+    split_pack_pair(w, idx % n3, Cin_total, ci_off, Cin, Cout, mode, ncc, NT, parity, (int)mfma_count, pc);
+    return __uint_as_float(pc[idx / n3]);
   }
   if (NT < 0) {
     // first-layer layout (conv3d_fwd_c2_kernel, Cin = -NT <= 2, Cout = 24): [r][lane 64], G = r*16 + (lane >> 2) =
@@ -231,6 +227,17 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t
 __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin_total, int ci_off, int Cin,
                             int Cout, int mode, int CK, int ncc, int NT, int nchunks, int parity, int NV,
                             int64_t mfma_count, int64_t total) {
+  if (NT <= -100) {  // split layouts: a thread gathers a weight pair once and writes its three pieces
+    const int64_t n3 = total / 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
+      uint32_t pc[3];
+      split_pack_pair(w, i, Cin_total, ci_off, Cin, Cout, mode, ncc, NT, parity, (int)mfma_count, pc);
+      packed[i] = __uint_as_float(pc[0]);
+      packed[i + n3] = __uint_as_float(pc[1]);
+      packed[i + 2 * n3] = __uint_as_float(pc[2]);
+    }
+    return;
+  }
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x)
     packed[idx] = pack_value(w, idx, Cin_total, ci_off, Cin, Cout, mode, CK, ncc, NT, parity, NV, mfma_count);
@@ -248,6 +255,17 @@ __global__ void pack_all_kernel(const float* __restrict__ params, float* __restr
   const int cin_total = (int)jb[3], ci_off = (int)jb[4], cin = (int)jb[5], cout = (int)jb[6], mode = (int)jb[7],
             ck = (int)jb[8], ncc = (int)jb[9], nt = (int)jb[10], parity = (int)jb[11], nv = (int)jb[12];
   const int64_t mfma_count = jb[13];
+  if (nt <= -100) {  // split layouts: a thread gathers a weight pair once and writes its three pieces
+    const int64_t n3 = count / 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
+      uint32_t pc[3];
+      split_pack_pair(w, i, cin_total, ci_off, cin, cout, mode, ncc, nt, parity, (int)mfma_count, pc);
+      dst[i] = __uint_as_float(pc[0]);
+      dst[i + n3] = __uint_as_float(pc[1]);
+      dst[i + 2 * n3] = __uint_as_float(pc[2]);
+    }
+    return;
+  }
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < count;
        idx += (int64_t)gridDim.x * blockDim.x)
     dst[idx] = pack_value(w, idx, cin_total, ci_off, cin, cout, mode, ck, ncc, nt, parity, nv, mfma_count);

@@ -182,7 +182,10 @@ def test_conv_arithmetic_switch_and_layer_plans():
     assert not ops.conv_runs_split('conv3d_fwd', big, 2, 24)              # first layer: 2 input channels
     assert not ops.conv_runs_split('conv3d_fwd', (20, 20, 20), 192, 192)  # too few tiles: fp32 MFMA kernels
     assert not ops.conv_runs_split('conv3d_wgrad', (20, 20, 20), 192, 192)
-    assert not ops.conv_runs_split('conv3d_up_fwd', big, 48, 24)          # folded decoder convs stay on fp32 MFMA
+    assert ops.conv_runs_split('conv3d_up_fwd', (80, 80, 80), 48, 24)     # folded decoder conv, up-sampled channels (low-res grid)
+    assert ops.conv_runs_split('conv3d_up_dgrad', (80, 80, 80), 48, 24)
+    assert not ops.conv_runs_split('conv3d_up_fwd', (20, 20, 20), 192, 96)
+    assert not ops.conv_runs_split('conv3d_up_wgrad', (80, 80, 80), 48, 24)   # fp32 MFMA in both modes
     prev = ops.set_conv_arithmetic('fp32_mfma')
     try:
         assert prev == 'split' and ops.conv_arithmetic() == 'fp32_mfma'
