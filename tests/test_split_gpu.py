@@ -137,6 +137,40 @@ def test_split_pieces_reconstruct_fp32_exactly():
     assert torch.equal(y, x)
 
 
+def test_split_one_hot_kernels_shift_exactly():
+    """asymmetric one-hot kernels at a split-eligible size: forward, data gradient and weight gradient must be exact shifts /
+    correlations of the input (catches a swapped tap, channel or lane-voxel mapping that random data could average out; the
+    weight 1.0 and the three pieces of every activation multiply exactly, so the forward results are bit-exact)"""
+    from synthsr_amd import ops
+    D, C = 48, 24
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x = torch.randn(D, D, D, C, generator=g)
+    assert ops.conv_arithmetic() == 'split' and _is_split((D, D, D), C, C)
+    for tap, ci, co in [((0, 1, 2), 3, 17), ((2, 0, 1), 23, 0), ((1, 1, 1), 5, 5), ((2, 2, 0), 8, 16)]:
+        w = torch.zeros(3, 3, 3, C, C)
+        w[tap[0], tap[1], tap[2], ci, co] = 1.0
+        wd = w.cuda()
+        y = ops.conv3d(x.cuda(), ops.pack_conv_weights(wd, (D, D, D), 0), None, C, 0).cpu()
+        # y[v, co] = x[v + tap - 1, ci] (zero outside the volume)
+        xp = torch.nn.functional.pad(x[..., ci], (1, 1, 1, 1, 1, 1))
+        want = xp[tap[0]:tap[0] + D, tap[1]:tap[1] + D, tap[2]:tap[2] + D]
+        assert torch.equal(y[..., co], want), (tap, ci, co)
+        others = [c for c in range(C) if c != co]
+        assert float(y[..., others].abs().max()) == 0.0   # nothing leaks into another output channel
+        # data gradient: dx[u, ci] = dy[u - (tap - 1), co]
+        dy = torch.randn(D, D, D, C, generator=g)
+        dx = ops.conv3d(dy.cuda(), ops.pack_conv_weights(wd, (D, D, D), 1), None, C, 0).cpu()
+        dyp = torch.nn.functional.pad(dy[..., co], (1, 1, 1, 1, 1, 1))
+        wantd = dyp[2 - tap[0]:2 - tap[0] + D, 2 - tap[1]:2 - tap[1] + D, 2 - tap[2]:2 - tap[2] + D]
+        assert torch.equal(dx[..., ci], wantd), (tap, ci, co)
+        # weight gradient at that tap / channel pair = <shifted x, dy> (a 110 592-term fp32 sum: 2e-5 of its scale)
+        dw = torch.zeros(3, 3, 3, C, C, device='cuda')
+        ops.conv3d_wgrad(x.cuda(), dy.cuda(), dw)
+        ref = float((want.double() * dy[..., co].double()).sum())
+        scale = float(want.double().pow(2).sum().sqrt() * dy[..., co].double().pow(2).sum().sqrt())
+        assert abs(float(dw[tap[0], tap[1], tap[2], ci, co]) - ref) < 2e-5 * scale, (tap, ci, co)
+
+
 @pytest.mark.parametrize('act', [0, 1])
 def test_split_forward_epilogues_and_fused_statistics(act):
     """bias + ELU, the addend / ELU'-gating epilogues and the BatchNorm statistics of the output, against torch on the device"""
