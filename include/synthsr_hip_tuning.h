@@ -30,8 +30,10 @@ int synthsr_conv3d_set_option(int option, int value);
  *      each partial product exact in the fp32 accumulator; what is left out is < 2^-26 |a b|, a quarter of the rounding error
  *      of an fp32 multiply.  Inputs, outputs, accumulation, BatchNorm statistics, gradients and weights stay fp32; against a
  *      float64 convolution the result is as accurate as the fp32-MFMA kernels' (tests/test_split_gpu.py).  Used for the
- *      layers with >= 256 tiles of 4x4x16 voxels and channel counts that are multiples of 8 (csrc/conv_split.hip); the rest
- *      (first layer, deep levels, folded decoder convs) runs on the fp32 matrix instructions in either mode.
+ *      layers with >= 256 tiles of 4x4x16 voxels and channel counts that are multiples of 8 (csrc/conv_split.hip: forward,
+ *      data gradient and weight gradient of plain convs, forward and data gradient of the folded decoder / stride-2 parity
+ *      convs); the rest (first layer, deep levels, the folded convs' weight gradient) runs on the fp32 matrix instructions
+ *      in either mode.
  *   0 "fp32_mfma": v_mfma_f32_4x4x1 / 16x16x4 kernels everywhere (csrc/conv3d.hip), the round-1/2 path.
  * The reference computes in fp32 on TensorFlow (SynthSR/training.py:330-341); both modes are fp32 computations of it. */
 int synthsr_set_conv_arithmetic(int mode);
