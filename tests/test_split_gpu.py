@@ -69,6 +69,9 @@ def test_split_conv_is_as_accurate_as_the_fp32_mfma_kernels(D, ci, co, kind):
     refs = (_ref64(x, w, b), _ref64(dy, torch.flip(w, (0, 1, 2)).transpose(3, 4)), _wgrad64(x, dy), dy.double().cpu().sum((0, 1, 2)))
     res = {}
     prev = ops.conv_arithmetic()
+    # deterministic mode: the weight / bias gradients are sums of per-workgroup partials; with atomics their last bits (and so
+    # the ratio of two tiny errors) would change from run to run -- ordered sums make this test reproducible
+    prev_det = ops.set_deterministic(True)
     try:
         for mode in ('fp32_mfma', 'split'):
             ops.set_conv_arithmetic(mode)
@@ -79,15 +82,16 @@ def test_split_conv_is_as_accurate_as_the_fp32_mfma_kernels(D, ci, co, kind):
             dw, db = torch.zeros_like(w), torch.zeros_like(b)
             ops.conv3d_wgrad(x, dy, dw, db)
             res[mode] = [_err(t, r) for t, r in zip((y, dx, dw, db), refs)]
+        assert ops.deterministic_status() == 1
     finally:
+        ops.set_deterministic(prev_det)
         ops.set_conv_arithmetic(prev)
     for k, name in enumerate(('forward', 'data gradient', 'weight gradient', 'bias gradient')):
         (nmax, nrms), (smax, srms) = res['fp32_mfma'][k], res['split'][k]
         # (1) not less accurate than the fp32 matrix instructions: rms error within 1.5x (+ 1e-8 for the cases where both are
-        #     ~0), worst element within 2.5x -- both arithmetics add their per-workgroup partial sums with atomics, whose order
-        #     (hence the last bits of a weight / bias gradient over 10^5 voxels) differs from run to run: measured ratios lie
-        #     between 0.8 and 1.3;  (2) an fp32 result in absolute terms: rms error below 4e-6 of the result's rms (bf16 inputs
-        #     alone would be at 4e-3)
+        #     ~0), worst element within 2.5x (the two arithmetics group the partial sums of a weight / bias gradient over 10^5
+        #     voxels differently: measured ratios lie between 0.8 and 1.3);  (2) an fp32 result in absolute terms: rms error
+        #     below 4e-6 of the result's rms (bf16 inputs alone would be at 4e-3)
         assert srms <= 1.5 * nrms + 1e-8, (name, kind, res)
         assert smax <= 2.5 * nmax + 1e-7, (name, kind, res)
         assert srms < 4e-6 or kind in ('cancel', 'offset'), (name, kind, res)
