@@ -60,7 +60,9 @@ class AdversarialTrainer:
             return None
         if list(seg.shape) != list(like.shape[:3]):
             raise NotImplementedError('labels_to_mask with a target resolution different from the label maps')
-        return ops.lut_gather(seg.contiguous(), self.mask_lut).view(*like.shape[:3], 1)
+        m = ops.lut_gather(seg.contiguous(), self.mask_lut).view(*like.shape[:3], 1)
+        # several output channels: the same mask on every channel (Keras broadcasts the Multiply, :365)
+        return m if like.shape[3] == 1 else m.expand(*like.shape).contiguous()
 
     def _generate(self):
         inputs = next(self.bg.model_inputs_generator)
@@ -158,8 +160,8 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
             raise Exception('indices in work_with_residual_channel cannot be greater than the total number of channels')
     if batchsize != 1:
         raise NotImplementedError('batchsize 1 only')
-    if n_output_channels != 1:
-        raise NotImplementedError('the adversarial path is built for one output channel')
+    if n_output_channels != 1 and segmentation_model_file is not None:
+        raise NotImplementedError('the segmentation loss needs a single-channel prediction')
     # data parallel like training(): one process per GPU (torchrun), batch 1 per rank, per-rank random streams
     dist_on = 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1
     rank, world = 0, 1

@@ -42,22 +42,23 @@ def test_critic_pieces():
     close(ops.axpby(v.cuda(), (2 * v).cuda(), 0.25, 0.5), 1.25 * v, 1e-6, 'axpby')
 
 
-@pytest.mark.parametrize('shape,n_filters,n_levels,masked', [((16, 16, 16), 8, 2, False), ((8, 16, 24), 32, 3, False),
-                                                          ((16, 16, 16), 8, 2, True)])
-def test_critic_loss_and_gradients_vs_autograd(shape, n_filters, n_levels, masked):
+@pytest.mark.parametrize('shape,n_filters,n_levels,masked,K', [((16, 16, 16), 8, 2, False, 1), ((8, 16, 24), 32, 3, False, 1),
+                                                            ((16, 16, 16), 8, 2, True, 1), ((16, 16, 16), 8, 2, True, 2),
+                                                            ((8, 16, 24), 8, 2, False, 3)])
+def test_critic_loss_and_gradients_vs_autograd(shape, n_filters, n_levels, masked, K):
     """-D(real) + D(fake) + 10 (1 - ||grad D(x_hat)||)^2 and its gradient w.r.t. every critic parameter (the penalty term
     through the masked forward pass) against autograd with create_graph; the input gradient used by the generator step"""
     import torch
     from synthsr_amd.critic import Critic3D
     from oracle import unet_ref as U
-    net = Critic3D(list(shape) + [1], n_filters=n_filters, n_levels=n_levels, seed=1)
+    net = Critic3D(list(shape) + [K], n_filters=n_filters, n_levels=n_levels, seed=1)   # K = output channels of the generator
     g = torch.Generator().manual_seed(7)
     for nm, _ in net.specs:                      # non-zero biases, larger weights (so that the penalty is active)
         v = net.view(nm)
         v.copy_((torch.randn(v.shape, generator=g) * (0.1 if nm.endswith('bias') else 1.0)).to(v.device) *
                 (1.0 if nm.endswith('bias') else 3.0 * v.abs().max().item()))
     net.repack()
-    real, fake = torch.rand(*shape, 1, generator=g), torch.rand(*shape, 1, generator=g)
+    real, fake = torch.rand(*shape, K, generator=g), torch.rand(*shape, K, generator=g)
     u = 0.3
     mask = None
     if masked:     # labels_to_mask: ConvertLabels(generation_labels, labels_to_mask)(segmentation) through the device LUT
@@ -67,6 +68,7 @@ def test_critic_loss_and_gradients_vs_autograd(shape, n_filters, n_levels, maske
         mask = lut[seg.long()][..., None]
         dmask = ops.lut_gather(seg.cuda(), lut.cuda())[..., None].contiguous()
         assert torch.equal(dmask.cpu(), mask)
+        dmask = dmask.expand(*shape, K).contiguous()      # the same mask on every channel (AdversarialTrainer._mask)
     loss, d_real, d_fake, norm = net.critic_loss_and_grads(real.cuda(), fake.cuda(), u, gp_weight=10.0,
                                                             mask=dmask if masked else None)
     P = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
@@ -143,6 +145,14 @@ def test_adversarial_fine_tuning_end_to_end(tmp_path):
                              steps_per_epoch=1, first_training_ratio=2, training_ratio=1, labels_to_mask=to_mask,
                              verbose=False)
     assert critic3.mask_input and critic3.iterations == 2 and gen3.iterations == 1
+    # two output channels (two synthetic input channels regressed onto themselves, no real images), masked critic
+    gen4, critic4 = training(str(ldir), None, str(tmp_path / 'm4'), None, None, str(tmp_path / 'gl.npy'), input_channels=[True, True],
+                             output_channel=[0, 1], output_shape=32, n_levels=3, nonlin_shape_factor=.125, bias_shape_factor=.125,
+                             epochs=1, steps_per_epoch=1, first_training_ratio=2, training_ratio=1, labels_to_mask=to_mask,
+                             verbose=False)
+    assert critic4.input_shape == [32, 32, 32, 2] and gen4.nb_labels == 2 and critic4.iterations == 2 and gen4.iterations == 1
+    g4 = np.load(os.path.join(str(tmp_path / 'm4'), 'logs', 'generator_loss.npy'))
+    assert np.isfinite(g4).all()
     with pytest.raises(Exception, match='not both'):
         training(str(ldir), str(idir), mdir, None, None, str(tmp_path / 'gl.npy'), output_channel=0)
     with pytest.raises(Exception, match='output_channel or image_dir'):
