@@ -201,12 +201,14 @@ class Critic3D:
         return g if mask is None else ops.mul(g, mask, out=g)
 
     # ------------------------------------------------------------------ WGAN-GP
-    def critic_loss_and_grads(self, real, fake, u_mix, gp_weight=10.0, mask=None):
+    def critic_loss_and_grads(self, real, fake, u_mix, gp_weight=10.0, mask=None, accumulate=False):
         """loss = -D(real) + D(fake) + gp_weight (1 - ||grad D(x_hat)||)^2 with x_hat = u real + (1 - u) fake
-        (build_discriminator_loss, batch of one); self.grads = its gradient.  mask (optional, `labels_to_mask`): the critic
+        (build_discriminator_loss, ONE sample); self.grads = its gradient (accumulate=True: += , the further samples of a
+        batch -- the caller divides by the batch size).  mask (optional, `labels_to_mask`): the critic
         sees x * mask (make_discriminator(mask_input=True)); the penalty's gradient is the one w.r.t. x_hat itself.
         Returns (loss, D(real), D(fake), ||grad||)"""
-        self.grads.zero_()
+        if not accumulate:
+            self.grads.zero_()
         if mask is not None:
             real = ops.mul(real, mask, out=self.buf('real_m', list(real.shape)))
             fake = ops.mul(fake, mask, out=self.buf('fake_m', list(fake.shape)))

@@ -65,11 +65,27 @@ class AdversarialTrainer:
         return m if like.shape[3] == 1 else m.expand(*like.shape).contiguous()
 
     def _generate(self):
+        """one batch: (image, target, [label map per item]); batchsize > 1: the items are generated one after the other and
+        stacked along the first spatial axis (the layout UNet3D.set_batch works on, as training.Trainer does)"""
+        import torch
         inputs = next(self.bg.model_inputs_generator)
         labels, means, stds = inputs[:3]
-        real = np.asarray(inputs[3])[0, ..., 0] if getattr(self.gen, 'use_real_image', False) else None
-        return self.gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0], np.asarray(stds)[0], None,
-                                 real_image=real)
+        B = int(np.asarray(means).shape[0])
+        self.net.set_batch(B)
+        imgs, tgts, segs = None, None, []
+        for b in range(B):
+            real = np.asarray(inputs[3])[b, ..., 0] if getattr(self.gen, 'use_real_image', False) else None
+            image, target, seg = self.gen.generate(np.asarray(labels)[b, ..., 0], np.asarray(means)[b], np.asarray(stds)[b],
+                                                   None, real_image=real)
+            if B == 1:
+                return image, target, [seg]
+            if imgs is None:   # generate() re-uses its output buffers: copy every item out
+                imgs = torch.empty((B * image.shape[0],) + tuple(image.shape[1:]), dtype=image.dtype, device=image.device)
+                tgts = torch.empty((B * target.shape[0],) + tuple(target.shape[1:]), dtype=target.dtype, device=target.device)
+            imgs.chunk(B, 0)[b].copy_(image)
+            tgts.chunk(B, 0)[b].copy_(target)
+            segs.append(seg.clone())
+        return imgs, tgts, segs
 
     def _forward_generator(self, image, target, want_dpred):
         residual, rs, ro = None, 1, 0
@@ -80,31 +96,39 @@ class AdversarialTrainer:
 
     def critic_step(self):
         """one update of the critic (discriminator_model.train_on_batch, :452-453); returns the critic loss"""
-        image, target, seg = self._generate()
+        image, target, segs = self._generate()
         _, pred = self._forward_generator(image, target, False)          # generator frozen: forward only
-        fake = pred.view(*target.shape)
-        u = float(self.rng.uniform())                                      # RandomWeightedAverage, one weight per sample
-        loss, _, _, _ = self.critic.critic_loss_and_grads(target.contiguous(), fake, u, self.gp,
-                                                           mask=self._mask(seg, target))
+        B = len(segs)
+        fakes, reals = pred.view(*target.shape).chunk(B, 0), target.chunk(B, 0)
+        loss = 0.0
+        for b in range(B):   # the critic sees one sample at a time (Dense on the flattened volume); loss = batch mean
+            u = float(self.rng.uniform())                                  # RandomWeightedAverage, one weight per sample
+            l, _, _, _ = self.critic.critic_loss_and_grads(reals[b].contiguous(), fakes[b].contiguous(), u, self.gp,
+                                                           mask=self._mask(segs[b], reals[b]), accumulate=b > 0)
+            loss += l / B
         scale = self.critic_reducer.reduce_all() if self.critic_reducer is not None else 1.0
-        self.critic.adam_step(self.lr_d, self.lr_decay, grad_scale=scale)
+        self.critic.adam_step(self.lr_d, self.lr_decay, grad_scale=scale / B)
         return loss
 
     def generator_step(self):
         """one update of the U-Net (generator_model.train_on_batch, :457-458); returns the generator loss"""
         from . import ops
         net = self.net
-        image, target, seg = self._generate()
+        image, target, segs = self._generate()
+        B = len(segs)
         l1, pred = self._forward_generator(image, target, True)
         w_dice = self.seg.rel_weight if self.seg is not None else 0.0
         w_l1 = 1.0 - self.w_d - w_dice
         ops.axpby(net.dpred, None, w_l1, 0.0, out=net.dpred)              # d(w_l1 L1)/d pred
-        fake = pred.view(*target.shape)
-        g_adv = self.critic.input_gradient(fake, -self.w_d, mask=self._mask(seg, target))   # d(w_d * -D(G))/d pred
-        d_fake = self.critic.last_output
-        ops.axpby(net.dpred, g_adv.reshape(-1), 1.0, 1.0, out=net.dpred)
-        loss = w_l1 * float(l1.item()) - self.w_d * float(d_fake.item())
+        fakes, reals, dpreds = pred.view(*target.shape).chunk(B, 0), target.chunk(B, 0), net.dpred.chunk(B, 0)
+        d_fake = 0.0
+        for b in range(B):   # d(w_d * mean_b -D(G_b))/d pred, sample by sample
+            g_adv = self.critic.input_gradient(fakes[b].contiguous(), -self.w_d / B, mask=self._mask(segs[b], reals[b]))
+            d_fake += float(self.critic.last_output.item()) / B
+            ops.axpby(dpreds[b], g_adv.reshape(-1), 1.0, 1.0, out=dpreds[b])
+        loss = w_l1 * float(l1.item()) - self.w_d * d_fake
         if self.seg is not None:
+            seg = segs[0]
             if list(seg.shape) != list(image.shape[:3]):
                 raise NotImplementedError('segmentation loss with a target resolution different from the label maps')
             loss += w_dice * float(self.seg(pred, seg, net.dpred, self.loss_cropping).item())
@@ -158,8 +182,8 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
             raise Exception('The number or residual channels and output channels must be the same')
         if any(x >= n_channels for x in work_with_residual_channel):
             raise Exception('indices in work_with_residual_channel cannot be greater than the total number of channels')
-    if batchsize != 1:
-        raise NotImplementedError('batchsize 1 only')
+    if batchsize != 1 and (segmentation_model_file is not None or dropout):
+        raise NotImplementedError('batchsize > 1 together with the segmentation loss or dropout is not supported')
     if n_output_channels != 1 and segmentation_model_file is not None:
         raise NotImplementedError('the segmentation loss needs a single-channel prediction')
     # data parallel like training(): one process per GPU (torchrun), batch 1 per rank, per-rank random streams

@@ -153,10 +153,36 @@ def test_adversarial_fine_tuning_end_to_end(tmp_path):
     assert critic4.input_shape == [32, 32, 32, 2] and gen4.nb_labels == 2 and critic4.iterations == 2 and gen4.iterations == 1
     g4 = np.load(os.path.join(str(tmp_path / 'm4'), 'logs', 'generator_loss.npy'))
     assert np.isfinite(g4).all()
+    # batchsize 2: the generator runs on the stacked batch, the critic sample by sample (loss and gradients = batch means)
+    gen5, critic5 = training(str(ldir), str(idir), str(tmp_path / 'm5'), None, None, str(tmp_path / 'gl.npy'), batchsize=2,
+                             output_shape=32, n_levels=3, nonlin_shape_factor=.125, bias_shape_factor=.125, epochs=1,
+                             steps_per_epoch=1, first_training_ratio=2, training_ratio=1, verbose=False)
+    assert gen5.batch == 2 and critic5.iterations == 2 and gen5.iterations == 1
+    assert np.isfinite(np.load(os.path.join(str(tmp_path / 'm5'), 'logs', 'generator_loss.npy'))).all()
     with pytest.raises(Exception, match='not both'):
         training(str(ldir), str(idir), mdir, None, None, str(tmp_path / 'gl.npy'), output_channel=0)
     with pytest.raises(Exception, match='output_channel or image_dir'):
         training(str(ldir), None, mdir, None, None, str(tmp_path / 'gl.npy'))
+
+
+def test_critic_gradients_accumulate_over_the_samples_of_a_batch():
+    """critic_loss_and_grads(accumulate=True) adds a sample's gradient to the buffer: two samples in a row = the sum of the two
+    single-sample gradients (what AdversarialTrainer.critic_step divides by the batch size)"""
+    import torch
+    from synthsr_amd.critic import Critic3D
+    shape = (16, 16, 16)
+    net = Critic3D(list(shape) + [1], n_filters=8, n_levels=2, seed=3)
+    g = torch.Generator().manual_seed(2)
+    xs = [(torch.rand(*shape, 1, generator=g).cuda(), torch.rand(*shape, 1, generator=g).cuda()) for _ in range(2)]
+    singles, losses = [], []
+    for real, fake in xs:
+        losses.append(net.critic_loss_and_grads(real, fake, 0.4, 10.0)[0])
+        singles.append(net.grads.clone())
+    l0 = net.critic_loss_and_grads(xs[0][0], xs[0][1], 0.4, 10.0)[0]
+    l1 = net.critic_loss_and_grads(xs[1][0], xs[1][1], 0.4, 10.0, accumulate=True)[0]
+    assert abs(l0 - losses[0]) < 1e-5 and abs(l1 - losses[1]) < 1e-5
+    want = singles[0] + singles[1]
+    assert float((net.grads - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
 @pytest.mark.parametrize('lo_shape,cin,cout', [((4, 6, 8), 8, 16), ((8, 8, 8), 1, 32), ((6, 4, 10), 32, 32),
