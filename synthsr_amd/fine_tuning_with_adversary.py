@@ -128,7 +128,7 @@ class AdversarialTrainer:
             ops.axpby(dpreds[b], g_adv.reshape(-1), 1.0, 1.0, out=dpreds[b])
         loss = w_l1 * float(l1.item()) - self.w_d * d_fake
         if self.seg is not None:
-            seg = segs[0]
+            seg = segs[0] if B == 1 else __import__('torch').cat(segs, 0)   # stacked like the volumes
             if list(seg.shape) != list(image.shape[:3]):
                 raise NotImplementedError('segmentation loss with a target resolution different from the label maps')
             loss += w_dice * float(self.seg(pred, seg, net.dpred, self.loss_cropping).item())
@@ -182,8 +182,8 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
             raise Exception('The number or residual channels and output channels must be the same')
         if any(x >= n_channels for x in work_with_residual_channel):
             raise Exception('indices in work_with_residual_channel cannot be greater than the total number of channels')
-    if batchsize != 1 and (segmentation_model_file is not None or dropout):
-        raise NotImplementedError('batchsize > 1 together with the segmentation loss or dropout is not supported')
+    if batchsize != 1 and dropout:
+        raise NotImplementedError('batchsize > 1 together with dropout > 0 (per-sample feature masks) is not supported')
     if n_output_channels != 1 and segmentation_model_file is not None:
         raise NotImplementedError('the segmentation loss needs a single-channel prediction')
     # data parallel like training(): one process per GPU (torchrun), batch 1 per rank, per-rank random streams

@@ -68,35 +68,47 @@ class SegmentationRegulariser:
         (metrics_model.py:166-183: the network still sees the whole volume, posteriors and labels are cropped).
         Returns the Dice loss as a 0-d device tensor."""
         torch = self.torch
+        net = self.net
+        # batchsize > 1: the volumes are stacked along the first spatial axis (UNet3D.set_batch); the frozen network runs on the
+        # stack (batch-statistics BatchNorm then normalises over the whole batch, as Keras does), the Dice is evaluated volume
+        # by volume and averaged (DiceLoss: mean over batch and labels)
+        d0 = int(net.input_shape[0])                 # (the FreeSurfer frame swaps axes 1 and 2 only)
+        nb = int(seg_target.shape[0]) // d0
+        if nb * d0 != int(seg_target.shape[0]):
+            raise ValueError('segmentation network built for %s, label maps are %s' % (net.input_shape[:3], list(seg_target.shape)))
+        net.set_batch(nb)
         shape = tuple(seg_target.shape)
+        one = (d0,) + shape[1:]                      # one volume, generator frame
         x = pred.reshape(shape)
         if self.m is not None:  # :155
             inside = (x > self.m) & (x < self.M)
             x = (torch.clamp(x, self.m, self.M) - self.m) / (self.M - self.m)
-        xs = self._to_seg_frame(x)
+        xs = self._to_seg_frame(x)                   # (the swap / flip leave the stacking axis alone)
         seg = self._to_seg_frame(seg_target).reshape(-1)
-        net = self.net
-        if list(xs.shape) != net.input_shape[:3]:
+        if [int(xs.shape[0]) // nb] + list(xs.shape[1:]) != net.input_shape[:3]:
             raise ValueError('segmentation network built for %s, prediction is %s' % (net.input_shape[:3], list(xs.shape)))
         probs = net.predict_probs(xs[..., None].contiguous(), batch_stats=self.batch_stats)
         if loss_cropping is not None:
             # outside the box: no ground-truth class (label -1) and zero posteriors, which removes those voxels from both
             # Dice sums and - the softmax Jacobian p_i (delta_ij - p_j) vanishing with p - from the gradient
             size = [int(loss_cropping)] * 3 if np.ndim(loss_cropping) == 0 else [int(v) for v in loss_cropping]
-            if len(size) != 3 or any(c < 1 or c > d for c, d in zip(size, shape)):
-                raise ValueError('loss_cropping %s does not fit the output shape %s' % (size, list(shape)))
-            lo = [int((d - c) / 2) for d, c in zip(shape, size)]
-            mask = torch.zeros(shape, dtype=torch.bool, device=probs.device)
+            if len(size) != 3 or any(c < 1 or c > d for c, d in zip(size, one)):
+                raise ValueError('loss_cropping %s does not fit the output shape %s' % (size, list(one)))
+            lo = [int((d - c) / 2) for d, c in zip(one, size)]
+            mask = torch.zeros(one, dtype=torch.bool, device=probs.device)
             mask[lo[0]:lo[0] + size[0], lo[1]:lo[1] + size[1], lo[2]:lo[2] + size[2]] = True
-            mask = self._to_seg_frame(mask).reshape(-1)
+            mask = self._to_seg_frame(mask.repeat(nb, 1, 1)).reshape(-1)
             seg = torch.where(mask, seg, torch.full_like(seg, -1))
             probs.mul_(mask[:, None])
-        ops.seg_dice_sums(probs, seg, self.cls_idx, self.cls_gt, self.sums)
-        T, B = self.sums[:self.K], self.sums[self.K:]
-        dice = (1.0 - (T + 1e-7) / (B + 1e-7)).mean()
         low, _ = net.saved['last']
         dbn = net.buf('seg_dbn', list(low.shape))
-        ops.seg_dice_bwd(probs, seg, net.view(net.head['w']), self.cls_idx, self.cls_gt, self.sums, self.rel_weight, dbn)
+        dice = None
+        for b, (pb, sb, db) in enumerate(zip(probs.chunk(nb, 0), seg.chunk(nb, 0), dbn.chunk(nb, 0))):
+            ops.seg_dice_sums(pb, sb, self.cls_idx, self.cls_gt, self.sums)
+            T, B = self.sums[:self.K], self.sums[self.K:]
+            d = (1.0 - (T + 1e-7) / (B + 1e-7)).mean() / nb
+            dice = d if dice is None else dice + d
+            ops.seg_dice_bwd(pb, sb, net.view(net.head['w']), self.cls_idx, self.cls_gt, self.sums, self.rel_weight / nb, db)
         dx = net.backward_input(dbn)[..., 0]
         dx = self._from_seg_frame(dx)
         if self.m is not None:

@@ -101,16 +101,14 @@ class Trainer:
         stacked along the first spatial axis, the layout UNet3D.set_batch works on"""
         import torch
         gen = self.gen
-        if self.seg is not None:
-            raise NotImplementedError('the segmentation loss is built for batchsize 1')
         if draws is not None and len(draws) != B:
             raise ValueError('one set of draws per batch item')
         labels, means, stds = model_inputs[:3]
         imgs, tgts = [], []
         for b in range(B):
             real = np.asarray(model_inputs[3])[b, ..., 0] if getattr(gen, 'use_real_image', False) else None
-            image, target, _ = gen.generate(np.asarray(labels)[b, ..., 0], np.asarray(means)[b], np.asarray(stds)[b],
-                                            None if draws is None else draws[b], real_image=real)
+            image, target, seg = gen.generate(np.asarray(labels)[b, ..., 0], np.asarray(means)[b], np.asarray(stds)[b],
+                                              None if draws is None else draws[b], real_image=real)
             if b == 0:
                 key = (B,) + tuple(image.shape) + tuple(target.shape)
                 if getattr(self, '_batch_key', None) != key:
@@ -121,7 +119,11 @@ class Trainer:
                                               device=target.device)
             self._img_b.chunk(B, 0)[b].copy_(image)   # generate() re-uses its output buffers
             self._tgt_b.chunk(B, 0)[b].copy_(target)
-        return self._img_b, self._tgt_b, None
+            if self.seg is not None:   # the label maps of the batch, stacked like the volumes (segmentation loss)
+                if b == 0:
+                    self._seg_b = torch.empty((B * seg.shape[0],) + tuple(seg.shape[1:]), dtype=seg.dtype, device=seg.device)
+                self._seg_b.chunk(B, 0)[b].copy_(seg)
+        return self._img_b, self._tgt_b, (self._seg_b if self.seg is not None else None)
 
     def make_labels_resident(self, label_maps):
         """upload a pool of int32 label maps once; steps then pick from the pool on the device"""
@@ -344,11 +346,8 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
         raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(regression_metric))
     # combinations this build does not cover are refused HERE, before the dataset, generator and network are built (the
     # reference has no such restriction, SynthSR/training.py:52)
-    if int(batchsize) > 1:
-        for bad, what in ((segmentation_model_file is not None, 'the segmentation-regularised loss'),
-                          (dropout > 0, 'dropout > 0 (per-sample feature masks)')):
-            if bad:
-                raise NotImplementedError('batchsize > 1 together with %s is not supported' % what)
+    if int(batchsize) > 1 and dropout > 0:
+        raise NotImplementedError('batchsize > 1 together with dropout > 0 (per-sample feature masks) is not supported')
 
     dist_on = 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1
     rank, world = 0, 1

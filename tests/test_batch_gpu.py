@@ -181,3 +181,61 @@ def test_batched_per_volume_losses_vs_oracle(kind, crop):
             assert e < (4e-3 if kind_ in ('kernel', 'head_w') else 8e-3), (nm, e)
     finally:
         ops.set_deterministic(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fs_header,crop', [(False, None), (True, (12, 16, 20))])
+def test_batched_segmentation_loss_vs_per_volume_oracle(fs_header, crop):
+    """segmentation-regularised loss on a stack of two volumes (batchsize 2): the frozen network runs on the stack, the Dice
+    is the mean of the per-volume Dice losses.  frozen_bn='inference' (moving averages: the volumes do not interact): Dice
+    and d(Dice)/d(prediction) against the oracle evaluated volume by volume under autograd.  frozen_bn='batch': two copies
+    of the same volume give the batch the statistics of the single volume -> the single-volume result."""
+    import torch
+    from synthsr_amd.unet import unet
+    from synthsr_amd.seg_loss import SegmentationRegulariser
+    from oracle import unet_ref as U
+    shape, levels, B = (16, 24, 32), 3, 2
+    gen_labels = np.array([0, 14, 2, 3, 41, 42, 17])
+    seg_labels = np.array([0, 2, 3, 4, 41, 42, 43, 17, 53])
+    equivalency = np.array([0, 2, 3, 3, 41, 42, 42, 17, 17])
+    segshape = (shape[0], shape[2], shape[1]) if fs_header else shape
+    g = torch.Generator().manual_seed(1)
+    segnet = unet(24, list(segshape) + [1], levels, 3, len(seg_labels), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
+                  activation='elu', final_pred_activation='softmax', seed=4)
+    segnet.bn_moving.copy_((torch.rand(segnet.bn_moving.shape, generator=g) * 0.5 + 0.25).to(segnet.device))
+    preds = [torch.rand(*shape, generator=g) for _ in range(B)]
+    segs = [torch.randint(0, len(gen_labels), shape, generator=g, dtype=torch.int32) for _ in range(B)]
+    Pseg = {k: v.clone().float() for k, v in segnet.state_dict().items()}
+    w = 0.5
+
+    # --- inference-mode BatchNorm: per-volume oracle
+    reg = SegmentationRegulariser(segnet, gen_labels, equivalency, w, fs_header=fs_header, frozen_bn='inference')
+    pred_b, seg_b = torch.cat(preds, 0).cuda(), torch.cat(segs, 0).cuda()
+    dpred = torch.zeros(pred_b.numel(), device='cuda')
+    dice = float(reg(pred_b.reshape(-1), seg_b, dpred, crop).item())
+    want, grads = 0.0, []
+    for p, s in zip(preds, segs):
+        pr = p.clone().requires_grad_(True)
+        d = U.seg_regularisation(pr, s, Pseg, segnet.prefix, levels, 2, gen_labels, equivalency, fs_header=fs_header,
+                                 loss_cropping=crop)
+        (w * d / B).backward()
+        want += float(d) / B
+        grads.append(pr.grad)
+    assert abs(dice - want) < 2e-5, (dice, want)
+    gref = torch.cat(grads, 0).reshape(-1)
+    got = dpred.cpu()
+    assert float((got - gref).abs().max()) < 3e-3 * float(gref.abs().max())
+    assert float((got * gref).sum() / (got.norm() * gref.norm())) > 0.9999
+
+    # --- batch-statistics BatchNorm: two copies of one volume = that volume alone
+    reg = SegmentationRegulariser(segnet, gen_labels, equivalency, w, fs_header=fs_header, frozen_bn='batch')
+    one_d = torch.zeros(preds[0].numel(), device='cuda')
+    dice1 = float(reg(preds[0].cuda().reshape(-1), segs[0].cuda(), one_d, crop).item())
+    two = torch.cat([preds[0], preds[0]], 0).cuda()
+    two_d = torch.zeros(two.numel(), device='cuda')
+    dice2 = float(reg(two.reshape(-1), torch.cat([segs[0], segs[0]], 0).cuda(), two_d, crop).item())
+    assert abs(dice1 - dice2) < 1e-5, (dice1, dice2)
+    a, b = two_d.chunk(2), one_d
+    # each copy carries half of the single-volume gradient of its own Dice term ... plus the coupling through the shared
+    # statistics, which for identical copies adds up to the single-volume gradient split in two
+    assert float(((a[0] + a[1]) - b).abs().max()) < 3e-3 * float(b.abs().max())

@@ -375,9 +375,9 @@ def test_multi_modality_affine_bounds_pick_one_block_at_build_time():
         hm.pick_bounds_block(np.zeros((3, 3)))
 
 
-@pytest.mark.parametrize('extra', [dict(dropout=.2), dict(segmentation_model_file='seg.h5')])
+@pytest.mark.parametrize('extra', [dict(dropout=.2)])
 def test_training_refuses_unsupported_batch_combinations_up_front(extra):
-    """batchsize > 1 together with dropout / the segmentation loss is refused at the top of
+    """batchsize > 1 together with dropout (per-sample feature masks) is refused at the top of
     training(), before any dataset, generator or network is built (no GPU, no file access needed to get the error)"""
     from synthsr_amd.training import training
     with pytest.raises(NotImplementedError, match='batchsize > 1'):

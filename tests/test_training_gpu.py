@@ -204,6 +204,13 @@ def test_training_with_segmentation_regularised_loss(tmp_path):
     plain = float(open(os.path.join(str(tmp_path / 'm_plain'), 'logs', 'loss.csv')).read().strip().split(',')[1])
     # same seeds, same first step: the regularised loss is the L1 loss plus 0.25 * Dice with 0 < Dice < 1
     assert np.isfinite(total) and plain < total < plain + 0.25
+    # batchsize 2: the frozen network runs on the stacked batch, the Dice is the mean over the two volumes
+    net2 = training(labels_dir, str(tmp_path / 'm_seg2'), None, None, str(tmp_path / 'gl.npy'), batchsize=2,
+                    segmentation_label_list=str(tmp_path / 'seg_labels.npy'),
+                    segmentation_label_equivalency=str(tmp_path / 'seg_eq.npy'),
+                    segmentation_model_file=str(tmp_path / 'seg.npz'), relative_weight_segmentation=0.25, **common)
+    total2 = float(open(os.path.join(str(tmp_path / 'm_seg2'), 'logs', 'loss.csv')).read().strip().split(',')[1])
+    assert net2.iterations == 2 and net2.batch == 2 and np.isfinite(total2) and 0 < total2 < 2
 
 
 @pytest.mark.parametrize('metric,cropping', [('l2', 16), ('laplace', None), ('laplace', [24, 16, 16]), ('ssim', None),
