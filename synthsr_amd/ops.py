@@ -5,6 +5,8 @@ caller).  No autograd, no CPU fallback: each function is one (or a few) kernel l
 current stream.
 """
 import ctypes
+import os
+
 import numpy as np
 import torch
 
@@ -96,6 +98,48 @@ def profile_pause():
         _prof_paused, _prof = _prof, None
 
 
+# ---- roctx ranges (tracing): named CPU-side ranges around the phases of a step and around every conv /
+# generator launch, visible in `rocprofv3 --marker-trace`.  Off unless SYNTHSR_ROCTX=1 (one ctypes call per range otherwise).
+_roctx = None
+
+
+def _roctx_lib():
+    global _roctx
+    if _roctx is None:
+        _roctx = False
+        if os.environ.get('SYNTHSR_ROCTX') == '1':
+            import ctypes
+            for name in ('libroctx64.so', 'librocprofiler-sdk-roctx.so'):
+                try:
+                    lib = ctypes.CDLL(name)
+                    lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    lib.roctxRangePushA.restype = ctypes.c_int
+                    lib.roctxRangePop.restype = ctypes.c_int
+                    _roctx = lib
+                    break
+                except (OSError, AttributeError):
+                    continue
+    return _roctx
+
+
+class trace_range:
+    """`with ops.trace_range('backward'):` -- a roctx range when SYNTHSR_ROCTX=1 and the marker library is present, else nothing"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        lib = _roctx_lib()
+        self.on = bool(lib)
+        if self.on:
+            lib.roctxRangePushA(str(self.name).encode())
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            _roctx.roctxRangePop()
+
+
 def timed(kind, shape=(0, 0, 0), cin=0, cout=0):
     """context manager: HIP events around a region on the launch stream, recorded while profile_start() is active
     (bench.py: conv launches and the generator's kernels); free otherwise"""
@@ -107,6 +151,10 @@ class _Timed:
         self.meta = (kind, tuple(int(s) for s in shape), int(cin), int(cout))
 
     def __enter__(self):
+        self.rng = None
+        if _roctx_lib():
+            k, sh, ci, co = self.meta
+            self.rng = trace_range('%s %dx%dx%d %d->%d' % (k, sh[0], sh[1], sh[2], ci, co)).__enter__()
         if _prof is not None:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
@@ -117,6 +165,8 @@ class _Timed:
         if _prof is not None:
             self.e.record()
             _prof.append(self.meta + (self.s, self.e))
+        if self.rng is not None:
+            self.rng.__exit__()
 
 
 def _L():

@@ -157,9 +157,10 @@ class Trainer:
         if self.residual is not None:
             residual, rs, ro = image, image.shape[-1], [int(c) for c in self.residual]
         # fuse_head_bwd: nothing touches net.dpred between the loss and the backward pass unless the segmentation loss adds to it
-        loss, pred = net.loss(image, target.reshape(-1), self.metric, self.loss_cropping, residual=residual,
-                              res_stride=rs, res_off=ro, want_pred=self.seg is not None,
-                              fuse_head_bwd=self.fuse_head_bwd and self.seg is None)
+        with ops.trace_range('forward + loss'):   # (roctx ranges: SYNTHSR_ROCTX=1, rocprofv3 --marker-trace)
+            loss, pred = net.loss(image, target.reshape(-1), self.metric, self.loss_cropping, residual=residual,
+                                  res_stride=rs, res_off=ro, want_pred=self.seg is not None,
+                                  fuse_head_bwd=self.fuse_head_bwd and self.seg is None)
         if self.seg is not None:  # total = image loss + w * Dice(frozen segmentation net(prediction), labels)
             if list(seg.shape) != list(image.shape[:3]):
                 raise NotImplementedError('segmentation loss with a target resolution different from the label maps')
@@ -177,10 +178,12 @@ class Trainer:
             else:
                 scale = self.reducer.finish()
         else:
-            net.backward()
+            with ops.trace_range('backward'):
+                net.backward()
             scale = 1.0
-        net.adam_step(self.lr, self.lr_decay, grad_scale=scale)
-        net.update_moving_stats()
+        with ops.trace_range('optimizer'):
+            net.adam_step(self.lr, self.lr_decay, grad_scale=scale)
+            net.update_moving_stats()
         return loss
 
 

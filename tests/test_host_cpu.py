@@ -382,3 +382,20 @@ def test_training_refuses_unsupported_batch_combinations_up_front(extra):
     from synthsr_amd.training import training
     with pytest.raises(NotImplementedError, match='batchsize > 1'):
         training('/nonexistent/labels', '/nonexistent/models', None, None, '/nonexistent/gl.npy', batchsize=2, **extra)
+
+
+def test_trace_ranges_are_noops_unless_enabled(monkeypatch):
+    """ops.trace_range: nothing without SYNTHSR_ROCTX=1; with it, roctx ranges through the marker library if the image has one
+    (no GPU needed: the calls only record markers for an attached profiler)"""
+    from synthsr_amd import ops
+    monkeypatch.setattr(ops, '_roctx', None)
+    monkeypatch.delenv('SYNTHSR_ROCTX', raising=False)
+    with ops.trace_range('x') as r:
+        assert not r.on
+    monkeypatch.setattr(ops, '_roctx', None)
+    monkeypatch.setenv('SYNTHSR_ROCTX', '1')
+    with ops.trace_range('step') as r:
+        with ops.trace_range('nested'):
+            pass
+    assert r.on == bool(ops._roctx)
+    monkeypatch.setattr(ops, '_roctx', None)
