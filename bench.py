@@ -196,7 +196,7 @@ def cpu_worker(size, timed):
 CONV_ARITH_NOTE = {
     'split': 'fp32 tensors, weights, accumulation, BatchNorm statistics and optimizer throughout; inside the 3x3x3 convs of the '
              'levels with >= 256 tiles every fp32 operand is split EXACTLY into three bf16 numbers and a product is accumulated as '
-             'six exact partial products on v_mfma_f32_16x16x32_bf16 (omitted terms < 2^-26 |a b|): as accurate against a float64 '
+             'six exact partial products on v_mfma_f32_16x16x32_bf16 (omitted terms <= 2^-24 |a b|, 2^-27 rms: within the rounding of an fp32 multiply-add): as accurate against a float64 '
              'convolution as the fp32 matrix instructions (tests/test_split_gpu.py); other layers on fp32 MFMA',
     'fp32_mfma': 'every convolution on the fp32 matrix instructions (v_mfma_f32_4x4x1 / 16x16x4)'}
 

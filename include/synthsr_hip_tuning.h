@@ -27,8 +27,8 @@ int synthsr_conv3d_set_option(int option, int value);
  * for the arithmetic it was packed under -- synthsr_amd.unet re-packs when the mode changed).
  *   1 (default) "split": every fp32 operand is the exact sum of three bf16 numbers (round to nearest even on what the previous
  *      pieces left); a product a*b is accumulated as a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0 on v_mfma_f32_16x16x32_bf16,
- *      each partial product exact in the fp32 accumulator; what is left out is < 2^-26 |a b|, a quarter of the rounding error
- *      of an fp32 multiply.  Inputs, outputs, accumulation, BatchNorm statistics, gradients and weights stay fp32; against a
+ *      each partial product exact in the fp32 accumulator; what is left out (a1 b2 + a2 b1 + a2 b2) is < 2^-23 |a b| in the
+ *      worst case, 2^-24 at most / 2^-27 rms over random operands: within the rounding of an fp32 multiply-add.  Inputs, outputs, accumulation, BatchNorm statistics, gradients and weights stay fp32; against a
  *      float64 convolution the result is as accurate as the fp32-MFMA kernels' (tests/test_split_gpu.py).  Used for the
  *      layers with >= 256 tiles of 4x4x16 voxels and channel counts that are multiples of 8 (csrc/conv_split.hip: forward,
  *      data gradient and weight gradient of plain convs, forward and data gradient of the folded decoder / stride-2 parity

@@ -6,9 +6,11 @@
 //                                                                                  bits cover the 24 of fp32: a2 is exact)
 // and a product a b is accumulated as the six partial products a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0, each EXACT in the
 // matrix core's fp32 accumulator (8 x 8 significand bits).  The three products left out are bounded by
-// |a1 b2 + a2 b1 + a2 b2| <= (2^-9 2^-18 + 2^-18 2^-9 + 2^-36) |a b| < 2^-26 |a b|: a quarter of the rounding error fp32 commits
-// on the product itself, so the result is as close to the exact convolution as the fp32-MFMA kernels of conv3d.hip are
-// (tests/test_split_gpu.py measures both against float64).  Six bf16 MFMAs per fp32 MFMA's worth of work = 2.6x the fp32
+// |a1 b2 + a2 b1 + a2 b2| <= (2 . 2^-8 2^-16 + 2^-32) |a b| < 2^-23 |a b| (|a1| <= 2^-8 |a|, |a2| <= 2^-16 |a|); over random
+// operands the omission measures 2^-24.2 |a b| at most and 2^-27.4 rms (tests/test_split_arithmetic_cpu.py) -- no more than the
+// rounding an fp32 multiply-add commits on the product (2^-24), far below the rounding of the 648-term accumulation that
+// follows, so the result is as close to the exact convolution as the fp32-MFMA kernels of conv3d.hip are
+// (tests/test_split_gpu.py measures both against float64; all nine products would be exact and cost 1.5x the MFMAs).  Six bf16 MFMAs per fp32 MFMA's worth of work = 2.6x the fp32
 // matrix rate; activations stay fp32 in HBM (the split happens on the way into LDS), weights are split when they are packed.
 //
 //   forward / data gradient:  D[co][voxel] += sum over the 6 (i, j) of  A_i[co][(tap, ci)] * B_j[(tap, ci)][voxel]
