@@ -198,6 +198,8 @@ CONV_ARITH_NOTE = {
              'levels with >= 256 tiles every fp32 operand is split EXACTLY into three bf16 numbers and a product is accumulated as '
              'six exact partial products on v_mfma_f32_16x16x32_bf16 (omitted terms <= 2^-24 |a b|, 2^-27 rms: within the rounding of an fp32 multiply-add): as accurate against a float64 '
              'convolution as the fp32 matrix instructions (tests/test_split_gpu.py); other layers on fp32 MFMA',
+    'split9': 'as split, with all NINE partial products: every fp32 product is reproduced exactly (no term dropped), 1.5x the '
+              'matrix instructions of split',
     'fp32_mfma': 'every convolution on the fp32 matrix instructions (v_mfma_f32_4x4x1 / 16x16x4)'}
 
 
@@ -217,7 +219,7 @@ def main():
                     help='sample rocm-smi clocks / power every 2 s during the timed region (sustained runs: --steps 1000)')
     ap.add_argument('--no-fuse-pool-bwd', action='store_true', help='A/B switch: separate max-pool / BatchNorm+ELU backward kernels')
     ap.add_argument('--no-fuse-head-bwd', action='store_true', help='A/B switch: separate head backward pass')
-    ap.add_argument('--conv-arith', default='split', choices=['split', 'fp32_mfma'],
+    ap.add_argument('--conv-arith', default='split', choices=['split', 'split9', 'fp32_mfma'],
                     help='arithmetic of the fp32 convolutions (ops.set_conv_arithmetic): split = three bf16 pieces per fp32 '
                          'operand, six exact partial products on the bf16 matrix cores, fp32 accumulation; fp32_mfma = fp32 '
                          'matrix instructions everywhere')
@@ -339,7 +341,7 @@ def main():
     # the same steps under the OTHER conv arithmetic, same process / box / clocks (N = 1): what the split arithmetic buys
     other = None
     if world == 1 and not args.no_arith_compare:
-        other_name = 'fp32_mfma' if args.conv_arith == 'split' else 'split'
+        other_name = 'fp32_mfma' if args.conv_arith != 'fp32_mfma' else 'split'
         ops.set_conv_arithmetic(other_name)
         net.repack()   # re-plans and re-packs every weight set for the new arithmetic
         for _ in range(3):
@@ -379,14 +381,15 @@ def main():
         flops_launch = conv_flops(dom['kernel'], dom['shape'], dom['cin'], dom['cout'])
         # the peak the dominant kernel is priced against: layers on the split arithmetic issue 6 bf16 MFMAs per fp32 MFMA's
         # worth of algorithmic work -> dense bf16 peak / 6; layers on the fp32 matrix instructions -> the fp32 MFMA peak
-        dom_split = args.conv_arith == 'split' and ops.conv_runs_split(dom['kernel'], dom['shape'], dom['cin'], dom['cout'])
-        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if dom_split else FP32_MFMA_PEAK_TFLOPS
+        dom_split = args.conv_arith != 'fp32_mfma' and ops.conv_runs_split(dom['kernel'], dom['shape'], dom['cin'], dom['cout'])
+        nprod = 9.0 if args.conv_arith == 'split9' else 6.0
+        peak = BF16_MFMA_PEAK_TFLOPS / nprod if dom_split else FP32_MFMA_PEAK_TFLOPS
         roofline = {'bound': 'mfma', 'kernel': '%s %s Cin=%d Cout=%d' % (dom['kernel'], 'x'.join(map(str, dom['shape'])),
                                                                           dom['cin'], dom['cout']),
                     'achieved': round(dom['tflops'], 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                     'frac': round(dom['tflops'] / peak, 4),
-                    'peak_basis': ('dense bf16 MFMA peak %.0f TFLOP/s / 6 partial products per fp32 product (split arithmetic); '
-                                   'achieved = ALGORITHMIC fp32 flops / time' % BF16_MFMA_PEAK_TFLOPS) if dom_split else
+                    'peak_basis': ('dense bf16 MFMA peak %.0f TFLOP/s / %d partial products per fp32 product (split arithmetic); '
+                                   'achieved = ALGORITHMIC fp32 flops / time' % (BF16_MFMA_PEAK_TFLOPS, nprod)) if dom_split else
                                   'dense fp32 MFMA peak',
                     'frac_of_fp32_mfma_peak': round(dom['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                     'flops_per_launch': flops_launch, 'avg_launch_ms': round(dom['avg_ms'], 4),

@@ -34,6 +34,8 @@ int synthsr_conv3d_set_option(int option, int value);
  *      data gradient and weight gradient of plain convs, forward and data gradient of the folded decoder / stride-2 parity
  *      convs); the rest (first layer, deep levels, the folded convs' weight gradient) runs on the fp32 matrix instructions
  *      in either mode.
+ *   2 "split9": the same kernels and packed weights with ALL nine partial products a_i b_j: an fp32 product is reproduced
+ *      exactly (no term dropped) at 1.5x the matrix instructions of "split".
  *   0 "fp32_mfma": v_mfma_f32_4x4x1 / 16x16x4 kernels everywhere (csrc/conv3d.hip), the round-1/2 path.
  * The reference computes in fp32 on TensorFlow (SynthSR/training.py:330-341); both modes are fp32 computations of it. */
 int synthsr_set_conv_arithmetic(int mode);

@@ -142,7 +142,7 @@ SIGNATURES = {
 }
 
 
-CONV_ARITHMETICS = ('fp32_mfma', 'split')   # include/synthsr_hip_tuning.h: synthsr_set_conv_arithmetic(index)
+CONV_ARITHMETICS = ('fp32_mfma', 'split', 'split9')   # include/synthsr_hip_tuning.h: synthsr_set_conv_arithmetic(index)
 
 
 class SynthSRHipError(RuntimeError):

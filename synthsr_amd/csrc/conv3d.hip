@@ -3916,13 +3916,17 @@ int synthsr_deterministic_status(void) {
   return v[1] ? 2 : 1;  // 1: on and every ordered wait completed; 2: on, but a wait timed out (order not guaranteed)
 }
 
+extern "C" void syn_split_set_products(int n);  // conv_split.hip: 6 or 9 partial products per multiplication
+static int g_arith = 1;
 int synthsr_set_conv_arithmetic(int mode) {
-  if (mode != 0 && mode != 1) return SYNTHSR_EINVAL;
-  g_split = mode;
+  if (mode < 0 || mode > 2) return SYNTHSR_EINVAL;
+  g_arith = mode;
+  g_split = mode ? 1 : 0;  // 1 "split" and 2 "split9" share plans, packed layouts and kernels (template NPROD)
+  syn_split_set_products(mode == 2 ? 9 : 6);
   return SYNTHSR_OK;
 }
 
-int synthsr_conv_arithmetic(void) { return g_split; }
+int synthsr_conv_arithmetic(void) { return g_arith; }
 
 int synthsr_conv3d_set_option(int option, int value) {
   if (option == 0) {

@@ -34,6 +34,11 @@ extern "C" int synthsr_split_timing_buffer(long long* p) {
 #define TM(i)
 #endif
 
+// synthsr_set_conv_arithmetic(2) ("split9"): all nine partial products a_i b_j instead of six -- an fp32 product is then
+// reproduced EXACTLY (tests/test_split_arithmetic_cpu.py) at 1.5x the MFMAs; same packed weights, same kernels (template NPROD)
+static int g_products = 6;
+extern "C" __attribute__((visibility("hidden"))) void syn_split_set_products(int n) { g_products = n == 9 ? 9 : 6; }
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -86,6 +91,27 @@ __device__ __forceinline__ void sfor(F&& f) {
   }
 }
 
+// the partial products (weight / first-operand piece a, activation / second-operand piece b) in issue order, smallest first:
+// six: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0); nine: the three smallest ones (2,2) (2,1) (1,2) in front
+constexpr int split_combo_a(int c, int np) {
+  if (np == 9) {
+    if (c == 0) return 2;
+    if (c == 1) return 2;
+    if (c == 2) return 1;
+    c -= 3;
+  }
+  return c == 0 ? 2 : ((c == 2 || c == 3) ? 1 : 0);
+}
+constexpr int split_combo_b(int c, int np) {
+  if (np == 9) {
+    if (c == 0) return 2;
+    if (c == 1) return 1;
+    if (c == 2) return 2;
+    c -= 3;
+  }
+  return c == 1 ? 2 : ((c == 2 || c == 4) ? 1 : 0);
+}
+
 // ELU(alpha = 1), fp32 accuracy (same function as conv3d.hip: exp2 away from 0, degree-5 Taylor on (-1/8, 0])
 __device__ __forceinline__ float elu_f(float v) {
   const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f;
@@ -110,8 +136,9 @@ struct SplitFwdArgs {
 // output parities are K chunks (chunk = parity * ncc + input-channel chunk): parity p stages the sub-lattice dz[2 v + p] and
 // multiplies by its transposed 8-tap set (2 K steps, taps syn_split_tap8), whose 2x2x2 window starts at halo offset 1 - p per
 // axis.  wp = 8 parity sets [piece][co-chunk][cc][step 2][mt][lane], back to back.
-template <int MT, bool ST, int UPM = 0>
+template <int MT, bool ST, int UPM = 0, int NPROD = 6>
 __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwdArgs a) {
+  static_assert(NPROD == 6 || NPROD == 9, "six partial products, or all nine");
   static_assert(UPM == 0 || UPM == 2, "the folded forward pass has its own kernel");
   static_assert(!(UPM && ST), "statistics belong to plain forward convs");
   constexpr int NSTEP = UPM ? 2 : NSTEP27;
@@ -285,6 +312,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
         constexpr bool last = s + 1 == NSTEP;
         const u32x4* wn = last ? wf_next : wf;
         constexpr int sn = last ? 0 : s + 1;
+        if constexpr (NPROD == 9) {  // all nine products: a weight piece is re-loaded after its three products, activations at the end
+          __builtin_amdgcn_sched_barrier(0);
+          mma(I0{}, I2{});
+          mma(I0{}, I1{});
+          mma(I0{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload(wn, sn, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(I1{}, I2{});
+          mma(I1{}, I1{});
+          mma(I1{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload(wn, sn, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(I2{}, I2{});
+          mma(I2{}, I1{});
+          mma(I2{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload(wn, sn, 2);
+          if constexpr (!last) {
+            xload(sn, 2);
+            xload(sn, 1);
+            xload(sn, 0);
+          }
+          return;
+        }
         __builtin_amdgcn_sched_barrier(0);
         mma(I0{}, I2{});
         __builtin_amdgcn_sched_barrier(0);
@@ -414,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
 // 4x4x16 low-resolution tile, two x-rows per wave; accumulators for NPAR parities x 2 rows x MT co-tiles stay in registers over
 // the input-channel chunks (register budget: NPAR = 4, or 2 for MT = 3; blockIdx.z = parity group).  Per chunk 2 NPAR K steps (parity, step) of
 // 6 x 2 x MT MFMAs, weights one step ahead (two register sets), activations re-loaded per step.  D0..D2 = the low-res grid.
-template <int MT, int NPAR>
+template <int MT, int NPAR, int NPROD = 6>
 __global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int NTHR = 512, RW = 2, NS = 2 * NPAR;  // rows per wave, K steps per chunk
@@ -534,9 +587,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitF
         if constexpr (n + 1 < NS) wload(cc, (n + 1) >> 1, (n + 1) & 1, slot ^ 1);
         else wload(cc_next, 0, 0, slot ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        sfor<0, 6>([&](auto CC) {
+        sfor<0, NPROD>([&](auto CC) {
           constexpr int c = decltype(CC)::value;
-          constexpr int qa = c == 0 ? 2 : ((c == 2 || c == 3) ? 1 : 0), qb = c == 1 ? 2 : ((c == 2 || c == 4) ? 1 : 0);
+          constexpr int qa = split_combo_a(c, NPROD), qb = split_combo_b(c, NPROD);
 #pragma unroll
           for (int y = 0; y < RW; ++y)
 #pragma unroll
@@ -587,14 +640,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitF
   }
 }
 
-template <int MT, int NPAR>
-int launch_split_upfwd(const SplitFwdArgs& a, hipStream_t st) {
+template <int MT, int NPAR, int NPROD>
+int launch_split_upfwd_np(const SplitFwdArgs& a, hipStream_t st) {
   constexpr int NG = 8 / NPAR;
   int gx = std::max(8, ((256 / NG) / 8) * 8);  // one workgroup per CU
   while (gx > 8 && gx > a.ntiles) gx -= 8;
   if (a.ntiles < 8) gx = a.ntiles;
   const size_t smem = 2 * BUF;
-  auto kern = conv3d_split_upfwd_kernel<MT, NPAR>;
+  auto kern = conv3d_split_upfwd_kernel<MT, NPAR, NPROD>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -604,10 +657,15 @@ int launch_split_upfwd(const SplitFwdArgs& a, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
-template <int MT, bool ST, int UPM = 0>
-int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
+template <int MT, int NPAR>
+int launch_split_upfwd(const SplitFwdArgs& a, hipStream_t st) {
+  return g_products == 9 ? launch_split_upfwd_np<MT, NPAR, 9>(a, st) : launch_split_upfwd_np<MT, NPAR, 6>(a, st);
+}
+
+template <int MT, bool ST, int UPM, int NPROD>
+int launch_split_fwd_np(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
   const size_t smem = 2 * BUF;
-  auto kern = conv3d_split_fwd_kernel<MT, ST, UPM>;
+  auto kern = conv3d_split_fwd_kernel<MT, ST, UPM, NPROD>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -615,6 +673,11 @@ int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st)
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(256), smem, st, a);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+template <int MT, bool ST, int UPM = 0>
+int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
+  return g_products == 9 ? launch_split_fwd_np<MT, ST, UPM, 9>(a, gx, nchunks, st) : launch_split_fwd_np<MT, ST, UPM, 6>(a, gx, nchunks, st);
 }
 
 inline int split_grid_x(int ntiles, int nchunks) {
@@ -667,7 +730,7 @@ struct WgCfg {
   static constexpr int NBUF = DBUF ? 2 : 1;
 };
 
-template <int COW>
+template <int COW, int NPROD = 6>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitWgArgs a) {
   using C = WgCfg<COW>;
   constexpr int NT = C::NT, DROWB = C::DROWB, DPLANE = C::DPLANE, RT = C::RT, NW = 8, NTHR = 512;
@@ -828,9 +891,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (q + 1 < RT) aload(q + 1, (q + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-        sfor<0, 6>([&](auto CC) {
+        sfor<0, NPROD>([&](auto CC) {
           constexpr int c = decltype(CC)::value;
-          constexpr int qa = c == 0 ? 2 : ((c == 2 || c == 3) ? 1 : 0), qb = c == 1 ? 2 : ((c == 2 || c == 4) ? 1 : 0);
+          constexpr int qa = split_combo_a(c, NPROD), qb = split_combo_b(c, NPROD);
 #pragma unroll
           for (int n = 0; n < NT; ++n)
             acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][qa]),
@@ -897,15 +960,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   }
 }
 
-template <int COW>
-int launch_split_wgrad(const SplitWgArgs& a0, hipStream_t st) {
+template <int COW, int NPROD>
+int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
   using C = WgCfg<COW>;
   SplitWgArgs a = a0;
   const int gy = a.ncc * a.nco;
   int gx = std::max(1, 256 / gy);  // one workgroup per CU
   if (gx > a.ntiles) gx = a.ntiles;
   const size_t smem = (size_t)C::NBUF * C::BUFB;
-  auto kern = conv3d_split_wgrad_kernel<COW>;
+  auto kern = conv3d_split_wgrad_kernel<COW, NPROD>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -918,6 +981,11 @@ int launch_split_wgrad(const SplitWgArgs& a0, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(512), smem, st, a);
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   return syn_det_finish(&det, st);
+}
+
+template <int COW>
+int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
+  return g_products == 9 ? launch_split_wgrad_np<COW, 9>(a, st) : launch_split_wgrad_np<COW, 6>(a, st);
 }
 
 }  // namespace

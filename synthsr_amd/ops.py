@@ -21,7 +21,8 @@ _prof = None
 def set_conv_arithmetic(name):
     """process-wide (include/synthsr_hip_tuning.h: synthsr_set_conv_arithmetic): 'split' (default) = fp32 convolutions on the
     bf16 matrix cores through three bf16 pieces per operand and six exact partial products (fp32 accumulation, as accurate as
-    the fp32 matrix instructions: tests/test_split_gpu.py); 'fp32_mfma' = fp32 matrix instructions everywhere.  Networks
+    the fp32 matrix instructions: tests/test_split_gpu.py); 'split9' = the same with all nine partial products (every fp32
+    product reproduced exactly, 1.5x the matrix instructions); 'fp32_mfma' = fp32 matrix instructions everywhere.  Networks
     re-pack their weights at the next `repack()` when the mode changed.  Returns the previous setting."""
     if name not in _lib.CONV_ARITHMETICS:
         raise ValueError('conv arithmetic should be one of %s' % (_lib.CONV_ARITHMETICS,))
@@ -40,7 +41,7 @@ def conv_runs_split(kind, shape, cin, cout):
     dispatch_wgrad); used by the benchmarks to price a kernel against the right peak"""
     import ctypes
     kinds = ('conv3d_fwd', 'conv3d_dgrad', 'conv3d_wgrad', 'conv3d_up_fwd', 'conv3d_up_dgrad')
-    if conv_arithmetic() != 'split' or kind not in kinds:   # (conv3d_up_wgrad: fp32 MFMA in both modes)
+    if conv_arithmetic() == 'fp32_mfma' or kind not in kinds:   # (conv3d_up_wgrad: fp32 MFMA in every mode)
         return False
     d0, d1, d2 = [int(v) for v in shape[:3]]
     if kind == 'conv3d_wgrad':

@@ -159,7 +159,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert _lib.load().synthsr_conv_arithmetic() == 1
     assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 3 * 3 * 7 * 2 * 64 * 4
     assert _lib.load().synthsr_conv3d_pack(None, None, _lib.i3([80, 80, 80]), 48, 48, 0, None) == 3 * 6 * 7 * 3 * 64 * 4
-    assert _lib.load().synthsr_set_conv_arithmetic(2) == -1
+    assert _lib.load().synthsr_set_conv_arithmetic(3) == -1
     assert _lib.load().synthsr_set_conv_arithmetic(0) == 0
     # fp32 MFMA: Cout = 24 uses the unpadded 4x4x1-MFMA layout, 48 -> 48 the 16x16x4 B-fragment layout
     assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 27 * 24 * 24

@@ -175,6 +175,33 @@ def test_split_one_hot_kernels_shift_exactly():
         assert abs(float(dw[tap[0], tap[1], tap[2], ci, co]) - ref) < 2e-5 * scale, (tap, ci, co)
 
 
+def test_split9_all_nine_products():
+    """ops.set_conv_arithmetic('split9'): the same kernels with all nine partial products -- every fp32 product exact; against
+    float64 at least as accurate as the fp32 matrix instructions, forward / data gradient / weight gradient, plain and folded"""
+    from synthsr_amd import ops
+    D, ci, co = 48, 24, 48
+    shape = (D, D, D)
+    x, dy, w, b = _data('normal', D, ci, co, seed=77)
+    refs = (_ref64(x, w, b), _ref64(dy, torch.flip(w, (0, 1, 2)).transpose(3, 4)), _wgrad64(x, dy))
+    res = {}
+    prev = ops.conv_arithmetic()
+    prev_det = ops.set_deterministic(True)
+    try:
+        for mode in ('fp32_mfma', 'split9'):
+            ops.set_conv_arithmetic(mode)
+            assert ops.conv_arithmetic() == mode and _is_split(shape, ci, co) == (mode == 'split9')
+            wp, wpd = ops.pack_conv_weights(w, shape, 0), ops.pack_conv_weights(w, shape, 1)
+            dw = torch.zeros_like(w)
+            ops.conv3d_wgrad(x, dy, dw)
+            res[mode] = [_err(t, r) for t, r in zip((ops.conv3d(x, wp, b, co, 0), ops.conv3d(dy, wpd, None, ci, 0), dw), refs)]
+    finally:
+        ops.set_deterministic(prev_det)
+        ops.set_conv_arithmetic(prev)
+    for k in range(3):
+        (nmax, nrms), (smax, srms) = res['fp32_mfma'][k], res['split9'][k]
+        assert srms <= 1.25 * nrms and smax <= 2.0 * nmax and srms < 1.5e-6, res
+
+
 @pytest.mark.parametrize('act', [0, 1])
 def test_split_forward_epilogues_and_fused_statistics(act):
     """bias + ELU, the addend / ELU'-gating epilogues and the BatchNorm statistics of the output, against torch on the device"""
