@@ -223,6 +223,7 @@ def main():
                     help='arithmetic of the fp32 convolutions (ops.set_conv_arithmetic): split = three bf16 pieces per fp32 '
                          'operand, six exact partial products on the bf16 matrix cores, fp32 accumulation; fp32_mfma = fp32 '
                          'matrix instructions everywhere')
+    ap.add_argument('--layer-table', default='', help='write the per-layer conv timings of the profiled steps to this file')
     ap.add_argument('--no-arith-compare', action='store_true',
                     help='skip the short second measurement under the other conv arithmetic (N = 1 only, 20 steps)')
     ap.add_argument('--force-allreduce', action='store_true',
@@ -378,6 +379,17 @@ def main():
         rows.sort(key=lambda r: -r['rank_ms'])
         conv_total = sum(r['total_ms'] for r in rows)
         dom = rows[0]
+        if args.layer_table:
+            with open(args.layer_table, 'w') as f:
+                f.write('# %s: every conv launch of the first %d timed steps (HIP events on the launch stream), per step\n'
+                        % (' '.join(sys.argv), min(3, args.steps)))
+                f.write('%-16s %-14s %4s %4s %9s %8s %8s %7s %s\n' % ('kernel', 'volume', 'cin', 'cout', 'launches', 'avg_ms',
+                                                                      'ms/step', 'TFLOP/s', 'arithmetic'))
+                for r in rows:
+                    sp = args.conv_arith != 'fp32_mfma' and ops.conv_runs_split(r['kernel'], tuple(r['shape']), r['cin'], r['cout'])
+                    f.write('%-16s %-14s %4d %4d %9.1f %8.4f %8.4f %7.1f %s\n' % (
+                        r['kernel'], 'x'.join(map(str, r['shape'])), r['cin'], r['cout'], r['launches'] / min(3, args.steps),
+                        r['avg_ms'], r['total_ms'] / min(3, args.steps), r['tflops'], args.conv_arith if sp else 'fp32_mfma'))
         flops_launch = conv_flops(dom['kernel'], dom['shape'], dom['cin'], dom['cout'])
         # the peak the dominant kernel is priced against: layers on the split arithmetic issue 6 bf16 MFMAs per fp32 MFMA's
         # worth of algorithmic work -> dense bf16 peak / 6; layers on the fp32 matrix instructions -> the fp32 MFMA peak

@@ -57,14 +57,24 @@ struct TileWalk {
   int pos, end, stride;
 };
 __device__ __forceinline__ TileWalk tile_walk(int ntiles) {
-  // workgroup (x, y) has linear id x + G y and runs on XCD id % 8; the workgroups of one XCD and one y are x, x + 8, ...
+  // workgroup (x, y) has linear id x + G y and runs on XCD id % 8; the workgroups of one XCD and one y are those of one
+  // class c = x % 8: x = c, c + 8, ... -- G / 8 of them, one more for c < G % 8.  The tiles are cut into 8 consecutive segments,
+  // one per XCD, each as long as its class has workgroups (so that every workgroup gets ntiles / G tiles +- 1 whatever G:
+  // with equal segments a G of 85 = 3 classes of 10 and 5 of 11 left 6 % of the weight-gradient's time to the small classes,
+  // a G of 10 27 %); inside a segment the workgroups of the class interleave, so neighbouring tiles are in flight together
   const int G = (int)gridDim.x, b = (int)blockIdx.x;
-  const int per = (ntiles + 7) / 8, k = (b + G * (int)(blockIdx.y + gridDim.y * blockIdx.z)) & 7;
   TileWalk w;
   if (G >= 8) {
-    w.pos = k * per + (b >> 3);
-    w.end = min(ntiles, (k + 1) * per);
-    w.stride = (G - (b & 7) + 7) >> 3;
+    const int base = G >> 3, rem = G & 7;
+    const int lin0 = G * (int)(blockIdx.y + gridDim.y * blockIdx.z);
+    const int k = (b + lin0) & 7;
+    int before = 0;  // workgroups (of this y) on the XCDs in front of this one
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) before += kk < k ? base + ((((kk - lin0) & 7) < rem) ? 1 : 0) : 0;
+    const int nc = base + (((b & 7) < rem) ? 1 : 0);
+    w.pos = (int)((int64_t)ntiles * before / G) + (b >> 3);
+    w.end = (int)((int64_t)ntiles * (before + nc) / G);
+    w.stride = nc;
   } else {  // fewer workgroups than XCDs: plain striding
     w.pos = b;
     w.end = ntiles;
@@ -644,7 +654,7 @@ template <int MT, int NPAR, int NPROD>
 int launch_split_upfwd_np(const SplitFwdArgs& a, hipStream_t st) {
   constexpr int NG = 8 / NPAR;
   int gx = std::max(8, ((256 / NG) / 8) * 8);  // one workgroup per CU
-  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  while (gx > 8 && gx - 8 >= a.ntiles) gx -= 8;
   if (a.ntiles < 8) gx = a.ntiles;
   const size_t smem = 2 * BUF;
   auto kern = conv3d_split_upfwd_kernel<MT, NPAR, NPROD>;
@@ -682,7 +692,7 @@ int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st)
 
 inline int split_grid_x(int ntiles, int nchunks) {
   int gx = std::max(8, ((512 / nchunks) / 8) * 8);  // 2 workgroups per CU in total
-  while (gx > 8 && gx > ntiles) gx -= 8;
+  while (gx > 8 && gx - 8 >= ntiles) gx -= 8;       // (never fewer workgroups than tiles: a second tile doubles a straggler's time)
   if (ntiles < 8) gx = ntiles;
   return gx;
 }
