@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_bf16_fwd_kernel(const FwdArgs a
 template <int CK, int MT, bool WLDS>
 int launch_fwd_w(const FwdArgs& a, int nchunks, hipStream_t st) {
   int gx = 512;
-  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  while (gx > 8 && gx - 8 >= a.ntiles) gx -= 8;  // never narrower than the tile count: a second tile doubles a straggler's time
   if (a.ntiles < 8) gx = a.ntiles;
   constexpr int NSTEP = (27 * (CK / 8) + 3) / 4;
   const size_t hbytes = ((size_t)HVOX * rowb_fwd(CK) + 1023) / 1024 * 1024;
@@ -587,7 +587,7 @@ int launch_fwd_w(const FwdArgs& a, int nchunks, hipStream_t st) {
 template <int CK, int MT, int UPM>
 int launch_fwd_up(const FwdArgs& a, int nchunks, hipStream_t st) {
   int gx = UPM == 1 ? 64 : 512;  // UPM 1: 8 parities x 64 x chunks workgroups
-  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  while (gx > 8 && gx - 8 >= a.ntiles) gx -= 8;  // never narrower than the tile count: a second tile doubles a straggler's time
   if (a.ntiles < 8) gx = a.ntiles;
   const size_t smem = ((size_t)HVOX * rowb_fwd(CK) + 1023) / 1024 * 1024;
   auto kern = conv3d_bf16_fwd_kernel<CK, MT, false, UPM>;
@@ -984,7 +984,7 @@ int launch_wgrad(const WgArgs& a0, hipStream_t st) {
   int gx = 512 / (a.ncc * a.nco * (UP ? 8 : 1));
   gx = (gx / 8) * 8;
   if (gx < 8) gx = 8;
-  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  while (gx > 8 && gx - 8 >= a.ntiles) gx -= 8;  // never narrower than the tile count: a second tile doubles a straggler's time
   if (a.ntiles < 8) gx = a.ntiles;
   const size_t smem = (size_t)HVOX * rowb_for(CK) + (size_t)TZ * TY * TX * ((NT & 1) ? NT * 32 : NT * 32 + 32);
   auto kern = conv3d_bf16_wgrad_kernel<CK, NT, UP>;
@@ -1100,7 +1100,7 @@ int synthsr_conv3d_bf16_fwd_ex(const void* in, const void* wp, const float* bias
   a.ksplit = 1;
   a.ncc_real = pl.ncc;
   int gx = 512;
-  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  while (gx > 8 && gx - 8 >= a.ntiles) gx -= 8;  // never narrower than the tile count: a second tile doubles a straggler's time
   if (a.ntiles < 8) gx = a.ntiles;
   const int W = 16 * pl.mt;
   hipStream_t st = (hipStream_t)stream;
@@ -1292,7 +1292,7 @@ int synthsr_conv3d_bf16_up_dgrad(const void* dout, const void* wpacked8, void* d
   hipStream_t st = (hipStream_t)stream;
   // small deep levels: split the 8 x ncc K chunks over gridDim.z, fp32 partial planes + the split-K epilogue
   int gx = 512;
-  while (gx > 8 && gx > a.ntiles) gx -= 8;
+  while (gx > 8 && gx - 8 >= a.ntiles) gx -= 8;  // never narrower than the tile count: a second tile doubles a straggler's time
   if (a.ntiles < 8) gx = a.ntiles;
   const int wgs_plain = gx * pl.nchunks;
   const int ks = std::min(a.ncc, (512 + wgs_plain - 1) / std::max(wgs_plain, 1));
