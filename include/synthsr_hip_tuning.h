@@ -41,6 +41,13 @@ int synthsr_conv3d_set_option(int option, int value);
 int synthsr_set_conv_arithmetic(int mode);
 int synthsr_conv_arithmetic(void);
 
+/* Diagnostic (host only, no device work): the launch width and tile range of one workgroup of the split kernels -- the same
+ * function the kernels evaluate (csrc/conv_split.hip: tile_walk_of).  kernel 0 = forward / data gradient (ny = output-channel
+ * chunks), 1 = weight gradient (ny = input-channel chunks x column groups), 2 = folded forward (ny = parity groups).
+ * out = {grid width, first tile, end, stride}: workgroup (block_x, linear y/z index block_yz) walks first, first + stride, ...
+ * < end.  tests/test_host_cpu.py checks that every tile of every launch geometry is visited exactly once, evenly. */
+int synthsr_split_tile_schedule(int kernel, int ntiles, int ny, int block_x, int block_yz, int out[4]);
+
 /* Deterministic mode (process-wide, per current device, single stream; synchronises the device).  on = 1: every
  * cross-workgroup float accumulation is performed in a fixed order -- small partials (channel sums, BatchNorm statistics,
  * losses, the critic's dense outputs) are parked per workgroup and added up in workgroup-id order by the workgroup that

@@ -54,6 +54,7 @@ SIGNATURES = {
     'synthsr_conv3d_fwd_add': (c_int, [_P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_conv3d_set_option': (c_int, [c_int, c_int]),
     'synthsr_set_conv_arithmetic': (c_int, [c_int]),
+    'synthsr_split_tile_schedule': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
     'synthsr_conv_arithmetic': (c_int, []),
     'synthsr_set_deterministic': (c_int, [c_int]),
     'synthsr_deterministic_status': (c_int, []),

@@ -56,19 +56,19 @@ constexpr int SLAB_Z = 4;
 struct TileWalk {
   int pos, end, stride;
 };
-__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
-  // workgroup (x, y) has linear id x + G y and runs on XCD id % 8; the workgroups of one XCD and one y are those of one
-  // class c = x % 8: x = c, c + 8, ... -- G / 8 of them, one more for c < G % 8.  The tiles are cut into 8 consecutive segments,
-  // one per XCD, each as long as its class has workgroups (so that every workgroup gets ntiles / G tiles +- 1 whatever G:
-  // with equal segments a G of 85 = 3 classes of 10 and 5 of 11 left 6 % of the weight-gradient's time to the small classes,
-  // a G of 10 27 %); inside a segment the workgroups of the class interleave, so neighbouring tiles are in flight together
-  const int G = (int)gridDim.x, b = (int)blockIdx.x;
+// Workgroup (x = b, y, z) of a G-wide launch has linear id b + lin0 (lin0 = G (y + gridDim.y z)) and runs on XCD id % 8; the
+// workgroups of one XCD and one (y, z) are those of one class c = b % 8: b = c, c + 8, ... -- G / 8 of them, one more for
+// c < G % 8.  The tiles are cut into 8 consecutive segments, one per XCD, each as long as its class has workgroups (so that
+// every workgroup gets ntiles / G tiles +- 1 whatever G: with equal segments a G of 85 = 3 classes of 10 and 5 of 11 left 6 % of
+// the weight-gradient's time to the small classes, a G of 10 27 %); inside a segment the workgroups of the class interleave, so
+// neighbouring tiles are in flight together.  Host-callable: synthsr_split_tile_schedule (tests/test_host_cpu.py walks every
+// launch geometry of the network and checks that each tile is visited exactly once).
+__host__ __device__ inline TileWalk tile_walk_of(int G, int b, int lin0, int ntiles) {
   TileWalk w;
   if (G >= 8) {
     const int base = G >> 3, rem = G & 7;
-    const int lin0 = G * (int)(blockIdx.y + gridDim.y * blockIdx.z);
     const int k = (b + lin0) & 7;
-    int before = 0;  // workgroups (of this y) on the XCDs in front of this one
+    int before = 0;  // workgroups (of this y, z) on the XCDs in front of this one
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) before += kk < k ? base + ((((kk - lin0) & 7) < rem) ? 1 : 0) : 0;
     const int nc = base + (((b & 7) < rem) ? 1 : 0);
@@ -81,6 +81,9 @@ __device__ __forceinline__ TileWalk tile_walk(int ntiles) {
     w.stride = G;
   }
   return w;
+}
+__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
+  return tile_walk_of((int)gridDim.x, (int)blockIdx.x, (int)gridDim.x * (int)(blockIdx.y + gridDim.y * blockIdx.z), ntiles);
 }
 __device__ __forceinline__ void tile_decode(int p, int tiles0, int tiles1, int tiles2, int& z0, int& y0, int& x0) {
   const int t12 = tiles1 * tiles2;
@@ -650,12 +653,30 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitF
   }
 }
 
+// grid widths (workgroups along x; y / z = channel chunks / parity groups).  Never narrower than the tile count where that is
+// possible: 296 workgroups for 300 tiles made 8 stragglers walk two tiles = twice the kernel's critical path.
+inline int split_upfwd_grid_x(int ntiles, int ngroups) {
+  int gx = std::max(8, ((256 / ngroups) / 8) * 8);  // one 512-thread workgroup per CU
+  while (gx > 8 && gx - 8 >= ntiles) gx -= 8;
+  if (ntiles < 8) gx = ntiles;
+  return gx;
+}
+inline int split_wgrad_grid_x(int ntiles, int gy) {
+  int gx = std::max(1, 256 / gy);  // one 512-thread workgroup per CU
+  if (gx > ntiles) gx = ntiles;
+  return gx;
+}
+inline int split_grid_x(int ntiles, int nchunks) {
+  int gx = std::max(8, ((512 / nchunks) / 8) * 8);  // 2 workgroups per CU in total
+  while (gx > 8 && gx - 8 >= ntiles) gx -= 8;
+  if (ntiles < 8) gx = ntiles;
+  return gx;
+}
+
 template <int MT, int NPAR, int NPROD>
 int launch_split_upfwd_np(const SplitFwdArgs& a, hipStream_t st) {
   constexpr int NG = 8 / NPAR;
-  int gx = std::max(8, ((256 / NG) / 8) * 8);  // one workgroup per CU
-  while (gx > 8 && gx - 8 >= a.ntiles) gx -= 8;
-  if (a.ntiles < 8) gx = a.ntiles;
+  const int gx = split_upfwd_grid_x(a.ntiles, NG);
   const size_t smem = 2 * BUF;
   auto kern = conv3d_split_upfwd_kernel<MT, NPAR, NPROD>;
   static bool attr_done = false;
@@ -690,12 +711,6 @@ int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st)
   return g_products == 9 ? launch_split_fwd_np<MT, ST, UPM, 9>(a, gx, nchunks, st) : launch_split_fwd_np<MT, ST, UPM, 6>(a, gx, nchunks, st);
 }
 
-inline int split_grid_x(int ntiles, int nchunks) {
-  int gx = std::max(8, ((512 / nchunks) / 8) * 8);  // 2 workgroups per CU in total
-  while (gx > 8 && gx - 8 >= ntiles) gx -= 8;       // (never fewer workgroups than tiles: a second tile doubles a straggler's time)
-  if (ntiles < 8) gx = ntiles;
-  return gx;
-}
 
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -975,8 +990,7 @@ int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
   using C = WgCfg<COW>;
   SplitWgArgs a = a0;
   const int gy = a.ncc * a.nco;
-  int gx = std::max(1, 256 / gy);  // one workgroup per CU
-  if (gx > a.ntiles) gx = a.ntiles;
+  const int gx = split_wgrad_grid_x(a.ntiles, gy);
   const size_t smem = (size_t)C::NBUF * C::BUFB;
   auto kern = conv3d_split_wgrad_kernel<COW, NPROD>;
   static bool attr_done = false;
@@ -999,6 +1013,23 @@ int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+// include/synthsr_hip_tuning.h: host restatement (the same function the kernels call) of the tile schedule, for tests
+extern "C" int synthsr_split_tile_schedule(int kernel, int ntiles, int ny, int block_x, int block_yz, int out[4]) {
+  if (ntiles < 1 || ny < 1 || block_x < 0 || block_yz < 0 || !out) return SYNTHSR_EINVAL;
+  int gx;
+  if (kernel == 0) gx = split_grid_x(ntiles, ny);             // forward / data gradient: ny = output-channel chunks
+  else if (kernel == 1) gx = split_wgrad_grid_x(ntiles, ny);  // weight gradient: ny = input-channel chunks x column groups
+  else if (kernel == 2) gx = split_upfwd_grid_x(ntiles, ny);  // folded forward: ny = parity groups (2 or 4)
+  else return SYNTHSR_EINVAL;
+  out[0] = gx;
+  if (block_x >= gx) return SYNTHSR_EINVAL;
+  const TileWalk w = tile_walk_of(gx, block_x, gx * block_yz, ntiles);
+  out[1] = w.pos;
+  out[2] = w.end;
+  out[3] = w.stride;
+  return SYNTHSR_OK;
+}
 
 // called by conv3d.hip's dispatcher when the plan of the layer says `split` (weights packed in the split layout by pack_value).
 // stats != null: BatchNorm batch statistics (mean | biased variance) of the output, from per-workgroup sums in `partial`

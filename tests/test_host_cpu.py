@@ -168,6 +168,59 @@ def test_c_abi_exports_every_declared_symbol():
     assert _lib.load().synthsr_set_conv_arithmetic(1) == 0   # process-wide: back to the default for the tests that follow
 
 
+def test_split_tile_schedule_visits_every_tile_once_and_evenly():
+    """synthsr_split_tile_schedule = the function the split kernels evaluate on the device (csrc/conv_split.hip: tile_walk_of,
+    host-callable): for every launch geometry of the U-Net levels at 160^3 / 192^3 and a sweep of awkward tile counts and grid
+    widths, the workgroups of one (y, z) column together visit each tile exactly once, no workgroup gets more than one tile
+    above the mean, and a launch is never narrower than its tile count when it could be wider"""
+    from synthsr_amd import _lib
+    lib = _lib.load()
+    out = (ctypes.c_int * 4)()
+
+    def column(kernel, ntiles, ny, yz):
+        assert lib.synthsr_split_tile_schedule(kernel, ntiles, ny, 0, yz, out) == 0
+        gx = out[0]
+        seen, loads = np.zeros(ntiles, dtype=np.int32), []
+        for b in range(gx):
+            assert lib.synthsr_split_tile_schedule(kernel, ntiles, ny, b, yz, out) == 0
+            assert out[0] == gx and out[3] >= 1
+            tiles = list(range(out[1], out[2], out[3]))
+            assert all(0 <= t < ntiles for t in tiles)
+            seen[tiles] += 1
+            loads.append(len(tiles))
+        assert np.all(seen == 1), (kernel, ntiles, ny, yz, gx)
+        assert max(loads) <= -(-ntiles // gx) + (1 if gx >= 8 and gx % 8 else 0), (kernel, ntiles, ny, gx, max(loads))
+        return gx, loads
+
+    def ntiles_of(d):
+        return -(-d // 4) * -(-d // 4) * -(-d // 16)
+
+    for size in (160, 192, 80, 96, 40, 48, 44):
+        nt = ntiles_of(size)
+        for ny in (1, 2, 3, 4, 6, 8, 12, 24):
+            for yz in (0, 1, ny - 1, 5):
+                gx, loads = column(0, nt, ny, yz)
+                assert gx % 8 == 0 or nt < 8
+                assert gx >= min(nt, (512 // ny) // 8 * 8) or gx * ny > 512 - 8 * ny
+                column(1, nt, ny, yz)
+        for groups in (2, 4):
+            for yz in range(groups):
+                column(2, nt, groups, yz)
+    # the weight-gradient widths of the network: 256 // (chunks x column groups) = 85, 42, 21, 10 are not multiples of 8
+    for nt, ny, width in ((16000, 3, 85), (2000, 6, 42), (300, 12, 21), (300, 24, 10)):
+        gx, loads = column(1, nt, ny, 2)
+        assert gx == width and max(loads) - min(loads) <= 1, (gx, loads)
+    # awkward small cases: fewer tiles than XCDs, one tile more than a multiple of 8, primes
+    for nt in (1, 2, 7, 8, 9, 50, 63, 65, 257, 300, 301, 1031):
+        for ny in (1, 2, 5, 24, 64):
+            for kernel in (0, 1):
+                for yz in (0, 3):
+                    column(kernel, nt, ny, yz)
+    gx, loads = column(0, 300, 1, 0)        # 300 tiles: 304 workgroups with at most one tile each, not 296 with 8 two-tile stragglers
+    assert gx == 304 and max(loads) == 1
+    assert lib.synthsr_split_tile_schedule(0, 300, 1, 304, 0, out) == -1 and lib.synthsr_split_tile_schedule(3, 300, 1, 0, 0, out) == -1
+
+
 def test_conv_arithmetic_switch_and_layer_plans():
     """ops.set_conv_arithmetic / conv_runs_split (host logic, no GPU): the split arithmetic is the default and covers the
     layers with >= 256 tiles of 4x4x16 voxels and channel counts that are multiples of 8"""
