@@ -440,8 +440,11 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
                       seg_regulariser=seg_reg, regression_metric=regression_metric, loss_cropping=loss_cropping)
 
     log_path = os.path.join(model_dir, 'logs', 'loss.csv')
+    tb = None
     if rank == 0:
         os.makedirs(os.path.dirname(log_path), exist_ok=True)
+        from .tb_events import EventFileWriter
+        tb = EventFileWriter(os.path.dirname(log_path))   # KC.TensorBoard(log_dir=model_dir/logs) (SynthSR/training.py:425-431)
     for epoch in range(init_epoch, epochs):
         t0 = time.time()
         acc = torch.zeros(1, device=net.device)
@@ -457,6 +460,9 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
                                                                                   steps_per_epoch / dt))
             with open(log_path, 'a') as f:
                 f.write('%d,%.8f,%.3f\n' % (epoch + 1, mean_loss, dt))
+            tb.add_scalar('loss', mean_loss, epoch)   # Keras logs the epoch's mean loss at step = 0-based epoch index
             save_checkpoint(os.path.join(model_dir, '%03d.npz' % (epoch + 1)), net)
             save_checkpoint(os.path.join(model_dir, '%03d.h5' % (epoch + 1)), net)  # SynthSR/training.py:429 file name
+    if tb is not None:
+        tb.close()
     return net

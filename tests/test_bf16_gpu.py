@@ -295,6 +295,11 @@ def test_training_entry_points_in_bf16(tmp_path):
     assert net.bf16 and net.saved['enc'][0][0].dtype == __import__('torch').bfloat16
     log = [float(l.split(',')[1]) for l in open(os.path.join(model_dir, 'logs', 'loss.csv')).read().strip().split('\n')]
     assert len(log) == 3 and all(np.isfinite(log)) and log[-1] < log[0]
+    # the TensorBoard event file KC.TensorBoard would have written (SynthSR/training.py:431): 'loss' at step = epoch index
+    from synthsr_amd.tb_events import read_events
+    ev = read_events(__import__('glob').glob(os.path.join(model_dir, 'logs', 'events.out.tfevents.*'))[0])
+    assert ev[0]['file_version'] == 'brain.Event:2' and [e['step'] for e in ev[1:]] == [0, 1, 2]
+    assert np.allclose([e['scalars'][0][1] for e in ev[1:]], log, rtol=1e-5, atol=1e-7) and ev[1]['scalars'][0][0] == 'loss'
     gen, critic = adv_training(str(tmp_path / 'labels'), str(tmp_path / 'images'), str(tmp_path / 'adv'), None, None,
                                str(tmp_path / 'gl.npy'), output_shape=32, n_levels=3, nonlin_shape_factor=.125,
                                bias_shape_factor=.125, epochs=1, steps_per_epoch=2, first_training_ratio=2,
