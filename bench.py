@@ -181,7 +181,11 @@ def cpu_baseline(size_all=160, size_one=64, timed=3):
 
 
 def conv_flops(kind, shape, cin, cout):
-    return 2.0 * 27 * cin * cout * float(np.prod(shape))
+    """flops a conv launch EXECUTES.  Folded decoder convs ('conv3d_up_*': recorded with the low-resolution shape) run 8 parity
+    convs of 2x2x2 taps per low-resolution voxel = 64 tap products (the 3x3x3 conv on the up-sampled tensor they replace would
+    be 8 x 27 = 216: the 3.4x saving of the folding is not counted as throughput)"""
+    taps = 64 if kind.startswith('conv3d_up_') else 27
+    return 2.0 * taps * cin * cout * float(np.prod(shape))
 
 
 def cpu_worker(size, timed):
@@ -383,13 +387,16 @@ def main():
             with open(args.layer_table, 'w') as f:
                 f.write('# %s: every conv launch of the first %d timed steps (HIP events on the launch stream), per step\n'
                         % (' '.join(sys.argv), min(3, args.steps)))
-                f.write('%-16s %-14s %4s %4s %9s %8s %8s %7s %s\n' % ('kernel', 'volume', 'cin', 'cout', 'launches', 'avg_ms',
-                                                                      'ms/step', 'TFLOP/s', 'arithmetic'))
+                f.write('%-16s %-14s %4s %4s %9s %8s %8s %7s %5s %s\n' % ('kernel', 'volume', 'cin', 'cout', 'launches', 'avg_ms',
+                                                                          'ms/step', 'TFLOP/s', 'frac', 'arithmetic (frac = '
+                                                                          'TFLOP/s / its MFMA peak: 2500 / products, or 157.3)'))
                 for r in rows:
                     sp = args.conv_arith != 'fp32_mfma' and ops.conv_runs_split(r['kernel'], tuple(r['shape']), r['cin'], r['cout'])
-                    f.write('%-16s %-14s %4d %4d %9.1f %8.4f %8.4f %7.1f %s\n' % (
+                    pk = BF16_MFMA_PEAK_TFLOPS / (9.0 if args.conv_arith == 'split9' else 6.0) if sp else FP32_MFMA_PEAK_TFLOPS
+                    f.write('%-16s %-14s %4d %4d %9.1f %8.4f %8.4f %7.1f %5.2f %s\n' % (
                         r['kernel'], 'x'.join(map(str, r['shape'])), r['cin'], r['cout'], r['launches'] / min(3, args.steps),
-                        r['avg_ms'], r['total_ms'] / min(3, args.steps), r['tflops'], args.conv_arith if sp else 'fp32_mfma'))
+                        r['avg_ms'], r['total_ms'] / min(3, args.steps), r['tflops'], r['tflops'] / pk,
+                        args.conv_arith if sp else 'fp32_mfma'))
         flops_launch = conv_flops(dom['kernel'], dom['shape'], dom['cin'], dom['cout'])
         # the peak the dominant kernel is priced against: layers on the split arithmetic issue 6 bf16 MFMAs per fp32 MFMA's
         # worth of algorithmic work -> dense bf16 peak / 6; layers on the fp32 matrix instructions -> the fp32 MFMA peak

@@ -73,8 +73,9 @@ def main():
     for (kind, shape, cin, cout), samples in agg.items():
         vox = float(np.prod(shape))
         cin_real = 1 if (dtype == 'bf16' and cin == 8 and shape[0] == S) else cin     # the zero-padded first layer
-        fl = 2.0 * 27 * cin_real * cout * vox
-        by = esz * vox * (cin_real + cout)
+        up = '_up_' in kind   # folded decoder conv of the generator (low-resolution shape): 8 parity convs of 2x2x2 taps
+        fl = 2.0 * (64 if up else 27) * cin_real * cout * vox
+        by = esz * vox * (cin_real + (8 if up else 1) * cout)
         ms, cnt = float(sum(samples)), len(samples)
         rows.append(dict(kernel=kind, shape=list(shape), cin=cin, cout=cout, launches=cnt, avg_ms=ms / cnt,
                          tflops=fl / (ms / cnt * 1e-3) / 1e12, gbs=by / (ms / cnt * 1e-3) / 1e9, total_ms=ms, flops=fl,

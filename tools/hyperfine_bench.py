@@ -78,11 +78,12 @@ def main():
             agg.setdefault((kind, shape, cin, cout), []).append(s.elapsed_time(e))
     rows = []
     for (kind, shape, cin, cout), samples in agg.items():
-        fl = 2.0 * 27 * cin * cout * float(np.prod(shape))
+        up = '_up_' in kind                                    # folded decoder conv, recorded with its LOW-resolution shape:
+        taps = 64 if up else 27                                # 8 parity convs of 2x2x2 taps per low-resolution voxel
         cin_real = min(cin, 2) if cin == 8 else cin            # the zero-padded first layer: algorithmic channels
-        fl_alg = 2.0 * 27 * cin_real * cout * float(np.prod(shape))
+        fl_alg = 2.0 * taps * cin_real * cout * float(np.prod(shape))
         esz = 2 if args.dtype == 'bf16' else 4
-        by = esz * float(np.prod(shape)) * (cin_real + cout)
+        by = esz * float(np.prod(shape)) * (cin_real + (8 if up else 1) * cout)
         ms, cnt = float(sum(samples)), len(samples)
         rows.append(dict(kernel=kind, shape=list(shape), cin=cin, cout=cout, launches=cnt, avg_ms=ms / cnt,
                          tflops=fl_alg / (ms / cnt * 1e-3) / 1e12, gbs=by / (ms / cnt * 1e-3) / 1e9, total_ms=ms,
