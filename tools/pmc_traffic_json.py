@@ -33,10 +33,11 @@ out = {'_note': __doc__.split('bench.py reads')[1].strip().replace('\n', ' '),
                   % (sys.argv[3] if len(sys.argv) > 3 else '?')}
 # the 160^3 24 -> 24 layers are the LARGEST dispatches of their kernels (the same kernels also run smaller layers)
 # (split arithmetic, the default: conv_split.hip kernels; fp32_mfma: the 4x4x1-MFMA kernels of conv3d.hip)
-for key, kerns, wide in (('conv3d_wgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_wgrad_kernel<24>', 'conv3d_wgrad_p4_kernel'), True),
-                         ('conv3d_fwd 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd_kernel<2, false>', 'conv3d_fwd_p4_kernel'), True),
-                         ('conv3d_dgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd_kernel<2, false>', 'conv3d_fwd_p4_kernel'), True)):
-    kern = next((k for k in kerns if k in fetch and k in write), None)
+# (kernel symbols are matched by prefix: the template argument lists grew -- <24> became <24, 6>: COW, partial products)
+for key, kerns, wide in (('conv3d_wgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_wgrad_kernel<24', 'conv3d_wgrad_p4_kernel'), True),
+                         ('conv3d_fwd 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd_kernel<2, false', 'conv3d_fwd_p4_kernel'), True),
+                         ('conv3d_dgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd_kernel<2, false', 'conv3d_fwd_p4_kernel'), True)):
+    kern = next((k for pre in kerns for k in sorted(fetch) if k.startswith(pre) and k in write), None)
     if kern is None:
         continue
     f, w = max(fetch[kern]), max(write[kern])
