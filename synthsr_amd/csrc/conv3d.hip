@@ -3917,6 +3917,7 @@ int synthsr_deterministic_status(void) {
 }
 
 extern "C" void syn_split_set_products(int n);  // conv_split.hip: 6 or 9 partial products per multiplication
+extern "C" void syn_split_set_variant(int v);   // conv_split.hip: kernel generation (A/B runs of tools/)
 static int g_arith = 1;
 int synthsr_set_conv_arithmetic(int mode) {
   if (mode < 0 || mode > 2) return SYNTHSR_EINVAL;
@@ -3959,6 +3960,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 7) {
     g_psplit = value ? 1 : 0;
+    return SYNTHSR_OK;
+  }
+  if (option == 8) {
+    syn_split_set_variant(value);
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;

@@ -24,6 +24,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef SYN_ABL  // ablation builds of the interleaved forward kernel (tools/split_ablate.sh): 1 no halo loads, 2 no conversion,
+#define SYN_ABL 0  // 4 no LDS image stores, 8 weights loaded once, 16 activation fragments loaded once per chunk, 32 no stores, 64 no MFMAs
+#endif
 #ifdef SYN_SPLIT_TIMING  // per-phase shader-clock stamps of wave 0 of workgroups 0 and 300 (tools/split_phase_timing.py)
 static __device__ long long* g_tm = nullptr;
 extern "C" int synthsr_split_timing_buffer(long long* p) {
@@ -38,6 +41,10 @@ extern "C" int synthsr_split_timing_buffer(long long* p) {
 // reproduced EXACTLY (tests/test_split_arithmetic_cpu.py) at 1.5x the MFMAs; same packed weights, same kernels (template NPROD)
 static int g_products = 6;
 extern "C" __attribute__((visibility("hidden"))) void syn_split_set_products(int n) { g_products = n == 9 ? 9 : 6; }
+// synthsr_conv3d_set_option(8, v) (tools/ A-B runs): 0 = the round-3 kernels (phases: K loop | convert | epilogue),
+// 1 (default) = the interleaved kernels of round 4
+static int g_variant = 1;
+extern "C" __attribute__((visibility("hidden"))) void syn_split_set_variant(int v) { g_variant = v; }
 
 namespace {
 
@@ -474,6 +481,389 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
   }
 }
 
+// ---- round 4: the same forward / data-gradient computation as ONE homogeneous instruction stream.
+// s_memtime stamps of the kernel above (profiles/r04_split_fwd_phase_cycles_before.txt): per 8-channel chunk a wave spends
+// 8 400 cycles in its K loop (336 MFMAs = 5 376 cycles of matrix pipe), 3 000-4 000 converting the next halo image and, once per
+// tile, 7 000-10 000 in the epilogue -- and the two waves of a SIMD (one of each co-resident workgroup) run these phases IN
+// step: the wave that is ahead shares the matrix pipe during its K loop, falls back while it converts, and the other one
+// catches up (being in phase is the attractor), so the pipe idles while both convert.  Here a wave has no phases: the
+// conversion of the next chunk's halo image (piece i of a thread in K step i + 1) and the epilogue of the PREVIOUS tile (its
+// accumulators parked in `pend`, one output row per K step of the next tile's first chunk) are issued between the MFMA groups
+// of the K loop, so that every wave feeds the matrix pipe all the time and vector-ALU / LDS / store instructions fill the
+// issue slots next to it.  Bias is folded into the accumulator initialisation; activation / addend handling is a template
+// parameter (a run-time branch inside the K loop would cut the scheduling region): EPI 0 linear, 1 ELU, 2 x ELU'(addend),
+// 3 + addend, 4 ELU(. + addend).  LDS planes are padded to 6 x 256 staging pieces so that every lane stores (no divergent tail).
+constexpr int PLANE2 = 6 * 256 * 8;  // bytes of one bf16 piece of an 8-channel halo image, padded (>= HVOX * 16)
+constexpr int BUF2 = 3 * PLANE2;
+static_assert(PLANE2 >= PLANE, "padded plane holds the halo image");
+
+template <int MT, bool ST, int EPI, bool DEFER>
+__global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFwdArgs a) {
+  constexpr int NSTEP = NSTEP27;
+  constexpr int NITEM = TY * MT;  // epilogue items: one f32x4 (4 channels of a voxel) per lane each
+  static_assert(!ST || EPI <= 1, "statistics belong to plain forward convs");
+  static_assert(NITEM <= 2 * NSTEP, "at most two epilogue items per K step");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int chunk = blockIdx.y, nchunks = gridDim.y;
+  const TileWalk walk = tile_walk(a.ntiles);
+  const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
+  const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout, ncc = a.ncc;
+
+  int koff[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    int tap = syn_split_tap(4 * s + g);
+    if (tap < 0) tap = syn_split_tap((4 * s + g) ^ 1);
+    koff[s] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * 16;
+  }
+  const int xv = syn_split_voxel(m);
+  const int lbase = (wave * HY * HX + xv) * 16;
+
+  constexpr int NP = HVOX * 2, NL = 6;
+  static_assert(NL * 256 >= NP, "six staging pieces per thread cover the halo image");
+  int prel[NL];
+  uint32_t pmask[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int j = tid + 256 * i;
+    const int v = j >> 1, h = j & 1;
+    const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
+    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4 + h * 16;
+    pmask[i] = j < NP ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+  }
+  const int plds0 = (tid >> 1) * 16 + (tid & 1) * 8;  // piece i sits 128 voxels = 2048 bytes further on
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  // the six pieces of a thread travel in two groups (registers): pieces 0-3 are requested at the top of a chunk and converted
+  // in K steps 1-4, pieces 4-5 are requested in step 2 (into the registers pieces 0-1 have left) and converted in steps 5-6
+  f32x4 stg[NL];
+  uint32_t hbad = 0;  // out-of-range mask of the halo image in flight (wave-uniform)
+  int hbase = 0;      // its byte offset
+  auto halo_where = [&](int t, int cc, bool none) {  // none: there is no next chunk -- every lane reads out of range (zeros)
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    uint32_t bad = none ? 0xFFFFFFFFu : 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    hbad = bad;
+    hbase = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
+  };
+  auto load_pieces = [&](auto I0_, auto I1_) {
+    constexpr int i0 = decltype(I0_)::value, i1 = decltype(I1_)::value;
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      const uint32_t vo = (pmask[i] & hbad) ? OOB : (uint32_t)(prel[i] + hbase);
+#if SYN_ABL & 1
+      stg[i] = (f32x4){__uint_as_float(vo), 1.f, 2.f, 3.f};
+#else
+      stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
+#endif
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P4 = std::integral_constant<int, 4>;
+  using P6 = std::integral_constant<int, 6>;
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  uint32_t cp[6];  // the piece being converted: three bf16 pairs of its first / second two values
+#if SYN_ABL & 2
+  auto conv_a = [&](int i) { cp[0] = __float_as_uint(stg[i][0]); cp[1] = __float_as_uint(stg[i][1]); cp[2] = cp[0] ^ cp[1]; };
+  auto conv_b = [&](int i) { cp[3] = __float_as_uint(stg[i][2]); cp[4] = __float_as_uint(stg[i][3]); cp[5] = cp[3] ^ cp[4]; };
+#else
+  auto conv_a = [&](int i) { syn_split3(stg[i][0], stg[i][1], cp[0], cp[1], cp[2]); };
+  auto conv_b = [&](int i) { syn_split3(stg[i][2], stg[i][3], cp[3], cp[4], cp[5]); };
+#endif
+  auto conv_c = [&](int i, unsigned char* dst) {
+#if SYN_ABL & 4
+    if (cp[0] == 0x12345u && cp[5] == 0x54321u)  // (never)
+#endif
+    {
+    *reinterpret_cast<u32x2*>(dst + plds0 + i * 2048) = (u32x2){cp[0], cp[3]};
+    *reinterpret_cast<u32x2*>(dst + PLANE2 + plds0 + i * 2048) = (u32x2){cp[1], cp[4]};
+    *reinterpret_cast<u32x2*>(dst + 2 * PLANE2 + plds0 + i * 2048) = (u32x2){cp[2], cp[5]};
+    }
+  };
+
+  const int64_t piece_stride = (int64_t)nchunks * ncc * NSTEP * MT * 64;
+  const u32x4* __restrict__ wbase = a.wp + (int64_t)chunk * ncc * NSTEP * MT * 64 + lane;
+
+  float s1[ST ? MT : 1][4], s2[ST ? MT : 1][4];
+#pragma unroll
+  for (int mt = 0; mt < (ST ? MT : 1); ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s1[mt][i] = s2[mt][i] = 0.f;
+
+  const int64_t out_bytes = (int64_t)D0 * D1 * D2 * Cout * 4;
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t radd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.addend ? a.addend : a.out), 0, (int)out_bytes, 0x00020000);
+  const uint32_t ystep = (uint32_t)(D2 * Cout * 4);
+
+  // the bias of this co-chunk sits in LDS behind the images (an epilogue item reads its four channels from there)
+  float* lbias = reinterpret_cast<float*>(lds + 2 * BUF2);
+  if (tid < MT * 16) {
+    const int co = chunk * MT * 16 + tid;
+    lbias[tid] = (a.bias && co < Cout) ? a.bias[co] : 0.f;
+  }
+
+  u32x4 wa[3][MT], xb[3][TY];
+  bool wfirst = true;
+  (void)wfirst;
+  auto wload = [&](const u32x4* wf, int s, int q) {
+#if SYN_ABL & 8
+    if (!wfirst) return;
+#endif
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wa[q][mt] = wf[q * piece_stride + (s * MT + mt) * 64];
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  f32x4 acc[TY][MT];
+  f32x4 pend[DEFER ? TY : 1][DEFER ? MT : 1];  // the previous tile's sums, waiting for their epilogue
+  uint32_t prow0 = OOB, pyok = 0;               // its first output row (byte offset of this lane's voxel) and valid rows
+  f32x4 ev[1], eb[1];
+  uint32_t eoff[1];
+
+  // epilogue item j = (mt, y) of the parked tile (src = pend) or of the finished one (src = acc), in three segments
+  auto item_off = [&](int j, uint32_t row0, uint32_t yok) -> uint32_t {
+    const int mt = j / TY, y = j % TY;
+    const int co = (chunk * MT + mt) * 16 + 4 * g;
+    return (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;
+  };
+  auto epi0 = [&](int k, int j, uint32_t row0, uint32_t yok) {
+#if SYN_ABL & 32
+    row0 = OOB; yok = 0;
+#endif
+    eoff[k] = item_off(j, row0, yok);
+    if constexpr (EPI >= 2) eb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)eoff[k], 0, 0));
+  };
+  auto epi1 = [&](int k, int j, const f32x4& src) {
+    const f32x4 bj = *reinterpret_cast<const f32x4*>(lbias + (j / TY) * 16 + 4 * g);
+    f32x4 v = src;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += bj[i];
+    if constexpr (EPI == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] *= elu_dy(eb[k][i]);
+    }
+    if constexpr (EPI == 3 || EPI == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += eb[k][i];
+    }
+    if constexpr (EPI == 1 || EPI == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
+    }
+    ev[k] = v;
+  };
+  auto epi2 = [&](int k, int j) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev[k]), rout, (int)eoff[k], 0, 0);
+    if constexpr (ST) {
+      const int mt = j / TY;
+      const float w = eoff[k] != OOB ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float r = w * ev[k][i];
+        s1[mt][i] += r;
+        s2[mt][i] += r * r;
+      }
+    }
+  };
+  auto tile_rows = [&](int t, uint32_t& row0, uint32_t& yok) {
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    const int gz = z0 + wave, gx = x0 + xv;
+    const bool zx_ok = gz < D0 && gx < D2;
+    row0 = (uint32_t)((gz * D1 + y0) * D2 + gx) * (uint32_t)(Cout * 4);
+    yok = 0;
+#pragma unroll
+    for (int y = 0; y < TY; ++y) yok |= (zx_ok && (y0 + y) < D1) ? (1u << y) : 0u;
+  };
+
+  int buf = 0;
+  if (walk.pos < walk.end) {
+    halo_where(walk.pos, 0, false);
+    load_pieces(P0{}, P6{});
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      conv_a(i);
+      conv_b(i);
+      conv_c(i, lds);
+    }
+    wload(wbase, 0, 0);
+    wload(wbase, 0, 1);
+    wload(wbase, 0, 2);
+    wfirst = false;
+  }
+  // one K chunk of tile t; WITH_EPI: the parked tile's epilogue rides along
+  auto body = [&](int t, int cc, auto WITH_EPI) {
+    constexpr bool WE = decltype(WITH_EPI)::value;
+    __syncthreads();  // image `buf` is complete; nobody reads the other one any more
+    const bool last_cc = cc + 1 == ncc;
+    const bool more = !last_cc || t + walk.stride < walk.end;
+    halo_where(last_cc ? (more ? t + walk.stride : t) : t, last_cc ? 0 : cc + 1, !more);
+    load_pieces(P0{}, P4{});
+    const u32x4* wf = wbase + (int64_t)cc * NSTEP * MT * 64;
+    const u32x4* wf_next = wbase + (int64_t)(last_cc ? 0 : cc + 1) * NSTEP * MT * 64;
+    const unsigned char* img = lds + buf * BUF2 + lbase;
+    unsigned char* nimg = lds + (buf ^ 1) * BUF2;
+    auto xload = [&](int s, int q) {
+#if SYN_ABL & 16
+      if (s != 0) return;
+#endif
+#pragma unroll
+      for (int y = 0; y < TY; ++y) xb[q][y] = *reinterpret_cast<const u32x4*>(img + q * PLANE2 + koff[s] + y * (HX * 16));
+    };
+    auto mma = [&](auto QA, auto QB) {
+      constexpr int qa = decltype(QA)::value, qb = decltype(QB)::value;
+#pragma unroll
+      for (int y = 0; y < TY; ++y)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#if SYN_ABL & 64
+          acc[y][mt][0] += __uint_as_float(wa[qa][mt][0] ^ xb[qb][y][0]);
+#else
+          acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[qa][mt]),
+                                                               __builtin_bit_cast(bf16x8, xb[qb][y]), acc[y][mt], 0, 0, 0);
+#endif
+    };
+    xload(0, 2);
+    xload(0, 1);
+    xload(0, 0);
+    sfor<0, NSTEP>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      constexpr bool last = s + 1 == NSTEP;
+      const u32x4* wn = last ? wf_next : wf;
+      constexpr int sn = last ? 0 : s + 1;
+      constexpr int ci = s - 1;                                        // staging piece converted in this step
+      constexpr bool cv = ci >= 0 && ci < NL;
+      constexpr int ja = s, jb = s + NSTEP;                            // epilogue items of this step
+      constexpr bool ea = WE && ja < NITEM, ebb = WE && jb < NITEM;
+      __builtin_amdgcn_sched_barrier(0);
+      mma(I0{}, I2{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!last) xload(sn, 2);
+      if constexpr (cv) conv_a(ci);
+      if constexpr (ea) epi0(0, ja, prow0, pyok);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(I0{}, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (cv) conv_b(ci);
+      if constexpr (ea) epi1(0, ja, pend[DEFER ? ja % TY : 0][DEFER ? ja / TY : 0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(I0{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      wload(wn, sn, 0);
+      if constexpr (cv) conv_c(ci, nimg);
+      if constexpr (ea) epi2(0, ja);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(I1{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (s == 2) load_pieces(P4{}, P6{});
+      if constexpr (ebb) epi0(0, jb, prow0, pyok);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(I1{}, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      wload(wn, sn, 1);
+      if constexpr (!last) xload(sn, 1);
+      if constexpr (ebb) epi1(0, jb, pend[DEFER ? jb % TY : 0][DEFER ? jb / TY : 0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(I2{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      wload(wn, sn, 2);
+      if constexpr (!last) xload(sn, 0);
+      if constexpr (ebb) epi2(0, jb);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    buf ^= 1;
+  };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int y = 0; y < TY; ++y)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  // No if / else between two copies of the K loop (the register allocator spills ~100 registers at such a join): every tile
+  // starts with the chunk that carries the parked epilogue, the others follow in a loop.
+  int t = walk.pos;
+  if constexpr (DEFER) {
+    auto park = [&](int t_) {
+#pragma unroll
+      for (int y = 0; y < TY; ++y)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) pend[y][mt] = acc[y][mt];
+      tile_rows(t_, prow0, pyok);
+    };
+    // the first tile's rider works on an empty parked tile (pend = 0, every row invalid: nothing is stored or counted)
+#pragma unroll
+    for (int y = 0; y < TY; ++y)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) pend[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t < walk.end) {
+      for (; t < walk.end; t += walk.stride) {
+        zero_acc();
+        body(t, 0, std::true_type{});
+        for (int cc = 1; cc < ncc; ++cc) body(t, cc, std::false_type{});
+        park(t);
+      }
+#pragma unroll
+      for (int j = 0; j < NITEM; ++j) {
+        epi0(0, j, prow0, pyok);
+        epi1(0, j, pend[j % TY][j / TY]);
+        epi2(0, j);
+      }
+    }
+  } else {
+    for (; t < walk.end; t += walk.stride) {
+      zero_acc();
+      for (int cc = 0; cc < ncc; ++cc) body(t, cc, std::false_type{});
+      uint32_t row0, yok;
+      tile_rows(t, row0, yok);
+#pragma unroll
+      for (int j = 0; j < NITEM; ++j) {
+        epi0(0, j, row0, yok);
+        epi1(0, j, acc[j % TY][j / TY]);
+        epi2(0, j);
+      }
+    }
+  }
+  if constexpr (ST) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);  // [wave][2][MT*16]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x1 = s1[mt][i], x2 = s2[mt][i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          x1 += __shfl_xor(x1, o, 64);
+          x2 += __shfl_xor(x2, o, 64);
+        }
+        if (m == 0) {
+          red[(wave * 2 + 0) * (MT * 16) + mt * 16 + 4 * g + i] = x1;
+          red[(wave * 2 + 1) * (MT * 16) + mt * 16 + 4 * g + i] = x2;
+        }
+      }
+    __syncthreads();
+    float* dst = a.stats_partial + (int64_t)blockIdx.x * (2 * Cout);
+    for (int e = tid; e < MT * 16; e += 256) {
+      const int c = chunk * MT * 16 + e;
+      if (c < Cout) {
+        dst[c] = red[e] + red[2 * MT * 16 + e] + red[4 * MT * 16 + e] + red[6 * MT * 16 + e];
+        dst[Cout + c] = red[MT * 16 + e] + red[3 * MT * 16 + e] + red[5 * MT * 16 + e] + red[7 * MT * 16 + e];
+      }
+    }
+  }
+}
+
 // Forward pass of the up-sampled channel range of a folded decoder conv: out[2 v + p] (+)= sum over the 8 taps (a, b, c) of parity
 // p's 2x2x2 window of W_p[(a, b, c)] . lo[v + (a, b, c) + p - 1], for all parities p from ONE staged (converted) low-resolution
 // halo image -- a converted element feeds 8 parities x 8 taps instead of 27 taps.  512 threads: wave = (z plane, y half) of the
@@ -706,8 +1096,41 @@ int launch_split_fwd_np(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t 
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
+template <int MT, bool ST, int EPI>
+int launch_split_fwd2_e(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
+  constexpr bool DEFER = MT <= 2;
+  const size_t smem = 2 * BUF2 + MT * 16 * 4;
+  auto kern = conv3d_split_fwd2_kernel<MT, ST, EPI, DEFER>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(256), smem, st, a);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+template <int MT, bool ST>
+int launch_split_fwd2(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
+  const int epi = a.act + ((a.addend && a.act < 2) ? 3 : 0);
+  if constexpr (ST) {
+    return epi == 1 ? launch_split_fwd2_e<MT, true, 1>(a, gx, nchunks, st) : launch_split_fwd2_e<MT, true, 0>(a, gx, nchunks, st);
+  } else {
+    switch (epi) {
+      case 0: return launch_split_fwd2_e<MT, false, 0>(a, gx, nchunks, st);
+      case 1: return launch_split_fwd2_e<MT, false, 1>(a, gx, nchunks, st);
+      case 2: return launch_split_fwd2_e<MT, false, 2>(a, gx, nchunks, st);
+      case 3: return launch_split_fwd2_e<MT, false, 3>(a, gx, nchunks, st);
+      default: return launch_split_fwd2_e<MT, false, 4>(a, gx, nchunks, st);
+    }
+  }
+}
+
 template <int MT, bool ST, int UPM = 0>
 int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
+  if constexpr (UPM == 0) {
+    if (g_products == 6 && g_variant >= 1) return launch_split_fwd2<MT, ST>(a, gx, nchunks, st);
+  }
   return g_products == 9 ? launch_split_fwd_np<MT, ST, UPM, 9>(a, gx, nchunks, st) : launch_split_fwd_np<MT, ST, UPM, 6>(a, gx, nchunks, st);
 }
 
