@@ -41,8 +41,8 @@ extern "C" int synthsr_split_timing_buffer(long long* p) {
 // reproduced EXACTLY (tests/test_split_arithmetic_cpu.py) at 1.5x the MFMAs; same packed weights, same kernels (template NPROD)
 static int g_products = 6;
 extern "C" __attribute__((visibility("hidden"))) void syn_split_set_products(int n) { g_products = n == 9 ? 9 : 6; }
-// synthsr_conv3d_set_option(8, v) (tools/ A-B runs): 0 = the round-3 kernels (phases: K loop | convert | epilogue),
-// 1 (default) = the interleaved kernels of round 4
+// synthsr_conv3d_set_option(8, v) (tools/ A-B runs): 0 = the round-3 forward kernel (phases: K loop | convert | epilogue),
+// 1 (default) = round 4: conversion inside the K loop (fwd2), the LDS-weights kernel (fwd3) where it quantises better; 2 = fwd3 everywhere
 static int g_variant = 1;
 extern "C" __attribute__((visibility("hidden"))) void syn_split_set_variant(int v) { g_variant = v; }
 
@@ -727,6 +727,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
       for (int y = 0; y < TY; ++y)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
+#if SYN_ABL & 128
+          if (!(mt == 1 && ((qa == 0 && qb == 2) || (qa == 1 && qb == 1))))
+#endif
 #if SYN_ABL & 64
           acc[y][mt][0] += __uint_as_float(wa[qa][mt][0] ^ xb[qb][y][0]);
 #else
@@ -859,6 +862,406 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
       if (c < Cout) {
         dst[c] = red[e] + red[2 * MT * 16 + e] + red[4 * MT * 16 + e] + red[6 * MT * 16 + e];
         dst[Cout + c] = red[MT * 16 + e] + red[3 * MT * 16 + e] + red[5 * MT * 16 + e] + red[7 * MT * 16 + e];
+      }
+    }
+  }
+}
+
+// ---- round 4, second step: no operand of an MFMA waits on the vector-memory counter.
+// Ablation builds of the kernel above (profiles/r04_split_fwd2_ablation.txt, 160^3 24->24): without its MFMAs it still takes
+// 0.66 ms, its MFMAs alone 0.59 ms, both together 0.96 ms.  vmcnt counts in order: a weight fragment (L2, requested one K step
+// ahead) cannot be waited for without also waiting for every older request of the wave -- the halo loads of the next chunk (HBM)
+// and the previous epilogue's stores -- so every chunk exposed one or two HBM round trips, and interleaving instructions could
+// not hide them.  Here the matrix operands come from LDS only (lgkmcnt): one 512-thread workgroup per CU; per 8-channel chunk the
+// weight fragments of the co-chunk (3 pieces x 7 steps x MT KB) are copied L2 -> registers -> LDS one chunk ahead (both buffers
+// when they fit, MT <= 2; one buffer and a second barrier otherwise), the halo image is requested a chunk ahead, converted in the
+// last K steps of the chunk before its own and written to the other image buffer; the previous tile's epilogue rides in the
+// first chunk of the next tile.  The only waits on vmcnt are for requests that are at least four K steps old, and stores are
+// never waited for.  wave = (z plane, y half) of the 4x4x16 tile: two x-rows, fragments of step s + 1 are read (second register
+// set) while step s multiplies.  Same products in the same order per accumulator as the kernels above: bit-identical results.
+template <int MT>
+struct F3Cfg {
+  static constexpr int NWP = 3 * NSTEP27 * MT * 64;    // 16-byte pieces of one chunk's weight fragments
+  static constexpr int NWL = (NWP + 511) / 512;         // per thread (the surplus ones repeat the thread's first piece)
+  static constexpr int WBYTES = NWP * 16;
+  static constexpr bool WDB = 2 * BUF + 2 * WBYTES + MT * 64 <= 160 * 1024;
+  static constexpr int SMEM = 2 * BUF + (WDB ? 2 : 1) * WBYTES + MT * 64;
+};
+
+template <int MT, bool ST, int EPI>
+__global__ __launch_bounds__(512, 1) void conv3d_split_fwd3_kernel(const SplitFwdArgs a) {
+  using C = F3Cfg<MT>;
+  constexpr int NSTEP = NSTEP27, RW = 2, NTHR = 512;
+  constexpr int NITEM = RW * MT;  // epilogue items per lane: one f32x4 (4 channels of a voxel) each
+  constexpr bool WDB = C::WDB;
+  static_assert(!ST || EPI <= 1, "statistics belong to plain forward convs");
+  static_assert(NITEM <= NSTEP, "one epilogue item per K step");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const wlds = lds + 2 * BUF;  // weight fragments: [buffer][piece 3][step 7][mt][lane] x 16 bytes
+  float* const lbias = reinterpret_cast<float*>(wlds + (WDB ? 2 : 1) * C::WBYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4, zw = wave & 3, yh = wave >> 2;
+  const int chunk = blockIdx.y, nchunks = gridDim.y;
+  const TileWalk walk = tile_walk(a.ntiles);
+  const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
+  const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout, ncc = a.ncc;
+
+  int koff[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    int tap = syn_split_tap(4 * s + g);
+    if (tap < 0) tap = syn_split_tap((4 * s + g) ^ 1);
+    koff[s] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * 16;
+  }
+  const int xv = syn_split_voxel(m);
+  const int lbase = ((zw * HY + RW * yh) * HX + xv) * 16;
+
+  // halo staging: 16-byte piece j = tid + 512 i (i < 3) of the 8-channel image -> halo voxel j >> 1, channels 4 (j & 1) .. + 3;
+  // a thread without a third piece repeats its second one (same value to the same address: no divergent tail)
+  constexpr int NP = HVOX * 2, NL = 3;
+  static_assert(NL * NTHR >= NP && (NL - 1) * NTHR < NP, "three staging pieces per thread");
+  int prel[NL], plds[NL];
+  uint32_t pmask[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int j = tid + NTHR * i;
+    if (j >= NP) j -= NTHR;
+    const int v = j >> 1, h = j & 1;
+    const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
+    prel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4 + h * 16;
+    plds[i] = v * 16 + h * 8;
+    pmask[i] = (1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx));
+  }
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  // two staging sets: hst is converted during a chunk (it holds the NEXT chunk's image), hnx was requested at the end of the
+  // chunk before and holds the image after that; at the end of a chunk hnx moves to hst (a chunk old: it has landed) and the
+  // following image is requested -- every request has two chunk times to arrive
+  f32x4 hst[NL], hnx[NL];
+  // (tile, chunk) -> the one after it; past the end of the walk every lane reads out of range (zeros, never used)
+  auto halo_issue = [&](int t, int cc) {
+    const bool none = t >= walk.end;
+    int z0, y0, x0;
+    tile_decode(none ? walk.pos : t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    uint32_t bad = none ? 0xFFFFFFFFu : 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const uint32_t vo = (pmask[i] & bad) ? OOB : (uint32_t)(prel[i] + base);
+#if SYN_ABL & 1
+      hnx[i] = (f32x4){__uint_as_float(vo), 1.f, 2.f, 3.f};
+#else
+      hnx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
+#endif
+    }
+  };
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  uint32_t cp[6];
+#if SYN_ABL & 2
+  auto conv_a = [&](int i) { cp[0] = __float_as_uint(hst[i][0]); cp[1] = __float_as_uint(hst[i][1]); cp[2] = cp[0] ^ cp[1]; };
+  auto conv_b = [&](int i) { cp[3] = __float_as_uint(hst[i][2]); cp[4] = __float_as_uint(hst[i][3]); cp[5] = cp[3] ^ cp[4]; };
+#else
+  auto conv_a = [&](int i) { syn_split3(hst[i][0], hst[i][1], cp[0], cp[1], cp[2]); };
+  auto conv_b = [&](int i) { syn_split3(hst[i][2], hst[i][3], cp[3], cp[4], cp[5]); };
+#endif
+  auto conv_c = [&](int i, unsigned char* dst) {
+#if SYN_ABL & 4
+    if (cp[0] == 0x12345u && cp[5] == 0x54321u)  // (never)
+#endif
+    {
+    *reinterpret_cast<u32x2*>(dst + plds[i]) = (u32x2){cp[0], cp[3]};
+    *reinterpret_cast<u32x2*>(dst + PLANE + plds[i]) = (u32x2){cp[1], cp[4]};
+    *reinterpret_cast<u32x2*>(dst + 2 * PLANE + plds[i]) = (u32x2){cp[2], cp[5]};
+    }
+  };
+
+  // weight staging: piece j = tid + 512 k of the chunk's 3 x (7 MT KB) fragment blocks
+  const int piece_stride = nchunks * ncc * NSTEP * MT * 64;  // u32x4 elements between the bf16 pieces of the packed set
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(a.wp), 0, (int)((int64_t)3 * piece_stride * 16), 0x00020000);
+  int wsrc[C::NWL];
+#pragma unroll
+  for (int k = 0; k < C::NWL; ++k) {
+    int j = tid + NTHR * k;
+    if (j >= C::NWP) j = tid;
+    const int q = j / (NSTEP * MT * 64), r = j - q * (NSTEP * MT * 64);
+    wsrc[k] = (q * piece_stride + chunk * ncc * NSTEP * MT * 64 + r) * 16;
+  }
+  u32x4 wst[C::NWL];
+  bool wfirst = true;
+  (void)wfirst;
+  auto w_issue = [&](int cc) {
+#if SYN_ABL & 8
+    if (!wfirst) return;
+#endif
+#pragma unroll
+    for (int k = 0; k < C::NWL; ++k) wst[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, wsrc[k] + cc * (NSTEP * MT * 64 * 16), 0, 0);
+  };
+  auto w_store = [&](unsigned char* dst) {
+#if SYN_ABL & 8
+    if (!wfirst) return;
+#endif
+#pragma unroll
+    for (int k = 0; k < C::NWL; ++k) {
+      const int j = (tid + NTHR * k) >= C::NWP ? tid : tid + NTHR * k;
+      *reinterpret_cast<u32x4*>(dst + j * 16) = wst[k];
+    }
+  };
+
+  float s1[ST ? MT : 1][4], s2[ST ? MT : 1][4];
+#pragma unroll
+  for (int mt = 0; mt < (ST ? MT : 1); ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s1[mt][i] = s2[mt][i] = 0.f;
+
+  const int64_t out_bytes = (int64_t)D0 * D1 * D2 * Cout * 4;
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t radd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.addend ? a.addend : a.out), 0, (int)out_bytes, 0x00020000);
+  const uint32_t ystep = (uint32_t)(D2 * Cout * 4);
+  if (tid < MT * 16) {
+    const int co = chunk * MT * 16 + tid;
+    lbias[tid] = (a.bias && co < Cout) ? a.bias[co] : 0.f;
+  }
+
+  f32x4 acc[RW][MT], pend[RW][MT];
+  uint32_t prow0 = OOB, pyok = 0;
+  f32x4 ev, eb[EPI >= 2 ? NITEM : 1];  // eb: the parked tile's addend values, requested when the tile was parked
+  uint32_t eoff;
+  auto item_off = [&](int j, uint32_t row0, uint32_t yok) -> uint32_t {
+    const int mt = j / RW, y = j % RW;
+    const int co = (chunk * MT + mt) * 16 + 4 * g;
+#if SYN_ABL & 32
+    yok = 0;
+#endif
+    return (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;
+  };
+  auto addend_issue = [&](uint32_t row0, uint32_t yok) {
+    if constexpr (EPI >= 2) {
+#pragma unroll
+      for (int j = 0; j < NITEM; ++j)
+        eb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)item_off(j, row0, yok), 0, 0));
+    }
+  };
+  auto epi0 = [&](int j, uint32_t row0, uint32_t yok) { eoff = item_off(j, row0, yok); };
+  auto epi1 = [&](int j, const f32x4& src) {
+    const f32x4 bj = *reinterpret_cast<const f32x4*>(lbias + (j / RW) * 16 + 4 * g);
+    f32x4 v = src;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += bj[i];
+    if constexpr (EPI == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] *= elu_dy(eb[EPI >= 2 ? j : 0][i]);
+    }
+    if constexpr (EPI == 3 || EPI == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += eb[EPI >= 2 ? j : 0][i];
+    }
+    if constexpr (EPI == 1 || EPI == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
+    }
+    ev = v;
+  };
+  auto epi2 = [&](int j) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), rout, (int)eoff, 0, 0);
+    if constexpr (ST) {
+      const int mt = j / RW;
+      const float w = eoff != OOB ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float r = w * ev[i];
+        s1[mt][i] += r;
+        s2[mt][i] += r * r;
+      }
+    }
+  };
+  auto tile_rows = [&](int t, uint32_t& row0, uint32_t& yok) {
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    const int gz = z0 + zw, gx = x0 + xv, gy = y0 + RW * yh;
+    const bool zx_ok = gz < D0 && gx < D2;
+    row0 = (uint32_t)((gz * D1 + gy) * D2 + gx) * (uint32_t)(Cout * 4);
+    yok = 0;
+#pragma unroll
+    for (int y = 0; y < RW; ++y) yok |= (zx_ok && (gy + y) < D1) ? (1u << y) : 0u;
+  };
+
+  u32x4 wa[2][3][MT], xb[2][3][RW];
+  int buf = 0;
+  if (walk.pos < walk.end) {  // prologue: image and weights of the first chunk, the second chunk's halo on its way
+    halo_issue(walk.pos, 0);
+    w_issue(0);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) hst[i] = hnx[i];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      conv_a(i);
+      conv_b(i);
+      conv_c(i, lds);
+    }
+    w_store(wlds);
+    wfirst = false;
+    const int t1 = ncc > 1 ? walk.pos : walk.pos + walk.stride, c1 = ncc > 1 ? 1 : 0;
+    halo_issue(t1, c1);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) hst[i] = hnx[i];
+    const bool last1 = c1 + 1 == ncc;
+    halo_issue(last1 ? t1 + walk.stride : t1, last1 ? 0 : c1 + 1);
+  }
+  // one K chunk of tile t; WITH_EPI: the parked tile's epilogue rides along
+  auto body = [&](int t, int cc, auto WITH_EPI) {
+    constexpr bool WE = decltype(WITH_EPI)::value;
+    __syncthreads();  // image `buf` and this chunk's weights are complete; nobody reads the other image any more
+    const bool last_cc = cc + 1 == ncc;
+    const int t1 = last_cc ? t + walk.stride : t, c1 = last_cc ? 0 : cc + 1;        // the next chunk ...
+    const bool last1 = c1 + 1 == ncc;
+    const int t2 = last1 ? t1 + walk.stride : t1, c2 = last1 ? 0 : c1 + 1;          // ... the one after it ...
+    const bool last2 = c2 + 1 == ncc;
+    const int t3 = last2 ? t2 + walk.stride : t2, c3 = last2 ? 0 : c2 + 1;          // ... and the third
+    w_issue(c1);
+    const unsigned char* img = lds + buf * BUF + lbase;
+    unsigned char* nimg = lds + (buf ^ 1) * BUF;
+    const unsigned char* wl = wlds + (WDB ? buf * C::WBYTES : 0) + lane * 16;
+    auto frags = [&](auto SS, auto PP) {  // piece PP of the operands of step SS -> register set SS & 1
+      constexpr int s = decltype(SS)::value, q = decltype(PP)::value;
+#if SYN_ABL & 16
+      if (s > 1) return;
+#endif
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        wa[s & 1][q][mt] = *reinterpret_cast<const u32x4*>(wl + ((q * NSTEP + s) * MT + mt) * 1024);
+#pragma unroll
+      for (int y = 0; y < RW; ++y) xb[s & 1][q][y] = *reinterpret_cast<const u32x4*>(img + q * PLANE + koff[s] + y * (HX * 16));
+    };
+    auto mma = [&](auto SS, auto QA, auto QB) {
+      constexpr int s = decltype(SS)::value, qa = decltype(QA)::value, qb = decltype(QB)::value;
+#pragma unroll
+      for (int y = 0; y < RW; ++y)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#if SYN_ABL & 64
+          acc[y][mt][0] += __uint_as_float(wa[s & 1][qa][mt][0] ^ xb[s & 1][qb][y][0]);
+#else
+          acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[s & 1][qa][mt]),
+                                                               __builtin_bit_cast(bf16x8, xb[s & 1][qb][y]), acc[y][mt], 0, 0, 0);
+#endif
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    frags(I0{}, I2{});
+    frags(I0{}, I1{});
+    frags(I0{}, I0{});
+    sfor<0, NSTEP>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      constexpr bool last = s + 1 == NSTEP;
+      using SN = std::integral_constant<int, last ? 0 : s + 1>;
+      constexpr int ci = s - (NSTEP - NL);                      // staging piece converted in this step (the last NL steps)
+      constexpr bool cv = ci >= 0;
+      constexpr bool ep = WE && s < NITEM;                      // epilogue item s of the parked tile
+      __builtin_amdgcn_sched_barrier(0);
+      mma(S, I0{}, I2{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!last) frags(SN{}, I2{});
+      if constexpr (ep) epi0(s, prow0, pyok);
+      if constexpr (cv) conv_a(ci);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(S, I0{}, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ep) epi1(s, pend[s % RW][s / RW]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(S, I0{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!last) frags(SN{}, I1{});
+      if constexpr (cv) conv_b(ci);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(S, I1{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ep) epi2(s);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(S, I1{}, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!last) frags(SN{}, I0{});
+      if constexpr (cv) conv_c(ci, nimg);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(S, I2{}, I0{});
+    });
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) hst[i] = hnx[i];  // (t2, c2), requested a chunk ago
+    halo_issue(t3, c3);
+    if constexpr (!WDB) __syncthreads();  // single weight buffer: everyone has read its fragments
+    w_store(wlds + (WDB ? (buf ^ 1) * C::WBYTES : 0));
+    buf ^= 1;
+  };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int y = 0; y < RW; ++y)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  // the first tile's rider works on an empty parked tile (pend = 0, every row invalid: nothing is stored or counted)
+#pragma unroll
+  for (int y = 0; y < RW; ++y)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) pend[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (walk.pos < walk.end) {
+    for (int t = walk.pos; t < walk.end; t += walk.stride) {
+      zero_acc();
+      body(t, 0, std::true_type{});
+      for (int cc = 1; cc < ncc; ++cc) body(t, cc, std::false_type{});
+#pragma unroll
+      for (int y = 0; y < RW; ++y)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) pend[y][mt] = acc[y][mt];
+      tile_rows(t, prow0, pyok);
+      addend_issue(prow0, pyok);
+    }
+#pragma unroll
+    for (int j = 0; j < NITEM; ++j) {
+      epi0(j, prow0, pyok);
+      epi1(j, pend[j % RW][j / RW]);
+      epi2(j);
+    }
+  }
+  if constexpr (ST) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);  // [wave 8][2][MT*16]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x1 = s1[mt][i], x2 = s2[mt][i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          x1 += __shfl_xor(x1, o, 64);
+          x2 += __shfl_xor(x2, o, 64);
+        }
+        if (m == 0) {
+          red[(wave * 2 + 0) * (MT * 16) + mt * 16 + 4 * g + i] = x1;
+          red[(wave * 2 + 1) * (MT * 16) + mt * 16 + 4 * g + i] = x2;
+        }
+      }
+    __syncthreads();
+    float* dst = a.stats_partial + (int64_t)blockIdx.x * (2 * Cout);
+    for (int e = tid; e < MT * 16; e += NTHR) {
+      const int c = chunk * MT * 16 + e;
+      if (c < Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          t1 += red[(w * 2 + 0) * (MT * 16) + e];
+          t2 += red[(w * 2 + 1) * (MT * 16) + e];
+        }
+        dst[c] = t1;
+        dst[Cout + c] = t2;
       }
     }
   }
@@ -1098,7 +1501,7 @@ int launch_split_fwd_np(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t 
 
 template <int MT, bool ST, int EPI>
 int launch_split_fwd2_e(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
-  constexpr bool DEFER = MT <= 2;
+  constexpr bool DEFER = false;
   const size_t smem = 2 * BUF2 + MT * 16 * 4;
   auto kern = conv3d_split_fwd2_kernel<MT, ST, EPI, DEFER>;
   static bool attr_done = false;
@@ -1126,9 +1529,48 @@ int launch_split_fwd2(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st
   }
 }
 
+// which forward kernel (measured, profiles/r04_split_fwd_variants.txt): the 4-wave kernel with two workgroups per CU, except
+// where the layer has fewer than two rounds of its 512 workgroup slots AND several co-chunks (40^3, 96 output channels: 600
+// units): there the 8-wave kernel (one workgroup per CU, weights through LDS) quantises better (-10 %)
+inline bool split_uses_fwd3(int ntiles, int nchunks) {
+  if (g_variant >= 2) return true;
+  return g_variant == 1 && nchunks >= 2 && (int64_t)ntiles * nchunks < 1024;
+}
+
+template <int MT, bool ST, int EPI>
+int launch_split_fwd3_e(const SplitFwdArgs& a, int nchunks, hipStream_t st) {
+  const int gx = split_upfwd_grid_x(a.ntiles, nchunks);  // one 512-thread workgroup per CU
+  const size_t smem = F3Cfg<MT>::SMEM;
+  auto kern = conv3d_split_fwd3_kernel<MT, ST, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(512), smem, st, a);
+  return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+}
+
+template <int MT, bool ST>
+int launch_split_fwd3(const SplitFwdArgs& a, int nchunks, hipStream_t st) {
+  const int epi = a.act + ((a.addend && a.act < 2) ? 3 : 0);
+  if constexpr (ST) {
+    return epi == 1 ? launch_split_fwd3_e<MT, true, 1>(a, nchunks, st) : launch_split_fwd3_e<MT, true, 0>(a, nchunks, st);
+  } else {
+    switch (epi) {
+      case 0: return launch_split_fwd3_e<MT, false, 0>(a, nchunks, st);
+      case 1: return launch_split_fwd3_e<MT, false, 1>(a, nchunks, st);
+      case 2: return launch_split_fwd3_e<MT, false, 2>(a, nchunks, st);
+      case 3: return launch_split_fwd3_e<MT, false, 3>(a, nchunks, st);
+      default: return launch_split_fwd3_e<MT, false, 4>(a, nchunks, st);
+    }
+  }
+}
+
 template <int MT, bool ST, int UPM = 0>
 int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
   if constexpr (UPM == 0) {
+    if (g_products == 6 && split_uses_fwd3(a.ntiles, nchunks)) return launch_split_fwd3<MT, ST>(a, nchunks, st);
     if (g_products == 6 && g_variant >= 1) return launch_split_fwd2<MT, ST>(a, gx, nchunks, st);
   }
   return g_products == 9 ? launch_split_fwd_np<MT, ST, UPM, 9>(a, gx, nchunks, st) : launch_split_fwd_np<MT, ST, UPM, 6>(a, gx, nchunks, st);
@@ -1486,7 +1928,8 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
     rc = mt == 1 ? launch_split_fwd<1, true>(a, gx, nchunks, st)
                  : (mt == 2 ? launch_split_fwd<2, true>(a, gx, nchunks, st) : launch_split_fwd<3, true>(a, gx, nchunks, st));
     if (rc != SYNTHSR_OK) return rc;
-    return synthsr_bn_stats_from_partials(partial, gx, vox, Cout, stats, (synthsr_stream_t)st);
+    const int gcols = (g_products == 6 && split_uses_fwd3(a.ntiles, nchunks)) ? split_upfwd_grid_x(a.ntiles, nchunks) : gx;  // workgroup columns that wrote partials
+    return synthsr_bn_stats_from_partials(partial, gcols, vox, Cout, stats, (synthsr_stream_t)st);
   }
   if (upm == 2)
     return mt == 1 ? launch_split_fwd<1, false, 2>(a, gx, nchunks, st)
