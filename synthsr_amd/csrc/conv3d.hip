@@ -2860,6 +2860,7 @@ static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
 static int g_ks_target = 1024;  // option 5: workgroup target of the split-K heuristic
 static int g_brick = 1;  // option 6: brick tiles (4x4 voxels per MFMA row block) on the small deep levels
 static int g_p4 = 1;  // option 4: 4x4x1-MFMA kernel for the Cout = 24 layers (no padding to 32 columns)
+static int g_split_min_wgs = 200;  // option 9: smallest layer (4x4x16 tiles x co-chunks) that takes the split kernels (200: the 20^3 convs with 192 output channels, measured -25 %)
 static int g_split = 1;  // synthsr_set_conv_arithmetic: fp32 convs through 3 x bf16 operand pieces on the bf16 matrix cores
                          // (conv_split.hip) where the layer has enough tiles; 0 = fp32 MFMA kernels everywhere
 extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int cin_total,
@@ -2902,7 +2903,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
     const int64_t wgs = (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) * nchunks;
     // (kind 0 = data gradient of a folded decoder conv: s is the low-resolution grid, the input lives on the 2x grid)
     // (kind 2 = their forward pass: the OUTPUT lives on the 2x grid, one co-chunk of <= 48 channels)
-    if (wgs >= 256 && (kind == 0 ? 8 : 1) * vox * Cin * 4 < (1ll << 31) && (kind == 2 ? 8 : 1) * vox * Cout * 4 < (1ll << 31) &&
+    if (wgs >= g_split_min_wgs && (kind == 0 ? 8 : 1) * vox * Cin * 4 < (1ll << 31) && (kind == 2 ? 8 : 1) * vox * Cout * 4 < (1ll << 31) &&
         (kind != 2 || nchunks == 1)) {
       p.split = plain ? 1 : (kind == 0 ? 2 : 3);
       p.ck = 8;
@@ -3964,6 +3965,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 8) {
     syn_split_set_variant(value);
+    return SYNTHSR_OK;
+  }
+  if (option == 9) {
+    g_split_min_wgs = value > 0 ? value : 200;
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;

@@ -31,12 +31,15 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--variants', default='0,1')
+    ap.add_argument('--min-wgs', type=int, default=0, help='option 9 per variant: v >= 100 means variant v - 100 with this threshold')
+    ap.add_argument('--no-wgrad', action='store_true')
     a = ap.parse_args()
     lib = _lib.load()
     variants = [int(v) for v in a.variants.split(',')]
     torch.manual_seed(0)
     print('%-16s %-8s' % ('layer', 'kernel') + ' '.join('v%d ms ' % v for v in variants) + '  max |diff| / rms')
-    for D, ci, co in [(160, 24, 24), (80, 24, 48), (80, 48, 48), (80, 48, 24), (40, 48, 96), (40, 96, 96), (40, 96, 48)]:
+    for D, ci, co in [(160, 24, 24), (80, 24, 48), (80, 48, 48), (80, 48, 24), (40, 48, 96), (40, 96, 96), (40, 96, 48),
+                      (20, 96, 192), (20, 192, 192), (20, 192, 96), (10, 192, 384), (10, 384, 384)]:
         if a.only and '%d_%d_%d' % (D, ci, co) not in a.only.split(','):
             continue
         shape = (D, D, D)
@@ -46,7 +49,8 @@ def main():
         dy = torch.randn(D, D, D, co, device='cuda')
         res, tm = {}, {}
         for v in variants:
-            lib.synthsr_conv3d_set_option(8, v)
+            lib.synthsr_conv3d_set_option(8, v % 100)
+            lib.synthsr_conv3d_set_option(9, a.min_wgs if v >= 100 and a.min_wgs else 0)
             wp, wpd = ops.pack_conv_weights(w, shape, 0), ops.pack_conv_weights(w, shape, 1)
             y = torch.empty(D, D, D, co, device='cuda')
             ys = torch.empty(D, D, D, co, device='cuda')
@@ -64,6 +68,7 @@ def main():
             f_wg()
             res[v] = (y.clone(), ys.clone(), dx.clone(), dw.clone(), stats.clone())
         lib.synthsr_conv3d_set_option(8, 1)
+        lib.synthsr_conv3d_set_option(9, 0)
         for k, nm in enumerate(('fwd', 'fwd+st', 'dgrad', 'wgrad')):
             d = ''
             if len(variants) > 1:
