@@ -207,6 +207,39 @@ CONV_ARITH_NOTE = {
     'fp32_mfma': 'every convolution on the fp32 matrix instructions (v_mfma_f32_4x4x1 / 16x16x4)'}
 
 
+def self_launch(n):
+    """re-executes this command line as n ranks of one node under torch.distributed.run (127.0.0.1, a free port); the ranks'
+    output is passed through, the exit code is theirs"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC (RCCL between processes on this driver)
+    return subprocess.call(cmd, env=env)
+
+
+def rendezvous_only(args, world, rank):
+    """--rendezvous-only: the ranks meet over gloo (CPU), count themselves with an all-reduce, rank 0 prints the record"""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('gloo')
+    seen = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({'metric': 'rendezvous only', 'n_gpus': args.gpus, 'n_ranks_seen': int(seen.item()),
+                          'world_size': dist.get_world_size() if world > 1 else 1, 'backend': 'gloo' if world > 1 else None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == '--cpu-worker':
         return cpu_worker(int(sys.argv[2]), int(sys.argv[3]))
@@ -232,7 +265,17 @@ def main():
                     help='skip the short second measurement under the other conv arithmetic (N = 1 only, 20 steps)')
     ap.add_argument('--force-allreduce', action='store_true',
                     help='initialise RCCL and run the bucketed gradient all-reduce even at world size 1 (path test)')
+    ap.add_argument('--rendezvous-only', action='store_true',
+                    help='launch / rendezvous path only: N ranks meet, all-reduce a counter, rank 0 prints n_gpus and '
+                         'n_ranks_seen (no device work: what the CPU test of the self-launch runs)')
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` launched plainly: start the N ranks ourselves (one process per GPU, the way the driver's
+        # torch.distributed.run command line does) instead of silently measuring one GPU under an N-GPU command
+        return self_launch(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -246,12 +289,25 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node N for --gpus N'
-    torch.cuda.set_device(local)
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d runs under WORLD_SIZE=%d: launch it plainly (it starts its own ranks) or with '
+                         'torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
+    if args.rendezvous_only:
+        return rendezvous_only(args, world, rank)
+    # one GPU per rank over RCCL; a box with fewer GPUs than ranks (the one-GPU test box) shares its devices and lets gloo
+    # carry the collectives (two processes on one device cannot form an RCCL communicator) -- recorded as `backend`
+    ndev = torch.cuda.device_count()
+    backend = 'nccl' if ndev >= world else 'gloo'
+    torch.cuda.set_device(local % max(1, ndev))
     if world > 1 or args.force_allreduce:
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('rendezvous gave %d ranks for --gpus %d' % (dist.get_world_size(), args.gpus))
 
     ops.set_conv_arithmetic(args.conv_arith)
     S = args.size
@@ -472,6 +528,7 @@ def main():
                'other_conv_arithmetic': other,
                'roofline': roofline, 'roofline_generator': roofline_generator, 'final_loss': round(final_loss, 6),
                'n_ranks_seen': dist.get_world_size() if dist.is_initialized() else 1,
+               'backend': (backend if dist.is_initialized() else None),
                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if dist.is_initialized() else None,
                'top_kernels': [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]}
         if per_rank is not None:
@@ -492,4 +549,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

@@ -73,13 +73,15 @@ typedef struct {
   int use_philox;       /* 0: noise buffer, 1: in-kernel Philox4x32-10 */
   uint32_t philox_key[2];
   uint64_t philox_offset;
+  int label_bytes;    /* element size of `labels`: 0 or 4 = int32 (the reference's label maps), 1 = uint8, 2 = int16 (a label
+                       * pool kept on the device in the narrowest type its values fit: model_inputs.py:104-107 loads them as int) */
 } synthsr_deform_params;
 
 /* Fuses RandomSpatialDeformation's final SpatialTransformer(nearest) (layers.py:200-203;
  * combine_non_linear_and_aff_to_shift utils.py:222-286; full-res Resize of the field layers.py:196),
  * RandomCrop, RandomFlip (+LUT swap), SampleConditionalGMM (layers.py:480-498), BiasFieldCorruption and
  * the clip + min/max reduction of IntensityAugmentation (layers.py:1214-1231).
- *   labels   int32 [in_shape]                 field_half float [half_shape,3] (may be NULL)
+ *   labels   int32 [in_shape] (uint8 / int16 with p->label_bytes = 1 / 2)   field_half float [half_shape,3] (may be NULL)
  *   gmm_lut  float [2][n_channels][lut_size]  (means then stds)
  *   swap_lut int32 [swap_lut_size] or NULL    noise float [out_shape, n_channels] or NULL (philox)
  *   bias_small float, concatenated small grids of the channels with bias_on (already scaled by std)

@@ -19,8 +19,10 @@ extern "C" {
 
 /* option 0 = persistent forward kernel on the large levels (default 1),
  * 1 = diagnostic ablation mask, 2 = force MT, 3 = EXPERIMENTAL MFMA+VALU co-execution for Cout % 16 == 8 (default 0),
- * 4 = 4x4x1-MFMA kernels, 5 = split-K workgroup target, 6 = brick tiles, 7 = parity split of small up-conv data gradients.  Options
- * that change the launch geometry must be set before weights are packed. */
+ * 4 = 4x4x1-MFMA kernels, 5 = split-K workgroup target, 6 = brick tiles, 7 = parity split of small up-conv data gradients,
+ * 8 = generation of the split forward kernel (0 round 3; 1 default: conversion inside the K loop, LDS-weights kernel where it
+ * quantises better; 2 LDS-weights kernel everywhere), 9 = smallest layer (4x4x16 tiles x co-chunks) planned on the split
+ * kernels (default 200).  Options that change the launch geometry must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
 
 /* Arithmetic of the fp32 3x3x3 convolutions (process-wide; set it BEFORE weights are packed: a packed weight set is only valid
@@ -40,6 +42,10 @@ int synthsr_conv3d_set_option(int option, int value);
  * The reference computes in fp32 on TensorFlow (SynthSR/training.py:330-341); both modes are fp32 computations of it. */
 int synthsr_set_conv_arithmetic(int mode);
 int synthsr_conv_arithmetic(void);
+/* 1 / 0: whether the weight gradient of a plain 3x3x3 conv of this shape runs on the split kernels under the current
+ * arithmetic (the dispatcher's own condition; forward / data-gradient plans: synthsr_conv3d_plan) -- what benchmarks price a
+ * layer against.  Negative: SYNTHSR_EINVAL. */
+int synthsr_conv3d_wgrad_runs_split(const int shape[3], int Cin, int Cout);
 
 /* Diagnostic (host only, no device work): the launch width and tile range of one workgroup of the split kernels -- the same
  * function the kernels evaluate (csrc/conv_split.hip: tile_walk_of).  kernel 0 = forward / data gradient (ny = output-channel

@@ -24,7 +24,7 @@ class DeformParams(Structure):
                 ('has_field', c_int), ('has_affine', c_int), ('half_shape', c_int * 3), ('aff', c_float * 12),
                 ('n_channels', c_int), ('lut_size', c_int), ('swap_lut_size', c_int), ('bias_on', c_int * 4),
                 ('bias_shape', (c_int * 3) * 4), ('clip_hi', c_float), ('use_philox', c_int),
-                ('philox_key', c_uint32 * 2), ('philox_offset', c_uint64)]
+                ('philox_key', c_uint32 * 2), ('philox_offset', c_uint64), ('label_bytes', c_int)]
 
 
 _P = c_void_p
@@ -56,6 +56,7 @@ SIGNATURES = {
     'synthsr_set_conv_arithmetic': (c_int, [c_int]),
     'synthsr_split_tile_schedule': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
     'synthsr_conv_arithmetic': (c_int, []),
+    'synthsr_conv3d_wgrad_runs_split': (c_int, [POINTER(c_int), c_int, c_int]),
     'synthsr_set_deterministic': (c_int, [c_int]),
     'synthsr_deterministic_status': (c_int, []),
     'synthsr_conv3d_plan': (c_int, [POINTER(c_int), c_int, c_int, c_int, POINTER(c_int64)]),

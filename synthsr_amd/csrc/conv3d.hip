@@ -2871,6 +2871,14 @@ extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias
                              const int s[3], int Cin, int Cout, int mt, int nchunks, int act, float* stats, float* partial,
                              int upm, hipStream_t st);
 
+// does the weight gradient of a plain 3x3x3 conv take the split kernel (conv_split.hip: syn_split_wgrad)?  One place: the
+// dispatcher and the query synthsr_conv3d_wgrad_runs_split (what the benchmarks price a layer against) both ask here
+inline bool wgrad_takes_split(const int s[3], int Cin, int Cout) {
+  const int64_t vox = (int64_t)s[0] * s[1] * s[2];
+  return g_split && (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) >= 256 && (Cin % 8) == 0 && (Cout % 24) == 0 &&
+         vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31);
+}
+
 struct FwdPlan {
   int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2, brick, wn, wm, split;
   // NT = 0 selects the 4x4x1 weight layout in pack_value, NT = -Cin the first-layer layout, NT = -100 - MT the split layout,
@@ -3642,7 +3650,7 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
     if (Cin <= 2 && Cout == 24 && g_p4 && (int64_t)shape[0] * shape[1] * shape[2] * Cout * 4 < (1ll << 31))
       return launch_wgrad_c2(in, dout, dw, ext.dbias, shape, Cin, st, ext);
     // fp32 through three bf16 pieces per operand (conv_split.hip): layers with enough 4x4x16 tiles
-    if (g_split && (int64_t)cdiv(shape[0], 4) * cdiv(shape[1], 4) * cdiv(shape[2], 16) >= 256) {
+    if (wgrad_takes_split(shape, Cin, Cout)) {
       const int rc = syn_split_wgrad(in, dout, dw, ext.dbias, shape, ext.cin_total, ext.ci_off, Cin, Cout, st);
       if (rc != SYNTHSR_EINVAL) return rc;  // EINVAL: channel counts the split kernel does not cover
     }
@@ -3733,6 +3741,11 @@ int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int6
   out[6] = pl.nv;
   out[7] = pl.count();
   return SYNTHSR_OK;
+}
+
+int synthsr_conv3d_wgrad_runs_split(const int shape[3], int Cin, int Cout) {
+  if (!shape || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
+  return (Cin > 2 || Cout != 24) && wgrad_takes_split(shape, Cin, Cout) ? 1 : 0;
 }
 
 int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* jobs_dev, int njobs,

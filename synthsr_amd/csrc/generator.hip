@@ -284,7 +284,10 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
     r0 = min(max(r0, 0), p.in_shape[0] - 1);
     r1 = min(max(r1, 0), p.in_shape[1] - 1);
     r2 = min(max(r2, 0), p.in_shape[2] - 1);
-    int lab = labels[((int64_t)r0 * p.in_shape[1] + r1) * p.in_shape[2] + r2];
+    const int64_t li = ((int64_t)r0 * p.in_shape[1] + r1) * p.in_shape[2] + r2;
+    // the label volume as uint8 / int16 when its values fit (the resident training pool: 1-2 instead of 4 bytes per gathered voxel)
+    int lab = p.label_bytes == 1 ? (int)reinterpret_cast<const uint8_t*>(labels)[li]
+                                 : (p.label_bytes == 2 ? (int)reinterpret_cast<const int16_t*>(labels)[li] : labels[li]);
     if (p.flip && swap_lut != nullptr && lab >= 0 && lab < p.swap_lut_size) lab = swap_lut[lab];
     if (seg_out) seg_out[o] = lab;
     if (real_in) {  // the same transform with inter_method 'linear' (edge-clamped trilinear, ext/neuron/utils.py:67-110)
@@ -622,6 +625,7 @@ int synthsr_deform_gmm_real(const int32_t* labels, const float* field_half, cons
   if (real_in && !real_out) return SYNTHSR_EINVAL;
   if (bad_shape(p->in_shape) || bad_shape(p->out_shape)) return SYNTHSR_EINVAL;
   if (p->n_channels < 1 || p->n_channels > 4 || p->lut_size < 1) return SYNTHSR_EINVAL;
+  if (p->label_bytes != 0 && p->label_bytes != 1 && p->label_bytes != 2 && p->label_bytes != 4) return SYNTHSR_EINVAL;
   if (p->has_field && (!field_half || bad_shape(p->half_shape))) return SYNTHSR_EINVAL;
   if (!p->use_philox && !noise) return SYNTHSR_EINVAL;
   if (p->swap_lut_size > 0 && !swap_lut) return SYNTHSR_EINVAL;

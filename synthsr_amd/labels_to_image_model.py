@@ -315,10 +315,12 @@ class LabelsToImageModel:
         d = self.sample_draws() if draws is None else draws
         C = self.n_channels
         # ---- labels on device (PadAroundCentre, ext/lab2im/layers.py:1754, is done on the host copy)
+        label_bytes = 4
         if labels_on_device:
             lab = labels.reshape(-1)
-            assert lab.numel() == self.d_labels.numel() and lab.dtype == torch.int32
+            assert lab.numel() == self.d_labels.numel() and lab.dtype in (torch.int32, torch.int16, torch.uint8)
             d_labels = lab
+            label_bytes = lab.element_size()  # a resident pool keeps its maps in the narrowest type that holds their values
         else:
             lab = np.asarray(labels)
             if self.padding_margin is not None:
@@ -341,6 +343,7 @@ class LabelsToImageModel:
         # ---- host-side O(1) parameters
         sm = self._Small(self)
         p = _lib.DeformParams()
+        p.label_bytes = label_bytes
         p.in_shape[:] = self.labels_shape
         p.out_shape[:] = self.crop_shape
         crop = [0, 0, 0]

@@ -68,14 +68,34 @@ def build_model_inputs(path_label_maps, n_labels, prior_means, prior_stds, prior
             return np.empty((1, n_labels, 0)), np.empty((1, n_labels, 0))
         return np.stack(cols_m, -1)[None], np.stack(cols_s, -1)[None]
 
-    while True:
-        picks = source.randint(len(maps), size=batchsize) if legacy else source.integers(len(maps), size=batchsize)
-        batch = [[], [], []] + ([[]] if scans is not None else [])
-        for i in (int(p) for p in picks):
-            batch[0].append(maps[i][None, ..., None])
-            if scans is not None:
-                batch[3].append(np.asarray(scans[i])[None, ..., None])
-            means, stds = class_stats()
-            batch[1].append(means)
-            batch[2].append(stds)
-        yield [np.concatenate(items, 0) if batchsize > 1 else items[0] for items in batch]
+    def batches(state):
+        while True:
+            picks = source.randint(len(maps), size=batchsize) if legacy else source.integers(len(maps), size=batchsize)
+            batch = [[], [], []] + ([[]] if scans is not None else [])
+            for i in (int(p) for p in picks):
+                batch[0].append(maps[i][None, ..., None])
+                if scans is not None:
+                    batch[3].append(np.asarray(scans[i])[None, ..., None])
+                means, stds = class_stats()
+                batch[1].append(means)
+                batch[2].append(stds)
+            state.last_picks = [int(p) for p in picks]
+            yield [np.concatenate(items, 0) if batchsize > 1 else items[0] for items in batch]
+
+    return ModelInputs(batches, len(maps), scans is not None)
+
+
+class ModelInputs:
+    """the generator object build_model_inputs returns: the reference's protocol (`next()` -> [labels, means, stds(, image)],
+    model_inputs.py:86-139) plus `last_picks`, the indices of the label maps of the batch just produced -- what lets
+    training() keep the maps it has already used on the device and pick from that pool instead of copying 16 MB per step"""
+
+    def __init__(self, batches, n_maps, has_images):
+        self.last_picks, self.n_maps, self.has_images = None, n_maps, has_images
+        self._it = batches(self)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._it)

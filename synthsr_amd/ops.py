@@ -39,14 +39,15 @@ def conv_runs_split(kind, shape, cin, cout):
     """whether a conv launch of this kind ('conv3d_fwd' | 'conv3d_dgrad' | 'conv3d_wgrad' | 'conv3d_up_fwd' | 'conv3d_up_dgrad',
     the names of the profile records) runs on the split kernels under the CURRENT arithmetic (mirrors the dispatcher: csrc/conv3d.hip plan_fwd /
     dispatch_wgrad); used by the benchmarks to price a kernel against the right peak"""
-    import ctypes
     kinds = ('conv3d_fwd', 'conv3d_dgrad', 'conv3d_wgrad', 'conv3d_up_fwd', 'conv3d_up_dgrad')
     if conv_arithmetic() == 'fp32_mfma' or kind not in kinds:   # (conv3d_up_wgrad: fp32 MFMA in every mode)
         return False
     d0, d1, d2 = [int(v) for v in shape[:3]]
-    if kind == 'conv3d_wgrad':
-        tiles = -(-d0 // 4) * -(-d1 // 4) * -(-d2 // 16)
-        return tiles >= 256 and cin % 8 == 0 and cout % 24 == 0
+    if kind == 'conv3d_wgrad':   # the dispatcher's own condition (csrc/conv3d.hip: wgrad_takes_split)
+        rc = int(_L().synthsr_conv3d_wgrad_runs_split(_lib.i3((d0, d1, d2)), int(cin), int(cout)))
+        if rc < 0:
+            _lib.check(rc, 'conv3d_wgrad_runs_split')
+        return rc == 1
     # folded decoder convs are recorded with (low-res shape, Cl, Cout): forward = plan kind 2 on (Cl -> Cout), data gradient =
     # plan kind 0 on (Cout -> Cl)
     plan_kind, ce, co = {'conv3d_up_fwd': (2, cin, cout), 'conv3d_up_dgrad': (0, cout, cin)}.get(kind, (1, cin, cout))

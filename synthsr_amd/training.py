@@ -92,6 +92,7 @@ class Trainer:
         self.residual = work_with_residual_channel
         self.reducer = GradBucketReducer(net.grads, bucket_elems, force=force_allreduce) if distributed else None
         self.resident_labels = None
+        self.auto_pool = True  # step() without explicit inputs: label maps drawn by the host sampler stay on the device
         self.fuse_head_bwd = True  # the head kernel also accumulates the sums of its backward pass (UNet3D.loss)
         self.comm_events = None  # a list: (start, end) HIP events around reducer.finish() of every step (bench.py --gpus N)
 
@@ -125,17 +126,50 @@ class Trainer:
                 self._seg_b.chunk(B, 0)[b].copy_(seg)
         return self._img_b, self._tgt_b, (self._seg_b if self.seg is not None else None)
 
-    def make_labels_resident(self, label_maps):
-        """upload a pool of int32 label maps once; steps then pick from the pool on the device"""
+    @staticmethod
+    def _narrowest_labels(m):
+        """a label map in the narrowest integer type that holds its values (uint8 < 256, int16 < 32768, else int32): the
+        generator gathers 1-2 instead of 4 bytes per voxel (csrc/generator.hip: synthsr_deform_params.label_bytes)"""
+        m = np.asarray(m)
+        lo, hi = (int(m.min()), int(m.max())) if m.size else (0, 0)
+        dt = np.uint8 if (lo >= 0 and hi < 256) else (np.int16 if (lo >= -32768 and hi < 32768) else np.int32)
+        return np.ascontiguousarray(m, dtype=dt)
+
+    def _to_device_labels(self, m):
         import torch
-        self.resident_labels = [torch.from_numpy(np.ascontiguousarray(m, dtype=np.int32)).to(self.gen.device)
-                                for m in label_maps]
+        gen = self.gen
+        m = np.asarray(m).reshape(gen.input_labels_shape)
+        if gen.padding_margin is not None:  # PadAroundCentre (ext/lab2im/layers.py:1754) once, on the host copy
+            m = np.pad(m, [(p, p) for p in gen.padding_margin])
+        return torch.from_numpy(self._narrowest_labels(m)).to(gen.device)
+
+    def make_labels_resident(self, label_maps):
+        """upload a pool of label maps once (narrowest integer type); steps then pick from the pool on the device"""
+        self.resident_labels = [self._to_device_labels(m) for m in label_maps]
+
+    # training() keeps every label map it has used on the device (SynthSR/model_inputs.py:86-107 re-reads the file each step;
+    # a 160^3 map is 4 MB as uint8): up to this many bytes, beyond that the remaining maps are copied per step as before
+    POOL_BYTES = 64 << 30
+
+    def _pooled_labels(self, index, host_map):
+        pool = self.__dict__.setdefault('_auto_pool', {})
+        t = pool.get(index)
+        if t is None:
+            used = sum(v.numel() * v.element_size() for v in pool.values())
+            t = self._to_device_labels(host_map)
+            if used + t.numel() * t.element_size() > self.POOL_BYTES:
+                return None
+            pool[index] = t
+        return t
 
     def step(self, model_inputs=None, draws=None, label_index=None):
         """one training step; returns the loss as a 1-element device tensor (no host sync)"""
         gen, net = self.gen, self.net
+        picks = None
         if model_inputs is None:
-            model_inputs = next(self.bg.model_inputs_generator)
+            mig = self.bg.model_inputs_generator
+            model_inputs = next(mig)
+            picks = getattr(mig, 'last_picks', None)   # which label maps: they stay on the device once used
         labels, means, stds = model_inputs[:3]
         from . import ops
         B = int(np.asarray(means).shape[0])
@@ -146,9 +180,14 @@ class Trainer:
         else:
             real = np.asarray(model_inputs[3])[0, ..., 0] if getattr(gen, 'use_real_image', False) else None
             with ops.timed('generator', gen.output_shape, gen.n_image_channels, gen.n_target_channels):
+                dev_labels = None
                 if label_index is not None and self.resident_labels is not None and real is None:
-                    image, target, seg = gen.generate(self.resident_labels[label_index], np.asarray(means)[0],
-                                                      np.asarray(stds)[0], draws, labels_on_device=True)
+                    dev_labels = self.resident_labels[label_index]
+                elif picks is not None and real is None and self.auto_pool:
+                    dev_labels = self._pooled_labels(picks[0], np.asarray(labels)[0, ..., 0])
+                if dev_labels is not None:
+                    image, target, seg = gen.generate(dev_labels, np.asarray(means)[0], np.asarray(stds)[0], draws,
+                                                      labels_on_device=True)
                 else:
                     image, target, seg = gen.generate(np.asarray(labels)[0, ..., 0], np.asarray(means)[0],
                                                       np.asarray(stds)[0], draws, real_image=real)

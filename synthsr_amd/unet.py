@@ -48,8 +48,11 @@ class UNet3D:
         self.conv_dropout = float(conv_dropout)
         if not 0.0 <= self.conv_dropout < 1.0:
             raise ValueError('conv_dropout should be in [0, 1)')
-        # the masks of optimizer step t are a function of (dropout seed, t) alone: a run resumed from a checkpoint (which
-        # restores `iterations`) continues the exact mask sequence of an uninterrupted one, on every rank
+        # the masks are a function of (dropout seed, optimizer iteration t, number of training forwards since that step): a run
+        # resumed from a checkpoint (which restores `iterations`) continues the exact mask sequence of an uninterrupted one,
+        # on every rank -- and forwards that share an iteration (the 10-100 critic updates per generator step of the
+        # adversarial schedule, repeated loss() calls) still draw a fresh mask each, as Keras does on every forward
+        self._drop_forwards = 0
         self._drop_gen = torch.Generator(device='cpu')
         self._drop_seed = int(seed) + 0x5eed
         self._drop_next = None      # scales for the next training forward (tests); None: drawn
@@ -412,7 +415,9 @@ class UNet3D:
         if self._drop_next is not None:
             flat = torch.cat([torch.as_tensor(np.asarray(self._drop_next[c['name']], dtype=np.float32)) for c in convs])
         else:  # tf.nn.dropout: keep where uniform >= rate, scale the kept features by 1 / (1 - rate); ONE draw for all layers
-            self._drop_gen.manual_seed((self._drop_seed * 1000003 + self.iterations) & 0x7fffffffffffffff)
+            self._drop_gen.manual_seed((self._drop_seed * 1000003 + self.iterations + 7046029254386353131 * self._drop_forwards)
+                                       & 0x7fffffffffffffff)
+            self._drop_forwards += 1
             flat = (torch.rand(total, generator=self._drop_gen) >= p).float() / (1.0 - p)
         self._drop_host.copy_(flat)
         self._drop_dev.copy_(self._drop_host, non_blocking=True)
@@ -922,6 +927,7 @@ class UNet3D:
         lr_t = lr * (math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
         ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, lr_t, beta1, beta2, eps, grad_scale)
         self.iterations = t
+        self._drop_forwards = 0   # the first forward of an iteration: the mask of (seed, t) alone (resume-exact)
         self.repack()
 
     def update_moving_stats(self):

@@ -141,6 +141,31 @@ def test_dropout_draws_keep_rate_and_determinism():
     assert torch.isfinite(a.predict(x)).all()
 
 
+def test_dropout_masks_differ_between_forwards_of_one_iteration():
+    """two training forwards WITHOUT an optimizer step in between (the critic updates of the adversarial schedule, repeated
+    loss() calls) draw different masks, as Keras does on every forward; the FIRST forward of an iteration is a function of
+    (seed, iteration) alone, so a network that skipped the extra forwards -- or was resumed -- sees the same mask there"""
+    import torch
+    from synthsr_amd.unet import unet
+    kw = dict(nb_features=24, input_shape=[16, 16, 16, 1], nb_levels=3, conv_size=3, nb_labels=1, feat_mult=2,
+              nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=9, conv_dropout=.5)
+    a, b = unet(**kw), unet(**kw)
+    x = torch.rand(16, 16, 16, 1).cuda()
+    t = torch.rand(16 ** 3).cuda()
+    a.loss_l1(x, t)
+    first = {k: v.clone() for k, v in a._drop.items()}
+    a.loss_l1(x, t)
+    second = {k: v.clone() for k, v in a._drop.items()}
+    assert any(not torch.equal(first[k], second[k]) for k in first)
+    b.loss_l1(x, t)
+    assert all(torch.equal(first[k], b._drop[k]) for k in first)       # first forward of iteration 0: same on both
+    a.backward(); a.adam_step()
+    b.backward(); b.adam_step()
+    a.loss_l1(x, t)
+    b.loss_l1(x, t)
+    assert all(torch.equal(a._drop[k], b._drop[k]) for k in first)     # first forward of iteration 1: same again
+
+
 def test_dropout_bf16_step_runs_and_matches_fp32_masks():
     """bf16 network: same mechanism (scaled kernels are re-packed to bf16); loose agreement with the fp32 network"""
     import torch

@@ -233,8 +233,11 @@ def test_conv_arithmetic_switch_and_layer_plans():
     assert ops.conv_runs_split('conv3d_wgrad', big, 24, 24) and ops.conv_runs_split('conv3d_wgrad', (80, 80, 80), 48, 48)
     assert ops.conv_runs_split('conv3d_fwd', (40, 40, 40), 96, 96)
     assert not ops.conv_runs_split('conv3d_fwd', big, 2, 24)              # first layer: 2 input channels
-    assert not ops.conv_runs_split('conv3d_fwd', (20, 20, 20), 192, 192)  # too few tiles: fp32 MFMA kernels
+    assert ops.conv_runs_split('conv3d_fwd', (20, 20, 20), 192, 192)      # round 4: 50 tiles x 4 co-chunks = 200 workgroups
+    assert not ops.conv_runs_split('conv3d_fwd', (20, 20, 20), 192, 96)   # 100 workgroups: fp32 MFMA kernels
+    assert not ops.conv_runs_split('conv3d_fwd', (10, 10, 10), 384, 384)
     assert not ops.conv_runs_split('conv3d_wgrad', (20, 20, 20), 192, 192)
+    assert not ops.conv_runs_split('conv3d_wgrad', big, 2, 24) and not ops.conv_runs_split('conv3d_wgrad', big, 24, 16)
     assert ops.conv_runs_split('conv3d_up_fwd', (80, 80, 80), 48, 24)     # folded decoder conv, up-sampled channels (low-res grid)
     assert ops.conv_runs_split('conv3d_up_dgrad', (80, 80, 80), 48, 24)
     assert not ops.conv_runs_split('conv3d_up_fwd', (20, 20, 20), 192, 96)
@@ -452,3 +455,22 @@ def test_trace_ranges_are_noops_unless_enabled(monkeypatch):
             pass
     assert r.on == bool(ops._roctx)
     monkeypatch.setattr(ops, '_roctx', None)
+
+
+def test_bench_self_launch_rendezvous_cpu():
+    """bench.py --gpus 2 launched plainly re-executes itself as two ranks (torch.distributed.run, 127.0.0.1); the rendezvous-only
+    mode runs that path without device work: both ranks meet (gloo) and are counted.  Under a launcher whose world size differs
+    from --gpus it refuses instead of measuring one GPU under a two-GPU command line (missing 1)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--rendezvous-only'], capture_output=True,
+                       text=True, timeout=600, env=env, cwd=repo)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['world_size'] == 2
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--rendezvous-only'], capture_output=True,
+                       text=True, timeout=600, env=dict(env, WORLD_SIZE='1', RANK='0'), cwd=repo)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stdout + r.stderr)

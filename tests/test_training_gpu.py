@@ -295,6 +295,21 @@ def test_bench_under_torchrun_with_forced_allreduce():
     assert d['roofline']['bound'] == 'mfma' and 0 < d['roofline']['frac'] < 1
 
 
+def test_bench_gpus_2_launched_plainly_starts_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver starts --gpus 1) must start its own two ranks
+    and report them: n_gpus == n_ranks_seen == 2 (RCCL with one GPU per rank when the box has two, gloo on the shared GPU
+    otherwise -- recorded in `backend`); value = the two ranks' volumes over the slower rank's wall time"""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--size', '32',
+           '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['steps'] == 2 and d['value'] > 0
+    assert d['backend'] in ('nccl', 'gloo') and len(d['per_rank']) == 2 and d['config']['global_batch'] == 2
+    assert np.isfinite(d['final_loss'])
+
+
 @pytest.mark.parametrize('case', ['sr', 'synthesis', 'multimodal', 'real'])
 def test_generation_examples_script(tmp_path, case):
     """scripts/tutorials/generate_examples.py (the use cases of the reference's tutorials 1-6) end to end on NIfTI files"""
