@@ -160,7 +160,7 @@ def _unwindows(w, shape):
     return w.reshape(d0 // 2, d1 // 2, d2 // 2, C, 2, 2, 2).permute(0, 4, 1, 5, 2, 6, 3).reshape(d0, d1, d2, C)
 
 
-def align_pool_ties(dev_choices, oracle_inputs, max_ties=8):
+def align_pool_ties(dev_choices, oracle_inputs, max_ties=8, max_ulp=4.0):
     """Max-pooling is discontinuous: when two candidates of a 2x2x2 window are within float32 rounding of each other, WHICH
     one wins depends on the last bits of the BatchNorm statistics, i.e. on the summation order of the implementation -- the
     device and the CPU oracle may legitimately differ there, and the level's gradients then differ by a few 1e-3 of their
@@ -169,7 +169,8 @@ def align_pool_ties(dev_choices, oracle_inputs, max_ties=8):
     be a TIE -- the oracle's value at the device's choice within 4 ulp of the oracle's maximum, an ulp being taken of the larger
     of the two candidates and the tensor's rms (the candidates are BatchNorm outputs (x - mean) / std: their rounding error is
     set by the magnitude of x and mean, i.e. by the tensor's scale, not by how close to zero the difference lands) -- and there may be at most
-    `max_ties`; anything else raises.  Returns (nudges, n_ties): per pooled level None or a tensor (oracle layout) that, added
+    `max_ties`; anything else raises (`max_ulp`: the full-size test widens the 4 ulp to the measured distance between the two
+    implementations' BatchNorm statistics over 4 M voxels).  Returns (nudges, n_ties): per pooled level None or a tensor (oracle layout) that, added
     before the oracle's pooling (pool_nudge=...), makes it break exactly those ties the way the device did."""
     import torch
     eps = torch.finfo(torch.float32).eps
@@ -187,7 +188,7 @@ def align_pool_ties(dev_choices, oracle_inputs, max_ties=8):
         a, b = w[diff, idx_dev[diff]], w[diff, idx_or[diff]]
         ulp = eps * torch.maximum(a.abs(), b.abs()).clamp_min(float(w.pow(2).mean().sqrt()))
         worst = float(((b - a) / ulp).max())
-        assert worst <= 4.0, 'pooled level %d: device and oracle pick different maxima in %d windows whose candidates are up ' \
+        assert worst <= max_ulp, 'pooled level %d: device and oracle pick different maxima in %d windows whose candidates are up ' \
             'to %.1f ulp apart: not a rounding tie' % (l, diff.numel(), worst)
         nud = torch.zeros_like(w)
         nud[diff, idx_dev[diff]] = (b - a) + 8 * ulp

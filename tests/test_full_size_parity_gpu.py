@@ -8,8 +8,8 @@
 The generator runs on the GPU (its own parity is covered in test_generator_gpu.py); its image / target are copied to
 the host and pushed through oracle/unet_ref.py (PyTorch-CPU float32, autograd).  Compared: loss (1e-4 relative), every
 BatchNorm layer's batch mean / variance (5e-4 of range), the prediction (1e-3 of range) and EVERY parameter gradient
-(per-tensor max error relative to the tensor's max-abs; bound 3e-3 for conv kernels / biases, 1e-2 for BatchNorm
-beta / gamma whose gradients are sums of +-cancelling terms over up to 4 M voxels).  This closes "kernel variants
+(per-tensor max error relative to the tensor's max-abs, max-pool rounding ties aligned: 1e-3 against the fp32 oracle;
+at 160^3 also against a FLOAT64 run of the oracle: 4e-4 of range and at most 6x the fp32 oracle's own distance).  This closes "kernel variants
 chosen at the bench shape are only covered by isolated conv cases at other shapes" (VERDICT r01).
 
 Run time on the GPU box (128 host cores): see the measured figures printed by the test (-s); the oracle step
@@ -21,7 +21,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(S, hyperfine):
+def _run(S, hyperfine, f64=False):
     import torch
     from synthsr_amd.brain_generator import BrainGenerator
     from synthsr_amd.unet import unet
@@ -68,12 +68,31 @@ def _run(S, hyperfine):
     # ---- oracle on the identical image / target
     x, tgt = image.cpu().clone(), target.cpu().clone().reshape(S, S, S, 1)
     P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
-    t0 = time.time()
-    stats = {}
-    pr = U.unet_forward(x, P, net.prefix, 5, 2, training=True, collect=stats)
+    # the device's own max-pool choices: where the oracle pools differently the two candidates must be within float32 rounding
+    # of each other (a tie: which one wins is a property of the summation order, not of the algorithm) and the oracle is re-run
+    # breaking those ties the device's way -- the protocol of every whole-network test (tests/conftest.py), here at full size
+    from conftest import _pool_choices, align_pool_ties
+    dev_pool = [(m.cpu(), None) for m, _ in _pool_choices(net)]
     res = None if residual is None else x[..., residual:residual + 1]
-    lr = U.regression_loss(pr, tgt, 'l1', residual=res)
-    lr.backward()
+
+    def oracle_step(Pd, xin, tg, rs):
+        stats_, pin = {}, []
+        pr_ = U.unet_forward(xin, Pd, net.prefix, 5, 2, training=True, collect=stats_, pool_inputs=pin)
+        # a tie here: within 512 ulp = 6e-5 of the tensor's scale (the two implementations' BatchNorm statistics over 4 M voxels
+        # agree to 1e-5, see `bn` below, and every candidate carries that difference)
+        nudges, n_ties = align_pool_ties(dev_pool, pin, max_ties=1000000, max_ulp=512.0)
+        if n_ties:
+            print('%d max-pool rounding tie(s) between device and oracle (%s): oracle re-run with the device\'s choices'
+                  % (n_ties, xin.dtype))
+            stats_ = {}
+            pr_ = U.unet_forward(xin, Pd, net.prefix, 5, 2, training=True, collect=stats_,
+                                 pool_nudge=[None if n is None else n.to(xin.dtype) for n in nudges])
+        l_ = U.regression_loss(pr_, tg, 'l1', residual=rs)
+        l_.backward()
+        return pr_, l_, stats_, n_ties
+
+    t0 = time.time()
+    pr, lr, stats, n_ties32 = oracle_step(P, x, tgt, res)
     t_cpu = time.time() - t0
     rep = {}
     expect = pr.detach() + (0 if res is None else res)
@@ -91,6 +110,28 @@ def _run(S, hyperfine):
         got = net.view(nm, net.grads).cpu().double()
         ref = P[nm].grad.double()
         grads[nm] = (float((got - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), kind)
+    if f64:
+        # attribution: the same step once more in FLOAT64 on the host; the device's and the fp32 oracle's
+        # errors are then both measured against it, per tensor -- who is further from the truth, and by how much
+        t0 = time.time()
+        P64 = {nm: v.detach().double().clone().requires_grad_(True) for nm, v in P.items()}
+        pr64, l64, _, n_ties64 = oracle_step(P64, x.double(), tgt.double(), None if res is None else res.double())
+        rep['t_f64'] = time.time() - t0
+        rep['pool_ties'] = (n_ties32, n_ties64)
+        e64 = pr64.detach() + (0 if res is None else res.double())
+        s64 = float(e64.abs().max())
+        rep['pred_vs_f64'] = (float((pred.view(S, S, S, 1).cpu().double() - e64).abs().max()) / s64,
+                              float((expect.double() - e64).abs().max()) / s64)
+        rep['loss_vs_f64'] = (abs(loss.item() - float(l64)) / abs(float(l64)), abs(float(lr) - float(l64)) / abs(float(l64)))
+        attr = {}
+        for nm, _, kind in net.specs:
+            ref = P64[nm].grad
+            sc = max(float(ref.abs().max()), 1e-300)
+            dev = net.view(nm, net.grads).cpu().double()
+            rms = max(float(ref.pow(2).mean().sqrt()), 1e-300)
+            attr[nm] = (float((dev - ref).abs().max()) / sc, float((P[nm].grad.double() - ref).abs().max()) / sc, kind,
+                        float((dev - ref).pow(2).mean().sqrt()) / rms, float((P[nm].grad.double() - ref).pow(2).mean().sqrt()) / rms)
+        rep['attr'] = attr
     if hyperfine:
         # configs[3] as BASELINE.json names it: the same step in bf16 (bf16 activations / packed weights, fp32 accumulation,
         # fp32 BatchNorm statistics, fp32 master weights) against the SAME fp32 oracle result -- stated bf16 tolerances
@@ -123,7 +164,7 @@ def _run(S, hyperfine):
 
 @pytest.mark.parametrize('S,hyperfine', [(160, False), (192, True)])
 def test_one_training_step_at_baseline_shape_vs_oracle(S, hyperfine):
-    rep, grads, t_gpu, t_cpu = _run(S, hyperfine)
+    rep, grads, t_gpu, t_cpu = _run(S, hyperfine, f64=not hyperfine)
     worst = sorted(((e, nm) for nm, (e, _) in grads.items()), reverse=True)[:6]
     print('\n%d^3 %s: HIP step %.2fs (first call, incl. allocation), oracle step %.1fs; pred %.2e loss %.2e bn %.2e; worst '
           'gradients %s' % (S, 'configs[3]' if hyperfine else 'configs[1]', t_gpu, t_cpu, rep['pred'], rep['loss'],
@@ -135,14 +176,42 @@ def test_one_training_step_at_baseline_shape_vs_oracle(S, hyperfine):
             f.write('%d^3: gpu %.2fs oracle %.1fs %r\n' % (S, t_gpu, t_cpu, rep))
             for nm, (e, kind) in grads.items():
                 f.write('%-40s %-8s %.3e\n' % (nm, kind, e))
+    if 'attr' in rep:
+        # device vs float64 next to fp32-oracle vs float64, per tensor (max-pool ties aligned in both oracle runs).  Measured
+        # (profiles/r04_full_size_parity_160_vs_float64.txt): every device gradient within 2.5e-4 of its tensor's range of the
+        # float64 result, typically 5e-5; that is 1-5x (typically 2-3x) the distance of the fp32 host evaluation (PyTorch CPU:
+        # blocked vector sums, where the device has sequential fp32 accumulator chains and float atomics).  The 1.9e-3 that
+        # rounds 1-3 reported for the encoder kernels were max-pool tie flips, not arithmetic.  Bounds: 4e-4 of range
+        # absolute, and never further from float64 than 6x the fp32 host evaluation (+ 2e-5 of range)
+        attr = rep.pop('attr')
+        lines = ['%-40s %-8s max/range: device %.3e  fp32 oracle %.3e  ratio %5.2f   rms/rms: device %.3e  fp32 oracle %.3e  ratio %5.2f'
+                 % (nm, kind, d, o, d / max(o, 1e-30), dr, orr, dr / max(orr, 1e-30)) for nm, (d, o, kind, dr, orr) in attr.items()]
+        print('float64 step %.1fs; prediction: device %.2e / oracle %.2e of range from float64; loss %.2e / %.2e'
+              % ((rep['t_f64'],) + rep['pred_vs_f64'] + rep['loss_vs_f64']))
+        print('\n'.join(lines))
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, 'full_size_parity_%d_vs_float64.txt' % S), 'w') as f:
+                f.write('# one training step at %d^3: per-tensor max gradient error / tensor range, against a float64 run of the '
+                        'oracle: device | fp32 oracle (PyTorch CPU)\n# prediction %r loss %r\n' % (S, rep['pred_vs_f64'], rep['loss_vs_f64']))
+                f.write('\n'.join(lines) + '\n')
+        for nm, (d, o, kind, dr, orr) in attr.items():
+            assert d <= 6.0 * o + 2e-5 and d <= 4e-4, 'gradient of %s: device %.3e of range from float64, fp32 oracle %.3e' % (nm, d, o)
+        assert rep['pred_vs_f64'][0] <= 4.0 * rep['pred_vs_f64'][1] + 1e-6 and rep['pred_vs_f64'][0] < 5e-5, rep['pred_vs_f64']
+        assert rep['loss_vs_f64'][0] < 2e-6, rep['loss_vs_f64']
     assert rep['loss'] < 1e-4, rep
     assert rep['bn'] < 5e-4, rep
     assert rep['pred'] < 1e-3, rep
     if hyperfine:   # bf16 vs the fp32 oracle (stated bf16 tolerances; gradients: see tests/test_bf16_gpu.py on pooling flips)
         assert rep['bf16_loss'] < 1e-2 and rep['bf16_pred'] < 5e-2 and rep['bf16_bn'] < 3e-2 and rep['bf16_min_cos'] > 0.98, rep   # measured 0.991
     for nm, (err, kind) in grads.items():
-        # biases of the conv right before a BatchNorm: BN's backward removes the mean of the signal, so their gradient is
-        # a sum of cancelling terms over every voxel (like dbeta / dgamma); measured up to 1.3e-2 at 192^3
+        # device vs the fp32 oracle with the max-pool ties aligned (rounds 1-3 allowed 3e-3 / 3e-2 here: tie flips); measured
+        # worst 3e-4 at 160^3
+        if not hyperfine:
+            assert err < 1e-3, 'gradient of %s: %.3e of its range (worst: %s)' % (nm, err, worst)
+            continue
+        # 192^3 three-channel Hyperfine: no float64 run (memory / time), the round-3 bounds stand -- biases of the conv right
+        # before a BatchNorm (BN's backward removes the mean of the signal: the gradient is a sum of cancelling terms over 7 M
+        # voxels and its RANGE is tiny; measured 1.2e-2) and BatchNorm beta / gamma 3e-2, everything else 3e-3 (measured 2.1e-3)
         bound = 3e-2 if (kind in ('beta', 'gamma') or nm.endswith('_1/bias')) else 3e-3
         assert err < bound, 'gradient of %s: %.3e of its range (worst: %s)' % (nm, err, worst)
 
