@@ -209,7 +209,9 @@ int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const
  * kind: 1 plain conv; 2 forward parity convs of a folded decoder conv; 0 their data gradient */
 int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int kind, int64_t out[8]);
 /* packs every layer of a network in ONE launch.  jobs_dev: int64 [njobs][14] = {w_off, dst_off, count, cin_total,
- * ci_off, cin, cout, mode, ck, ncc, nt, parity(-1 plain), nv, mfma_count}; w_off / dst_off are float offsets */
+ * ci_off, cin, cout, mode, ck, ncc, nt, parity(-1 plain), nv, mfma_count}; w_off / dst_off are float offsets.
+ * `packed` must have been ZEROED once by the caller: of a 27-slot parity set (parity 0..7, nt > 0) only the 8 slots of the
+ * parity's 2x2x2 window are written, the structurally empty 19 are left as they are */
 int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* jobs_dev, int njobs,
                             synthsr_stream_t stream);
 

@@ -266,6 +266,22 @@ __global__ void pack_all_kernel(const float* __restrict__ params, float* __restr
     }
     return;
   }
+  if (nt > 0 && parity >= 0 && parity < 8 && nv == 0) {
+    // one parity set of a folded decoder conv in the 27-slot MFMA layout [nc][cc][slot 27][cg][nt][lane][2]: only the 8 slots of
+    // the parity's 2x2x2 window (forward orientation: coordinates p .. p + 1 per axis, up_axis_taps) are ever non-zero, the
+    // other 19 stay at the zeros the buffer was created with -- 143 of the 259 MB this kernel used to write per step (the
+    // 10^3 384 -> 192 sets alone: 2 x 64 MB) were those zeros
+    const int64_t inner = (int64_t)(ck / 8) * nt * 128, count8 = count / 27 * 8;
+    const int pz = (parity >> 2) & 1, py = (parity >> 1) & 1, px = parity & 1;
+    for (int64_t i8 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i8 < count8; i8 += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t q = i8 / inner, rem = i8 - q * inner;
+      const int t8 = (int)(q & 7);
+      const int slot = ((pz + (t8 >> 2)) * 3 + py + ((t8 >> 1) & 1)) * 3 + px + (t8 & 1);
+      const int64_t idx = ((q >> 3) * 27 + (mode ? 26 - slot : slot)) * inner + rem;
+      dst[idx] = pack_value(w, idx, cin_total, ci_off, cin, cout, mode, ck, ncc, nt, parity, nv, mfma_count);
+    }
+    return;
+  }
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < count;
        idx += (int64_t)gridDim.x * blockDim.x)
     dst[idx] = pack_value(w, idx, cin_total, ci_off, cin, cout, mode, ck, ncc, nt, parity, nv, mfma_count);

@@ -59,7 +59,8 @@ class AdversarialTrainer:
         if self.mask_lut is None:
             return None
         if list(seg.shape) != list(like.shape[:3]):
-            raise NotImplementedError('labels_to_mask with a target resolution different from the label maps')
+            raise ValueError('labels_to_mask with a target resolution different from the label maps: the mask of the label maps\' grid '
+                             'cannot multiply a prediction on another grid (the reference fails with incompatible shapes too)')
         m = ops.lut_gather(seg.contiguous(), self.mask_lut).view(*like.shape[:3], 1)
         # several output channels: the same mask on every channel (Keras broadcasts the Multiply, :365)
         return m if like.shape[3] == 1 else m.expand(*like.shape).contiguous()
@@ -130,7 +131,9 @@ class AdversarialTrainer:
         if self.seg is not None:
             seg = segs[0] if B == 1 else __import__('torch').cat(segs, 0)   # stacked like the volumes
             if list(seg.shape) != list(image.shape[:3]):
-                raise NotImplementedError('segmentation loss with a target resolution different from the label maps')
+                raise ValueError('segmentation loss with a target resolution different from the label maps: `segmentation_target` '
+                                 'has the label maps\' grid, the posteriors the prediction\'s, and DiceLoss multiplies them voxel by voxel '
+                                 '(SynthSR/metrics_model.py:191-207) -- the reference\'s graph fails with incompatible shapes too')
             loss += w_dice * float(self.seg(pred, seg, net.dpred, self.loss_cropping).item())
         if self.gen_reducer is not None:
             self.gen_reducer.start()
@@ -185,7 +188,8 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
     if batchsize != 1 and dropout:
         raise NotImplementedError('batchsize > 1 together with dropout > 0 (per-sample feature masks) is not supported')
     if n_output_channels != 1 and segmentation_model_file is not None:
-        raise NotImplementedError('the segmentation loss needs a single-channel prediction')
+        raise ValueError('the segmentation loss needs ONE regression target (the segmentation network takes a single-channel '
+                         'image, SynthSR/training.py:375)')
     # data parallel like training(): one process per GPU (torchrun), batch 1 per rank, per-rank random streams
     dist_on = 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1
     rank, world = 0, 1

@@ -61,14 +61,21 @@ class SegmentationRegulariser:
     def _from_seg_frame(self, t):  # :162-163
         return self.torch.flip(t, dims=[1]).permute(0, 2, 1).contiguous() if self.fs_header else t
 
-    def __call__(self, pred, seg_target, dpred, loss_cropping=None):
+    def __call__(self, pred, seg_target, dpred, loss_cropping=None, head_channels=1):
         """pred: predicted image, device float [nvox] (or [d0,d1,d2]); seg_target: int32 [d0,d1,d2] (the generator's
         `segmentation_target`); dpred [nvox]: gradient of the image loss w.r.t. pred, incremented IN PLACE by
         rel_weight * d(dice)/d(pred).  loss_cropping: sizes of the centred box the Dice is evaluated on
         (metrics_model.py:166-183: the network still sees the whole volume, posteriors and labels are cropped).
-        Returns the Dice loss as a 0-d device tensor."""
+        head_channels = 2: the Laplace head (metrics_model.py:33-49) -- pred / dpred are [nvox][2] = (intensity, spread);
+        `predicted_image`, what the segmentation network sees, is the intensity channel alone (:53) and only that channel
+        receives the Dice gradient.  Returns the Dice loss as a 0-d device tensor."""
         torch = self.torch
         net = self.net
+        if head_channels != 1:
+            pred2, dpred2 = pred.reshape(-1, head_channels), dpred.reshape(-1, head_channels)
+            pred, dpred_out = pred2[:, 0].contiguous(), dpred2[:, 0]
+        else:
+            dpred_out = dpred
         # batchsize > 1: the volumes are stacked along the first spatial axis (UNet3D.set_batch); the frozen network runs on the
         # stack (batch-statistics BatchNorm then normalises over the whole batch, as Keras does), the Dice is evaluated volume
         # by volume and averaged (DiceLoss: mean over batch and labels)
@@ -113,5 +120,5 @@ class SegmentationRegulariser:
         dx = self._from_seg_frame(dx)
         if self.m is not None:
             dx = dx * inside / (self.M - self.m)
-        dpred.add_(dx.reshape(-1))
+        dpred_out.add_(dx.reshape(-1))
         return dice

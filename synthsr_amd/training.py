@@ -81,8 +81,12 @@ class Trainer:
         if regression_metric not in ('l1', 'l2', 'laplace', 'ssim'):
             raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(
                 regression_metric))  # the reference's message (metrics_model.py:127), typo included
-        if (regression_metric == 'laplace' or net.nb_labels != 1) and seg_regulariser is not None:
-            raise NotImplementedError('the segmentation loss needs a single-channel l1 / l2 prediction')
+        n_targets = net.nb_labels // 2 if regression_metric == 'laplace' else net.nb_labels
+        if n_targets != 1 and seg_regulariser is not None:
+            # the reference builds the segmentation network on [..., 1] (SynthSR/training.py:375) and feeds it the whole
+            # `predicted_image` (metrics_model.py:148,165): with several regression targets Keras refuses the graph
+            raise ValueError('the segmentation loss needs ONE regression target (the segmentation network takes a '
+                             'single-channel image, SynthSR/training.py:375), this network predicts %d' % n_targets)
         self.metric, self.loss_cropping = regression_metric, loss_cropping
         self.bg = brain_generator
         self.seg = seg_regulariser  # synthsr_amd.seg_loss.SegmentationRegulariser or None
@@ -202,8 +206,11 @@ class Trainer:
                                   fuse_head_bwd=self.fuse_head_bwd and self.seg is None)
         if self.seg is not None:  # total = image loss + w * Dice(frozen segmentation net(prediction), labels)
             if list(seg.shape) != list(image.shape[:3]):
-                raise NotImplementedError('segmentation loss with a target resolution different from the label maps')
-            loss = loss + self.seg.rel_weight * self.seg(pred, seg, net.dpred, self.loss_cropping)
+                raise ValueError('segmentation loss with a target resolution different from the label maps: `segmentation_target` '
+                                 'has the label maps\' grid, the posteriors the prediction\'s, and DiceLoss multiplies them voxel by voxel '
+                                 '(SynthSR/metrics_model.py:191-207) -- the reference\'s graph fails with incompatible shapes too')
+            loss = loss + self.seg.rel_weight * self.seg(pred, seg, net.dpred, self.loss_cropping,
+                                                         head_channels=2 if self.metric == 'laplace' else 1)
         if self.reducer is not None:
             self.reducer.start()
             net.backward(on_grad_ready=self.reducer.ready)

@@ -255,7 +255,8 @@ class UNet3D:
                 if not first or self.need_input_grad:  # the first layer's input normally has no gradient
                     add(c, 'wpd', c['shape'], 0, c['cin'], 1, False)
             first = False
-        self._packed = torch.empty(off, dtype=torch.float32, device=self.device)
+        # zeros: synthsr_conv3d_pack_all never writes the 19 structurally empty slots of a 27-slot parity set
+        self._packed = torch.zeros(off, dtype=torch.float32, device=self.device)
         self._jobs = torch.tensor(jobs, dtype=torch.int64, device=self.device)
         for c in self.all_convs():
             for key in ('wp', 'wpd', 'wp_s', 'wpd_s', 'wp_u', 'wpd_u'):

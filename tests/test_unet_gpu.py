@@ -319,6 +319,73 @@ def test_training_reduces_loss(T):
     assert losses[-1] < losses[0]
 
 
+def test_segmentation_loss_with_the_laplace_head_vs_autograd(T):
+    """regression_metric='laplace' together with the segmentation-regularised loss (one regression target: a 2-channel head,
+    SynthSR/metrics_model.py:33-49): `predicted_image` -- what the frozen segmentation network sees -- is the INTENSITY
+    channel (:53), so the Dice gradient lands on head channel 0 only.  Loss values and every gradient of the trained
+    network against autograd through the oracle (single shot, conftest.single_shot_parity)."""
+    torch = T
+    from synthsr_amd.unet import unet
+    from synthsr_amd.seg_loss import SegmentationRegulariser
+    from oracle import unet_ref as U
+    shape, levels, w = (16, 24, 32), 3, 0.25
+    gen_labels = np.array([0, 14, 2, 3, 41, 42, 17])
+    seg_labels = np.array([0, 2, 3, 4, 41, 42, 43, 17, 53])
+    equivalency = np.array([0, 2, 3, 3, 41, 42, 42, 17, 17])
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(*shape, 2, generator=g)
+    target = torch.rand(*shape, generator=g)
+    seg_target = torch.randint(0, len(gen_labels), shape, generator=g, dtype=torch.int32)
+
+    def nets():
+        net = unet(24, list(shape) + [2], levels, 3, 2, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
+                   final_pred_activation='linear', seed=3)
+        segnet = unet(24, list(shape) + [1], levels, 3, len(seg_labels), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
+                      activation='elu', final_pred_activation='softmax', seed=4)
+        return net, segnet
+
+    def run():
+        net, segnet = nets()
+        reg = SegmentationRegulariser(segnet, gen_labels, equivalency, w)
+        loss, pred = net.loss(x.cuda(), target.cuda().reshape(-1), 'laplace', want_pred=True)
+        net.test_loss = loss.clone()
+        net.test_dice = reg(pred, seg_target.cuda(), net.dpred, None, head_channels=2).clone()
+        net.backward()
+        net.test_segnet = segnet
+        return net
+
+    def oracle(net, nudge):
+        P = {k: v.clone().float().requires_grad_(True) for k, v in net.state_dict().items() if 'moving' not in k}
+        Pseg = {k: v.clone().float() for k, v in net.test_segnet.state_dict().items()}
+        pin, pin_seg, n1 = [], [], levels - 1
+        pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, pool_inputs=pin,
+                            pool_nudge=None if nudge is None else nudge[:n1])
+        lap = U.regression_loss(pr, target[..., None], 'laplace')
+        dref = U.seg_regularisation(pr[..., 0], seg_target, Pseg, net.test_segnet.prefix, levels, 2, gen_labels, equivalency,
+                                    pool_inputs=pin_seg, pool_nudge=None if nudge is None else nudge[n1:],
+                                    bn_batch_stats=True)
+        (lap + w * dref).backward()
+        return (P, lap.detach(), dref.detach()), pin + pin_seg
+
+    def compare(net, ref):
+        P, lap, dref = ref
+        assert abs(float(net.test_loss.item()) - float(lap)) < 2e-5 * max(1.0, abs(float(lap)))
+        assert abs(float(net.test_dice.item()) - float(dref)) < 2e-5
+        for nm, _, _ in net.specs:
+            close(net.view(nm, net.grads), P[nm].grad, 2e-3, 'grad ' + nm)
+
+    single_shot_parity(run, oracle, compare, loss_of=lambda n_: n_.test_loss, pool_nets=lambda n_: [n_, n_.test_segnet])
+    # two regression targets: refused like the reference's graph (the segmentation network takes ONE channel)
+    from synthsr_amd.training import Trainer
+    net4 = unet(24, list(shape) + [2], levels, 3, 4, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
+                final_pred_activation='linear', seed=3)
+
+    class _BG:
+        labels_to_image_model = None
+    with pytest.raises(ValueError):
+        Trainer(_BG(), net4, regression_metric='laplace', seg_regulariser=object())
+
+
 @pytest.mark.parametrize('fs_header,clip,crop,frozen_bn', [(False, False, None, 'batch'), (True, True, None, 'inference'),
                                                            (True, False, (12, 16, 20), 'batch'),
                                                            (False, True, (8, 24, 12), 'inference'),
