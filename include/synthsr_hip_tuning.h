@@ -61,7 +61,7 @@ int synthsr_split_tile_schedule(int kernel, int ntiles, int ny, int block_x, int
  * order (no serialisation: ~1.1x the default step time at 160^3); in-workgroup LDS float atomics are replaced by ordered
  * sums, and the split-K / parity-split forward variants (partial sums meeting in atomics) are not selected: the same
  * inputs give bit-identical results run after run.  The default (0) keeps plain atomics.  Not covered: channel counts
- * C with 384 % (C / 4) != 0 and the Dice sums of the segmentation-regularised loss (data-indexed LDS atomics).  An
+ * C with 384 % (C / 4) != 0.  An
  * allocation failure leaves the mode off and nothing half-installed.
  * Reference: SURVEY.md section 5 (determinism); the reference itself relies on TF's non-deterministic GPU reductions. */
 int synthsr_set_deterministic(int on);

@@ -977,9 +977,10 @@ __global__ __launch_bounds__(256) void seg_dice_sums_kernel(const float* __restr
                                                             int64_t nvox, int N, const int32_t* __restrict__ cls_idx,
                                                             const int32_t* __restrict__ cls_gt, int K,
                                                             float* __restrict__ sums) {
-  __shared__ float st[2 * SEG_MAXK];
-  for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) st[i] = 0.f;
-  __syncthreads();
+  // per-wave partials in fixed LDS slots, added in wave order, then ONE flush per workgroup (syn_det_gather: in deterministic
+  // mode the last workgroup adds all rows in id order) -- round 4: the LDS float atomics this kernel used made the Dice sums the
+  // one reduction deterministic mode did not cover
+  __shared__ float st[2 * SEG_MAXK], sw4[4][2 * SEG_MAXK];
   for (int k = 0; k < K; ++k) {
     const int i0 = cls_idx[3 * k], i1 = cls_idx[3 * k + 1], i2 = cls_idx[3 * k + 2], g = cls_gt[k];
     float top = 0.f, bot = 0.f;
@@ -995,12 +996,16 @@ __global__ __launch_bounds__(256) void seg_dice_sums_kernel(const float* __restr
     top = syn_wave_sum(top);
     bot = syn_wave_sum(bot);
     if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&st[k], top);
-      atomicAdd(&st[K + k], bot);
+      sw4[threadIdx.x >> 6][k] = top;
+      sw4[threadIdx.x >> 6][K + k] = bot;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) atomicAdd(&sums[i], st[i]);
+  for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) st[i] = (sw4[0][i] + sw4[1][i]) + (sw4[2][i] + sw4[3][i]);
+  __syncthreads();
+  if (syn_det_gather(st, 2 * K))
+    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) atomicAdd(&sums[i], st[i]);
+  syn_det_gather_end(2 * K);
 }
 
 // Backward of  scale * mean_k(1 - (T_k + e)/(B_k + e))  through the label merging, the softmax and the 1x1x1 head:

@@ -342,13 +342,11 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
     """Parameters as documented in SynthSR/training.py:90-240 (+ `seed`, `verbose`, `dtype`: 'f32' like the reference, or
     'bf16' = bf16 activations / packed weights with fp32 accumulation, BatchNorm statistics and master weights,
     BASELINE.json configs[3]; `deterministic`: bit-identical weights run after run for the same seed, ops.set_deterministic,
-    1.2x (fp32) / 1.4x (bf16) slower at 160^3 -- not with the segmentation-regularised loss; `segnet_frozen_bn`: what the frozen
+    1.2x (fp32) / 1.4x (bf16) slower at 160^3; `segnet_frozen_bn`: what the frozen
     segmentation network's BatchNormalization normalises with, 'batch' = the statistics of its own activations, which is what
     Keras 2.3.1 does to a trainable=False BatchNormalization under fit(), or 'inference' = its moving averages)."""
     import torch
     if deterministic:  # process-wide switch: on for the duration of this call, previous setting restored on the way out
-        if segmentation_model_file is not None:
-            raise NotImplementedError('deterministic mode does not cover the Dice sums of the segmentation-regularised loss')
         from . import ops as _ops
         kw = dict(locals())
         kw.pop('torch', None)

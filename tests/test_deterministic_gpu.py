@@ -227,3 +227,34 @@ def test_fused_head_backward_sums_match_the_separate_pass(det, dtype, kind, crop
         worst = max(worst, (float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30), nm))
     print('fused head sums: worst gradient difference %.2e of the range (%s)' % worst)
     assert worst[0] <= (2e-5 if dtype == 'f32' else 2e-3), worst
+
+
+def test_segmentation_regularised_loss_is_bitwise_reproducible(det):
+    """the Dice sums of SynthSR/metrics_model.py:187-207 (round 4: per-wave partials in fixed slots + the ordered gather instead
+    of LDS float atomics): Dice value, the gradient it adds to the prediction and the trained network's gradients are
+    bit-identical run after run in deterministic mode -- training(deterministic=True) now takes segmentation_model_file"""
+    import torch
+    from synthsr_amd.unet import unet
+    from synthsr_amd.seg_loss import SegmentationRegulariser
+    shape, levels = (32, 32, 48), 3
+    gen_labels = np.array([0, 14, 2, 3, 41, 42, 17])
+    equivalency = np.array([0, 2, 3, 3, 41, 42, 42, 17, 17])
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(*shape, 2, generator=g).cuda()
+    target = torch.rand(int(np.prod(shape)), generator=g).cuda()
+    seg_target = torch.randint(0, len(gen_labels), shape, generator=g, dtype=torch.int32).cuda()
+    runs = []
+    for rep in range(3):
+        net = _net('f32', 24, levels, shape, 2)
+        segnet = unet(24, list(shape) + [1], levels, 3, len(equivalency), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
+                      activation='elu', final_pred_activation='softmax', seed=4)
+        reg = SegmentationRegulariser(segnet, gen_labels, equivalency, 0.25)
+        loss, pred = net.loss(x, target, 'l1', want_pred=True)
+        dice = reg(pred, seg_target, net.dpred, (24, 24, 32)).clone()
+        dpred = net.dpred.clone()
+        net.backward()
+        torch.cuda.synchronize()
+        runs.append((dice, dpred, net.grads.clone()))
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2])
+    assert float(runs[0][0]) > 0 and float(runs[0][2].abs().max()) > 0
