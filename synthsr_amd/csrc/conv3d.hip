@@ -153,11 +153,41 @@ __device__ __forceinline__ void split_pack_pair(const float* __restrict__ w, int
   syn_split3(v0, v1, pc[0], pc[1], pc[2]);
 }
 
+// Stacked layout of the plain Cout = 24 split convs (NT = -400; conv_split.hip: conv3d_split_fwd2_kernel<2, ., ., true>):
+// [cc][step 7][tile 5][lane 64][8 bf16]; lane = (m = lane & 15 -> row of the tile, g = lane >> 4 -> K slot 4 step + g), value j ->
+// input channel cc*8 + j.  Rows: T0 = piece 0 of channels 0..15, T1 = piece 1, T2 = piece 2 of the same channels; T3 = piece 0 of
+// channels 16..23 (rows 0..7) | piece 1 of channels 16..23 (rows 8..15); T4 = piece 2 of channels 16..23 (rows 0..7) | zeros.
+__device__ __forceinline__ float stacked_pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
+                                                    int Cout, int mode) {
+  uint32_t r = (uint32_t)idx * 2u;  // bf16 index
+  const int j = (int)(r & 7);
+  r >>= 3;
+  const int lane = (int)(r & 63);
+  r >>= 6;
+  const int tile = (int)(r % 5);
+  r /= 5;
+  const int step = (int)(r % 7);
+  const int cc = (int)(r / 7);
+  const int m = lane & 15;
+  const int tap = syn_split_tap(4 * step + (lane >> 4));
+  int piece, co;
+  if (tile < 3) { piece = tile; co = m; }
+  else if (tile == 3) { piece = m < 8 ? 0 : 1; co = 16 + (m & 7); }
+  else { piece = m < 8 ? 2 : -1; co = 16 + (m & 7); }
+  if (tap < 0 || piece < 0) return 0.f;
+  const float v0 = weight_value(w, tap, cc * 8 + j, co, Cin_total, ci_off, Cin, Cout, mode, -1);
+  const float v1 = weight_value(w, tap, cc * 8 + j + 1, co, Cin_total, ci_off, Cin, Cout, mode, -1);
+  uint32_t pc[3];
+  syn_split3(v0, v1, pc[0], pc[1], pc[2]);
+  return __uint_as_float(pc[piece]);
+}
+
 // packed layout of one weight set: MFMA section [nc][cc][tap][cg][nt][lane][2] (B fragments), followed — when the layer
 // keeps NV output channels on the vector ALUs — by the VALU section [cc][tap][ci (CK)][NV] (wave-uniform scalar loads)
 __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t idx, int Cin_total, int ci_off, int Cin,
                                             int Cout, int mode, int CK, int ncc, int NT, int parity, int NV,
                                             int64_t mfma_count) {
+  if (NT == -400) return stacked_pack_value(w, idx, Cin_total, ci_off, Cin, Cout, mode);
   if (NT <= -100) {  // split layouts: one piece of split_pack_pair
     const int64_t n3 = split_plane_floats(NT, ncc, (int)mfma_count);
     uint32_t pc[3];
@@ -227,7 +257,7 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int64_t
 __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin_total, int ci_off, int Cin,
                             int Cout, int mode, int CK, int ncc, int NT, int nchunks, int parity, int NV,
                             int64_t mfma_count, int64_t total) {
-  if (NT <= -100) {  // split layouts: a thread gathers a weight pair once and writes its three pieces
+  if (NT <= -100 && NT != -400) {  // split layouts: a thread gathers a weight pair once and writes its three pieces
     const int64_t n3 = total / 3;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
       uint32_t pc[3];
@@ -255,7 +285,7 @@ __global__ void pack_all_kernel(const float* __restrict__ params, float* __restr
   const int cin_total = (int)jb[3], ci_off = (int)jb[4], cin = (int)jb[5], cout = (int)jb[6], mode = (int)jb[7],
             ck = (int)jb[8], ncc = (int)jb[9], nt = (int)jb[10], parity = (int)jb[11], nv = (int)jb[12];
   const int64_t mfma_count = jb[13];
-  if (nt <= -100) {  // split layouts: a thread gathers a weight pair once and writes its three pieces
+  if (nt <= -100 && nt != -400) {  // split layouts: a thread gathers a weight pair once and writes its three pieces
     const int64_t n3 = count / 3;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
       uint32_t pc[3];
@@ -2885,7 +2915,9 @@ extern "C" int syn_split_upfwd(const float* lo, const float* wp, const float* bi
                                const int s[3], int Cin, int Cout, int mt, int act, hipStream_t st);
 extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias, const float* addend, float* out,
                              const int s[3], int Cin, int Cout, int mt, int nchunks, int act, float* stats, float* partial,
-                             int upm, hipStream_t st);
+                             int upm, int stacked, hipStream_t st);
+static int g_arith = 1;  // synthsr_set_conv_arithmetic: 0 fp32_mfma, 1 split, 2 split9
+static int g_stack24 = 1;  // option 10: stacked weight layout (10 instead of 12 MFMAs per K step) for the plain Cout = 24 split convs
 
 // does the weight gradient of a plain 3x3x3 conv take the split kernel (conv_split.hip: syn_split_wgrad)?  One place: the
 // dispatcher and the query synthsr_conv3d_wgrad_runs_split (what the benchmarks price a layer against) both ask here
@@ -2896,16 +2928,17 @@ inline bool wgrad_takes_split(const int s[3], int Cin, int Cout) {
 }
 
 struct FwdPlan {
-  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2, brick, wn, wm, split;
+  int nt, mt, ksplit, nchunks, ncc, ck, persist, nv, p4, c2, brick, wn, wm, split, stacked;
   // NT = 0 selects the 4x4x1 weight layout in pack_value, NT = -Cin the first-layer layout, NT = -100 - MT the split layout,
   // NT = -200 - MT / -300 - MT the split layout of a folded conv's parity set (data gradient / forward window);
   // split: 0 no, 1 plain conv, 2 folded data gradient, 3 folded forward
-  int pack_nt() const { return split == 3 ? -300 - mt : (split == 2 ? -200 - mt : (split ? -100 - mt : (c2 ? -c2 : (p4 ? 0 : nt)))); }
+  int pack_nt() const { return stacked ? -400 : split == 3 ? -300 - mt : (split == 2 ? -200 - mt : (split ? -100 - mt : (c2 ? -c2 : (p4 ? 0 : nt)))); }
   int64_t mfma_count() const {
     if (split) return nchunks;  // what pack_value needs to decode the split layout
     return (p4 || c2) ? 0 : (int64_t)nchunks * ncc * 27 * (ck / 8) * nt * 128;
   }
   int64_t count() const {
+    if (stacked) return (int64_t)ncc * 7 * 5 * 64 * 4;  // [cc][step 7][tile 5][lane 64] x 8 bf16
     if (split) return (int64_t)3 * nchunks * ncc * (split >= 2 ? 2 : 7) * mt * 64 * 4;  // floats (= pairs of bf16)
     if (c2) return (int64_t)((27 * c2 * 6 + 15) / 16) * 64;
     return p4 ? (int64_t)ncc * 27 * 9 * 64 : mfma_count() + (int64_t)ncc * 27 * ck * nv;
@@ -2918,6 +2951,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
   const bool plain = kind == 1;
   FwdPlan p;
   p.split = 0;
+  p.stacked = 0;
   if (g_split && (Cin % 8) == 0 && (Cout % 8) == 0) {
     // fp32 through three bf16 pieces per operand on the bf16 matrix cores (conv_split.hip): layers with enough 4x4x16 tiles
     const int64_t vox = (int64_t)s[0] * s[1] * s[2];
@@ -2936,6 +2970,8 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
       p.nt = mt;
       p.nchunks = nchunks;
       p.ksplit = 1;
+      // the plain Cout = 24 convs (160^3: forward and data gradient): weight pieces stacked along M (conv_split.hip, STK)
+      p.stacked = (plain && Cout == 24 && g_arith == 1 && g_stack24) ? 1 : 0;
       p.nv = p.persist = p.p4 = p.c2 = p.brick = 0;
       p.wn = p.wm = 1;
       return p;
@@ -3813,7 +3849,7 @@ int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias,
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   if (pl.split)
     return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr, 0,
-                         (hipStream_t)stream);
+                         pl.stacked, (hipStream_t)stream);
   const ConvExt ext{0, nullptr, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
@@ -3828,7 +3864,7 @@ int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* b
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   if (pl.split)
     return syn_split_fwd(in, wpacked, bias, addend, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr, 0,
-                         (hipStream_t)stream);
+                         pl.stacked, (hipStream_t)stream);
   const ConvExt ext{0, addend, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
@@ -3846,7 +3882,7 @@ int synthsr_conv3d_fwd_stats(const float* in, const float* wpacked, const float*
     float* partial = lib_scratch((size_t)512 * 2 * Cout * sizeof(float));
     if (!partial) return SYNTHSR_ELAUNCH;
     return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, stats, partial, 0,
-                         (hipStream_t)stream);
+                         pl.stacked, (hipStream_t)stream);
   }
   if (pl.p4 && nvox * Cin * 4 < (1ll << 31))  // statistics accumulated in the conv epilogue
     return launch_fwd_p4(in, wpacked, bias, out, shape, Cin, pl, act, (hipStream_t)stream, nullptr, stats);
@@ -3878,7 +3914,7 @@ int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo
   // effective conv: input channels = Cout (of the forward layer), output channels = Cl
   const FwdPlan pl = plan_fwd(lo_shape, Cout, Cl, 0);
   if (pl.split)  // the 8 parities as K chunks of one split-arithmetic launch (conv_split.hip, UPM 2)
-    return syn_split_fwd(dout, wpacked8, nullptr, nullptr, dlo, lo_shape, Cout, Cl, pl.mt, pl.nchunks, 0, nullptr, nullptr, 2,
+    return syn_split_fwd(dout, wpacked8, nullptr, nullptr, dlo, lo_shape, Cout, Cl, pl.mt, pl.nchunks, 0, nullptr, nullptr, 2, 0,
                          (hipStream_t)stream);
   const int64_t wstride = pl.count();
   const ConvExt ext{2, nullptr, wstride, pl.mfma_count()};
@@ -3948,7 +3984,6 @@ int synthsr_deterministic_status(void) {
 
 extern "C" void syn_split_set_products(int n);  // conv_split.hip: 6 or 9 partial products per multiplication
 extern "C" void syn_split_set_variant(int v);   // conv_split.hip: kernel generation (A/B runs of tools/)
-static int g_arith = 1;
 int synthsr_set_conv_arithmetic(int mode) {
   if (mode < 0 || mode > 2) return SYNTHSR_EINVAL;
   g_arith = mode;
@@ -3994,6 +4029,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 8) {
     syn_split_set_variant(value);
+    return SYNTHSR_OK;
+  }
+  if (option == 10) {
+    g_stack24 = value ? 1 : 0;
     return SYNTHSR_OK;
   }
   if (option == 9) {

@@ -149,6 +149,7 @@ struct SplitFwdArgs {
   float* out;
   float* stats_partial;  // [gridDim.x][2 Cout] per-workgroup-column sums | sums of squares of the output (ST), or null
   int D0, D1, D2, Cin, Cout, ncc, tiles1, tiles2, ntiles, act;
+  int stacked;  // wp holds the stacked 24-channel layout [cc][step 7][tile 5][lane] (conv3d_split_fwd2_kernel<2, ., ., true>)
 };
 
 // UPM = 2: data gradient of the up-sampled channel range of a folded decoder conv (unet.py; ext/neuron/models.py:426-444
@@ -481,28 +482,38 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
   }
 }
 
-// ---- round 4: the same forward / data-gradient computation as ONE homogeneous instruction stream.
+// ---- round 4: the forward / data-gradient kernel with the conversion of the next halo image INSIDE the K loop.
 // s_memtime stamps of the kernel above (profiles/r04_split_fwd_phase_cycles_before.txt): per 8-channel chunk a wave spends
 // 8 400 cycles in its K loop (336 MFMAs = 5 376 cycles of matrix pipe), 3 000-4 000 converting the next halo image and, once per
-// tile, 7 000-10 000 in the epilogue -- and the two waves of a SIMD (one of each co-resident workgroup) run these phases IN
-// step: the wave that is ahead shares the matrix pipe during its K loop, falls back while it converts, and the other one
-// catches up (being in phase is the attractor), so the pipe idles while both convert.  Here a wave has no phases: the
-// conversion of the next chunk's halo image (piece i of a thread in K step i + 1) and the epilogue of the PREVIOUS tile (its
-// accumulators parked in `pend`, one output row per K step of the next tile's first chunk) are issued between the MFMA groups
-// of the K loop, so that every wave feeds the matrix pipe all the time and vector-ALU / LDS / store instructions fill the
-// issue slots next to it.  Bias is folded into the accumulator initialisation; activation / addend handling is a template
-// parameter (a run-time branch inside the K loop would cut the scheduling region): EPI 0 linear, 1 ELU, 2 x ELU'(addend),
-// 3 + addend, 4 ELU(. + addend).  LDS planes are padded to 6 x 256 staging pieces so that every lane stores (no divergent tail).
+// tile, 7 000-10 000 in the epilogue.  Here piece i of a thread's share of the next image is converted in K step i + 1, between
+// the MFMA groups (its loads travel in two register groups: 16 instead of 24 staging registers), the bias sits in LDS, and the
+// LDS planes are padded to 6 x 256 staging pieces so that every lane stores (no divergent tail): 217 -> 176 registers at MT = 2
+// and 5-15 % less time on the layers with many tiles.  (Parking a tile's accumulators and running its epilogue inside the next
+// tile's K loop was built too: two copies of the K loop behind an if / else cost ~100 spilled registers, and without that the
+// gain was nil -- profiles/r04_split_fwd2_ablation.txt: what is left is exposed memory latency and the instruction mix, not
+// phases.)  Activation / addend handling is a template parameter: EPI 0 linear, 1 ELU, 2 x ELU'(addend), 3 + addend,
+// 4 ELU(. + addend).
+//
+// STK (round 4, the Cout = 24 layers: 160^3, the matrix pipe's largest customers): the three bf16 pieces of the weights are stacked
+// along M instead of padding 24 output channels to two 16-row tiles per piece.  The six products a0 b0 + a0 b1 + a1 b0 + a1 b1 +
+// a0 b2 + a2 b0 need, per activation piece, the weight pieces {a0, a1, a2} (b0), {a0, a1} (b1), {a0} (b2) = 72 + 48 + 24 rows:
+// with the row tiles  T0 = a0[0..15]  T1 = a1[0..15]  T2 = a2[0..15]  T3 = a0[16..23] | a1[16..23]  T4 = a2[16..23] | 0
+// that is b0 x {T0..T4}, b1 x {T0, T1, T3}, b2 x {T0, T3} = 10 MFMAs per K step and voxel row instead of 12 (T3 x b2 also forms
+// a1 b2 for channels 16..23: one of the three omitted products, exact like the others).  Each tile has its own accumulator;
+// the epilogue adds T0 + T1 + T2 (same lanes) and, for channels 16..23, the two halves of T3 (rows 8..15 sit 32 lanes up) + T4.
+// Every accumulator still receives its products smallest first (b2, b1, b0).
 constexpr int PLANE2 = 6 * 256 * 8;  // bytes of one bf16 piece of an 8-channel halo image, padded (>= HVOX * 16)
 constexpr int BUF2 = 3 * PLANE2;
 static_assert(PLANE2 >= PLANE, "padded plane holds the halo image");
+constexpr int STK_TILES = 5;
 
-template <int MT, bool ST, int EPI, bool DEFER>
+template <int MT, bool ST, int EPI, bool STK>
 __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFwdArgs a) {
   constexpr int NSTEP = NSTEP27;
-  constexpr int NITEM = TY * MT;  // epilogue items: one f32x4 (4 channels of a voxel) per lane each
+  constexpr int NITEM = TY * MT;            // epilogue items: one f32x4 (4 channels of a voxel) per lane each
+  constexpr int NWT = STK ? STK_TILES : MT; // weight row tiles per piece set (STK: of the stacked set) = accumulators per row
   static_assert(!ST || EPI <= 1, "statistics belong to plain forward convs");
-  static_assert(NITEM <= 2 * NSTEP, "at most two epilogue items per K step");
+  static_assert(!STK || MT == 2, "the stacked layout is the 24-channel one (two output tiles)");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
@@ -589,8 +600,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
     }
   };
 
+  // weight fragments.  Plain layout: piece q at q * piece_stride, fragment (cc, step, mt) at ((cc * NSTEP + step) * MT + mt) * 64;
+  // stacked layout (STK): one set [cc][step][tile 5][lane]
   const int64_t piece_stride = (int64_t)nchunks * ncc * NSTEP * MT * 64;
-  const u32x4* __restrict__ wbase = a.wp + (int64_t)chunk * ncc * NSTEP * MT * 64 + lane;
+  const u32x4* __restrict__ wbase = a.wp + (STK ? 0 : (int64_t)chunk * ncc * NSTEP * MT * 64) + lane;
+  constexpr int WCHUNK = NSTEP * NWT * 64;  // fragments (u32x4) of one input-channel chunk in one piece set
 
   float s1[ST ? MT : 1][4], s2[ST ? MT : 1][4];
 #pragma unroll
@@ -611,80 +625,88 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
     lbias[tid] = (a.bias && co < Cout) ? a.bias[co] : 0.f;
   }
 
-  u32x4 wa[3][MT], xb[3][TY];
+  // Register budget (2 workgroups per CU: 256 VGPRs): ONE set of weight fragments and ONE set of activation fragments; every
+  // fragment is re-loaded for the next step right after its last use and then not needed for >= 12 (plain) / 20 (STK) MFMAs
+  u32x4 wa[STK ? 1 : 3][STK ? STK_TILES : MT], xb[3][TY];
   bool wfirst = true;
   (void)wfirst;
-  auto wload = [&](const u32x4* wf, int s, int q) {
+  auto wload = [&](const u32x4* wf, int s, int q) {  // plain: piece q of step s
 #if SYN_ABL & 8
     if (!wfirst) return;
 #endif
+    if constexpr (!STK) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) wa[q][mt] = wf[q * piece_stride + (s * MT + mt) * 64];
+      for (int mt = 0; mt < MT; ++mt) wa[q][mt] = wf[q * piece_stride + (s * MT + mt) * 64];
+    }
+  };
+  auto wload_t = [&](const u32x4* wf, int s, int tl) {  // STK: row tile tl of step s
+#if SYN_ABL & 8
+    if (!wfirst) return;
+#endif
+    if constexpr (STK) wa[0][tl] = wf[(s * STK_TILES + tl) * 64];
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
 
-  f32x4 acc[TY][MT];
-  f32x4 pend[DEFER ? TY : 1][DEFER ? MT : 1];  // the previous tile's sums, waiting for their epilogue
-  uint32_t prow0 = OOB, pyok = 0;               // its first output row (byte offset of this lane's voxel) and valid rows
-  f32x4 ev[1], eb[1];
-  uint32_t eoff[1];
-
-  // epilogue item j = (mt, y) of the parked tile (src = pend) or of the finished one (src = acc), in three segments
-  auto item_off = [&](int j, uint32_t row0, uint32_t yok) -> uint32_t {
+  f32x4 acc[TY][NWT];
+  f32x4 ev, eb;
+  uint32_t eoff;
+  // epilogue item j = (mt, y) of the finished tile, in three segments
+  auto epi0 = [&](int j, uint32_t row0, uint32_t yok) {
     const int mt = j / TY, y = j % TY;
     const int co = (chunk * MT + mt) * 16 + 4 * g;
-    return (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;
-  };
-  auto epi0 = [&](int k, int j, uint32_t row0, uint32_t yok) {
 #if SYN_ABL & 32
-    row0 = OOB; yok = 0;
+    yok = 0;
 #endif
-    eoff[k] = item_off(j, row0, yok);
-    if constexpr (EPI >= 2) eb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)eoff[k], 0, 0));
+    eoff = (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;
+    if constexpr (EPI >= 2) eb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)eoff, 0, 0));
   };
-  auto epi1 = [&](int k, int j, const f32x4& src) {
-    const f32x4 bj = *reinterpret_cast<const f32x4*>(lbias + (j / TY) * 16 + 4 * g);
-    f32x4 v = src;
+  auto epi1 = [&](int j) {
+    const int mt = j / TY, y = j % TY;
+    const f32x4 bj = *reinterpret_cast<const f32x4*>(lbias + mt * 16 + 4 * g);
+    f32x4 v;
+    if constexpr (STK) {
+      if (mt == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (acc[y][0][i] + acc[y][1][i]) + acc[y][2][i];
+      } else {  // channels 16 + 4 g + i (g < 2): the a0 part here, the a1 part in the lane 32 up (rows 8..15 of T3), a2 in T4
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (acc[y][3][i] + __shfl_down(acc[y][3][i], 32, 64)) + acc[y][4][i];
+      }
+    } else {
+      v = acc[y][mt];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += bj[i];
     if constexpr (EPI == 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] *= elu_dy(eb[k][i]);
+      for (int i = 0; i < 4; ++i) v[i] *= elu_dy(eb[i]);
     }
     if constexpr (EPI == 3 || EPI == 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += eb[k][i];
+      for (int i = 0; i < 4; ++i) v[i] += eb[i];
     }
     if constexpr (EPI == 1 || EPI == 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
     }
-    ev[k] = v;
+    ev = v;
   };
-  auto epi2 = [&](int k, int j) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev[k]), rout, (int)eoff[k], 0, 0);
+  auto epi2 = [&](int j) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), rout, (int)eoff, 0, 0);
     if constexpr (ST) {
       const int mt = j / TY;
-      const float w = eoff[k] != OOB ? 1.f : 0.f;
+      const float w = eoff != OOB ? 1.f : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float r = w * ev[k][i];
+        const float r = w * ev[i];
         s1[mt][i] += r;
         s2[mt][i] += r * r;
       }
     }
-  };
-  auto tile_rows = [&](int t, uint32_t& row0, uint32_t& yok) {
-    int z0, y0, x0;
-    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
-    const int gz = z0 + wave, gx = x0 + xv;
-    const bool zx_ok = gz < D0 && gx < D2;
-    row0 = (uint32_t)((gz * D1 + y0) * D2 + gx) * (uint32_t)(Cout * 4);
-    yok = 0;
-#pragma unroll
-    for (int y = 0; y < TY; ++y) yok |= (zx_ok && (y0 + y) < D1) ? (1u << y) : 0u;
   };
 
   int buf = 0;
@@ -697,144 +719,163 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
       conv_b(i);
       conv_c(i, lds);
     }
-    wload(wbase, 0, 0);
-    wload(wbase, 0, 1);
-    wload(wbase, 0, 2);
+    if constexpr (STK) {
+#pragma unroll
+      for (int tl = 0; tl < STK_TILES; ++tl) wload_t(wbase, 0, tl);
+    } else {
+      wload(wbase, 0, 0);
+      wload(wbase, 0, 1);
+      wload(wbase, 0, 2);
+    }
     wfirst = false;
   }
-  // one K chunk of tile t; WITH_EPI: the parked tile's epilogue rides along
-  auto body = [&](int t, int cc, auto WITH_EPI) {
-    constexpr bool WE = decltype(WITH_EPI)::value;
-    __syncthreads();  // image `buf` is complete; nobody reads the other one any more
-    const bool last_cc = cc + 1 == ncc;
-    const bool more = !last_cc || t + walk.stride < walk.end;
-    halo_where(last_cc ? (more ? t + walk.stride : t) : t, last_cc ? 0 : cc + 1, !more);
-    load_pieces(P0{}, P4{});
-    const u32x4* wf = wbase + (int64_t)cc * NSTEP * MT * 64;
-    const u32x4* wf_next = wbase + (int64_t)(last_cc ? 0 : cc + 1) * NSTEP * MT * 64;
-    const unsigned char* img = lds + buf * BUF2 + lbase;
-    unsigned char* nimg = lds + (buf ^ 1) * BUF2;
-    auto xload = [&](int s, int q) {
+  for (int t = walk.pos; t < walk.end; t += walk.stride) {
+#pragma unroll
+    for (int y = 0; y < TY; ++y)
+#pragma unroll
+      for (int tl = 0; tl < NWT; ++tl) acc[y][tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < ncc; ++cc) {
+      __syncthreads();  // image `buf` is complete; nobody reads the other one any more
+      const bool last_cc = cc + 1 == ncc;
+      const bool more = !last_cc || t + walk.stride < walk.end;
+      halo_where(last_cc ? (more ? t + walk.stride : t) : t, last_cc ? 0 : cc + 1, !more);
+      load_pieces(P0{}, P4{});
+      const u32x4* wf = wbase + (int64_t)cc * WCHUNK;
+      const u32x4* wf_next = wbase + (int64_t)(last_cc ? 0 : cc + 1) * WCHUNK;
+      const unsigned char* img = lds + buf * BUF2 + lbase;
+      unsigned char* nimg = lds + (buf ^ 1) * BUF2;
+      auto xload = [&](int s, int q) {
 #if SYN_ABL & 16
-      if (s != 0) return;
+        if (s != 0) return;
 #endif
 #pragma unroll
-      for (int y = 0; y < TY; ++y) xb[q][y] = *reinterpret_cast<const u32x4*>(img + q * PLANE2 + koff[s] + y * (HX * 16));
-    };
-    auto mma = [&](auto QA, auto QB) {
-      constexpr int qa = decltype(QA)::value, qb = decltype(QB)::value;
+        for (int y = 0; y < TY; ++y) xb[q][y] = *reinterpret_cast<const u32x4*>(img + q * PLANE2 + koff[s] + y * (HX * 16));
+      };
+      auto mma = [&](auto QA, auto QB) {  // plain: acc += (weight piece QA) x (activation piece QB)
+        constexpr int qa = decltype(QA)::value, qb = decltype(QB)::value;
+        if constexpr (!STK) {
 #pragma unroll
-      for (int y = 0; y < TY; ++y)
+          for (int y = 0; y < TY; ++y)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#if SYN_ABL & 128
-          if (!(mt == 1 && ((qa == 0 && qb == 2) || (qa == 1 && qb == 1))))
-#endif
+            for (int mt = 0; mt < MT; ++mt)
 #if SYN_ABL & 64
-          acc[y][mt][0] += __uint_as_float(wa[qa][mt][0] ^ xb[qb][y][0]);
+              acc[y][mt][0] += __uint_as_float(wa[qa][mt][0] ^ xb[qb][y][0]);
 #else
-          acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[qa][mt]),
-                                                               __builtin_bit_cast(bf16x8, xb[qb][y]), acc[y][mt], 0, 0, 0);
+              acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[qa][mt]),
+                                                                   __builtin_bit_cast(bf16x8, xb[qb][y]), acc[y][mt], 0, 0, 0);
 #endif
-    };
-    xload(0, 2);
-    xload(0, 1);
-    xload(0, 0);
-    sfor<0, NSTEP>([&](auto S) {
-      constexpr int s = decltype(S)::value;
-      constexpr bool last = s + 1 == NSTEP;
-      const u32x4* wn = last ? wf_next : wf;
-      constexpr int sn = last ? 0 : s + 1;
-      constexpr int ci = s - 1;                                        // staging piece converted in this step
-      constexpr bool cv = ci >= 0 && ci < NL;
-      constexpr int ja = s, jb = s + NSTEP;                            // epilogue items of this step
-      constexpr bool ea = WE && ja < NITEM, ebb = WE && jb < NITEM;
-      __builtin_amdgcn_sched_barrier(0);
-      mma(I0{}, I2{});
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!last) xload(sn, 2);
-      if constexpr (cv) conv_a(ci);
-      if constexpr (ea) epi0(0, ja, prow0, pyok);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(I0{}, I1{});
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (cv) conv_b(ci);
-      if constexpr (ea) epi1(0, ja, pend[DEFER ? ja % TY : 0][DEFER ? ja / TY : 0]);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(I0{}, I0{});
-      __builtin_amdgcn_sched_barrier(0);
-      wload(wn, sn, 0);
-      if constexpr (cv) conv_c(ci, nimg);
-      if constexpr (ea) epi2(0, ja);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(I1{}, I0{});
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (s == 2) load_pieces(P4{}, P6{});
-      if constexpr (ebb) epi0(0, jb, prow0, pyok);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(I1{}, I1{});
-      __builtin_amdgcn_sched_barrier(0);
-      wload(wn, sn, 1);
-      if constexpr (!last) xload(sn, 1);
-      if constexpr (ebb) epi1(0, jb, pend[DEFER ? jb % TY : 0][DEFER ? jb / TY : 0]);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(I2{}, I0{});
-      __builtin_amdgcn_sched_barrier(0);
-      wload(wn, sn, 2);
-      if constexpr (!last) xload(sn, 0);
-      if constexpr (ebb) epi2(0, jb);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    buf ^= 1;
-  };
-  auto zero_acc = [&]() {
+        }
+      };
+      auto mmt = [&](auto TL, auto QB) {  // STK: acc[.][tile TL] += (row tile TL) x (activation piece QB)
+        constexpr int tl = decltype(TL)::value, qb = decltype(QB)::value;
+        if constexpr (STK) {
 #pragma unroll
-    for (int y = 0; y < TY; ++y)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  };
-  // No if / else between two copies of the K loop (the register allocator spills ~100 registers at such a join): every tile
-  // starts with the chunk that carries the parked epilogue, the others follow in a loop.
-  int t = walk.pos;
-  if constexpr (DEFER) {
-    auto park = [&](int t_) {
-#pragma unroll
-      for (int y = 0; y < TY; ++y)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) pend[y][mt] = acc[y][mt];
-      tile_rows(t_, prow0, pyok);
-    };
-    // the first tile's rider works on an empty parked tile (pend = 0, every row invalid: nothing is stored or counted)
-#pragma unroll
-    for (int y = 0; y < TY; ++y)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) pend[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (t < walk.end) {
-      for (; t < walk.end; t += walk.stride) {
-        zero_acc();
-        body(t, 0, std::true_type{});
-        for (int cc = 1; cc < ncc; ++cc) body(t, cc, std::false_type{});
-        park(t);
-      }
-#pragma unroll
-      for (int j = 0; j < NITEM; ++j) {
-        epi0(0, j, prow0, pyok);
-        epi1(0, j, pend[j % TY][j / TY]);
-        epi2(0, j);
-      }
+          for (int y = 0; y < TY; ++y)
+#if SYN_ABL & 64
+            acc[y][tl][0] += __uint_as_float(wa[0][tl][0] ^ xb[qb][y][0]);
+#else
+            acc[y][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[0][tl]),
+                                                                 __builtin_bit_cast(bf16x8, xb[qb][y]), acc[y][tl], 0, 0, 0);
+#endif
+        }
+      };
+      xload(0, 2);
+      xload(0, 1);
+      xload(0, 0);
+      sfor<0, NSTEP>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        constexpr bool last = s + 1 == NSTEP;
+        const u32x4* wn = last ? wf_next : wf;
+        constexpr int sn = last ? 0 : s + 1;
+        constexpr int ci = s - 1;  // staging piece converted in this step
+        constexpr bool cv = ci >= 0 && ci < NL;
+        if constexpr (STK) {
+          // T0 and T3 (needed first in the next step) finish first: T0 b2, T3 b2, T0 b1, T3 b1, T0 b0, T3 b0 | T1 b1, T1 b0 |
+          // T2 b0, T4 b0 -- every fragment is re-loaded >= 20 MFMAs before its next use, every accumulator gets b2, b1, b0
+          __builtin_amdgcn_sched_barrier(0);
+          mmt(I0{}, I2{});
+          mmt(I3{}, I2{});
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!last) xload(sn, 2);
+          if constexpr (cv) conv_a(ci);
+          __builtin_amdgcn_sched_barrier(0);
+          mmt(I0{}, I1{});
+          mmt(I3{}, I1{});
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (cv) conv_b(ci);
+          __builtin_amdgcn_sched_barrier(0);
+          mmt(I0{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload_t(wn, sn, 0);
+          if constexpr (cv) conv_c(ci, nimg);
+          __builtin_amdgcn_sched_barrier(0);
+          mmt(I3{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload_t(wn, sn, 3);
+          if constexpr (s == 2) load_pieces(P4{}, P6{});
+          __builtin_amdgcn_sched_barrier(0);
+          mmt(I1{}, I1{});
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!last) xload(sn, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mmt(I1{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload_t(wn, sn, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mmt(I2{}, I0{});
+          mmt(I4{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload_t(wn, sn, 2);
+          wload_t(wn, sn, 4);
+          if constexpr (!last) xload(sn, 0);
+        } else {
+          __builtin_amdgcn_sched_barrier(0);
+          mma(I0{}, I2{});
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!last) xload(sn, 2);
+          if constexpr (cv) conv_a(ci);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(I0{}, I1{});
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (cv) conv_b(ci);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(I0{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload(wn, sn, 0);
+          if constexpr (cv) conv_c(ci, nimg);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(I1{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (s == 2) load_pieces(P4{}, P6{});
+          __builtin_amdgcn_sched_barrier(0);
+          mma(I1{}, I1{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload(wn, sn, 1);
+          if constexpr (!last) xload(sn, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(I2{}, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          wload(wn, sn, 2);
+          if constexpr (!last) xload(sn, 0);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      buf ^= 1;
     }
-  } else {
-    for (; t < walk.end; t += walk.stride) {
-      zero_acc();
-      for (int cc = 0; cc < ncc; ++cc) body(t, cc, std::false_type{});
-      uint32_t row0, yok;
-      tile_rows(t, row0, yok);
+    // ---- epilogue: lane (m, g): channels (chunk*MT + mt)*16 + 4g + i of voxel (z0 + wave, y0 + y, x0 + xv)
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    const int gz = z0 + wave, gx = x0 + xv;
+    const bool zx_ok = gz < D0 && gx < D2;
+    const uint32_t row0 = (uint32_t)((gz * D1 + y0) * D2 + gx) * (uint32_t)(Cout * 4);
+    uint32_t yok = 0;
 #pragma unroll
-      for (int j = 0; j < NITEM; ++j) {
-        epi0(0, j, row0, yok);
-        epi1(0, j, acc[j % TY][j / TY]);
-        epi2(0, j);
-      }
+    for (int y = 0; y < TY; ++y) yok |= (zx_ok && (y0 + y) < D1) ? (1u << y) : 0u;
+#pragma unroll
+    for (int j = 0; j < NITEM; ++j) {
+      epi0(j, row0, yok);
+      epi1(j);
+      epi2(j);
     }
   }
   if constexpr (ST) {
@@ -1499,11 +1540,10 @@ int launch_split_fwd_np(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t 
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
-template <int MT, bool ST, int EPI>
+template <int MT, bool ST, int EPI, bool STK>
 int launch_split_fwd2_e(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
-  constexpr bool DEFER = false;
   const size_t smem = 2 * BUF2 + MT * 16 * 4;
-  auto kern = conv3d_split_fwd2_kernel<MT, ST, EPI, DEFER>;
+  auto kern = conv3d_split_fwd2_kernel<MT, ST, EPI, STK>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1513,18 +1553,18 @@ int launch_split_fwd2_e(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t 
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
-template <int MT, bool ST>
+template <int MT, bool ST, bool STK = false>
 int launch_split_fwd2(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
   const int epi = a.act + ((a.addend && a.act < 2) ? 3 : 0);
   if constexpr (ST) {
-    return epi == 1 ? launch_split_fwd2_e<MT, true, 1>(a, gx, nchunks, st) : launch_split_fwd2_e<MT, true, 0>(a, gx, nchunks, st);
+    return epi == 1 ? launch_split_fwd2_e<MT, true, 1, STK>(a, gx, nchunks, st) : launch_split_fwd2_e<MT, true, 0, STK>(a, gx, nchunks, st);
   } else {
     switch (epi) {
-      case 0: return launch_split_fwd2_e<MT, false, 0>(a, gx, nchunks, st);
-      case 1: return launch_split_fwd2_e<MT, false, 1>(a, gx, nchunks, st);
-      case 2: return launch_split_fwd2_e<MT, false, 2>(a, gx, nchunks, st);
-      case 3: return launch_split_fwd2_e<MT, false, 3>(a, gx, nchunks, st);
-      default: return launch_split_fwd2_e<MT, false, 4>(a, gx, nchunks, st);
+      case 0: return launch_split_fwd2_e<MT, false, 0, STK>(a, gx, nchunks, st);
+      case 1: return launch_split_fwd2_e<MT, false, 1, STK>(a, gx, nchunks, st);
+      case 2: return launch_split_fwd2_e<MT, false, 2, STK>(a, gx, nchunks, st);
+      case 3: return launch_split_fwd2_e<MT, false, 3, STK>(a, gx, nchunks, st);
+      default: return launch_split_fwd2_e<MT, false, 4, STK>(a, gx, nchunks, st);
     }
   }
 }
@@ -1569,6 +1609,10 @@ int launch_split_fwd3(const SplitFwdArgs& a, int nchunks, hipStream_t st) {
 
 template <int MT, bool ST, int UPM = 0>
 int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
+  if (a.stacked) {  // the layout decides the kernel (conv3d.hip plans it only for 6 products, Cout = 24, one co-chunk)
+    if constexpr (UPM == 0 && MT == 2) return launch_split_fwd2<2, ST, true>(a, gx, nchunks, st);
+    return SYNTHSR_EINVAL;
+  }
   if constexpr (UPM == 0) {
     if (g_products == 6 && split_uses_fwd3(a.ntiles, nchunks)) return launch_split_fwd3<MT, ST>(a, nchunks, st);
     if (g_products == 6 && g_variant >= 1) return launch_split_fwd2<MT, ST>(a, gx, nchunks, st);
@@ -1903,8 +1947,9 @@ extern "C" int synthsr_split_tile_schedule(int kernel, int ntiles, int ny, int b
 extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* in, const float* wp, const float* bias,
                                                                     const float* addend, float* out, const int s[3], int Cin,
                                                                     int Cout, int mt, int nchunks, int act, float* stats,
-                                                                    float* partial, int upm, hipStream_t st) {
+                                                                    float* partial, int upm, int stacked, hipStream_t st) {
   if ((Cin % 8) != 0 || (Cout % 4) != 0 || mt < 1 || mt > 3 || nchunks < 1 || (upm != 0 && upm != 2)) return SYNTHSR_EINVAL;
+  if (stacked && (Cout != 24 || mt != 2 || nchunks != 1 || upm != 0 || g_products != 6)) return SYNTHSR_EINVAL;
   if (stats && (!partial || addend || act == 2 || upm)) return SYNTHSR_EINVAL;
   if (upm && (bias || addend || act != 0)) return SYNTHSR_EINVAL;
   const int64_t vox = (int64_t)s[0] * s[1] * s[2];
@@ -1922,13 +1967,14 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
   a.tiles2 = (s[2] + TX - 1) / TX;
   a.ntiles = ((s[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
   a.act = act;
+  a.stacked = stacked;
   const int gx = split_grid_x(a.ntiles, nchunks);
   int rc;
   if (stats) {
     rc = mt == 1 ? launch_split_fwd<1, true>(a, gx, nchunks, st)
                  : (mt == 2 ? launch_split_fwd<2, true>(a, gx, nchunks, st) : launch_split_fwd<3, true>(a, gx, nchunks, st));
     if (rc != SYNTHSR_OK) return rc;
-    const int gcols = (g_products == 6 && split_uses_fwd3(a.ntiles, nchunks)) ? split_upfwd_grid_x(a.ntiles, nchunks) : gx;  // workgroup columns that wrote partials
+    const int gcols = (!stacked && g_products == 6 && split_uses_fwd3(a.ntiles, nchunks)) ? split_upfwd_grid_x(a.ntiles, nchunks) : gx;  // workgroup columns that wrote partials
     return synthsr_bn_stats_from_partials(partial, gcols, vox, Cout, stats, (synthsr_stream_t)st);
   }
   if (upm == 2)
@@ -1960,6 +2006,7 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_upfwd(const float
   a.tiles2 = (s[2] + TX - 1) / TX;
   a.ntiles = ((s[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
   a.act = act;
+  a.stacked = 0;
   if (mt == 1) return launch_split_upfwd<1, 4>(a, st);
   if (mt == 2) return launch_split_upfwd<2, 4>(a, st);
   return launch_split_upfwd<3, 2>(a, st);

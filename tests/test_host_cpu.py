@@ -157,7 +157,11 @@ def test_c_abi_exports_every_declared_symbol():
     # packed sizes (query mode).  split arithmetic (the default): 3 pieces x [co-chunk][8-channel chunk][7 K steps][co tiles]
     # fragments of 64 lanes x 8 bf16 (= 4 floats)
     assert _lib.load().synthsr_conv_arithmetic() == 1
+    # (Cout = 24, round 4: the three pieces stacked along M -- [8-channel chunk][7 K steps][5 row tiles] fragments instead of 3 x 2)
+    assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 3 * 7 * 5 * 64 * 4
+    assert _lib.load().synthsr_conv3d_set_option(10, 0) == 0
     assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 3 * 3 * 7 * 2 * 64 * 4
+    assert _lib.load().synthsr_conv3d_set_option(10, 1) == 0
     assert _lib.load().synthsr_conv3d_pack(None, None, _lib.i3([80, 80, 80]), 48, 48, 0, None) == 3 * 6 * 7 * 3 * 64 * 4
     assert _lib.load().synthsr_set_conv_arithmetic(3) == -1
     assert _lib.load().synthsr_set_conv_arithmetic(0) == 0

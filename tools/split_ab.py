@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""A/B of the split-arithmetic conv kernels (synthsr_conv3d_set_option(8, v): 0 = round-3 kernels, 1 = interleaved round-4
-kernels): per layer shape, time of forward (ELU), forward + BatchNorm statistics, data gradient (x ELU'), weight gradient, and
+"""A/B of the split-arithmetic conv kernels (variant code: units digit = synthsr_conv3d_set_option(8, .): 0 = round-3 kernels,
+1 = round-4 kernels, 2 = LDS-weights kernel everywhere; tens digit 1 = stacked 24-channel layout OFF (option 10); >= 100:
+option 9 = --min-wgs): per layer shape, time of forward (ELU), forward + BatchNorm statistics, data gradient (x ELU'), weight gradient, and
 the largest difference between the two variants' results (same arithmetic: expected ~1 ulp of the accumulation).
 
     python tools/split_ab.py [--reps 20] [--only 160_24_24,...] [--variants 0,1]"""
@@ -49,7 +50,8 @@ def main():
         dy = torch.randn(D, D, D, co, device='cuda')
         res, tm = {}, {}
         for v in variants:
-            lib.synthsr_conv3d_set_option(8, v % 100)
+            lib.synthsr_conv3d_set_option(8, v % 10)
+            lib.synthsr_conv3d_set_option(10, 0 if (v // 10) % 10 == 1 else 1)   # tens digit 1: stacked 24-channel layout off
             lib.synthsr_conv3d_set_option(9, a.min_wgs if v >= 100 and a.min_wgs else 0)
             wp, wpd = ops.pack_conv_weights(w, shape, 0), ops.pack_conv_weights(w, shape, 1)
             y = torch.empty(D, D, D, co, device='cuda')
@@ -68,6 +70,7 @@ def main():
             f_wg()
             res[v] = (y.clone(), ys.clone(), dx.clone(), dw.clone(), stats.clone())
         lib.synthsr_conv3d_set_option(8, 1)
+        lib.synthsr_conv3d_set_option(10, 1)
         lib.synthsr_conv3d_set_option(9, 0)
         for k, nm in enumerate(('fwd', 'fwd+st', 'dgrad', 'wgrad')):
             d = ''
