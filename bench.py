@@ -486,8 +486,8 @@ def main():
             pass
         vox = dom['shape'][0] * dom['shape'][1] * dom['shape'][2]
         roofline['algorithmic_bytes'] = 4 * vox * (dom['cin'] + dom['cout'])
-        # the generator against ITS roofline (HBM): compulsory bytes = labels int32 in, image (C_in(+maps)) and
-        # target out, each touched once = 16 B/voxel at configs[1]; per-kernel times from the same HIP events
+        # the generator against ITS roofline (HBM): compulsory bytes = labels in (uint8 in the resident pool), image
+        # (C_in(+maps)) and target out (float32), each touched once = 13 B/voxel at configs[1]; per-kernel times from the same HIP events
         nsteps_prof = min(3, args.steps)
         gen_ms = [v for k, v in gen_agg.items() if k[0] == 'generator']
         roofline_generator = None
@@ -495,10 +495,11 @@ def main():
             ms = float(np.mean(gen_ms[0]))
             key = [k for k in gen_agg if k[0] == 'generator'][0]
             nvox = S ** 3
-            comp = nvox * 4 * (1 + key[2] + key[3])
+            label_bytes = tr.resident_labels[0].element_size()   # the resident pool keeps its maps in the narrowest integer type
+            comp = nvox * (label_bytes + 4 * (key[2] + key[3]))
             roofline_generator = {'bound': 'hbm', 'achieved': round(comp / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
                                   'unit': 'GB/s', 'frac': round(comp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  'compulsory_bytes': comp, 'two_pass_floor_bytes': comp + 8 * nvox,
+                                  'compulsory_bytes': comp, 'label_bytes_per_voxel': label_bytes, 'two_pass_floor_bytes': comp + 8 * nvox,
                                   'ms_per_volume': round(ms, 4),
                                   'kernels_ms': {k[0][4:]: round(float(np.sum(v)) / nsteps_prof, 4)
                                                  for k, v in gen_agg.items() if k[0].startswith('gen:')},

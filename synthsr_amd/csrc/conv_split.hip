@@ -1570,11 +1570,14 @@ int launch_split_fwd2(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st
 }
 
 // which forward kernel (measured, profiles/r04_split_fwd_variants.txt): the 4-wave kernel with two workgroups per CU, except
-// where the layer has fewer than two rounds of its 512 workgroup slots AND several co-chunks (40^3, 96 output channels: 600
-// units): there the 8-wave kernel (one workgroup per CU, weights through LDS) quantises better (-10 %)
+// where the layer has between one and two rounds of its 512 workgroup slots AND several co-chunks (40^3, 96 output channels:
+// 600 units): there the 8-wave kernel (one workgroup per CU, weights through LDS) quantises better (-10 %); with fewer units
+// than slots (20^3, 192 output channels: 200) the 4-wave kernel wins again (0.126 vs 0.14 ms)
 inline bool split_uses_fwd3(int ntiles, int nchunks) {
-  if (g_variant >= 2) return true;
-  return g_variant == 1 && nchunks >= 2 && (int64_t)ntiles * nchunks < 1024;
+  if (g_variant == 2) return true;
+  if (g_variant == 3) return false;  // (A/B: the 4-wave kernel everywhere)
+  const int64_t units = (int64_t)ntiles * nchunks;
+  return g_variant == 1 && nchunks >= 2 && units >= 512 && units < 1024;
 }
 
 template <int MT, bool ST, int EPI>

@@ -114,7 +114,9 @@ def main():
             print('%-40s %s %s  %s ms/step' % (dst, d.get('value'), d.get('unit'), d.get('ms_per_step')))
     for src, dst in (('conv_bf16_bench.txt', T + '_conv_bf16_bench.txt'), ('det_f32.txt', T + '_deterministic_mode_f32.txt'),
                      ('split_check.txt', T + '_split_vs_fp32_mfma_accuracy_and_time.txt'),
-                     ('predict_bench.txt', T + '_predict_bench.txt'),
+                     ('predict_bench.txt', T + '_predict_bench.txt'), ('layer_table.txt', T + '_layer_table.txt'),
+                     ('split_fwd_variants.txt', T + '_split_fwd_variants.txt'), ('split_stacked24_ab.txt', T + '_split_stacked24_ab.txt'),
+                     ('mfma_mix.txt', T + '_mfma_mix_ubench.txt'),
                      ('det_bf16.txt', T + '_deterministic_mode_bf16.txt')):
         if os.path.exists(os.path.join(O, src)):
             shutil.copy(os.path.join(O, src), os.path.join(P, dst))

@@ -34,16 +34,20 @@ out = {'_note': __doc__.split('bench.py reads')[1].strip().replace('\n', ' '),
 # the 160^3 24 -> 24 layers are the LARGEST dispatches of their kernels (the same kernels also run smaller layers)
 # (split arithmetic, the default: conv_split.hip kernels; fp32_mfma: the 4x4x1-MFMA kernels of conv3d.hip)
 # (kernel symbols are matched by prefix: the template argument lists grew -- <24> became <24, 6>: COW, partial products)
+# (round 4: forward / data gradient of the Cout = 24 layers = conv3d_split_fwd2_kernel<2, ST, EPI, true>: EPI 1 / 4 forward,
+#  EPI 2 data gradient)
 for key, kerns, wide in (('conv3d_wgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_wgrad_kernel<24', 'conv3d_wgrad_p4_kernel'), True),
-                         ('conv3d_fwd 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd_kernel<2, false', 'conv3d_fwd_p4_kernel'), True),
-                         ('conv3d_dgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd_kernel<2, false', 'conv3d_fwd_p4_kernel'), True)):
+                         ('conv3d_fwd 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd2_kernel<2, false, 1', 'conv3d_split_fwd_kernel<2, false',
+                                                                    'conv3d_fwd_p4_kernel'), True),
+                         ('conv3d_dgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd2_kernel<2, false, 2', 'conv3d_split_fwd_kernel<2, false',
+                                                                      'conv3d_fwd_p4_kernel'), True)):
     kern = next((k for pre in kerns for k in sorted(fetch) if k.startswith(pre) and k in write), None)
     if kern is None:
         continue
     f, w = max(fetch[kern]), max(write[kern])
     out[key] = {'kernel': kern, 'fetch_kb': round(f, 1), 'write_kb': round(w, 1), 'bytes': int((2 if wide else 1) * f * 1024 + w * 1024)}
 nvox = 160 ** 3
-for kern, alg in (('deform_gmm_kernel', 12), ('normalise_blur2_kernel', 16), ('normalise_gamma_kernel', 8), ('blur3d_kernel', None),
+for kern, alg in (('deform_gmm_kernel', 9), ('normalise_blur2_kernel', 16), ('normalise_gamma_kernel', 8), ('blur3d_kernel', None),
                   ('copy_strided_kernel', 8), ('svf_step_kernel', None), ('resize_kernel', None)):
     if kern not in fetch and kern not in write:
         continue
@@ -57,6 +61,7 @@ for kern, alg in (('deform_gmm_kernel', 12), ('normalise_blur2_kernel', 16), ('n
     out['generator ' + kern] = e
 gen = [v for k, v in out.items() if k.startswith('generator ')]
 out['generator total'] = {'bytes_raw_per_volume': int(sum(v['bytes_raw'] * max(v['launches_per_volume'], 1) for v in gen)),
-                          'compulsory_bytes': 16 * nvox, 'two_pass_floor_bytes': 24 * nvox}
+                          'compulsory_bytes': 13 * nvox, 'two_pass_floor_bytes': 21 * nvox,
+                          'compulsory_note': 'labels uint8 in (resident pool, round 4) + image, reliability map and target float32 out'}
 out['generator total']['bytes_per_voxel_raw'] = round(out['generator total']['bytes_raw_per_volume'] / nvox, 1)
 print(json.dumps(out, indent=1))
