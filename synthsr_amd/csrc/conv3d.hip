@@ -1310,6 +1310,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_c2_kernel(const float* __re
                                                                int act) {
   __shared__ __attribute__((aligned(16))) float lds[FH0 * 6 * FH2 * CIN];
   constexpr int FH1 = 6, FHV = FH0 * FH1 * FH2, NS = (FHV + 255) / 256, Cout = 24;
+  __shared__ __attribute__((aligned(16))) float otile[4 * 64 * Cout];  // output staging: [wave][voxel 64][24]
   constexpr int NG = 27 * CIN * 6, NR = (NG + 15) / 16;
   constexpr uint32_t OOB = 0x80000000u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1386,26 +1387,36 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_c2_kernel(const float* __re
         acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[GG / 16], xq[tap & 1][ci], acc[g], 4, GG % 16, 0);
       });
     });
-    const int gz = z0 + wave, gy = y0 + vy, gx = x0 + vx;
-    if (gz < D0 && gy < D1 && gx < D2) {
-      const size_t o = (((size_t)gz * D1 + gy) * D2 + gx) * Cout;
+    // Epilogue through LDS (round 4): a lane holds the 24 channels of ONE voxel, so a float4 store per lane wrote 64 pieces of
+    // 16 bytes 96 bytes apart (this kernel is bound by its 393 MB of output: 2.4 TB/s).  The wave's 64 voxels x 96 B are four
+    // x-rows of 1536 contiguous bytes each in memory: written to the wave's own 6 KB of LDS voxel by voxel and read back as 384
+    // consecutive 16-byte pieces, six per lane, every store instruction covers 1 KB of consecutive addresses.
+    float* ot = otile + wave * (64 * Cout);
 #pragma unroll
-      for (int g = 0; g < 6; ++g) {
-        float4 v = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-        if (bias) {
-          v.x += bias[4 * g];
-          v.y += bias[4 * g + 1];
-          v.z += bias[4 * g + 2];
-          v.w += bias[4 * g + 3];
-        }
-        if (act == 1) {
-          v.x = elu_f(v.x);
-          v.y = elu_f(v.y);
-          v.z = elu_f(v.z);
-          v.w = elu_f(v.w);
-        }
-        *reinterpret_cast<float4*>(out + o + 4 * g) = v;
+    for (int g = 0; g < 6; ++g) {
+      float4 v = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+      if (bias) {
+        v.x += bias[4 * g];
+        v.y += bias[4 * g + 1];
+        v.z += bias[4 * g + 2];
+        v.w += bias[4 * g + 3];
       }
+      if (act == 1) {
+        v.x = elu_f(v.x);
+        v.y = elu_f(v.y);
+        v.z = elu_f(v.z);
+        v.w = elu_f(v.w);
+      }
+      *reinterpret_cast<float4*>(ot + lane * Cout + 4 * g) = v;
+    }
+    const int gz = z0 + wave;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int q = lane + 64 * k;           // 16-byte piece of the wave's tile: row q / 96, piece c of the row
+      const int r = q / 96, c = q - r * 96;
+      const float4 v = *reinterpret_cast<const float4*>(ot + q * 4);
+      if (gz < D0 && y0 + r < D1 && x0 + c / 6 < D2)
+        *reinterpret_cast<float4*>(out + (((size_t)gz * D1 + y0 + r) * D2 + x0) * Cout + c * 4) = v;
     }
   }
 }
