@@ -95,9 +95,11 @@ class LabelsToImageModel:
         self.flipping = flipping
         if flipping:
             assert aff is not None, 'aff should not be None if flipping is True'
-            if int(hm.get_ras_axes(aff, 3)[0]) != 0:
-                # RandomFlip reverses the axis at POSITION 0 of flip_axes (F10); SynthSR always passes eye(4)
-                raise NotImplementedError('flipping is only supported for RAS-aligned label maps (aff=eye(4))')
+            # labels_to_image_model.py:154-162 hands RandomFlip the right/left axis of `aff`, but the vendored RandomFlip
+            # reverses the axis at the POSITION of that entry inside flip_axes (ext/lab2im/layers.py:398-400,424-427; SURVEY
+            # F10) -- a one-element list, position 0: the reference flips axis 0 whatever the affine says, and so does the
+            # kernel (pinned by the graph_nonras_* goldens, generated by the reference with a non-RAS aff)
+            hm.get_ras_axes(aff, 3)   # (validates aff like the reference does)
         self.swap_lut = hm.flip_swap_lut(self.generation_labels, n_neutral_labels) if flipping else None
         # a (2n, m) array of bounds: ONE of its n two-row blocks serves the whole model, picked with numpy's global stream
         # while the graph is built (utils.draw_value_from_distribution, ext/lab2im/utils.py:1013-1016, called by

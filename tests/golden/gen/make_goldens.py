@@ -208,7 +208,7 @@ def golden_layers():
     print('layers.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
 
 
-def run_graph(name, labels, means, stds, seed, real_image=None, **kw):
+def run_graph(name, labels, means, stds, seed, real_image=None, aff=None, **kw):
     """whole labels_to_image_model() graph (SynthSR/labels_to_image_model.py:32-266)"""
     tape = shim.Tape(seed=seed)
     shim.set_tape(tape)
@@ -219,7 +219,7 @@ def run_graph(name, labels, means, stds, seed, real_image=None, **kw):
     model = ref_l2i_model.labels_to_image_model(labels_shape=list(labels.shape[1:4]),
                                                 generation_labels=GEN_LABELS,
                                                 n_neutral_labels=len(GEN_LABELS),
-                                                aff=np.eye(4), **kw)
+                                                aff=np.eye(4) if aff is None else aff, **kw)
     image, target = model.outputs
     out = dict(labels=labels, means=means, stds=stds, image=np.asarray(image), target=np.asarray(target),
                seg=np.asarray(NAMED['segmentation_target']))
@@ -355,6 +355,23 @@ def golden_separable_blur():
     print('separable', out['sep_fixed'].shape)
 
 
+def golden_nonras():
+    """the whole graph with a NON-RAS `aff` and flipping (labels_to_image_model.py:154-162 hands RandomFlip the RAS axis of
+    `aff`; the vendored RandomFlip reverses the axis at the POSITION of that entry in flip_axes, i.e. axis 0 whatever the
+    affine says -- SURVEY F10): two tapes, one that flips and one that does not"""
+    rng = np.random.default_rng(77)
+    kw = dict(atlas_res=[1., 1., 1.], target_res=None, output_div_by_n=32, padding_margin=None, flipping=True,
+              scaling_bounds=.15, rotation_bounds=15, shearing_bounds=.02, translation_bounds=5, nonlin_std=4.,
+              nonlin_shape_factor=.125, simulate_registration_error=True, randomise_res=False, data_res=None, thickness=None,
+              downsample=True, build_reliability_maps=True, blur_range=1.15, bias_field_std=.3, bias_shape_factor=.125)
+    lab = load_label_crop(2, (60, 74, 60), (32, 32, 32))[None, ..., None]
+    means, stds = class_stats(rng)
+    aff = np.array([[0., 0., -1., 90.], [1., 0., 0., -126.], [0., -1., 0., 72.], [0., 0., 0., 1.]])   # PIL-like: x <- -k, y <- i, z <- -j
+    for seed in (171, 175):
+        run_graph('graph_nonras_s%d' % seed, lab, means, stds, seed, aff=aff, input_channels=[True], output_channel=[0],
+                  output_shape=32, **kw)
+
+
 def golden_metrics():
     """SynthSR/metrics_model.py:27-132 (`metrics_model`) run verbatim on a stand-in input model: l1 / l2 / laplace, with
     and without loss_cropping and work_with_residual_channel"""
@@ -456,3 +473,5 @@ if __name__ == '__main__':
         golden_layers()
     if 'graphs' in which:
         golden_graphs()
+    if 'nonras' in which or not sys.argv[1:]:
+        golden_nonras()

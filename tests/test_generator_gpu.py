@@ -99,6 +99,23 @@ def test_whole_graph_config2_vs_golden(env, name):
     np.testing.assert_allclose(target.cpu().numpy(), g['target'][0], atol=2e-5)
 
 
+@pytest.mark.parametrize('name', ['graph_nonras_s171', 'graph_nonras_s175'])
+def test_whole_graph_non_ras_affine_vs_golden(env, name):
+    """flipping with a NON-RAS `aff` (x <- -k, y <- i, z <- -j): the reference's RandomFlip reverses axis 0 whatever the affine
+    says, goldens generated by the reference's own graph; s175 flips, s171 does not"""
+    from synthsr_amd.labels_to_image_model import labels_to_image_model
+    g = load_golden(name)
+    aff = np.array([[0., 0., -1., 90.], [1., 0., 0., -126.], [0., -1., 0., 72.], [0., 0., 0., 1.]])
+    m = labels_to_image_model(labels_shape=list(g['labels'].shape[1:4]), generation_labels=GEN, n_neutral_labels=len(GEN),
+                              aff=aff, output_shape=32, input_channels=[True], output_channel=[0], **C2_KW)
+    draws = m.draws_from_tape(tape_from_golden(g))
+    assert (float(np.asarray(draws.u_flip).reshape(-1)[0]) < 0.5) == (name == 'graph_nonras_s175')
+    image, target, seg = m.generate(g['labels'][0, ..., 0], g['means'][0], g['stds'][0], draws)
+    np.testing.assert_array_equal(seg.cpu().numpy(), g['seg'][0, ..., 0])
+    np.testing.assert_allclose(image.cpu().numpy(), g['image'][0], atol=2e-5)
+    np.testing.assert_allclose(target.cpu().numpy(), g['target'][0], atol=2e-5)
+
+
 @pytest.mark.parametrize('name,margin,real', [('graph_pad_s161', 4, False), ('graph_pad_s162', [2, 4, 6], False),
                                               ('graph_real_pad_s163', 4, True)])
 def test_whole_graph_padding_margin_vs_golden(env, name, margin, real):

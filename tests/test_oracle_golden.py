@@ -158,6 +158,16 @@ def test_whole_graph_config2(name, gen_labels):
     assert np.all(out['image'][..., 1] == 1)  # reliability map of a non-downsampled channel
 
 
+@pytest.mark.parametrize('name', ['graph_nonras_s171', 'graph_nonras_s175'])
+def test_whole_graph_non_ras_affine_flips_axis_0(name, gen_labels):
+    """goldens produced by the reference's graph with a NON-RAS aff: its RandomFlip reverses axis 0 whatever the affine says
+     -- which is what the oracle (and the kernel) do; s175's tape flips, s171's does not"""
+    g, out = _run_graph(name, gen_labels, input_channels=[True], output_channel=[0])
+    np.testing.assert_array_equal(out['seg'], g['seg'][0, ..., 0])
+    np.testing.assert_allclose(out['image'], g['image'][0], atol=5e-6)
+    np.testing.assert_allclose(out['target'], g['target'][0], atol=5e-6)
+
+
 @pytest.mark.parametrize('name,margin,real', [('graph_pad_s161', 4, False), ('graph_pad_s162', [2, 4, 6], False),
                                               ('graph_real_pad_s163', 4, True)])
 def test_whole_graph_padding_margin(name, margin, real, gen_labels):
