@@ -62,7 +62,7 @@ typedef struct {
   int has_affine;     /* affine part present (else position = x + u, ext/neuron/layers.py:148-149) */
   int half_shape[3];  /* shape of the integrated half-resolution SVF */
   float aff[12];      /* affine rows 0..2 (identity if no affine) */
-  int n_channels;     /* synthetic channels (<= 4) */
+  int n_channels;     /* synthetic channels of this launch (<= 4; see chan_first) */
   int lut_size;       /* max(generation_labels)+1 */
   int swap_lut_size;  /* 0 = no L/R swap LUT */
   /* per-channel post-ops fused behind the GMM (BiasFieldCorruption layers.py:1067-1097 and the
@@ -73,6 +73,10 @@ typedef struct {
   int use_philox;       /* 0: noise buffer, 1: in-kernel Philox4x32-10 */
   uint32_t philox_key[2];
   uint64_t philox_offset;
+  int chan_first;        /* models with more than 4 synthetic channels run one launch per group of four: first channel of */
+  int n_channels_total;  /* this launch (a multiple of 4) and the channel count of the whole model = rows of gmm_lut / of a
+                          * noise tape; 0 = this launch carries all channels.  chan_out, minmax, bias_on / bias_shape and
+                          * bias_small are the GROUP's; in-kernel noise: the group index enters the Philox counter */
   int label_bytes;    /* element size of `labels`: 0 or 4 = int32 (the reference's label maps), 1 = uint8, 2 = int16 (a label
                        * pool kept on the device in the narrowest type its values fit: model_inputs.py:104-107 loads them as int) */
 } synthsr_deform_params;

@@ -31,15 +31,16 @@ def box_muller(r0, r1):
 
 
 def normals(n_vox, n_channels, key, offset):
-    """noise [n_vox, n_channels] exactly as deform_gmm_kernel draws it: counter = (voxel, offset)"""
+    """noise [n_vox, n_channels] exactly as deform_gmm_kernel draws it: counter = (voxel, offset); channels 4 g .. 4 g + 3 (one
+    kernel launch per group of four) come from the counter whose last word carries g in its bits 16 and up"""
     v = np.arange(n_vox, dtype=np.uint64)
     c0, c1 = v & MASK, v >> np.uint64(32)
     c2 = np.full(n_vox, np.uint64(offset) & MASK)
-    c3 = np.full(n_vox, np.uint64(offset) >> np.uint64(32))
-    r = philox4x32_10(c0, c1, c2, c3, int(key[0]), int(key[1]))
-    n0, n1 = box_muller(r[0], r[1])
-    out = [n0, n1]
-    if n_channels > 2:
+    out = []
+    for grp in range((n_channels + 3) // 4):
+        c3 = np.full(n_vox, ((np.uint64(offset) >> np.uint64(32)) + np.uint64(grp << 16)) & MASK)
+        r = philox4x32_10(c0, c1, c2, c3, int(key[0]), int(key[1]))
+        n0, n1 = box_muller(r[0], r[1])
         n2, n3 = box_muller(r[2], r[3])
-        out += [n2, n3]
+        out += [n0, n1, n2, n3]
     return np.stack(out[:n_channels], -1).astype(np.float32)

@@ -24,7 +24,8 @@ class DeformParams(Structure):
                 ('has_field', c_int), ('has_affine', c_int), ('half_shape', c_int * 3), ('aff', c_float * 12),
                 ('n_channels', c_int), ('lut_size', c_int), ('swap_lut_size', c_int), ('bias_on', c_int * 4),
                 ('bias_shape', (c_int * 3) * 4), ('clip_hi', c_float), ('use_philox', c_int),
-                ('philox_key', c_uint32 * 2), ('philox_offset', c_uint64), ('label_bytes', c_int)]
+                ('philox_key', c_uint32 * 2), ('philox_offset', c_uint64), ('chan_first', c_int), ('n_channels_total', c_int),
+                ('label_bytes', c_int)]
 
 
 _P = c_void_p

@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
                                                          synthsr_deform_params p) {
   const int64_t n = (int64_t)p.out_shape[0] * p.out_shape[1] * p.out_shape[2];
   const int C = p.n_channels;
+  // more than four synthetic channels: one launch per group of four (chan_first = 4 k); Ct = channels of the whole model (the
+  // rows of the GMM LUT and of a noise tape), 0 = this launch has them all
+  const int Ct = p.n_channels_total > 0 ? p.n_channels_total : C, c00 = p.n_channels_total > 0 ? p.chan_first : 0;
   float lmin[4], lmax[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -304,20 +307,20 @@ __global__ __launch_bounds__(256) void deform_gmm_kernel(const int32_t* __restri
     float nz[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.use_philox) {
       uint32_t c[4] = {(uint32_t)o, (uint32_t)((uint64_t)o >> 32), (uint32_t)p.philox_offset,
-                       (uint32_t)(p.philox_offset >> 32)};
+                       (uint32_t)(p.philox_offset >> 32) + ((uint32_t)(c00 >> 2) << 16)};  // channel group in the counter
       philox4x32_10(c, p.philox_key[0], p.philox_key[1]);
       box_muller(c[0], c[1], nz[0], nz[1]);
       if (C > 2) box_muller(c[2], c[3], nz[2], nz[3]);
     } else {
-      for (int c = 0; c < C; ++c) nz[c] = noise[o * C + c];
+      for (int c = 0; c < C; ++c) nz[c] = noise[o * Ct + c00 + c];
     }
     const bool known = (lab >= 0 && lab < p.lut_size);
     int boff = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c < C) {
-        const float mu = known ? gmm_lut[c * p.lut_size + lab] : 0.f;
-        const float sd = known ? gmm_lut[(C + c) * p.lut_size + lab] : 0.f;
+        const float mu = known ? gmm_lut[(c00 + c) * p.lut_size + lab] : 0.f;
+        const float sd = known ? gmm_lut[(Ct + c00 + c) * p.lut_size + lab] : 0.f;
         float x = sd * nz[c] + mu;  // layers.py:498
         const int b0 = p.bias_shape[c][0], b1 = p.bias_shape[c][1], b2 = p.bias_shape[c][2];
         if (b0 > 0) {
@@ -626,6 +629,8 @@ int synthsr_deform_gmm_real(const int32_t* labels, const float* field_half, cons
   if (bad_shape(p->in_shape) || bad_shape(p->out_shape)) return SYNTHSR_EINVAL;
   if (p->n_channels < 1 || p->n_channels > 4 || p->lut_size < 1) return SYNTHSR_EINVAL;
   if (p->label_bytes != 0 && p->label_bytes != 1 && p->label_bytes != 2 && p->label_bytes != 4) return SYNTHSR_EINVAL;
+  if (p->n_channels_total != 0 && (p->chan_first < 0 || (p->chan_first & 3) || p->chan_first + p->n_channels > p->n_channels_total))
+    return SYNTHSR_EINVAL;
   if (p->has_field && (!field_half || bad_shape(p->half_shape))) return SYNTHSR_EINVAL;
   if (!p->use_philox && !noise) return SYNTHSR_EINVAL;
   if (p->swap_lut_size > 0 && !swap_lut) return SYNTHSR_EINVAL;

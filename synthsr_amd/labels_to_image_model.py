@@ -122,8 +122,7 @@ class LabelsToImageModel:
         self.bias_shape_factor = bias_shape_factor
         self.small_bias_shape = hm.get_resample_shape(self.crop_shape, bias_shape_factor)
         self.resample_target = self.crop_shape != self.output_shape
-        if n_channels > 4:
-            raise NotImplementedError('at most 4 synthetic channels')
+        # (more than 4 synthetic channels: the fused deformation / GMM kernel runs once per group of four)
 
         # ---- output layout
         self.n_image_channels = sum(input_channels) * (2 if build_reliability_maps else 1)
@@ -375,20 +374,18 @@ class LabelsToImageModel:
         off_bias = None
         gates = []
         bias_grids = []  # deform_gmm_kernel walks the grids back to back (boff += b0*b1*b2): ONE contiguous block
+        bias_on_all, bias_elems_before = [], []   # per channel: gate (None = no bias grid), floats of the grids in front of it
         for i in range(C):
             ch = d.channels[i]
+            bias_elems_before.append(sum(g_.size for g_ in bias_grids))
             if self.input_channels[i] and self.bias_field_std > 0:
                 bstd = hm.uniform_f32(ch['u_bias_std'], 0., self.bias_field_std)  # layers.py:1080
                 bias_grids.append((np.asarray(ch['n_bias'], np.float32) * bstd).reshape(-1))
                 gate = bool(np.float32(ch['u_bias_gate']) < np.float32(0.95))  # :1090
-                p.bias_on[i] = int(gate)
-                for k in range(3):
-                    p.bias_shape[i][k] = self.small_bias_shape[k]
+                bias_on_all.append(gate)
                 gates.append(gate)
             else:
-                p.bias_on[i] = 0
-                for k in range(3):
-                    p.bias_shape[i][k] = 0
+                bias_on_all.append(None)
         if bias_grids:
             off_bias = sm.put(np.concatenate(bias_grids))
         p.clip_hi = 300.0  # IntensityAugmentation(clip=300), labels_to_image_model.py:184
@@ -465,14 +462,27 @@ class LabelsToImageModel:
         real_mm = ctypes.c_void_p(self.d_minmax.data_ptr() + 8 * C)
         _t_dg = tk('gen:deform_gmm')
         _t_dg.__enter__()
-        _lib.check(lib.synthsr_deform_gmm_real(
-            _lib.ptr(d_labels), _lib.ptr(self.d_svf) if self.apply_elastic else None, sm.dptr(off_lut),
-            _lib.ptr(self.d_swap) if self.d_swap is not None else None,
-            _lib.ptr(self.d_noise) if not p.use_philox else None,
-            sm.dptr(off_bias) if off_bias is not None else None, _lib.ptr(self.d_seg), _lib.ptr(self.d_chan),
-            _lib.ptr(self.d_minmax), _lib.ptr(self.d_real_in) if self.use_real_image else None,
-            _lib.ptr(self.d_real) if self.use_real_image else None, real_mm if self.use_real_image else None,
-            ctypes.byref(p), st), 'deform_gmm')
+        for c0 in range(0, C, 4):   # one launch per group of four channels (the label gather / real image ride in the first)
+            p.n_channels = min(4, C - c0)
+            p.chan_first, p.n_channels_total = c0, (C if C > 4 else 0)
+            for j in range(4):
+                on = bias_on_all[c0 + j] if c0 + j < C else None
+                p.bias_on[j] = int(bool(on)) if on is not None else 0
+                for k in range(3):
+                    p.bias_shape[j][k] = self.small_bias_shape[k] if on is not None else 0
+            first = c0 == 0
+            _lib.check(lib.synthsr_deform_gmm_real(
+                _lib.ptr(d_labels), _lib.ptr(self.d_svf) if self.apply_elastic else None, sm.dptr(off_lut),
+                _lib.ptr(self.d_swap) if self.d_swap is not None else None,
+                _lib.ptr(self.d_noise) if not p.use_philox else None,
+                sm.dptr(off_bias + bias_elems_before[c0]) if off_bias is not None else None,
+                _lib.ptr(self.d_seg) if first else None,
+                ctypes.c_void_p(self.d_chan.data_ptr() + 4 * c0 * self.ncrop),
+                ctypes.c_void_p(self.d_minmax.data_ptr() + 8 * c0),
+                _lib.ptr(self.d_real_in) if (self.use_real_image and first) else None,
+                _lib.ptr(self.d_real) if (self.use_real_image and first) else None,
+                real_mm if (self.use_real_image and first) else None,
+                ctypes.byref(p), st), 'deform_gmm')
         _t_dg.__exit__()
 
         nc, no = self.ncrop, self.nout

@@ -517,3 +517,63 @@ def test_fused_normalise_blur_blur_is_bit_identical(env, shape):
     assert torch.equal(outs[0][1], outs[1][1]), (outs[0][1] - outs[1][1]).abs().max().item()
     assert torch.equal(outs[0][0], outs[1][0]), (outs[0][0] - outs[1][0]).abs().max().item()
     assert (outs[0][0][..., 1] == 1).all()
+
+
+def test_six_synthetic_channels_vs_oracle(env):
+    """more than four synthetic channels (the reference has no limit, SynthSR/labels_to_image_model.py:164-176; round 4: the
+    fused deformation / GMM kernel runs once per group of four channels): six channels, four of them inputs with bias
+    fields, two with simulated registration error, against the oracle on a fresh tape -- labels bit-exact; and the in-kernel
+    Philox stream of channels 4 and 5 (second group: its index enters the counter) against oracle/philox_ref"""
+    torch, _lib, lib = env
+    from conftest import random_tape
+    from oracle import generator_ref as R
+    from oracle import philox_ref
+    from synthsr_amd.labels_to_image_model import labels_to_image_model
+    rng = np.random.default_rng(66)
+    shape = (32, 32, 32)
+    labels = np.kron(np.asarray(GEN)[rng.integers(0, len(GEN), (8, 8, 8))], np.ones((4, 4, 4), np.int32)).astype(np.int32)
+    ic = [True, False, True, True, False, True]
+    kw = dict(C2_KW)
+    m = labels_to_image_model(labels_shape=list(shape), input_channels=ic, output_channel=[1, 4], generation_labels=GEN,
+                              n_neutral_labels=len(GEN), aff=np.eye(4), output_shape=32, **kw)
+    means = rng.uniform(20, 220, (len(GEN), 6)).astype(np.float32)
+    stds = rng.uniform(2, 20, (len(GEN), 6)).astype(np.float32)
+    tape = random_tape(m, rng)
+    ref = R.labels_to_image(labels, means, stds, tape, GEN, len(GEN), input_channels=ic, output_channel=[1, 4],
+                            output_shape=32, **kw)
+    image, target, seg = m.generate(labels, means, stds, m.draws_from_tape(tape))
+    np.testing.assert_array_equal(seg.cpu().numpy(), ref['seg'])
+    assert image.shape[-1] == 8 and target.shape[-1] == 2
+    np.testing.assert_allclose(image.cpu().numpy(), ref['image'], atol=2e-4)   # registered channels: a 4x4 inverse
+    np.testing.assert_allclose(target.cpu().numpy(), ref['target'], atol=2e-5)
+    # in-kernel noise of a 6-channel model: planar channel buffer after the fused kernel with mu = 0, sigma = 1 is not
+    # reachable through generate(); use the C ABI as test_philox_noise_per_voxel does, second group only
+    import ctypes
+    from synthsr_amd import host_math as hm
+    n = int(np.prod(shape))
+    key, offset = (0x1234abcd, 0x9e3779b9), 777
+    p = _lib.DeformParams()
+    p.in_shape[:] = shape
+    p.out_shape[:] = shape
+    p.crop[:] = [0, 0, 0]
+    p.flip = p.has_field = p.has_affine = 0
+    p.aff[:] = [float(v) for v in np.eye(4, dtype=np.float32)[:3].reshape(-1)]
+    p.n_channels, p.chan_first, p.n_channels_total = 2, 4, 6
+    p.lut_size, p.swap_lut_size, p.clip_hi, p.use_philox = 2, 0, 0.0, 1
+    p.philox_key[0], p.philox_key[1] = key
+    p.philox_offset = offset
+    lut = dev(torch, hm.gmm_luts(np.array([0, 1]), np.zeros((2, 6), np.float32), np.ones((2, 6), np.float32)).reshape(-1))
+    lab1 = torch.ones(n, dtype=torch.int32, device='cuda')
+    chan = torch.empty(2 * n, dtype=torch.float32, device='cuda')
+    mm = torch.empty(2 * 2 + 2, dtype=torch.int32, device='cuda')
+    _lib.check(lib.synthsr_minmax_init(_lib.ptr(mm), 3, None), 'minmax_init')
+    _lib.check(lib.synthsr_deform_gmm(_lib.ptr(lab1), None, _lib.ptr(lut), None, None, None, None, _lib.ptr(chan),
+                                      _lib.ptr(mm), ctypes.byref(p), None), 'deform_gmm')
+    want = philox_ref.normals(n, 6, key, offset)[:, 4:6]
+    got = chan.cpu().numpy().reshape(2, n).T
+    assert np.abs(got - want).max() < 3e-6
+    first = philox_ref.normals(n, 4, key, offset)
+    assert np.abs(want[:, 0] - first[:, 0]).max() > 1.0   # a different stream from the first group's
+    p.chan_first = 2
+    assert lib.synthsr_deform_gmm(_lib.ptr(lab1), None, _lib.ptr(lut), None, None, None, None, _lib.ptr(chan), _lib.ptr(mm),
+                                  ctypes.byref(p), None) == -1   # groups start at multiples of four
