@@ -652,17 +652,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
   using I4 = std::integral_constant<int, 4>;
 
   f32x4 acc[TY][NWT];
-  f32x4 ev, eb;
-  uint32_t eoff;
-  // epilogue item j = (mt, y) of the finished tile, in three segments
+  f32x4 ev, eb[2];
+  uint32_t eoff[2];
+  // epilogue item j = (mt, y) of the finished tile, in three segments; the addend of item j + 1 is requested before item j is
+  // worked on (two slots: its HBM latency hides behind an item's ELU / stores instead of being exposed eight times per tile)
   auto epi0 = [&](int j, uint32_t row0, uint32_t yok) {
     const int mt = j / TY, y = j % TY;
     const int co = (chunk * MT + mt) * 16 + 4 * g;
 #if SYN_ABL & 32
     yok = 0;
 #endif
-    eoff = (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;
-    if constexpr (EPI >= 2) eb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)eoff, 0, 0));
+    eoff[j & 1] = (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;
+    if constexpr (EPI >= 2)
+      eb[j & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)eoff[j & 1], 0, 0));
   };
   auto epi1 = [&](int j) {
     const int mt = j / TY, y = j % TY;
@@ -683,11 +685,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
     for (int i = 0; i < 4; ++i) v[i] += bj[i];
     if constexpr (EPI == 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] *= elu_dy(eb[i]);
+      for (int i = 0; i < 4; ++i) v[i] *= elu_dy(eb[j & 1][i]);
     }
     if constexpr (EPI == 3 || EPI == 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += eb[i];
+      for (int i = 0; i < 4; ++i) v[i] += eb[j & 1][i];
     }
     if constexpr (EPI == 1 || EPI == 4) {
 #pragma unroll
@@ -696,10 +698,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
     ev = v;
   };
   auto epi2 = [&](int j) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), rout, (int)eoff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), rout, (int)eoff[j & 1], 0, 0);
     if constexpr (ST) {
       const int mt = j / TY;
-      const float w = eoff != OOB ? 1.f : 0.f;
+      const float w = eoff[j & 1] != OOB ? 1.f : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float r = w * ev[i];
@@ -871,9 +873,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
     uint32_t yok = 0;
 #pragma unroll
     for (int y = 0; y < TY; ++y) yok |= (zx_ok && (y0 + y) < D1) ? (1u << y) : 0u;
+    epi0(0, row0, yok);
 #pragma unroll
     for (int j = 0; j < NITEM; ++j) {
-      epi0(j, row0, yok);
+      if (j + 1 < NITEM) epi0(j + 1, row0, yok);
       epi1(j);
       epi2(j);
     }
