@@ -2928,13 +2928,14 @@ extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias
                              const int s[3], int Cin, int Cout, int mt, int nchunks, int act, float* stats, float* partial,
                              int upm, int stacked, hipStream_t st);
 static int g_arith = 1;  // synthsr_set_conv_arithmetic: 0 fp32_mfma, 1 split, 2 split9
+static int g_split_wgrad_min_tiles = 1;  // option 11: smallest layer (4x4x16 tiles) whose weight gradient takes the split kernel (round 3: 256; the 20^3 / 10^3 layers gain 4-29 %, profiles/r04_split_wgrad_deep_levels.txt)
 static int g_stack24 = 1;  // option 10: stacked weight layout (10 instead of 12 MFMAs per K step) for the plain Cout = 24 split convs
 
 // does the weight gradient of a plain 3x3x3 conv take the split kernel (conv_split.hip: syn_split_wgrad)?  One place: the
 // dispatcher and the query synthsr_conv3d_wgrad_runs_split (what the benchmarks price a layer against) both ask here
 inline bool wgrad_takes_split(const int s[3], int Cin, int Cout) {
   const int64_t vox = (int64_t)s[0] * s[1] * s[2];
-  return g_split && (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) >= 256 && (Cin % 8) == 0 && (Cout % 24) == 0 &&
+  return g_split && (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) >= g_split_wgrad_min_tiles && (Cin % 8) == 0 && (Cout % 24) == 0 &&
          vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31);
 }
 
@@ -4044,6 +4045,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 10) {
     g_stack24 = value ? 1 : 0;
+    return SYNTHSR_OK;
+  }
+  if (option == 11) {
+    g_split_wgrad_min_tiles = value > 0 ? value : 1;
     return SYNTHSR_OK;
   }
   if (option == 9) {

@@ -240,7 +240,7 @@ def test_conv_arithmetic_switch_and_layer_plans():
     assert ops.conv_runs_split('conv3d_fwd', (20, 20, 20), 192, 192)      # round 4: 50 tiles x 4 co-chunks = 200 workgroups
     assert not ops.conv_runs_split('conv3d_fwd', (20, 20, 20), 192, 96)   # 100 workgroups: fp32 MFMA kernels
     assert not ops.conv_runs_split('conv3d_fwd', (10, 10, 10), 384, 384)
-    assert not ops.conv_runs_split('conv3d_wgrad', (20, 20, 20), 192, 192)
+    assert ops.conv_runs_split('conv3d_wgrad', (20, 20, 20), 192, 192)    # round 4: the split weight gradient at every size
     assert not ops.conv_runs_split('conv3d_wgrad', big, 2, 24) and not ops.conv_runs_split('conv3d_wgrad', big, 24, 16)
     assert ops.conv_runs_split('conv3d_up_fwd', (80, 80, 80), 48, 24)     # folded decoder conv, up-sampled channels (low-res grid)
     assert ops.conv_runs_split('conv3d_up_dgrad', (80, 80, 80), 48, 24)
