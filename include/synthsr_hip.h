@@ -356,6 +356,20 @@ int synthsr_bn_elu_bwd_head(const float* dpred, const float* whead, const float*
                             int C, const float* stats, const float* gamma, float eps, const float* sums,
                             synthsr_stream_t stream);
 
+/* Feature-wise dropout with ONE MASK PER SAMPLE of a batch (KL.Dropout(rate, noise_shape=[None, 1, 1, 1, C]),
+ * ext/neuron/models.py:320-324, 448-451; `batchsize > 1` together with `dropout > 0`): the volumes of a batch are stacked
+ * along the first axis (nvox_per_sample voxels each), scale [B][C] holds 0 or 1 / (1 - rate).
+ *   synthsr_scale_channels: out[v][c] = x[v][c] * scale[sample(v)][c] (the dropped-out tensor, or a gradient; in place allowed)
+ *   synthsr_elu_bwd_drop:   the three ELU-backward entry points above for a conv output y whose consumer (the next conv, or the
+ *     BatchNorm when stats / gamma / sums are given; dpred / whead: the rank-1 gradient of the head) read d = scale * y: the
+ *     incoming gradient is w.r.t. d (BatchNorm: x-hat from d), is multiplied by scale, dy2 (the skip connection reads y itself)
+ *     is added unscaled, then * ELU'(y); dbias += sum dz */
+int synthsr_scale_channels(const float* x, float* out, int64_t nvox, int C, const float* scale, int64_t nvox_per_sample,
+                           synthsr_stream_t stream);
+int synthsr_elu_bwd_drop(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
+                         const float* stats, const float* gamma, float eps, const float* sums, const float* dpred,
+                         const float* whead, const float* drop, int64_t nvox_per_sample, synthsr_stream_t stream);
+
 /* BatchNormalization(axis=-1), training mode (models.py:351,477; Keras 2.3.1 semantics, eps=1e-3):
  * stats[0..C) = mean, stats[C..2C) = biased variance over the nvox voxels */
 int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* ws /* 2C doubles scratch */,

@@ -66,6 +66,13 @@ def round_bf16(x):
     return _RoundBF16.apply(x)
 
 
+def _drop_factor(s, t):
+    """per-feature dropout factor [C], or one per sample and feature [B, C] for a batch t [B, d0, d1, d2, C]
+    (KL.Dropout(noise_shape=[None, 1, 1, 1, C]), ext/neuron/models.py:320-324)"""
+    s = torch.as_tensor(s, dtype=t.dtype)
+    return s.reshape(s.shape[0], 1, 1, 1, s.shape[1]) if s.dim() == 2 else s
+
+
 def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, collect=None, softmax=False, quant=None,
                  dropout=None, pool_inputs=None, pool_nudge=None):
     """P: dict name -> tensor with the Keras layer names (`<prefix>_conv_downarm_l_k/kernel`, ...).
@@ -101,7 +108,7 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
         for k in range(nconv):
             nm = '%s_conv_downarm_%d_%d' % (prefix, l, k)
             pre = q(F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias'])))
-            cur = pre * dropout[nm] if dropout is not None else pre
+            cur = pre * _drop_factor(dropout[nm], pre) if dropout is not None else pre
         skips.append(pre)  # pre-BN (and pre-dropout) skip: the conv layer's output (models.py:431-432)
         cur = bn(cur, '%s_bn_down_%d' % (prefix, l))
         if l < L - 1:
@@ -117,7 +124,7 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
             nm = '%s_conv_uparm_%d_%d' % (prefix, L + k, j)
             cur = q(F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias'])))
             if dropout is not None:
-                cur = cur * dropout[nm]
+                cur = cur * _drop_factor(dropout[nm], cur)
         cur = bn(cur, '%s_bn_up_%d' % (prefix, k))
     w, b = P['%s_likelihood/kernel' % prefix], P['%s_likelihood/bias' % prefix]
     out = cur @ w.reshape(w.shape[-2], w.shape[-1]) + b
@@ -135,7 +142,7 @@ def dice_loss(gt, pred, eps=1e-7):
 
 def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, generation_labels, label_equivalency,
                        m=None, M=None, fs_header=False, loss_cropping=None, pool_inputs=None, pool_nudge=None,
-                       bn_batch_stats=False):
+                       bn_batch_stats=False, dropout=None):
     """SynthSR/metrics_model.py:136-215 (add_seg_loss_to_model) for one volume: the predicted image [d0,d1,d2] is
     normalised (:152-155), optionally permuted / flipped to the FreeSurfer orientation (:158-163), pushed through the
     FROZEN segmentation U-Net (softmax head; BatchNorm on its moving averages, or with bn_batch_stats on batch statistics) and
@@ -150,8 +157,10 @@ def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, g
         x = torch.flip(x.permute(0, 2, 1, 3), dims=[1])
     # bn_batch_stats: the frozen network's BatchNormalization layers use the statistics of the current activations (Keras
     # 2.3.1 with the learning phase set, `trainable = False` notwithstanding) instead of their moving averages
+    # dropout: factors of the frozen network's own Dropout layers (it is built with conv_dropout=dropout, training.py:381,
+    # and the learning phase switches them on whatever `trainable` says)
     probs = unet_forward(x, Pseg, prefix, nb_levels, nconv, training=bool(bn_batch_stats), moving=Pseg, softmax=True,
-                         pool_inputs=pool_inputs, pool_nudge=pool_nudge)
+                         pool_inputs=pool_inputs, pool_nudge=pool_nudge, dropout=dropout)
     if fs_header:
         probs = torch.flip(probs, dims=[1]).permute(0, 2, 1, 3)
     if loss_cropping is not None:  # :166-183: posteriors and label map cropped to the centred box

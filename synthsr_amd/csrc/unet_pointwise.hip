@@ -116,7 +116,12 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ bn_stats,
                                                      const float* __restrict__ bn_gamma,
                                                      const float* __restrict__ bn_sums, float eps, float inv_n,
-                                                     const float* __restrict__ g1, const float* __restrict__ w1) {
+                                                     const float* __restrict__ g1, const float* __restrict__ w1,
+                                                     const float* __restrict__ drop = nullptr, int64_t n4ps = 0) {
+  // drop != nullptr (feature-wise dropout with one mask per SAMPLE, batchsize > 1: KL.Dropout(noise_shape=[None,1,1,1,C]),
+  // ext/neuron/models.py:320-324): y is the conv + ELU output, what followed it (the BatchNorm, or the next conv) read
+  // d = s * y with s = drop[sample][c] (n4ps float4 per sample).  The incoming gradient is w.r.t. d (BatchNorm: w.r.t.
+  // BN(d), xhat from s * y) and is multiplied by s; dy2 (the skip connection reads y itself) is added unscaled.
   extern __shared__ float smem[];
   const bool fixed = (RB % C4) == 0;
   if (dbias)
@@ -134,10 +139,12 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const T* __restrict__ dy, c
       g = ld4(dy + i * 4);
     }
     const float4 a = ld4(y + i * 4);
+    float4 sd = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (drop) sd = *reinterpret_cast<const float4*>(drop + (i / n4ps) * (C4 * 4) + (i % C4) * 4);
     if (bn_sums) {
       const int C = C4 * 4, c = (int)(i % C4) * 4;
       float gg[4] = {g.x, g.y, g.z, g.w};
-      const float aa[4] = {a.x, a.y, a.z, a.w};
+      const float aa[4] = {a.x * sd.x, a.y * sd.y, a.z * sd.z, a.w * sd.w};  // the BatchNorm's input (sd = 1 without dropout)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float inv = rsqrtf(bn_stats[C + c + k] + eps);
@@ -145,6 +152,9 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const T* __restrict__ dy, c
         gg[k] = bn_gamma[c + k] * inv * (gg[k] - bn_sums[c + k] * inv_n - xh * bn_sums[C + c + k] * inv_n);
       }
       g = make_float4(gg[0], gg[1], gg[2], gg[3]);
+    }
+    if (drop) {
+      g.x *= sd.x; g.y *= sd.y; g.z *= sd.z; g.w *= sd.w;
     }
     if (dy2) {
       const float4 g2 = ld4(dy2 + i * 4);
@@ -173,6 +183,17 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const T* __restrict__ dy, c
     if (syn_det_gather(smem, C4 * 4))
       for (int i = threadIdx.x; i < C4 * 4; i += RB) atomicAdd(&dbias[i], smem[i]);
     syn_det_gather_end(C4 * 4);
+  }
+}
+
+// out[v][c] = x[v][c] * scale[sample(v)][c]: the dropped-out tensor of a batch with one feature mask per sample (and the same
+// factor on a gradient); in place allowed
+__global__ __launch_bounds__(256) void scale_channels_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n4,
+                                                             int C4, const float* __restrict__ scale, int64_t n4ps) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = ld4(x + i * 4);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + (i / n4ps) * (C4 * 4) + (i % C4) * 4);
+    st4(out + i * 4, make_float4(a.x * sc.x, a.y * sc.y, a.z * sc.z, a.w * sc.w));
   }
 }
 
@@ -1334,6 +1355,31 @@ int synthsr_bn_elu_bwd_head(const float* dpred, const float* whead, const float*
 }
 int synthsr_bn_elu_bwd_head_bf16(const float* dpred, const float* whead, const void* y, void* dz, float* dbias, int64_t nvox, int C, const float* stats, const float* gamma, float eps, const float* sums, synthsr_stream_t stream) {
   return bn_elu_bwd_head_t<bf16_t>(dpred, whead, (const bf16_t*)y, (bf16_t*)dz, dbias, nvox, C, stats, gamma, eps, sums, stream);
+}
+
+int synthsr_scale_channels(const float* x, float* out, int64_t nvox, int C, const float* scale, int64_t nvox_per_sample,
+                           synthsr_stream_t stream) {
+  if (!x || !out || !scale || nvox < 1 || !ok_c4(C) || nvox_per_sample < 1 || (nvox % nvox_per_sample) != 0) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(scale_channels_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n4, C / 4, scale,
+                     nvox_per_sample * (C / 4));
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
+int synthsr_elu_bwd_drop(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
+                         const float* stats, const float* gamma, float eps, const float* sums, const float* dpred,
+                         const float* whead, const float* drop, int64_t nvox_per_sample, synthsr_stream_t stream) {
+  const bool bn = stats || gamma || sums, head = dpred || whead;
+  if (!y || !dz || !drop || nvox < 1 || !ok_c4(C) || nvox_per_sample < 1 || (nvox % nvox_per_sample) != 0 ||
+      (bn && (!stats || !gamma || !sums)) || (head && (!dpred || !whead || !bn || dy || dy2)) || (!head && !dy))
+    return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(elu_bwd_kernel<float>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), C * sizeof(float), (hipStream_t)stream,
+                     dy, dy2, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps, bn ? (float)(1.0 / (double)nvox) : 0.f, dpred,
+                     whead, drop, nvox_per_sample * (C / 4));
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
 }
 
 int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* ws, synthsr_stream_t stream) {

@@ -185,8 +185,6 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
             raise Exception('The number or residual channels and output channels must be the same')
         if any(x >= n_channels for x in work_with_residual_channel):
             raise Exception('indices in work_with_residual_channel cannot be greater than the total number of channels')
-    if batchsize != 1 and dropout:
-        raise NotImplementedError('batchsize > 1 together with dropout > 0 (per-sample feature masks) is not supported')
     if n_output_channels != 1 and segmentation_model_file is not None:
         raise ValueError('the segmentation loss needs ONE regression target (the segmentation network takes a single-channel '
                          'image, SynthSR/training.py:375)')

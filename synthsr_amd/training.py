@@ -391,10 +391,6 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
                                  % len(work_with_residual_channel))
     if regression_metric not in ('l1', 'l2', 'laplace', 'ssim'):
         raise Exception('metrics should either be "l1" or "l2" or "ssim" oro "laplace", got {}'.format(regression_metric))
-    # combinations this build does not cover are refused HERE, before the dataset, generator and network are built (the
-    # reference has no such restriction, SynthSR/training.py:52)
-    if int(batchsize) > 1 and dropout > 0:
-        raise NotImplementedError('batchsize > 1 together with dropout > 0 (per-sample feature masks) is not supported')
 
     dist_on = 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1
     rank, world = 0, 1

@@ -57,6 +57,7 @@ class UNet3D:
         self._drop_seed = int(seed) + 0x5eed
         self._drop_next = None      # scales for the next training forward (tests); None: drawn
         self._drop = None           # conv name -> per-channel scale of the step in flight
+        self._drop_ps = None        # batchsize > 1: conv name -> [B, C] scales, one mask per sample (see _start_dropout_batch)
         self._mult = None
         self._packed_scaled = False
         if conv_size != 3:
@@ -399,37 +400,85 @@ class UNet3D:
         self._drop_seed = int(seed)
 
     def set_dropout_scales(self, scales):
-        """explicit per-channel factors {conv layer name: [Cout] of 0 | 1/(1-rate)} for the NEXT training forward (parity
-        tests against the oracle); None: drawn from the network's own generator"""
+        """explicit per-channel factors {conv layer name: [Cout] (or [B, Cout]: one row per sample of the batch) of
+        0 | 1/(1-rate)} for the NEXT training forward (parity tests against the oracle); None: drawn from the network's own
+        generator"""
         self._drop_next = scales
+
+    def _draw_dropout(self, rows, total):
+        # tf.nn.dropout: keep where uniform >= rate, scale the kept features by 1 / (1 - rate); ONE draw for all layers
+        p = self.conv_dropout
+        self._drop_gen.manual_seed((self._drop_seed * 1000003 + self.iterations + 7046029254386353131 * self._drop_forwards)
+                                   & 0x7fffffffffffffff)
+        self._drop_forwards += 1
+        return (torch.rand(rows * total, generator=self._drop_gen) >= p).float() / (1.0 - p)
+
+    def _upload_dropout(self, flat):
+        n = flat.numel()
+        if getattr(self, '_drop_host', None) is None or self._drop_host.numel() != n:
+            self._drop_host = torch.empty(n, dtype=torch.float32).pin_memory()  # one pinned staging + one device buffer
+            self._drop_dev = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._drop_event = None
+        if self._drop_event is not None:
+            self._drop_event.synchronize()  # the previous step's upload has left the staging buffer
+        self._drop_host.copy_(flat)
+        self._drop_dev.copy_(self._drop_host, non_blocking=True)
+        self._drop_event = torch.cuda.Event()
+        self._drop_event.record()
+        return self._drop_dev
+
+    def _start_dropout_batch(self):
+        """batchsize > 1: KL.Dropout(noise_shape=[None, 1, 1, 1, C]) draws one feature mask PER SAMPLE
+        (ext/neuron/models.py:320-324).  A per-sample factor cannot ride on the kernels shared by the batch nor on the
+        BatchNorm of the whole stack, so the dropped-out tensors d = s_b * y are materialised (ops.scale_channels) next to
+        the conv outputs y: convs, BatchNorm statistics, pooling and up-sampling read d; the skip connections and ELU' read
+        y (models.py:431-432); the backward multiplies by s_b in the ELU-backward kernel (ops.elu_bwd_drop)."""
+        convs = list(self.all_convs())
+        B, total = self.batch, sum(c['cout'] for c in convs)
+        if self._drop_next is not None:
+            rows = []
+            for c in convs:
+                a = np.asarray(self._drop_next[c['name']], dtype=np.float32)
+                rows.append(torch.as_tensor(np.array(np.broadcast_to(a, (B, c['cout'])))).reshape(-1))
+            flat = torch.cat(rows)
+        else:  # sample-major draw: sample 0 sees the masks a batch of one would
+            r = self._draw_dropout(B, total).view(B, total)
+            o, rows = 0, []
+            for c in convs:
+                rows.append(r[:, o:o + c['cout']].reshape(-1))
+                o += c['cout']
+            flat = torch.cat(rows)
+        dev = self._upload_dropout(flat)
+        drop, o = {}, 0
+        for c in convs:
+            drop[c['name']] = dev[o:o + B * c['cout']].view(B, c['cout'])
+            o += B * c['cout']
+        self._drop_next = None
+        self._drop = None
+        self._drop_ps = drop
+        if self._packed_scaled:
+            self.repack()
+
+    def _dropped(self, y, conv, key):
+        return ops.scale_channels(y, self._drop_ps[conv['name']], out=self.buf(key, list(y.shape)))
 
     def _start_dropout(self):
         p = self.conv_dropout
         convs = list(self.all_convs())
         total = sum(c['cout'] for c in convs)
-        if getattr(self, '_drop_host', None) is None:  # one pinned staging buffer + one device buffer for all masks
-            self._drop_host = torch.empty(total, dtype=torch.float32).pin_memory()
-            self._drop_dev = torch.empty(total, dtype=torch.float32, device=self.device)
-            self._drop_event = None
-        if self._drop_event is not None:
-            self._drop_event.synchronize()  # the previous step's upload has left the staging buffer
         if self._drop_next is not None:
-            flat = torch.cat([torch.as_tensor(np.asarray(self._drop_next[c['name']], dtype=np.float32)) for c in convs])
-        else:  # tf.nn.dropout: keep where uniform >= rate, scale the kept features by 1 / (1 - rate); ONE draw for all layers
-            self._drop_gen.manual_seed((self._drop_seed * 1000003 + self.iterations + 7046029254386353131 * self._drop_forwards)
-                                       & 0x7fffffffffffffff)
-            self._drop_forwards += 1
-            flat = (torch.rand(total, generator=self._drop_gen) >= p).float() / (1.0 - p)
-        self._drop_host.copy_(flat)
-        self._drop_dev.copy_(self._drop_host, non_blocking=True)
-        self._drop_event = torch.cuda.Event()
-        self._drop_event.record()
+            flat = torch.cat([torch.as_tensor(np.asarray(self._drop_next[c['name']], dtype=np.float32).reshape(-1))
+                              for c in convs])
+        else:
+            flat = self._draw_dropout(1, total)
+        dev = self._upload_dropout(flat)
         drop, o = {}, 0
         for c in convs:
-            drop[c['name']] = self._drop_dev[o:o + c['cout']]
+            drop[c['name']] = dev[o:o + c['cout']]
             o += c['cout']
         self._drop_next = None
         self._drop = drop
+        self._drop_ps = None
         if self._mult is None:
             self._mult = torch.ones_like(self.params)
             self._params_eff = torch.empty_like(self.params)
@@ -459,15 +508,17 @@ class UNet3D:
         L = self.nb_levels
         self.saved = dict(x=[], enc=[], cat=[], dec=[])
         dropping = self.training and self.conv_dropout > 0
-        if dropping and self.batch > 1:
-            # KL.Dropout(noise_shape=[None, 1, 1, 1, C]) draws one mask PER SAMPLE of the batch (ext/neuron/models.py:320-324);
-            # the per-feature factors here ride on the shared conv kernels and on the BatchNorm of the whole stack, which
-            # can only express ONE mask per step: refuse rather than train with a different regularisation
-            raise NotImplementedError('conv_dropout > 0 with batchsize > 1 (per-sample feature masks) is not supported')
-        if dropping:
+        per_sample = dropping and self.batch > 1
+        if per_sample:
+            if self.bf16:
+                raise NotImplementedError('conv_dropout > 0 with batchsize > 1 needs float32 activations (dtype="f32")')
+            self._start_dropout_batch()
+            dropping = False    # no factors folded into the kernels / BatchNorm slots: the dropped-out tensors exist
+            self.saved['encd'], self.saved['decd'] = [], []
+        elif dropping:
             self._start_dropout()
         else:
-            self._drop = None
+            self._drop = self._drop_ps = None
             if self._packed_scaled:  # a training forward without its optimizer step left scaled kernels behind
                 self.repack()
         if self.bf16 and x.dtype != torch.bfloat16:
@@ -489,9 +540,16 @@ class UNet3D:
                 else:
                     self._pb(lambda x_, o_, c=c: ops.conv3d(x_, c['wp'], self.view(c['b']), c['cout'], 1, out=o_), cur, out)
                     cur = out
-                    if self.training and k == nconv - 1:
+                    if self.training and k == nconv - 1 and not per_sample:
                         ops.bn_stats(cur, self._stats(e['bn']), self.bn_ws)
                 acts.append(cur)
+                if per_sample:
+                    cur = self._dropped(cur, c, 'encd%d_%d' % (l, k))
+                    if k == 0:
+                        self.saved['encd'].append([])
+                    self.saved['encd'][l].append(cur)
+                    if k == nconv - 1:
+                        ops.bn_stats(cur, self._stats(e['bn']), self.bn_ws)
             self.saved['enc'].append(acts)
             if dropping:
                 self._dropout_bn(e['bn'], self._drop[e['convs'][-1]['name']])
@@ -502,7 +560,7 @@ class UNet3D:
         for k, d in enumerate(self.dec):
             l = d['level']
             skip = self.saved['enc'][l][-1]
-            acts = []
+            acts, dacts = [], []
             if d['fold']:
                 c0 = d['convs'][0]
                 lo_bn = ops.bn_apply(low, self._stats(low_bn), self.view(low_bn['gamma']), self.view(low_bn['beta']),
@@ -517,6 +575,9 @@ class UNet3D:
                     ops.conv3d_add(skip_, c0['wp_s'], self.view(c0['b']), o_, c0['cout'], 1, out=o_)
                 self._pb(folded, lo_bn, skip, cur)
                 acts.append(cur)
+                if per_sample:
+                    cur = self._dropped(cur, c0, 'decd%d_0' % k)
+                    dacts.append(cur)
             else:
                 cat = ops.upsample_concat(skip, low, self._stats(low_bn), self.view(low_bn['gamma']),
                                           self.view(low_bn['beta']),
@@ -537,8 +598,13 @@ class UNet3D:
                     self._pb(lambda x_, o_, c=c: ops.conv3d(x_, c['wp'], self.view(c['b']), c['cout'], 1, out=o_), cur, out)
                     cur = out
                 acts.append(cur)
+                if per_sample:
+                    cur = self._dropped(cur, c, 'decd%d_%d' % (k, j))
+                    dacts.append(cur)
             self.saved['dec'].append(acts)
-            if self.training and not stats_done:  # single-conv level whose only conv was the folded one
+            if per_sample:
+                self.saved['decd'].append(dacts)
+            if self.training and not stats_done:  # single-conv level whose only conv was the folded one (or per-sample dropout)
                 ops.bn_stats(cur, self._stats(d['bn']), self.bn_ws)
             if dropping:
                 self._dropout_bn(d['bn'], self._drop[d['convs'][-1]['name']])
@@ -661,9 +727,10 @@ class UNet3D:
         assert self.nb_labels > 1
         self.frozen_batch_stats = bool(batch_stats)
         if batch_stats:
-            if self.conv_dropout > 0:
-                raise NotImplementedError('a frozen network with batch statistics and dropout')
-            self.training = True      # the forward pass gathers the batch statistics (conv epilogues / bn_stats)
+            # Keras' learning phase: the forward pass gathers the batch statistics (conv epilogues / bn_stats) and the
+            # Dropout layers of a network built with conv_dropout > 0 are active, frozen or not (the reference builds its
+            # segmentation unet with conv_dropout=dropout, SynthSR/training.py:381); backward_input sees the same masks
+            self.training = True
             try:
                 low, bn = self.forward(x)
             finally:
@@ -753,18 +820,20 @@ class UNet3D:
             d = self.dec[k]
             l = d['level']
             acts = self.saved['dec'][k]
-            g = self._bn_backward(g, acts[-1], d['bn'])
+            ps = self._drop_ps is not None
+            dacts = self.saved['decd'][k] if ps else acts  # what the consumers of the conv outputs read (per-sample dropout)
+            g = self._bn_backward(g, dacts[-1], d['bn'])
             Cs = self.feats[l]
             if d['fold']:
                 skip, lo_bn = self.saved['cat'][k]
                 Cl = lo_bn.shape[3]
                 # all convs but the first: regular; the first one through the folded kernels
                 if len(d['convs']) > 1:
-                    dz = self._convs_backward(g, None, d['convs'][1:], acts[1:], acts[0], need_dx=True, tag='d%d' % k,
-                                              elu_below=acts[0])
+                    dz = self._convs_backward(g, None, d['convs'][1:], acts[1:], dacts[0], need_dx=True, tag='d%d' % k,
+                                              elu_below=acts[0], below_conv=d['convs'][0], dacts=dacts[1:])
                 else:  # nb_conv_per_level = 1: the folded conv feeds the BatchNorm itself
                     self._join()
-                    dz = self._elu_backward(g, acts[0], None, None)
+                    dz = self._elu_backward(g, acts[0], None, None, conv=d['convs'][0])
                 c0 = d['convs'][0]
                 if not frozen:
                     dW = self.view(c0['w'], self.grads)
@@ -785,7 +854,8 @@ class UNet3D:
                     ops.conv3d_up_dgrad(dz_, c0['wpd_u'], Cl, out=dl_)
                 self._pb(c0_dgrads, dz, dskips[l], g)
             else:
-                g = self._convs_backward(g, None, d['convs'], acts, self.saved['cat'][k], need_dx=True, tag='d%d' % k)
+                g = self._convs_backward(g, None, d['convs'], acts, self.saved['cat'][k], need_dx=True, tag='d%d' % k,
+                                         dacts=dacts)
                 # g = d(concat)
                 Cl = g.shape[3] - Cs
                 dskips[l], g = ops.upsample_concat_bwd(g, Cs, Cl, dskip=self.buf('dskip%d' % l, self._bshape(l) + [Cs]),
@@ -796,6 +866,8 @@ class UNet3D:
         for l in range(L - 1, -1, -1):
             e = self.enc[l]
             acts = self.saved['enc'][l]
+            ps = self._drop_ps is not None
+            dacts = self.saved['encd'][l] if ps else acts
             if l < L - 1:
                 # the pool backward also emits the sums of this level's BatchNorm backward (its output is the BN-output
                 # gradient): no separate reduction pass
@@ -804,21 +876,21 @@ class UNet3D:
                 if frozen and self.frozen_batch_stats:  # batch-statistics BatchNorm: its backward needs the two sums
                     sums = self._frozen_sums[:2 * e['bn']['C']]
                     sums.zero_()
-                if self.fuse_pool_bwd and not frozen:
+                if self.fuse_pool_bwd and not frozen and not ps:
                     # only the BatchNorm-backward sums now; the routed gradient (7/8 zeros) is never written: the fused
                     # pool + BatchNorm + ELU backward re-derives it from the pooled gradient (ops.bn_pool_elu_bwd)
                     ops.bn_maxpool_bwd(g, acts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
                                        self.view(e['bn']['beta']), out=False, sums=sums)
                     self._pending_bn = (e['bn'], sums, 'pooled')
                 else:
-                    g = ops.bn_maxpool_bwd(g, acts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
+                    g = ops.bn_maxpool_bwd(g, dacts[-1], self._stats(e['bn']), self.view(e['bn']['gamma']),
                                            self.view(e['bn']['beta']), out=self.buf('gpool%d' % l, list(acts[-1].shape)),
                                            sums=sums)
                     self._pending_bn = (e['bn'], self._zero_sums[:2 * e['bn']['C']] if (frozen and sums is None) else sums)
             else:
-                g = self._bn_backward(g, acts[-1], e['bn'])
+                g = self._bn_backward(g, dacts[-1], e['bn'])
             g = self._convs_backward(g, dskips[l], e['convs'], acts, self.saved['x'][l], need_dx=(l > 0) or frozen,
-                                     tag='e%d' % l)
+                                     tag='e%d' % l, dacts=dacts)
             if on_grad_ready is not None:
                 self._join()
                 on_grad_ready(self.offsets[e['convs'][0]['w']][0])
@@ -865,10 +937,18 @@ class UNet3D:
         self._pending_bn = (bn, sums)
         return g
 
-    def _elu_backward(self, g, y, dy2, dbias):
+    def _elu_backward(self, g, y, dy2, dbias, conv=None):
         """ELU backward of a conv output y; consumes a pending BN backward (y was the BN input)"""
         out = self.buf('dz', list(y.shape))
         pend, self._pending_bn = self._pending_bn, None
+        if self._drop_ps is not None:  # per-sample dropout sits between y and its consumer
+            bn_args = head = None
+            if pend is not None:
+                assert len(pend) == 2
+                bn_args = (self._stats(pend[0]), self.view(pend[0]['gamma']), pend[1])
+                if g is None:
+                    head = self._rank1
+            return ops.elu_bwd_drop(g, y, self._drop_ps[conv['name']], dy2=dy2, dbias=dbias, out=out, bn=bn_args, head=head)
         if pend is not None:
             bn, sums = pend[:2]
             if len(pend) > 2:  # g is the gradient w.r.t. the POOLED tensor: pool + BatchNorm + ELU backward in one pass
@@ -882,14 +962,17 @@ class UNet3D:
             return ops.bn_elu_bwd(g, y, self._stats(bn), self.view(bn['gamma']), sums, dy2=dy2, dbias=dbias, out=out)
         return ops.elu_bwd(g, y, dy2=dy2, dbias=dbias, out=out)
 
-    def _convs_backward(self, g, g2, convs, acts, x_in, need_dx, tag, elu_below=None):
+    def _convs_backward(self, g, g2, convs, acts, x_in, need_dx, tag, elu_below=None, below_conv=None, dacts=None):
         """g (+g2) = gradient w.r.t. the output of the last conv's ELU. Returns gradient w.r.t. x_in (or None);
-        with elu_below = x_in being itself an ELU output, the returned gradient is w.r.t. the pre-activation of x_in."""
+        with elu_below = x_in being itself an ELU output (of below_conv), the returned gradient is w.r.t. the pre-activation
+        of x_in.  dacts: what the next layer read of each conv output (per-sample dropout: the dropped-out copies)."""
         fused = False  # g already is dz of conv j (ELU backward applied in the data-gradient epilogue of conv j+1)
+        dacts = acts if dacts is None else dacts
+        ps = self._drop_ps is not None
         for j in range(len(convs) - 1, -1, -1):
             c = convs[j]
             y = acts[j]
-            xin = acts[j - 1] if j > 0 else x_in
+            xin = dacts[j - 1] if j > 0 else x_in
             self._join()  # the previous layer's wgrad still reads the buffer dz is about to reuse
             frozen = getattr(self, '_frozen', False)
             if fused:
@@ -899,7 +982,7 @@ class UNet3D:
                         x_, dz_, self.view(c['w'], self.grads), dbias=self.view(c['b'], self.grads)), xin, dz),
                         xin[..., 0].numel())
             else:
-                dz = self._elu_backward(g, y, g2, None if frozen else self.view(c['b'], self.grads))
+                dz = self._elu_backward(g, y, g2, None if frozen else self.view(c['b'], self.grads), conv=c)
                 if not frozen:
                     self._fork(lambda: self._pb(lambda x_, dz_: ops.conv3d_wgrad(x_, dz_, self.view(c['w'], self.grads)),
                                                 xin, dz), xin[..., 0].numel())
@@ -912,6 +995,8 @@ class UNet3D:
                 below = acts[j - 1] if j > 0 else elu_below
                 if below is not None:
                     self._pb(lambda dz_, b_, o_: ops.conv3d_add(dz_, c['wpd'], None, b_, c['cin'], 2, out=o_), dz, below, out)
+                    if ps:  # the conv read s_b * ELU(below): the factor of the layer below's dropout on its gradient
+                        ops.scale_channels(out, self._drop_ps[(convs[j - 1] if j > 0 else below_conv)['name']], out=out)
                     fused = True
                 else:
                     self._pb(lambda dz_, o_: ops.conv3d(dz_, c['wpd'], None, c['cin'], 0, out=o_), dz, out)

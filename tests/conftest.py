@@ -140,7 +140,8 @@ def _pool_choices(net):
     out = []
     for l in range(net.nb_levels - 1):
         e = net.enc[l]
-        x = net.saved['enc'][l][-1]
+        # per-sample dropout (batchsize > 1): the BatchNorm + pooling read the dropped-out copy of the conv output
+        x = (net.saved['encd'] if getattr(net, '_drop_ps', None) is not None else net.saved['enc'])[l][-1]
         st, C = net._stats(e['bn']), e['bn']['C']
         gamma, beta = net.view(e['bn']['gamma']), net.view(e['bn']['beta'])
         ones = torch.ones([x.shape[0] // 2, x.shape[1] // 2, x.shape[2] // 2, C], dtype=x.dtype, device=x.device)

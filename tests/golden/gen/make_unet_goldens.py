@@ -382,8 +382,36 @@ def golden_batch(out):
     print('batch pred', out['b2_pred'].shape)
 
 
+def golden_batch_dropout(out):
+    """batchsize 2 WITH conv_dropout: KL.Dropout(rate, noise_shape=[None, 1, 1, 1, C]) draws one keep mask per SAMPLE and
+    feature (ext/neuron/models.py:320-324, 448-451); BatchNorm statistics over both samples of the dropped tensors"""
+    rng = np.random.default_rng(19)
+    x = rng.uniform(0, 1, (2, 16, 8, 16, 2)).astype(np.float32)
+    x[1] *= 1.7
+    ks.reset(seed=8, learning_phase=1)
+    FEED[:] = [('unet_input', x)]
+    model = nrn_models.unet(nb_features=8, input_shape=[16, 8, 16, 2], nb_levels=3, conv_size=3, nb_labels=1, feat_mult=2,
+                            nb_conv_per_level=2, conv_dropout=.4, final_pred_activation='linear', batch_norm=-1,
+                            activation='elu', input_model=None)
+    out['b2d_x'] = x
+    out.update(params_dict('b2d_w:'))
+    out['b2d_pred'] = np.asarray(model.output)
+    for k, v in ks.STATE['dropout'].items():
+        assert v.shape[0] == 2 and v.shape[1:4] == (1, 1, 1), v.shape      # one factor per sample and feature
+        out['b2d_scale:%s' % k] = v.reshape(2, -1)
+    for k, (m, v) in ks.STATE['bn_batch'].items():
+        out['b2d_bnmean:%s' % k] = m
+        out['b2d_bnvar:%s' % k] = v
+    differ = sum(int(not np.array_equal(v[0], v[1])) for k, v in out.items() if k.startswith('b2d_scale:'))
+    print('batch + dropout pred', out['b2d_pred'].shape, 'dropout layers', len(ks.STATE['dropout']), 'with different masks per sample:', differ)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['wiring', 'graph', 'seg', 'critic', 'dropout', 'batch']
+    which = sys.argv[1:] or ['wiring', 'graph', 'seg', 'critic', 'dropout', 'batch', 'batch_dropout']
+    if 'batch_dropout' in which:
+        out = {}
+        golden_batch_dropout(out)
+        np.savez_compressed(os.path.join(OUT, 'unet_batch_dropout.npz'), **out)
     if 'batch' in which:
         out = {}
         golden_batch(out)

@@ -239,3 +239,187 @@ def test_batched_segmentation_loss_vs_per_volume_oracle(fs_header, crop):
     # each copy carries half of the single-volume gradient of its own Dice term ... plus the coupling through the shared
     # statistics, which for identical copies adds up to the single-volume gradient split in two
     assert float(((a[0] + a[1]) - b).abs().max()) < 3e-3 * float(b.abs().max())
+
+
+def _sample_scales(net, B, rate, seed):
+    rng = np.random.default_rng(seed)
+    out = {}
+    for c in net.all_convs():
+        keep = rng.random((B, c['cout'])) >= rate
+        for b in range(B):  # every layer drops a feature of every sample, and not the same one
+            keep[b, (3 * b + 1) % c['cout']] = False
+            keep[b, (3 * b + 2) % c['cout']] = True
+        out[c['name']] = (keep / (1.0 - rate)).astype(np.float32)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fold', [False, True])
+@pytest.mark.parametrize('B,feats,levels,shape,cin,nconv,kind', [
+    (2, 24, 3, (16, 16, 32), 2, 2, 'l1'), (3, 8, 2, (8, 12, 16), 1, 2, 'l1'), (2, 8, 3, (16, 16, 16), 1, 1, 'l1'),
+    (2, 8, 2, (8, 8, 16), 1, 3, 'l1'), (2, 8, 2, (8, 16, 16), 2, 2, 'laplace')])
+def test_batched_unet_with_per_sample_dropout_vs_oracle(B, feats, levels, shape, cin, nconv, kind, fold):
+    """batchsize > 1 with conv_dropout: one feature mask per SAMPLE (ext/neuron/models.py:320-324; UNet3D._start_dropout_batch).
+    Loss, prediction, every parameter gradient and the BatchNorm statistics against the oracle, which multiplies the
+    activations by the [B, C] factors the way the reference graph does, with autograd behind it."""
+    import torch
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    g = torch.Generator()
+    tensors = {}
+    K = 2 if kind == 'laplace' else 1
+    rate = .3
+
+    def run():
+        net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=K, feat_mult=2,
+                   nb_conv_per_level=nconv, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3,
+                   fold_upsample=fold, conv_dropout=rate)
+        g.manual_seed(11)
+        for nm, v in net.named_parameters():
+            if nm.endswith('/gamma'):
+                v.copy_(torch.rand(v.shape, generator=g) + .5)
+            elif nm.endswith('/beta') or nm.endswith('/bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * .1)
+        net.repack()
+        net.set_batch(B)
+        x = torch.rand(B, *shape, cin, generator=g)
+        x[1] *= 1.7
+        target = torch.rand(B, *shape, 1, generator=g)
+        sc = _sample_scales(net, B, rate, 5)
+        net.set_dropout_scales(sc)
+        xs = x.reshape(B * shape[0], shape[1], shape[2], cin).cuda()
+        loss, pred = net.loss(xs, target.reshape(-1).cuda(), kind, None, want_pred=True)
+        net.test_loss, net.test_pred = loss.clone(), pred.clone()
+        ready = []
+        net.backward(on_grad_ready=ready.append)
+        assert ready and ready == sorted(ready, reverse=True)
+        tensors.update(x=x, target=target, sc=sc)
+        return net
+
+    def oracle(net, nudge):
+        P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+        stats, pin = {}, []
+        pr = U.unet_forward(tensors['x'], P, net.prefix, levels, nconv, training=True, collect=stats,
+                            dropout={k: torch.from_numpy(v) for k, v in tensors['sc'].items()}, pool_inputs=pin,
+                            pool_nudge=nudge)
+        lr = sum(U.regression_loss(pr[b], tensors['target'][b], kind, None) for b in range(B)) / B
+        lr.backward()
+        return (P, stats, pr.detach(), lr.detach()), pin
+
+    def compare(net, ref):
+        P, stats, pr, lr = ref
+        err = (net.test_pred.view(B, *shape, K).cpu() - pr).abs().max().item() / pr.abs().max().item()
+        assert err < 5e-4, err
+        assert abs(net.test_loss.item() - lr.item()) < 3e-5 * max(1.0, abs(lr.item()))
+        for nm, _, kd in net.specs:
+            got = net.view(nm, net.grads).cpu().double()
+            ref_g = P[nm].grad.double()
+            e = (got - ref_g).abs().max().item() / max(ref_g.abs().max().item(), 1e-12)
+            assert e < (4e-3 if kd in ('kernel', 'head_w') else 8e-3), (nm, e)
+        for bn in net.bn_layers:    # statistics of the dropped-out tensors, over batch and voxels
+            o, C = bn['soff'], bn['C']
+            m, v = stats[bn['name']]
+            assert (net.bn_batch[o:o + C].cpu() - m).abs().max().item() < 1e-4 * max(1.0, m.abs().max().item())
+            assert (net.bn_batch[o + C:o + 2 * C].cpu() - v).abs().max().item() < 1e-4 * max(1.0, v.abs().max().item())
+
+    net, _ = single_shot_parity(run, oracle, compare)
+    assert net._drop is None and not net._packed_scaled      # nothing folded into the kernels in this mode
+    # a feature dropped for EVERY sample has no gradient on the input-channel slice of the kernel that consumes it;
+    # one dropped for only one sample still has
+    sc = tensors['sc']
+    for grp in net.enc + net.dec:
+        for k in range(1, len(grp['convs'])):
+            s = sc[grp['convs'][k - 1]['name']]
+            dW = net.view(grp['convs'][k]['w'], net.grads)
+            dead = np.flatnonzero((s == 0).all(0))
+            part = np.flatnonzero((s == 0).any(0) & ~(s == 0).all(0))
+            assert dead.size == 0 or dW[:, :, :, dead, :].abs().max().item() == 0.0
+            assert part.size > 0 and dW[:, :, :, part, :].abs().amax((0, 1, 2, 4)).min().item() > 0.0
+
+
+@pytest.mark.gpu
+def test_per_sample_dropout_draws():
+    """drawn masks at batchsize 2: one row per sample, rows differ, keep rate, sample 0 sees the mask a batch of one would;
+    a few optimizer steps stay finite; inference afterwards is dropout-free"""
+    import torch
+    from synthsr_amd.unet import unet
+    kw = dict(nb_features=24, input_shape=[16, 16, 16, 1], nb_levels=3, conv_size=3, nb_labels=1, feat_mult=2,
+              nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=4, conv_dropout=.25)
+    a, one = unet(**kw), unet(**kw)
+    a.set_batch(2)
+    x = torch.rand(32, 16, 16, 1).cuda()
+    t = torch.rand(2 * 16 ** 3).cuda()
+    one.loss_l1(x[:16].contiguous(), t[:16 ** 3].contiguous())
+    kept = total = 0
+    for it in range(5):
+        a.loss_l1(x, t)
+        assert a._drop is None and a._drop_ps is not None
+        differ = 0
+        for nm, s in a._drop_ps.items():
+            v = s.cpu().numpy()
+            assert v.shape[0] == 2 and np.all((v == 0) | (np.abs(v - 1 / .75) < 1e-6))
+            differ += int(not np.array_equal(v[0], v[1]))
+            kept += int((v > 0).sum())
+            total += v.size
+            if it == 0:
+                assert np.array_equal(v[0], one._drop[nm].cpu().numpy()), nm
+        assert differ >= len(a._drop_ps) - 1
+        a.backward(); a.adam_step(); a.update_moving_stats()
+    assert abs(kept / total - .75) < .05, kept / total
+    assert torch.isfinite(a.params).all() and torch.isfinite(a.bn_moving).all()
+    a.training = False
+    p1 = a.predict(x).clone()
+    p2 = a.predict(x)   # (not bitwise: the small levels' split-K forward adds its partial sums with float atomics)
+    assert (p1 - p2).abs().max().item() < 1e-5 and torch.isfinite(p1).all() and a._drop_ps is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B', [1, 2])
+def test_frozen_network_with_active_dropout_vs_oracle(B):
+    """a frozen softmax-headed network built with conv_dropout, run in Keras' learning phase (the reference's segmentation
+    unet: SynthSR/training.py:381 builds it with conv_dropout=dropout; `trainable = False` switches neither its Dropout
+    layers nor its BatchNorm's batch statistics off): posteriors and the gradient w.r.t. the input image of
+    UNet3D.predict_probs(batch_stats=True) / backward_input against the oracle under autograd, with one mask per sample."""
+    import torch
+    from synthsr_amd import ops
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    shape, levels, N = (16, 16, 32), 3, 5
+    prev = ops.set_deterministic(True)
+    try:
+        net = unet(8, list(shape) + [1], levels, 3, N, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
+                   final_pred_activation='softmax', seed=6, conv_dropout=.3)
+        g = torch.Generator().manual_seed(3)
+        for nm, v in net.named_parameters():
+            if nm.endswith('/gamma'):
+                v.copy_(torch.rand(v.shape, generator=g) + .5)
+            elif nm.endswith('/beta') or nm.endswith('/bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * .1)
+        net.repack()
+        net.set_batch(B)
+        net.training = False
+        net.enable_input_grad()
+        sc = _sample_scales(net, B, .3, 9)
+        if B == 1:
+            sc = {k: v[0] for k, v in sc.items()}
+        x = torch.rand(B, *shape, 1, generator=g)
+        R = torch.rand(B, *shape, N, generator=g)
+        net.set_dropout_scales(sc)
+        probs = net.predict_probs(x.reshape(B * shape[0], shape[1], shape[2], 1).cuda(), batch_stats=True)
+        p = probs.view(-1, N)
+        r = R.reshape(-1, N).cuda()
+        dlogits = p * (r - (p * r).sum(1, keepdim=True))                  # d sum(p * R) / d logits
+        W = net.view(net.head['w']).reshape(-1, N)
+        low = net.saved['last'][0]
+        dbn = (dlogits @ W.t()).view(*low.shape).contiguous()
+        dx = net.backward_input(dbn).clone()
+        P = {k: v.clone().float() for k, v in net.state_dict().items()}
+        xr = (x if B > 1 else x[0]).clone().requires_grad_(True)
+        pr = U.unet_forward(xr, P, net.prefix, levels, 2, training=True, moving=P, softmax=True,
+                            dropout={k: torch.from_numpy(np.asarray(v)) for k, v in sc.items()})
+        (pr * (R if B > 1 else R[0])).sum().backward()
+        assert (probs.view(*pr.shape).cpu() - pr.detach()).abs().max().item() < 2e-5
+        e = (dx.view(*xr.shape).cpu() - xr.grad).abs().max().item() / xr.grad.abs().max().item()
+        assert e < 2e-3, e   # (max-pool rounding ties between device and oracle would show as ~1e-2 here: none at this seed)
+    finally:
+        ops.set_deterministic(prev)

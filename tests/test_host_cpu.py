@@ -435,15 +435,6 @@ def test_multi_modality_affine_bounds_pick_one_block_at_build_time():
         hm.pick_bounds_block(np.zeros((3, 3)))
 
 
-@pytest.mark.parametrize('extra', [dict(dropout=.2)])
-def test_training_refuses_unsupported_batch_combinations_up_front(extra):
-    """batchsize > 1 together with dropout (per-sample feature masks) is refused at the top of
-    training(), before any dataset, generator or network is built (no GPU, no file access needed to get the error)"""
-    from synthsr_amd.training import training
-    with pytest.raises(NotImplementedError, match='batchsize > 1'):
-        training('/nonexistent/labels', '/nonexistent/models', None, None, '/nonexistent/gl.npy', batchsize=2, **extra)
-
-
 def test_trace_ranges_are_noops_unless_enabled(monkeypatch):
     """ops.trace_range: nothing without SYNTHSR_ROCTX=1; with it, roctx ranges through the marker library if the image has one
     (no GPU needed: the calls only record markers for an attached profiler)"""

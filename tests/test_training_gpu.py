@@ -213,6 +213,27 @@ def test_training_with_segmentation_regularised_loss(tmp_path):
     assert net2.iterations == 2 and net2.batch == 2 and np.isfinite(total2) and 0 < total2 < 2
 
 
+def test_training_batchsize_2_with_dropout(tmp_path):
+    """training(batchsize=2, dropout=.2) (SynthSR/training.py:52, 76): the U-Net draws one feature mask per sample
+    (KL.Dropout noise_shape [None, 1, 1, 1, C]); the loss of a fixed pair of label maps goes down, checkpoints hold finite
+    weights and the moving statistics"""
+    from synthsr_amd.training import training
+    from synthsr_amd.synthetic import GENERATION_LABELS
+    labels_dir = _write_labels(tmp_path, 2, (32, 32, 32))
+    np.save(tmp_path / 'gl.npy', GENERATION_LABELS)
+    net = training(labels_dir, str(tmp_path / 'm'), None, None, str(tmp_path / 'gl.npy'), batchsize=2, dropout=.2,
+                   output_shape=32, n_levels=3, unet_feat_count=24, nonlin_shape_factor=.125, bias_shape_factor=.125,
+                   steps_per_epoch=4, epochs=3, verbose=False, lr=1e-3)
+    assert net.iterations == 12 and net.batch == 2 and net.conv_dropout == .2
+    assert net._drop is None and net._drop_ps is not None
+    masks = next(iter(net._drop_ps.values())).cpu().numpy()
+    assert masks.shape[0] == 2 and np.all((masks == 0) | (np.abs(masks - 1.25) < 1e-6))
+    log = [float(l.split(',')[1]) for l in open(os.path.join(str(tmp_path / 'm'), 'logs', 'loss.csv')).read().strip().split('\n')]
+    assert len(log) == 3 and all(np.isfinite(log)) and log[-1] < log[0]
+    z = np.load(os.path.join(str(tmp_path / 'm'), '003.npz'))
+    assert all(np.isfinite(z[k]).all() for k in z.files if z[k].dtype.kind == 'f')
+
+
 @pytest.mark.parametrize('metric,cropping', [('l2', 16), ('laplace', None), ('laplace', [24, 16, 16]), ('ssim', None),
                                              ('ssim', 24)])
 def test_training_regression_metrics_and_loss_cropping(tmp_path, metric, cropping):

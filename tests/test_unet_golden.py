@@ -298,3 +298,23 @@ def test_oracle_batch_of_volumes_vs_reference():
     # per-volume statistics would differ: the second volume is 1.7x the first
     solo = U.unet_forward(tt(g['b2_x'][0]), P, 'unet', 3, 2, training=True)
     assert float((solo - tt(g['b2_pred'][0])).abs().max()) > 1e-3
+
+
+def test_oracle_batch_with_per_sample_dropout_vs_reference():
+    """batchsize 2 with conv_dropout: KL.Dropout(noise_shape=[None, 1, 1, 1, C]) draws one keep mask per SAMPLE and feature
+    (ext/neuron/models.py:320-324); the reference's unet run on the Keras shim, its factors [2, C] handed to the oracle:
+    prediction of both volumes and the BatchNorm statistics (over both samples of the dropped tensors)"""
+    g = load_golden('unet_batch_dropout')
+    P = {k: tt(v) for k, v in golden_weights(g, 'b2d_w:').items()}
+    P['unet_likelihood/kernel'] = P['unet_likelihood/kernel'].reshape(P['unet_likelihood/kernel'].shape[-2:])
+    sc = _dropout_scales(g, 'b2d')
+    assert all(tuple(v.shape)[0] == 2 for v in sc.values())
+    assert any(not np.array_equal(v[0].numpy(), v[1].numpy()) for v in sc.values())     # the two samples' masks differ
+    stats = {}
+    pred = U.unet_forward(tt(g['b2d_x']), P, 'unet', 3, 2, training=True, collect=stats, dropout=sc)
+    close(pred, g['b2d_pred'], name='prediction of the batch')
+    for name, (m, v) in stats.items():
+        close(m, g['b2d_bnmean:' + name], name=name + ' mean')
+        close(v, g['b2d_bnvar:' + name], name=name + ' var')
+    same = {k: v[:1].expand(2, -1) for k, v in sc.items()}                             # ONE mask for both samples is different
+    assert float((U.unet_forward(tt(g['b2d_x']), P, 'unet', 3, 2, training=True, dropout=same) - tt(g['b2d_pred'])).abs().max()) > 1e-3

@@ -120,6 +120,35 @@ def test_batch_of_volumes_vs_reference(T, fold):
         close(v, g['b2_bnvar:' + bn['name']], name=bn['name'] + ' var')
 
 
+@pytest.mark.parametrize('fold', [False, True])
+def test_batch_with_per_sample_dropout_vs_reference(T, fold):
+    """batchsize 2 WITH conv_dropout: KL.Dropout(noise_shape=[None, 1, 1, 1, C]) draws one keep mask per sample and feature
+    (ext/neuron/models.py:320-324); the reference's unet on the Keras shim, the factors [2, C] its Dropout layers drew handed
+    to UNet3D.set_dropout_scales: prediction of both volumes, BatchNorm statistics of the dropped-out tensors"""
+    torch = T
+    from synthsr_amd.unet import unet
+    from test_unet_golden import _dropout_scales
+    g = load_golden('unet_batch_dropout')
+    net = unet(nb_features=8, input_shape=[16, 8, 16, 2], nb_levels=3, conv_size=3, nb_labels=1, feat_mult=2,
+               nb_conv_per_level=2, batch_norm=-1, activation='elu', final_pred_activation='linear', fold_upsample=fold,
+               conv_dropout=.4)
+    net.load_state_dict(golden_weights(g, 'b2d_w:'))
+    net.set_batch(2)
+    sc = {k: v.numpy() for k, v in _dropout_scales(g, 'b2d').items()}
+    net.set_dropout_scales(sc)
+    x = torch.as_tensor(g['b2d_x']).reshape(32, 8, 16, 2).cuda()
+    _, pred = net.loss_l1(x, torch.zeros(2 * 16 * 8 * 16, device='cuda'), want_pred=True)
+    close(pred.view(2, 16, 8, 16, 1), g['b2d_pred'], name='prediction of the batch')
+    for bn in net.bn_layers:
+        m, v = _bn_stats(net, bn['name'])
+        close(m, g['b2d_bnmean:' + bn['name']], name=bn['name'] + ' mean')
+        close(v, g['b2d_bnvar:' + bn['name']], name=bn['name'] + ' var')
+    # ONE mask for both samples (what a batch of one draws) is a different network output
+    net.set_dropout_scales({k: np.broadcast_to(v[:1], v.shape) for k, v in sc.items()})
+    _, pred1 = net.loss_l1(x, torch.zeros(2 * 16 * 8 * 16, device='cuda'), want_pred=True)
+    assert float((pred1.view(2, 16, 8, 16, 1).cpu() - torch.as_tensor(g['b2d_pred'])).abs().max()) > 1e-3
+
+
 def test_training_graph_vs_reference(T):
     """the graph training() compiles (labels_to_image_model -> unet -> metrics_model, SynthSR/training.py:319-347) at 32^3
     with the benchmark network: HIP generator from the golden's labels + tape, HIP U-Net, fused head + L1 loss; plain and

@@ -386,11 +386,12 @@ def test_segmentation_loss_with_the_laplace_head_vs_autograd(T):
         Trainer(_BG(), net4, regression_metric='laplace', seg_regulariser=object())
 
 
-@pytest.mark.parametrize('fs_header,clip,crop,frozen_bn', [(False, False, None, 'batch'), (True, True, None, 'inference'),
-                                                           (True, False, (12, 16, 20), 'batch'),
-                                                           (False, True, (8, 24, 12), 'inference'),
-                                                           (True, True, (8, 24, 12), 'batch')])
-def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop, frozen_bn):
+@pytest.mark.parametrize('fs_header,clip,crop,frozen_bn,seg_drop', [
+    (False, False, None, 'batch', 0.), (True, True, None, 'inference', 0.), (True, False, (12, 16, 20), 'batch', 0.),
+    (False, True, (8, 24, 12), 'inference', 0.), (True, True, (8, 24, 12), 'batch', 0.),
+    # the frozen network built with conv_dropout (SynthSR/training.py:381): its Dropout layers are active in the learning phase
+    (False, False, None, 'batch', .3), (True, True, (8, 24, 12), 'batch', .3)])
+def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop, frozen_bn, seg_drop):
     """SynthSR/metrics_model.py:136-215: L1 + w * Dice(frozen segmentation U-Net(prediction), label map).  Loss value and
     every gradient of the TRAINED network against torch autograd through the oracle; the frozen network's BatchNorm on batch
     statistics (Keras' learning phase, the default) or on its moving averages.
@@ -414,10 +415,18 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop, fro
         net = unet(24, list(shape) + [2], levels, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
                    final_pred_activation='linear', seed=3)
         segnet = unet(24, list(segshape) + [1], levels, 3, len(seg_labels), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
-                      activation='elu', final_pred_activation='softmax', seed=4)
+                      activation='elu', final_pred_activation='softmax', seed=4, conv_dropout=seg_drop)
         return net, segnet
 
     net, segnet = nets()
+    seg_scales = None
+    if seg_drop:
+        rng = np.random.default_rng(21)
+        seg_scales = {}
+        for c in segnet.all_convs():
+            keep = rng.random(c['cout']) >= seg_drop
+            keep[:2] = [False, True]
+            seg_scales[c['name']] = (keep / (1.0 - seg_drop)).astype(np.float32)
     moving = torch.rand(segnet.bn_moving.shape, generator=g) * 0.5 + 0.25
     x = torch.rand(*shape, 2, generator=g)
     target = torch.rand(*shape, generator=g)
@@ -434,6 +443,8 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop, fro
             if dice_only:  # image-loss gradient zeroed
                 net.dpred.zero_()
             net.test_loss = loss.clone()
+            if seg_scales is not None:
+                segnet.set_dropout_scales(seg_scales)
             net.test_dice = reg(pred, seg_target.cuda(), net.dpred, crop).clone()
             net.backward()
             net.test_segnet = segnet
@@ -452,7 +463,9 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop, fro
             dref = U.seg_regularisation(pr, seg_target, Pseg, net.test_segnet.prefix, levels, 2, gen_labels, equivalency, m=m,
                                         M=M, fs_header=fs_header, loss_cropping=crop, pool_inputs=pin_seg,
                                         pool_nudge=None if nudge is None else nudge[n1:],
-                                        bn_batch_stats=frozen_bn == 'batch')
+                                        bn_batch_stats=frozen_bn == 'batch',
+                                        dropout=None if seg_scales is None else {k: torch.from_numpy(v)
+                                                                                 for k, v in seg_scales.items()})
             (dref if dice_only else l1 + w * dref).backward()
             return (P, l1.detach(), dref.detach()), pin + pin_seg
         return oracle
