@@ -45,6 +45,9 @@ int synthsr_conv3d_set_option(int option, int value);
  * The reference computes in fp32 on TensorFlow (SynthSR/training.py:330-341); both modes are fp32 computations of it. */
 int synthsr_set_conv_arithmetic(int mode);
 int synthsr_conv_arithmetic(void);
+/* A counter that moves whenever the arithmetic or a plan-changing option above takes a new value: weights packed under an
+ * older epoch must be packed again (synthsr_amd.unet / synthsr_amd.critic compare it at every repack()). */
+int synthsr_conv3d_layout_epoch(void);
 /* 1 / 0: whether the weight gradient of a plain 3x3x3 conv of this shape runs on the split kernels under the current
  * arithmetic (the dispatcher's own condition; forward / data-gradient plans: synthsr_conv3d_plan) -- what benchmarks price a
  * layer against.  Negative: SYNTHSR_EINVAL. */

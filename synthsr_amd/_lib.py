@@ -57,6 +57,7 @@ SIGNATURES = {
     'synthsr_set_conv_arithmetic': (c_int, [c_int]),
     'synthsr_split_tile_schedule': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
     'synthsr_conv_arithmetic': (c_int, []),
+    'synthsr_conv3d_layout_epoch': (c_int, []),
     'synthsr_conv3d_wgrad_runs_split': (c_int, [POINTER(c_int), c_int, c_int]),
     'synthsr_set_deterministic': (c_int, [c_int]),
     'synthsr_deterministic_status': (c_int, []),

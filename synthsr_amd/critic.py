@@ -93,6 +93,12 @@ class Critic3D:
         return t[:n].view(*shape)
 
     def repack(self):
+        epoch = ops.conv_layout_epoch()
+        if getattr(self, '_pack_epoch', epoch) != epoch:   # arithmetic / plan options changed: the old buffers belong to
+            for c in self.convs:                           # another layout (size and fragment order), pack into fresh ones
+                c.pop('wp', None)
+                c.pop('wpd', None)
+        self._pack_epoch = epoch
         if self.bf16:
             for c in self.convs:
                 c['wp'] = ops.pack_conv_weights_bf16(self.view(c['w']), 0, out=c.get('wp'))

@@ -3996,8 +3996,13 @@ int synthsr_deterministic_status(void) {
 
 extern "C" void syn_split_set_products(int n);  // conv_split.hip: 6 or 9 partial products per multiplication
 extern "C" void syn_split_set_variant(int v);   // conv_split.hip: kernel generation (A/B runs of tools/)
+// bumped whenever a process-wide setting that can change a plan (and with it a packed weight layout) takes a new value
+static int g_layout_epoch = 0;
+int synthsr_conv3d_layout_epoch(void) { return g_layout_epoch; }
+
 int synthsr_set_conv_arithmetic(int mode) {
   if (mode < 0 || mode > 2) return SYNTHSR_EINVAL;
+  if (mode != g_arith) ++g_layout_epoch;
   g_arith = mode;
   g_split = mode ? 1 : 0;  // 1 "split" and 2 "split9" share plans, packed layouts and kernels (template NPROD)
   syn_split_set_products(mode == 2 ? 9 : 6);
@@ -4007,6 +4012,7 @@ int synthsr_set_conv_arithmetic(int mode) {
 int synthsr_conv_arithmetic(void) { return g_arith; }
 
 int synthsr_conv3d_set_option(int option, int value) {
+  if (option == 2 || option == 4 || option == 6 || (option >= 8 && option <= 10)) ++g_layout_epoch;  // plan-changing options
   if (option == 0) {
     g_persist = value ? 1 : 0;
     return SYNTHSR_OK;

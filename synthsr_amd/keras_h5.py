@@ -498,6 +498,30 @@ def load_keras_weights(path):
     return out
 
 
+def _adam_slot_count(names, arrays):
+    """number of trainable weights behind Adam's slot list, decided FROM THE DATA (a count divisible by both 2 and 3 is
+    ambiguous): [ms, vs, vhats] when the last third is what Keras 2.3.1 writes for amsgrad=False -- one shape-(1,) zero
+    placeholder per weight (keras/optimizers.py: `vhats = [K.zeros(1) for _ in params]`) -- or, amsgrad=True, arrays shaped
+    like the first third, with 'vhat' in their names if the names say anything; otherwise [ms, vs] with the two halves shaped
+    alike.  None if neither reading fits."""
+    k = len(arrays)
+    shapes = [tuple(np.shape(a)) for a in arrays]
+    if k % 3 == 0 and k:
+        n = k // 3
+        tail = shapes[2 * n:]
+        placeholders = all(t == (1,) for t in tail) and any(sh != (1,) for sh in shapes[:n])
+        named = all('vhat' in str(nm).lower() for nm in names[2 * n:])
+        if shapes[:n] == shapes[n:2 * n] and (placeholders or (named and tail == shapes[:n])):
+            return n
+    if k % 2 == 0 and k:
+        n = k // 2
+        if shapes[:n] == shapes[n:]:
+            return n
+    if k % 3 == 0 and k and shapes[:k // 3] == shapes[k // 3:2 * k // 3] == shapes[2 * k // 3:]:
+        return k // 3       # three alike thirds that are not two alike halves: amsgrad slots under foreign names
+    return None
+
+
 def load_keras_optimizer(path):
     """Adam slots of a full-model Keras file (`model.save()` / `ModelCheckpoint`, what SynthSR/training.py:429-439 resumes from
     with `models.load_model`): -> (iterations, [m_i], [v_i]) or None if the file has no /optimizer_weights.  Keras 2.3.1's
@@ -509,12 +533,15 @@ def load_keras_optimizer(path):
         return None
     og = f.root['optimizer_weights']
     names = _string_list(og.attrs, 'weight_names')
-    if not names or (len(names) - 1) % 3 not in (0,) and (len(names) - 1) % 2 != 0:
+    if not names or ((len(names) - 1) % 3 != 0 and (len(names) - 1) % 2 != 0):
         raise H5FormatError('%s: /optimizer_weights does not look like Adam slots (%d entries)' % (path, len(names)))
     arrays = [np.asarray(og[n].read()) for n in names]
     it = int(np.asarray(arrays[0]).reshape(-1)[0])
     rest = arrays[1:]
-    n = len(rest) // 3 if len(rest) % 3 == 0 else len(rest) // 2     # with / without the vhat placeholders
+    n = _adam_slot_count(names[1:], rest)
+    if n is None:
+        raise H5FormatError('%s: /optimizer_weights: %d arrays after the iteration counter are neither [ms, vs] nor '
+                            '[ms, vs, vhats] of one set of weights' % (path, len(rest)))
     ms = [np.ascontiguousarray(a, dtype=np.float32) for a in rest[:n]]
     vs = [np.ascontiguousarray(a, dtype=np.float32) for a in rest[n:2 * n]]
     return it, ms, vs

@@ -35,6 +35,12 @@ def conv_arithmetic():
     return _lib.CONV_ARITHMETICS[int(_L().synthsr_conv_arithmetic())]
 
 
+def conv_layout_epoch():
+    """moves whenever the arithmetic or a plan-changing option changed (synthsr_conv3d_layout_epoch): packed weights of an
+    older epoch are stale -- their size or fragment order may belong to another plan"""
+    return int(_L().synthsr_conv3d_layout_epoch())
+
+
 def conv_runs_split(kind, shape, cin, cout):
     """whether a conv launch of this kind ('conv3d_fwd' | 'conv3d_dgrad' | 'conv3d_wgrad' | 'conv3d_up_fwd' | 'conv3d_up_dgrad',
     the names of the profile records) runs on the split kernels under the CURRENT arithmetic (mirrors the dispatcher: csrc/conv3d.hip plan_fwd /

@@ -319,8 +319,8 @@ class UNet3D:
         if self.bf16:
             return self._repack_bf16(src)
         from . import _lib
-        if getattr(self, '_jobs', None) is None or getattr(self, '_jobs_arith', None) != ops.conv_arithmetic():
-            self._jobs_arith = ops.conv_arithmetic()   # the packed layouts depend on it (ops.set_conv_arithmetic)
+        if getattr(self, '_jobs', None) is None or getattr(self, '_jobs_epoch', None) != ops.conv_layout_epoch():
+            self._jobs_epoch = ops.conv_layout_epoch()   # the packed layouts depend on the arithmetic / plan options
             self._pack_jobs()
         _lib.check(_lib.load().synthsr_conv3d_pack_all(_lib.ptr(self.params if src is None else src), _lib.ptr(self._packed),
                                                        _lib.ptr(self._jobs), int(self._jobs.shape[0]), _lib.stream()),
@@ -900,7 +900,9 @@ class UNet3D:
     # ---- weight gradients on a second stream: wgrad(layer) and dgrad(layer) both only read dz, so they can share
     # the GPU; on the small deep levels neither fills 256 CUs alone.  _join() before anything overwrites dz / reads grads.
     def _fork(self, fn, nvox=0):
-        if not self.overlap_wgrad or nvox > self.overlap_max_voxels:
+        # deterministic mode: the ordered weight-gradient planes are ONE buffer for the process (csrc/conv3d.hip:
+        # syn_det_prepare, "one stream" rule) -- a second stream's launch would memset / accumulate into them concurrently
+        if not self.overlap_wgrad or nvox > self.overlap_max_voxels or ops._deterministic:
             fn()
             return
         if self._side_stream is None:

@@ -185,6 +185,47 @@ def test_critic_gradients_accumulate_over_the_samples_of_a_batch():
     assert float((net.grads - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+def test_live_critic_and_unet_survive_a_change_of_conv_arithmetic():
+    """packed weight layouts belong to the plan they were made for (arithmetic / plan options): repack() after
+    ops.set_conv_arithmetic must re-plan and pack into fresh buffers (ops.conv_layout_epoch), for Critic3D as for UNet3D"""
+    import torch
+    from synthsr_amd import ops
+    from synthsr_amd.critic import Critic3D
+    from synthsr_amd.unet import unet
+    shape = (32, 32, 32)
+    net = Critic3D(list(shape) + [1], n_filters=24, n_levels=2, seed=3)
+    gen = unet(24, list(shape) + [1], 2, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
+               final_pred_activation='linear', seed=5)
+    g = torch.Generator().manual_seed(2)
+    real, fake = torch.rand(*shape, 1, generator=g).cuda(), torch.rand(*shape, 1, generator=g).cuda()
+    x, t = torch.rand(*shape, 1, generator=g).cuda(), torch.rand(32 ** 3, generator=g).cuda()
+    first = ops.conv_arithmetic()
+    e0 = ops.conv_layout_epoch()
+    l0 = net.critic_loss_and_grads(real, fake, 0.4, 10.0)[0]
+    g0 = net.grads.clone()
+    u0 = gen.loss_l1(x, t)[0].item()
+    try:
+        other = 'fp32_mfma' if first != 'fp32_mfma' else 'split'
+        ops.set_conv_arithmetic(other)
+        assert ops.conv_layout_epoch() != e0
+        net.repack()
+        gen.repack()
+        l1 = net.critic_loss_and_grads(real, fake, 0.4, 10.0)[0]
+        assert abs(l1 - l0) < 1e-4 * max(1.0, abs(l0))
+        assert float((net.grads - g0).abs().max()) <= 2e-3 * float(g0.abs().max())
+        assert abs(gen.loss_l1(x, t)[0].item() - u0) < 1e-5
+    finally:
+        ops.set_conv_arithmetic(first)
+    e1 = ops.conv_layout_epoch()
+    ops.set_conv_arithmetic(first)          # no change, no new epoch
+    assert ops.conv_layout_epoch() == e1
+    net.repack()
+    gen.repack()
+    l2 = net.critic_loss_and_grads(real, fake, 0.4, 10.0)[0]
+    assert abs(l2 - l0) < 1e-5 * max(1.0, abs(l0))
+    assert abs(gen.loss_l1(x, t)[0].item() - u0) < 1e-6
+
+
 @pytest.mark.parametrize('lo_shape,cin,cout', [((4, 6, 8), 8, 16), ((8, 8, 8), 1, 32), ((6, 4, 10), 32, 32),
                                                ((4, 4, 8), 48, 24), ((8, 8, 16), 24, 48)])
 def test_stride2_conv_on_the_parity_kernels(lo_shape, cin, cout):

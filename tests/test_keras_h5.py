@@ -197,6 +197,22 @@ def test_adam_slots_of_a_full_model_file():
     assert keras_h5.load_keras_optimizer(os.path.join(GOLD, 'keras_weights_tiny.h5')) is None   # save_weights(): no slots
 
 
+def test_adam_slot_layout_is_decided_from_the_data():
+    """[ms, vs] vs [ms, vs, vhats] by shapes / names, not by divisibility of the count (9 weights without vhats = 18 arrays,
+    which is also 3 x 6)"""
+    f = keras_h5._adam_slot_count
+    w9 = [np.zeros((3, 3, 3, 2, 4)), np.zeros(4)] * 4 + [np.zeros((1, 1, 1, 4, 1))]
+    assert f(['a'] * 18, w9 + w9) == 9                                         # two slots, count divisible by 3
+    w6 = w9[:6]
+    assert f(['a'] * 18, w6 + w6 + [np.zeros(1)] * 6) == 6                     # amsgrad=False placeholders
+    names = ['m'] * 6 + ['v'] * 6 + ['Adam/vhat_%d' % i for i in range(6)]
+    assert f(names, w6 + w6 + w6) == 6                                         # amsgrad=True, named
+    assert f(['a'] * 18, w6 + w6 + w6) == 6                                    # ... unnamed: three alike thirds
+    assert f(['a'] * 4, [np.zeros(3), np.zeros(2), np.zeros(3), np.zeros(2)]) == 2
+    assert f(['a'] * 4, [np.zeros(3), np.zeros(2), np.zeros(2), np.zeros(3)]) is None
+    assert f([], []) is None
+
+
 @pytest.mark.gpu
 def test_resume_from_a_full_model_h5_restores_the_adam_state():
     """training(checkpoint='NNN.h5') on a file the reference's ModelCheckpoint wrote (full model): weights by layer name AND the
