@@ -3995,6 +3995,7 @@ int synthsr_deterministic_status(void) {
 }
 
 extern "C" void syn_split_set_products(int n);  // conv_split.hip: 6 or 9 partial products per multiplication
+extern "C" void syn_split_set_wgrad_stack(int v);  // conv_split.hip: stacked column tiles of the 24-column weight gradient
 extern "C" void syn_split_set_variant(int v);   // conv_split.hip: kernel generation (A/B runs of tools/)
 // bumped whenever a process-wide setting that can change a plan (and with it a packed weight layout) takes a new value
 static int g_layout_epoch = 0;
@@ -4059,6 +4060,10 @@ int synthsr_conv3d_set_option(int option, int value) {
   }
   if (option == 9) {
     g_split_min_wgs = value > 0 ? value : 200;
+    return SYNTHSR_OK;
+  }
+  if (option == 12) {
+    syn_split_set_wgrad_stack(value);
     return SYNTHSR_OK;
   }
   return SYNTHSR_EINVAL;

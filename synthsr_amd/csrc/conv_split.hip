@@ -45,6 +45,10 @@ extern "C" __attribute__((visibility("hidden"))) void syn_split_set_products(int
 // 1 (default) = round 4: conversion inside the K loop (fwd2), the LDS-weights kernel (fwd3) where it quantises better; 2 = fwd3 everywhere
 static int g_variant = 1;
 extern "C" __attribute__((visibility("hidden"))) void syn_split_set_variant(int v) { g_variant = v; }
+// 1 (default): the 24-column weight gradient reads the dz pieces as five stacked column tiles (10 MFMAs per row tile and K step
+// instead of 12, see conv3d_split_wgrad_kernel); 0: two padded column tiles per piece (rounds 3 / early 4)
+static int g_wgrad_stack = 1;
+extern "C" __attribute__((visibility("hidden"))) void syn_split_set_wgrad_stack(int v) { g_wgrad_stack = v ? 1 : 0; }
 
 namespace {
 
@@ -1643,6 +1647,13 @@ int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st)
 //     * accumulators stay in registers over the workgroup's whole tile range; at the end the 8 waves' partial sums are added
 //       through LDS and flushed with one atomic per element (deterministic mode: private planes, common.h DetRun).
 //   8 waves x 1 workgroup per CU; LDS double buffered when it fits (COW = 24: 2 x 68 KB): one barrier per tile.
+//   STK (COW = 24, six products): 24 columns are 1.5 column tiles, and two padded tiles per dz piece spend a quarter of the
+//   matrix instructions on columns nobody reads.  The transpose read takes an address per lane, so the column tiles are
+//   STACKED purely by addressing (the LDS image is unchanged): U0, U1, U2 = channels 0-15 of pieces 0, 1, 2; U3 = channels
+//   16-23 of piece 0 | of piece 1 (lane quads 0-1 | 2-3); U4 = channels 16-23 of piece 2 | zeros (the quads 2-3 read 8 zeroed
+//   bytes behind the image).  x0 (U0 U1 U2 U3 U4), x1 (U0 U1 U3), x2 (U0 U3) = 10 MFMAs per row tile instead of 12 cover the
+//   six products (plus x2 dz1 on channels 16-23, a term the six-product sum merely omits); columns 16-23 are accumulator
+//   columns 0-7 + 8-15 of the second tile, added once before the flush.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ __forceinline__ u32x4 tr_read8(const unsigned char* p_lo, const unsigned char* p_hi) {
@@ -1670,8 +1681,9 @@ struct WgCfg {
   static constexpr int NBUF = DBUF ? 2 : 1;
 };
 
-template <int COW, int NPROD = 6>
+template <int COW, int NPROD = 6, bool STK = false>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitWgArgs a) {
+  static_assert(!STK || (COW == 24 && NPROD == 6), "stacked column tiles: 24 columns, six products");
   using C = WgCfg<COW>;
   constexpr int NT = C::NT, DROWB = C::DROWB, DPLANE = C::DPLANE, RT = C::RT, NW = 8, NTHR = 512;
   constexpr int NXP = HVOX * 2, NXL = (NXP + NTHR - 1) / NTHR;             // 16-byte pieces of the 8-channel x halo image
@@ -1703,6 +1715,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   const int vx = 4 * (g & 1) + lrow, vr = g >> 1;
   const uint32_t abase = (uint32_t)((((kz * HY + kyb + vr) * HX) + vx) * 16);
   const uint32_t bbase = (uint32_t)(3 * WG_XPLANE) + (uint32_t)((((kz * TY + kyb + vr) * TX) + vx) * DROWB + lq * 8);
+  // stacked column tiles U3 / U4: channels 16-23 (byte 32 of the row) of piece lq >> 1 resp. of piece 2 | the zeroed slack
+  constexpr uint32_t ZOFF = (uint32_t)(3 * WG_XPLANE + 3 * DPLANE);
+  const uint32_t bvox = bbase - (uint32_t)(lq * 8);
+  const uint32_t u3off = bvox + (uint32_t)((lq >> 1) * DPLANE + 32 + (lq & 1) * 8);
+  const uint32_t u4off = lq < 2 ? bvox + (uint32_t)(2 * DPLANE + 32 + (lq & 1) * 8) : ZOFF;
+  const uint32_t u4hi = lq < 2 ? (uint32_t)(8 * DROWB) : 0u;
+  if constexpr (STK) {
+    if (tid < 2 * C::NBUF) *reinterpret_cast<uint64_t*>(lds + (tid >> 1) * C::BUFB + ZOFF + (tid & 1) * 8) = 0ull;
+  }
 
   // staging: x piece j -> halo voxel j >> 1, channels 4 (j & 1) .. + 3 of the chunk; dz piece j -> voxel j / DQ, quad j % DQ
   int xrel[NXL], xlds[NXL];
@@ -1809,8 +1830,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < (STK ? 1 : NT); ++n)
           bfr[p][n] = tr_read8(img + bbase + kj * BK + p * DPLANE + n * 32, img + bbase + kj * BK + p * DPLANE + n * 32 + 8 * DROWB);
+      if constexpr (STK) {  // bfr[0][1] = U3, bfr[1][1] = U4 (bfr[2][1] unused)
+        static_assert(KPW == 1, "the zero lanes of U4 take no K-step offset");
+        bfr[0][1] = tr_read8(img + u3off, img + u3off + 8 * DROWB);
+        bfr[1][1] = tr_read8(img + u4off, img + u4off + u4hi);
+      }
       auto aload = [&](int q, int slot) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -1822,23 +1848,43 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
+          for (int n = 0; n < NT; ++n) {
+            if (STK && n == 1 && p == 2) continue;
             acc[RT][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
                                                                   __builtin_bit_cast(bf16x8, bfr[p][n]), acc[RT][n], 0, 0, 0);
+          }
       }
       sfor<0, RT>([&](auto Q) {
         constexpr int q = decltype(Q)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (q + 1 < RT) aload(q + 1, (q + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-        sfor<0, NPROD>([&](auto CC) {
-          constexpr int c = decltype(CC)::value;
-          constexpr int qa = split_combo_a(c, NPROD), qb = split_combo_b(c, NPROD);
+        if constexpr (STK) {
+          // (x piece, column tile, accumulator): the two accumulators alternate; smallest terms first as in the plain order
+          auto mm = [&](int xa, int pb, int nb, int ac) {
+            acc[q][ac] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][xa]),
+                                                                  __builtin_bit_cast(bf16x8, bfr[pb][nb]), acc[q][ac], 0, 0, 0);
+          };
+          mm(0, 2, 0, 0);  // x0 U2
+          mm(0, 1, 1, 1);  // x0 U4
+          mm(2, 0, 0, 0);  // x2 U0
+          mm(2, 0, 1, 1);  // x2 U3
+          mm(1, 1, 0, 0);  // x1 U1
+          mm(1, 0, 1, 1);  // x1 U3
+          mm(0, 1, 0, 0);  // x0 U1
+          mm(0, 0, 1, 1);  // x0 U3
+          mm(1, 0, 0, 0);  // x1 U0
+          mm(0, 0, 0, 0);  // x0 U0
+        } else {
+          sfor<0, NPROD>([&](auto CC) {
+            constexpr int c = decltype(CC)::value;
+            constexpr int qa = split_combo_a(c, NPROD), qb = split_combo_b(c, NPROD);
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][qa]),
-                                                                 __builtin_bit_cast(bf16x8, bfr[qb][n]), acc[q][n], 0, 0, 0);
-        });
+            for (int n = 0; n < NT; ++n)
+              acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][qa]),
+                                                                   __builtin_bit_cast(bf16x8, bfr[qb][n]), acc[q][n], 0, 0, 0);
+          });
+        }
       });
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -1874,6 +1920,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     }
   }
   if (wg != 0) return;
+  if constexpr (STK) {  // columns 16-23 = columns 0-7 + 8-15 of the stacked tile (lane li + 8 of the same 16-lane row group)
+#pragma unroll
+    for (int q = 0; q <= RT; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[q][1][i] += __shfl_down(acc[q][1][i], 8, 16);
+  }
   // lane (li -> co, rows 4 g + i -> block g of the row tile: tap 2 (rh RT + q) + (g >> 1), channel 4 (g & 1) + i of the chunk)
   float* dwp = a.dw + (size_t)blockIdx.x * a.det_stride;
   if (want_db && g == 0) {  // row 0 of the ones tile
@@ -1900,14 +1952,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   }
 }
 
-template <int COW, int NPROD>
+template <int COW, int NPROD, bool STK = false>
 int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
   using C = WgCfg<COW>;
   SplitWgArgs a = a0;
   const int gy = a.ncc * a.nco;
   const int gx = split_wgrad_grid_x(a.ntiles, gy);
   const size_t smem = (size_t)C::NBUF * C::BUFB;
-  auto kern = conv3d_split_wgrad_kernel<COW, NPROD>;
+  auto kern = conv3d_split_wgrad_kernel<COW, NPROD, STK>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1924,6 +1976,9 @@ int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
 
 template <int COW>
 int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
+  if constexpr (COW == 24) {
+    if (g_products == 6 && g_wgrad_stack) return launch_split_wgrad_np<24, 6, true>(a, st);
+  }
   return g_products == 9 ? launch_split_wgrad_np<COW, 9>(a, st) : launch_split_wgrad_np<COW, 6>(a, st);
 }
 
