@@ -48,7 +48,7 @@ extern "C" __attribute__((visibility("hidden"))) void syn_split_set_variant(int 
 // 1 (default): the 24-column weight gradient reads the dz pieces as five stacked column tiles (10 MFMAs per row tile and K step
 // instead of 12, see conv3d_split_wgrad_kernel); 0: two padded column tiles per piece (rounds 3 / early 4)
 static int g_wgrad_stack = 1;
-extern "C" __attribute__((visibility("hidden"))) void syn_split_set_wgrad_stack(int v) { g_wgrad_stack = v ? 1 : 0; }
+extern "C" __attribute__((visibility("hidden"))) void syn_split_set_wgrad_stack(int v) { g_wgrad_stack = v; }  // (bit 1, A/B only: 24-column workgroups everywhere)
 
 namespace {
 
@@ -1977,7 +1977,7 @@ int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
 template <int COW>
 int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
   if constexpr (COW == 24) {
-    if (g_products == 6 && g_wgrad_stack) return launch_split_wgrad_np<24, 6, true>(a, st);
+    if (g_products == 6 && (g_wgrad_stack & 1)) return launch_split_wgrad_np<24, 6, true>(a, st);
   }
   return g_products == 9 ? launch_split_wgrad_np<COW, 9>(a, st) : launch_split_wgrad_np<COW, 6>(a, st);
 }
@@ -2089,7 +2089,8 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_wgrad(const float
   a.D0 = s[0]; a.D1 = s[1]; a.D2 = s[2];
   a.Cin = Cin; a.Cout = Cout; a.cin_total = cin_total; a.ci_off = ci_off;
   a.ncc = Cin / 8;
-  const bool c48 = (Cout % 48) == 0;  // 48-wide workgroups where they divide Cout (measured: 10 % faster than 2 x 24)
+  // 48-wide workgroups where they divide Cout (measured in round 3: 10 % faster than 2 x 24 padded column chunks)
+  const bool c48 = (Cout % 48) == 0 && !(g_wgrad_stack & 2);
   a.nco = c48 ? Cout / 48 : Cout / 24;
   a.tiles1 = (s[1] + TY - 1) / TY;
   a.tiles2 = (s[2] + TX - 1) / TX;
