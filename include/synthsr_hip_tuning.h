@@ -24,9 +24,10 @@ extern "C" {
  * quantises better; 2 LDS-weights kernel everywhere), 9 = smallest layer (4x4x16 tiles x co-chunks) planned on the split
  * kernels (default 200), 10 = stacked weight layout of the plain Cout = 24 split convs (default 1: the three bf16 pieces share
  * row tiles, 10 instead of 12 MFMAs per K step; 0: two padded 16-row tiles per piece), 11 = smallest layer (4x4x16 tiles) whose
- * weight gradient takes the split kernel (default 1; rounds 1-3: 256), 12 = stacked column tiles of the Cout = 24 split weight
- * gradient (default 1: the dz pieces are read as five column tiles, 10 instead of 12 MFMAs per row tile and K step; 0: two
- * padded tiles per piece).  Options that change the launch geometry
+ * weight gradient takes the split kernel (default 1; rounds 1-3: 256), 12 = bit mask over the split weight gradient (default
+ * 1): bit 0 stacked column tiles for Cout = 24 (the dz pieces are read as five column tiles, 10 instead of 12 MFMAs per row
+ * tile and K step; off: two padded tiles per piece), bit 1 (A/B only) 24-column workgroups also where Cout % 48 == 0, bit 2
+ * (A/B only) 8 instead of 16 input channels per 48-column workgroup where Cin % 16 == 0.  Options that change the launch geometry
  * or a packed layout must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
 

@@ -1647,6 +1647,10 @@ int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st)
 //     * accumulators stay in registers over the workgroup's whole tile range; at the end the 8 waves' partial sums are added
 //       through LDS and flushed with one atomic per element (deterministic mode: private planes, common.h DetRun).
 //   8 waves x 1 workgroup per CU; LDS double buffered when it fits (COW = 24: 2 x 68 KB): one barrier per tile.
+//   CIW = 16 (COW = 48 and Cin % 16 == 0, six products): 16 input channels per workgroup -- 28 row tiles of one tap x 16 channels in
+//   four row groups of two waves, four K steps per wave, one 136 KB image.  The dz tile is loaded and converted once per 16
+//   instead of once per 8 input channels and a barrier pair covers twice the matrix work: 8-21 % faster from 80^3 48->48 down
+//   to 20^3 192->192 (profiles/r04_split_wgrad_ciw16_ab.txt).  The bias row of ones takes the spare 28th row tile.
 //   STK (COW = 24, six products): 24 columns are 1.5 column tiles, and two padded tiles per dz piece spend a quarter of the
 //   matrix instructions on columns nobody reads.  The transpose read takes an address per lane, so the column tiles are
 //   STACKED purely by addressing (the LDS image is unchanged): U0, U1, U2 = channels 0-15 of pieces 0, 1, 2; U3 = channels
@@ -1667,32 +1671,38 @@ struct SplitWgArgs {
   const float* dout;  // dz [vox][Cout]
   float* dw;          // [27][cin_total][Cout], accumulated with atomics
   float* dbias;       // [Cout] += sum over voxels of dz, or null
-  int D0, D1, D2, Cin, Cout, cin_total, ci_off, ncc, nco, tiles1, tiles2, ntiles;
+  int D0, D1, D2, Cin, Cout, cin_total, ci_off, ncc, nco, tiles1, tiles2, ntiles, ciw;
   int64_t det_stride;
 };
 
-constexpr int WG_XPLANE = HVOX * 16;
-template <int COW>
+template <int COW, int CIW = 8>
 struct WgCfg {
   static constexpr int NT = (COW + 15) / 16, DROWB = COW * 2, DPLANE = TZ * TY * TX * DROWB;
-  static constexpr int RT = COW <= 24 ? 14 : 7;                 // row tiles per workgroup
-  static constexpr int BUFB = 3 * WG_XPLANE + 3 * DPLANE + 64;  // + slack: the last column tile reads past a 24-channel row
+  static constexpr int XB = CIW * 2, XPLANE = HVOX * XB;        // bytes of a halo voxel / of a piece plane of the x image
+  static constexpr int NRT = 14 * (CIW / 8);                    // row tiles of 27 taps x CIW input channels (one spare half / tile)
+  static constexpr int RT = COW <= 24 ? 14 : 7;                 // row tiles per wave
+  static constexpr int BUFB = 3 * XPLANE + 3 * DPLANE + 64;     // + slack: the last column tile reads past a 24-channel row
   static constexpr bool DBUF = 2 * BUFB <= 160 * 1024;
   static constexpr int NBUF = DBUF ? 2 : 1;
 };
 
-template <int COW, int NPROD = 6, bool STK = false>
+template <int COW, int NPROD = 6, bool STK = false, int CIW = 8>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitWgArgs a) {
   static_assert(!STK || (COW == 24 && NPROD == 6), "stacked column tiles: 24 columns, six products");
-  using C = WgCfg<COW>;
+  static_assert(CIW == 8 || (CIW == 16 && COW == 48), "16 input channels per workgroup: the 48-column kernel");
+  // CIW = 16 (Cin % 16 == 0): a workgroup owns 16 input channels = 28 row tiles (one tap x 16 channels each) in four row
+  // groups of two waves with four K steps each: the dz tile is staged and converted once per 16 instead of once per 8 input
+  // channels and a barrier pair covers twice the matrix work (one 136 KB image).
+  using C = WgCfg<COW, CIW>;
   constexpr int NT = C::NT, DROWB = C::DROWB, DPLANE = C::DPLANE, RT = C::RT, NW = 8, NTHR = 512;
-  constexpr int NXP = HVOX * 2, NXL = (NXP + NTHR - 1) / NTHR;             // 16-byte pieces of the 8-channel x halo image
+  constexpr int XB = C::XB, WG_XPLANE = C::XPLANE, XQ = CIW / 4;           // channel quads of a halo voxel
+  constexpr int NXP = HVOX * XQ, NXL = (NXP + NTHR - 1) / NTHR;            // 16-byte pieces (4 channels) of the x halo image
   constexpr int DQ = COW / 4, NDP = TZ * TY * TX * DQ, NDL = NDP / NTHR;   // 16-byte pieces (4 channels) of the dz tile
   static_assert(NDP % NTHR == 0, "dz pieces divide among the threads");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15, lrow = li >> 2, lq = li & 3;
-  constexpr int GROUPS = 14 / RT, WPG = NW / GROUPS, KPW = 8 / WPG;  // row groups, waves per group, K steps per wave
+  constexpr int GROUPS = C::NRT / RT, WPG = NW / GROUPS, KPW = 8 / WPG;  // row groups, waves per group, K steps per wave
   const int rh = wave / WPG, wg = wave % WPG;                          // this wave's row group and its place in it
   const int cc = blockIdx.y % a.ncc, oc = blockIdx.y / a.ncc;
   const TileWalk walk = tile_walk(a.ntiles);
@@ -1700,20 +1710,25 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout;
 
   // A addresses: lane i = (voxel row lrow, block lq) of the row tile: tap = 2 (rh RT + q) + (lq >> 1), channel quad lq & 1
+  // (CIW = 16: tap = rh RT + q, channel quad lq)
   int aoff[RT];
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
-    int tap = 2 * (rh * RT + q) + (lq >> 1);
-    if (tap > 26) tap = 26;  // the spare slot of the last pair: its rows are not flushed
-    aoff[q] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * 16 + (lq & 1) * 8;
+    int tap = CIW == 8 ? 2 * (rh * RT + q) + (lq >> 1) : rh * RT + q;
+    if (tap > 26) tap = 26;  // the spare slot of the last pair / the 28th tile: its rows are not flushed
+    aoff[q] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * XB + (CIW == 8 ? (lq & 1) : lq) * 8;
   }
   // this wave's K step: 32 voxels = x-rows (z, yb) and (z, yb + 1); K index 8 g + j <-> voxel (row g >> 1, x = 8 (j >> 2) +
   // 4 (g & 1) + (j & 3)) -- the same bijection for both operands (conv_bf16.hip)
   // (KPW = 2: K steps 2 wg and 2 wg + 1 = the four x-rows of z plane wg; the second one sits 2 rows further down)
+  // (KPW = 4: the K steps of z planes 2 wg and 2 wg + 1)
   const int ks0 = wg * KPW, kz = ks0 >> 1, kyb = 2 * (ks0 & 1);
-  constexpr uint32_t AK = 2 * HX * 16, BK = 2 * TX * DROWB;  // address step from one K step of a wave to its next
+  // address of K step kj of this wave relative to its first one: two x-rows down, or (every second step) one z plane on
+  auto akoff = [](int kj) { return (uint32_t)(((kj >> 1) * HY * HX + (kj & 1) * 2 * HX) * XB); };
+  auto bkoff = [](int kj) { return (uint32_t)(((kj >> 1) * TY * TX + (kj & 1) * 2 * TX) * DROWB); };
+  static_assert(KPW == 1 || KPW == 2 || KPW == 4, "K steps of a wave: whole x-row pairs of consecutive z planes");
   const int vx = 4 * (g & 1) + lrow, vr = g >> 1;
-  const uint32_t abase = (uint32_t)((((kz * HY + kyb + vr) * HX) + vx) * 16);
+  const uint32_t abase = (uint32_t)((((kz * HY + kyb + vr) * HX) + vx) * XB);
   const uint32_t bbase = (uint32_t)(3 * WG_XPLANE) + (uint32_t)((((kz * TY + kyb + vr) * TX) + vx) * DROWB + lq * 8);
   // stacked column tiles U3 / U4: channels 16-23 (byte 32 of the row) of piece lq >> 1 resp. of piece 2 | the zeroed slack
   constexpr uint32_t ZOFF = (uint32_t)(3 * WG_XPLANE + 3 * DPLANE);
@@ -1725,31 +1740,29 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     if (tid < 2 * C::NBUF) *reinterpret_cast<uint64_t*>(lds + (tid >> 1) * C::BUFB + ZOFF + (tid & 1) * 8) = 0ull;
   }
 
-  // staging: x piece j -> halo voxel j >> 1, channels 4 (j & 1) .. + 3 of the chunk; dz piece j -> voxel j / DQ, quad j % DQ
-  int xrel[NXL], xlds[NXL];
+  // staging: x piece j -> halo voxel j / XQ, channels 4 (j % XQ) .. + 3 of the chunk; dz piece j -> voxel j / DQ, quad j % DQ
+  // (LDS address of piece j, either image: 8 j -- a voxel's XQ resp. DQ pieces are 8 bytes apart and fill its XB resp. DROWB bytes)
+  static_assert(XB == XQ * 8 && DROWB == DQ * 8, "pieces tile the voxel rows");
+  int xrel[NXL];
   uint32_t xmask[NXL];
 #pragma unroll
   for (int i = 0; i < NXL; ++i) {
     const int j = tid + NTHR * i;
-    const int v = j >> 1, h = j & 1;
+    const int v = j / XQ, h = j % XQ;
     const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
     xrel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4 + h * 16;
-    xlds[i] = v * 16 + h * 8;
     xmask[i] = j < NXP ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
   }
-  int drel[NDL], dlds[NDL], dvz[NDL], dvy[NDL], dvx[NDL];
-  bool dcok[NDL];
+  int drel[NDL];
+  uint32_t dmask[NDL];  // bits (z | 4 + y | 8 + x) of the voxel inside the tile, against the tile's out-of-volume bits
 #pragma unroll
   for (int i = 0; i < NDL; ++i) {
     const int j = tid + NTHR * i;
     const int v = j / DQ, c4 = j - v * DQ;
-    dvz[i] = v / (TY * TX);
-    dvy[i] = (v / TX) % TY;
-    dvx[i] = v % TX;
+    const int vz = v / (TY * TX), vy = (v / TX) % TY, vxx = v % TX;
     const int co = oc * COW + c4 * 4;
-    dcok[i] = co < Cout;
-    drel[i] = ((dvz[i] * D1 + dvy[i]) * D2 + dvx[i]) * Cout * 4 + co * 4;
-    dlds[i] = v * DROWB + c4 * 8;
+    dmask[i] = co < Cout ? ((1u << vz) | (1u << (4 + vy)) | (1u << (8 + vxx))) : 0xFFFFFFFFu;
+    drel[i] = ((vz * D1 + vy) * D2 + vxx) * Cout * 4 + co * 4;
   }
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
@@ -1766,18 +1779,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
 #pragma unroll
     for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
-    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
+    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * CIW) * 4;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       const uint32_t vo = (xmask[i] & bad) ? OOB : (uint32_t)(xrel[i] + base);
       xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
     }
     const int dbase = ((z0 * D1 + y0) * D2 + x0) * Cout * 4;
+    uint32_t dbad = 0x80000000u;
 #pragma unroll
-    for (int i = 0; i < NDL; ++i) {
-      const bool ok = dcok[i] && z0 + dvz[i] < D0 && y0 + dvy[i] < D1 && x0 + dvx[i] < D2;
-      dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, ok ? drel[i] + dbase : (int)OOB, 0, 0));
-    }
+    for (int h = 0; h < TZ; ++h) dbad |= (z0 + h >= D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < TY; ++h) dbad |= (y0 + h >= D1) ? (1u << (4 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < TX; ++h) dbad |= (x0 + h >= D2) ? (1u << (8 + h)) : 0u;
+#pragma unroll
+    for (int i = 0; i < NDL; ++i)
+      dst[i] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, (dmask[i] & dbad) ? (int)OOB : drel[i] + dbase, 0, 0));
   };
   auto store_tile = [&](int buf) {  // four fp32 -> 3 x (four bf16 = 8 bytes)
     unsigned char* xd = lds + buf * C::BUFB;
@@ -1785,32 +1804,36 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
-      if (i == NXL - 1 && tid + NTHR * i >= NXP) continue;
+      if (NXP % NTHR != 0 && i == NXL - 1 && tid + NTHR * i >= NXP) continue;
       uint32_t p0, p1, p2, q0, q1, q2;
       syn_split3(xst[i][0], xst[i][1], p0, p1, p2);
       syn_split3(xst[i][2], xst[i][3], q0, q1, q2);
-      *reinterpret_cast<u32x2*>(xd + xlds[i]) = (u32x2){p0, q0};
-      *reinterpret_cast<u32x2*>(xd + WG_XPLANE + xlds[i]) = (u32x2){p1, q1};
-      *reinterpret_cast<u32x2*>(xd + 2 * WG_XPLANE + xlds[i]) = (u32x2){p2, q2};
+      const int xl = (tid + NTHR * i) * 8;
+      *reinterpret_cast<u32x2*>(xd + xl) = (u32x2){p0, q0};
+      *reinterpret_cast<u32x2*>(xd + WG_XPLANE + xl) = (u32x2){p1, q1};
+      *reinterpret_cast<u32x2*>(xd + 2 * WG_XPLANE + xl) = (u32x2){p2, q2};
     }
 #pragma unroll
     for (int i = 0; i < NDL; ++i) {
       uint32_t p0, p1, p2, q0, q1, q2;
       syn_split3(dst[i][0], dst[i][1], p0, p1, p2);
       syn_split3(dst[i][2], dst[i][3], q0, q1, q2);
-      *reinterpret_cast<u32x2*>(dd + dlds[i]) = (u32x2){p0, q0};
-      *reinterpret_cast<u32x2*>(dd + DPLANE + dlds[i]) = (u32x2){p1, q1};
-      *reinterpret_cast<u32x2*>(dd + 2 * DPLANE + dlds[i]) = (u32x2){p2, q2};
+      const int dl = (tid + NTHR * i) * 8;
+      *reinterpret_cast<u32x2*>(dd + dl) = (u32x2){p0, q0};
+      *reinterpret_cast<u32x2*>(dd + DPLANE + dl) = (u32x2){p1, q1};
+      *reinterpret_cast<u32x2*>(dd + 2 * DPLANE + dl) = (u32x2){p2, q2};
     }
   };
 
   // row tile RT: the bias gradient = (a row of ones) x dz, in the workgroups of the first input-channel chunk / row half only
-  const bool want_db = a.dbias != nullptr && cc == 0 && rh == 0;
+  // (CIW = 16: no extra tile -- the ones sit in the spare 28th row tile, the last one of the last row group)
+  constexpr int BT = CIW == 16 ? RT - 1 : RT, NACC = BT + 1;
+  const bool want_db = a.dbias != nullptr && cc == 0 && rh == (CIW == 16 ? GROUPS - 1 : 0);
   const uint32_t one2 = li == 0 ? 0x3f803f80u : 0u;  // A fragment whose row 0 is all ones (bf16 1.0), exact in piece 0
   const u32x4 ones = {one2, one2, one2, one2};
-  f32x4 acc[RT + 1][NT];
+  f32x4 acc[NACC][NT];
 #pragma unroll
-  for (int q = 0; q <= RT; ++q)
+  for (int q = 0; q < NACC; ++q)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -1831,7 +1854,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int n = 0; n < (STK ? 1 : NT); ++n)
-          bfr[p][n] = tr_read8(img + bbase + kj * BK + p * DPLANE + n * 32, img + bbase + kj * BK + p * DPLANE + n * 32 + 8 * DROWB);
+          bfr[p][n] = tr_read8(img + bbase + bkoff(kj) + p * DPLANE + n * 32, img + bbase + bkoff(kj) + p * DPLANE + n * 32 + 8 * DROWB);
       if constexpr (STK) {  // bfr[0][1] = U3, bfr[1][1] = U4 (bfr[2][1] unused)
         static_assert(KPW == 1, "the zero lanes of U4 take no K-step offset");
         bfr[0][1] = tr_read8(img + u3off, img + u3off + 8 * DROWB);
@@ -1839,20 +1862,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
       }
       auto aload = [&](int q, int slot) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          afr[slot][p] = tr_read8(img + abase + kj * AK + aoff[q] + p * WG_XPLANE,
-                                  img + abase + kj * AK + aoff[q] + p * WG_XPLANE + 8 * 16);
+        for (int p = 0; p < 3; ++p) {
+          afr[slot][p] = tr_read8(img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE,
+                                  img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE + 8 * XB);
+          if (CIW == 16 && q == BT && want_db) afr[slot][p] = p == 0 ? ones : (u32x4){0u, 0u, 0u, 0u};
+        }
       };
       aload(0, 0);
-      if (want_db) {
+      if constexpr (CIW == 8) {
+        if (want_db) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < 3; ++p)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            if (STK && n == 1 && p == 2) continue;
-            acc[RT][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
-                                                                  __builtin_bit_cast(bf16x8, bfr[p][n]), acc[RT][n], 0, 0, 0);
-          }
+            for (int n = 0; n < NT; ++n) {
+              if (STK && n == 1 && p == 2) continue;
+              acc[BT][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
+                                                                    __builtin_bit_cast(bf16x8, bfr[p][n]), acc[BT][n], 0, 0, 0);
+            }
+        }
       }
       sfor<0, RT>([&](auto Q) {
         constexpr int q = decltype(Q)::value;
@@ -1894,7 +1921,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   }
   // ---- add the partial sums of the WPG waves of a row group through LDS (halving), the group's first wave flushes
   float* red = reinterpret_cast<float*>(lds);  // [row group][wave slot][RT + 1][NT][4][64]
-  constexpr int WSZ = (RT + 1) * NT * 4 * 64;
+  constexpr int WSZ = NACC * NT * 4 * 64;
   static_assert((size_t)GROUPS * (WPG / 2) * WSZ * 4 <= (size_t)C::NBUF * C::BUFB, "the reduction slots fit the LDS images");
 #pragma unroll
   for (int half = WPG / 2; half >= 1; half >>= 1) {
@@ -1902,7 +1929,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     if (wg >= half && wg < 2 * half) {
       float* dstw = red + (size_t)(rh * (WPG / 2) + wg - half) * WSZ;
 #pragma unroll
-      for (int q = 0; q <= RT; ++q)
+      for (int q = 0; q < NACC; ++q)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -1912,7 +1939,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     if (wg < half) {
       const float* srcw = red + (size_t)(rh * (WPG / 2) + wg) * WSZ;
 #pragma unroll
-      for (int q = 0; q <= RT; ++q)
+      for (int q = 0; q < NACC; ++q)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -1922,7 +1949,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   if (wg != 0) return;
   if constexpr (STK) {  // columns 16-23 = columns 0-7 + 8-15 of the stacked tile (lane li + 8 of the same 16-lane row group)
 #pragma unroll
-    for (int q = 0; q <= RT; ++q)
+    for (int q = 0; q < NACC; ++q)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[q][1][i] += __shfl_down(acc[q][1][i], 8, 16);
   }
@@ -1932,12 +1959,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int col = n * 16 + li, co = oc * COW + col;
-      if (col < COW && co < Cout) atomicAdd(a.dbias + (size_t)blockIdx.x * a.det_stride + co, acc[RT][n][0]);
+      if (col < COW && co < Cout) atomicAdd(a.dbias + (size_t)blockIdx.x * a.det_stride + co, acc[BT][n][0]);
     }
   }
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
-    const int tap = 2 * (rh * RT + q) + (g >> 1);
+    const int tap = CIW == 8 ? 2 * (rh * RT + q) + (g >> 1) : rh * RT + q;
     if (tap > 26) continue;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -1945,21 +1972,21 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
       if (col >= COW || co >= Cout) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ci = a.ci_off + cc * 8 + 4 * (g & 1) + i;
+        const int ci = a.ci_off + cc * CIW + (CIW == 8 ? 4 * (g & 1) : 4 * g) + i;
         atomicAdd(dwp + ((int64_t)tap * a.cin_total + ci) * Cout + co, acc[q][n][i]);
       }
     }
   }
 }
 
-template <int COW, int NPROD, bool STK = false>
+template <int COW, int NPROD, bool STK = false, int CIW = 8>
 int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
-  using C = WgCfg<COW>;
+  using C = WgCfg<COW, CIW>;
   SplitWgArgs a = a0;
   const int gy = a.ncc * a.nco;
   const int gx = split_wgrad_grid_x(a.ntiles, gy);
   const size_t smem = (size_t)C::NBUF * C::BUFB;
-  auto kern = conv3d_split_wgrad_kernel<COW, NPROD, STK>;
+  auto kern = conv3d_split_wgrad_kernel<COW, NPROD, STK, CIW>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1978,6 +2005,9 @@ template <int COW>
 int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
   if constexpr (COW == 24) {
     if (g_products == 6 && (g_wgrad_stack & 1)) return launch_split_wgrad_np<24, 6, true>(a, st);
+  }
+  if constexpr (COW == 48) {
+    if (g_products == 6 && a.ciw == 16) return launch_split_wgrad_np<48, 6, false, 16>(a, st);
   }
   return g_products == 9 ? launch_split_wgrad_np<COW, 9>(a, st) : launch_split_wgrad_np<COW, 6>(a, st);
 }
@@ -2088,9 +2118,11 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_wgrad(const float
   a.dbias = dbias;
   a.D0 = s[0]; a.D1 = s[1]; a.D2 = s[2];
   a.Cin = Cin; a.Cout = Cout; a.cin_total = cin_total; a.ci_off = ci_off;
-  a.ncc = Cin / 8;
   // 48-wide workgroups where they divide Cout (measured in round 3: 10 % faster than 2 x 24 padded column chunks)
   const bool c48 = (Cout % 48) == 0 && !(g_wgrad_stack & 2);
+  // ... with 16 input channels each where those divide Cin (six products; option 12 bit 2 switches it off for A/B runs)
+  a.ciw = (c48 && (Cin % 16) == 0 && g_products == 6 && !(g_wgrad_stack & 4)) ? 16 : 8;
+  a.ncc = Cin / a.ciw;
   a.nco = c48 ? Cout / 48 : Cout / 24;
   a.tiles1 = (s[1] + TY - 1) / TY;
   a.tiles2 = (s[2] + TX - 1) / TX;
