@@ -27,7 +27,9 @@ extern "C" {
  * weight gradient takes the split kernel (default 1; rounds 1-3: 256), 12 = bit mask over the split weight gradient (default
  * 1): bit 0 stacked column tiles for Cout = 24 (the dz pieces are read as five column tiles, 10 instead of 12 MFMAs per row
  * tile and K step; off: two padded tiles per piece), bit 1 (A/B only) 24-column workgroups also where Cout % 48 == 0, bit 2
- * (A/B only) 8 instead of 16 input channels per 48-column workgroup where Cin % 16 == 0.  Options that change the launch geometry
+ * (A/B only) 8 instead of 16 input channels per 48-column workgroup where Cin % 16 == 0, bit 3 (A/B only) 8 instead of all 24
+ * input channels per stacked 24-column workgroup (Cin = 24).  The environment variable SYNTHSR_CONV_OPTIONS="12=9,8=3" applies
+ * options when the Python host loads the library (profiling tools only).  Options that change the launch geometry
  * or a packed layout must be set before weights are packed. */
 int synthsr_conv3d_set_option(int option, int value);
 

@@ -173,6 +173,12 @@ def load():
         if arith not in CONV_ARITHMETICS:
             raise ValueError('SYNTHSR_CONV_ARITH should be one of %s' % (CONV_ARITHMETICS,))
         lib.synthsr_set_conv_arithmetic(CONV_ARITHMETICS.index(arith))
+    opts = os.environ.get('SYNTHSR_CONV_OPTIONS')  # A/B runs of the profiling tools: "12=9,8=3" -> synthsr_conv3d_set_option
+    if opts:
+        for item in opts.split(','):
+            k, v = item.split('=')
+            if lib.synthsr_conv3d_set_option(int(k), int(v)) != 0:
+                raise ValueError('SYNTHSR_CONV_OPTIONS: option %s is not one of include/synthsr_hip_tuning.h' % k)
     _lib = lib
     return lib
 

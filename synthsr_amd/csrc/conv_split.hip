@@ -1651,6 +1651,9 @@ int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st)
 //   four row groups of two waves, four K steps per wave, one 136 KB image.  The dz tile is loaded and converted once per 16
 //   instead of once per 8 input channels and a barrier pair covers twice the matrix work: 8-21 % faster from 80^3 48->48 down
 //   to 20^3 192->192 (profiles/r04_split_wgrad_ciw16_ab.txt).  The bias row of ones takes the spare 28th row tile.
+//   CIW = 24 (the stacked 24-column kernel when Cin = 24: the 160^3 layers): all input channels in one workgroup, 40.5 row
+//   tiles whose 4 channel quads straddle taps, four row groups of 11; dz converted once instead of three times per tile,
+//   HBM traffic halves: 0.83 -> 0.72 ms inside the training step (profiles/r04_split_wgrad_ciw24_ab.txt).
 //   STK (COW = 24, six products): 24 columns are 1.5 column tiles, and two padded tiles per dz piece spend a quarter of the
 //   matrix instructions on columns nobody reads.  The transpose read takes an address per lane, so the column tiles are
 //   STACKED purely by addressing (the LDS image is unchanged): U0, U1, U2 = channels 0-15 of pieces 0, 1, 2; U3 = channels
@@ -1679,8 +1682,9 @@ template <int COW, int CIW = 8>
 struct WgCfg {
   static constexpr int NT = (COW + 15) / 16, DROWB = COW * 2, DPLANE = TZ * TY * TX * DROWB;
   static constexpr int XB = CIW * 2, XPLANE = HVOX * XB;        // bytes of a halo voxel / of a piece plane of the x image
-  static constexpr int NRT = 14 * (CIW / 8);                    // row tiles of 27 taps x CIW input channels (one spare half / tile)
-  static constexpr int RT = COW <= 24 ? 14 : 7;                 // row tiles per wave
+  // row tiles of 27 taps x CIW input channels (CIW = 8, 16: one spare half tile / tile; 24: 40.5 -> four groups of 11) ...
+  static constexpr int NRT = CIW == 24 ? 44 : 14 * (CIW / 8);
+  static constexpr int RT = CIW == 24 ? 11 : (COW <= 24 ? 14 : 7);  // ... and per wave
   static constexpr int BUFB = 3 * XPLANE + 3 * DPLANE + 64;     // + slack: the last column tile reads past a 24-channel row
   static constexpr bool DBUF = 2 * BUFB <= 160 * 1024;
   static constexpr int NBUF = DBUF ? 2 : 1;
@@ -1689,7 +1693,11 @@ struct WgCfg {
 template <int COW, int NPROD = 6, bool STK = false, int CIW = 8>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitWgArgs a) {
   static_assert(!STK || (COW == 24 && NPROD == 6), "stacked column tiles: 24 columns, six products");
-  static_assert(CIW == 8 || (CIW == 16 && COW == 48), "16 input channels per workgroup: the 48-column kernel");
+  static_assert(CIW == 8 || (CIW == 16 && COW == 48) || (CIW == 24 && COW == 24 && STK),
+                "16 input channels per workgroup: the 48-column kernel; 24: the stacked 24-column kernel");
+  // CIW = 24 (Cin = 24, the 160^3 layers): ALL input channels in one workgroup -- 648 rows = 40.5 row tiles of 4 channel quads
+  // (a tile straddles taps: quad Q = 4 tile + lq -> tap Q / 6, channels 4 (Q % 6) ..), four row groups of 11, two waves x four
+  // K steps each, one 130 KB image: the dz tile is loaded and converted once instead of three times per tile.
   // CIW = 16 (Cin % 16 == 0): a workgroup owns 16 input channels = 28 row tiles (one tap x 16 channels each) in four row
   // groups of two waves with four K steps each: the dz tile is staged and converted once per 16 instead of once per 8 input
   // channels and a barrier pair covers twice the matrix work (one 136 KB image).
@@ -1710,13 +1718,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout;
 
   // A addresses: lane i = (voxel row lrow, block lq) of the row tile: tap = 2 (rh RT + q) + (lq >> 1), channel quad lq & 1
-  // (CIW = 16: tap = rh RT + q, channel quad lq)
+  // (CIW = 16: tap = rh RT + q, channel quad lq; CIW = 24: quad Q = 4 (rh RT + q) + lq of the 27 x 6 quads)
   int aoff[RT];
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
-    int tap = CIW == 8 ? 2 * (rh * RT + q) + (lq >> 1) : rh * RT + q;
-    if (tap > 26) tap = 26;  // the spare slot of the last pair / the 28th tile: its rows are not flushed
-    aoff[q] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * XB + (CIW == 8 ? (lq & 1) : lq) * 8;
+    const int Q = 4 * (rh * RT + q) + lq;
+    int tap = CIW == 8 ? 2 * (rh * RT + q) + (lq >> 1) : (CIW == 16 ? rh * RT + q : Q / 6);
+    if (tap > 26) tap = 26;  // the spare slot of the last pair / the spare tiles: their rows are not flushed
+    aoff[q] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * XB + (CIW == 8 ? (lq & 1) : (CIW == 16 ? lq : Q % 6)) * 8;
   }
   // this wave's K step: 32 voxels = x-rows (z, yb) and (z, yb + 1); K index 8 g + j <-> voxel (row g >> 1, x = 8 (j >> 2) +
   // 4 (g & 1) + (j & 3)) -- the same bijection for both operands (conv_bf16.hip)
@@ -1736,6 +1745,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   const uint32_t u3off = bvox + (uint32_t)((lq >> 1) * DPLANE + 32 + (lq & 1) * 8);
   const uint32_t u4off = lq < 2 ? bvox + (uint32_t)(2 * DPLANE + 32 + (lq & 1) * 8) : ZOFF;
   const uint32_t u4hi = lq < 2 ? (uint32_t)(8 * DROWB) : 0u;
+  auto u4koff = [&](int kj) { return lq < 2 ? bkoff(kj) : 0u; };  // (the zero lanes take no K-step offset)
   if constexpr (STK) {
     if (tid < 2 * C::NBUF) *reinterpret_cast<uint64_t*>(lds + (tid >> 1) * C::BUFB + ZOFF + (tid & 1) * 8) = 0ull;
   }
@@ -1827,8 +1837,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
 
   // row tile RT: the bias gradient = (a row of ones) x dz, in the workgroups of the first input-channel chunk / row half only
   // (CIW = 16: no extra tile -- the ones sit in the spare 28th row tile, the last one of the last row group)
-  constexpr int BT = CIW == 16 ? RT - 1 : RT, NACC = BT + 1;
-  const bool want_db = a.dbias != nullptr && cc == 0 && rh == (CIW == 16 ? GROUPS - 1 : 0);
+  constexpr int BT = CIW != 8 ? RT - 1 : RT, NACC = BT + 1;
+  const bool want_db = a.dbias != nullptr && cc == 0 && rh == (CIW != 8 ? GROUPS - 1 : 0);
   const uint32_t one2 = li == 0 ? 0x3f803f80u : 0u;  // A fragment whose row 0 is all ones (bf16 1.0), exact in piece 0
   const u32x4 ones = {one2, one2, one2, one2};
   f32x4 acc[NACC][NT];
@@ -1856,16 +1866,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
         for (int n = 0; n < (STK ? 1 : NT); ++n)
           bfr[p][n] = tr_read8(img + bbase + bkoff(kj) + p * DPLANE + n * 32, img + bbase + bkoff(kj) + p * DPLANE + n * 32 + 8 * DROWB);
       if constexpr (STK) {  // bfr[0][1] = U3, bfr[1][1] = U4 (bfr[2][1] unused)
-        static_assert(KPW == 1, "the zero lanes of U4 take no K-step offset");
-        bfr[0][1] = tr_read8(img + u3off, img + u3off + 8 * DROWB);
-        bfr[1][1] = tr_read8(img + u4off, img + u4off + u4hi);
+        bfr[0][1] = tr_read8(img + u3off + bkoff(kj), img + u3off + bkoff(kj) + 8 * DROWB);
+        bfr[1][1] = tr_read8(img + u4off + u4koff(kj), img + u4off + u4koff(kj) + u4hi);
       }
       auto aload = [&](int q, int slot) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           afr[slot][p] = tr_read8(img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE,
                                   img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE + 8 * XB);
-          if (CIW == 16 && q == BT && want_db) afr[slot][p] = p == 0 ? ones : (u32x4){0u, 0u, 0u, 0u};
+          if (CIW != 8 && q == BT && want_db) afr[slot][p] = p == 0 ? ones : (u32x4){0u, 0u, 0u, 0u};
         }
       };
       aload(0, 0);
@@ -1964,7 +1973,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   }
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
-    const int tap = CIW == 8 ? 2 * (rh * RT + q) + (g >> 1) : rh * RT + q;
+    const int Qf = 4 * (rh * RT + q) + g;  // CIW = 24: the channel quad of accumulator rows 4 g .. 4 g + 3
+    const int tap = CIW == 8 ? 2 * (rh * RT + q) + (g >> 1) : (CIW == 16 ? rh * RT + q : Qf / 6);
     if (tap > 26) continue;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -1972,7 +1982,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
       if (col >= COW || co >= Cout) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ci = a.ci_off + cc * CIW + (CIW == 8 ? 4 * (g & 1) : 4 * g) + i;
+        const int ci = a.ci_off + cc * CIW + (CIW == 8 ? 4 * (g & 1) : (CIW == 16 ? 4 * g : 4 * (Qf % 6))) + i;
         atomicAdd(dwp + ((int64_t)tap * a.cin_total + ci) * Cout + co, acc[q][n][i]);
       }
     }
@@ -2004,6 +2014,7 @@ int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
 template <int COW>
 int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
   if constexpr (COW == 24) {
+    if (g_products == 6 && a.ciw == 24) return launch_split_wgrad_np<24, 6, true, 24>(a, st);
     if (g_products == 6 && (g_wgrad_stack & 1)) return launch_split_wgrad_np<24, 6, true>(a, st);
   }
   if constexpr (COW == 48) {
@@ -2122,6 +2133,8 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_wgrad(const float
   const bool c48 = (Cout % 48) == 0 && !(g_wgrad_stack & 2);
   // ... with 16 input channels each where those divide Cin (six products; option 12 bit 2 switches it off for A/B runs)
   a.ciw = (c48 && (Cin % 16) == 0 && g_products == 6 && !(g_wgrad_stack & 4)) ? 16 : 8;
+  // the stacked 24-column kernel with all 24 input channels in one workgroup (option 12 bit 3 switches it off for A/B runs)
+  if (!c48 && Cin == 24 && g_products == 6 && (g_wgrad_stack & 1) && !(g_wgrad_stack & 8)) a.ciw = 24;
   a.ncc = Cin / a.ciw;
   a.nco = c48 ? Cout / 48 : Cout / 24;
   a.tiles1 = (s[1] + TY - 1) / TY;
