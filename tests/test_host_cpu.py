@@ -255,6 +255,43 @@ def test_conv_arithmetic_switch_and_layer_plans():
     assert ops.conv_arithmetic() == 'split'
 
 
+def _repo_root():
+    return os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_layout_epoch_and_option_hook(monkeypatch):
+    """the layout epoch moves when (and only when) the arithmetic or a plan-changing option takes effect -- what UNet3D / Critic3D
+    re-pack on; SYNTHSR_CONV_OPTIONS applies options when the library is loaded (A/B runs of the profiling tools) and refuses
+    unknown ones (no GPU needed: host-side state of the library)"""
+    import subprocess
+    import sys
+    from synthsr_amd import _lib, ops
+    e0 = ops.conv_layout_epoch()
+    first = ops.conv_arithmetic()
+    ops.set_conv_arithmetic(first)
+    assert ops.conv_layout_epoch() == e0                      # same value: nothing to re-pack
+    other = 'fp32_mfma' if first != 'fp32_mfma' else 'split'
+    ops.set_conv_arithmetic(other)
+    e1 = ops.conv_layout_epoch()
+    assert e1 != e0
+    ops.set_conv_arithmetic(first)
+    assert ops.conv_layout_epoch() != e1
+    e2 = ops.conv_layout_epoch()
+    assert _lib.load().synthsr_conv3d_set_option(12, 1) == 0  # the weight gradient reads no packed weights: no new epoch
+    assert ops.conv_layout_epoch() == e2
+    assert _lib.load().synthsr_conv3d_set_option(10, 1) == 0  # the stacked 24-channel layout does
+    assert ops.conv_layout_epoch() != e2
+    assert _lib.load().synthsr_conv3d_set_option(99, 1) == -1
+    code = ('import os, sys; sys.path.insert(0, %r); from synthsr_amd import _lib; lib = _lib.load(); '
+            'print(lib.synthsr_conv3d_pack(None, None, _lib.i3([160, 160, 160]), 24, 24, 0, None))' % _repo_root())
+    env = dict(os.environ, SYNTHSR_CONV_OPTIONS='10=0,12=9')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and int(out.stdout.split()[-1]) == 3 * 3 * 7 * 2 * 64 * 4, out.stderr[-500:]   # not stacked
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, SYNTHSR_CONV_OPTIONS='99=1'), capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode != 0 and 'SYNTHSR_CONV_OPTIONS' in out.stderr
+
+
 def test_product_fails_loudly_without_the_library(monkeypatch, tmp_path):
     from synthsr_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)
