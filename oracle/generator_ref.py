@@ -265,6 +265,16 @@ def sample_gmm(labels, generation_labels, means, stds, noise):
     return sm * f32(noise) + mm  # :498
 
 
+def sample_gmm_batch(labels, generation_labels, means, stds, noise):
+    """SampleConditionalGMM.call on a batch (layers.py:480-498) AS THE REFERENCE COMPUTES IT: the scatter indices are tiled
+    over the batch (:482-483) and scattered into one table of shape [max index + 1] (:490, :495), where tf.scatter_nd adds up
+    what lands on the same index -- the per-label means / stds of all B items are SUMMED, the table is tiled back over the
+    batch and every item gathers from the sums (pinned by tests/golden/gmm_batch.npz).
+    labels int [B,X,Y,Z], means / stds [B,L,C], noise [B,X,Y,Z,C]"""
+    msum, ssum = f32(means).sum(0, dtype=F), f32(stds).sum(0, dtype=F)
+    return np.stack([sample_gmm(labels[b], generation_labels, msum, ssum, noise[b]) for b in range(len(labels))], 0)
+
+
 def bias_field(x, u_std, n_small, u_gate, bias_std, bias_scale, prob=0.95):
     """BiasFieldCorruption.call (layers.py:1067-1097) for one single-channel volume x [X,Y,Z,1]"""
     shape = x.shape[:3]

@@ -74,9 +74,10 @@ class AdversarialTrainer:
         B = int(np.asarray(means).shape[0])
         self.net.set_batch(B)
         imgs, tgts, segs = None, None, []
+        means_b, stds_b = hm.batch_gmm_parameters(means, stds, getattr(self.gen, 'sum_gmm_over_batch', False))
         for b in range(B):
             real = np.asarray(inputs[3])[b, ..., 0] if getattr(self.gen, 'use_real_image', False) else None
-            image, target, seg = self.gen.generate(np.asarray(labels)[b, ..., 0], np.asarray(means)[b], np.asarray(stds)[b],
+            image, target, seg = self.gen.generate(np.asarray(labels)[b, ..., 0], means_b[b], stds_b[b],
                                                    None, real_image=real)
             if B == 1:
                 return image, target, [seg]

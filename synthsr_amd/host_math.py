@@ -328,6 +328,19 @@ def gmm_luts(generation_labels, means, stds):
     return lut
 
 
+def batch_gmm_parameters(means, stds, sum_over_batch=False):
+    """per-item GMM parameters of a batch: means / stds [B, L, C] -> two lists of B arrays [L, C].
+    sum_over_batch: what the reference's SampleConditionalGMM does to a batch -- its scatter indices are tiled over the batch
+    and scattered into ONE look-up table, so every item samples from the SUM of the B items' means / stds
+    (ext/lab2im/layers.py:482-495; SURVEY F9, tests/golden/gmm_batch.npz).  Identical for B = 1."""
+    means, stds = _f(means), _f(stds)
+    B = means.shape[0]
+    if sum_over_batch and B > 1:
+        m, s = means.sum(0, dtype=_F), stds.sum(0, dtype=_F)
+        return [m] * B, [s] * B
+    return [means[b] for b in range(B)], [stds[b] for b in range(B)]
+
+
 def draw_value_from_distribution(hyperparameter, size=1, distribution='uniform', centre=0., default_range=10.0,
                                  positive_only=False, rng=None):
     """`size` values from U(a, b) or N(a, b) with (a, b) given as in ext/lab2im/utils.py:961-1049 (numpy branch): None ->

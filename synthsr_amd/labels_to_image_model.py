@@ -15,7 +15,8 @@ Scope: synthetic or real-image (output_channel=None, §8f-4) regres
 resolution (non-separable or, for |sigma| > 5, separable blur) or `randomise_res=True` (SampleResolution /
 DynamicGaussianBlur / MimicAcquisition, §8f-2 generator half), with or without registration error.
 Batch items are generated independently; for batchsize > 1 the reference sums the GMM LUT over the
-batch (F9, a bug) — that is NOT reproduced.
+batch (F9, a bug: every item samples from the SUM of the items' means / stds) — reproduced only on request
+(`model.sum_gmm_over_batch = True`, `training(..., reference_batch_gmm=True)`; host_math.batch_gmm_parameters).
 """
 import ctypes
 import numpy as np
@@ -50,6 +51,7 @@ class LabelsToImageModel:
         self.torch = torch
         self.lib = _lib.load()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.sum_gmm_over_batch = False   # True: the reference's batch-wise LUT sum (F9), see host_math.batch_gmm_parameters
 
         # ---- parameter normalisation, SynthSR/labels_to_image_model.py:69-100
         input_channels = [bool(c) for c in hm.reformat_to_list(input_channels)]
@@ -652,8 +654,9 @@ class LabelsToImageModel:
         real = np.asarray(inputs[3]) if self.use_real_image else None  # 4th Keras input 'real_image_input'
         B = labels.shape[0]
         images, targets = [], []
+        means_b, stds_b = hm.batch_gmm_parameters(means, stds, self.sum_gmm_over_batch)
         for b in range(B):
-            img, tgt, _ = self.generate(labels[b, ..., 0], np.asarray(means)[b], np.asarray(stds)[b],
+            img, tgt, _ = self.generate(labels[b, ..., 0], means_b[b], stds_b[b],
                                         None if draws is None else draws[b],
                                         real_image=None if real is None else real[b, ..., 0])
             if B > 1:

@@ -102,17 +102,18 @@ class Trainer:
 
     def _generate_batch(self, model_inputs, draws, B):
         """batchsize > 1 (SynthSR/training.py:52): the B items of the batch are generated one after the other (each with
-        its own label map, GMM parameters and draws -- the reference's batch-wise GMM LUT bug F9 is not reproduced) and
-        stacked along the first spatial axis, the layout UNet3D.set_batch works on"""
+        its own label map, GMM parameters and draws -- the reference's batch-wise GMM LUT sum, F9, only when the generator
+        says so: gen.sum_gmm_over_batch) and stacked along the first spatial axis, the layout UNet3D.set_batch works on"""
         import torch
         gen = self.gen
         if draws is not None and len(draws) != B:
             raise ValueError('one set of draws per batch item')
         labels, means, stds = model_inputs[:3]
         imgs, tgts = [], []
+        means_b, stds_b = hm.batch_gmm_parameters(means, stds, getattr(gen, 'sum_gmm_over_batch', False))
         for b in range(B):
             real = np.asarray(model_inputs[3])[b, ..., 0] if getattr(gen, 'use_real_image', False) else None
-            image, target, seg = gen.generate(np.asarray(labels)[b, ..., 0], np.asarray(means)[b], np.asarray(stds)[b],
+            image, target, seg = gen.generate(np.asarray(labels)[b, ..., 0], means_b[b], stds_b[b],
                                               None if draws is None else draws[b], real_image=real)
             if b == 0:
                 key = (B,) + tuple(image.shape) + tuple(target.shape)
@@ -338,8 +339,10 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
              feat_multiplier=2, dropout=0, activation='elu', lr=1e-4, lr_decay=0, epochs=100, steps_per_epoch=1000,
              regression_metric='l1', work_with_residual_channel=None, loss_cropping=None, checkpoint=None,
              model_file_has_different_lhood_layer=False, seed=0, verbose=True, dtype='f32', deterministic=False,
-             segnet_frozen_bn='batch'):
-    """Parameters as documented in SynthSR/training.py:90-240 (+ `seed`, `verbose`, `dtype`: 'f32' like the reference, or
+             segnet_frozen_bn='batch', reference_batch_gmm=False):
+    """Parameters as documented in SynthSR/training.py:90-240 (+ `reference_batch_gmm`: at batchsize > 1 sample every item
+    from the SUM of the batch's GMM means / stds like the reference's SampleConditionalGMM does (a bug; off: each
+    item from its own); `seed`, `verbose`, `dtype`: 'f32' like the reference, or
     'bf16' = bf16 activations / packed weights with fp32 accumulation, BatchNorm statistics and master weights,
     BASELINE.json configs[3]; `deterministic`: bit-identical weights run after run for the same seed, ops.set_deterministic,
     1.2x (fp32) / 1.4x (bf16) slower at 160^3; `segnet_frozen_bn`: what the frozen
@@ -427,6 +430,7 @@ def training(labels_dir, model_dir, prior_means, prior_stds, path_generation_lab
                                      build_reliability_maps=build_reliability_maps, bias_field_std=bias_field_std,
                                      bias_shape_factor=bias_shape_factor, rng=rng)
     brain_generator.labels_to_image_model.seed(seed, rank)
+    brain_generator.labels_to_image_model.sum_gmm_over_batch = bool(reference_batch_gmm)
     unet_input_shape = brain_generator.model_output_shape
     n_output_channels = 1 if output_channel is None else len(output_channel)
     if regression_metric == 'laplace':  # intensities + spreads (SynthSR/training.py:325-326)

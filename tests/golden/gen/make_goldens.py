@@ -455,7 +455,29 @@ def golden_estimate_priors():
     print('estimate_priors', pm.shape, ps.shape, pm1.shape)
 
 
+def golden_gmm_batch():
+    """SampleConditionalGMM on a BATCH of two (ext/lab2im/layers.py:480-498): the scatter indices are tiled over the batch and
+    scattered into ONE look-up table, so the per-label means / stds of the two items are SUMMED and both items sample from
+    the sums; two channels, different label crops and statistics per item"""
+    out = {}
+    rng = np.random.default_rng(23)
+    lab = np.stack([load_label_crop(1, (60, 70, 60), (12, 10, 16)), load_label_crop(2, (55, 80, 60), (12, 10, 16))])[..., None]
+    m0, s0 = class_stats(rng, ('t1_hr', 't2'))
+    m1, s1 = class_stats(rng, ('t1_hr', 't2'))
+    means, stds = np.concatenate([m0, m1], 0), np.concatenate([s0, s1], 0)
+    tape = shim.Tape(seed=37)
+    shim.set_tape(tape)
+    img = l2i_layers.SampleConditionalGMM(GEN_LABELS)([t(lab), t(means), t(stds)])
+    out['gmm2_labels'], out['gmm2_means'], out['gmm2_stds'], out['gmm2_out'] = lab, means, stds, np.asarray(img)
+    out.update(tape_to_dict(tape, 'gmm2_tape'))
+    np.savez_compressed(os.path.join(OUT, 'gmm_batch.npz'), **out)
+    print('gmm_batch.npz', {k: getattr(v, 'shape', None) for k, v in out.items()})
+
+
 if __name__ == '__main__':
+    if 'gmm_batch' in sys.argv[1:]:
+        golden_gmm_batch()
+        sys.exit(0)
     which = sys.argv[1:] or ['resampler', 'host_math', 'layers', 'graphs', 'inference', 'estimate_priors', 'metrics', 'separable']
     if 'metrics' in which:
         golden_metrics()

@@ -99,6 +99,30 @@ def test_sigma_and_shapes_and_lut():
     assert R.swap_lut(np.arange(5), 5) is None
 
 
+def test_gmm_on_a_batch_sums_the_items_parameters(gen_labels):
+    """F9: SampleConditionalGMM on a batch of two scatters the tiled indices into ONE look-up table: both items sample from the
+    SUM of the two items' means / stds (ext/lab2im/layers.py:482-495).  The reference layer's output on the shim, bit for bit;
+    the per-item LUTs (what this build does unless asked) do NOT reproduce it; host_math.batch_gmm_parameters is the switch."""
+    from synthsr_amd import host_math as hm
+    g = load_golden('gmm_batch')
+    lab, means, stds, noise = g['gmm2_labels'][..., 0], g['gmm2_means'], g['gmm2_stds'], g['gmm2_tape_00']
+    np.testing.assert_array_equal(R.sample_gmm_batch(lab, gen_labels, means, stds, noise), g['gmm2_out'])
+    per_item = np.stack([R.sample_gmm(lab[b], gen_labels, means[b], stds[b], noise[b]) for b in range(2)], 0)
+    assert np.abs(per_item - g['gmm2_out']).max() > 10
+    mb, sb = hm.batch_gmm_parameters(means, stds, sum_over_batch=True)
+    out = np.stack([R.sample_gmm(lab[b], gen_labels, mb[b], sb[b], noise[b]) for b in range(2)], 0)
+    np.testing.assert_array_equal(out, g['gmm2_out'])
+    assert np.array_equal(mb[0], mb[1]) and np.array_equal(mb[0], means[0] + means[1])
+    # the LUTs handed to the device kernel: the host restatement agrees with the oracle's, summed or not
+    for b in range(2):
+        lut = hm.gmm_luts(gen_labels, mb[b], sb[b])
+        np.testing.assert_array_equal(lut[0], R.gmm_lut(gen_labels, means.sum(0, dtype=np.float32)))
+    m1, s1 = hm.batch_gmm_parameters(means, stds)
+    assert np.array_equal(m1[1], means[1]) and np.array_equal(s1[0], stds[0])
+    m0, _ = hm.batch_gmm_parameters(means[:1], stds[:1], sum_over_batch=True)
+    assert np.array_equal(m0[0], means[0])
+
+
 def test_layers(gen_labels):
     g = load_golden('layers')
     # GMM: two channels, per-channel LUT
