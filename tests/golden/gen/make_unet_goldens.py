@@ -406,7 +406,71 @@ def golden_batch_dropout(out):
     print('batch + dropout pred', out['b2d_pred'].shape, 'dropout layers', len(ks.STATE['dropout']), 'with different masks per sample:', differ)
 
 
+def golden_seg_loss_limits():
+    """What the REFERENCE's own graph does for the two segmentation-loss configurations this build refuses with a ValueError:
+    (a) two regression targets (`output_channel=[0, 1]`): training() builds the segmentation unet on `[..., 1]`
+    (SynthSR/training.py:375) and add_seg_loss_to_model feeds it the whole `predicted_image` (metrics_model.py:149-163);
+    (b) `target_res != atlas_res`: `segmentation_target` lives on the label maps' grid, the posteriors on the prediction's, and
+    DiceLoss multiplies them voxel by voxel (metrics_model.py:187-207, ext/lab2im/layers.py:1300-1320).
+    The glue is golden_seg_loss's; the outcome (exception type and message on the shim, or the loss value if the graph builds)
+    goes to tests/golden/seg_loss_limits.json.  The shim checks shapes the way the ops it stands in for do (a convolution's
+    kernel against its input's channel count, an element-wise product's operand shapes); it is not Keras, so the record shows
+    THAT the reference graph breaks there, not the text Keras would print."""
+    import json
+    import keras.layers as KL
+    rng = np.random.default_rng(7)
+    res = {}
+    gen_labels = np.array([0, 2, 3, 4, 41, 42, 43])
+    seg_labels = np.array([0, 2, 3, 41, 42, 2, 77])
+    for tag, S, S_seg, n_out in (('control_one_target_same_grid', [16, 16, 16], [16, 16, 16], 1),
+                                 ('two_regression_targets', [16, 16, 16], [16, 16, 16], 2),
+                                 ('segmentation_target_on_another_grid', [16, 16, 16], [8, 8, 8], 1)):
+        image = rng.uniform(0, 1, [1] + S + [2]).astype(np.float32)
+        target = rng.uniform(0, 1, [1] + S + [n_out]).astype(np.float32)
+        seg = rng.integers(0, len(gen_labels), [1] + S_seg).astype(np.int32)
+        ks.reset(seed=4)
+        ks.STATE['frozen_bn_inference'] = False
+        FEED[:] = [('gen_image', image), ('gen_target', target), ('gen_seg', seg[..., None])]
+        im_in = KL.Input(shape=S + [2], name='gen_image')
+        tg_in = KL.Input(shape=S + [n_out], name='gen_target')
+        sg_in = KL.Input(shape=S_seg + [1], name='gen_seg', dtype='int32')
+        seg_t = KL.Lambda(lambda x: x + 0, name='segmentation_target')(sg_in)
+        tg = KL.Lambda(lambda x: x[0] + 0., name='regression_target')([tg_in, seg_t])
+        im = KL.Lambda(lambda x: x[0] + 0., name='image_out')([im_in, tg])
+        gen = models.Model(inputs=[im_in, tg_in, sg_in], outputs=[im, tg])
+        rec = {'prediction_grid': S, 'segmentation_target_grid': S_seg, 'regression_targets': n_out}
+        try:
+            model = nrn_models.unet(nb_features=4, input_shape=S + [2], nb_levels=2, conv_size=3, nb_labels=n_out,
+                                    feat_mult=2, nb_conv_per_level=2, conv_dropout=0, final_pred_activation='linear',
+                                    batch_norm=-1, activation='elu', input_model=gen)
+            model = models.Model(model.inputs, model.output)
+            model = ref_mm.metrics_model(input_model=model, loss_cropping=None, metrics='l1', work_with_residual_channel=None)
+            ks.PARAMS.clear()
+            FEED[:] = [('unet_input', np.zeros([1] + S + [1], np.float32))]
+            seg_model = nrn_models.unet(nb_features=4, input_shape=S + [1], nb_levels=2, conv_size=3,     # training.py:375
+                                        nb_labels=len(seg_labels), feat_mult=2, nb_conv_per_level=2, conv_dropout=0,
+                                        final_pred_activation='softmax', batch_norm=-1, activation='elu', input_model=None)
+            total = ref_mm.add_seg_loss_to_model(input_model=model, seg_model=seg_model, generation_labels=gen_labels,
+                                                 segmentation_label_equivalency=seg_labels, rel_weight=.25,
+                                                 loss_cropping=None, m=None, M=None, fs_header=False)
+            rec.update(raised=False, total_loss=float(np.asarray(total.outputs[0])))
+        except Exception as e:   # noqa: BLE001 -- the outcome IS the record
+            import traceback
+            frames = traceback.extract_tb(e.__traceback__)
+            where = [f for f in frames if '/root/reference/' in f.filename]
+            rec.update(raised=True, type=type(e).__name__, message=str(e)[:300],
+                       reference_frame=None if not where else '%s:%d' % (where[-1].filename.replace('/root/reference/', ''),
+                                                                         where[-1].lineno))
+        res[tag] = rec
+        print(tag, rec)
+    with open(os.path.join(OUT, 'seg_loss_limits.json'), 'w') as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
+    if 'seg_limits' in sys.argv[1:]:
+        golden_seg_loss_limits()
+        sys.exit(0)
     which = sys.argv[1:] or ['wiring', 'graph', 'seg', 'critic', 'dropout', 'batch', 'batch_dropout']
     if 'batch_dropout' in which:
         out = {}

@@ -292,6 +292,28 @@ def test_layout_epoch_and_option_hook(monkeypatch):
     assert out.returncode != 0 and 'SYNTHSR_CONV_OPTIONS' in out.stderr
 
 
+def test_refused_segmentation_loss_configurations_break_the_reference_graph_too():
+    """The two segmentation-loss configurations this build refuses with a ValueError are ones the reference's own graph
+    cannot be built for: tests/golden/seg_loss_limits.json records what add_seg_loss_to_model does on the shim
+    (tests/golden/gen/make_unet_goldens.py seg_limits) -- the control builds and gives a loss; two regression targets fail
+    where the single-channel segmentation unet is applied to `predicted_image` (metrics_model.py:165); a segmentation target
+    on another grid fails the reference's OWN assertion in DiceLoss.build (ext/lab2im/layers.py:1314)."""
+    import json
+    with open(os.path.join(REPO, 'tests', 'golden', 'seg_loss_limits.json')) as f:
+        rec = json.load(f)
+    assert rec['control_one_target_same_grid']['raised'] is False and rec['control_one_target_same_grid']['total_loss'] > 0
+    two = rec['two_regression_targets']
+    assert two['raised'] and two['reference_frame'].startswith('SynthSR/metrics_model.py:')
+    grid = rec['segmentation_target_on_another_grid']
+    assert grid['raised'] and grid['reference_frame'].startswith('ext/lab2im/layers.py:') and \
+        'same shape' in grid['message']
+    # ours: refused before anything is built (no GPU, no files needed)
+    from synthsr_amd.fine_tuning_with_adversary import training as adv_training
+    with pytest.raises(ValueError, match='ONE regression target'):
+        adv_training('/nonexistent/labels', None, '/nonexistent/models', None, None, '/nonexistent/gl.npy',
+                     segmentation_model_file='/nonexistent/seg.npz', input_channels=[True, True], output_channel=[0, 1])
+
+
 def test_product_fails_loudly_without_the_library(monkeypatch, tmp_path):
     from synthsr_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)
