@@ -211,8 +211,11 @@ def test_split_tile_schedule_visits_every_tile_once_and_evenly():
             for yz in range(groups):
                 column(2, nt, groups, yz)
     # the weight-gradient widths of the network: 256 // (chunks x column groups) = 85, 42, 21, 10 are not multiples of 8
-    for nt, ny, width in ((16000, 3, 85), (2000, 6, 42), (300, 12, 21), (300, 24, 10)):
-        gx, loads = column(1, nt, ny, 2)
+    # (round 4, 16 / 24 input channels per workgroup: 160^3 24->24 one chunk, 80^3 48->48 three, 40^3 96->96 6 x 2,
+    #  20^3 192->192 12 x 4, 10^3 384->384 24 x 8 chunks x column groups)
+    for nt, ny, width in ((16000, 3, 85), (2000, 6, 42), (300, 12, 21), (300, 24, 10), (16000, 1, 256), (2000, 3, 85),
+                          (50, 48, 5), (9, 192, 1)):
+        gx, loads = column(1, nt, ny, min(2, ny - 1))
         assert gx == width and max(loads) - min(loads) <= 1, (gx, loads)
     # awkward small cases: fewer tiles than XCDs, one tile more than a multiple of 8, primes
     for nt in (1, 2, 7, 8, 9, 50, 63, 65, 257, 300, 301, 1031):
