@@ -8,11 +8,34 @@ here.  This file restates their documented Keras 2.3.1 semantics w
 autograd and serves as the independent float32 implementation the HIP kernels are compared against,
 and as the U-Net half of bench.py's cpu_baseline.  Only tests/, smoke() and bench.py import it.
 """
+import contextlib
 import math
 import torch
 import torch.nn.functional as F
 
 BN_EPS = 1e-3
+
+_COMPUTE = None   # None: compute in the dtype of the tensors handed in (float32 in every parity test)
+
+
+@contextlib.contextmanager
+def compute_dtype(dtype):
+    """Inside this context unet_forward / seg_regularisation evaluate in `dtype` (torch.float64) whatever they are handed:
+    inputs and parameters are cast on entry, so autograd still delivers `.grad` on the caller's float32 leaves (the float64
+    gradient rounded once).  The parity tests use it as their yardstick: the device's distance from the float64 result is
+    bounded by the distance of this same oracle evaluated in float32 (tests/conftest.py: single_shot_parity)."""
+    global _COMPUTE
+    prev, _COMPUTE = _COMPUTE, dtype
+    try:
+        yield
+    finally:
+        _COMPUTE = prev
+
+
+def _cd(t):
+    if _COMPUTE is None or t is None or not torch.is_tensor(t) or not t.is_floating_point():
+        return t
+    return t.to(_COMPUTE)
 
 
 def to_ncdhw(x):  # [d0,d1,d2,C] -> [1,C,d0,d1,d2];  a batch [B,d0,d1,d2,C] -> [B,C,d0,d1,d2]
@@ -88,6 +111,10 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
     did (a few ulp on one element of an identified window; tests/conftest.py: align_pool_ties) -- max-pooling is
     discontinuous, and which of two values within float32 rounding of each other wins is not a property of the algorithm."""
     L = nb_levels
+    if _COMPUTE is not None:
+        x, P = _cd(x), {k: _cd(v) for k, v in P.items()}
+        moving = None if moving is None else {k: _cd(v) for k, v in moving.items()}
+        pool_nudge = None if pool_nudge is None else [_cd(n) for n in pool_nudge]
     if quant is not None:
         x = quant(x)
         P = {k: (quant(v) if k.endswith('/kernel') and 'likelihood' not in k else v) for k, v in P.items()}
@@ -149,7 +176,7 @@ def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, g
     compared with the generator's label map by the soft Dice over the generation labels that have an equivalent
     (:187-207).  NB the reference builds the ground-truth one-hot as `segmentation_target == i` with i the INDEX of the
     generation label (:191), not its value; mirrored here.  Returns the Dice loss (scalar tensor)."""
-    x = pred_image
+    x = _cd(pred_image)
     if m is not None:
         x = (torch.clamp(x, m, M) - m) / (M - m)
     x = x[..., None]
@@ -175,7 +202,7 @@ def seg_regularisation(pred_image, seg_target, Pseg, prefix, nb_levels, nconv, g
         if len(idx) > 0:
             if len(idx) > 3:
                 raise Exception("uuummm weird that you're merging so many labels...")
-            gts.append((seg_target == i).float())
+            gts.append((seg_target == i).to(probs.dtype))
             preds.append(sum(probs[..., int(j)] for j in idx))
     return dice_loss(torch.stack(gts, -1), torch.stack(preds, -1))
 
@@ -189,7 +216,7 @@ def tf_image_ssim(img1, img2, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=
     `_ssim_helper`, window `_fspecial_gauss`), restated from the published algorithm -- TensorFlow is a third-party
     dependency of the reference (requirements.txt: tensorflow-gpu==2.0.0), not vendored, so this restatement is UNPINNED.
     img1, img2 [..., H, W, C]; returns [...] = mean over channels of the per-channel SSIM."""
-    coords = torch.arange(filter_size, dtype=torch.float32) - (filter_size - 1) / 2.0
+    coords = torch.arange(filter_size, dtype=img1.dtype) - (filter_size - 1) / 2.0
     g = coords ** 2 * (-0.5 / (filter_sigma * filter_sigma))
     g = (g.reshape(1, -1) + g.reshape(-1, 1)).reshape(-1)
     kernel = torch.softmax(g, 0).reshape(1, 1, filter_size, filter_size)      # 2-D window, sums to 1
@@ -234,6 +261,7 @@ def regression_loss(pred, target, kind='l1', loss_cropping=None, residual=None):
         intens, spread = pred, None
     if residual is not None:
         intens = intens + residual
+    target = target.to(intens.dtype)   # (float64 inside compute_dtype)
     if loss_cropping is not None:
         size = [int(loss_cropping)] * 3 if not hasattr(loss_cropping, '__len__') else [int(v) for v in loss_cropping]
         b = [int((s - c) / 2) for s, c in zip(target.shape[:3], size)]

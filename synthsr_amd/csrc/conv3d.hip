@@ -1392,6 +1392,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_c2_kernel(const float* __re
     // x-rows of 1536 contiguous bytes each in memory: written to the wave's own 6 KB of LDS voxel by voxel and read back as 384
     // consecutive 16-byte pieces, six per lane, every store instruction covers 1 KB of consecutive addresses.
     float* ot = otile + wave * (64 * Cout);
+    // (the wave's 6 KB are its own: a wave barrier + a wavefront-scope fence order this tile's writes after the previous tile's
+    // read-back and before the read-back below -- no reliance on the DS queue's in-order execution or on instruction order)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
       float4 v = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
@@ -1410,6 +1414,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_c2_kernel(const float* __re
       *reinterpret_cast<float4*>(ot + lane * Cout + 4 * g) = v;
     }
     const int gz = z0 + wave;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const int q = lane + 64 * k;           // 16-byte piece of the wave's tile: row q / 96, piece c of the row

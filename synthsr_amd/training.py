@@ -153,18 +153,46 @@ class Trainer:
         self.resident_labels = [self._to_device_labels(m) for m in label_maps]
 
     # training() keeps every label map it has used on the device (SynthSR/model_inputs.py:86-107 re-reads the file each step;
-    # a 160^3 map is 4 MB as uint8): up to this many bytes, beyond that the remaining maps are copied per step as before
+    # a 160^3 map is 4 MB as uint8): up to POOL_FRACTION of the device memory that is free when the pool is first used (the
+    # network and its activations are allocated by then), and never more than POOL_BYTES; beyond that, and after any
+    # allocation failure, the remaining maps are copied per step as before (one upload per step, never two)
     POOL_BYTES = 64 << 30
+    POOL_FRACTION = 0.25
+
+    def _pool_budget(self):
+        import torch
+        cap = self.__dict__.get('_auto_pool_cap')
+        if cap is None:
+            free, _ = torch.cuda.mem_get_info(self.gen.device)
+            cap = self._auto_pool_cap = min(int(self.POOL_BYTES), int(self.POOL_FRACTION * free))
+        return cap
 
     def _pooled_labels(self, index, host_map):
+        """the device copy of label map `index` (uploaded once, narrowest integer type), or None when the pool is full or
+        switched off: the caller then hands the host map to the generator"""
+        import torch
         pool = self.__dict__.setdefault('_auto_pool', {})
         t = pool.get(index)
-        if t is None:
-            used = sum(v.numel() * v.element_size() for v in pool.values())
-            t = self._to_device_labels(host_map)
-            if used + t.numel() * t.element_size() > self.POOL_BYTES:
-                return None
-            pool[index] = t
+        if t is not None or not self.auto_pool:
+            return t
+        if self.__dict__.get('_auto_pool_full'):
+            return None
+        gen = self.gen
+        m = np.asarray(host_map).reshape(gen.input_labels_shape)
+        if gen.padding_margin is not None:  # PadAroundCentre (ext/lab2im/layers.py:1754) once, on the host copy
+            m = np.pad(m, [(p, p) for p in gen.padding_margin])
+        host = self._narrowest_labels(m)
+        used = self.__dict__.get('_auto_pool_used', 0)
+        if used + host.nbytes > self._pool_budget():   # full: checked on the host array, BEFORE anything is uploaded
+            self._auto_pool_full = True
+            return None
+        try:
+            t = torch.from_numpy(host).to(gen.device)
+        except torch.cuda.OutOfMemoryError:            # somebody else took the memory: stop pooling, keep what is there
+            self._auto_pool_full = True
+            return None
+        pool[index] = t
+        self._auto_pool_used = used + host.nbytes
         return t
 
     def step(self, model_inputs=None, draws=None, label_index=None):

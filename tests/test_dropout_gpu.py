@@ -73,11 +73,7 @@ def test_dropout_network_vs_oracle(feats, levels, shape, cin, nconv, rate, fold)
         err = (net.test_pred.view(*shape, 1).cpu() - pr).abs().max().item() / pr.abs().max().item()
         assert err < 5e-4, err
         assert abs(net.test_loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
-        for nm, _, kind in net.specs:
-            got = net.view(nm, net.grads).cpu().double()
-            ref_g = P[nm].grad.double()
-            e = (got - ref_g).abs().max().item() / max(ref_g.abs().max().item(), 1e-12)
-            assert e < (2e-3 if kind in ('kernel', 'head_w') else 5e-3), (nm, e)
+        # (every parameter gradient: the float64-anchored rule of conftest.single_shot_parity)
 
     net, _ = single_shot_parity(run, oracle, compare)
     x, sc = tensors['x'], tensors['sc']

@@ -264,3 +264,47 @@ def test_network_step_agrees_between_the_two_arithmetics():
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
     assert cos > 1 - 1e-6, cos
     assert float((g0 - g1).abs().max()) < 2e-3 * float(g0.abs().max())   # max-pool ties may route a few gradients differently
+
+
+@pytest.mark.parametrize('shape,ci,co', [
+    ((16, 16, 32), 24, 24), ((32, 16, 16), 24, 24), ((8, 8, 16), 24, 24), ((4, 4, 16), 24, 24), ((20, 20, 20), 24, 24),
+    ((10, 10, 10), 24, 24), ((18, 14, 34), 24, 24), ((5, 7, 9), 24, 24),          # Cin = Cout = 24: all 24 input channels per workgroup
+    ((16, 16, 32), 48, 48), ((8, 8, 16), 96, 48), ((12, 10, 18), 48, 96), ((10, 10, 10), 192, 192),   # Cin % 16 == 0, Cout % 48 == 0
+    ((16, 16, 32), 24, 48), ((8, 12, 16), 72, 24), ((6, 6, 6), 8, 24)])            # 8 input channels per workgroup
+def test_split_weight_gradient_small_and_ragged_layers_vs_float64(shape, ci, co):
+    """every split weight-gradient kernel at the sizes the small whole-network tests run it (since round 4 the split kernel takes
+    layers of ANY size: include/synthsr_hip_tuning.h option 11) -- few tiles, volumes that are no multiples of the 4x4x16 tile, and
+    TWO volumes accumulated into one dW / dbias as a batch does (synthsr_amd/unet.py: set_batch) -- against a float64 evaluation,
+    next to the fp32 matrix instructions; ordered sums and float atomics."""
+    from synthsr_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(sum(shape) + 7 * ci + co)
+    xs = [torch.randn(*shape, ci, generator=g) for _ in range(2)]
+    dys = [torch.randn(*shape, co, generator=g) * s for s in (1.0, 1.7)]
+    ref_w = sum(_wgrad64(x, dy) for x, dy in zip(xs, dys))
+    ref_b = sum(dy.double().sum((0, 1, 2)) for dy in dys)
+    xs, dys = [x.cuda() for x in xs], [dy.cuda() for dy in dys]
+    res = {}
+    prev = ops.conv_arithmetic()
+    try:
+        for mode in ('fp32_mfma', 'split'):
+            ops.set_conv_arithmetic(mode)
+            assert ops.conv_runs_split('conv3d_wgrad', shape, ci, co) == (mode == 'split')
+            for det in (True, False):
+                prev_det = ops.set_deterministic(det)
+                try:
+                    dw, db = torch.zeros(3, 3, 3, ci, co, device='cuda'), torch.zeros(co, device='cuda')
+                    for x, dy in zip(xs, dys):
+                        ops.conv3d_wgrad(x, dy, dw, db)
+                    assert not det or ops.deterministic_status() == 1
+                finally:
+                    ops.set_deterministic(prev_det)
+                res[mode, det] = (_err(dw, ref_w), _err(db, ref_b))
+    finally:
+        ops.set_conv_arithmetic(prev)
+    for det in (True, False):
+        for k, name in enumerate(('weight gradient', 'bias gradient')):
+            (nmax, nrms), (smax, srms) = res['fp32_mfma', det][k], res['split', det][k]
+            # an fp32 result in absolute terms (sums of <= 2 x 16 384 products: rms error below 2e-6 of the result's rms, worst
+            # element 2e-5), and not less accurate than the fp32 matrix instructions (rms 1.5x, worst element 2.5x; + floors)
+            assert srms < 2e-6 and smax < 2e-5, (name, det, res)
+            assert srms <= 1.5 * nrms + 2e-8 and smax <= 2.5 * nmax + 2e-7, (name, det, res)

@@ -418,3 +418,45 @@ def test_generation_examples_script(tmp_path, case):
         tg, _, _ = read_nifti(str(tmp_path / 'out' / ('target_%d.nii.gz' % i)))
         assert im.shape[:3] == (32, 32, 32) and (im.shape[3] if im.ndim == 4 else 1) == n_in and tg.shape == (32, 32, 32)
         assert np.isfinite(im).all() and np.isfinite(tg).all() and tg.max() > 0
+
+
+def test_label_pool_respects_its_budget_and_falls_back_to_per_step_copies():
+    """Trainer.step() keeps the label maps it has used on the device (synthsr_amd/training.py: _pooled_labels): the pool's budget is
+    derived from the free device memory (and POOL_BYTES), checked on the host array before anything is uploaded; a full pool
+    stops growing and the remaining maps go through the per-step host path -- same training, no second upload."""
+    import torch
+    from synthsr_amd.brain_generator import BrainGenerator
+    from synthsr_amd.training import Trainer
+    from synthsr_amd.unet import unet
+    from synthsr_amd.synthetic import (synthetic_label_pool, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
+                                       PRIOR_STDS_T1_HR)
+
+    def losses(pool_bytes):
+        pool = synthetic_label_pool(4, (32, 32, 32), 5)
+        bg = BrainGenerator(None, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', GENERATION_LABELS,
+                            generation_classes=GENERATION_CLASSES, output_shape=32, output_div_by_n=8, nonlin_std=4.,
+                            nonlin_shape_factor=.125, bias_shape_factor=.125, build_reliability_maps=True, downsample=True,
+                            shearing_bounds=.02, label_maps=pool, rng=np.random.default_rng(0))
+        net = unet(24, bg.model_output_shape, 3, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
+                   batch_norm=-1, seed=1)
+        tr = Trainer(bg, net, lr=1e-3)
+        bg.labels_to_image_model.seed(3, 0)
+        if pool_bytes is not None:
+            tr.POOL_BYTES = pool_bytes
+        from synthsr_amd import ops
+        prev = ops.set_deterministic(True)   # bit-identical steps: the three runs can be compared with ==
+        try:
+            out = [tr.step().item() for _ in range(12)]
+        finally:
+            ops.set_deterministic(prev)
+        return tr, out
+
+    tr, full = losses(None)
+    assert 1 < len(tr._auto_pool) <= 4 and not tr.__dict__.get('_auto_pool_full')
+    free, _ = torch.cuda.mem_get_info()
+    assert tr._auto_pool_cap <= tr.POOL_FRACTION * free * 1.5 and tr._auto_pool_used == sum(t.numel() * t.element_size() for t in tr._auto_pool.values())
+    tr1, capped = losses(32 ** 3)            # room for ONE uint8 map
+    assert len(tr1._auto_pool) == 1 and tr1._auto_pool_full and tr1._auto_pool_used == 32 ** 3
+    assert capped == full                     # the host path and the device-resident path feed the generator the same maps
+    tr0, none = losses(0)
+    assert len(tr0._auto_pool) == 0 and none == full
