@@ -1690,8 +1690,22 @@ struct WgCfg {
   static constexpr int NBUF = DBUF ? 2 : 1;
 };
 
-template <int COW, int NPROD = 6, bool STK = false, int CIW = 8>
+// VAR (CIW = 24 only; round 5, A/B through option 12 bits 4-6 until one is kept):
+//   bit 0  the x image is stored as six channel-quad PLANES per piece ([quad][halo voxel] x 8 bytes) instead of voxel rows of
+//          48 bytes: the 32 lanes a ds_read_b64_tr_b16 serves together (8 voxels x 4 quads) then read 4 x 64 contiguous bytes
+//          whose plane offsets (5184 = 20 x 256 + 64 bytes) put them on four disjoint sets of 16 banks; with 48-byte rows voxel
+//          v + 5 lands on the banks of voxel v (2-way conflict on EVERY A read: SQ_LDS_BANK_CONFLICT was 45 % of the kernel's
+//          LDS cycles, profiles/r04_pmc_lds_valu.txt).  Row tiles that straddle two taps (quads 4, 5 | 0, 1) keep a conflict
+//          where the taps are x neighbours: 8 of the 41 tiles.
+//   bit 1  the six reads of row tile q + 1 are issued one behind each of the first six MFMAs of row tile q instead of in one
+//          burst in front of them (the two waves of a SIMD run in phase after every barrier: bursts leave the matrix pipe idle)
+//   bit 2  41 row tiles + the ones row = 42 slots in groups of 11, 10, 10, 11 instead of 4 x 11: waves w and w + 4 share a SIMD,
+//          i.e. groups (0, 2) and (1, 3): 21 instead of 22 slots per SIMD and tile
+template <int COW, int NPROD = 6, bool STK = false, int CIW = 8, int VAR = 0>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitWgArgs a) {
+  static_assert(VAR == 0 || CIW == 24, "layout / schedule variants: the all-channels kernel");
+  constexpr bool PL = (VAR & 1) != 0, ILV = (VAR & 2) != 0, BAL = (VAR & 4) != 0;
+  constexpr int QP = HVOX * 8;  // PL: bytes of one channel-quad plane of a piece
   static_assert(!STK || (COW == 24 && NPROD == 6), "stacked column tiles: 24 columns, six products");
   static_assert(CIW == 8 || (CIW == 16 && COW == 48) || (CIW == 24 && COW == 24 && STK),
                 "16 input channels per workgroup: the 48-column kernel; 24: the stacked 24-column kernel");
@@ -1711,7 +1725,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15, lrow = li >> 2, lq = li & 3;
   constexpr int GROUPS = C::NRT / RT, WPG = NW / GROUPS, KPW = 8 / WPG;  // row groups, waves per group, K steps per wave
-  const int rh = wave / WPG, wg = wave % WPG;                          // this wave's row group and its place in it
+  const int rh = __builtin_amdgcn_readfirstlane(wave / WPG), wg = wave % WPG;  // this wave's row group and its place in it
+  // first row tile of the group and whether it has an 11th slot (BAL: 11 | 10 | 10 | 11 slots, the last one the ones row)
+  const int rt0 = BAL ? rh * (RT - 1) + (rh > 0 ? 1 : 0) : rh * RT;
+  const bool slot10 = !BAL || rh == 0 || rh == GROUPS - 1;
   const int cc = blockIdx.y % a.ncc, oc = blockIdx.y / a.ncc;
   const TileWalk walk = tile_walk(a.ntiles);
   const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
@@ -1722,10 +1739,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   int aoff[RT];
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
-    const int Q = 4 * (rh * RT + q) + lq;
+    const int Q = 4 * (rt0 + q) + lq;
     int tap = CIW == 8 ? 2 * (rh * RT + q) + (lq >> 1) : (CIW == 16 ? rh * RT + q : Q / 6);
     if (tap > 26) tap = 26;  // the spare slot of the last pair / the spare tiles: their rows are not flushed
-    aoff[q] = ((tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3) * XB + (CIW == 8 ? (lq & 1) : (CIW == 16 ? lq : Q % 6)) * 8;
+    const int tvox = (tap / 9 * HY + (tap / 3) % 3) * HX + tap % 3;
+    if constexpr (PL) aoff[q] = tvox * 8 + (Q % 6) * QP;
+    else aoff[q] = tvox * XB + (CIW == 8 ? (lq & 1) : (CIW == 16 ? lq : Q % 6)) * 8;
   }
   // this wave's K step: 32 voxels = x-rows (z, yb) and (z, yb + 1); K index 8 g + j <-> voxel (row g >> 1, x = 8 (j >> 2) +
   // 4 (g & 1) + (j & 3)) -- the same bijection for both operands (conv_bf16.hip)
@@ -1733,11 +1752,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   // (KPW = 4: the K steps of z planes 2 wg and 2 wg + 1)
   const int ks0 = wg * KPW, kz = ks0 >> 1, kyb = 2 * (ks0 & 1);
   // address of K step kj of this wave relative to its first one: two x-rows down, or (every second step) one z plane on
-  auto akoff = [](int kj) { return (uint32_t)(((kj >> 1) * HY * HX + (kj & 1) * 2 * HX) * XB); };
+  constexpr int XVB = PL ? 8 : XB;  // bytes from a halo voxel to the next one (same channel quad)
+  auto akoff = [](int kj) { return (uint32_t)(((kj >> 1) * HY * HX + (kj & 1) * 2 * HX) * XVB); };
   auto bkoff = [](int kj) { return (uint32_t)(((kj >> 1) * TY * TX + (kj & 1) * 2 * TX) * DROWB); };
   static_assert(KPW == 1 || KPW == 2 || KPW == 4, "K steps of a wave: whole x-row pairs of consecutive z planes");
   const int vx = 4 * (g & 1) + lrow, vr = g >> 1;
-  const uint32_t abase = (uint32_t)((((kz * HY + kyb + vr) * HX) + vx) * XB);
+  const uint32_t abase = (uint32_t)((((kz * HY + kyb + vr) * HX) + vx) * XVB);
   const uint32_t bbase = (uint32_t)(3 * WG_XPLANE) + (uint32_t)((((kz * TY + kyb + vr) * TX) + vx) * DROWB + lq * 8);
   // stacked column tiles U3 / U4: channels 16-23 (byte 32 of the row) of piece lq >> 1 resp. of piece 2 | the zeroed slack
   constexpr uint32_t ZOFF = (uint32_t)(3 * WG_XPLANE + 3 * DPLANE);
@@ -1818,7 +1838,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
       uint32_t p0, p1, p2, q0, q1, q2;
       syn_split3(xst[i][0], xst[i][1], p0, p1, p2);
       syn_split3(xst[i][2], xst[i][3], q0, q1, q2);
-      const int xl = (tid + NTHR * i) * 8;
+      const int xj = tid + NTHR * i;
+      const int xl = PL ? (xj % XQ) * QP + (xj / XQ) * 8 : xj * 8;
       *reinterpret_cast<u32x2*>(xd + xl) = (u32x2){p0, q0};
       *reinterpret_cast<u32x2*>(xd + WG_XPLANE + xl) = (u32x2){p1, q1};
       *reinterpret_cast<u32x2*>(xd + 2 * WG_XPLANE + xl) = (u32x2){p2, q2};
@@ -1873,9 +1894,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           afr[slot][p] = tr_read8(img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE,
-                                  img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE + 8 * XB);
+                                  img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE + 8 * XVB);
           if (CIW != 8 && q == BT && want_db) afr[slot][p] = p == 0 ? ones : (u32x4){0u, 0u, 0u, 0u};
         }
+      };
+      auto aload1 = [&](int q, int slot, int p) {  // ILV: one piece of a row tile's A fragment (pieces in the order of their use)
+        afr[slot][p] = tr_read8(img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE,
+                                img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE + 8 * XVB);
+        if (q == BT && want_db) afr[slot][p] = p == 0 ? ones : (u32x4){0u, 0u, 0u, 0u};
       };
       aload(0, 0);
       if constexpr (CIW == 8) {
@@ -1892,8 +1918,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
       }
       sfor<0, RT>([&](auto Q) {
         constexpr int q = decltype(Q)::value;
+        if (BAL && q == RT - 1 && !slot10) return;  // (wave-uniform) the 10-slot groups
+        const bool pre = q + 1 < RT && (!BAL || q + 2 < RT || slot10);  // is there a next row tile to fetch
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (q + 1 < RT) aload(q + 1, (q + 1) & 1);
+        if constexpr (!(STK && ILV)) {
+          if constexpr (q + 1 < RT) {
+            if (pre) aload(q + 1, (q + 1) & 1);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (STK) {
           // (x piece, column tile, accumulator): the two accumulators alternate; smallest terms first as in the plain order
@@ -1901,11 +1933,21 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
             acc[q][ac] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][xa]),
                                                                   __builtin_bit_cast(bf16x8, bfr[pb][nb]), acc[q][ac], 0, 0, 0);
           };
+          auto rd = [&](int p) {  // ILV: piece p of the next row tile, pinned behind the MFMA in front of it
+            if constexpr (ILV && q + 1 < RT) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (pre) aload1(q + 1, (q + 1) & 1, p);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          };
           mm(0, 2, 0, 0);  // x0 U2
+          rd(0);
           mm(0, 1, 1, 1);  // x0 U4
           mm(2, 0, 0, 0);  // x2 U0
+          rd(2);
           mm(2, 0, 1, 1);  // x2 U3
           mm(1, 1, 0, 0);  // x1 U1
+          rd(1);
           mm(1, 0, 1, 1);  // x1 U3
           mm(0, 1, 0, 0);  // x0 U1
           mm(0, 0, 1, 1);  // x0 U3
@@ -1973,7 +2015,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   }
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
-    const int Qf = 4 * (rh * RT + q) + g;  // CIW = 24: the channel quad of accumulator rows 4 g .. 4 g + 3
+    if (BAL && q == RT - 1 && !slot10) continue;
+    const int Qf = 4 * (rt0 + q) + g;  // CIW = 24: the channel quad of accumulator rows 4 g .. 4 g + 3
     const int tap = CIW == 8 ? 2 * (rh * RT + q) + (g >> 1) : (CIW == 16 ? rh * RT + q : Qf / 6);
     if (tap > 26) continue;
 #pragma unroll
@@ -1989,14 +2032,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   }
 }
 
-template <int COW, int NPROD, bool STK = false, int CIW = 8>
+template <int COW, int NPROD, bool STK = false, int CIW = 8, int VAR = 0>
 int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
   using C = WgCfg<COW, CIW>;
   SplitWgArgs a = a0;
   const int gy = a.ncc * a.nco;
   const int gx = split_wgrad_grid_x(a.ntiles, gy);
   const size_t smem = (size_t)C::NBUF * C::BUFB;
-  auto kern = conv3d_split_wgrad_kernel<COW, NPROD, STK, CIW>;
+  auto kern = conv3d_split_wgrad_kernel<COW, NPROD, STK, CIW, VAR>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -2014,7 +2057,15 @@ int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
 template <int COW>
 int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
   if constexpr (COW == 24) {
-    if (g_products == 6 && a.ciw == 24) return launch_split_wgrad_np<24, 6, true, 24>(a, st);
+    if (g_products == 6 && a.ciw == 24) {
+      switch ((g_wgrad_stack >> 4) & 7) {  // option 12 bits 4-6 (A/B): layout / schedule variant of the all-channels kernel
+        case 1: return launch_split_wgrad_np<24, 6, true, 24, 1>(a, st);
+        case 3: return launch_split_wgrad_np<24, 6, true, 24, 3>(a, st);
+        case 5: return launch_split_wgrad_np<24, 6, true, 24, 5>(a, st);
+        case 7: return launch_split_wgrad_np<24, 6, true, 24, 7>(a, st);
+        default: return launch_split_wgrad_np<24, 6, true, 24>(a, st);
+      }
+    }
     if (g_products == 6 && (g_wgrad_stack & 1)) return launch_split_wgrad_np<24, 6, true>(a, st);
   }
   if constexpr (COW == 48) {

@@ -208,8 +208,14 @@ def align_pool_ties(dev_choices, oracle_inputs, max_ties=8, max_ulp=4.0):
 # and the device must satisfy  d <= GRAD_K * o + GRAD_FLOOR  -- never more than GRAD_K times further from the truth than the
 # fp32 host evaluation of the same graph, plus a floor for tensors the host happens to hit almost exactly (the rule of the
 # 160^3 step, tests/test_full_size_parity_gpu.py).  range = max |float64 gradient| of the tensor, but at least RANGE_FLOOR of
-# the largest gradient of the network (a bias whose gradient is a sum of cancelling terms has no range of its own).
+# the largest gradient of the network (a bias whose gradient is a sum of cancelling terms has no range of its own).  The floor
+# is 2e-5 for conv / head kernels and 4x that for the per-channel SUMS over every voxel (biases, BatchNorm beta / gamma): their
+# terms cancel, and the rounding of a sum scales with the sum of |terms|, not with |sum| = the range.
+# Measured over the 47 whole-network tests of the suite (3016 tensor records, profiles/r05_parity_anchor_distribution.txt): device
+# vs float64 at most 2.5e-5 (kernels) / 3.0e-5 (sums) of range -- median 1.6e-6 --, the fp32 oracle at most 1.6e-5 / 2.8e-5;
+# device / oracle 1.2 in the median, 3.2-4.2 at the 99th percentile; the tightest record sits 2.6x inside the rule.
 GRAD_K, GRAD_FLOOR, RANGE_FLOOR = 6.0, 2e-5, 1e-3
+SUM_FLOOR_FACTOR = 4.0
 
 
 def _anchor_log(rows, tag):
@@ -232,11 +238,12 @@ def assert_grads_anchored(dev, g32, g64, kinds=None, tag='', k=GRAD_K, floor=GRA
         o = float((g32[nm].double().cpu() - ref).abs().max()) / rng
         a = None if extra is None else float((extra[nm].double().cpu() - dev[nm].double().cpu()).abs().max()) / rng
         rows.append((nm, d, o, a))
-        if d > k * o + floor or (a is not None and a > k * o + floor):
+        fl = floor * (1.0 if nm.endswith('/kernel') else SUM_FLOOR_FACTOR)
+        if d > k * o + fl or (a is not None and a > k * o + fl):
             bad.append((nm, d, o, a))
     _anchor_log(rows, tag)
-    assert not bad, '%s: gradients further from float64 than %g x the fp32 oracle + %g (name, device, fp32 oracle%s): %s' % (
-        tag, k, floor, ', second run vs first' if extra is not None else '', bad)
+    assert not bad, '%s: gradients further from float64 than %g x the fp32 oracle + %g (x %g for per-channel sums) (name, device, fp32 oracle%s): %s' % (
+        tag, k, floor, SUM_FLOOR_FACTOR, ', second run vs first' if extra is not None else '', bad)
     return {nm: (d, o) for nm, d, o, _ in rows}
 
 
