@@ -1690,21 +1690,20 @@ struct WgCfg {
   static constexpr int NBUF = DBUF ? 2 : 1;
 };
 
-// VAR (CIW = 24 only; round 5, A/B through option 12 bits 4-6 until one is kept):
-//   bit 0  the x image is stored as six channel-quad PLANES per piece ([quad][halo voxel] x 8 bytes) instead of voxel rows of
-//          48 bytes: the 32 lanes a ds_read_b64_tr_b16 serves together (8 voxels x 4 quads) then read 4 x 64 contiguous bytes
-//          whose plane offsets (5184 = 20 x 256 + 64 bytes) put them on four disjoint sets of 16 banks; with 48-byte rows voxel
-//          v + 5 lands on the banks of voxel v (2-way conflict on EVERY A read: SQ_LDS_BANK_CONFLICT was 45 % of the kernel's
-//          LDS cycles, profiles/r04_pmc_lds_valu.txt).  Row tiles that straddle two taps (quads 4, 5 | 0, 1) keep a conflict
-//          where the taps are x neighbours: 8 of the 41 tiles.
-//   bit 1  the six reads of row tile q + 1 are issued one behind each of the first six MFMAs of row tile q instead of in one
-//          burst in front of them (the two waves of a SIMD run in phase after every barrier: bursts leave the matrix pipe idle)
-//   bit 2  41 row tiles + the ones row = 42 slots in groups of 11, 10, 10, 11 instead of 4 x 11: waves w and w + 4 share a SIMD,
-//          i.e. groups (0, 2) and (1, 3): 21 instead of 22 slots per SIMD and tile
-template <int COW, int NPROD = 6, bool STK = false, int CIW = 8, int VAR = 0>
+// CIW = 24 (round 5; profiles/r05_split_wgrad_var24_ab.txt: 0.84 -> 0.69 ms on the same box, bit-identical results):
+//   PL   the x image is stored as six channel-quad PLANES per piece ([quad][halo voxel] x 8 bytes) instead of voxel rows of 48
+//        bytes: the 32 lanes a ds_read_b64_tr_b16 serves together (8 voxels x 4 quads) then read 4 x 64 contiguous bytes whose
+//        plane offsets (5184 = 20 x 256 + 64 bytes) put them on four disjoint sets of 16 banks; with 48-byte rows voxel v + 5
+//        landed on the banks of voxel v (a 2-way conflict on EVERY A read: SQ_LDS_BANK_CONFLICT was 45 % of the kernel's LDS
+//        cycles, profiles/r04_pmc_lds_valu.txt).  Row tiles that straddle two taps (quads 4, 5 | 0, 1) keep a conflict where
+//        the taps are x neighbours: 8 of the 41 tiles.
+//   BAL  41 row tiles + the ones row = 42 slots in groups of 11, 10, 10, 11 instead of 4 x 11: waves w and w + 4 share a SIMD,
+//        i.e. groups (0, 2) and (1, 3): 21 instead of 22 slots per SIMD and tile.
+//   (Issuing the six reads of row tile q + 1 one by one behind the MFMAs of row tile q instead of as a burst: -2 % without BAL,
+//   nothing with it -- not kept.)
+template <int COW, int NPROD = 6, bool STK = false, int CIW = 8>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitWgArgs a) {
-  static_assert(VAR == 0 || CIW == 24, "layout / schedule variants: the all-channels kernel");
-  constexpr bool PL = (VAR & 1) != 0, ILV = (VAR & 2) != 0, BAL = (VAR & 4) != 0;
+  constexpr bool PL = CIW == 24, BAL = CIW == 24;
   constexpr int QP = HVOX * 8;  // PL: bytes of one channel-quad plane of a piece
   static_assert(!STK || (COW == 24 && NPROD == 6), "stacked column tiles: 24 columns, six products");
   static_assert(CIW == 8 || (CIW == 16 && COW == 48) || (CIW == 24 && COW == 24 && STK),
@@ -1898,11 +1897,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
           if (CIW != 8 && q == BT && want_db) afr[slot][p] = p == 0 ? ones : (u32x4){0u, 0u, 0u, 0u};
         }
       };
-      auto aload1 = [&](int q, int slot, int p) {  // ILV: one piece of a row tile's A fragment (pieces in the order of their use)
-        afr[slot][p] = tr_read8(img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE,
-                                img + abase + akoff(kj) + aoff[q] + p * WG_XPLANE + 8 * XVB);
-        if (q == BT && want_db) afr[slot][p] = p == 0 ? ones : (u32x4){0u, 0u, 0u, 0u};
-      };
       aload(0, 0);
       if constexpr (CIW == 8) {
         if (want_db) {
@@ -1921,10 +1915,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
         if (BAL && q == RT - 1 && !slot10) return;  // (wave-uniform) the 10-slot groups
         const bool pre = q + 1 < RT && (!BAL || q + 2 < RT || slot10);  // is there a next row tile to fetch
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(STK && ILV)) {
-          if constexpr (q + 1 < RT) {
-            if (pre) aload(q + 1, (q + 1) & 1);
-          }
+        if constexpr (q + 1 < RT) {
+          if (pre) aload(q + 1, (q + 1) & 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (STK) {
@@ -1933,21 +1925,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
             acc[q][ac] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][xa]),
                                                                   __builtin_bit_cast(bf16x8, bfr[pb][nb]), acc[q][ac], 0, 0, 0);
           };
-          auto rd = [&](int p) {  // ILV: piece p of the next row tile, pinned behind the MFMA in front of it
-            if constexpr (ILV && q + 1 < RT) {
-              __builtin_amdgcn_sched_barrier(0);
-              if (pre) aload1(q + 1, (q + 1) & 1, p);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          };
           mm(0, 2, 0, 0);  // x0 U2
-          rd(0);
           mm(0, 1, 1, 1);  // x0 U4
           mm(2, 0, 0, 0);  // x2 U0
-          rd(2);
           mm(2, 0, 1, 1);  // x2 U3
           mm(1, 1, 0, 0);  // x1 U1
-          rd(1);
           mm(1, 0, 1, 1);  // x1 U3
           mm(0, 1, 0, 0);  // x0 U1
           mm(0, 0, 1, 1);  // x0 U3
@@ -2032,14 +2014,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   }
 }
 
-template <int COW, int NPROD, bool STK = false, int CIW = 8, int VAR = 0>
+template <int COW, int NPROD, bool STK = false, int CIW = 8>
 int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
   using C = WgCfg<COW, CIW>;
   SplitWgArgs a = a0;
   const int gy = a.ncc * a.nco;
   const int gx = split_wgrad_grid_x(a.ntiles, gy);
   const size_t smem = (size_t)C::NBUF * C::BUFB;
-  auto kern = conv3d_split_wgrad_kernel<COW, NPROD, STK, CIW, VAR>;
+  auto kern = conv3d_split_wgrad_kernel<COW, NPROD, STK, CIW>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -2057,15 +2039,7 @@ int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
 template <int COW>
 int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
   if constexpr (COW == 24) {
-    if (g_products == 6 && a.ciw == 24) {
-      switch ((g_wgrad_stack >> 4) & 7) {  // option 12 bits 4-6 (A/B): layout / schedule variant of the all-channels kernel
-        case 1: return launch_split_wgrad_np<24, 6, true, 24, 1>(a, st);
-        case 3: return launch_split_wgrad_np<24, 6, true, 24, 3>(a, st);
-        case 5: return launch_split_wgrad_np<24, 6, true, 24, 5>(a, st);
-        case 7: return launch_split_wgrad_np<24, 6, true, 24, 7>(a, st);
-        default: return launch_split_wgrad_np<24, 6, true, 24>(a, st);
-      }
-    }
+    if (g_products == 6 && a.ciw == 24) return launch_split_wgrad_np<24, 6, true, 24>(a, st);
     if (g_products == 6 && (g_wgrad_stack & 1)) return launch_split_wgrad_np<24, 6, true>(a, st);
   }
   if constexpr (COW == 48) {

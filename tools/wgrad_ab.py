@@ -5,9 +5,8 @@
     python tools/wgrad_ab.py col24      # bit 1: 24-column workgroups also where 48 divides Cout     (1 | 3)
     python tools/wgrad_ab.py ciw16      # bit 2: 8 | 16 input channels per 48-column workgroup       (5 | 1)
     python tools/wgrad_ab.py ciw24      # bit 3: 8 | all 24 input channels per 24-column workgroup   (9 | 1)
-    python tools/wgrad_ab.py var24      # bits 4-6 (round 5): layout / schedule variants of the all-channels kernel: 16 = channel-quad
-                                        # planes (conflict-free A reads), 32 = reads interleaved with the MFMAs, 64 = 42 instead of 44
-                                        # row-tile slots; every variant must reproduce variant 0 BIT FOR BIT in deterministic mode
+    (round 5: `var24` compared layout / schedule variants of the all-channels kernel behind option 12 bits 4-6 at commit 9f-series;
+     the winner -- channel-quad planes + 42 row-tile slots -- is now THE kernel, the record is profiles/r05_split_wgrad_var24_ab.txt)
 
 For each setting: the error of dW / dbias against a float64 convolution gradient (torch, small volumes with ragged edges)
 relative to the largest |dW| / |dbias|, then the time per launch (torch.cuda.Event over 20 launches, with the bias gradient)
