@@ -8,7 +8,11 @@
  *
  * Conventions
  *   - plain device pointers + explicit sizes; no allocation, no ownership transfer, no global
- *     state; every call is stream-ordered on `stream` (a hipStream_t) and re-entrant.
+ *     state; every call is stream-ordered on `stream` (a hipStream_t) and re-entrant.  What a
+ *     convolution call computes depends on its arguments only: the arithmetic is a field of the
+ *     caller-owned synthsr_conv_ctx handed to every conv entry point (NULL = the default), the
+ *     launch plans are pure functions of (shape, channels, kind, context).  The one deliberate
+ *     exception, the deterministic TEST mode, lives in synthsr_hip_tuning.h and is per device.
  *   - volumes are NDHWC / channels-last, float32 unless stated, 3 spatial dims [d0][d1][d2][C].
  *   - return value: 0 (SYNTHSR_OK) or a negative SYNTHSR_E* code (argument/shape error or a
  *     HIP launch error); the Python layer turns these into the reference's exception types.
@@ -29,6 +33,28 @@ extern "C" {
 #define SYNTHSR_ELAUNCH (-2)  /* hip launch error */
 
 typedef void* synthsr_stream_t; /* hipStream_t */
+
+/* Context of the fp32 3x3x3 convolutions: caller-owned, read-only during a call, never stored by the library; two contexts
+ * (two networks, two threads) coexist.  Packed weights are only valid under the arithmetic they were packed with.
+ *   SYNTHSR_ARITH_SPLIT (default, also what NULL means): every fp32 operand is the exact sum of three bf16 numbers (round to
+ *     nearest even on what the previous pieces left); a product a*b is accumulated as a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 +
+ *     a2 b0 on v_mfma_f32_16x16x32_bf16, each partial product exact in the fp32 accumulator; what is left out is < 2^-23 |a b|
+ *     in the worst case, 2^-27 rms: within the rounding of an fp32 multiply-add.  Inputs, outputs, accumulation, BatchNorm
+ *     statistics, gradients and weights stay fp32; against a float64 convolution the result is as accurate as the fp32-MFMA
+ *     kernels' (tests/test_split_gpu.py).  Used where the layer has enough 4x4x16 tiles and channel counts that are multiples
+ *     of 8 (csrc/conv_split.hip); the rest (first layer, the smallest deep layers, the folded convs' weight gradient) runs on
+ *     the fp32 matrix instructions in every mode.
+ *   SYNTHSR_ARITH_SPLIT9: the same kernels and packed weights with ALL nine partial products a_i b_j: an fp32 product is
+ *     reproduced exactly at 1.5x the matrix instructions.
+ *   SYNTHSR_ARITH_FP32_MFMA: v_mfma_f32_4x4x1 / 16x16x4 kernels everywhere (csrc/conv3d.hip), the round-1/2 path.
+ * The reference computes these layers in fp32 on TensorFlow (SynthSR/training.py:330-341). */
+#define SYNTHSR_ARITH_FP32_MFMA 0
+#define SYNTHSR_ARITH_SPLIT 1
+#define SYNTHSR_ARITH_SPLIT9 2
+typedef struct synthsr_conv_ctx {
+  int arithmetic;  /* SYNTHSR_ARITH_* */
+  int reserved[7]; /* zero */
+} synthsr_conv_ctx;
 
 /* library / device introspection */
 int synthsr_abi_version(void);
@@ -158,43 +184,45 @@ int synthsr_copy_strided(const float* in, float* out, int64_t n, int in_stride, 
  * launch geometry chosen for that size).  mode 0: forward; mode 1: data-gradient (taps flipped, Cin<->Cout
  * swapped; `shape`, Cin, Cout are still those of the FORWARD layer).
  * Returns the number of floats written (or required if packed==NULL), negative on error. */
-int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], int Cin, int Cout, int mode,
-                            synthsr_stream_t stream);
+int64_t synthsr_conv3d_pack(const synthsr_conv_ctx* ctx, const float* w, float* packed, const int shape[3], int Cin, int Cout,
+                            int mode, synthsr_stream_t stream);
 
 /* Conv3D 3x3x3 'same' + bias + activation (0 linear, 1 ELU alpha=1) — models.py:316,444.
  * in [d0,d1,d2,Cin], out [d0,d1,d2,Cout]; wpacked from synthsr_conv3d_pack(shape,...) with the same shape.
  * For the data-gradient call it with (dout, pack(mode 1), NULL, din, shape, Cout, Cin, 0). bias may be NULL. */
-int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
-                       int Cin, int Cout, int act, synthsr_stream_t stream);
+int synthsr_conv3d_fwd(const synthsr_conv_ctx* ctx, const float* in, const float* wpacked, const float* bias, float* out,
+                       const int shape[3], int Cin, int Cout, int act, synthsr_stream_t stream);
 
 /* synthsr_conv3d_fwd followed by synthsr_bn_stats(out) -- BatchNorm batch statistics of the layer output (stats[2C],
  * ws = 2C doubles of scratch).  For the layers that run on the 4x4x1 kernel the sums are accumulated in the conv
  * epilogue (per-workgroup partials + a tiny reduction; no extra pass over the activation); otherwise the two calls are
  * simply chained. */
-int synthsr_conv3d_fwd_stats(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
-                             int Cin, int Cout, int act, float* stats, double* ws, synthsr_stream_t stream);
+int synthsr_conv3d_fwd_stats(const synthsr_conv_ctx* ctx, const float* in, const float* wpacked, const float* bias, float* out,
+                             const int shape[3], int Cin, int Cout, int act, float* stats, double* ws, synthsr_stream_t stream);
 
 /* act 0/1: out = act(conv3(in) + addend + bias); addend is indexed like out and may alias it (in-place accumulation).
  * Layers that are split over input channels (small deep levels) accumulate with atomics and require addend == out or NULL.
  * act 2 (data gradient fused with the ELU backward of the layer below): out = conv3(in) * elu'(y), y = addend != out is
  * that layer's ELU output, elu'(y) = 1 for y > 0 else y + 1 (layers.py ELU, models.py:283). */
-int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* bias, const float* addend, float* out,
-                           const int shape[3], int Cin, int Cout, int act, synthsr_stream_t stream);
+int synthsr_conv3d_fwd_add(const synthsr_conv_ctx* ctx, const float* in, const float* wpacked, const float* bias,
+                           const float* addend, float* out, const int shape[3], int Cin, int Cout, int act,
+                           synthsr_stream_t stream);
 
 /* --- nearest-upsample folding (decoder conv on concatenate([skip, UpSampling3D(2)(lo)]), models.py:426-444) ------
  * A 3x3x3 conv over an up-sampled tensor equals 8 parity-wise 2x2x2 convs over the low-res tensor with summed taps
  * (3.4x fewer FLOPs, same result up to float32 re-association).  The layer is evaluated as
  *   out = act( conv3(skip; W[:, :Cs]) + upconv(lo; W[:, Cs:]) + bias ).
  * `w` is the layer's Keras kernel [3][3][3][Cin_total][Cout]; (ci_off, Cin) selects the input-channel range. */
-int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3], int Cin_total, int ci_off, int Cin,
-                               int Cout, int mode, int up /* 0 plain, 1: 8 parity weight sets, shape = lo shape */,
-                               synthsr_stream_t stream);
+int64_t synthsr_conv3d_pack_ex(const synthsr_conv_ctx* ctx, const float* w, float* packed, const int shape[3], int Cin_total,
+                               int ci_off, int Cin, int Cout, int mode,
+                               int up /* 0 plain, 1: 8 parity weight sets, shape = lo shape */, synthsr_stream_t stream);
 /* out[2*lo_shape, Cout] = act(upconv(lo [lo_shape, Cl]) + addend + bias); wpacked8 from pack_ex(..., mode 0, up 1) */
-int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* bias, const float* addend, float* out,
-                          const int lo_shape[3], int Cl, int Cout, int act, synthsr_stream_t stream);
+int synthsr_conv3d_up_fwd(const synthsr_conv_ctx* ctx, const float* lo, const float* wpacked8, const float* bias,
+                          const float* addend, float* out, const int lo_shape[3], int Cl, int Cout, int act,
+                          synthsr_stream_t stream);
 /* dlo[lo_shape, Cl] = adjoint of upconv applied to dout [2*lo_shape, Cout]; wpacked8 from pack_ex(..., mode 1, up 1) */
-int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo, const int lo_shape[3], int Cl, int Cout,
-                            synthsr_stream_t stream);
+int synthsr_conv3d_up_dgrad(const synthsr_conv_ctx* ctx, const float* dout, const float* wpacked8, float* dlo,
+                            const int lo_shape[3], int Cl, int Cout, synthsr_stream_t stream);
 /* per-parity weight gradients dwc[8][27][Cl][Cout] (zeroed by the caller) ... */
 int synthsr_conv3d_up_wgrad(const float* lo, const float* dout, float* dwc, const int lo_shape[3], int Cl, int Cout,
                             synthsr_stream_t stream);
@@ -203,15 +231,18 @@ int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_
                              synthsr_stream_t stream);
 /* weight gradient of a layer part: in has Cin channels, dw rows are Cin_total wide, written at ci_off */
 /* as synthsr_conv3d_wgrad_ex, and dbias[Cout] += sum over voxels of dout (a constant-1 row of the same GEMM); NULL = skip */
-int synthsr_conv3d_wgrad_bias(const float* in, const float* dout, float* dw, float* dbias, const int shape[3],
-                              int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream);
-int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
-                            int Cin, int Cout, synthsr_stream_t stream);
+int synthsr_conv3d_wgrad_bias(const synthsr_conv_ctx* ctx, const float* in, const float* dout, float* dw, float* dbias,
+                              const int shape[3], int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream);
+int synthsr_conv3d_wgrad_ex(const synthsr_conv_ctx* ctx, const float* in, const float* dout, float* dw, const int shape[3],
+                            int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream);
 
 /* launch geometry the kernels will use: out = {chunk width CK, #ci chunks, n-tiles per workgroup (0: 4x4x1-MFMA layout of
  * the Cout = 24 layers, -Cin: first-layer layout), #n chunks, MT, ksplit, NV, floats per packed weight set}.
  * kind: 1 plain conv; 2 forward parity convs of a folded decoder conv; 0 their data gradient */
-int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int kind, int64_t out[8]);
+int synthsr_conv3d_plan(const synthsr_conv_ctx* ctx, const int shape[3], int CinE, int CoutE, int kind, int64_t out[8]);
+/* 1 / 0: whether the weight gradient of a plain 3x3x3 conv of this shape runs on the split kernels under this context (the
+ * dispatcher's own condition) -- what benchmarks price a layer against.  Negative: SYNTHSR_EINVAL. */
+int synthsr_conv3d_wgrad_runs_split(const synthsr_conv_ctx* ctx, const int shape[3], int Cin, int Cout);
 /* packs every layer of a network in ONE launch.  jobs_dev: int64 [njobs][14] = {w_off, dst_off, count, cin_total,
  * ci_off, cin, cout, mode, ck, ncc, nt, parity(-1 plain), nv, mfma_count}; w_off / dst_off are float offsets.
  * `packed` must have been ZEROED once by the caller: of a 27-slot parity set (parity 0..7, nt > 0) only the 8 slots of the
@@ -219,8 +250,9 @@ int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int kind, int64
 int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* jobs_dev, int njobs,
                             synthsr_stream_t stream);
 
-/* (the process-wide tuning switch of the conv kernels lives in synthsr_hip_tuning.h: it is a development hook for
- * tools/, NOT part of this stateless boundary) */
+/* (rounds 1-4 had a process-wide option switch and a process-wide arithmetic setter behind these kernels; both are gone --
+ * plan parameters are constants of the library, the arithmetic travels in synthsr_conv_ctx.  What is left in
+ * synthsr_hip_tuning.h: the deterministic TEST mode and a host-only tile-schedule query.) */
 
 /* ---- bf16 twins of the HBM-bound U-Net kernels: same arguments and semantics as the float32 entry point of the same
  * name (which cites the reference layers it replaces); activation / activation-gradient tensors are NDHWC bfloat16
@@ -337,8 +369,8 @@ int synthsr_conv3d_bf16_up_wgrad(const void* lo, const void* dout, float* dwc, c
 int synthsr_f32_to_bf16_pad(const float* src, void* dst, int64_t n, int Cs, int Cd, synthsr_stream_t stream);
 
 /* weight gradient: dw[3][3][3][Cin][Cout] += sum_v in[v+t-1][ci] * dout[v][co]   (dw must be zeroed by caller) */
-int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout,
-                         synthsr_stream_t stream);
+int synthsr_conv3d_wgrad(const synthsr_conv_ctx* ctx, const float* in, const float* dout, float* dw, const int shape[3], int Cin,
+                         int Cout, synthsr_stream_t stream);
 
 /* dz = dy * ELU'(y) (y = saved activation output), optional dy2 added first (skip-connection gradient),
  * dbias[c] += sum_v dz[v][c]  (dbias zeroed by caller; may be NULL) */

@@ -28,8 +28,14 @@ class DeformParams(Structure):
                 ('label_bytes', c_int)]
 
 
+class ConvCtx(Structure):
+    """mirror of synthsr_conv_ctx (include/synthsr_hip.h): the caller-owned context of the fp32 convolutions"""
+    _fields_ = [('arithmetic', c_int), ('reserved', c_int * 7)]
+
+
 _P = c_void_p
 _S = c_void_p  # stream
+_C = POINTER(ConvCtx)  # conv context (None = the library's default: split arithmetic)
 
 SIGNATURES = {
     'synthsr_abi_version': (c_int, []),
@@ -48,29 +54,25 @@ SIGNATURES = {
     'synthsr_normalise_blur2': (c_int, [_P, POINTER(c_int), _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _S]),
     'synthsr_outer3': (c_int, [_P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_copy_strided': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_pack': (c_int64, [_P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_fwd': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_fwd_stats': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _P, _P, _S]),
+    'synthsr_conv3d_pack': (c_int64, [_C, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_fwd': (c_int, [_C, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_fwd_stats': (c_int, [_C, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _P, _P, _S]),
     'synthsr_bn_stats_from_partials': (c_int, [_P, c_int, c_int64, c_int, _P, _S]),
-    'synthsr_conv3d_fwd_add': (c_int, [_P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_set_option': (c_int, [c_int, c_int]),
-    'synthsr_set_conv_arithmetic': (c_int, [c_int]),
+    'synthsr_conv3d_fwd_add': (c_int, [_C, _P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_split_tile_schedule': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
-    'synthsr_conv_arithmetic': (c_int, []),
-    'synthsr_conv3d_layout_epoch': (c_int, []),
-    'synthsr_conv3d_wgrad_runs_split': (c_int, [POINTER(c_int), c_int, c_int]),
+    'synthsr_conv3d_wgrad_runs_split': (c_int, [_C, POINTER(c_int), c_int, c_int]),
     'synthsr_set_deterministic': (c_int, [c_int]),
     'synthsr_deterministic_status': (c_int, []),
-    'synthsr_conv3d_plan': (c_int, [POINTER(c_int), c_int, c_int, c_int, POINTER(c_int64)]),
+    'synthsr_conv3d_plan': (c_int, [_C, POINTER(c_int), c_int, c_int, c_int, POINTER(c_int64)]),
     'synthsr_conv3d_pack_all': (c_int, [_P, _P, _P, c_int, _S]),
-    'synthsr_conv3d_pack_ex': (c_int64, [_P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_up_fwd': (c_int, [_P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_up_dgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_conv3d_pack_ex': (c_int64, [_C, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_up_fwd': (c_int, [_C, _P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_up_dgrad': (c_int, [_C, _P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_conv3d_up_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_conv3d_up_unpack': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_wgrad_bias': (c_int, [_P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_wgrad_ex': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
-    'synthsr_conv3d_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_conv3d_wgrad_bias': (c_int, [_C, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_wgrad_ex': (c_int, [_C, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
+    'synthsr_conv3d_wgrad': (c_int, [_C, _P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
     'synthsr_elu_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),
     'synthsr_bn_elu_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
     'synthsr_bn_elu_bwd_head_bf16': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
@@ -148,7 +150,7 @@ SIGNATURES = {
 }
 
 
-CONV_ARITHMETICS = ('fp32_mfma', 'split', 'split9')   # include/synthsr_hip_tuning.h: synthsr_set_conv_arithmetic(index)
+CONV_ARITHMETICS = ('fp32_mfma', 'split', 'split9')   # include/synthsr_hip.h: SYNTHSR_ARITH_* (index = value of synthsr_conv_ctx.arithmetic)
 
 
 class SynthSRHipError(RuntimeError):
@@ -168,17 +170,6 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    arith = os.environ.get('SYNTHSR_CONV_ARITH')   # 'fp32_mfma' | 'split' (default): ops.set_conv_arithmetic
-    if arith:
-        if arith not in CONV_ARITHMETICS:
-            raise ValueError('SYNTHSR_CONV_ARITH should be one of %s' % (CONV_ARITHMETICS,))
-        lib.synthsr_set_conv_arithmetic(CONV_ARITHMETICS.index(arith))
-    opts = os.environ.get('SYNTHSR_CONV_OPTIONS')  # A/B runs of the profiling tools: "12=9,8=3" -> synthsr_conv3d_set_option
-    if opts:
-        for item in opts.split(','):
-            k, v = item.split('=')
-            if lib.synthsr_conv3d_set_option(int(k), int(v)) != 0:
-                raise ValueError('SYNTHSR_CONV_OPTIONS: option %s is not one of include/synthsr_hip_tuning.h' % k)
     _lib = lib
     return lib
 

@@ -167,6 +167,21 @@ __device__ __forceinline__ void syn_det_gather_end(int n) {
     syn_turn_end(&d->chain[SYN_DET_CHAINS - 1], syn_wg_linear(), syn_wg_count());
 }
 
+// A kernel attribute (hipFuncSetAttribute: the dynamic LDS size) is set once per kernel AND DEVICE: a launcher keeps one of these
+// as a function-local static and asks first() before its launch (a process that drives several devices sets it on each).
+#include <atomic>
+struct SynOncePerDevice {
+  std::atomic<uint64_t> done{0};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return false;
+    done.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+  }
+};
+
 // host side of the deterministic WEIGHT-GRADIENT flush (conv3d.hip: det_prepare / det_finish): private planes per workgroup
 // column + an ordered reduction; shared by the fp32 and the bf16 weight-gradient launchers
 struct DetRun {

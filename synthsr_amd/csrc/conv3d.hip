@@ -2898,50 +2898,92 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   syn_turn_end(turn, blockIdx.x, gridDim.x);
 }
 
+// ---- per-device library state (a process may drive several devices; every lookup is by the CURRENT device) ----------------
+// Nothing here changes what a call computes: scratch buffers grown on demand, and the deterministic mode's planes / tickets
+// (synthsr_hip_tuning.h: synthsr_set_deterministic is per device).
+constexpr int SYN_MAX_DEVICES = 64;
+struct SynDeviceState {
+  float* scratch = nullptr;       // lib_scratch
+  size_t scratch_bytes = 0;
+  int det = 0;                    // synthsr_set_deterministic: ordered sums, no split-K / parity-split forward
+  SynDet* det_state = nullptr;    // device block (tickets, timeout flag, scratch of the ordered reductions)
+  float* det_planes = nullptr;    // private dW planes of the ordered weight-gradient flush
+  size_t det_planes_floats = 0;
+};
+static SynDeviceState g_dev[SYN_MAX_DEVICES];
+static SynDeviceState& dev_state() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return g_dev[(d >= 0 && d < SYN_MAX_DEVICES) ? d : 0];
+}
+static inline int det_on() { return dev_state().det; }
+
 // library-owned device scratch (grown on demand, reused by later calls on the same stream order)
 static float* lib_scratch(size_t bytes) {
-  static float* buf = nullptr;
-  static size_t cap = 0;
-  if (bytes > cap) {
-    if (buf) (void)hipFree(buf);
-    buf = nullptr;
-    cap = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&buf), bytes) != hipSuccess) return nullptr;
-    cap = bytes;
+  SynDeviceState& st = dev_state();
+  if (bytes > st.scratch_bytes) {
+    if (st.scratch) (void)hipFree(st.scratch);
+    st.scratch = nullptr;
+    st.scratch_bytes = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&st.scratch), bytes) != hipSuccess) return nullptr;
+    st.scratch_bytes = bytes;
   }
-  return buf;
+  return st.scratch;
 }
 
-static int g_det = 0;  // synthsr_set_deterministic: no split-K / parity-split forward (their partial sums meet in atomics)
-static int g_persist = 1;
-static int g_force_mt = 0;
-static int g_hybrid = 0;  // EXPERIMENTAL (option 3, default off): keep the Cout % 16 == 8 remainder channels on the
-                          // vector ALUs.  Correct, but hipcc serialises the scalar weight loads / v_pk_fma block behind
-                          // the MFMAs, so it is slower than padding to 32 columns until the issue order is hand-pinned.
-static int g_dbg = 0;  // debugging / A-B switch (synthsr_conv3d_set_option)
+// ---- plan parameters.  Rounds 1-4 had a process-wide A/B switch behind each of them (synthsr_conv3d_set_option); every one was
+// measured against its alternative (docs/DESIGN_NOTES_r01_r02.md, profiles/r03_*, r04_*) and the library now ships the winners
+// as constants -- a plan is a pure function of (shape, channels, kind, the context's arithmetic, the device's deterministic mode).
+constexpr int PLAN_PERSIST = 1;            // persistent forward kernel on the large levels
+constexpr int PLAN_FORCE_MT = 0;           // (was a diagnostic override of the tile height)
+constexpr int PLAN_HYBRID = 0;             // MFMA + VALU co-execution for Cout % 16 == 8: correct but slower than padding (hipcc
+                                           // serialises the scalar weight loads behind the MFMAs); kept for the record, off
+constexpr int PLAN_DBG = 0;                // (was the ablation mask)
+constexpr int PLAN_KS_TARGET = 1024;       // workgroup target of the split-K heuristic
+constexpr int PLAN_BRICK = 1;              // brick tiles (4x4 voxels per MFMA row block) on the small deep levels
+constexpr int PLAN_P4 = 1;                 // 4x4x1-MFMA kernels for the Cout = 24 layers (no padding to 32 columns)
+constexpr int PLAN_SPLIT_MIN_WGS = 200;    // smallest layer (4x4x16 tiles x co-chunks) on the split kernels (20^3 x 192: -25 %)
+constexpr int PLAN_SPLIT_WGRAD_MIN_TILES = 1;  // split weight gradient at every size (20^3 / 10^3: 4-29 % faster than fp32 MFMA)
+constexpr int PLAN_STACK24 = 1;            // stacked weight layout of the plain Cout = 24 split convs (10 instead of 12 MFMAs)
+constexpr int PLAN_PSPLIT = 1;             // parity split of small up-conv data gradients
 
-static int g_ks_target = 1024;  // option 5: workgroup target of the split-K heuristic
-static int g_brick = 1;  // option 6: brick tiles (4x4 voxels per MFMA row block) on the small deep levels
-static int g_p4 = 1;  // option 4: 4x4x1-MFMA kernel for the Cout = 24 layers (no padding to 32 columns)
-static int g_split_min_wgs = 200;  // option 9: smallest layer (4x4x16 tiles x co-chunks) that takes the split kernels (200: the 20^3 convs with 192 output channels, measured -25 %)
-static int g_split = 1;  // synthsr_set_conv_arithmetic: fp32 convs through 3 x bf16 operand pieces on the bf16 matrix cores
-                         // (conv_split.hip) where the layer has enough tiles; 0 = fp32 MFMA kernels everywhere
+// ---- the call's context (include/synthsr_hip.h: synthsr_conv_ctx).  Every extern "C" conv entry point opens a CtxScope on the
+// pointer it was handed; the planners below read cfg().  The scope is thread-local and ends with the call: two threads, or two
+// calls with different contexts, never see each other's arithmetic.
+struct ConvCfg {
+  int arith;   // 0 fp32_mfma, 1 split, 2 split9
+  int split;   // arith != 0: fp32 convs through 3 x bf16 operand pieces on the bf16 matrix cores where the layer has enough tiles
+  int nprod;   // 6 | 9 partial products per multiplication
+};
+static thread_local ConvCfg t_cfg = {1, 1, 6};
+static inline const ConvCfg& cfg() { return t_cfg; }
+struct CtxScope {
+  ConvCfg prev;
+  bool ok;
+  explicit CtxScope(const synthsr_conv_ctx* ctx) : prev(t_cfg), ok(true) {
+    const int a = ctx ? ctx->arithmetic : SYNTHSR_ARITH_SPLIT;
+    if (a < 0 || a > 2) {
+      ok = false;
+      return;
+    }
+    t_cfg = ConvCfg{a, a ? 1 : 0, a == 2 ? 9 : 6};
+  }
+  ~CtxScope() { t_cfg = prev; }
+};
+
 extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int cin_total,
-                               int ci_off, int Cin, int Cout, hipStream_t st);
+                               int ci_off, int Cin, int Cout, int nprod, hipStream_t st);
 extern "C" int syn_split_upfwd(const float* lo, const float* wp, const float* bias, const float* addend, float* out,
-                               const int s[3], int Cin, int Cout, int mt, int act, hipStream_t st);
+                               const int s[3], int Cin, int Cout, int mt, int act, int nprod, hipStream_t st);
 extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias, const float* addend, float* out,
                              const int s[3], int Cin, int Cout, int mt, int nchunks, int act, float* stats, float* partial,
-                             int upm, int stacked, hipStream_t st);
-static int g_arith = 1;  // synthsr_set_conv_arithmetic: 0 fp32_mfma, 1 split, 2 split9
-static int g_split_wgrad_min_tiles = 1;  // option 11: smallest layer (4x4x16 tiles) whose weight gradient takes the split kernel (round 3: 256; the 20^3 / 10^3 layers gain 4-29 %, profiles/r04_split_wgrad_deep_levels.txt)
-static int g_stack24 = 1;  // option 10: stacked weight layout (10 instead of 12 MFMAs per K step) for the plain Cout = 24 split convs
+                             int upm, int stacked, int nprod, hipStream_t st);
 
 // does the weight gradient of a plain 3x3x3 conv take the split kernel (conv_split.hip: syn_split_wgrad)?  One place: the
 // dispatcher and the query synthsr_conv3d_wgrad_runs_split (what the benchmarks price a layer against) both ask here
 inline bool wgrad_takes_split(const int s[3], int Cin, int Cout) {
   const int64_t vox = (int64_t)s[0] * s[1] * s[2];
-  return g_split && (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) >= g_split_wgrad_min_tiles && (Cin % 8) == 0 && (Cout % 24) == 0 &&
+  return cfg().split && (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) >= PLAN_SPLIT_WGRAD_MIN_TILES && (Cin % 8) == 0 && (Cout % 24) == 0 &&
          vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31);
 }
 
@@ -2970,7 +3012,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
   FwdPlan p;
   p.split = 0;
   p.stacked = 0;
-  if (g_split && (Cin % 8) == 0 && (Cout % 8) == 0) {
+  if (cfg().split && (Cin % 8) == 0 && (Cout % 8) == 0) {
     // fp32 through three bf16 pieces per operand on the bf16 matrix cores (conv_split.hip): layers with enough 4x4x16 tiles
     const int64_t vox = (int64_t)s[0] * s[1] * s[2];
     const int ntiles = cdiv(Cout, 16);
@@ -2979,7 +3021,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
     const int64_t wgs = (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) * nchunks;
     // (kind 0 = data gradient of a folded decoder conv: s is the low-resolution grid, the input lives on the 2x grid)
     // (kind 2 = their forward pass: the OUTPUT lives on the 2x grid, one co-chunk of <= 48 channels)
-    if (wgs >= g_split_min_wgs && (kind == 0 ? 8 : 1) * vox * Cin * 4 < (1ll << 31) && (kind == 2 ? 8 : 1) * vox * Cout * 4 < (1ll << 31) &&
+    if (wgs >= PLAN_SPLIT_MIN_WGS && (kind == 0 ? 8 : 1) * vox * Cin * 4 < (1ll << 31) && (kind == 2 ? 8 : 1) * vox * Cout * 4 < (1ll << 31) &&
         (kind != 2 || nchunks == 1)) {
       p.split = plain ? 1 : (kind == 0 ? 2 : 3);
       p.ck = 8;
@@ -2989,7 +3031,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
       p.nchunks = nchunks;
       p.ksplit = 1;
       // the plain Cout = 24 convs (160^3: forward and data gradient): weight pieces stacked along M (conv_split.hip, STK)
-      p.stacked = (plain && Cout == 24 && g_arith == 1 && g_stack24) ? 1 : 0;
+      p.stacked = (plain && Cout == 24 && cfg().arith == 1 && PLAN_STACK24) ? 1 : 0;
       p.nv = p.persist = p.p4 = p.c2 = p.brick = 0;
       p.wn = p.wm = 1;
       return p;
@@ -3001,7 +3043,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
   auto wgs = [&](int mt, int nt) { return (int64_t)cdiv(s[0], FT0) * cdiv(s[1], mt) * cdiv(s[2], FT2) * cdiv(ntiles, nt); };
   p.mt = 4;
   int max_nt = MAX_NT;
-  if (wgs(4, std::min(MAX_NT, ntiles)) < 768 || (g_force_mt == 2 && ntiles <= 3) || p.ck == 32) {  // ck 32: 62 KB halo tile
+  if (wgs(4, std::min(MAX_NT, ntiles)) < 768 || (PLAN_FORCE_MT == 2 && ntiles <= 3) || p.ck == 32) {  // ck 32: 62 KB halo tile
     p.mt = 2;
     max_nt = 3;
   }
@@ -3012,20 +3054,20 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
   // MFMA + VALU co-execution: the matrix and vector pipes of a SIMD run concurrently, so instead of padding
   // Cout = 16 a + 8 to 16 (a + 1) MFMA columns (25 % waste at Cout = 24) the last 8 output channels are computed with
   // v_fma (weights from SGPRs, activations from the same LDS tile) in the shadow of the MFMAs of the first 16 a.
-  if (g_hybrid && p.ck == 24 && p.mt == 4 && (Cout % 16) == 8 && Cout >= 24 && ntiles <= 5) {
+  if (PLAN_HYBRID && p.ck == 24 && p.mt == 4 && (Cout % 16) == 8 && Cout >= 24 && ntiles <= 5) {
     p.nv = 8;
     p.nchunks = 1;
     p.nt = (Cout - 8) / 16;
   }
   const bool lt2g = (int64_t)s[0] * s[1] * s[2] * Cin * 4 < (1ll << 31);  // raw buffer addressing (32-bit offsets)
-  p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && g_persist && p.nv == 0 && lt2g) ? 1 : 0;
+  p.persist = (p.mt == 4 && p.ck == 24 && p.nt <= 3 && (Cout % 4) == 0 && PLAN_PERSIST && p.nv == 0 && lt2g) ? 1 : 0;
   // 4x4x1 layouts: plain Cout = 24 layers, and the forward parity convs of a folded decoder conv with Cout = 24
-  p.p4 = (p.persist && (kind == 1 || kind == 2) && Cout == 24 && (Cin % 24) == 0 && g_p4) ? 1 : 0;
-  p.c2 = (plain && Cout == 24 && Cin <= 2 && lt2g && g_p4) ? Cin : 0;  // first layer: 4x4x1 MFMA over K = 27*Cin
+  p.p4 = (p.persist && (kind == 1 || kind == 2) && Cout == 24 && (Cin % 24) == 0 && PLAN_P4) ? 1 : 0;
+  p.c2 = (plain && Cout == 24 && Cin <= 2 && lt2g && PLAN_P4) ? Cin : 0;  // first layer: 4x4x1 MFMA over K = 27*Cin
   p.brick = 0;
   p.wn = 1;
   p.wm = 1;
-  if (g_brick && p.ck == 24 && p.mt == 2 && lt2g && (Cout % 16) == 0 && p.nv == 0 && (s[0] % 4) == 0 &&
+  if (PLAN_BRICK && p.ck == 24 && p.mt == 2 && lt2g && (Cout % 16) == 0 && p.nv == 0 && (s[0] % 4) == 0 &&
       (s[1] % 4) == 0 && (s[2] % 4) == 0 && (s[2] % 16) != 0) {
     // output channels: NT n-tiles per wave, WN waves side by side; `nchunks` (= groups of NT n-tiles) is the packing unit
     p.brick = 1;
@@ -3044,19 +3086,19 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
     const int64_t w = (int64_t)(s[0] / 4) * (s[1] / (4 * p.wm)) * (s[2] / 4) * (p.nchunks / p.wn);
     p.ksplit = 1;
     if (w < 400 && p.ncc >= 2 && plain) {
-      int ks = (int)cdiv(g_ks_target, (int)w);
+      int ks = (int)cdiv(PLAN_KS_TARGET, (int)w);
       if (ks > p.ncc) ks = p.ncc;
       if (ks > 16) ks = 16;
-      if (ks >= 2 && !g_det) p.ksplit = ks;
+      if (ks >= 2 && !det_on()) p.ksplit = ks;
     }
     return p;
   }
   const int64_t w = wgs(p.mt, p.nt);
   if (w < 512 && p.ncc >= 4 && plain && p.nv == 0) {
-    int ks = (int)cdiv(g_ks_target, (int)w);
+    int ks = (int)cdiv(PLAN_KS_TARGET, (int)w);
     if (ks > p.ncc / 2) ks = p.ncc / 2;
     if (ks > 8) ks = 8;
-    if (ks >= 2 && !g_det) p.ksplit = ks;
+    if (ks >= 2 && !det_on()) p.ksplit = ks;
   }
   return p;
 }
@@ -3064,9 +3106,8 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
 // mode 2 (data gradient of a folded decoder conv = sum of 8 parity convs): number of workgroups along z the parities are
 // spread over.  1 = all eight inside one workgroup (plain stores); more only when the launch would not fill the chip
 // (20^3 / 10^3 levels: 120 workgroups ran at 16-34 % of the MFMA peak), then every workgroup adds its share atomically.
-static int g_psplit = 1;  // option 7: 0 disables
 inline int parity_split(int64_t workgroups, const float* bias, int act, const ConvExt& ext) {
-  if (!g_psplit || g_det || bias != nullptr || act != 0 || ext.addend != nullptr) return 1;
+  if (!PLAN_PSPLIT || det_on() || bias != nullptr || act != 0 || ext.addend != nullptr) return 1;
   int ps = 1;
   while (ps < 8 && workgroups * ps < 400) ps *= 2;
   return ps;
@@ -3080,7 +3121,7 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
   if constexpr (CK == 24 && NT <= 3 && NV == 0) {
     const int64_t in_bytes = (int64_t)s[0] * s[1] * s[2] * (ext.mode == 2 ? 8 : 1) * Cin * 4;
     const int64_t w_bytes = pl.count() * 4 * (ext.mode ? 8 : 1);
-    if (in_bytes < (1ll << 31) && w_bytes < (1ll << 31) && !(g_dbg & 32)) {
+    if (in_bytes < (1ll << 31) && w_bytes < (1ll << 31) && !(PLAN_DBG & 32)) {
       const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
       if (KS) {  // split-K accumulates with atomics: onto zeros, or onto the addend when it already sits in `out`
         if (act != 2 && ext.addend && ext.addend != out) return SYNTHSR_EINVAL;
@@ -3094,21 +3135,19 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
       }
       const dim3 grid(tiles0 * tiles1 * tiles2, pl.nchunks, gz);
       if (ext.mode == 0) {
-        static bool done27 = false;
+        static SynOncePerDevice done27;
         auto k27 = conv3d_fwd_lean_kernel<NT, MT, KS, 27>;
-        if (!done27) {
+        if (done27.first()) {
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k27), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-          done27 = true;
         }
         hipLaunchKernelGGL(k27, grid, dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1,
                            tiles2, act, ext);
       } else {
         if constexpr (!KS) {
-          static bool done8 = false;
+          static SynOncePerDevice done8;
           auto k8 = conv3d_fwd_lean_kernel<NT, MT, false, 8>;
-          if (!done8) {
+          if (done8.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            done8 = true;
           }
           hipLaunchKernelGGL(k8, grid, dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1,
                              tiles2, act, ext);
@@ -3125,11 +3164,10 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
       return SYNTHSR_OK;
     }
   }
-  static bool attr_done = false;
+  static SynOncePerDevice attr_done;
   auto kern = conv3d_fwd_kernel<CK, NT, MT, KS, NV>;
-  if (!attr_done) {
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
   if (KS) {
@@ -3139,7 +3177,7 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
   }
   const int gz = KS ? pl.ksplit : (ext.mode == 1 ? 8 : 1);
   hipLaunchKernelGGL(kern, dim3(tiles0 * tiles1 * tiles2, pl.nchunks, gz), dim3(256), smem, st, in, wp, bias, out, s[0],
-                     s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act | (g_dbg << 8), ext);
+                     s[1], s[2], Cin, Cout, pl.ncc, tiles1, tiles2, act | (PLAN_DBG << 8), ext);
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   if (KS && (bias != nullptr || act != 0)) {
     hipLaunchKernelGGL(bias_act_kernel, dim3(syn_grid(nout, 256)), dim3(256), 0, st, out, bias, nout, Cout, act,
@@ -3155,11 +3193,10 @@ int launch_fwd_persist(const float* in, const float* wp, const float* bias, floa
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
   const int ntiles = tiles0 * tiles1 * tiles2;
   const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
-  static bool attr_done = false;
+  static SynOncePerDevice attr_done;
   auto kern = conv3d_fwd_persist_kernel<NT>;
-  if (!attr_done) {
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   int gx = 512 / pl.nchunks;  // 2 workgroups per CU in total
   gx = std::max(8, (gx / 8) * 8);
@@ -3175,11 +3212,10 @@ int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* ou
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
   const int ntiles = tiles0 * tiles1 * tiles2;
   const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_fwd_p4_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   int gx = 512;
   while (gx > 8 && gx > ntiles) gx -= 8;
@@ -3189,7 +3225,7 @@ int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* ou
     if (!partial) return SYNTHSR_ELAUNCH;
   }
   hipLaunchKernelGGL(conv3d_fwd_p4_kernel, dim3(gx), dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, pl.ncc,
-                     tiles1, tiles2, ntiles, act | (g_dbg << 8), addend, partial);
+                     tiles1, tiles2, ntiles, act | (PLAN_DBG << 8), addend, partial);
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   if (stats) return synthsr_bn_stats_from_partials(partial, gx, (int64_t)s[0] * s[1] * s[2], 24, stats, st);
   return SYNTHSR_OK;
@@ -3271,11 +3307,10 @@ int launch_up_fwd_p4(const float* in, const float* wp, const float* bias, float*
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
   const int ntiles = tiles0 * tiles1 * tiles2;
   const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_up_fwd_p4_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   int gx = 512;
   while (gx > 8 && gx > ntiles) gx -= 8;
@@ -3339,22 +3374,21 @@ int dispatch_fwd(const float* in, const float* wp, const float* bias, float* out
 // split; the other grid dimensions split dW itself) its own zeroed copy of dW (+ dbias) -- "plane" x -- and a second kernel
 // adds the planes up in x order.  No serialisation: the chained-ticket flush this replaces cost ~3 us per hand-over,
 // 98 instead of 29 ms per 160^3 step; the planes cost one memset + one read of gx * |dW| floats per launch.
-static float* g_det_planes = nullptr;
-static size_t g_det_planes_floats = 0;
 static float* det_planes(size_t floats) {
-  if (floats > g_det_planes_floats) {
+  SynDeviceState& ds = dev_state();   // the planes belong to the device the call runs on
+  if (floats > ds.det_planes_floats) {
     if (hipDeviceSynchronize() != hipSuccess) return nullptr;  // the old buffer may still be read by a queued reduction
-    if (g_det_planes) (void)hipFree(g_det_planes);
-    g_det_planes = nullptr;
-    g_det_planes_floats = 0;
+    if (ds.det_planes) (void)hipFree(ds.det_planes);
+    ds.det_planes = nullptr;
+    ds.det_planes_floats = 0;
     const size_t want = std::max(floats + floats / 4, (size_t)16 << 20);
-    if (hipMalloc(reinterpret_cast<void**>(&g_det_planes), want * sizeof(float)) != hipSuccess) {
-      g_det_planes = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&ds.det_planes), want * sizeof(float)) != hipSuccess) {
+      ds.det_planes = nullptr;
       return nullptr;
     }
-    g_det_planes_floats = want;
+    ds.det_planes_floats = want;
   }
-  return g_det_planes;
+  return ds.det_planes;
 }
 __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ planes, int64_t stride, int gx,
                                                          float* __restrict__ dw, int64_t dw_elems,
@@ -3370,7 +3404,7 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict
 // before the launch: redirects dw / dbias to the planes (no-op unless deterministic mode is on)
 static int det_prepare_impl(DetRun* d, float** dw, float** dbias, int64_t dw_elems, int cout, int gx, hipStream_t st) {
   d->stride = 0;
-  if (!g_det) return SYNTHSR_OK;
+  if (!det_on()) return SYNTHSR_OK;
   d->dw = *dw;
   d->dbias = *dbias;
   d->dw_elems = dw_elems;
@@ -3403,7 +3437,7 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
   const int ncc = cdiv(Cin, CK), nco = cdiv(Cout, NT * 16);
   const int ymul = (NTAPS == 8) ? 8 : MS;
   // 512 workgroups in total = the 2 per CU that fit: every extra workgroup only adds a 27*CK*Cout atomic flush
-  int gx = (g_force_mt > 8 ? g_force_mt : 512) / (ncc * nco * ymul);
+  int gx = (PLAN_FORCE_MT > 8 ? PLAN_FORCE_MT : 512) / (ncc * nco * ymul);
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   const size_t smem = ((size_t)(CK + 1) * WVPX + (size_t)NT * 16 * WVPD) * sizeof(float);
@@ -3413,7 +3447,7 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
     if constexpr (NTAPS == 27) {
       // small deep levels: box tiles that divide the volume exactly (4x4x8 for x = 40, 4x4x4 for x = 20)
       const bool div4 = (s[0] % 4) == 0 && (s[1] % 4) == 0 && (s[2] % 4) == 0 && (s[2] % 16) != 0;
-      if (g_brick && div4 && (Cout % 4) == 0 && xbytes < (1ll << 31) && dbytes < (1ll << 31) && !(g_dbg & 16)) {
+      if (PLAN_BRICK && div4 && (Cout % 4) == 0 && xbytes < (1ll << 31) && dbytes < (1ll << 31) && !(PLAN_DBG & 16)) {
         const bool x8 = (s[2] % 8) == 0;
         const int tx = x8 ? 8 : 4;
         const int bt0 = s[0] / 4, bt1 = s[1] / 4, bt2 = s[2] / tx;
@@ -3437,13 +3471,12 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
         return syn_det_finish(&det, st);
       }
     }
-    if ((Cout % 4) == 0 && xbytes < (1ll << 31) && dbytes < (1ll << 31) && !(g_dbg & 16)) {
-      static bool lean_attr_done = false;
+    if ((Cout % 4) == 0 && xbytes < (1ll << 31) && dbytes < (1ll << 31) && !(PLAN_DBG & 16)) {
+      static SynOncePerDevice lean_attr_done;
       auto lkern = conv3d_wgrad_lean_kernel<NT, MS, NTAPS>;
-      if (!lean_attr_done) {
+      if (lean_attr_done.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lkern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
-        lean_attr_done = true;
       }
       if (syn_det_prepare(&det, &dw, &ext.dbias, dw_elems, Cout, gx, st) != SYNTHSR_OK) return SYNTHSR_ELAUNCH;
       ext.det_stride = det.stride;
@@ -3453,11 +3486,10 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
       return syn_det_finish(&det, st);
     }
   }
-  static bool attr_done = false;
+  static SynOncePerDevice attr_done;
   auto kern = conv3d_wgrad_kernel<CK, NT, MS, NTAPS>;
-  if (!attr_done) {
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   if (ext.dbias) {  // the generic kernel has no dbias row
     hipLaunchKernelGGL(colsum_kernel, dim3(1024), dim3(256), 0, st, dout, (int64_t)s[0] * s[1] * s[2], Cout, ext.dbias);
@@ -3672,7 +3704,7 @@ int launch_wgrad_c2(const float* in, const float* dout, float* dw, float* dbias,
                     const WgExt& ext) {
   const int tiles0 = cdiv(s[0], FT0), tiles1 = cdiv(s[1], 4), tiles2 = cdiv(s[2], FT2);
   const int ntiles = tiles0 * tiles1 * tiles2;
-  int gx = g_force_mt > 8 ? g_force_mt : 2048;  // 8 per CU: per-tile work is short, latency is hidden by occupancy
+  int gx = PLAN_FORCE_MT > 8 ? PLAN_FORCE_MT : 2048;  // 8 per CU: per-tile work is short, latency is hidden by occupancy
   while (gx > 8 && gx > ntiles) gx -= 8;
   float* partial = lib_scratch((size_t)gx * 1536 * sizeof(float));
   if (!partial) return SYNTHSR_ELAUNCH;
@@ -3696,14 +3728,13 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
     const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
     const int tiles0 = cdiv(shape[0], FT0), tiles1 = cdiv(shape[1], 4), tiles2 = cdiv(shape[2], FT2);
     const int ntiles = tiles0 * tiles1 * tiles2, ncc = Cin / 24;
-    if (Cout == 24 && (Cin % 24) == 0 && g_p4 && ntiles >= 768 && vox * Cin * 4 < (1ll << 31) &&
-        vox * 8 * Cout * 4 < (1ll << 31) && !(g_dbg & 16)) {
+    if (Cout == 24 && (Cin % 24) == 0 && PLAN_P4 && ntiles >= 768 && vox * Cin * 4 < (1ll << 31) &&
+        vox * 8 * Cout * 4 < (1ll << 31) && !(PLAN_DBG & 16)) {
       const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
-      static bool attr_done = false;
-      if (!attr_done) {
+      static SynOncePerDevice attr_done;
+      if (attr_done.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_up_wgrad_p4_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
       }
       int gx = std::max(8, ((512 / (ncc * 2)) / 8) * 8);  // each workgroup carries 4 of the 8 parities (one per wave)
       while (gx > 8 && gx > ntiles) gx -= 8;
@@ -3717,26 +3748,25 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
     }
   }
   if constexpr (NTAPS == 27) {
-    if (Cin <= 2 && Cout == 24 && g_p4 && (int64_t)shape[0] * shape[1] * shape[2] * Cout * 4 < (1ll << 31))
+    if (Cin <= 2 && Cout == 24 && PLAN_P4 && (int64_t)shape[0] * shape[1] * shape[2] * Cout * 4 < (1ll << 31))
       return launch_wgrad_c2(in, dout, dw, ext.dbias, shape, Cin, st, ext);
     // fp32 through three bf16 pieces per operand (conv_split.hip): layers with enough 4x4x16 tiles
     if (wgrad_takes_split(shape, Cin, Cout)) {
-      const int rc = syn_split_wgrad(in, dout, dw, ext.dbias, shape, ext.cin_total, ext.ci_off, Cin, Cout, st);
+      const int rc = syn_split_wgrad(in, dout, dw, ext.dbias, shape, ext.cin_total, ext.ci_off, Cin, Cout, cfg().nprod, st);
       if (rc != SYNTHSR_EINVAL) return rc;  // EINVAL: channel counts the split kernel does not cover
     }
   }
   if constexpr (NTAPS == 27) {
     const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
-    if (Cout == 24 && (Cin % 24) == 0 && g_p4 && vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31) &&
-        !(g_dbg & 16)) {
+    if (Cout == 24 && (Cin % 24) == 0 && PLAN_P4 && vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31) &&
+        !(PLAN_DBG & 16)) {
       const int tiles0 = cdiv(shape[0], FT0), tiles1 = cdiv(shape[1], 4), tiles2 = cdiv(shape[2], FT2);
       const int ntiles = tiles0 * tiles1 * tiles2, ncc = Cin / 24;
       const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
-      static bool attr_done = false;
-      if (!attr_done) {
+      static SynOncePerDevice attr_done;
+      if (attr_done.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_p4_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
       }
       int gx = std::max(8, ((512 / ncc) / 8) * 8);
       while (gx > 8 && gx > ntiles) gx -= 8;
@@ -3770,8 +3800,10 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
 
 extern "C" {
 
-int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3], int Cin_total, int ci_off, int Cin,
-                               int Cout, int mode, int up, synthsr_stream_t stream) {
+int64_t synthsr_conv3d_pack_ex(const synthsr_conv_ctx* ctx, const float* w, float* packed, const int shape[3], int Cin_total,
+                               int ci_off, int Cin, int Cout, int mode, int up, synthsr_stream_t stream) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!shape || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || (mode != 0 && mode != 1) ||
       shape[0] < 1 || shape[1] < 1 || shape[2] < 1 || up < 0 || up > 2)
     return SYNTHSR_EINVAL;
@@ -3794,12 +3826,14 @@ int64_t synthsr_conv3d_pack_ex(const float* w, float* packed, const int shape[3]
   return total;
 }
 
-int64_t synthsr_conv3d_pack(const float* w, float* packed, const int shape[3], int Cin, int Cout, int mode,
-                            synthsr_stream_t stream) {
-  return synthsr_conv3d_pack_ex(w, packed, shape, Cin, 0, Cin, Cout, mode, 0, stream);
+int64_t synthsr_conv3d_pack(const synthsr_conv_ctx* ctx, const float* w, float* packed, const int shape[3], int Cin, int Cout,
+                            int mode, synthsr_stream_t stream) {
+  return synthsr_conv3d_pack_ex(ctx, w, packed, shape, Cin, 0, Cin, Cout, mode, 0, stream);
 }
 
-int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int64_t out[8]) {
+int synthsr_conv3d_plan(const synthsr_conv_ctx* ctx, const int shape[3], int CinE, int CoutE, int plain, int64_t out[8]) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!shape || !out || CinE < 1 || CoutE < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, CinE, CoutE, plain);
   out[0] = pl.ck;
@@ -3813,7 +3847,9 @@ int synthsr_conv3d_plan(const int shape[3], int CinE, int CoutE, int plain, int6
   return SYNTHSR_OK;
 }
 
-int synthsr_conv3d_wgrad_runs_split(const int shape[3], int Cin, int Cout) {
+int synthsr_conv3d_wgrad_runs_split(const synthsr_conv_ctx* ctx, const int shape[3], int Cin, int Cout) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!shape || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
   return (Cin > 2 || Cout != 24) && wgrad_takes_split(shape, Cin, Cout) ? 1 : 0;
 }
@@ -3859,38 +3895,45 @@ int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
-int synthsr_conv3d_fwd(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3], int Cin,
-                       int Cout, int act, synthsr_stream_t stream) {
+int synthsr_conv3d_fwd(const synthsr_conv_ctx* ctx, const float* in, const float* wpacked, const float* bias, float* out,
+                       const int shape[3], int Cin, int Cout, int act, synthsr_stream_t stream) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!in || !wpacked || !out || !shape || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1 ||
       (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   if (pl.split)
     return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr, 0,
-                         pl.stacked, (hipStream_t)stream);
+                         pl.stacked, cfg().nprod, (hipStream_t)stream);
   const ConvExt ext{0, nullptr, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
 }
 
-int synthsr_conv3d_fwd_add(const float* in, const float* wpacked, const float* bias, const float* addend, float* out,
-                           const int shape[3], int Cin, int Cout, int act, synthsr_stream_t stream) {
+int synthsr_conv3d_fwd_add(const synthsr_conv_ctx* ctx, const float* in, const float* wpacked, const float* bias,
+                           const float* addend, float* out, const int shape[3], int Cin, int Cout, int act,
+                           synthsr_stream_t stream) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!in || !wpacked || !out || !shape || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1 ||
       (act != 0 && act != 1 && act != 2) || (act == 2 && (!addend || addend == out)))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   if (pl.split)
     return syn_split_fwd(in, wpacked, bias, addend, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, nullptr, nullptr, 0,
-                         pl.stacked, (hipStream_t)stream);
+                         pl.stacked, cfg().nprod, (hipStream_t)stream);
   const ConvExt ext{0, addend, 0, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   if (pl.ck == 32) return dispatch_fwd<32>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
   return dispatch_fwd<8>(in, wpacked, bias, out, shape, Cin, Cout, pl, act, (hipStream_t)stream, ext);
 }
 
-int synthsr_conv3d_fwd_stats(const float* in, const float* wpacked, const float* bias, float* out, const int shape[3],
-                             int Cin, int Cout, int act, float* stats, double* ws, synthsr_stream_t stream) {
+int synthsr_conv3d_fwd_stats(const synthsr_conv_ctx* ctx, const float* in, const float* wpacked, const float* bias, float* out,
+                             const int shape[3], int Cin, int Cout, int act, float* stats, double* ws, synthsr_stream_t stream) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!in || !wpacked || !out || !shape || !stats || !ws || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 ||
       shape[2] < 1 || (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
@@ -3900,23 +3943,26 @@ int synthsr_conv3d_fwd_stats(const float* in, const float* wpacked, const float*
     float* partial = lib_scratch((size_t)512 * 2 * Cout * sizeof(float));
     if (!partial) return SYNTHSR_ELAUNCH;
     return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, stats, partial, 0,
-                         pl.stacked, (hipStream_t)stream);
+                         pl.stacked, cfg().nprod, (hipStream_t)stream);
   }
   if (pl.p4 && nvox * Cin * 4 < (1ll << 31))  // statistics accumulated in the conv epilogue
     return launch_fwd_p4(in, wpacked, bias, out, shape, Cin, pl, act, (hipStream_t)stream, nullptr, stats);
-  const int rc = synthsr_conv3d_fwd(in, wpacked, bias, out, shape, Cin, Cout, act, stream);
+  const int rc = synthsr_conv3d_fwd(ctx, in, wpacked, bias, out, shape, Cin, Cout, act, stream);
   if (rc != SYNTHSR_OK) return rc;
   return synthsr_bn_stats(out, nvox, Cout, stats, ws, stream);
 }
 
-int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* bias, const float* addend, float* out,
-                          const int lo_shape[3], int Cl, int Cout, int act, synthsr_stream_t stream) {
+int synthsr_conv3d_up_fwd(const synthsr_conv_ctx* ctx, const float* lo, const float* wpacked8, const float* bias,
+                          const float* addend, float* out, const int lo_shape[3], int Cl, int Cout, int act,
+                          synthsr_stream_t stream) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!lo || !wpacked8 || !out || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 ||
       lo_shape[2] < 1 || (act != 0 && act != 1))
     return SYNTHSR_EINVAL;
   const FwdPlan pl = plan_fwd(lo_shape, Cl, Cout, 2);
   if (pl.split)  // all parities from one converted low-resolution halo (conv_split.hip: conv3d_split_upfwd_kernel)
-    return syn_split_upfwd(lo, wpacked8, bias, addend, out, lo_shape, Cl, Cout, pl.mt, act, (hipStream_t)stream);
+    return syn_split_upfwd(lo, wpacked8, bias, addend, out, lo_shape, Cl, Cout, pl.mt, act, cfg().nprod, (hipStream_t)stream);
   const int64_t wstride = pl.count();
   const ConvExt ext{1, addend, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
@@ -3924,8 +3970,10 @@ int synthsr_conv3d_up_fwd(const float* lo, const float* wpacked8, const float* b
   return dispatch_fwd<8>(lo, wpacked8, bias, out, lo_shape, Cl, Cout, pl, act, (hipStream_t)stream, ext);
 }
 
-int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo, const int lo_shape[3], int Cl, int Cout,
-                            synthsr_stream_t stream) {
+int synthsr_conv3d_up_dgrad(const synthsr_conv_ctx* ctx, const float* dout, const float* wpacked8, float* dlo,
+                            const int lo_shape[3], int Cl, int Cout, synthsr_stream_t stream) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!dout || !wpacked8 || !dlo || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 ||
       lo_shape[2] < 1)
     return SYNTHSR_EINVAL;
@@ -3933,7 +3981,7 @@ int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo
   const FwdPlan pl = plan_fwd(lo_shape, Cout, Cl, 0);
   if (pl.split)  // the 8 parities as K chunks of one split-arithmetic launch (conv_split.hip, UPM 2)
     return syn_split_fwd(dout, wpacked8, nullptr, nullptr, dlo, lo_shape, Cout, Cl, pl.mt, pl.nchunks, 0, nullptr, nullptr, 2, 0,
-                         (hipStream_t)stream);
+                         cfg().nprod, (hipStream_t)stream);
   const int64_t wstride = pl.count();
   const ConvExt ext{2, nullptr, wstride, pl.mfma_count()};
   if (pl.ck == 24) return dispatch_fwd<24>(dout, wpacked8, nullptr, dlo, lo_shape, Cout, Cl, pl, 0, (hipStream_t)stream, ext);
@@ -3943,7 +3991,7 @@ int synthsr_conv3d_up_dgrad(const float* dout, const float* wpacked8, float* dlo
 
 
 // ---- deterministic mode (see common.h: syn_det_gather / syn_turn_begin) ------------------------------------------------
-extern "C" __attribute__((visibility("hidden"))) int syn_det_enabled() { return g_det; }
+extern "C" __attribute__((visibility("hidden"))) int syn_det_enabled() { return det_on(); }
 extern "C" __attribute__((visibility("hidden"))) int syn_det_prepare(DetRun* d, float** dw, float** dbias, int64_t dw_elems,
                                                                       int cout, int gx, hipStream_t st) {
   return det_prepare_impl(d, dw, dbias, dw_elems, cout, gx, st);
@@ -3955,12 +4003,12 @@ extern "C" int syn_det_set_pointwise(SynDet*);
 extern "C" int syn_det_set_critic(SynDet*);
 extern "C" int syn_det_set_ssim(SynDet*);
 extern "C" int syn_det_set_conv_bf16(SynDet*);
-static SynDet* g_det_state = nullptr;
 constexpr long long DET_SCRATCH_FLOATS = 16ll << 20;  // 64 MB of partial rows (4096 workgroups x 4096 sums)
 
 int synthsr_set_deterministic(int on) {
   if (hipDeviceSynchronize() != hipSuccess) return SYNTHSR_ELAUNCH;  // no kernel may see the switch mid-flight
-  if (on && !g_det_state) {
+  SynDeviceState& ds = dev_state();   // the CURRENT device: its state block, its device symbols, its planes
+  if (on && !ds.det_state) {
     // all-or-nothing: a half-built state block (struct allocated, scratch not) must never be installed by a later call
     SynDet* state = nullptr;
     float* scratch = nullptr;
@@ -3978,15 +4026,15 @@ int synthsr_set_deterministic(int on) {
       (void)hipFree(state);
       return SYNTHSR_ELAUNCH;
     }
-    g_det_state = state;
+    ds.det_state = state;
   }
-  if (g_det_state) {  // fresh tickets / counters / timeout flag (scratch pointer and size stay)
-    if (hipMemset(g_det_state, 0, offsetof(SynDet, scratch_floats)) != hipSuccess) return SYNTHSR_ELAUNCH;
-    if (hipMemset(reinterpret_cast<char*>(g_det_state) + offsetof(SynDet, chain), 0, sizeof(int) * SYN_DET_CHAINS) != hipSuccess)
+  if (ds.det_state) {  // fresh tickets / counters / timeout flag (scratch pointer and size stay)
+    if (hipMemset(ds.det_state, 0, offsetof(SynDet, scratch_floats)) != hipSuccess) return SYNTHSR_ELAUNCH;
+    if (hipMemset(reinterpret_cast<char*>(ds.det_state) + offsetof(SynDet, chain), 0, sizeof(int) * SYN_DET_CHAINS) != hipSuccess)
       return SYNTHSR_ELAUNCH;
   }
-  SynDet* p = on ? g_det_state : nullptr;
-  g_det = on ? 1 : 0;
+  SynDet* p = on ? ds.det_state : nullptr;
+  ds.det = on ? 1 : 0;
   if (syn_det_set_conv3d(p) || syn_det_set_pointwise(p) || syn_det_set_critic(p) || syn_det_set_ssim(p) ||
       syn_det_set_conv_bf16(p))
     return SYNTHSR_ELAUNCH;
@@ -3994,111 +4042,39 @@ int synthsr_set_deterministic(int on) {
 }
 
 int synthsr_deterministic_status(void) {
-  if (!g_det) return 0;
+  const SynDeviceState& ds = dev_state();
+  if (!ds.det) return 0;
   int v[2] = {0, 0};
-  if (hipMemcpy(v, g_det_state, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(v, ds.det_state, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return v[1] ? 2 : 1;  // 1: on and every ordered wait completed; 2: on, but a wait timed out (order not guaranteed)
 }
 
-extern "C" void syn_split_set_products(int n);  // conv_split.hip: 6 or 9 partial products per multiplication
-extern "C" void syn_split_set_wgrad_stack(int v);  // conv_split.hip: stacked column tiles of the 24-column weight gradient
-extern "C" void syn_split_set_variant(int v);   // conv_split.hip: kernel generation (A/B runs of tools/)
-// bumped whenever a process-wide setting that can change a plan (and with it a packed weight layout) takes a new value
-static int g_layout_epoch = 0;
-int synthsr_conv3d_layout_epoch(void) { return g_layout_epoch; }
-
-int synthsr_set_conv_arithmetic(int mode) {
-  if (mode < 0 || mode > 2) return SYNTHSR_EINVAL;
-  if (mode != g_arith) ++g_layout_epoch;
-  g_arith = mode;
-  g_split = mode ? 1 : 0;  // 1 "split" and 2 "split9" share plans, packed layouts and kernels (template NPROD)
-  syn_split_set_products(mode == 2 ? 9 : 6);
-  return SYNTHSR_OK;
-}
-
-int synthsr_conv_arithmetic(void) { return g_arith; }
-
-int synthsr_conv3d_set_option(int option, int value) {
-  if (option == 2 || option == 4 || option == 6 || (option >= 8 && option <= 10)) ++g_layout_epoch;  // plan-changing options
-  if (option == 0) {
-    g_persist = value ? 1 : 0;
-    return SYNTHSR_OK;
-  }
-  if (option == 1) {
-    g_dbg = value & 0xff;
-    return SYNTHSR_OK;
-  }
-  if (option == 2) {
-    g_force_mt = value;
-    return SYNTHSR_OK;
-  }
-  if (option == 3) {
-    g_hybrid = value ? 1 : 0;
-    return SYNTHSR_OK;
-  }
-  if (option == 4) {
-    g_p4 = value ? 1 : 0;
-    return SYNTHSR_OK;
-  }
-  if (option == 5) {
-    g_ks_target = value > 0 ? value : 1024;
-    return SYNTHSR_OK;
-  }
-  if (option == 6) {
-    g_brick = value ? 1 : 0;
-    return SYNTHSR_OK;
-  }
-  if (option == 7) {
-    g_psplit = value ? 1 : 0;
-    return SYNTHSR_OK;
-  }
-  if (option == 8) {
-    syn_split_set_variant(value);
-    return SYNTHSR_OK;
-  }
-  if (option == 10) {
-    g_stack24 = value ? 1 : 0;
-    return SYNTHSR_OK;
-  }
-  if (option == 11) {
-    g_split_wgrad_min_tiles = value > 0 ? value : 1;
-    return SYNTHSR_OK;
-  }
-  if (option == 9) {
-    g_split_min_wgs = value > 0 ? value : 200;
-    return SYNTHSR_OK;
-  }
-  if (option == 12) {
-    syn_split_set_wgrad_stack(value);
-    return SYNTHSR_OK;
-  }
-  return SYNTHSR_EINVAL;
-}
-
-int synthsr_conv3d_wgrad_bias(const float* in, const float* dout, float* dw, float* dbias, const int shape[3],
-                              int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream) {
+int synthsr_conv3d_wgrad_bias(const synthsr_conv_ctx* ctx, const float* in, const float* dout, float* dw, float* dbias,
+                              const int shape[3], int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!in || !dout || !dw || !shape || Cin < 1 || Cout < 1 || ci_off < 0 || ci_off + Cin > Cin_total || shape[0] < 1 ||
       shape[1] < 1 || shape[2] < 1)
     return SYNTHSR_EINVAL;
-  const WgExt ext{0, Cin_total, ci_off, 0, g_dbg, dbias};
+  const WgExt ext{0, Cin_total, ci_off, 0, PLAN_DBG, dbias};
   return dispatch_wgrad<27>(in, dout, dw, shape, Cin, Cout, (hipStream_t)stream, ext);
 }
 
-int synthsr_conv3d_wgrad_ex(const float* in, const float* dout, float* dw, const int shape[3], int Cin_total, int ci_off,
-                            int Cin, int Cout, synthsr_stream_t stream) {
-  return synthsr_conv3d_wgrad_bias(in, dout, dw, nullptr, shape, Cin_total, ci_off, Cin, Cout, stream);
+int synthsr_conv3d_wgrad_ex(const synthsr_conv_ctx* ctx, const float* in, const float* dout, float* dw, const int shape[3],
+                            int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream) {
+  return synthsr_conv3d_wgrad_bias(ctx, in, dout, dw, nullptr, shape, Cin_total, ci_off, Cin, Cout, stream);
 }
 
-int synthsr_conv3d_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout,
-                         synthsr_stream_t stream) {
-  return synthsr_conv3d_wgrad_ex(in, dout, dw, shape, Cin, 0, Cin, Cout, stream);
+int synthsr_conv3d_wgrad(const synthsr_conv_ctx* ctx, const float* in, const float* dout, float* dw, const int shape[3], int Cin,
+                         int Cout, synthsr_stream_t stream) {
+  return synthsr_conv3d_wgrad_ex(ctx, in, dout, dw, shape, Cin, 0, Cin, Cout, stream);
 }
 
 int synthsr_conv3d_up_wgrad(const float* lo, const float* dout, float* dwc, const int lo_shape[3], int Cl, int Cout,
                             synthsr_stream_t stream) {
   if (!lo || !dout || !dwc || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1)
     return SYNTHSR_EINVAL;
-  const WgExt ext{1, Cl, 0, (int64_t)27 * Cl * Cout, g_dbg, nullptr};
+  const WgExt ext{1, Cl, 0, (int64_t)27 * Cl * Cout, PLAN_DBG, nullptr};
   return dispatch_wgrad<8>(lo, dout, dwc, lo_shape, Cl, Cout, (hipStream_t)stream, ext);
 }
 

@@ -574,10 +574,9 @@ int launch_fwd_w(const FwdArgs& a, int nchunks, hipStream_t st) {
   const size_t hbytes = ((size_t)HVOX * rowb_fwd(CK) + 1023) / 1024 * 1024;
   const size_t smem = hbytes + (WLDS ? (size_t)NSTEP * MT * 1024 : 0);
   auto kern = conv3d_bf16_fwd_kernel<CK, MT, WLDS>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks, a.ksplit), dim3(256), smem, st, a);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
@@ -591,10 +590,9 @@ int launch_fwd_up(const FwdArgs& a, int nchunks, hipStream_t st) {
   if (a.ntiles < 8) gx = a.ntiles;
   const size_t smem = ((size_t)HVOX * rowb_fwd(CK) + 1023) / 1024 * 1024;
   auto kern = conv3d_bf16_fwd_kernel<CK, MT, false, UPM>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks, UPM == 1 ? 8 : a.ksplit), dim3(256), smem, st, a);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
@@ -988,10 +986,9 @@ int launch_wgrad(const WgArgs& a0, hipStream_t st) {
   if (a.ntiles < 8) gx = a.ntiles;
   const size_t smem = (size_t)HVOX * rowb_for(CK) + (size_t)TZ * TY * TX * ((NT & 1) ? NT * 32 : NT * 32 + 32);
   auto kern = conv3d_bf16_wgrad_kernel<CK, NT, UP>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   DetRun det;
   if (syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)(UP ? 8 : 1) * 27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)

@@ -37,18 +37,16 @@ extern "C" int synthsr_split_timing_buffer(long long* p) {
 #define TM(i)
 #endif
 
-// synthsr_set_conv_arithmetic(2) ("split9"): all nine partial products a_i b_j instead of six -- an fp32 product is then
-// reproduced EXACTLY (tests/test_split_arithmetic_cpu.py) at 1.5x the MFMAs; same packed weights, same kernels (template NPROD)
-static int g_products = 6;
-extern "C" __attribute__((visibility("hidden"))) void syn_split_set_products(int n) { g_products = n == 9 ? 9 : 6; }
-// synthsr_conv3d_set_option(8, v) (tools/ A-B runs): 0 = the round-3 forward kernel (phases: K loop | convert | epilogue),
-// 1 (default) = round 4: conversion inside the K loop (fwd2), the LDS-weights kernel (fwd3) where it quantises better; 2 = fwd3 everywhere
-static int g_variant = 1;
-extern "C" __attribute__((visibility("hidden"))) void syn_split_set_variant(int v) { g_variant = v; }
-// 1 (default): the 24-column weight gradient reads the dz pieces as five stacked column tiles (10 MFMAs per row tile and K step
-// instead of 12, see conv3d_split_wgrad_kernel); 0: two padded column tiles per piece (rounds 3 / early 4)
-static int g_wgrad_stack = 1;
-extern "C" __attribute__((visibility("hidden"))) void syn_split_set_wgrad_stack(int v) { g_wgrad_stack = v; }  // (bit 1, A/B only: 24-column workgroups everywhere)
+// Arithmetic "split9" (synthsr_conv_ctx.arithmetic = 2): all nine partial products a_i b_j instead of six -- an fp32 product is
+// then reproduced EXACTLY (tests/test_split_arithmetic_cpu.py) at 1.5x the MFMAs; same packed weights, same kernels (template
+// NPROD).  The number of products is an ARGUMENT of the three entry points below (syn_split_fwd / _upfwd / _wgrad, `nprod`); the
+// launch helpers of this file read it from t_nprod, which those entry points set on every call -- no state survives a call.
+static thread_local int t_nprod = 6;
+// Kernel choices that were A/B switches in rounds 3-4 (options 8 and 12 of the former synthsr_conv3d_set_option) and are now
+// fixed at what the measurements kept (profiles/r04_split_fwd_variants.txt, r04_split_wgrad_*_ab.txt, r05_split_wgrad_var24_ab.txt):
+// forward = conversion inside the K loop (fwd2), the LDS-weights kernel (fwd3) where it quantises better; weight gradient = five
+// stacked column tiles for 24 columns, 48-column workgroups where 48 divides Cout with 16 input channels each where 16 divides
+// Cin, all 24 input channels in one workgroup where Cin = Cout = 24.
 
 namespace {
 
@@ -1520,10 +1518,9 @@ int launch_split_upfwd_np(const SplitFwdArgs& a, hipStream_t st) {
   const int gx = split_upfwd_grid_x(a.ntiles, NG);
   const size_t smem = 2 * BUF;
   auto kern = conv3d_split_upfwd_kernel<MT, NPAR, NPROD>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(gx, 1, NG), dim3(512), smem, st, a);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
@@ -1531,17 +1528,16 @@ int launch_split_upfwd_np(const SplitFwdArgs& a, hipStream_t st) {
 
 template <int MT, int NPAR>
 int launch_split_upfwd(const SplitFwdArgs& a, hipStream_t st) {
-  return g_products == 9 ? launch_split_upfwd_np<MT, NPAR, 9>(a, st) : launch_split_upfwd_np<MT, NPAR, 6>(a, st);
+  return t_nprod == 9 ? launch_split_upfwd_np<MT, NPAR, 9>(a, st) : launch_split_upfwd_np<MT, NPAR, 6>(a, st);
 }
 
 template <int MT, bool ST, int UPM, int NPROD>
 int launch_split_fwd_np(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
   const size_t smem = 2 * BUF;
   auto kern = conv3d_split_fwd_kernel<MT, ST, UPM, NPROD>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(256), smem, st, a);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
@@ -1551,10 +1547,9 @@ template <int MT, bool ST, int EPI, bool STK>
 int launch_split_fwd2_e(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
   const size_t smem = 2 * BUF2 + MT * 16 * 4;
   auto kern = conv3d_split_fwd2_kernel<MT, ST, EPI, STK>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(256), smem, st, a);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
@@ -1581,10 +1576,8 @@ int launch_split_fwd2(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st
 // 600 units): there the 8-wave kernel (one workgroup per CU, weights through LDS) quantises better (-10 %); with fewer units
 // than slots (20^3, 192 output channels: 200) the 4-wave kernel wins again (0.126 vs 0.14 ms)
 inline bool split_uses_fwd3(int ntiles, int nchunks) {
-  if (g_variant == 2) return true;
-  if (g_variant == 3) return false;  // (A/B: the 4-wave kernel everywhere)
   const int64_t units = (int64_t)ntiles * nchunks;
-  return g_variant == 1 && nchunks >= 2 && units >= 512 && units < 1024;
+  return nchunks >= 2 && units >= 512 && units < 1024;
 }
 
 template <int MT, bool ST, int EPI>
@@ -1592,10 +1585,9 @@ int launch_split_fwd3_e(const SplitFwdArgs& a, int nchunks, hipStream_t st) {
   const int gx = split_upfwd_grid_x(a.ntiles, nchunks);  // one 512-thread workgroup per CU
   const size_t smem = F3Cfg<MT>::SMEM;
   auto kern = conv3d_split_fwd3_kernel<MT, ST, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(512), smem, st, a);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
@@ -1624,10 +1616,10 @@ int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st)
     return SYNTHSR_EINVAL;
   }
   if constexpr (UPM == 0) {
-    if (g_products == 6 && split_uses_fwd3(a.ntiles, nchunks)) return launch_split_fwd3<MT, ST>(a, nchunks, st);
-    if (g_products == 6 && g_variant >= 1) return launch_split_fwd2<MT, ST>(a, gx, nchunks, st);
+    if (t_nprod == 6 && split_uses_fwd3(a.ntiles, nchunks)) return launch_split_fwd3<MT, ST>(a, nchunks, st);
+    if (t_nprod == 6) return launch_split_fwd2<MT, ST>(a, gx, nchunks, st);
   }
-  return g_products == 9 ? launch_split_fwd_np<MT, ST, UPM, 9>(a, gx, nchunks, st) : launch_split_fwd_np<MT, ST, UPM, 6>(a, gx, nchunks, st);
+  return t_nprod == 9 ? launch_split_fwd_np<MT, ST, UPM, 9>(a, gx, nchunks, st) : launch_split_fwd_np<MT, ST, UPM, 6>(a, gx, nchunks, st);
 }
 
 
@@ -2022,10 +2014,9 @@ int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
   const int gx = split_wgrad_grid_x(a.ntiles, gy);
   const size_t smem = (size_t)C::NBUF * C::BUFB;
   auto kern = conv3d_split_wgrad_kernel<COW, NPROD, STK, CIW>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static SynOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
   }
   DetRun det;
   if (syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)
@@ -2039,13 +2030,13 @@ int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
 template <int COW>
 int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
   if constexpr (COW == 24) {
-    if (g_products == 6 && a.ciw == 24) return launch_split_wgrad_np<24, 6, true, 24>(a, st);
-    if (g_products == 6 && (g_wgrad_stack & 1)) return launch_split_wgrad_np<24, 6, true>(a, st);
+    if (t_nprod == 6 && a.ciw == 24) return launch_split_wgrad_np<24, 6, true, 24>(a, st);
+    if (t_nprod == 6) return launch_split_wgrad_np<24, 6, true>(a, st);
   }
   if constexpr (COW == 48) {
-    if (g_products == 6 && a.ciw == 16) return launch_split_wgrad_np<48, 6, false, 16>(a, st);
+    if (t_nprod == 6 && a.ciw == 16) return launch_split_wgrad_np<48, 6, false, 16>(a, st);
   }
-  return g_products == 9 ? launch_split_wgrad_np<COW, 9>(a, st) : launch_split_wgrad_np<COW, 6>(a, st);
+  return t_nprod == 9 ? launch_split_wgrad_np<COW, 9>(a, st) : launch_split_wgrad_np<COW, 6>(a, st);
 }
 
 }  // namespace
@@ -2074,9 +2065,12 @@ extern "C" int synthsr_split_tile_schedule(int kernel, int ntiles, int ny, int b
 extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* in, const float* wp, const float* bias,
                                                                     const float* addend, float* out, const int s[3], int Cin,
                                                                     int Cout, int mt, int nchunks, int act, float* stats,
-                                                                    float* partial, int upm, int stacked, hipStream_t st) {
+                                                                    float* partial, int upm, int stacked, int nprod,
+                                                                    hipStream_t st) {
+  if (nprod != 6 && nprod != 9) return SYNTHSR_EINVAL;
+  t_nprod = nprod;
   if ((Cin % 8) != 0 || (Cout % 4) != 0 || mt < 1 || mt > 3 || nchunks < 1 || (upm != 0 && upm != 2)) return SYNTHSR_EINVAL;
-  if (stacked && (Cout != 24 || mt != 2 || nchunks != 1 || upm != 0 || g_products != 6)) return SYNTHSR_EINVAL;
+  if (stacked && (Cout != 24 || mt != 2 || nchunks != 1 || upm != 0 || t_nprod != 6)) return SYNTHSR_EINVAL;
   if (stats && (!partial || addend || act == 2 || upm)) return SYNTHSR_EINVAL;
   if (upm && (bias || addend || act != 0)) return SYNTHSR_EINVAL;
   const int64_t vox = (int64_t)s[0] * s[1] * s[2];
@@ -2101,7 +2095,7 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
     rc = mt == 1 ? launch_split_fwd<1, true>(a, gx, nchunks, st)
                  : (mt == 2 ? launch_split_fwd<2, true>(a, gx, nchunks, st) : launch_split_fwd<3, true>(a, gx, nchunks, st));
     if (rc != SYNTHSR_OK) return rc;
-    const int gcols = (!stacked && g_products == 6 && split_uses_fwd3(a.ntiles, nchunks)) ? split_upfwd_grid_x(a.ntiles, nchunks) : gx;  // workgroup columns that wrote partials
+    const int gcols = (!stacked && t_nprod == 6 && split_uses_fwd3(a.ntiles, nchunks)) ? split_upfwd_grid_x(a.ntiles, nchunks) : gx;  // workgroup columns that wrote partials
     return synthsr_bn_stats_from_partials(partial, gcols, vox, Cout, stats, (synthsr_stream_t)st);
   }
   if (upm == 2)
@@ -2116,7 +2110,9 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
 // wp = 8 parity sets in the split layout; act 0 / 1, optional bias and addend (indexed like the output)
 extern "C" __attribute__((visibility("hidden"))) int syn_split_upfwd(const float* lo, const float* wp, const float* bias,
                                                                       const float* addend, float* out, const int s[3], int Cin,
-                                                                      int Cout, int mt, int act, hipStream_t st) {
+                                                                      int Cout, int mt, int act, int nprod, hipStream_t st) {
+  if (nprod != 6 && nprod != 9) return SYNTHSR_EINVAL;
+  t_nprod = nprod;
   if ((Cin % 8) != 0 || (Cout % 4) != 0 || mt < 1 || mt > 3 || Cout > 16 * mt || (act != 0 && act != 1)) return SYNTHSR_EINVAL;
   const int64_t vox = (int64_t)s[0] * s[1] * s[2];
   if (vox * Cin * 4 >= (1ll << 31) || 8 * vox * Cout * 4 >= (1ll << 31)) return SYNTHSR_EINVAL;
@@ -2143,7 +2139,9 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_upfwd(const float
 // bias gradient); SYNTHSR_EINVAL = shape not covered, the caller takes the fp32-MFMA path
 extern "C" __attribute__((visibility("hidden"))) int syn_split_wgrad(const float* in, const float* dout, float* dw, float* dbias,
                                                                       const int s[3], int cin_total, int ci_off, int Cin,
-                                                                      int Cout, hipStream_t st) {
+                                                                      int Cout, int nprod, hipStream_t st) {
+  if (nprod != 6 && nprod != 9) return SYNTHSR_EINVAL;
+  t_nprod = nprod;
   if ((Cin % 8) != 0 || (Cout % 24) != 0) return SYNTHSR_EINVAL;
   const int64_t vox = (int64_t)s[0] * s[1] * s[2];
   if (vox * Cin * 4 >= (1ll << 31) || vox * Cout * 4 >= (1ll << 31)) return SYNTHSR_EINVAL;
@@ -2155,11 +2153,11 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_wgrad(const float
   a.D0 = s[0]; a.D1 = s[1]; a.D2 = s[2];
   a.Cin = Cin; a.Cout = Cout; a.cin_total = cin_total; a.ci_off = ci_off;
   // 48-wide workgroups where they divide Cout (measured in round 3: 10 % faster than 2 x 24 padded column chunks)
-  const bool c48 = (Cout % 48) == 0 && !(g_wgrad_stack & 2);
+  const bool c48 = (Cout % 48) == 0;
   // ... with 16 input channels each where those divide Cin (six products; option 12 bit 2 switches it off for A/B runs)
-  a.ciw = (c48 && (Cin % 16) == 0 && g_products == 6 && !(g_wgrad_stack & 4)) ? 16 : 8;
+  a.ciw = (c48 && (Cin % 16) == 0 && t_nprod == 6) ? 16 : 8;
   // the stacked 24-column kernel with all 24 input channels in one workgroup (option 12 bit 3 switches it off for A/B runs)
-  if (!c48 && Cin == 24 && g_products == 6 && (g_wgrad_stack & 1) && !(g_wgrad_stack & 8)) a.ciw = 24;
+  if (!c48 && Cin == 24 && t_nprod == 6) a.ciw = 24;
   a.ncc = Cin / a.ciw;
   a.nco = c48 ? Cout / 48 : Cout / 24;
   a.tiles1 = (s[1] + TY - 1) / TY;

@@ -18,27 +18,42 @@ BN_EPS = 1e-3  # keras.layers.BatchNormalization default epsilon (Keras 2.3.1)
 _prof = None
 
 
+# The context handed to every fp32 conv entry point (include/synthsr_hip.h: synthsr_conv_ctx).  The LIBRARY holds no arithmetic
+# state; this module keeps one default context for the host code that does not pass its own (unet.py, critic.py, the tests),
+# and a counter that moves when it is replaced: packed weights are only valid under the arithmetic they were packed with.
+_ctx = _lib.ConvCtx(arithmetic=1)
+_ctx_epoch = 0
+
+
+def conv_ctx():
+    """ctypes reference to the current default conv context"""
+    return ctypes.byref(_ctx)
+
+
 def set_conv_arithmetic(name):
-    """process-wide (include/synthsr_hip_tuning.h: synthsr_set_conv_arithmetic): 'split' (default) = fp32 convolutions on the
-    bf16 matrix cores through three bf16 pieces per operand and six exact partial products (fp32 accumulation, as accurate as
-    the fp32 matrix instructions: tests/test_split_gpu.py); 'split9' = the same with all nine partial products (every fp32
-    product reproduced exactly, 1.5x the matrix instructions); 'fp32_mfma' = fp32 matrix instructions everywhere.  Networks
-    re-pack their weights at the next `repack()` when the mode changed.  Returns the previous setting."""
+    """replaces this module's default conv context: 'split' (default) = fp32 convolutions on the bf16 matrix cores through three
+    bf16 pieces per operand and six exact partial products (fp32 accumulation, as accurate as the fp32 matrix instructions:
+    tests/test_split_gpu.py); 'split9' = the same with all nine partial products (every fp32 product reproduced exactly, 1.5x
+    the matrix instructions); 'fp32_mfma' = fp32 matrix instructions everywhere.  Networks re-pack their weights at the next
+    `repack()` when the context changed (conv_layout_epoch).  Returns the previous setting."""
+    global _ctx, _ctx_epoch
     if name not in _lib.CONV_ARITHMETICS:
         raise ValueError('conv arithmetic should be one of %s' % (_lib.CONV_ARITHMETICS,))
     prev = conv_arithmetic()
-    _lib.check(_L().synthsr_set_conv_arithmetic(_lib.CONV_ARITHMETICS.index(name)), 'set_conv_arithmetic')
+    if name != prev:
+        _ctx = _lib.ConvCtx(arithmetic=_lib.CONV_ARITHMETICS.index(name))
+        _ctx_epoch += 1
     return prev
 
 
 def conv_arithmetic():
-    return _lib.CONV_ARITHMETICS[int(_L().synthsr_conv_arithmetic())]
+    return _lib.CONV_ARITHMETICS[int(_ctx.arithmetic)]
 
 
 def conv_layout_epoch():
-    """moves whenever the arithmetic or a plan-changing option changed (synthsr_conv3d_layout_epoch): packed weights of an
-    older epoch are stale -- their size or fragment order may belong to another plan"""
-    return int(_L().synthsr_conv3d_layout_epoch())
+    """moves whenever the default conv context was replaced: packed weights of an older epoch are stale -- their size or
+    fragment order may belong to another plan"""
+    return _ctx_epoch
 
 
 def conv_runs_split(kind, shape, cin, cout):
@@ -50,7 +65,7 @@ def conv_runs_split(kind, shape, cin, cout):
         return False
     d0, d1, d2 = [int(v) for v in shape[:3]]
     if kind == 'conv3d_wgrad':   # the dispatcher's own condition (csrc/conv3d.hip: wgrad_takes_split)
-        rc = int(_L().synthsr_conv3d_wgrad_runs_split(_lib.i3((d0, d1, d2)), int(cin), int(cout)))
+        rc = int(_L().synthsr_conv3d_wgrad_runs_split(conv_ctx(), _lib.i3((d0, d1, d2)), int(cin), int(cout)))
         if rc < 0:
             _lib.check(rc, 'conv3d_wgrad_runs_split')
         return rc == 1
@@ -58,7 +73,7 @@ def conv_runs_split(kind, shape, cin, cout):
     # plan kind 0 on (Cout -> Cl)
     plan_kind, ce, co = {'conv3d_up_fwd': (2, cin, cout), 'conv3d_up_dgrad': (0, cout, cin)}.get(kind, (1, cin, cout))
     out = (ctypes.c_int64 * 8)()
-    _lib.check(_L().synthsr_conv3d_plan(_lib.i3((d0, d1, d2)), int(ce), int(co), plan_kind, out), 'conv3d_plan')
+    _lib.check(_L().synthsr_conv3d_plan(conv_ctx(), _lib.i3((d0, d1, d2)), int(ce), int(co), plan_kind, out), 'conv3d_plan')
     return int(out[2]) <= -100
 
 
@@ -192,13 +207,13 @@ def pack_conv_weights(w, shape, mode=0, out=None):
     lib = _L()
     Cin, Cout = int(w.shape[3]), int(w.shape[4])
     s3 = _lib.i3(shape[:3])
-    n = lib.synthsr_conv3d_pack(None, None, s3, Cin, Cout, mode, None)
+    n = lib.synthsr_conv3d_pack(conv_ctx(), None, None, s3, Cin, Cout, mode, None)
     if n < 0:
         _lib.check(int(n), 'conv3d_pack(size)')
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=w.device)
     assert out.numel() == n
-    r = lib.synthsr_conv3d_pack(_lib.ptr(w), _lib.ptr(out), s3, Cin, Cout, mode, _lib.stream())
+    r = lib.synthsr_conv3d_pack(conv_ctx(), _lib.ptr(w), _lib.ptr(out), s3, Cin, Cout, mode, _lib.stream())
     if r < 0:
         _lib.check(int(r), 'conv3d_pack')
     return out
@@ -210,13 +225,13 @@ def pack_conv_weights_ex(w, shape, ci_off, cin, mode=0, up=False, out=None):
     lib = _L()
     cin_total, cout = int(w.shape[3]), int(w.shape[4])
     s3 = _lib.i3(shape[:3])
-    n = lib.synthsr_conv3d_pack_ex(None, None, s3, cin_total, int(ci_off), int(cin), cout, mode, int(up), None)
+    n = lib.synthsr_conv3d_pack_ex(conv_ctx(), None, None, s3, cin_total, int(ci_off), int(cin), cout, mode, int(up), None)
     if n < 0:
         _lib.check(int(n), 'conv3d_pack_ex(size)')
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=w.device)
     assert out.numel() == n
-    r = lib.synthsr_conv3d_pack_ex(_lib.ptr(w), _lib.ptr(out), s3, cin_total, int(ci_off), int(cin), cout, mode,
+    r = lib.synthsr_conv3d_pack_ex(conv_ctx(), _lib.ptr(w), _lib.ptr(out), s3, cin_total, int(ci_off), int(cin), cout, mode,
                                    int(up), _lib.stream())
     if r < 0:
         _lib.check(int(r), 'conv3d_pack_ex')
@@ -239,7 +254,7 @@ def conv3d_up(lo, wpacked8, bias, addend, Cout, act=1, out=None):
     if out is None:
         out = torch.empty((2 * s[0], 2 * s[1], 2 * s[2], Cout), dtype=torch.float32, device=lo.device)
     with _Timed('conv3d_up_fwd', s[:3], s[3], Cout):
-        _lib.check(lib.synthsr_conv3d_up_fwd(_lib.ptr(lo), _lib.ptr(wpacked8), _lib.ptr(bias), _lib.ptr(addend),
+        _lib.check(lib.synthsr_conv3d_up_fwd(conv_ctx(), _lib.ptr(lo), _lib.ptr(wpacked8), _lib.ptr(bias), _lib.ptr(addend),
                                              _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), int(Cout), int(act),
                                              _lib.stream()), 'conv3d_up_fwd')
     return out
@@ -265,7 +280,7 @@ def conv3d_up_dgrad(dout, wpacked8, Cl, out=None):
     if out is None:
         out = torch.empty(lo_shape + (Cl,), dtype=torch.float32, device=dout.device)
     with _Timed('conv3d_up_dgrad', lo_shape, Cl, s[3]):
-        _lib.check(lib.synthsr_conv3d_up_dgrad(_lib.ptr(dout), _lib.ptr(wpacked8), _lib.ptr(out), _lib.i3(lo_shape),
+        _lib.check(lib.synthsr_conv3d_up_dgrad(conv_ctx(), _lib.ptr(dout), _lib.ptr(wpacked8), _lib.ptr(out), _lib.i3(lo_shape),
                                                int(Cl), int(s[3]), _lib.stream()), 'conv3d_up_dgrad')
     return out
 
@@ -302,7 +317,7 @@ def conv3d_wgrad_part(x, dout, dw, ci_off, dbias=None):
                                                           int(dout.shape[3]), _lib.stream()), 'conv3d_bf16_wgrad_part')
         return dw
     with _Timed('conv3d_wgrad', s[:3], s[3], dout.shape[3]):
-        _lib.check(lib.synthsr_conv3d_wgrad_bias(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.ptr(dbias),
+        _lib.check(lib.synthsr_conv3d_wgrad_bias(conv_ctx(), _lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.ptr(dbias),
                                                  _lib.i3(s[:3]), int(dw.shape[3]), int(ci_off), int(s[3]),
                                                  int(dout.shape[3]), _lib.stream()), 'conv3d_wgrad_bias')
     return dw
@@ -317,7 +332,7 @@ def conv3d(x, wpacked, bias, Cout, act=1, out=None):
     if out is None:
         out = torch.empty((s[0], s[1], s[2], Cout), dtype=torch.float32, device=x.device)
     with _Timed('conv3d_fwd' if bias is not None else 'conv3d_dgrad', s[:3], s[3], Cout):
-        _lib.check(lib.synthsr_conv3d_fwd(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out),
+        _lib.check(lib.synthsr_conv3d_fwd(conv_ctx(), _lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out),
                                           _lib.i3(s[:3]), int(s[3]), int(Cout), int(act), _lib.stream()), 'conv3d_fwd')
     return out
 
@@ -331,7 +346,7 @@ def conv3d_stats(x, wpacked, bias, Cout, stats, ws, act=1, out=None):
     if out is None:
         out = torch.empty((s[0], s[1], s[2], Cout), dtype=torch.float32, device=x.device)
     with _Timed('conv3d_fwd', s[:3], s[3], Cout):
-        _lib.check(lib.synthsr_conv3d_fwd_stats(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out),
+        _lib.check(lib.synthsr_conv3d_fwd_stats(conv_ctx(), _lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(out),
                                                 _lib.i3(s[:3]), int(s[3]), int(Cout), int(act), _lib.ptr(stats),
                                                 _lib.ptr(ws), _lib.stream()), 'conv3d_fwd_stats')
     return out
@@ -349,7 +364,7 @@ def conv3d_add(x, wpacked, bias, addend, Cout, act=1, out=None):
     if out is None:
         out = torch.empty((s[0], s[1], s[2], Cout), dtype=torch.float32, device=x.device)
     with _Timed('conv3d_dgrad' if act == 2 else 'conv3d_fwd', s[:3], s[3], Cout):
-        _lib.check(lib.synthsr_conv3d_fwd_add(_lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(addend),
+        _lib.check(lib.synthsr_conv3d_fwd_add(conv_ctx(), _lib.ptr(x), _lib.ptr(wpacked), _lib.ptr(bias), _lib.ptr(addend),
                                               _lib.ptr(out), _lib.i3(s[:3]), int(s[3]), int(Cout), int(act),
                                               _lib.stream()), 'conv3d_fwd_add')
     return out
@@ -792,7 +807,7 @@ def conv3d_stride2(x, wpacked8, Cout, out=None):
     lo_shape = (s[0] // 2, s[1] // 2, s[2] // 2)
     if out is None:
         out = torch.empty(lo_shape + (Cout,), dtype=torch.float32, device=x.device)
-    _lib.check(lib.synthsr_conv3d_up_dgrad(_lib.ptr(x), _lib.ptr(wpacked8), _lib.ptr(out), _lib.i3(lo_shape), int(Cout),
+    _lib.check(lib.synthsr_conv3d_up_dgrad(conv_ctx(), _lib.ptr(x), _lib.ptr(wpacked8), _lib.ptr(out), _lib.i3(lo_shape), int(Cout),
                                            int(s[3]), _lib.stream()), 'conv3d_stride2')
     return out
 
@@ -803,7 +818,7 @@ def conv3d_stride2_dgrad(dy, wpacked8d, Cin, out=None):
     s = dy.shape
     if out is None:
         out = torch.empty((2 * s[0], 2 * s[1], 2 * s[2], Cin), dtype=torch.float32, device=dy.device)
-    _lib.check(lib.synthsr_conv3d_up_fwd(_lib.ptr(dy), _lib.ptr(wpacked8d), None, None, _lib.ptr(out), _lib.i3(s[:3]),
+    _lib.check(lib.synthsr_conv3d_up_fwd(conv_ctx(), _lib.ptr(dy), _lib.ptr(wpacked8d), None, None, _lib.ptr(out), _lib.i3(s[:3]),
                                          int(s[3]), int(Cin), 0, _lib.stream()), 'conv3d_stride2_dgrad')
     return out
 

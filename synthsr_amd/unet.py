@@ -224,7 +224,7 @@ class UNet3D:
 
         def plan(shape, cin_e, cout_e, plain):
             out = (ctypes.c_int64 * 8)()
-            _lib.check(lib.synthsr_conv3d_plan(_lib.i3(shape), cin_e, cout_e, int(plain), out), 'conv3d_plan')
+            _lib.check(lib.synthsr_conv3d_plan(ops.conv_ctx(), _lib.i3(shape), cin_e, cout_e, int(plain), out), 'conv3d_plan')
             return [int(v) for v in out]
 
         def add(c, key, shape, ci_off, cin, mode, up):

@@ -303,7 +303,7 @@ def single_shot_parity(run, oracle, compare, max_flips=8, loss_of=lambda net: ne
        two predictions, at most 8 voxels), the oracle re-run on the device's side.
     2. run() once more on the default path (float atomics) and compare it WITH THE DETERMINISTIC RUN only: the arg-max masks of
        both device runs window by window (`_pool_choices`) -- differing windows must hold two candidates within 4 ulp of each
-       other, at most `max_flips` of them --, the loss kinks the same way (predictions within 4 ulp), the loss to 2e-6, and with
+       other, at most `max_flips` of them --, the loss kinks the same way (predictions within 64 ulp), the loss to 2e-6, and with
        identical choices every gradient within GRAD_K * o + GRAD_FLOOR of the deterministic one (accumulation-order noise is one
        more fp32 evaluation of the graph).
     Returns (net of the atomics run, number of windows flipped between the two device runs)."""
@@ -395,7 +395,9 @@ def single_shot_parity(run, oracle, compare, max_flips=8, loss_of=lambda net: ne
         assert a_pr is not None and det_kink[0] is not None, 'the loss derivative of the two device runs differs grossly at %d ' \
             'voxels and the runs kept no prediction' % kidx.numel()
         worst = float(((a_pr[kidx] - det_kink[0][kidx]).abs() / _ulp_of(det_kink[0], kidx)).max())
-        assert kidx.numel() <= max_flips and worst <= 4.0, '%d voxels changed the side of a loss kink between the deterministic ' \
+        # (64 ulp as against the oracle: the soak run measured up to 18 ulp between the two device runs' predictions at such a voxel
+        # -- accumulation-order noise of the BatchNorm statistics over a few hundred values, profiles/r05_soak_atomics.txt)
+        assert kidx.numel() <= max_flips and worst <= 64.0, '%d voxels changed the side of a loss kink between the deterministic ' \
             'and the atomics run, predictions up to %.1f ulp apart: not a rounding tie' % (kidx.numel(), worst)
         print('single_shot_parity: %d identified loss-kink flip(s) on the atomics path (predictions %.1f ulp apart)' % (kidx.numel(), worst))
         flips += int(kidx.numel())

@@ -142,8 +142,11 @@ def test_c_abi_exports_every_declared_symbol():
     import glob
     hdr = ''.join(open(h).read() for h in sorted(glob.glob(os.path.join(REPO, 'include', '*.h'))))
     declared = set(re.findall(r'\b(synthsr_[a-z0-9_]+)\s*\(', hdr))
-    # the stateless boundary header must not declare the process-wide tuning switch (synthsr_hip_tuning.h does)
-    assert 'synthsr_conv3d_set_option(' not in open(os.path.join(REPO, 'include', 'synthsr_hip.h')).read()
+    # the process-wide option switch / arithmetic setter / layout epoch of rounds 1-4 are gone from the ABI
+    for gone in ('synthsr_conv3d_set_option', 'synthsr_set_conv_arithmetic', 'synthsr_conv_arithmetic', 'synthsr_conv3d_layout_epoch'):
+        assert gone not in declared
+        with pytest.raises(AttributeError):
+            getattr(ctypes.CDLL(_lib.LIB_PATH), gone)
     assert len(declared) >= 25
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
@@ -152,24 +155,59 @@ def test_c_abi_exports_every_declared_symbol():
     lib.synthsr_abi_version.restype = ctypes.c_int
     assert lib.synthsr_abi_version() == 1
     # argument validation happens before any HIP call: usable without a GPU
-    _lib.load()
+    lib = _lib.load()
     big = _lib.i3([160, 160, 160])
-    # packed sizes (query mode).  split arithmetic (the default): 3 pieces x [co-chunk][8-channel chunk][7 K steps][co tiles]
-    # fragments of 64 lanes x 8 bf16 (= 4 floats)
-    assert _lib.load().synthsr_conv_arithmetic() == 1
-    # (Cout = 24, round 4: the three pieces stacked along M -- [8-channel chunk][7 K steps][5 row tiles] fragments instead of 3 x 2)
-    assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 3 * 7 * 5 * 64 * 4
-    assert _lib.load().synthsr_conv3d_set_option(10, 0) == 0
-    assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 3 * 3 * 7 * 2 * 64 * 4
-    assert _lib.load().synthsr_conv3d_set_option(10, 1) == 0
-    assert _lib.load().synthsr_conv3d_pack(None, None, _lib.i3([80, 80, 80]), 48, 48, 0, None) == 3 * 6 * 7 * 3 * 64 * 4
-    assert _lib.load().synthsr_set_conv_arithmetic(3) == -1
-    assert _lib.load().synthsr_set_conv_arithmetic(0) == 0
+    # packed sizes (query mode).  NULL context = split arithmetic (the default): 3 pieces x [co-chunk][8-channel chunk][7 K steps]
+    # [co tiles] fragments of 64 lanes x 8 bf16 (= 4 floats); Cout = 24: the three pieces stacked along M -- [8-channel chunk][7 K
+    # steps][5 row tiles] fragments instead of 3 x 2
+    assert lib.synthsr_conv3d_pack(None, None, None, big, 24, 24, 0, None) == 3 * 7 * 5 * 64 * 4
+    assert lib.synthsr_conv3d_pack(None, None, None, _lib.i3([80, 80, 80]), 48, 48, 0, None) == 3 * 6 * 7 * 3 * 64 * 4
+    assert lib.synthsr_conv3d_pack(None, None, None, big, 0, 24, 0, None) == -1
+    bad = _lib.ConvCtx(arithmetic=3)
+    assert lib.synthsr_conv3d_pack(ctypes.byref(bad), None, None, big, 24, 24, 0, None) == -1
+
+
+def test_two_conv_contexts_with_different_arithmetic_coexist():
+    """include/synthsr_hip.h: the arithmetic of the fp32 convolutions is a field of the caller's synthsr_conv_ctx, not state of the
+    library.  Two contexts used alternately -- and from two threads at once -- each keep their own plans and
+    packed-weight sizes; NULL means split.  Host-only entry points: no GPU needed."""
+    import threading
+    from synthsr_amd import _lib
+    lib = _lib.load()
+    split, split9, mfma = (_lib.ConvCtx(arithmetic=a) for a in (1, 2, 0))
+    big, mid = _lib.i3([160, 160, 160]), _lib.i3([80, 80, 80])
+
+    def sizes(ctx):
+        c = None if ctx is None else ctypes.byref(ctx)
+        out = (ctypes.c_int64 * 8)()
+        assert lib.synthsr_conv3d_plan(c, big, 24, 24, 1, out) == 0
+        return (int(lib.synthsr_conv3d_pack(c, None, None, big, 24, 24, 0, None)),
+                int(lib.synthsr_conv3d_pack(c, None, None, mid, 48, 48, 0, None)), int(out[2]) <= -100,
+                int(lib.synthsr_conv3d_wgrad_runs_split(c, mid, 48, 48)))
+    want_split = (3 * 7 * 5 * 64 * 4, 3 * 6 * 7 * 3 * 64 * 4, True, 1)
     # fp32 MFMA: Cout = 24 uses the unpadded 4x4x1-MFMA layout, 48 -> 48 the 16x16x4 B-fragment layout
-    assert _lib.load().synthsr_conv3d_pack(None, None, big, 24, 24, 0, None) == 27 * 24 * 24
-    assert _lib.load().synthsr_conv3d_pack(None, None, _lib.i3([80, 80, 80]), 48, 48, 0, None) == 2 * 27 * 3 * 3 * 128
-    assert _lib.load().synthsr_conv3d_pack(None, None, big, 0, 24, 0, None) == -1
-    assert _lib.load().synthsr_set_conv_arithmetic(1) == 0   # process-wide: back to the default for the tests that follow
+    want_mfma = (27 * 24 * 24, 2 * 27 * 3 * 3 * 128, False, 0)
+    for _ in range(3):     # interleaved: no call leaves anything behind for the next one
+        assert sizes(split) == want_split
+        assert sizes(mfma) == want_mfma
+        assert sizes(None) == want_split
+        assert sizes(split9)[2:] == want_split[2:]      # same kernels and plans, nine products
+    errors = []
+
+    def worker(ctx, want):
+        try:
+            for _ in range(2000):
+                if sizes(ctx) != want:
+                    errors.append((ctx.arithmetic, sizes(ctx)))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=a) for a in ((split, want_split), (mfma, want_mfma), (split, want_split), (mfma, want_mfma))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
 
 
 def test_split_tile_schedule_visits_every_tile_once_and_evenly():
@@ -262,13 +300,10 @@ def _repo_root():
     return os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_layout_epoch_and_option_hook(monkeypatch):
-    """the layout epoch moves when (and only when) the arithmetic or a plan-changing option takes effect -- what UNet3D / Critic3D
-    re-pack on; SYNTHSR_CONV_OPTIONS applies options when the library is loaded (A/B runs of the profiling tools) and refuses
-    unknown ones (no GPU needed: host-side state of the library)"""
-    import subprocess
-    import sys
-    from synthsr_amd import _lib, ops
+def test_layout_epoch_follows_the_default_context():
+    """synthsr_amd.ops keeps ONE default conv context for the host code that passes none; conv_layout_epoch moves when (and only
+    when) that context is replaced -- what UNet3D / Critic3D re-pack on.  The library itself has no such state."""
+    from synthsr_amd import ops
     e0 = ops.conv_layout_epoch()
     first = ops.conv_arithmetic()
     ops.set_conv_arithmetic(first)
@@ -276,23 +311,10 @@ def test_layout_epoch_and_option_hook(monkeypatch):
     other = 'fp32_mfma' if first != 'fp32_mfma' else 'split'
     ops.set_conv_arithmetic(other)
     e1 = ops.conv_layout_epoch()
-    assert e1 != e0
+    assert e1 != e0 and ops.conv_arithmetic() == other
     ops.set_conv_arithmetic(first)
-    assert ops.conv_layout_epoch() != e1
-    e2 = ops.conv_layout_epoch()
-    assert _lib.load().synthsr_conv3d_set_option(12, 1) == 0  # the weight gradient reads no packed weights: no new epoch
-    assert ops.conv_layout_epoch() == e2
-    assert _lib.load().synthsr_conv3d_set_option(10, 1) == 0  # the stacked 24-channel layout does
-    assert ops.conv_layout_epoch() != e2
-    assert _lib.load().synthsr_conv3d_set_option(99, 1) == -1
-    code = ('import os, sys; sys.path.insert(0, %r); from synthsr_amd import _lib; lib = _lib.load(); '
-            'print(lib.synthsr_conv3d_pack(None, None, _lib.i3([160, 160, 160]), 24, 24, 0, None))' % _repo_root())
-    env = dict(os.environ, SYNTHSR_CONV_OPTIONS='10=0,12=9')
-    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0 and int(out.stdout.split()[-1]) == 3 * 3 * 7 * 2 * 64 * 4, out.stderr[-500:]   # not stacked
-    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, SYNTHSR_CONV_OPTIONS='99=1'), capture_output=True,
-                         text=True, timeout=120)
-    assert out.returncode != 0 and 'SYNTHSR_CONV_OPTIONS' in out.stderr
+    assert ops.conv_layout_epoch() != e1 and ops.conv_arithmetic() == first
+    assert not any(k.startswith('SYNTHSR_CONV') for k in open(os.path.join(_repo_root(), 'synthsr_amd', '_lib.py')).read().split("'"))
 
 
 def test_refused_segmentation_loss_configurations_break_the_reference_graph_too():

@@ -9,9 +9,10 @@ time, the atomics run differs by its accumulation order) and N steps with a diff
   atm/f32   atomics device run vs the fp32 oracle                atm/f64   ... vs float64
   atm-det   atomics run vs deterministic run                     o32/f64   the fp32 oracle itself vs float64
 
-Variants: the default options; option 12=9 (8 instead of all 24 input channels per stacked 24-column workgroup: the round-4
-23:43 kernel); option 11=256 (layers below 256 tiles take the fp32-MFMA weight gradient: the round-3 rule); fp32_mfma
-arithmetic everywhere.  Max-pool rounding ties between device and oracle are aligned as in tests/conftest.py.
+Variants: split (default) and fp32_mfma arithmetic.  (The run recorded in profiles/r05_batch_test_error_distribution.txt, made
+before the process-wide option switch was removed, also covers option 12=9 -- 8 instead of all 24 input channels per stacked
+24-column workgroup, the round-4 23:43 kernel -- and option 11=256 -- layers below 256 tiles on the fp32-MFMA weight gradient,
+the round-3 rule.)  Max-pool rounding ties between device and oracle are aligned as in tests/conftest.py.
 
     python tools/batch_test_errors.py [N] > profiles/r05_batch_test_error_distribution.txt
 """
@@ -92,17 +93,14 @@ def step_errors(B, feats, levels, shape, cin, fold, seed, focus):
 
 def main():
     from synthsr_amd import _lib, ops
-    lib = _lib.load()
+    _lib.load()
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     focus = 'unet_conv_downarm_0_1/kernel'
     case = dict(B=2, feats=24, levels=3, shape=(16, 16, 32), cin=2, fold=True)
-    variants = [('default', [], 'split'), ('option 12=9 (CIW 8)', [(12, 9)], 'split'), ('option 11=256 (fp32-MFMA wgrad < 256 tiles)', [(11, 256)], 'split'),
-                ('fp32_mfma arithmetic', [], 'fp32_mfma')]
+    variants = [('default', [], 'split'), ('fp32_mfma arithmetic', [], 'fp32_mfma')]
     print('# %s, N = %d; columns: det/f32 det/f64 atm/f32 atm/f64 atm-det o32/f64 | worst tensor: same six | pool ties (f32, f64 '
           'oracle), det->atm flips' % (case, N))
     for name, opts, arith in variants:
-        for k, v in opts:
-            assert lib.synthsr_conv3d_set_option(k, v) == 0
         ops.set_conv_arithmetic(arith)
         print('\n## %s' % name)
         for label, seeds in (('test seed 11, repeated', [11] * N), ('input seeds 100..', list(range(100, 100 + N)))):
@@ -119,8 +117,6 @@ def main():
             print('# every tensor of the last step (det/f32 det/f64 atm/f32 atm/f64 atm-det o32/f64):')
             for nm, r in rows.items():
                 print('  %-36s ' % nm + ' '.join('%.2e' % v for v in r))
-        for k, _ in opts:   # back to the defaults
-            lib.synthsr_conv3d_set_option(k, {12: 1, 11: 1}[k])
     ops.set_conv_arithmetic('split')
 
 

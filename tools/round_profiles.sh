@@ -27,9 +27,6 @@ python tools/hyperfine_bench.py --dtype f32 --steps 20 --warmup 3 > $O/f32_hf_be
 python tools/adversarial_bench.py --dtype bf16 --steps 10 > $O/adversarial_bf16.json 2> $O/adversarial_bf16.err
 python tools/adversarial_bench.py --dtype f32 --steps 5 > $O/adversarial_f32.json 2> $O/adversarial_f32.err
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-arith-compare --layer-table $O/layer_table.txt > $O/bench_layer_table.json 2> $O/bench_layer_table.err
-python tools/split_ab.py --variants 0,1 --reps 20 > $O/split_fwd_variants.txt 2>&1
-python tools/split_ab.py --variants 11,1 --only 160_24_24,80_48_24 --reps 30 > $O/split_stacked24_ab.txt 2>&1
-./tools/ubench/mfma_mix > $O/mfma_mix.txt 2>&1
 python tools/conv_bf16_bench.py 160 > $O/conv_bf16_bench.txt 2>&1
 python tools/split_check.py --acc --time > $O/split_check.txt 2>&1
 python tools/predict_bench.py 160 > $O/predict_bench.txt 2>&1

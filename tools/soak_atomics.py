@@ -10,7 +10,7 @@ parity-split kernels (option 7 = 0), while every forward tensor agrees with the 
 within float32 rounding of its target, and sign(pred - target) of the L1 loss -- d(loss)/d(pred) = +-1/N -- takes either side.
 The tool now identifies such runs from d(loss)/d(pred) (tests/conftest.py: "kinks of the loss") and reports them separately.
 
-    python tools/soak_atomics.py [N] [option=value ...]      e.g.  python tools/soak_atomics.py 300 11=256
+    python tools/soak_atomics.py [N] [arithmetic]      e.g.  python tools/soak_atomics.py 300 fp32_mfma
 """
 import os
 import sys
@@ -66,12 +66,11 @@ def snapshot(net):
 def main():
     from synthsr_amd import _lib, ops
     from conftest import _pool_choices, _kink_state, _kink_disagreements, _ulp_of
-    lib = _lib.load()
+    _lib.load()
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    for item in sys.argv[2:]:
-        k, v = item.split('=')
-        assert lib.synthsr_conv3d_set_option(int(k), int(v)) == 0
-    print('# N = %d per configuration, options %s' % (N, sys.argv[2:] or 'default'))
+    if len(sys.argv) > 2:   # (the bisect runs of round 5 passed option=value pairs of the former synthsr_conv3d_set_option here)
+        ops.set_conv_arithmetic(sys.argv[2])
+    print('# N = %d per configuration, arithmetic %s' % (N, ops.conv_arithmetic()))
     cases = [(2, 24, 3, (16, 16, 32), 2, True), (2, 24, 3, (16, 16, 32), 2, False), (2, 24, 4, (32, 16, 16), 2, True),
              (1, 24, 5, (32, 32, 32), 2, True)]
     for case in cases[:int(os.environ.get('SOAK_CASES', len(cases)))]:
