@@ -401,6 +401,12 @@ int synthsr_scale_channels(const float* x, float* out, int64_t nvox, int C, cons
 int synthsr_elu_bwd_drop(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
                          const float* stats, const float* gamma, float eps, const float* sums, const float* dpred,
                          const float* whead, const float* drop, int64_t nvox_per_sample, synthsr_stream_t stream);
+/* (their bf16 twins: activations / activation gradients bfloat16, scale / statistics / sums / dpred / whead / dbias float32) */
+int synthsr_scale_channels_bf16(const void* x, void* out, int64_t nvox, int C, const float* scale, int64_t nvox_per_sample,
+                                synthsr_stream_t stream);
+int synthsr_elu_bwd_drop_bf16(const void* dy, const void* dy2, const void* y, void* dz, float* dbias, int64_t nvox, int C,
+                              const float* stats, const float* gamma, float eps, const float* sums, const float* dpred,
+                              const float* whead, const float* drop, int64_t nvox_per_sample, synthsr_stream_t stream);
 
 /* BatchNormalization(axis=-1), training mode (models.py:351,477; Keras 2.3.1 semantics, eps=1e-3):
  * stats[0..C) = mean, stats[C..2C) = biased variance over the nvox voxels */

@@ -114,6 +114,14 @@ def _drop_factor(s, t):
     return s.reshape(s.shape[0], 1, 1, 1, s.shape[1]) if s.dim() == 2 else s
 
 
+def _dropped(t, s, q):
+    """the dropped-out tensor s * t.  One mask per SAMPLE (s [B, C], batchsize > 1): the bf16 network stores that tensor (the
+    factor cannot ride on weights shared by the batch), so its storage rounding `q` applies; a per-feature s [C] is folded into
+    the next layer's weights there and never stored"""
+    f = _drop_factor(s, t)
+    return q(t * f) if f.dim() > 1 else t * f
+
+
 def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, collect=None, softmax=False, quant=None,
                  dropout=None, pool_inputs=None, pool_nudge=None):
     """P: dict name -> tensor with the Keras layer names (`<prefix>_conv_downarm_l_k/kernel`, ...).
@@ -153,7 +161,7 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
         for k in range(nconv):
             nm = '%s_conv_downarm_%d_%d' % (prefix, l, k)
             pre = q(F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias'])))
-            cur = pre * _drop_factor(dropout[nm], pre) if dropout is not None else pre
+            cur = _dropped(pre, dropout[nm], q) if dropout is not None else pre
         skips.append(pre)  # pre-BN (and pre-dropout) skip: the conv layer's output (models.py:431-432)
         cur = bn(cur, '%s_bn_down_%d' % (prefix, l))
         if l < L - 1:
@@ -169,7 +177,7 @@ def unet_forward(x, P, prefix, nb_levels, nconv, training=True, moving=None, col
             nm = '%s_conv_uparm_%d_%d' % (prefix, L + k, j)
             cur = q(F.elu(conv3d_same(cur, P[nm + '/kernel'], P[nm + '/bias'])))
             if dropout is not None:
-                cur = cur * _drop_factor(dropout[nm], cur)
+                cur = _dropped(cur, dropout[nm], q)
         cur = bn(cur, '%s_bn_up_%d' % (prefix, k))
     w, b = P['%s_likelihood/kernel' % prefix], P['%s_likelihood/bias' % prefix]
     out = cur @ w.reshape(w.shape[-2], w.shape[-1]) + b

@@ -108,6 +108,8 @@ SIGNATURES = {
     'synthsr_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _S]),
     'synthsr_scale_channels': (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _S]),
     'synthsr_elu_bwd_drop': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _P, _P, _P, c_int64, _S]),
+    'synthsr_scale_channels_bf16': (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _S]),
+    'synthsr_elu_bwd_drop_bf16': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _P, _P, _P, c_int64, _S]),
     'synthsr_bn_elu_bwd': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, _P, _S]),
     'synthsr_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P, _S]),
     'synthsr_bn_apply': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, c_float, _S]),

@@ -188,7 +188,8 @@ __global__ __launch_bounds__(RB) void elu_bwd_kernel(const T* __restrict__ dy, c
 
 // out[v][c] = x[v][c] * scale[sample(v)][c]: the dropped-out tensor of a batch with one feature mask per sample (and the same
 // factor on a gradient); in place allowed
-__global__ __launch_bounds__(256) void scale_channels_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n4,
+template <typename T>
+__global__ __launch_bounds__(256) void scale_channels_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t n4,
                                                              int C4, const float* __restrict__ scale, int64_t n4ps) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 a = ld4(x + i * 4);
@@ -1334,6 +1335,22 @@ int head_bwd_t(const float* dpred, const T* x, int64_t nvox, int C, const float*
   return SYNTHSR_OK;
 }
 
+template <typename T>
+static int elu_bwd_drop_t(const T* dy, const T* dy2, const T* y, T* dz, float* dbias, int64_t nvox, int C, const float* stats,
+                          const float* gamma, float eps, const float* sums, const float* dpred, const float* whead,
+                          const float* drop, int64_t nvox_per_sample, synthsr_stream_t stream) {
+  const bool bn = stats || gamma || sums, head = dpred || whead;
+  if (!y || !dz || !drop || nvox < 1 || !ok_c4(C) || nvox_per_sample < 1 || (nvox % nvox_per_sample) != 0 ||
+      (bn && (!stats || !gamma || !sums)) || (head && (!dpred || !whead || !bn || dy || dy2)) || (!head && !dy))
+    return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(elu_bwd_kernel<T>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), C * sizeof(float), (hipStream_t)stream,
+                     dy, dy2, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps, bn ? (float)(1.0 / (double)nvox) : 0.f, dpred,
+                     whead, drop, nvox_per_sample * (C / 4));
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+
 extern "C" {
 
 int synthsr_elu_bwd(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C, synthsr_stream_t stream) {
@@ -1361,8 +1378,17 @@ int synthsr_scale_channels(const float* x, float* out, int64_t nvox, int C, cons
                            synthsr_stream_t stream) {
   if (!x || !out || !scale || nvox < 1 || !ok_c4(C) || nvox_per_sample < 1 || (nvox % nvox_per_sample) != 0) return SYNTHSR_EINVAL;
   const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(scale_channels_kernel, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n4, C / 4, scale,
-                     nvox_per_sample * (C / 4));
+  hipLaunchKernelGGL(scale_channels_kernel<float>, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n4, C / 4,
+                     scale, nvox_per_sample * (C / 4));
+  SYN_CHECK_LAUNCH();
+  return SYNTHSR_OK;
+}
+int synthsr_scale_channels_bf16(const void* x, void* out, int64_t nvox, int C, const float* scale, int64_t nvox_per_sample,
+                                synthsr_stream_t stream) {
+  if (!x || !out || !scale || nvox < 1 || !ok_c4(C) || nvox_per_sample < 1 || (nvox % nvox_per_sample) != 0) return SYNTHSR_EINVAL;
+  const int64_t n4 = nvox * (C / 4);
+  hipLaunchKernelGGL(scale_channels_kernel<bf16_t>, dim3(syn_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)out, n4, C / 4, scale, nvox_per_sample * (C / 4));
   SYN_CHECK_LAUNCH();
   return SYNTHSR_OK;
 }
@@ -1370,16 +1396,13 @@ int synthsr_scale_channels(const float* x, float* out, int64_t nvox, int C, cons
 int synthsr_elu_bwd_drop(const float* dy, const float* dy2, const float* y, float* dz, float* dbias, int64_t nvox, int C,
                          const float* stats, const float* gamma, float eps, const float* sums, const float* dpred,
                          const float* whead, const float* drop, int64_t nvox_per_sample, synthsr_stream_t stream) {
-  const bool bn = stats || gamma || sums, head = dpred || whead;
-  if (!y || !dz || !drop || nvox < 1 || !ok_c4(C) || nvox_per_sample < 1 || (nvox % nvox_per_sample) != 0 ||
-      (bn && (!stats || !gamma || !sums)) || (head && (!dpred || !whead || !bn || dy || dy2)) || (!head && !dy))
-    return SYNTHSR_EINVAL;
-  const int64_t n4 = nvox * (C / 4);
-  hipLaunchKernelGGL(elu_bwd_kernel<float>, dim3(syn_grid(n4, RB, red_grid())), dim3(RB), C * sizeof(float), (hipStream_t)stream,
-                     dy, dy2, y, dz, dbias, n4, C / 4, stats, gamma, sums, eps, bn ? (float)(1.0 / (double)nvox) : 0.f, dpred,
-                     whead, drop, nvox_per_sample * (C / 4));
-  SYN_CHECK_LAUNCH();
-  return SYNTHSR_OK;
+  return elu_bwd_drop_t<float>(dy, dy2, y, dz, dbias, nvox, C, stats, gamma, eps, sums, dpred, whead, drop, nvox_per_sample, stream);
+}
+int synthsr_elu_bwd_drop_bf16(const void* dy, const void* dy2, const void* y, void* dz, float* dbias, int64_t nvox, int C,
+                              const float* stats, const float* gamma, float eps, const float* sums, const float* dpred,
+                              const float* whead, const float* drop, int64_t nvox_per_sample, synthsr_stream_t stream) {
+  return elu_bwd_drop_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (bf16_t*)dz, dbias, nvox, C, stats, gamma,
+                                eps, sums, dpred, whead, drop, nvox_per_sample, stream);
 }
 
 int synthsr_bn_stats(const float* x, int64_t nvox, int C, float* stats, double* ws, synthsr_stream_t stream) {

@@ -391,16 +391,16 @@ def elu_bwd(dy, y, dy2=None, dbias=None, out=None):
 def scale_channels(x, scale, out=None):
     """out[b, ..., c] = x[b, ..., c] * scale[b, c]: the dropped-out tensor of a batch with one feature mask per sample
     (KL.Dropout(noise_shape=[None, 1, 1, 1, C]), ext/neuron/models.py:320-324); x: the B volumes stacked along the first
-    axis ([B * d0, d1, d2, C], fp32); in place allowed"""
-    lib = _L()
+    axis ([B * d0, d1, d2, C], fp32 or bf16; scale float32); in place allowed"""
     C = int(x.shape[-1])
     B = int(scale.shape[0])
-    if x.dtype != torch.float32 or tuple(scale.shape) != (B, C) or (x.numel() // C) % B:
-        raise ValueError('scale_channels: x fp32, B volumes stacked along the first axis, and scale [B, C]')
+    if x.dtype not in (torch.float32, torch.bfloat16) or scale.dtype != torch.float32 or tuple(scale.shape) != (B, C) or \
+            (x.numel() // C) % B:
+        raise ValueError('scale_channels: B volumes stacked along the first axis, and a float32 scale [B, C]')
     if out is None:
         out = torch.empty_like(x)
     nvox = x.numel() // C
-    _lib.check(lib.synthsr_scale_channels(_lib.ptr(x), _lib.ptr(out), nvox, C, _lib.ptr(scale), nvox // B, _lib.stream()),
+    _lib.check(_sym('synthsr_scale_channels', x)(_lib.ptr(x), _lib.ptr(out), nvox, C, _lib.ptr(scale), nvox // B, _lib.stream()),
                'scale_channels')
     return out
 
@@ -408,17 +408,14 @@ def scale_channels(x, scale, out=None):
 def elu_bwd_drop(dy, y, drop, dy2=None, dbias=None, out=None, bn=None, head=None, eps=BN_EPS):
     """ELU backward of a conv output y ([B * d0, d1, d2, C]) whose consumer read drop[b, c] * y (see synthsr_elu_bwd_drop);
     bn = (stats, gamma, sums) when that consumer is a BatchNorm, head = (dpred, whead) for the rank-1 gradient of the head"""
-    lib = _L()
     C = int(y.shape[-1])
     B = int(drop.shape[0])
-    if y.dtype != torch.float32:
-        raise ValueError('elu_bwd_drop: fp32 activations only')
     if out is None:
         out = torch.empty_like(y)
     stats, gamma, sums = bn if bn is not None else (None, None, None)
     dpred, whead = head if head is not None else (None, None)
     nvox = y.numel() // C
-    _lib.check(lib.synthsr_elu_bwd_drop(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(out), _lib.ptr(dbias), nvox, C,
+    _lib.check(_sym('synthsr_elu_bwd_drop', y)(_lib.ptr(dy), _lib.ptr(dy2), _lib.ptr(y), _lib.ptr(out), _lib.ptr(dbias), nvox, C,
                                         _lib.ptr(stats), _lib.ptr(gamma), eps, _lib.ptr(sums), _lib.ptr(dpred), _lib.ptr(whead),
                                         _lib.ptr(drop), nvox // B, _lib.stream()), 'elu_bwd_drop')
     return out

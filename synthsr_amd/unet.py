@@ -510,8 +510,6 @@ class UNet3D:
         dropping = self.training and self.conv_dropout > 0
         per_sample = dropping and self.batch > 1
         if per_sample:
-            if self.bf16:
-                raise NotImplementedError('conv_dropout > 0 with batchsize > 1 needs float32 activations (dtype="f32")')
             self._start_dropout_batch()
             dropping = False    # no factors folded into the kernels / BatchNorm slots: the dropped-out tensors exist
             self.saved['encd'], self.saved['decd'] = [], []

@@ -246,6 +246,71 @@ def test_unet_bf16_step_vs_oracle(T, feats, levels, shape, cin, fold):
     assert torch.isfinite(out).all() and list(out.shape) == list(shape) + [1] and out.dtype == torch.float32
 
 
+@pytest.mark.parametrize('fold', [False, True])
+@pytest.mark.parametrize('B,feats,levels,shape,cin', [(2, 24, 3, (16, 16, 32), 2), (3, 8, 2, (8, 12, 16), 1)])
+def test_unet_bf16_per_sample_dropout_vs_oracle(T, B, feats, levels, shape, cin, fold):
+    """batchsize > 1 with conv_dropout in bf16 (BASELINE.json configs[4]: `mixed bf16` fine-tuning takes batchsize / dropout like
+    training()): one feature mask per SAMPLE (ext/neuron/models.py:320-324), the dropped-out tensors materialised in bf16
+    (synthsr_scale_channels_bf16), the ELU backward with the per-sample factor (synthsr_elu_bwd_drop_bf16).  Against the oracle
+    with the same [B, C] factors: (a) plain fp32 -- stated bf16 tolerances; (b) with the bf16 storage roundings restated -- tight."""
+    torch = T
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    rate = .3
+    net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1, feat_mult=2,
+               nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3, dtype='bf16',
+               fold_upsample=fold, conv_dropout=rate)
+    g = torch.Generator().manual_seed(11)
+    for nm, v in net.named_parameters():
+        if nm.endswith('/gamma'):
+            v.copy_(torch.rand(v.shape, generator=g) + .5)
+        elif nm.endswith('/beta') or nm.endswith('/bias'):
+            v.copy_(torch.randn(v.shape, generator=g) * .1)
+    net.repack()
+    net.set_batch(B)
+    x = torch.rand(B, *shape, cin, generator=g)
+    x[1] *= 1.7
+    target = torch.rand(B, *shape, 1, generator=g)
+    rng = np.random.default_rng(5)
+    sc = {}
+    for c in net.all_convs():
+        keep = rng.random((B, c['cout'])) >= rate
+        for b in range(B):  # every layer drops a feature of every sample, and not the same one
+            keep[b, (3 * b + 1) % c['cout']] = False
+            keep[b, (3 * b + 2) % c['cout']] = True
+        sc[c['name']] = (keep / (1.0 - rate)).astype(np.float32)
+    net.set_dropout_scales(sc)
+    loss, pred = net.loss_l1(x.reshape(B * shape[0], shape[1], shape[2], cin).cuda(), target.reshape(-1).cuda(), want_pred=True)
+    pred = pred.clone()
+    net.backward()
+    assert net.saved['encd'][0][0].dtype == torch.bfloat16 and net._drop_ps is not None
+    for mode in ('fp32', 'bf16-storage'):
+        P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+        stats = {}
+        pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, collect=stats,
+                            dropout={k: torch.from_numpy(v) for k, v in sc.items()},
+                            quant=None if mode == 'fp32' else U.round_bf16)
+        lr = U.l1_loss(pr, target)
+        lr.backward()
+        tight = mode != 'fp32'
+        close(pred.view(B, *shape, 1), pr, 2.5e-2 if tight else 3e-2, mode + ' prediction')
+        assert abs(loss.item() - lr.item()) < (3e-3 if tight else 1e-2) * abs(lr.item()), (mode, loss.item(), lr.item())
+        for bn in net.bn_layers:      # statistics of the dropped-out tensors, over batch and voxels
+            o, C = bn['soff'], bn['C']
+            close(net.bn_batch[o:o + C], stats[bn['name']][0], 1.5e-2 if tight else 2e-2, mode + ' ' + bn['name'] + ' mean')
+            close(net.bn_batch[o + C:o + 2 * C], stats[bn['name']][1], 1.5e-2 if tight else 2e-2, mode + ' ' + bn['name'] + ' var')
+        rep = _grad_report(net, P)
+        worst = sorted(((c, e, nm) for nm, (e, c, _) in rep.items()))[:4]
+        for nm, (err, cos, kind) in rep.items():
+            cmin, emax = ((0.985, 0.15) if fold else (0.997, 8e-2)) if tight else (0.9, 10.0)   # as test_unet_bf16_step_vs_oracle
+            assert cos > cmin and err < emax, '%s: gradient of %s: err %.3e cos %.5f (worst %s)' % (mode, nm, err, cos, worst)
+    # a feature dropped for EVERY sample has no gradient on the input-channel slice of the kernel that consumes it
+    for grp in net.enc + net.dec:
+        for k in range(1, len(grp['convs'])):
+            dead = np.flatnonzero((sc[grp['convs'][k - 1]['name']] == 0).all(0))
+            assert dead.size == 0 or net.view(grp['convs'][k]['w'], net.grads)[:, :, :, dead, :].abs().max().item() == 0.0
+
+
 def test_bf16_training_reduces_loss(T):
     """a few bf16 steps of the full loop (generator -> bf16 U-Net -> Adam on fp32 master weights) on a fixed sample"""
     torch = T
