@@ -24,14 +24,6 @@
 #include <type_traits>
 #include <utility>
 
-#ifndef SYN_SETPRIO  // A/B build (round 5, tools/lib_ab.py): 1 = s_setprio 1 around every MFMA cluster of fwd2 and the weight gradient
-#define SYN_SETPRIO 0
-#endif
-#if SYN_SETPRIO
-#define SYN_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define SYN_PRIO(x)
-#endif
 #ifndef SYN_ABL  // ablation builds of the interleaved forward kernel (tools/split_ablate.sh): 1 no halo loads, 2 no conversion,
 #define SYN_ABL 0  // 4 no LDS image stores, 8 weights loaded once, 16 activation fragments loaded once per chunk, 32 no stores, 64 no MFMAs
 #endif
@@ -766,7 +758,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
       auto mma = [&](auto QA, auto QB) {  // plain: acc += (weight piece QA) x (activation piece QB)
         constexpr int qa = decltype(QA)::value, qb = decltype(QB)::value;
         if constexpr (!STK) {
-          SYN_PRIO(1);
 #pragma unroll
           for (int y = 0; y < TY; ++y)
 #pragma unroll
@@ -777,13 +768,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
               acc[y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[qa][mt]),
                                                                    __builtin_bit_cast(bf16x8, xb[qb][y]), acc[y][mt], 0, 0, 0);
 #endif
-          SYN_PRIO(0);
         }
       };
       auto mmt = [&](auto TL, auto QB) {  // STK: acc[.][tile TL] += (row tile TL) x (activation piece QB)
         constexpr int tl = decltype(TL)::value, qb = decltype(QB)::value;
         if constexpr (STK) {
-          SYN_PRIO(1);
 #pragma unroll
           for (int y = 0; y < TY; ++y)
 #if SYN_ABL & 64
@@ -792,7 +781,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
             acc[y][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[0][tl]),
                                                                  __builtin_bit_cast(bf16x8, xb[qb][y]), acc[y][tl], 0, 0, 0);
 #endif
-          SYN_PRIO(0);
         }
       };
       xload(0, 2);
@@ -1923,7 +1911,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
           if (pre) aload(q + 1, (q + 1) & 1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        SYN_PRIO(1);
         if constexpr (STK) {
           // (x piece, column tile, accumulator): the two accumulators alternate; smallest terms first as in the plain order
           auto mm = [&](int xa, int pb, int nb, int ac) {
@@ -1950,7 +1937,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
                                                                    __builtin_bit_cast(bf16x8, bfr[qb][n]), acc[q][n], 0, 0, 0);
           });
         }
-        SYN_PRIO(0);
       });
       __builtin_amdgcn_sched_barrier(0);
     });
