@@ -1716,7 +1716,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15, lrow = li >> 2, lq = li & 3;
   constexpr int GROUPS = C::NRT / RT, WPG = NW / GROUPS, KPW = 8 / WPG;  // row groups, waves per group, K steps per wave
-  const int rh = __builtin_amdgcn_readfirstlane(wave / WPG), wg = wave % WPG;  // this wave's row group and its place in it
+  // this wave's row group and its place in it (CIW = 24: as a scalar -- the address tables of 11 row tiles then cost no vector
+  // registers; the other variants keep the round-4 form: their register allocation spills MORE with the scalar, measured)
+  const int rh = CIW == 24 ? __builtin_amdgcn_readfirstlane(wave / WPG) : wave / WPG, wg = wave % WPG;
   // first row tile of the group and whether it has an 11th slot (BAL: 11 | 10 | 10 | 11 slots, the last one the ones row)
   const int rt0 = BAL ? rh * (RT - 1) + (rh > 0 ? 1 : 0) : rh * RT;
   const bool slot10 = !BAL || rh == 0 || rh == GROUPS - 1;
