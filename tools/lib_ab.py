@@ -57,6 +57,11 @@ def worker(reps):
         r['dgrad*elu\''] = t(lambda: ops.conv3d_add(dy, wpd, None, below, ci, 2, out=dx))
         r['dgrad_md5'] = md5(dx)
         r['wgrad'] = t(lambda: ops.conv3d_wgrad(x, dy, dw, db))
+        prev = ops.set_deterministic(True)     # ordered sums: the weight gradient's bits are comparable between builds
+        dwd, dbd = torch.zeros_like(w), torch.zeros_like(b)
+        ops.conv3d_wgrad(x, dy, dwd, dbd)
+        ops.set_deterministic(prev)
+        r['wgrad_md5'] = md5(torch.cat([dwd.reshape(-1), dbd]))
         out['%d^3 %d->%d' % (D, ci, co)] = r
         del x, dy, below, y, dx
     print('LIBAB ' + json.dumps(out))
@@ -82,7 +87,7 @@ def main():
             a = [r[layer][k] for r in res[libs[0]]]
             b = [r[layer][k] for r in res[libs[1]]]
             print('%-16s %-12s A %.4f %.4f   B %.4f %.4f   B/A %.3f' % (layer, k, a[0], a[1], b[0], b[1], min(b) / min(a)))
-        for k in ('fwd_md5', 'stats_md5', 'dgrad_md5'):
+        for k in ('fwd_md5', 'stats_md5', 'dgrad_md5', 'wgrad_md5'):
             a, b = res[libs[0]][0][layer][k], res[libs[1]][0][layer][k]
             print('%-16s %-12s %s | %s %s' % (layer, k, a, b, 'identical' if a == b else 'DIFFERENT'))
     for p in libs + libs:
