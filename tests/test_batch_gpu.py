@@ -420,3 +420,72 @@ def test_frozen_network_with_active_dropout_vs_oracle(B):
         assert e < 2e-3, e   # (max-pool rounding ties between device and oracle would show as ~1e-2 here: none at this seed)
     finally:
         ops.set_deterministic(prev)
+
+
+@pytest.mark.gpu
+def test_loss_kink_ties_are_identified_and_aligned(capsys):
+    """The protocol's treatment of loss kinks (tests/conftest.py: "kinks of the loss"), exercised on purpose: the target of twelve
+    voxels is planted 1 ulp beside the DEVICE's own prediction, so sign(pred - target) of the L1 loss there is decided by the last
+    bits of the forward pass -- the oracle (whose prediction differs from the device's by a few ulp) lands on the other side at about
+    half of them, the atomics run at some.  single_shot_parity must identify exactly these voxels from d(loss)/d(pred), prove each
+    a rounding tie, re-run the oracle on the device's side and then hold every gradient to the float64-anchored bound; without the
+    alignment each flipped voxel moves the gradients by ~1 % (the round-4 red test)."""
+    import torch
+    from synthsr_amd import ops
+    from synthsr_amd.unet import unet
+    from oracle import unet_ref as U
+    B, feats, levels, shape, cin = 2, 24, 3, (16, 16, 32), 2
+    g = torch.Generator()
+    tensors = {}
+
+    def run():
+        net = unet(nb_features=feats, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=1, feat_mult=2,
+                   nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=3)
+        g.manual_seed(11)
+        for nm, v in net.named_parameters():
+            if nm.endswith('/gamma'):
+                v.copy_(torch.rand(v.shape, generator=g) + .5)
+            elif nm.endswith('/beta') or nm.endswith('/bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * .1)
+        net.repack()
+        net.set_batch(B)
+        x = torch.rand(B, *shape, cin, generator=g)
+        x[1] *= 1.7
+        target = torch.rand(B, *shape, 1, generator=g) if 'target' not in tensors else tensors['target']
+        xs = x.reshape(B * shape[0], shape[1], shape[2], cin).cuda()
+        loss, pred = net.loss_l1(xs, target.reshape(-1).cuda(), want_pred=True)
+        net.test_loss, net.test_pred = loss.clone(), pred.clone()
+        net.backward()
+        tensors.update(x=x, target=target)
+        return net
+
+    prev = ops.set_deterministic(True)        # pass 1: learn the device's (reproducible) prediction
+    try:
+        pred0 = run().test_pred.float().cpu().reshape(-1)
+    finally:
+        ops.set_deterministic(prev)
+    planted = torch.arange(12) * 1291 + 77
+    ulp = torch.finfo(torch.float32).eps * pred0[planted].abs().clamp_min(float(pred0.pow(2).mean().sqrt()))
+    tgt = tensors['target'].reshape(-1).clone()
+    tgt[planted] = pred0[planted] + ulp * torch.where(torch.arange(12) % 2 == 0, 1.0, -1.0)
+    assert bool((tgt[planted] != pred0[planted]).all())
+    tensors['target'] = tgt.reshape(B, *shape, 1)
+
+    def oracle(net, nudge):
+        P = {nm: v.detach().cpu().clone().requires_grad_(True) for nm, v in net.named_parameters()}
+        pin = []
+        pr = U.unet_forward(tensors['x'], P, net.prefix, levels, 2, training=True, pool_inputs=pin, pool_nudge=nudge)
+        lr = U.l1_loss(pr, tensors['target'])
+        lr.backward()
+        return (P, pr.detach(), lr.detach()), pin
+
+    def compare(net, ref):
+        _, pr, lr = ref
+        assert (net.test_pred.view(B, *shape, 1).cpu() - pr).abs().max().item() < 5e-4 * pr.abs().max().item()
+        assert abs(net.test_loss.item() - lr.item()) < 2e-5 * max(1.0, abs(lr.item()))
+
+    single_shot_parity(run, oracle, compare, max_flips=16)
+    out = capsys.readouterr().out
+    # at least one of the identification paths ran: device vs oracle (fp32 / float64 run), deterministic vs atomics run
+    assert 'loss-kink rounding tie(s) between device and oracle' in out or 'identified loss-kink flip(s) on the atomics path' in out, out
+    print(out)
