@@ -217,7 +217,7 @@ def align_pool_ties(dev_choices, oracle_inputs, max_ties=8, max_ulp=4.0, report=
 # the largest gradient of the network (a bias whose gradient is a sum of cancelling terms has no range of its own).  The floor
 # is 2e-5 for conv / head kernels and 4x that for the per-channel SUMS over every voxel (biases, BatchNorm beta / gamma): their
 # terms cancel, and the rounding of a sum scales with the sum of |terms|, not with |sum| = the range.
-# Measured over the 47 whole-network tests of the suite (3016 tensor records, profiles/r05_parity_anchor_distribution.txt): device
+# Measured over the 47 whole-network tests of the suite at the time (3016 tensor records; 48 tests since, profiles/r05_parity_anchor_distribution.txt): device
 # vs float64 at most 2.5e-5 (kernels) / 3.0e-5 (sums) of range -- median 1.6e-6 --, the fp32 oracle at most 1.6e-5 / 2.8e-5;
 # device / oracle 1.2 in the median, 3.2-4.2 at the 99th percentile; the tightest record sits 2.6x inside the rule.
 GRAD_K, GRAD_FLOOR, RANGE_FLOOR = 6.0, 2e-5, 1e-3
