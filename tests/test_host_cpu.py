@@ -553,3 +553,21 @@ def test_bench_self_launch_rendezvous_cpu():
     r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--rendezvous-only'], capture_output=True,
                        text=True, timeout=600, env=dict(env, WORLD_SIZE='1', RANK='0'), cwd=repo)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stdout + r.stderr)
+
+
+def test_public_headers_are_plain_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/*.h compile as C99 (no C++, no torch / HIP types in any signature) and a caller can
+    fill the conv context as a plain aggregate"""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "synthsr_hip.h"\n#include "synthsr_hip_tuning.h"\n'
+                   'int main(void) { synthsr_conv_ctx c = { SYNTHSR_ARITH_SPLIT9, {0} }; synthsr_stream_t s = 0; (void)s;\n'
+                   '  return c.arithmetic == 2 && sizeof(c) == 8 * sizeof(int) ? 0 : 1; }\n')
+    r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(REPO, 'include'), str(src), '-o',
+                        str(tmp_path / 'hdr')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([str(tmp_path / 'hdr')]).returncode == 0
