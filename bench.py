@@ -439,6 +439,12 @@ def main():
         rows.sort(key=lambda r: -r['rank_ms'])
         conv_total = sum(r['total_ms'] for r in rows)
         dom = rows[0]
+        for r in rows[:6]:   # `top_kernels` of the line: each against ITS matrix peak (split: dense bf16 / partial products)
+            sp = args.conv_arith != 'fp32_mfma' and ops.conv_runs_split(r['kernel'], tuple(r['shape']), r['cin'], r['cout'])
+            pk = BF16_MFMA_PEAK_TFLOPS / (9.0 if args.conv_arith == 'split9' else 6.0) if sp else FP32_MFMA_PEAK_TFLOPS
+            r['frac'] = r['tflops'] / pk
+            r['arithmetic'] = args.conv_arith if sp else 'fp32_mfma'
+
         if args.layer_table:
             with open(args.layer_table, 'w') as f:
                 f.write('# %s: every conv launch of the first %d timed steps (HIP events on the launch stream), per step\n'
