@@ -222,18 +222,52 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_version(backend):
+    """RCCL's version string when the collectives run over it (backend 'nccl' IS RCCL on ROCm), else None"""
+    if backend != 'nccl':
+        return None
+    try:
+        import torch
+        return '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as ex:  # noqa: BLE001 -- a missing version query must not lose the measurement
+        return 'unknown (%r)' % (ex,)
+
+
+N_PARAMS_C1 = 13240489   # trainable parameters of the configs[1] network = floats of the flat gradient buffer (DESIGN section 2)
+
+
 def rendezvous_only(args, world, rank):
-    """--rendezvous-only: the ranks meet over gloo (CPU), count themselves with an all-reduce, rank 0 prints the record"""
+    """--rendezvous-only: the ranks meet over gloo (CPU), count themselves with an all-reduce and push a buffer of the flat
+    gradient's size through the product's GradBucketReducer (same bucket size as the training step, readiness reported tail
+    first); rank 0 prints the record -- n_ranks_seen, the bytes and buckets one step's all-reduce consists of, and whether
+    every rank ended with the same sum"""
     import torch
     import torch.distributed as dist
+    from synthsr_amd.training import GradBucketReducer
     if world > 1:
         dist.init_process_group('gloo')
     seen = torch.ones(1)
+    rec = {}
     if world > 1:
         dist.all_reduce(seen)
+        g = torch.full((N_PARAMS_C1,), float(rank + 1))
+        red = GradBucketReducer(g)
+        red.start()
+        for lo in range(N_PARAMS_C1 - 700001, 0, -1300003):   # "layer boundaries": the reducer cuts buckets of >= its size
+            red.ready(lo)
+        scale = red.finish()
+        ok = torch.tensor([float(bool((g == world * (world + 1) / 2).all()) and abs(scale * world - 1.0) < 1e-12)])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        covered = sorted(red.ranges)
+        rec = {'allreduce_bytes_per_step': int(red.bytes_launched), 'allreduce_buckets_per_step': int(red.n_launched),
+               'allreduce_covers_buffer_once': bool(covered[0][0] == 0 and covered[-1][1] == N_PARAMS_C1 and
+                                                    all(a[1] == b[0] for a, b in zip(covered, covered[1:]))),
+               'allreduce_tail_first': bool(all(a[0] == b[1] for a, b in zip(red.ranges, red.ranges[1:]))),
+               'allreduce_identical_on_every_rank': bool(ok.item() == 1.0), 'gradient_scale': scale}
     if rank == 0:
-        print(json.dumps({'metric': 'rendezvous only', 'n_gpus': args.gpus, 'n_ranks_seen': int(seen.item()),
-                          'world_size': dist.get_world_size() if world > 1 else 1, 'backend': 'gloo' if world > 1 else None}))
+        print(json.dumps(dict({'metric': 'rendezvous only', 'n_gpus': args.gpus, 'n_ranks_seen': int(seen.item()),
+                               'world_size': dist.get_world_size() if world > 1 else 1,
+                               'backend': 'gloo' if world > 1 else None, 'rccl_version': rccl_version('gloo')}, **rec)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -536,7 +570,11 @@ def main():
                'roofline': roofline, 'roofline_generator': roofline_generator, 'final_loss': round(final_loss, 6),
                'n_ranks_seen': dist.get_world_size() if dist.is_initialized() else 1,
                'backend': (backend if dist.is_initialized() else None),
-               'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if dist.is_initialized() else None,
+               'rccl_version': rccl_version(backend) if dist.is_initialized() else None,
+               # payload of the gradient all-reduce of the LAST step as the reducer issued it (expected: the whole flat
+               # gradient buffer, 13 240 489 floats = 52.96 MB, in tail-first buckets)
+               'allreduce_bytes_per_step': (int(tr.reducer.bytes_launched) if tr.reducer is not None and (world > 1 or args.force_allreduce) else 0),
+               'allreduce_buckets_per_step': (int(tr.reducer.n_launched) if tr.reducer is not None and (world > 1 or args.force_allreduce) else 0),
                'top_kernels': [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]}
         if per_rank is not None:
             out['per_rank'] = per_rank

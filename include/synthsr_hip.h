@@ -7,7 +7,8 @@
  * reference function emits; the reference file:line it stands in for is cited per function.
  *
  * Conventions
- *   - plain device pointers + explicit sizes; no allocation, no ownership transfer, no global
+ *   - plain device pointers + explicit sizes; no allocation (scratch is the caller's: synthsr_conv_ctx.workspace),
+ *     no ownership transfer, no global
  *     state; every call is stream-ordered on `stream` (a hipStream_t) and re-entrant.  What a
  *     convolution call computes depends on its arguments only: the arithmetic is a field of the
  *     caller-owned synthsr_conv_ctx handed to every conv entry point (NULL = the default), the
@@ -31,11 +32,20 @@ extern "C" {
 #define SYNTHSR_OK 0
 #define SYNTHSR_EINVAL (-1)   /* bad argument / unsupported shape */
 #define SYNTHSR_ELAUNCH (-2)  /* hip launch error */
+#define SYNTHSR_EWORKSPACE (-3) /* the call needs scratch and the context's workspace (or, in the deterministic test mode,
+                                 * the registered plane buffer) is missing or too small; nothing was launched */
 
 typedef void* synthsr_stream_t; /* hipStream_t */
 
 /* Context of the fp32 3x3x3 convolutions: caller-owned, read-only during a call, never stored by the library; two contexts
- * (two networks, two threads) coexist.  Packed weights are only valid under the arithmetic they were packed with.
+ * (two networks, two threads, two streams of one device) coexist.  Packed weights are only valid under the arithmetic they
+ * were packed with -- SPLIT, SPLIT9 and FP32_MFMA each have their own packed layout (SPLIT stacks the three pieces of the
+ * Cout = 24 layers, SPLIT9 does not): pack and run under the SAME arithmetic value.
+ * workspace: device scratch of workspace_bytes >= synthsr_conv_workspace_bytes() (16 MiB; a bound over every shape) that the
+ *   calls made with this context may overwrite: per-workgroup partial sums of BatchNorm statistics and of the first layer's
+ *   weight gradient.  Calls sharing a context must be ordered on ONE stream; concurrent streams take one context (one
+ *   workspace) each.  A call that needs scratch under a context without one (or NULL) returns SYNTHSR_EWORKSPACE; host-only
+ *   queries (plan, pack sizes) and most launches need none.
  *   SYNTHSR_ARITH_SPLIT (default, also what NULL means): every fp32 operand is the exact sum of three bf16 numbers (round to
  *     nearest even on what the previous pieces left); a product a*b is accumulated as a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 +
  *     a2 b0 on v_mfma_f32_16x16x32_bf16, each partial product exact in the fp32 accumulator; what is left out is < 2^-23 |a b|
@@ -44,19 +54,25 @@ typedef void* synthsr_stream_t; /* hipStream_t */
  *     kernels' (tests/test_split_gpu.py).  Used where the layer has enough 4x4x16 tiles and channel counts that are multiples
  *     of 8 (csrc/conv_split.hip); the rest (first layer, the smallest deep layers, the folded convs' weight gradient) runs on
  *     the fp32 matrix instructions in every mode.
- *   SYNTHSR_ARITH_SPLIT9: the same kernels and packed weights with ALL nine partial products a_i b_j: an fp32 product is
- *     reproduced exactly at 1.5x the matrix instructions.
+ *   SYNTHSR_ARITH_SPLIT9: the same kernels with ALL nine partial products a_i b_j (own packed weights: the three pieces of a
+ *     Cout = 24 layer are not stacked): an fp32 product is reproduced exactly at 1.5x the matrix instructions.
  *   SYNTHSR_ARITH_FP32_MFMA: v_mfma_f32_4x4x1 / 16x16x4 kernels everywhere (csrc/conv3d.hip), the round-1/2 path.
  * The reference computes these layers in fp32 on TensorFlow (SynthSR/training.py:330-341). */
 #define SYNTHSR_ARITH_FP32_MFMA 0
 #define SYNTHSR_ARITH_SPLIT 1
 #define SYNTHSR_ARITH_SPLIT9 2
 typedef struct synthsr_conv_ctx {
-  int arithmetic;  /* SYNTHSR_ARITH_* */
-  int reserved[7]; /* zero */
+  int arithmetic;           /* SYNTHSR_ARITH_* */
+  int reserved0;            /* zero (checked: SYNTHSR_EINVAL otherwise) */
+  void* workspace;          /* device scratch owned by the caller, or NULL */
+  uint64_t workspace_bytes; /* its size */
+  int reserved[2];          /* zero (checked) */
 } synthsr_conv_ctx;
+/* upper bound of the scratch any call reads or writes in ctx->workspace, whatever the shape */
+unsigned long long synthsr_conv_workspace_bytes(void);
 
-/* library / device introspection */
+/* library / device introspection.  ABI version 2 (round 6): every conv entry point takes the context as its FIRST argument
+ * (round 5) and the context carries the caller's workspace; version 1 callers must be rebuilt. */
 int synthsr_abi_version(void);
 const char* synthsr_build_arch(void);
 

@@ -5,7 +5,7 @@
  * of rounds 1-4 no longer exist).  The exception:
  *  - synthsr_set_deterministic: called by synthsr_amd.ops.set_deterministic, training(deterministic=True) and the parity
  *    tests.  Its state (a device block holding tickets and scratch for ordered reductions, installed in every translation
- *    unit's g_syn_det symbol, plus the private dW planes of the weight-gradient flush) is per DEVICE -- the device that is
+ *    unit's g_syn_det symbol, plus the caller-provided private dW planes of the weight-gradient flush) is per DEVICE -- the device that is
  *    current when it is called; another device of the same process keeps its own setting -- and assumes ONE stream per device:
  *    kernels of two streams must not overlap while it is on.  Not thread-safe.
  * Also here: a host-only query of the tile schedule (tests). */
@@ -33,6 +33,14 @@ int synthsr_split_tile_schedule(int kernel, int ntiles, int ny, int block_x, int
  * allocation failure leaves the mode off and nothing half-installed.
  * Reference: SURVEY.md section 5 (determinism); the reference itself relies on TF's non-deterministic GPU reductions. */
 int synthsr_set_deterministic(int on);
+/* The private dW planes of the deterministic weight-gradient flush are CALLER memory (torch allocates): `planes` = device
+ * buffer of `bytes` on the current device, kept until replaced or withdrawn (NULL, 0); synchronises the device.  A weight
+ * gradient that needs more than is registered returns SYNTHSR_EWORKSPACE and does nothing;
+ * synthsr_deterministic_workspace_demand() = the largest demand (bytes) any call on this device has had so far -- register
+ * at least that much and call again (synthsr_amd/ops.py does exactly this).  The library itself allocates device memory in
+ * ONE place: the ticket block + 64 MB of ordered-reduction scratch inside synthsr_set_deterministic(1). */
+int synthsr_set_deterministic_workspace(void* planes, unsigned long long bytes);
+unsigned long long synthsr_deterministic_workspace_demand(void);
 /* 0 = off, 1 = on and every ordered wait completed, 2 = on but a wait timed out (results may be unordered), -1 = error */
 int synthsr_deterministic_status(void);
 

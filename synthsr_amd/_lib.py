@@ -30,7 +30,8 @@ class DeformParams(Structure):
 
 class ConvCtx(Structure):
     """mirror of synthsr_conv_ctx (include/synthsr_hip.h): the caller-owned context of the fp32 convolutions"""
-    _fields_ = [('arithmetic', c_int), ('reserved', c_int * 7)]
+    _fields_ = [('arithmetic', c_int), ('reserved0', c_int), ('workspace', c_void_p), ('workspace_bytes', c_uint64),
+                ('reserved', c_int * 2)]
 
 
 _P = c_void_p
@@ -62,6 +63,9 @@ SIGNATURES = {
     'synthsr_split_tile_schedule': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
     'synthsr_conv3d_wgrad_runs_split': (c_int, [_C, POINTER(c_int), c_int, c_int]),
     'synthsr_set_deterministic': (c_int, [c_int]),
+    'synthsr_set_deterministic_workspace': (c_int, [_P, c_uint64]),
+    'synthsr_deterministic_workspace_demand': (c_uint64, []),
+    'synthsr_conv_workspace_bytes': (c_uint64, []),
     'synthsr_deterministic_status': (c_int, []),
     'synthsr_conv3d_plan': (c_int, [_C, POINTER(c_int), c_int, c_int, c_int, POINTER(c_int64)]),
     'synthsr_conv3d_pack_all': (c_int, [_P, _P, _P, c_int, _S]),
@@ -181,6 +185,9 @@ def check(rc, what=''):
         return
     if rc == -1:
         raise ValueError('synthsr_hip: invalid argument / unsupported shape in %s' % what)
+    if rc == -3:
+        raise SynthSRHipError('synthsr_hip: %s needs scratch and the conv context carries no (or too small a) workspace '
+                              '(include/synthsr_hip.h: synthsr_conv_ctx.workspace)' % what)
     raise SynthSRHipError('synthsr_hip: HIP launch error (%d) in %s' % (rc, what))
 
 

@@ -145,6 +145,7 @@ class Critic3D:
         """x [d0,d1,d2,C] -> D(x) as a 1-element device tensor; the LeakyReLU outputs are kept under `tag`"""
         if self.bf16:
             return self._forward_bf16(x, tag)
+        ops.check_layout_epoch(getattr(self, '_pack_epoch', None), 'Critic3D.forward')
         hs = [x]
         cur = x
         for i, c in enumerate(self.convs):
@@ -167,6 +168,7 @@ class Critic3D:
         self.grads (weight_grads), returns grad_x D * dout (input_grad), keeps the per-layer signals for the penalty"""
         if self.bf16:
             return self._backward_bf16(dout, weight_grads, input_grad, keep_deltas)
+        ops.check_layout_epoch(getattr(self, '_pack_epoch', None), 'Critic3D.backward')
         hs, h9 = self._saved['hs'], self._saved['h9']
         d0, d1 = self.dense
         G = self.grads

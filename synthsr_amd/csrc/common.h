@@ -168,18 +168,29 @@ __device__ __forceinline__ void syn_det_gather_end(int n) {
 }
 
 // A kernel attribute (hipFuncSetAttribute: the dynamic LDS size) is set once per kernel AND DEVICE: a launcher keeps one of these
-// as a function-local static and asks first() before its launch (a process that drives several devices sets it on each).
+// as a function-local static and writes  if (auto once_ = attr_done.first()) { hipFuncSetAttribute(...); }  -- the guard marks the
+// device when the if statement ENDS.
+// The device's bit is set only AFTER the attribute call returned: a second thread that launches on the same device meanwhile
+// sets the (idempotent, cheap) attribute again instead of launching without it.  Device ids beyond 63 never cache.
 #include <atomic>
 struct SynOncePerDevice {
-  std::atomic<uint64_t> done{0};
-  bool first() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return true;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (done.load(std::memory_order_relaxed) & bit) return false;
-    done.fetch_or(bit, std::memory_order_relaxed);
-    return true;
+  std::atomic<uint64_t> bits{0};
+  bool needed() const {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    return !(bits.load(std::memory_order_acquire) & (1ull << dev));
   }
+  void done() {
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev <= 63) bits.fetch_or(1ull << dev, std::memory_order_release);
+  }
+  struct Guard {
+    SynOncePerDevice* o;
+    bool need;
+    ~Guard() { if (need) o->done(); }
+    explicit operator bool() const { return need; }
+  };
+  Guard first() { return Guard{this, needed()}; }
 };
 
 // host side of the deterministic WEIGHT-GRADIENT flush (conv3d.hip: det_prepare / det_finish): private planes per workgroup

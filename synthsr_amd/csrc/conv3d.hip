@@ -2903,33 +2903,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // (synthsr_hip_tuning.h: synthsr_set_deterministic is per device).
 constexpr int SYN_MAX_DEVICES = 64;
 struct SynDeviceState {
-  float* scratch = nullptr;       // lib_scratch
-  size_t scratch_bytes = 0;
   int det = 0;                    // synthsr_set_deterministic: ordered sums, no split-K / parity-split forward
   SynDet* det_state = nullptr;    // device block (tickets, timeout flag, scratch of the ordered reductions)
-  float* det_planes = nullptr;    // private dW planes of the ordered weight-gradient flush
-  size_t det_planes_floats = 0;
+  float* det_planes = nullptr;    // private dW planes of the ordered weight-gradient flush: CALLER memory
+  size_t det_planes_floats = 0;   //   (synthsr_set_deterministic_workspace), never allocated here
+  unsigned long long det_demand_bytes = 0;  // largest plane demand a weight gradient of this device has asked for
 };
 static SynDeviceState g_dev[SYN_MAX_DEVICES];
+static SynDeviceState g_dev_invalid;   // device ids >= SYN_MAX_DEVICES / a failed hipGetDevice: never deterministic, no planes
 static SynDeviceState& dev_state() {
-  int d = 0;
-  (void)hipGetDevice(&d);
-  return g_dev[(d >= 0 && d < SYN_MAX_DEVICES) ? d : 0];
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= SYN_MAX_DEVICES) return g_dev_invalid;
+  return g_dev[d];
 }
 static inline int det_on() { return dev_state().det; }
-
-// library-owned device scratch (grown on demand, reused by later calls on the same stream order)
-static float* lib_scratch(size_t bytes) {
-  SynDeviceState& st = dev_state();
-  if (bytes > st.scratch_bytes) {
-    if (st.scratch) (void)hipFree(st.scratch);
-    st.scratch = nullptr;
-    st.scratch_bytes = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&st.scratch), bytes) != hipSuccess) return nullptr;
-    st.scratch_bytes = bytes;
-  }
-  return st.scratch;
-}
 
 // ---- plan parameters.  Rounds 1-4 had a process-wide A/B switch behind each of them (synthsr_conv3d_set_option); every one was
 // measured against its alternative (docs/DESIGN_NOTES_r01_r02.md, profiles/r03_*, r04_*) and the library now ships the winners
@@ -2954,22 +2941,33 @@ struct ConvCfg {
   int arith;   // 0 fp32_mfma, 1 split, 2 split9
   int split;   // arith != 0: fp32 convs through 3 x bf16 operand pieces on the bf16 matrix cores where the layer has enough tiles
   int nprod;   // 6 | 9 partial products per multiplication
+  void* ws;    // the caller's scratch (synthsr_conv_ctx.workspace) and its size; the library owns no device memory
+  size_t ws_bytes;
 };
-static thread_local ConvCfg t_cfg = {1, 1, 6};
+static thread_local ConvCfg t_cfg = {1, 1, 6, nullptr, 0};
 static inline const ConvCfg& cfg() { return t_cfg; }
 struct CtxScope {
   ConvCfg prev;
   bool ok;
   explicit CtxScope(const synthsr_conv_ctx* ctx) : prev(t_cfg), ok(true) {
     const int a = ctx ? ctx->arithmetic : SYNTHSR_ARITH_SPLIT;
-    if (a < 0 || a > 2) {
+    // reserved fields must be zero (they can then be given a meaning later); a workspace needs its size
+    if (a < 0 || a > 2 || (ctx && (ctx->reserved0 || ctx->reserved[0] || ctx->reserved[1] || (ctx->workspace_bytes && !ctx->workspace)))) {
       ok = false;
       return;
     }
-    t_cfg = ConvCfg{a, a ? 1 : 0, a == 2 ? 9 : 6};
+    t_cfg = ConvCfg{a, a ? 1 : 0, a == 2 ? 9 : 6, ctx ? ctx->workspace : nullptr, ctx ? (size_t)ctx->workspace_bytes : 0};
   }
   ~CtxScope() { t_cfg = prev; }
 };
+// scratch of the call in flight: a piece of the CALLER's workspace (include/synthsr_hip.h: synthsr_conv_ctx.workspace, at most
+// synthsr_conv_workspace_bytes() are ever asked for).  nullptr = the context carries none / too little: SYNTHSR_EWORKSPACE.
+// Calls that share a context are ordered on one stream by contract, so successive launches may reuse the same bytes.
+constexpr size_t SYN_WORKSPACE_BOUND = (size_t)16 << 20;
+static float* ctx_scratch(size_t bytes) {
+  static_assert((size_t)2048 * 1536 * sizeof(float) <= SYN_WORKSPACE_BOUND, "first-layer weight-gradient partials");
+  return (bytes <= SYN_WORKSPACE_BOUND && bytes <= cfg().ws_bytes) ? static_cast<float*>(cfg().ws) : nullptr;
+}
 
 extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int cin_total,
                                int ci_off, int Cin, int Cout, int nprod, hipStream_t st);
@@ -3137,7 +3135,7 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
       if (ext.mode == 0) {
         static SynOncePerDevice done27;
         auto k27 = conv3d_fwd_lean_kernel<NT, MT, KS, 27>;
-        if (done27.first()) {
+        if (auto once_ = done27.first()) {
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k27), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         }
         hipLaunchKernelGGL(k27, grid, dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1,
@@ -3146,7 +3144,7 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
         if constexpr (!KS) {
           static SynOncePerDevice done8;
           auto k8 = conv3d_fwd_lean_kernel<NT, MT, false, 8>;
-          if (done8.first()) {
+          if (auto once_ = done8.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
           }
           hipLaunchKernelGGL(k8, grid, dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, Cout, pl.ncc, tiles1,
@@ -3166,7 +3164,7 @@ int launch_fwd(const float* in, const float* wp, const float* bias, float* out, 
   }
   static SynOncePerDevice attr_done;
   auto kern = conv3d_fwd_kernel<CK, NT, MT, KS, NV>;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   const int64_t nout = (int64_t)s[0] * s[1] * s[2] * Cout;
@@ -3195,7 +3193,7 @@ int launch_fwd_persist(const float* in, const float* wp, const float* bias, floa
   const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
   static SynOncePerDevice attr_done;
   auto kern = conv3d_fwd_persist_kernel<NT>;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   int gx = 512 / pl.nchunks;  // 2 workgroups per CU in total
@@ -3213,7 +3211,7 @@ int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* ou
   const int ntiles = tiles0 * tiles1 * tiles2;
   const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_fwd_p4_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
@@ -3221,8 +3219,8 @@ int launch_fwd_p4(const float* in, const float* wp, const float* bias, float* ou
   while (gx > 8 && gx > ntiles) gx -= 8;
   float* partial = nullptr;
   if (stats) {  // BatchNorm statistics of the output: per-workgroup partials in library scratch, then a tiny reduction
-    partial = lib_scratch((size_t)gx * 48 * sizeof(float));
-    if (!partial) return SYNTHSR_ELAUNCH;
+    partial = ctx_scratch((size_t)gx * 48 * sizeof(float));
+    if (!partial) return SYNTHSR_EWORKSPACE;
   }
   hipLaunchKernelGGL(conv3d_fwd_p4_kernel, dim3(gx), dim3(256), smem, st, in, wp, bias, out, s[0], s[1], s[2], Cin, pl.ncc,
                      tiles1, tiles2, ntiles, act | (PLAN_DBG << 8), addend, partial);
@@ -3308,7 +3306,7 @@ int launch_up_fwd_p4(const float* in, const float* wp, const float* bias, float*
   const int ntiles = tiles0 * tiles1 * tiles2;
   const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_up_fwd_p4_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
@@ -3376,19 +3374,9 @@ int dispatch_fwd(const float* in, const float* wp, const float* bias, float* out
 // 98 instead of 29 ms per 160^3 step; the planes cost one memset + one read of gx * |dW| floats per launch.
 static float* det_planes(size_t floats) {
   SynDeviceState& ds = dev_state();   // the planes belong to the device the call runs on
-  if (floats > ds.det_planes_floats) {
-    if (hipDeviceSynchronize() != hipSuccess) return nullptr;  // the old buffer may still be read by a queued reduction
-    if (ds.det_planes) (void)hipFree(ds.det_planes);
-    ds.det_planes = nullptr;
-    ds.det_planes_floats = 0;
-    const size_t want = std::max(floats + floats / 4, (size_t)16 << 20);
-    if (hipMalloc(reinterpret_cast<void**>(&ds.det_planes), want * sizeof(float)) != hipSuccess) {
-      ds.det_planes = nullptr;
-      return nullptr;
-    }
-    ds.det_planes_floats = want;
-  }
-  return ds.det_planes;
+  const unsigned long long need = (unsigned long long)floats * sizeof(float);
+  if (need > ds.det_demand_bytes) ds.det_demand_bytes = need;
+  return floats <= ds.det_planes_floats ? ds.det_planes : nullptr;   // too small: SYNTHSR_EWORKSPACE, the caller re-registers
 }
 __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ planes, int64_t stride, int gx,
                                                          float* __restrict__ dw, int64_t dw_elems,
@@ -3412,7 +3400,7 @@ static int det_prepare_impl(DetRun* d, float** dw, float** dbias, int64_t dw_ele
   d->gx = gx;
   d->stride = (dw_elems + cout + 3) / 4 * 4;
   d->planes = det_planes((size_t)gx * (size_t)d->stride);
-  if (!d->planes) return SYNTHSR_ELAUNCH;
+  if (!d->planes) return SYNTHSR_EWORKSPACE;
   if (hipMemsetAsync(d->planes, 0, (size_t)gx * (size_t)d->stride * sizeof(float), st) != hipSuccess) return SYNTHSR_ELAUNCH;
   *dw = d->planes;
   if (*dbias) *dbias = d->planes + dw_elems;
@@ -3458,7 +3446,7 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
         const int hv = 6 * 6 * (tx + 2), tv = 16 * tx;
         const int vpx = hv + ((hv / 2) % 2 == 0 ? 2 : 0) + (hv % 2);
         const size_t bsmem = ((size_t)(CK + 1) * vpx + (size_t)NT * 16 * (tv + 2)) * sizeof(float);
-        if (syn_det_prepare(&det, &dw, &ext.dbias, dw_elems, Cout, bgx, st) != SYNTHSR_OK) return SYNTHSR_ELAUNCH;
+        if (const int rc_ = syn_det_prepare(&det, &dw, &ext.dbias, dw_elems, Cout, bgx, st)) return rc_;
         ext.det_stride = det.stride;
         if (x8) {
           hipLaunchKernelGGL((conv3d_wgrad_box_kernel<NT, MS, 4, 4, 8>), dim3(bgx, ncc * ymul, nco), dim3(256), bsmem, st, in,
@@ -3474,11 +3462,11 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
     if ((Cout % 4) == 0 && xbytes < (1ll << 31) && dbytes < (1ll << 31) && !(PLAN_DBG & 16)) {
       static SynOncePerDevice lean_attr_done;
       auto lkern = conv3d_wgrad_lean_kernel<NT, MS, NTAPS>;
-      if (lean_attr_done.first()) {
+      if (auto once_ = lean_attr_done.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lkern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
       }
-      if (syn_det_prepare(&det, &dw, &ext.dbias, dw_elems, Cout, gx, st) != SYNTHSR_OK) return SYNTHSR_ELAUNCH;
+      if (const int rc_ = syn_det_prepare(&det, &dw, &ext.dbias, dw_elems, Cout, gx, st)) return rc_;
       ext.det_stride = det.stride;
       hipLaunchKernelGGL(lkern, dim3(gx, ncc * ymul, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout,
                          tiles0, tiles1, tiles2, ext);
@@ -3488,7 +3476,7 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
   }
   static SynOncePerDevice attr_done;
   auto kern = conv3d_wgrad_kernel<CK, NT, MS, NTAPS>;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   if (ext.dbias) {  // the generic kernel has no dbias row
@@ -3496,7 +3484,7 @@ int launch_wgrad(const float* in, const float* dout, float* dw, const int s[3], 
     if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
   }
   float* no_dbias = nullptr;
-  if (syn_det_prepare(&det, &dw, &no_dbias, dw_elems, Cout, gx, st) != SYNTHSR_OK) return SYNTHSR_ELAUNCH;
+  if (const int rc_ = syn_det_prepare(&det, &dw, &no_dbias, dw_elems, Cout, gx, st)) return rc_;
   ext.det_stride = det.stride;
   hipLaunchKernelGGL(kern, dim3(gx, ncc * ymul, nco), dim3(256), smem, st, in, dout, dw, s[0], s[1], s[2], Cin, Cout,
                      tiles0, tiles1, tiles2, ext);
@@ -3706,8 +3694,8 @@ int launch_wgrad_c2(const float* in, const float* dout, float* dw, float* dbias,
   const int ntiles = tiles0 * tiles1 * tiles2;
   int gx = PLAN_FORCE_MT > 8 ? PLAN_FORCE_MT : 2048;  // 8 per CU: per-tile work is short, latency is hidden by occupancy
   while (gx > 8 && gx > ntiles) gx -= 8;
-  float* partial = lib_scratch((size_t)gx * 1536 * sizeof(float));
-  if (!partial) return SYNTHSR_ELAUNCH;
+  float* partial = ctx_scratch((size_t)gx * 1536 * sizeof(float));
+  if (!partial) return SYNTHSR_EWORKSPACE;
   if (Cin == 2)
     hipLaunchKernelGGL(conv3d_wgrad_c2_kernel<2>, dim3(gx), dim3(256), 0, st, in, dout, partial, s[0], s[1], s[2], tiles1,
                        tiles2, ntiles);
@@ -3732,7 +3720,7 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
         vox * 8 * Cout * 4 < (1ll << 31) && !(PLAN_DBG & 16)) {
       const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
       static SynOncePerDevice attr_done;
-      if (attr_done.first()) {
+      if (auto once_ = attr_done.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_up_wgrad_p4_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       }
@@ -3740,7 +3728,7 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
       while (gx > 8 && gx > ntiles) gx -= 8;
       DetRun det;
       float* no_dbias = nullptr;
-      if (syn_det_prepare(&det, &dw, &no_dbias, 8 * ext.dwstride, Cout, gx, st) != SYNTHSR_OK) return SYNTHSR_ELAUNCH;
+      if (const int rc_ = syn_det_prepare(&det, &dw, &no_dbias, 8 * ext.dwstride, Cout, gx, st)) return rc_;
       hipLaunchKernelGGL(conv3d_up_wgrad_p4_kernel, dim3(gx, ncc * 2), dim3(256), smem, st, in, dout, dw, shape[0], shape[1],
                          shape[2], Cin, tiles1, tiles2, ntiles, ext.dwstride, ext.dbg, det.stride);
       if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
@@ -3764,7 +3752,7 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
       const int ntiles = tiles0 * tiles1 * tiles2, ncc = Cin / 24;
       const size_t smem = (size_t)FH0 * 6 * FH2 * 28 * sizeof(float);
       static SynOncePerDevice attr_done;
-      if (attr_done.first()) {
+      if (auto once_ = attr_done.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_p4_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       }
@@ -3772,8 +3760,7 @@ int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shap
       while (gx > 8 && gx > ntiles) gx -= 8;
       DetRun det;
       float* dbias = ext.dbias;
-      if (syn_det_prepare(&det, &dw, &dbias, (int64_t)27 * ext.cin_total * Cout, Cout, gx, st) != SYNTHSR_OK)
-        return SYNTHSR_ELAUNCH;
+      if (const int rc_ = syn_det_prepare(&det, &dw, &dbias, (int64_t)27 * ext.cin_total * Cout, Cout, gx, st)) return rc_;
       hipLaunchKernelGGL(conv3d_wgrad_p4_kernel, dim3(gx, ncc), dim3(256), smem, st, in, dout, dw, shape[0], shape[1],
                          shape[2], Cin, tiles1, tiles2, ntiles, ext.cin_total, ext.ci_off, ext.dbg, dbias, det.stride);
       if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
@@ -3940,8 +3927,8 @@ int synthsr_conv3d_fwd_stats(const synthsr_conv_ctx* ctx, const float* in, const
   const int64_t nvox = (int64_t)shape[0] * shape[1] * shape[2];
   const FwdPlan pl = plan_fwd(shape, Cin, Cout);
   if (pl.split) {  // statistics accumulated in the conv epilogue (conv_split.hip)
-    float* partial = lib_scratch((size_t)512 * 2 * Cout * sizeof(float));
-    if (!partial) return SYNTHSR_ELAUNCH;
+    float* partial = ctx_scratch((size_t)512 * 2 * Cout * sizeof(float));
+    if (!partial) return SYNTHSR_EWORKSPACE;
     return syn_split_fwd(in, wpacked, bias, nullptr, out, shape, Cin, Cout, pl.mt, pl.nchunks, act, stats, partial, 0,
                          pl.stacked, cfg().nprod, (hipStream_t)stream);
   }
@@ -4007,7 +3994,9 @@ constexpr long long DET_SCRATCH_FLOATS = 16ll << 20;  // 64 MB of partial rows (
 
 int synthsr_set_deterministic(int on) {
   if (hipDeviceSynchronize() != hipSuccess) return SYNTHSR_ELAUNCH;  // no kernel may see the switch mid-flight
-  SynDeviceState& ds = dev_state();   // the CURRENT device: its state block, its device symbols, its planes
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur < 0 || cur >= SYN_MAX_DEVICES) return SYNTHSR_EINVAL;  // never alias another device
+  SynDeviceState& ds = g_dev[cur];   // the CURRENT device: its state block, its device symbols, its planes
   if (on && !ds.det_state) {
     // all-or-nothing: a half-built state block (struct allocated, scratch not) must never be installed by a later call
     SynDet* state = nullptr;
@@ -4040,6 +4029,20 @@ int synthsr_set_deterministic(int on) {
     return SYNTHSR_ELAUNCH;
   return hipDeviceSynchronize() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
+
+int synthsr_set_deterministic_workspace(void* planes, unsigned long long bytes) {
+  if (hipDeviceSynchronize() != hipSuccess) return SYNTHSR_ELAUNCH;  // a queued ordered reduction may still read the old planes
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= SYN_MAX_DEVICES || (bytes && !planes)) return SYNTHSR_EINVAL;
+  SynDeviceState& ds = g_dev[d];
+  ds.det_planes = static_cast<float*>(planes);
+  ds.det_planes_floats = planes ? (size_t)(bytes / sizeof(float)) : 0;
+  return SYNTHSR_OK;
+}
+
+unsigned long long synthsr_deterministic_workspace_demand(void) { return dev_state().det_demand_bytes; }
+
+unsigned long long synthsr_conv_workspace_bytes(void) { return (unsigned long long)SYN_WORKSPACE_BOUND; }
 
 int synthsr_deterministic_status(void) {
   const SynDeviceState& ds = dev_state();

@@ -575,7 +575,7 @@ int launch_fwd_w(const FwdArgs& a, int nchunks, hipStream_t st) {
   const size_t smem = hbytes + (WLDS ? (size_t)NSTEP * MT * 1024 : 0);
   auto kern = conv3d_bf16_fwd_kernel<CK, MT, WLDS>;
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks, a.ksplit), dim3(256), smem, st, a);
@@ -591,7 +591,7 @@ int launch_fwd_up(const FwdArgs& a, int nchunks, hipStream_t st) {
   const size_t smem = ((size_t)HVOX * rowb_fwd(CK) + 1023) / 1024 * 1024;
   auto kern = conv3d_bf16_fwd_kernel<CK, MT, false, UPM>;
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks, UPM == 1 ? 8 : a.ksplit), dim3(256), smem, st, a);
@@ -987,12 +987,11 @@ int launch_wgrad(const WgArgs& a0, hipStream_t st) {
   const size_t smem = (size_t)HVOX * rowb_for(CK) + (size_t)TZ * TY * TX * ((NT & 1) ? NT * 32 : NT * 32 + 32);
   auto kern = conv3d_bf16_wgrad_kernel<CK, NT, UP>;
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   DetRun det;
-  if (syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)(UP ? 8 : 1) * 27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)
-    return SYNTHSR_ELAUNCH;
+  if (const int rc_ = syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)(UP ? 8 : 1) * 27 * a.cin_total * a.Cout, a.Cout, gx, st)) return rc_;
   a.det_stride = det.stride;
   hipLaunchKernelGGL(kern, dim3(gx, a.ncc * a.nco, UP ? 8 : 1), dim3(512), smem, st, a);
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;

@@ -1519,7 +1519,7 @@ int launch_split_upfwd_np(const SplitFwdArgs& a, hipStream_t st) {
   const size_t smem = 2 * BUF;
   auto kern = conv3d_split_upfwd_kernel<MT, NPAR, NPROD>;
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   hipLaunchKernelGGL(kern, dim3(gx, 1, NG), dim3(512), smem, st, a);
@@ -1536,7 +1536,7 @@ int launch_split_fwd_np(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t 
   const size_t smem = 2 * BUF;
   auto kern = conv3d_split_fwd_kernel<MT, ST, UPM, NPROD>;
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(256), smem, st, a);
@@ -1548,7 +1548,7 @@ int launch_split_fwd2_e(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t 
   const size_t smem = 2 * BUF2 + MT * 16 * 4;
   auto kern = conv3d_split_fwd2_kernel<MT, ST, EPI, STK>;
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(256), smem, st, a);
@@ -1586,7 +1586,7 @@ int launch_split_fwd3_e(const SplitFwdArgs& a, int nchunks, hipStream_t st) {
   const size_t smem = F3Cfg<MT>::SMEM;
   auto kern = conv3d_split_fwd3_kernel<MT, ST, EPI>;
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   hipLaunchKernelGGL(kern, dim3(gx, nchunks), dim3(512), smem, st, a);
@@ -2017,12 +2017,11 @@ int launch_split_wgrad_np(const SplitWgArgs& a0, hipStream_t st) {
   const size_t smem = (size_t)C::NBUF * C::BUFB;
   auto kern = conv3d_split_wgrad_kernel<COW, NPROD, STK, CIW>;
   static SynOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (auto once_ = attr_done.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
   DetRun det;
-  if (syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)27 * a.cin_total * a.Cout, a.Cout, gx, st) != SYNTHSR_OK)
-    return SYNTHSR_ELAUNCH;
+  if (const int rc_ = syn_det_prepare(&det, &a.dw, &a.dbias, (int64_t)27 * a.cin_total * a.Cout, a.Cout, gx, st)) return rc_;
   a.det_stride = det.stride;
   hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(512), smem, st, a);
   if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;

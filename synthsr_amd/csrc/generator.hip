@@ -747,7 +747,7 @@ int synthsr_copy_strided(const float* in, float* out, int64_t n, int in_stride, 
   return SYNTHSR_OK;
 }
 
-int synthsr_abi_version(void) { return 1; }
+int synthsr_abi_version(void) { return 2; }  // 2: conv context first + caller workspace (include/synthsr_hip.h)
 const char* synthsr_build_arch(void) { return "gfx950"; }
 
 }  // extern "C"

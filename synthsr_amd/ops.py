@@ -19,35 +19,70 @@ _prof = None
 
 
 # The context handed to every fp32 conv entry point (include/synthsr_hip.h: synthsr_conv_ctx).  The LIBRARY holds no arithmetic
-# state; this module keeps one default context for the host code that does not pass its own (unet.py, critic.py, the tests),
-# and a counter that moves when it is replaced: packed weights are only valid under the arithmetic they were packed with.
-_ctx = _lib.ConvCtx(arithmetic=1)
+# state and owns no scratch: this module keeps the default arithmetic for the host code that does not pass its own (unet.py,
+# critic.py, the tests), one context PER (device, stream) -- each with its own torch-allocated workspace, so that two streams of
+# one device never share scratch -- and a counter that moves when the arithmetic is replaced: packed weights are only valid under
+# the arithmetic they were packed with (check_layout_epoch).
+_arith = 1
 _ctx_epoch = 0
+_ctx_host = _lib.ConvCtx(arithmetic=1)        # host-only queries (plans, packed sizes): no workspace, usable without a GPU
+_ctxs = {}                                    # (device, stream handle) -> (ConvCtx, its workspace tensor)
+_ctx_last = (None, None)
+
+
+def conv_ctx_host():
+    """ctypes reference to a workspace-less context of the current arithmetic (host-only entry points)"""
+    return ctypes.byref(_ctx_host)
 
 
 def conv_ctx():
-    """ctypes reference to the current default conv context"""
-    return ctypes.byref(_ctx)
+    """ctypes reference to the conv context of the CURRENT device and stream (created on first use: the current arithmetic and
+    a workspace of synthsr_conv_workspace_bytes() that torch allocates)"""
+    global _ctx_last
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    if _ctx_last[0] == key:
+        return _ctx_last[1]
+    e = _ctxs.get(key)
+    if e is None:
+        n = int(_L().synthsr_conv_workspace_bytes())
+        ws = torch.empty(n, dtype=torch.uint8, device='cuda:%d' % key[0])
+        e = (_lib.ConvCtx(arithmetic=_arith, workspace=ws.data_ptr(), workspace_bytes=n), ws)
+        _ctxs[key] = e
+    _ctx_last = (key, ctypes.byref(e[0]))
+    return _ctx_last[1]
 
 
 def set_conv_arithmetic(name):
-    """replaces this module's default conv context: 'split' (default) = fp32 convolutions on the bf16 matrix cores through three
+    """replaces this module's default conv arithmetic: 'split' (default) = fp32 convolutions on the bf16 matrix cores through three
     bf16 pieces per operand and six exact partial products (fp32 accumulation, as accurate as the fp32 matrix instructions:
     tests/test_split_gpu.py); 'split9' = the same with all nine partial products (every fp32 product reproduced exactly, 1.5x
-    the matrix instructions); 'fp32_mfma' = fp32 matrix instructions everywhere.  Networks re-pack their weights at the next
-    `repack()` when the context changed (conv_layout_epoch).  Returns the previous setting."""
-    global _ctx, _ctx_epoch
+    the matrix instructions); 'fp32_mfma' = fp32 matrix instructions everywhere.  Networks must re-pack their weights
+    (`repack()`) before their next forward / backward: conv_layout_epoch moves and check_layout_epoch raises on stale packed
+    weights.  Returns the previous setting."""
+    global _arith, _ctx_epoch, _ctx_host, _ctx_last
     if name not in _lib.CONV_ARITHMETICS:
         raise ValueError('conv arithmetic should be one of %s' % (_lib.CONV_ARITHMETICS,))
     prev = conv_arithmetic()
     if name != prev:
-        _ctx = _lib.ConvCtx(arithmetic=_lib.CONV_ARITHMETICS.index(name))
+        _arith = _lib.CONV_ARITHMETICS.index(name)
+        _ctx_host = _lib.ConvCtx(arithmetic=_arith)
+        for key, (c, ws) in list(_ctxs.items()):   # fresh structs (a launch in flight has read its own already): same workspaces
+            _ctxs[key] = (_lib.ConvCtx(arithmetic=_arith, workspace=ws.data_ptr(), workspace_bytes=ws.numel()), ws)
+        _ctx_last = (None, None)
         _ctx_epoch += 1
     return prev
 
 
+def check_layout_epoch(epoch, what):
+    """a network's packed weights were laid out under conv_layout_epoch() == epoch: using them under another arithmetic would
+    plan for one layout and read another (silently wrong results on the Cout = 24 layers) -- raise instead"""
+    if epoch is not None and epoch != _ctx_epoch:
+        raise RuntimeError('%s: the conv arithmetic changed (ops.set_conv_arithmetic) since these weights were packed; call '
+                           'repack() first' % what)
+
+
 def conv_arithmetic():
-    return _lib.CONV_ARITHMETICS[int(_ctx.arithmetic)]
+    return _lib.CONV_ARITHMETICS[_arith]
 
 
 def conv_layout_epoch():
@@ -65,7 +100,7 @@ def conv_runs_split(kind, shape, cin, cout):
         return False
     d0, d1, d2 = [int(v) for v in shape[:3]]
     if kind == 'conv3d_wgrad':   # the dispatcher's own condition (csrc/conv3d.hip: wgrad_takes_split)
-        rc = int(_L().synthsr_conv3d_wgrad_runs_split(conv_ctx(), _lib.i3((d0, d1, d2)), int(cin), int(cout)))
+        rc = int(_L().synthsr_conv3d_wgrad_runs_split(conv_ctx_host(), _lib.i3((d0, d1, d2)), int(cin), int(cout)))
         if rc < 0:
             _lib.check(rc, 'conv3d_wgrad_runs_split')
         return rc == 1
@@ -73,7 +108,7 @@ def conv_runs_split(kind, shape, cin, cout):
     # plan kind 0 on (Cout -> Cl)
     plan_kind, ce, co = {'conv3d_up_fwd': (2, cin, cout), 'conv3d_up_dgrad': (0, cout, cin)}.get(kind, (1, cin, cout))
     out = (ctypes.c_int64 * 8)()
-    _lib.check(_L().synthsr_conv3d_plan(conv_ctx(), _lib.i3((d0, d1, d2)), int(ce), int(co), plan_kind, out), 'conv3d_plan')
+    _lib.check(_L().synthsr_conv3d_plan(conv_ctx_host(), _lib.i3((d0, d1, d2)), int(ce), int(co), plan_kind, out), 'conv3d_plan')
     return int(out[2]) <= -100
 
 
@@ -87,7 +122,36 @@ def set_deterministic(on=True):
     torch.cuda.synchronize()
     _lib.check(_L().synthsr_set_deterministic(int(bool(on))), 'set_deterministic')
     _deterministic = bool(on)
+    if on:
+        _register_det_planes(64 << 20)
     return prev
+
+
+_det_planes = {}    # device -> the torch buffer registered as the private dW planes of the deterministic weight-gradient flush
+
+
+def _register_det_planes(min_bytes):
+    """the planes are CALLER memory (include/synthsr_hip_tuning.h: synthsr_set_deterministic_workspace): torch allocates, grown to
+    1.25x the library's recorded demand whenever a weight gradient reported SYNTHSR_EWORKSPACE"""
+    dev = torch.cuda.current_device()
+    want = max(int(min_bytes), int(1.25 * int(_L().synthsr_deterministic_workspace_demand())))
+    cur = _det_planes.get(dev)
+    if cur is None or cur.numel() < want:
+        torch.cuda.synchronize()
+        _det_planes[dev] = None     # release the old buffer before asking for the larger one
+        cur = torch.empty(want, dtype=torch.uint8, device='cuda:%d' % dev)
+        _det_planes[dev] = cur
+        _lib.check(_L().synthsr_set_deterministic_workspace(_lib.ptr(cur), cur.numel()), 'set_deterministic_workspace')
+
+
+def _check_wgrad(call, what):
+    """weight-gradient launches: in deterministic mode the call may report that the registered plane buffer is too small
+    (nothing was launched) -- register a larger one and repeat ONCE"""
+    rc = call()
+    if rc == -3 and _deterministic:
+        _register_det_planes(0)
+        rc = call()
+    _lib.check(rc, what)
 
 
 def deterministic_status():
@@ -207,7 +271,7 @@ def pack_conv_weights(w, shape, mode=0, out=None):
     lib = _L()
     Cin, Cout = int(w.shape[3]), int(w.shape[4])
     s3 = _lib.i3(shape[:3])
-    n = lib.synthsr_conv3d_pack(conv_ctx(), None, None, s3, Cin, Cout, mode, None)
+    n = lib.synthsr_conv3d_pack(conv_ctx_host(), None, None, s3, Cin, Cout, mode, None)
     if n < 0:
         _lib.check(int(n), 'conv3d_pack(size)')
     if out is None:
@@ -225,7 +289,7 @@ def pack_conv_weights_ex(w, shape, ci_off, cin, mode=0, up=False, out=None):
     lib = _L()
     cin_total, cout = int(w.shape[3]), int(w.shape[4])
     s3 = _lib.i3(shape[:3])
-    n = lib.synthsr_conv3d_pack_ex(conv_ctx(), None, None, s3, cin_total, int(ci_off), int(cin), cout, mode, int(up), None)
+    n = lib.synthsr_conv3d_pack_ex(conv_ctx_host(), None, None, s3, cin_total, int(ci_off), int(cin), cout, mode, int(up), None)
     if n < 0:
         _lib.check(int(n), 'conv3d_pack_ex(size)')
     if out is None:
@@ -292,13 +356,13 @@ def conv3d_up_wgrad(lo, dout, dwc, dw, ci_off):
     dwc.zero_()
     if lo.dtype == torch.bfloat16:
         with _Timed('conv3d_bf16_up_wgrad', s[:3], s[3], dout.shape[3]):
-            _lib.check(lib.synthsr_conv3d_bf16_up_wgrad(_lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]), int(s[3]),
+            _check_wgrad(lambda: lib.synthsr_conv3d_bf16_up_wgrad(_lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]), int(s[3]),
                                                         int(dout.shape[3]), _lib.stream()), 'conv3d_bf16_up_wgrad')
         _lib.check(lib.synthsr_conv3d_up_unpack(_lib.ptr(dwc), _lib.ptr(dw), int(dw.shape[3]), int(ci_off), int(s[3]),
                                                 int(dout.shape[3]), _lib.stream()), 'conv3d_up_unpack')
         return dw
     with _Timed('conv3d_up_wgrad', s[:3], s[3], dout.shape[3]):
-        _lib.check(lib.synthsr_conv3d_up_wgrad(_lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]), int(s[3]),
+        _check_wgrad(lambda: lib.synthsr_conv3d_up_wgrad(_lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]), int(s[3]),
                                                int(dout.shape[3]), _lib.stream()), 'conv3d_up_wgrad')
     _lib.check(lib.synthsr_conv3d_up_unpack(_lib.ptr(dwc), _lib.ptr(dw), int(dw.shape[3]), int(ci_off), int(s[3]),
                                             int(dout.shape[3]), _lib.stream()), 'conv3d_up_unpack')
@@ -312,12 +376,12 @@ def conv3d_wgrad_part(x, dout, dw, ci_off, dbias=None):
     s = x.shape
     if x.dtype == torch.bfloat16:
         with _Timed('conv3d_bf16_wgrad', s[:3], s[3], dout.shape[3]):
-            _lib.check(lib.synthsr_conv3d_bf16_wgrad_part(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.ptr(dbias),
+            _check_wgrad(lambda: lib.synthsr_conv3d_bf16_wgrad_part(_lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.ptr(dbias),
                                                           _lib.i3(s[:3]), int(dw.shape[3]), int(ci_off), int(s[3]),
                                                           int(dout.shape[3]), _lib.stream()), 'conv3d_bf16_wgrad_part')
         return dw
     with _Timed('conv3d_wgrad', s[:3], s[3], dout.shape[3]):
-        _lib.check(lib.synthsr_conv3d_wgrad_bias(conv_ctx(), _lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.ptr(dbias),
+        _check_wgrad(lambda: lib.synthsr_conv3d_wgrad_bias(conv_ctx(), _lib.ptr(x), _lib.ptr(dout), _lib.ptr(dw), _lib.ptr(dbias),
                                                  _lib.i3(s[:3]), int(dw.shape[3]), int(ci_off), int(s[3]),
                                                  int(dout.shape[3]), _lib.stream()), 'conv3d_wgrad_bias')
     return dw
@@ -825,7 +889,7 @@ def conv3d_stride2_wgrad(x, dy, dw, dwc, dbias=None):
     lib = _L()
     Ci, Co = int(x.shape[3]), int(dy.shape[3])
     dwc.zero_()
-    _lib.check(lib.synthsr_conv3d_up_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dwc), _lib.i3(dy.shape[:3]), Co, Ci,
+    _check_wgrad(lambda: lib.synthsr_conv3d_up_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dwc), _lib.i3(dy.shape[:3]), Co, Ci,
                                            _lib.stream()), 'conv3d_stride2_wgrad')
     _lib.check(lib.synthsr_conv3d_stride_unpack(_lib.ptr(dwc), _lib.ptr(dw), Ci, Co, _lib.stream()), 'stride_unpack')
     if dbias is not None:
@@ -920,7 +984,7 @@ def conv3d_wgrad_bf16(x, dz, dw, dbias=None):
     s = x.shape
     assert x.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16 and dw.dtype == torch.float32
     with _Timed('conv3d_bf16_wgrad', s[:3], s[3], dz.shape[3]):
-        _lib.check(lib.synthsr_conv3d_bf16_wgrad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(dbias), _lib.i3(s[:3]),
+        _check_wgrad(lambda: lib.synthsr_conv3d_bf16_wgrad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(dbias), _lib.i3(s[:3]),
                                                  int(dw.shape[3]), 0, int(s[3]), int(dz.shape[3]), _lib.stream()),
                    'conv3d_bf16_wgrad')
     return dw

@@ -40,6 +40,8 @@ class GradBucketReducer:
         self.hi = self.g.numel()
         self.works = []
         self.n_launched = 0  # collectives issued for this step (diagnostics / tests)
+        self.bytes_launched = 0  # payload handed to all_reduce this step (bench.py: allreduce_bytes_per_step)
+        self.ranges = []  # [lo, hi) of every collective of this step, in issue order (tail first)
 
     def ready(self, offset_lo, force=False):
         """every gradient at flat offset >= offset_lo is final"""
@@ -51,6 +53,8 @@ class GradBucketReducer:
             self.works.append(self.dist.all_reduce(self.g[offset_lo:self.hi], op=self.dist.ReduceOp.SUM,
                                                    group=self.group, async_op=True))
             self.n_launched += 1
+            self.bytes_launched += (self.hi - offset_lo) * self.g.element_size()
+            self.ranges.append((int(offset_lo), int(self.hi)))
             self.hi = offset_lo
 
     def reduce_all(self):

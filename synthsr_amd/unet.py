@@ -224,7 +224,7 @@ class UNet3D:
 
         def plan(shape, cin_e, cout_e, plain):
             out = (ctypes.c_int64 * 8)()
-            _lib.check(lib.synthsr_conv3d_plan(ops.conv_ctx(), _lib.i3(shape), cin_e, cout_e, int(plain), out), 'conv3d_plan')
+            _lib.check(lib.synthsr_conv3d_plan(ops.conv_ctx_host(), _lib.i3(shape), cin_e, cout_e, int(plain), out), 'conv3d_plan')
             return [int(v) for v in out]
 
         def add(c, key, shape, ci_off, cin, mode, up):
@@ -506,6 +506,8 @@ class UNet3D:
     def forward(self, x):
         """x [d0,d1,d2,Cin] -> saves activations; returns the last decoder activation (pre-BN) and its BN"""
         L = self.nb_levels
+        if not self.bf16:   # packed weights of another arithmetic would be read under this one's plans (ADVICE r05)
+            ops.check_layout_epoch(getattr(self, '_jobs_epoch', None), 'UNet3D.forward')
         self.saved = dict(x=[], enc=[], cat=[], dec=[])
         dropping = self.training and self.conv_dropout > 0
         per_sample = dropping and self.batch > 1
@@ -757,6 +759,8 @@ class UNet3D:
         (used to overlap the RCCL all-reduce with the rest of the backward)."""
         L = self.nb_levels
         G = self.grads
+        if not self.bf16:
+            ops.check_layout_epoch(getattr(self, '_jobs_epoch', None), 'UNet3D.backward')
         self._frozen = frozen
         self._pending_bn = None
         if ops._deterministic:  # ordered in-workgroup sums need a fixed channel group per thread (unet_pointwise.hip)

@@ -312,7 +312,8 @@ def single_shot_parity(run, oracle, compare, max_flips=8, loss_of=lambda net: ne
        both device runs window by window (`_pool_choices`) -- differing windows must hold two candidates within 4 ulp of each
        other, at most `max_flips` of them --, the loss kinks the same way (predictions within KINK_ULP), the loss to 2e-6, and with
        identical choices every gradient within GRAD_K * o + GRAD_FLOOR of the deterministic one (accumulation-order noise is one
-       more fp32 evaluation of the graph).
+       more fp32 evaluation of the graph) and compare() against the oracle once more.  With identified flips the oracle is
+       re-aligned to the ATOMICS run's own choices (float32 + float64) and compare() / assert_grads_anchored apply to that.
     Returns (net of the atomics run, number of windows flipped between the two device runs)."""
     import torch
     from synthsr_amd import ops
@@ -407,8 +408,20 @@ def single_shot_parity(run, oracle, compare, max_flips=8, loss_of=lambda net: ne
         print('single_shot_parity: %d identified loss-kink flip(s) on the atomics path (predictions %.1f ulp apart)' % (kidx.numel(), worst))
         flips += int(kidx.numel())
     if flips == 0:
+        compare(net, ref)                  # prediction / loss / BatchNorm statistics of the DEFAULT path against the oracle too
         assert_grads_anchored(net_grads(net, det_grads), g32, g64, tag='atomics run vs deterministic run', extra=net_grads(net))
     else:
-        print('single_shot_parity: %d identified tie flip(s) (max-pool / loss kink) on the atomics path: its gradients legitimately '
-              'differ from the deterministic run' % flips)
+        # the default path took the other side of `flips` identified rounding ties: its gradients legitimately differ from the
+        # deterministic run's, so it gets its OWN oracle -- aligned with the atomics run's pooling masks and kink sides, float32
+        # and float64 -- and the same anchored rule (this branch used to skip the gradient check)
+        print('single_shot_parity: %d identified tie flip(s) (max-pool / loss kink) on the atomics path: oracle re-aligned to the '
+              "atomics run's own choices" % flips)
+        atom_pool = [c for n_ in pool_nets(net) for c in _pool_choices(n_)]
+        atom_kink = (a_pr, a_dp)
+        ref_a = aligned_oracle(atom_pool, atom_kink)
+        with U.compute_dtype(torch.float64):
+            ref64_a = aligned_oracle(atom_pool, atom_kink)
+        compare(net, ref_a)
+        assert_grads_anchored(net_grads(net), {nm: ref_a[0][nm].grad for nm, _, _ in net.specs},
+                              {nm: ref64_a[0][nm].grad for nm, _, _ in net.specs}, tag='atomics run (own oracle alignment)')
     return net, flips

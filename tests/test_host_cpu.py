@@ -153,7 +153,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), 'missing export %s' % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib.synthsr_abi_version.restype = ctypes.c_int
-    assert lib.synthsr_abi_version() == 1
+    assert lib.synthsr_abi_version() == 2
     # argument validation happens before any HIP call: usable without a GPU
     lib = _lib.load()
     big = _lib.i3([160, 160, 160])
@@ -165,6 +165,10 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.synthsr_conv3d_pack(None, None, None, big, 0, 24, 0, None) == -1
     bad = _lib.ConvCtx(arithmetic=3)
     assert lib.synthsr_conv3d_pack(ctypes.byref(bad), None, None, big, 24, 24, 0, None) == -1
+    for kw in (dict(reserved0=1), dict(reserved=(ctypes.c_int * 2)(0, 7)), dict(workspace_bytes=16)):   # reserved fields are
+        bad = _lib.ConvCtx(arithmetic=1, **kw)                                # checked; a workspace size needs a workspace
+        assert lib.synthsr_conv3d_pack(ctypes.byref(bad), None, None, big, 24, 24, 0, None) == -1, kw
+    assert ctypes.sizeof(_lib.ConvCtx) == 32 and int(lib.synthsr_conv_workspace_bytes()) == 16 << 20
 
 
 def test_two_conv_contexts_with_different_arithmetic_coexist():
@@ -373,16 +377,64 @@ print('OK', rank)
 '''
 
 
-def test_grad_bucket_reducer_two_ranks_gloo(tmp_path):
+# world size 8 = BASELINE.json configs[2]: bucket order (tail first, contiguous, the whole buffer exactly once), the 1 / world
+# gradient scale, and -- the point of data parallelism -- identical weights on every rank after the Keras-Adam update of the
+# averaged gradient (oracle.unet_ref.adam_keras: the restated formula the HIP adam_kernel is tested against)
+_GLOO_WORKER_8 = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from synthsr_amd.training import GradBucketReducer
+from oracle import unet_ref as U
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 100003
+gen = torch.Generator().manual_seed(100 + rank)
+g = torch.randn(n, generator=gen)                       # every rank its own gradient
+mine = g.clone()
+everyone = [torch.empty(n) for _ in range(world)]
+dist.all_gather(everyone, mine)
+red = GradBucketReducer(g, bucket_elems=16384)
+red.start()
+for lo in (99000, 90000, 83000, 60000, 59999, 30000, 12000, 100):
+    red.ready(lo)
+scale = red.finish()
+assert abs(scale - 1.0 / world) < 1e-12
+assert all(a[0] == b[1] for a, b in zip(red.ranges, red.ranges[1:])), red.ranges           # tail first, contiguous
+assert red.ranges[0][1] == n and red.ranges[-1][0] == 0 and red.bytes_launched == 4 * n      # the whole buffer, once
+assert all(hi - lo >= 16384 for lo, hi in red.ranges[:-1])                                   # full buckets but the last
+exp = torch.stack(everyone).double().sum(0)
+assert float((g.double() - exp).abs().max()) < 1e-5, float((g.double() - exp).abs().max())
+p = torch.full((n,), float(rank))                        # weights: rank 0's, broadcast
+dist.broadcast(p, 0)
+p2, m, v = U.adam_keras(p, g * scale, torch.zeros(n), torch.zeros(n), 1, lr=1e-3)
+digest = torch.stack([p2.double().sum(), p2.double().abs().max(), m.double().sum(), v.double().sum()])
+lo_, hi_ = digest.clone(), digest.clone()
+dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+assert torch.equal(lo_, hi_), (lo_, hi_)                 # bit-identical weights and moments on all ranks
+dist.barrier()
+print('OK', rank)
+'''
+
+
+def _run_gloo_worker(tmp_path, text, world):
     script = tmp_path / 'worker.py'
-    script.write_text(_GLOO_WORKER)
-    port = 29500 + (os.getpid() % 2000)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
+    script.write_text(text)
+    port = 29500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr',
            '127.0.0.1', '--master-port', str(port), str(script), REPO]
     env = dict(os.environ, OMP_NUM_THREADS='1')
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count('OK') == 2
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count('OK') == world
+
+
+def test_grad_bucket_reducer_two_ranks_gloo(tmp_path):
+    _run_gloo_worker(tmp_path, _GLOO_WORKER, 2)
+
+
+def test_grad_bucket_reducer_eight_ranks_gloo(tmp_path):
+    _run_gloo_worker(tmp_path, _GLOO_WORKER_8, 8)
 
 
 @pytest.mark.parametrize('script', ['training', 'predict_command_line', 'predict_command_line_hyperfine'])
@@ -550,6 +602,16 @@ def test_bench_self_launch_rendezvous_cpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['world_size'] == 2
+    # configs[2]: eight ranks; the record carries what one step's gradient all-reduce consists of
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '8', '--rendezvous-only'], capture_output=True,
+                       text=True, timeout=900, env=dict(env, OMP_NUM_THREADS='1'), cwd=repo)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 8 and d['n_ranks_seen'] == 8 and d['world_size'] == 8 and d['backend'] == 'gloo'
+    assert d['rccl_version'] is None                                     # only filled when the collectives run over RCCL
+    assert d['allreduce_bytes_per_step'] == 4 * 13240489                 # 52.96 MB: the flat gradient buffer, once
+    assert d['allreduce_covers_buffer_once'] and d['allreduce_tail_first'] and d['allreduce_identical_on_every_rank']
+    assert d['allreduce_buckets_per_step'] >= 2 and abs(d['gradient_scale'] - 0.125) < 1e-12
     r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--rendezvous-only'], capture_output=True,
                        text=True, timeout=600, env=dict(env, WORLD_SIZE='1', RANK='0'), cwd=repo)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stdout + r.stderr)
@@ -565,8 +627,8 @@ def test_public_headers_are_plain_c(tmp_path):
         pytest.skip('no gcc')
     src = tmp_path / 'hdr.c'
     src.write_text('#include "synthsr_hip.h"\n#include "synthsr_hip_tuning.h"\n'
-                   'int main(void) { synthsr_conv_ctx c = { SYNTHSR_ARITH_SPLIT9, {0} }; synthsr_stream_t s = 0; (void)s;\n'
-                   '  return c.arithmetic == 2 && sizeof(c) == 8 * sizeof(int) ? 0 : 1; }\n')
+                   'int main(void) { synthsr_conv_ctx c = { SYNTHSR_ARITH_SPLIT9, 0, 0, 0, {0, 0} }; synthsr_stream_t s = 0; (void)s;\n'
+                   '  return c.arithmetic == 2 && c.workspace == 0 && sizeof(c) == 32 && SYNTHSR_EWORKSPACE == -3 ? 0 : 1; }\n')
     r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(REPO, 'include'), str(src), '-o',
                         str(tmp_path / 'hdr')], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

@@ -36,7 +36,7 @@ def _is_split(shape, cin, cout):
     from synthsr_amd import _lib
     out = (ctypes.c_int64 * 8)()
     from synthsr_amd import ops
-    _lib.check(_lib.load().synthsr_conv3d_plan(ops.conv_ctx(), _lib.i3(shape), cin, cout, 1, out), 'plan')
+    _lib.check(_lib.load().synthsr_conv3d_plan(ops.conv_ctx_host(), _lib.i3(shape), cin, cout, 1, out), 'plan')
     return int(out[2]) <= -100
 
 

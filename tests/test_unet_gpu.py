@@ -588,301 +588,6 @@ def test_unet_other_losses_gradients_vs_autograd(T, kind, crop):
     x, target = tensors['x'], tensors['target']
     net.update_moving_stats()
     out = net.predict(x.cuda())
-    assert torch.isfinite(out).all() and list(out.shape) == list(shape) + [1]
-
-
-def test_training_reduces_loss(T):
-    """a few steps of the full loop (generator -> U-Net -> Adam) on a tiny volume: loss is finite and decreases on a
-    fixed sample"""
-    torch = T
-    from synthsr_amd.brain_generator import BrainGenerator
-    from synthsr_amd.training import Trainer
-    from synthsr_amd.unet import unet
-    from synthsr_amd.synthetic import (synthetic_label_pool, GENERATION_LABELS, GENERATION_CLASSES, PRIOR_MEANS_T1_HR,
-                                       PRIOR_STDS_T1_HR)
-    pool = synthetic_label_pool(2, (32, 32, 32), 5)
-    bg = BrainGenerator(None, PRIOR_MEANS_T1_HR, PRIOR_STDS_T1_HR, 'normal', GENERATION_LABELS,
-                        generation_classes=GENERATION_CLASSES, output_shape=32, output_div_by_n=8, nonlin_std=4.,
-                        nonlin_shape_factor=.125, bias_shape_factor=.125, build_reliability_maps=True, downsample=True,
-                        shearing_bounds=.02, label_maps=pool, rng=np.random.default_rng(0))
-    net = unet(24, bg.model_output_shape, 3, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
-               batch_norm=-1, seed=1)
-    tr = Trainer(bg, net, lr=1e-3)
-    inputs = next(bg.model_inputs_generator)
-    draws = bg.labels_to_image_model.sample_draws()
-    losses = [tr.step(inputs, draws).item() for _ in range(8)]
-    assert all(np.isfinite(losses))
-    assert losses[-1] < losses[0]
-
-
-def test_segmentation_loss_with_the_laplace_head_vs_autograd(T):
-    """regression_metric='laplace' together with the segmentation-regularised loss (one regression target: a 2-channel head,
-    SynthSR/metrics_model.py:33-49): `predicted_image` -- what the frozen segmentation network sees -- is the INTENSITY
-    channel (:53), so the Dice gradient lands on head channel 0 only.  Loss values and every gradient of the trained
-    network against autograd through the oracle (single shot, conftest.single_shot_parity)."""
-    torch = T
-    from synthsr_amd.unet import unet
-    from synthsr_amd.seg_loss import SegmentationRegulariser
-    from oracle import unet_ref as U
-    shape, levels, w = (16, 24, 32), 3, 0.25
-    gen_labels = np.array([0, 14, 2, 3, 41, 42, 17])
-    seg_labels = np.array([0, 2, 3, 4, 41, 42, 43, 17, 53])
-    equivalency = np.array([0, 2, 3, 3, 41, 42, 42, 17, 17])
-    g = torch.Generator().manual_seed(5)
-    x = torch.rand(*shape, 2, generator=g)
-    target = torch.rand(*shape, generator=g)
-    seg_target = torch.randint(0, len(gen_labels), shape, generator=g, dtype=torch.int32)
-
-    def nets():
-        net = unet(24, list(shape) + [2], levels, 3, 2, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
-                   final_pred_activation='linear', seed=3)
-        segnet = unet(24, list(shape) + [1], levels, 3, len(seg_labels), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
-                      activation='elu', final_pred_activation='softmax', seed=4)
-        return net, segnet
-
-    def run():
-        net, segnet = nets()
-        reg = SegmentationRegulariser(segnet, gen_labels, equivalency, w)
-        loss, pred = net.loss(x.cuda(), target.cuda().reshape(-1), 'laplace', want_pred=True)
-        net.test_loss = loss.clone()
-        net.test_dice = reg(pred, seg_target.cuda(), net.dpred, None, head_channels=2).clone()
-        net.backward()
-        net.test_segnet = segnet
-        return net
-
-    def oracle(net, nudge):
-        P = {k: v.clone().float().requires_grad_(True) for k, v in net.state_dict().items() if 'moving' not in k}
-        Pseg = {k: v.clone().float() for k, v in net.test_segnet.state_dict().items()}
-        pin, pin_seg, n1 = [], [], levels - 1
-        pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, pool_inputs=pin,
-                            pool_nudge=None if nudge is None else nudge[:n1])
-        lap = U.regression_loss(pr, target[..., None], 'laplace')
-        dref = U.seg_regularisation(pr[..., 0], seg_target, Pseg, net.test_segnet.prefix, levels, 2, gen_labels, equivalency,
-                                    pool_inputs=pin_seg, pool_nudge=None if nudge is None else nudge[n1:],
-                                    bn_batch_stats=True)
-        (lap + w * dref).backward()
-        return (P, lap.detach(), dref.detach()), pin + pin_seg
-
-    def compare(net, ref):
-        P, lap, dref = ref
-        assert abs(float(net.test_loss.item()) - float(lap)) < 2e-5 * max(1.0, abs(float(lap)))
-        assert abs(float(net.test_dice.item()) - float(dref)) < 2e-5
-        # (every parameter gradient: the float64-anchored rule of conftest.single_shot_parity)
-
-    single_shot_parity(run, oracle, compare, loss_of=lambda n_: n_.test_loss, pool_nets=lambda n_: [n_, n_.test_segnet])
-    # two regression targets: refused like the reference's graph (the segmentation network takes ONE channel)
-    from synthsr_amd.training import Trainer
-    net4 = unet(24, list(shape) + [2], levels, 3, 4, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
-                final_pred_activation='linear', seed=3)
-
-    class _BG:
-        labels_to_image_model = None
-    with pytest.raises(ValueError):
-        Trainer(_BG(), net4, regression_metric='laplace', seg_regulariser=object())
-
-
-@pytest.mark.parametrize('fs_header,clip,crop,frozen_bn,seg_drop', [
-    (False, False, None, 'batch', 0.), (True, True, None, 'inference', 0.), (True, False, (12, 16, 20), 'batch', 0.),
-    (False, True, (8, 24, 12), 'inference', 0.), (True, True, (8, 24, 12), 'batch', 0.),
-    # the frozen network built with conv_dropout (SynthSR/training.py:381): its Dropout layers are active in the learning phase
-    (False, False, None, 'batch', .3), (True, True, (8, 24, 12), 'batch', .3)])
-def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop, frozen_bn, seg_drop):
-    """SynthSR/metrics_model.py:136-215: L1 + w * Dice(frozen segmentation U-Net(prediction), label map).  Loss value and
-    every gradient of the TRAINED network against torch autograd through the oracle; the frozen network's BatchNorm on batch
-    statistics (Keras' learning phase, the default) or on its moving averages.
-    Single shot in deterministic mode; on the atomics path the pooling choices of BOTH networks are compared
-    (conftest.single_shot_parity)"""
-    torch = T
-    from synthsr_amd.unet import unet
-    from synthsr_amd.seg_loss import SegmentationRegulariser
-    from oracle import unet_ref as U
-    shape, levels = (16, 24, 32), 3
-    gen_labels = np.array([0, 14, 2, 3, 41, 42, 17])
-    seg_labels = np.array([0, 2, 3, 4, 41, 42, 43, 17, 53])          # labels the segmentation net predicts
-    equivalency = np.array([0, 2, 3, 3, 41, 42, 42, 17, 17])        # ... mapped onto generation-label VALUES (merges)
-    segshape = (shape[0], shape[2], shape[1]) if fs_header else shape
-    g = torch.Generator().manual_seed(0)
-    moving = None
-    m, M = (0.1, 0.7) if clip else (None, None)
-    w = 0.25
-
-    def nets():
-        net = unet(24, list(shape) + [2], levels, 3, 1, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
-                   final_pred_activation='linear', seed=3)
-        segnet = unet(24, list(segshape) + [1], levels, 3, len(seg_labels), feat_mult=2, nb_conv_per_level=2, batch_norm=-1,
-                      activation='elu', final_pred_activation='softmax', seed=4, conv_dropout=seg_drop)
-        return net, segnet
-
-    net, segnet = nets()
-    seg_scales = None
-    if seg_drop:
-        rng = np.random.default_rng(21)
-        seg_scales = {}
-        for c in segnet.all_convs():
-            keep = rng.random(c['cout']) >= seg_drop
-            keep[:2] = [False, True]
-            seg_scales[c['name']] = (keep / (1.0 - seg_drop)).astype(np.float32)
-    moving = torch.rand(segnet.bn_moving.shape, generator=g) * 0.5 + 0.25
-    x = torch.rand(*shape, 2, generator=g)
-    target = torch.rand(*shape, generator=g)
-    seg_target = torch.randint(0, len(gen_labels), shape, generator=g, dtype=torch.int32)  # indices, cf. the module docstring
-    del net, segnet
-
-    def make_run(rel_weight, dice_only):
-        def run():
-            net, segnet = nets()
-            segnet.bn_moving.copy_(moving.to(segnet.device))
-            reg = SegmentationRegulariser(segnet, gen_labels, equivalency, rel_weight, m=m, M=M, fs_header=fs_header,
-                                          frozen_bn=frozen_bn)
-            loss, pred = net.loss_l1(x.cuda(), target.cuda().reshape(-1), want_pred=True)
-            if dice_only:  # image-loss gradient zeroed
-                net.dpred.zero_()
-            net.test_loss = loss.clone()
-            if seg_scales is not None:
-                segnet.set_dropout_scales(seg_scales)
-            net.test_dice = reg(pred, seg_target.cuda(), net.dpred, crop).clone()
-            net.backward()
-            net.test_segnet = segnet
-            return net
-        return run
-
-    def make_oracle(dice_only):
-        def oracle(net, nudge):          # nudge / pool inputs: the pooled levels of the trained net, then of the frozen one
-            P = {k: v.clone().float().requires_grad_(True) for k, v in net.state_dict().items() if 'moving' not in k}
-            Pseg = {k: v.clone().float() for k, v in net.test_segnet.state_dict().items()}
-            pin, pin_seg = [], []
-            n1 = levels - 1
-            pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True, pool_inputs=pin,
-                                pool_nudge=None if nudge is None else nudge[:n1])[..., 0]
-            l1 = (pr - target).abs().mean()
-            dref = U.seg_regularisation(pr, seg_target, Pseg, net.test_segnet.prefix, levels, 2, gen_labels, equivalency, m=m,
-                                        M=M, fs_header=fs_header, loss_cropping=crop, pool_inputs=pin_seg,
-                                        pool_nudge=None if nudge is None else nudge[n1:],
-                                        bn_batch_stats=frozen_bn == 'batch',
-                                        dropout=None if seg_scales is None else {k: torch.from_numpy(v)
-                                                                                 for k, v in seg_scales.items()})
-            (dref if dice_only else l1 + w * dref).backward()
-            return (P, l1.detach(), dref.detach()), pin + pin_seg
-        return oracle
-
-    def compare_total(net, ref):
-        P, l1, dref = ref
-        assert abs(float(net.test_loss.item()) - float(l1)) < 1e-5
-        assert abs(float(net.test_dice.item()) - float(dref)) < 2e-5, (float(net.test_dice.item()), float(dref))
-        # (every parameter gradient: the float64-anchored rule of conftest.single_shot_parity)
-
-    def compare_dice(net, ref):
-        # the gradients by the float64-anchored rule; the head bias of the Dice term alone is a sum of cancelling contributions
-        # (its range is ~0: the rule measures it against 1e-3 of the largest gradient), so also absolutely:
-        hb = net.view(net.head['b'], net.grads).cpu()
-        assert float((hb - ref[0][net.head['b']].grad).abs().max()) < 1e-5
-
-    both = lambda net: [net, net.test_segnet]
-    single_shot_parity(make_run(w, False), make_oracle(False), compare_total, pool_nets=both)
-    # the Dice term alone (it is ~1 % of the total gradient here): weight 1
-    single_shot_parity(make_run(1.0, True), make_oracle(True), compare_dice, pool_nets=both)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('kind,crop,with_res,n', [('l1', None, False, 1), ('l1', (8, 6, 12), True, 1), ('l2', None, True, 1),
-                                                  ('l2', (10, 12, 4), False, 1), ('laplace', None, False, 1),
-                                                  ('laplace', (8, 6, 12), True, 1), ('l1', (8, 6, 12), True, 2),
-                                                  ('l2', None, True, 3), ('l1', None, False, 4),
-                                                  ('laplace', (8, 6, 12), True, 2)])
-def test_head_regression_losses_vs_autograd(T, kind, crop, with_res, n):
-    """synthsr_head_loss_fwd / synthsr_head_bwd_multi (metrics_model.py:30-132: l1, l2, laplace, loss_cropping, residual
-    channel) against the oracle's regression_loss under autograd.  Tolerance 2e-5 relative (fp32 sums of 3k terms)."""
-    torch = T
-    from synthsr_amd import ops
-    from oracle import unet_ref as U
-    g = torch.Generator().manual_seed(21)
-    shape, C = (10, 12, 14), 24
-    K = 2 * n if kind == 'laplace' else n
-    x = torch.randn(*shape, C, generator=g)
-    mean, var = torch.randn(C, generator=g) * .1, torch.rand(C, generator=g) + .5
-    gamma, beta = torch.rand(C, generator=g) + .5, torch.randn(C, generator=g) * .1
-    w = (torch.randn(C, K, generator=g) * .2).requires_grad_(True)
-    b = (torch.randn(K, generator=g) * .1).requires_grad_(True)
-    target = torch.rand(*shape, n, generator=g)
-    image = torch.rand(*shape, 5, generator=g)
-    res_ch = [3, 1, 4, 0][:n]
-    bn = ((x - mean) * torch.rsqrt(var + ops.BN_EPS) * gamma + beta).requires_grad_(True)
-    pred_ref = bn @ w + b
-    res = image[..., res_ch] if with_res else None
-    loss_ref = U.regression_loss(pred_ref, target, kind, crop, res)
-    loss_ref.backward()
-    stats = torch.cat([mean, var]).cuda()
-    xd = x.cuda()
-    loss = torch.zeros(1, device='cuda')
-    pred = torch.empty(x[..., 0].numel() * K, device='cuda')
-    dpred = torch.empty_like(pred)
-    box = None if crop is None else ([int((s - c) / 2) for s, c in zip(shape, crop)], list(crop))
-    ops.head_loss_fwd(xd, stats, gamma.cuda(), beta.cuda(), w.detach().cuda(), b.detach().cuda(), target.reshape(-1).cuda(),
-                      loss, kind=kind, crop=box, pred=pred, dpred=dpred, residual=image.cuda() if with_res else None,
-                      res_stride=5, res_off=res_ch if n > 1 else res_ch[0])
-    expect = pred_ref.detach().clone()
-    if with_res:
-        expect[..., :n] += res
-    close(pred.view(*shape, K), expect, 2e-5, 'pred')
-    assert abs(loss.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
-    # dloss/dpred: recover it from the autograd gradient of bn (dbn = dpred @ w^T) through head_bwd / head_bwd_multi
-    dw, db = torch.zeros(C, K, device='cuda'), torch.zeros(K, device='cuda')
-    dbn = torch.empty_like(xd)
-    if K == 1:
-        ops.head_bwd(dpred, xd, stats, gamma.cuda(), beta.cuda(), w.detach().cuda().view(-1), dbn, dw.view(-1), db)
-    else:
-        ops.head_bwd_multi(dpred, xd, stats, gamma.cuda(), beta.cuda(), w.detach().cuda(), dbn, dw, db)
-    close(dbn, bn.grad, 2e-5, 'dbn')
-    for got, ref, nm in ((dw, w.grad, 'dw'), (db, b.grad, 'db')):   # sums of +-1/N can cancel to ~0: absolute floor
-        err = (got.cpu().double() - ref.double()).abs().max().item()
-        assert err < 2e-5 * max(ref.abs().max().item(), 1e-2), '%s abs err %.3e' % (nm, err)
-    if crop is not None:  # no gradient outside the box
-        d = dpred.view(*shape, K).clone()
-        lo, sz = box
-        d[lo[0]:lo[0] + sz[0], lo[1]:lo[1] + sz[1], lo[2]:lo[2] + sz[2]] = 0
-        assert not d.any()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('kind,crop', [('l2', (8, 8, 16)), ('laplace', None), ('laplace', (16, 8, 8)), ('ssim', None),
-                                       ('ssim', (12, 14, 24))])
-def test_unet_other_losses_gradients_vs_autograd(T, kind, crop):
-    """whole network under regression_metric='l2' / 'laplace' (2-channel head) and loss_cropping vs the oracle"""
-    torch = T
-    from synthsr_amd.unet import unet
-    from oracle import unet_ref as U
-    shape, cin, levels = (16, 16, 32), 2, 3
-    K = 2 if kind == 'laplace' else 1
-    net = unet(nb_features=24, input_shape=list(shape) + [cin], nb_levels=levels, conv_size=3, nb_labels=K, feat_mult=2,
-               nb_conv_per_level=2, final_pred_activation='linear', batch_norm=-1, activation='elu', seed=5)
-    g = torch.Generator().manual_seed(12)
-    for nm, v in net.named_parameters():
-        if nm.endswith('/gamma'):
-            v.copy_(torch.rand(v.shape, generator=g) + .5)
-        elif nm.endswith('/beta') or nm.endswith('/bias'):
-            v.copy_(torch.randn(v.shape, generator=g) * .1)
-    net.repack()
-    x = torch.rand(*shape, cin, generator=g)
-    target = torch.rand(*shape, 1, generator=g)
-    loss, pred = net.loss(x.cuda(), target.reshape(-1).cuda(), kind, crop, residual=x.cuda(), res_stride=cin, res_off=1,
-                          want_pred=True)
-    pred = pred.clone()
-    net.backward()
-    P = _copy_params(net, torch)
-    pr = U.unet_forward(x, P, net.prefix, levels, 2, training=True)
-    lr = U.regression_loss(pr, target, kind, crop, x[..., 1:2])
-    lr.backward()
-    expect = pr.detach().clone()
-    expect[..., :1] += x[..., 1:2]
-    close(pred.view(*shape, K), expect, 5e-4, 'prediction')
-    assert abs(loss.item() - lr.item()) < 5e-5 * max(1.0, abs(lr.item()))
-    for nm, _, _ in net.specs:
-        got = net.view(nm, net.grads).cpu().double()
-        ref = P[nm].grad.double().reshape(got.shape)
-        err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
-        assert err < 5e-3, '%s grad rel err %.3e' % (nm, err)
-    net.update_moving_stats()
-    out = net.predict(x.cuda())
     assert torch.isfinite(out).all() and list(out.shape) == list(shape) + [K]
     with pytest.raises(ValueError):
         net.loss(x.cuda(), target.reshape(-1).cuda(), 'l1' if K == 2 else 'laplace')

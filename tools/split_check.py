@@ -20,7 +20,7 @@ def set_split(on):
 
 def plan_is_split(shape, cin, cout):
     out = (ctypes.c_int64 * 8)()
-    _lib.check(_lib.load().synthsr_conv3d_plan(ops.conv_ctx(), _lib.i3(shape), cin, cout, 1, out), 'plan')
+    _lib.check(_lib.load().synthsr_conv3d_plan(ops.conv_ctx_host(), _lib.i3(shape), cin, cout, 1, out), 'plan')
     return int(out[2]) <= -100
 
 
