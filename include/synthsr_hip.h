@@ -253,7 +253,8 @@ int synthsr_conv3d_wgrad_ex(const synthsr_conv_ctx* ctx, const float* in, const 
                             int Cin_total, int ci_off, int Cin, int Cout, synthsr_stream_t stream);
 
 /* launch geometry the kernels will use: out = {chunk width CK, #ci chunks, n-tiles per workgroup (0: 4x4x1-MFMA layout of
- * the Cout = 24 layers, -Cin: first-layer layout), #n chunks, MT, ksplit, NV, floats per packed weight set}.
+ * the Cout = 24 layers, -Cin: first-layer layout), #n chunks, MT, ksplit (split arithmetic: 2 = the 512-thread split-K-halves
+ * kernel of the layers that leave CUs single-occupied), NV, floats per packed weight set}.
  * kind: 1 plain conv; 2 forward parity convs of a folded decoder conv; 0 their data gradient */
 int synthsr_conv3d_plan(const synthsr_conv_ctx* ctx, const int shape[3], int CinE, int CoutE, int kind, int64_t out[8]);
 /* 1 / 0: whether the weight gradient of a plain 3x3x3 conv of this shape runs on the split kernels under this context (the

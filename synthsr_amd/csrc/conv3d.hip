@@ -2973,6 +2973,7 @@ extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, fl
                                int ci_off, int Cin, int Cout, int nprod, hipStream_t st);
 extern "C" int syn_split_upfwd(const float* lo, const float* wp, const float* bias, const float* addend, float* out,
                                const int s[3], int Cin, int Cout, int mt, int act, int nprod, hipStream_t st);
+extern "C" int syn_split_fwd_halves(const int s[3], int Cin, int nchunks, int stacked, int nprod);
 extern "C" int syn_split_fwd(const float* in, const float* wp, const float* bias, const float* addend, float* out,
                              const int s[3], int Cin, int Cout, int mt, int nchunks, int act, float* stats, float* partial,
                              int upm, int stacked, int nprod, hipStream_t st);
@@ -3828,7 +3829,7 @@ int synthsr_conv3d_plan(const synthsr_conv_ctx* ctx, const int shape[3], int Cin
   out[2] = pl.pack_nt();
   out[3] = pl.nchunks;
   out[4] = pl.mt;
-  out[5] = pl.ksplit;
+  out[5] = (pl.split == 1 && syn_split_fwd_halves(shape, CinE, pl.nchunks, pl.stacked, cfg().nprod)) ? 2 : pl.ksplit;
   out[6] = pl.nv;
   out[7] = pl.count();
   return SYNTHSR_OK;

@@ -509,15 +509,24 @@ constexpr int BUF2 = 3 * PLANE2;
 static_assert(PLANE2 >= PLANE, "padded plane holds the halo image");
 constexpr int STK_TILES = 5;
 
-template <int MT, bool ST, int EPI, bool STK>
-__global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFwdArgs a) {
+// KS = 2 (round 6; launches with at most one workgroup per CU, i.e. the 20^3 layers: 200 or 100 units on 256 CUs): a 512-thread
+// workgroup whose two halves (waves 0-3 | 4-7) take the EVEN | ODD input-channel chunks of the same tile and co-chunk, each half
+// with its own double-buffered image; at the end of a tile the halves exchange half of their accumulators through LDS (the image
+// buffer that was consumed last) and each runs the epilogue of two of the four y rows.  The serial chain of a workgroup halves
+// (24 -> 12 chunks at 192 input channels) without staging anything twice, and every SIMD holds two waves instead of one.
+template <int MT, bool ST, int EPI, bool STK, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_kernel(const SplitFwdArgs a) {
+  static_assert(KS == 1 || (KS == 2 && !STK), "split-K halves: the plain layout");
   constexpr int NSTEP = NSTEP27;
-  constexpr int NITEM = TY * MT;            // epilogue items: one f32x4 (4 channels of a voxel) per lane each
+  constexpr int TYE = TY / KS;              // y rows whose epilogue a wave runs (KS = 2: each half takes two of the four)
+  constexpr int NITEM = TYE * MT;           // epilogue items: one f32x4 (4 channels of a voxel) per lane each
   constexpr int NWT = STK ? STK_TILES : MT; // weight row tiles per piece set (STK: of the stacked set) = accumulators per row
   static_assert(!ST || EPI <= 1, "statistics belong to plain forward convs");
   static_assert(!STK || MT == 2, "the stacked layout is the 24-channel one (two output tiles)");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // wave-uniform
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // roles inside the half
+  unsigned char* const ldsh = lds + half * (2 * BUF2);                   // the half's own pair of images
   const int m = lane & 15, g = lane >> 4;
   const int chunk = blockIdx.y, nchunks = gridDim.y;
   const TileWalk walk = tile_walk(a.ntiles);
@@ -621,8 +630,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
   const uint32_t ystep = (uint32_t)(D2 * Cout * 4);
 
   // the bias of this co-chunk sits in LDS behind the images (an epilogue item reads its four channels from there)
-  float* lbias = reinterpret_cast<float*>(lds + 2 * BUF2);
-  if (tid < MT * 16) {
+  float* lbias = reinterpret_cast<float*>(lds + KS * 2 * BUF2);
+  if ((int)threadIdx.x < MT * 16) {
     const int co = chunk * MT * 16 + tid;
     lbias[tid] = (a.bias && co < Cout) ? a.bias[co] : 0.f;
   }
@@ -659,17 +668,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
   // epilogue item j = (mt, y) of the finished tile, in three segments; the addend of item j + 1 is requested before item j is
   // worked on (two slots: its HBM latency hides behind an item's ELU / stores instead of being exposed eight times per tile)
   auto epi0 = [&](int j, uint32_t row0, uint32_t yok) {
-    const int mt = j / TY, y = j % TY;
+    const int mt = j / TYE, y = j % TYE;
     const int co = (chunk * MT + mt) * 16 + 4 * g;
 #if SYN_ABL & 32
     yok = 0;
 #endif
-    eoff[j & 1] = (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;
+    eoff[j & 1] = (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;   // (row0, yok: of the half's rows)
     if constexpr (EPI >= 2)
       eb[j & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)eoff[j & 1], 0, 0));
   };
   auto epi1 = [&](int j) {
-    const int mt = j / TY, y = j % TY;
+    const int mt = j / TYE, y = j % TYE;
     const f32x4 bj = *reinterpret_cast<const f32x4*>(lbias + mt * 16 + 4 * g);
     f32x4 v;
     if constexpr (STK) {
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
   auto epi2 = [&](int j) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), rout, (int)eoff[j & 1], 0, 0);
     if constexpr (ST) {
-      const int mt = j / TY;
+      const int mt = j / TYE;
       const float w = eoff[j & 1] != OOB ? 1.f : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -715,21 +724,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
 
   int buf = 0;
   if (walk.pos < walk.end) {
-    halo_where(walk.pos, 0, false);
+    halo_where(walk.pos, half, false);
     load_pieces(P0{}, P6{});
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       conv_a(i);
       conv_b(i);
-      conv_c(i, lds);
+      conv_c(i, ldsh);
     }
     if constexpr (STK) {
 #pragma unroll
       for (int tl = 0; tl < STK_TILES; ++tl) wload_t(wbase, 0, tl);
     } else {
-      wload(wbase, 0, 0);
-      wload(wbase, 0, 1);
-      wload(wbase, 0, 2);
+      wload(wbase + (int64_t)half * WCHUNK, 0, 0);
+      wload(wbase + (int64_t)half * WCHUNK, 0, 1);
+      wload(wbase + (int64_t)half * WCHUNK, 0, 2);
     }
     wfirst = false;
   }
@@ -738,16 +747,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
     for (int y = 0; y < TY; ++y)
 #pragma unroll
       for (int tl = 0; tl < NWT; ++tl) acc[y][tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cc = 0; cc < ncc; ++cc) {
+    for (int cc = half; cc < ncc; cc += KS) {   // (KS = 2: ncc is even, both halves run the same number of chunks)
       __syncthreads();  // image `buf` is complete; nobody reads the other one any more
-      const bool last_cc = cc + 1 == ncc;
+      const bool last_cc = cc + KS >= ncc;
       const bool more = !last_cc || t + walk.stride < walk.end;
-      halo_where(last_cc ? (more ? t + walk.stride : t) : t, last_cc ? 0 : cc + 1, !more);
+      halo_where(last_cc ? (more ? t + walk.stride : t) : t, last_cc ? half : cc + KS, !more);
       load_pieces(P0{}, P4{});
       const u32x4* wf = wbase + (int64_t)cc * WCHUNK;
-      const u32x4* wf_next = wbase + (int64_t)(last_cc ? 0 : cc + 1) * WCHUNK;
-      const unsigned char* img = lds + buf * BUF2 + lbase;
-      unsigned char* nimg = lds + (buf ^ 1) * BUF2;
+      const u32x4* wf_next = wbase + (int64_t)(last_cc ? half : cc + KS) * WCHUNK;
+      const unsigned char* img = ldsh + buf * BUF2 + lbase;
+      unsigned char* nimg = ldsh + (buf ^ 1) * BUF2;
       auto xload = [&](int s, int q) {
 #if SYN_ABL & 16
         if (s != 0) return;
@@ -869,12 +878,34 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
     // ---- epilogue: lane (m, g): channels (chunk*MT + mt)*16 + 4g + i of voxel (z0 + wave, y0 + y, x0 + xv)
     int z0, y0, x0;
     tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    if constexpr (KS == 2) {
+      // the halves' partial sums meet: rows 2, 3 of half 0 and rows 0, 1 of half 1 travel through the image buffer that was
+      // consumed last (`buf ^ 1` after the flip: the NEXT tile's second chunk will be converted into it after the next barrier;
+      // `buf` already holds the next tile's first chunk), and half 1 ends with its rows 2, 3 in the slots the epilogue reads
+      __syncthreads();  // every wave has left the K loop: nobody reads that image any more
+      f32x4* xch = reinterpret_cast<f32x4*>(ldsh + (buf ^ 1) * BUF2) + tid;
+#pragma unroll
+      for (int y = 0; y < TYE; ++y)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xch[(y * MT + mt) * 256] = half ? acc[y][mt] : acc[y + TYE][mt];
+      __syncthreads();
+      const f32x4* rcv = reinterpret_cast<const f32x4*>(lds + (half ^ 1) * (2 * BUF2) + (buf ^ 1) * BUF2) + tid;
+#pragma unroll
+      for (int y = 0; y < TYE; ++y)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 mine = half ? acc[y + TYE][mt] : acc[y][mt];
+          const f32x4 theirs = rcv[(y * MT + mt) * 256];
+          acc[y][mt] = half ? theirs + mine : mine + theirs;   // even chunks + odd chunks, the same order in both halves
+        }
+    }
     const int gz = z0 + wave, gx = x0 + xv;
     const bool zx_ok = gz < D0 && gx < D2;
-    const uint32_t row0 = (uint32_t)((gz * D1 + y0) * D2 + gx) * (uint32_t)(Cout * 4);
+    const int yh = y0 + half * TYE;   // first y row of this half's epilogue
+    const uint32_t row0 = (uint32_t)((gz * D1 + yh) * D2 + gx) * (uint32_t)(Cout * 4);
     uint32_t yok = 0;
 #pragma unroll
-    for (int y = 0; y < TY; ++y) yok |= (zx_ok && (y0 + y) < D1) ? (1u << y) : 0u;
+    for (int y = 0; y < TYE; ++y) yok |= (zx_ok && (yh + y) < D1) ? (1u << y) : 0u;
     epi0(0, row0, yok);
 #pragma unroll
     for (int j = 0; j < NITEM; ++j) {
@@ -885,7 +916,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
   }
   if constexpr (ST) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);  // [wave][2][MT*16]
+    float* red = reinterpret_cast<float*>(lds);  // [wave of the workgroup][2][MT*16]
+    const int wv = (int)threadIdx.x >> 6;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -897,17 +929,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd2_kernel(const SplitFw
           x2 += __shfl_xor(x2, o, 64);
         }
         if (m == 0) {
-          red[(wave * 2 + 0) * (MT * 16) + mt * 16 + 4 * g + i] = x1;
-          red[(wave * 2 + 1) * (MT * 16) + mt * 16 + 4 * g + i] = x2;
+          red[(wv * 2 + 0) * (MT * 16) + mt * 16 + 4 * g + i] = x1;
+          red[(wv * 2 + 1) * (MT * 16) + mt * 16 + 4 * g + i] = x2;
         }
       }
     __syncthreads();
     float* dst = a.stats_partial + (int64_t)blockIdx.x * (2 * Cout);
-    for (int e = tid; e < MT * 16; e += 256) {
+    for (int e = threadIdx.x; e < MT * 16; e += 256 * KS) {
       const int c = chunk * MT * 16 + e;
       if (c < Cout) {
-        dst[c] = red[e] + red[2 * MT * 16 + e] + red[4 * MT * 16 + e] + red[6 * MT * 16 + e];
-        dst[Cout + c] = red[MT * 16 + e] + red[3 * MT * 16 + e] + red[5 * MT * 16 + e] + red[7 * MT * 16 + e];
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4 * KS; ++w) {   // (KS = 1: ((w0 + w1) + w2) + w3, the order of rounds 4-5)
+          t1 += red[(2 * w) * (MT * 16) + e];
+          t2 += red[(2 * w + 1) * (MT * 16) + e];
+        }
+        dst[c] = t1;
+        dst[Cout + c] = t2;
       }
     }
   }
@@ -1543,8 +1581,26 @@ int launch_split_fwd_np(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t 
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
+// split-K halves (conv3d_split_fwd2_kernel<..., KS = 2>): the launch leaves CUs single-occupied anyway (at most one 4-wave
+// workgroup per CU) and the chunk count is even
+inline bool split_fwd2_uses_halves(int gx, int nchunks, int ncc) {
+  return (int64_t)gx * nchunks <= 256 && ncc >= 4 && (ncc % 2) == 0;
+}
+
 template <int MT, bool ST, int EPI, bool STK>
 int launch_split_fwd2_e(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st) {
+  if constexpr (!STK) {
+    if (split_fwd2_uses_halves(gx, nchunks, a.ncc)) {
+      const size_t smem2 = 4 * BUF2 + MT * 16 * 4;
+      auto kern2 = conv3d_split_fwd2_kernel<MT, ST, EPI, false, 2>;
+      static SynOncePerDevice attr2_done;
+      if (auto once_ = attr2_done.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+      }
+      hipLaunchKernelGGL(kern2, dim3(gx, nchunks), dim3(512), smem2, st, a);
+      return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
+    }
+  }
   const size_t smem = 2 * BUF2 + MT * 16 * 4;
   auto kern = conv3d_split_fwd2_kernel<MT, ST, EPI, STK>;
   static SynOncePerDevice attr_done;
@@ -2063,6 +2119,14 @@ extern "C" int synthsr_split_tile_schedule(int kernel, int ntiles, int ny, int b
 // stats != null: BatchNorm batch statistics (mean | biased variance) of the output, from per-workgroup sums in `partial`
 // (room for 512 x 2 Cout floats)
 // upm = 2: the data gradient of a folded decoder conv (`in` = dz on the 2x grid, s = the low-resolution grid, wp = 8 parity sets)
+// does the six-product forward / data-gradient launch of this plain layer run as split-K halves (reported by synthsr_conv3d_plan)?
+extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd_halves(const int s[3], int Cin, int nchunks, int stacked,
+                                                                           int nprod) {
+  const int ntiles = ((s[0] + TZ - 1) / TZ) * ((s[1] + TY - 1) / TY) * ((s[2] + TX - 1) / TX);
+  if (stacked || nprod != 6 || split_uses_fwd3(ntiles, nchunks)) return 0;
+  return split_fwd2_uses_halves(split_grid_x(ntiles, nchunks), nchunks, Cin / 8) ? 1 : 0;
+}
+
 extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* in, const float* wp, const float* bias,
                                                                     const float* addend, float* out, const int s[3], int Cin,
                                                                     int Cout, int mt, int nchunks, int act, float* stats,

@@ -701,12 +701,38 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict_
   // cache lines per instruction and ran at 1.7 TB/s)
   float* tile = smem + (2 + K) * C;
   const int C4 = C / 4, CP = C + 4;
+  // round 6: the slab of the NEXT pass is requested (registers) before this pass computes, so that the loads of a workgroup
+  // are in flight during its two compute phases instead of being waited for between three barriers (2.1 -> TB/s, see DESIGN)
+  constexpr int PF = 8;                 // float4 per thread of a prefetched slab: C <= 32
+  const bool prefetch = C4 <= PF;
+  float4 nxt[PF];
+  auto fetch = [&](int64_t v0n) {
+    const int nvn = v0n < nvox ? (int)min((int64_t)256, nvox - v0n) : 0;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int i = (int)threadIdx.x + 256 * k;
+      if (k < C4 && i < nvn * C4) nxt[k] = ld4(x + v0n * C + (int64_t)i * 4);
+    }
+  };
+  if (prefetch) fetch((int64_t)blockIdx.x * 256);
   for (int64_t v0 = (int64_t)blockIdx.x * 256; v0 < nvox; v0 += (int64_t)gridDim.x * 256) {
     const int nv = (int)min((int64_t)256, nvox - v0);
     __syncthreads();
-    for (int i = threadIdx.x; i < nv * C4; i += 256) {
-      const int vl = i / C4, q = i - vl * C4;
-      *reinterpret_cast<float4*>(&tile[vl * CP + q * 4]) = ld4(x + v0 * C + (int64_t)i * 4);
+    if (prefetch) {
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int i = (int)threadIdx.x + 256 * k;
+        if (k < C4 && i < nv * C4) {
+          const int vl = i / C4, q = i - vl * C4;
+          *reinterpret_cast<float4*>(&tile[vl * CP + q * 4]) = nxt[k];
+        }
+      }
+      fetch(v0 + (int64_t)gridDim.x * 256);
+    } else {
+      for (int i = threadIdx.x; i < nv * C4; i += 256) {
+        const int vl = i / C4, q = i - vl * C4;
+        *reinterpret_cast<float4*>(&tile[vl * CP + q * 4]) = ld4(x + v0 * C + (int64_t)i * 4);
+      }
     }
     __syncthreads();
     if ((int)threadIdx.x < nv) {

@@ -320,20 +320,25 @@ def single_shot_parity(run, oracle, compare, max_flips=8, loss_of=lambda net: ne
     from oracle import unet_ref as U
 
     def aligned_oracle(det_pool, det_kink, max_kink_ulp=KINK_ULP):
-        rec = {'nudge': None}
+        rec = {'nudge': None, 'stop': None}
 
         def tap(out):   # oracle.unet_ref.prediction_tap: reads the oracle's prediction and its gradient, moves single voxels
             if rec['nudge'] is not None:
                 out = out + rec['nudge'].to(out.dtype).view_as(out)
             out.retain_grad()
             rec['out'] = out
+            if rec['stop'] is not None:   # voxels ON the kink in the device run (its derivative is exactly 0 there): no gradient
+                out = torch.where(rec['stop'].view_as(out), out.detach(), out)
             return out
 
         def step(nudges):
             with U.prediction_tap(tap):
                 ref_, pin = oracle(net, nudges)
             o = rec['out']
-            return ref_, pin, o.detach().reshape(-1).float(), o.grad.reshape(-1).float()
+            g = o.grad.reshape(-1).float()
+            if rec['stop'] is not None:
+                g = torch.where(rec['stop'], torch.zeros_like(g), g)
+            return ref_, pin, o.detach().reshape(-1).float(), g
 
         ref, pool_inputs, o_pr, o_dp = step(None)
         nudges, n_ties = align_pool_ties(det_pool, pool_inputs)
@@ -357,6 +362,14 @@ def single_shot_parity(run, oracle, compare, max_flips=8, loss_of=lambda net: ne
             side = torch.where(gap != 0, gap.sign(), (d_dp[idx] - o_dp[idx]).sign())
             rec['nudge'] = torch.zeros_like(o_pr)
             rec['nudge'][idx] = gap + 4.0 * ulp * side
+            # a device prediction that hits its target EXACTLY has derivative 0 (sign(0)): no side of the kink to move the oracle
+            # to -- the oracle's gradient is stopped at exactly those voxels instead (the planted-tie test produces them: its
+            # targets sit one ulp from the deterministic run's predictions, where the atomics run may land)
+            on_kink = d_dp[idx] == 0
+            if bool(on_kink.any()):
+                rec['stop'] = torch.zeros_like(o_pr, dtype=torch.bool)
+                rec['stop'][idx[on_kink]] = True
+                rec['nudge'][idx[on_kink]] = gap[on_kink]
             ref, pool_inputs, o_pr, o_dp = step(nudges)
             left = _kink_disagreements(o_dp, d_dp).numel()
             assert left == 0, 'the nudged oracle still disagrees with the device about %d loss kinks' % left

@@ -263,55 +263,75 @@ def test_segmentation_regularised_loss_is_bitwise_reproducible(det):
 def test_two_streams_of_one_device_run_concurrently_with_their_own_workspaces():
     """include/synthsr_hip.h: the library owns no scratch -- per-workgroup partials (BatchNorm statistics gathered in a conv
     epilogue, the first layer's weight gradient) live in the caller's synthsr_conv_ctx.workspace, and synthsr_amd.ops keeps one
-    context per (device, stream).  Two networks with different weights are driven on two streams of one device AT THE SAME
-    TIME (launches interleaved from one host thread, no synchronisation in between); everything the default path computes in
-    a fixed order -- activations, batch statistics, prediction, the first layer's weight gradient -- must be BIT-identical
-    to the same work run serially on one stream.  With round 5's one scratch buffer per device the two streams raced on it
+    context per (device, stream).  Two networks with different weights and inputs are driven on two streams of one device AT
+    THE SAME TIME (launches interleaved from one host thread, no synchronisation in between) and compared with the same work
+    run serially on one stream: conv outputs BIT for bit (they are order-independent), the quantities whose last bits depend
+    on the arrival order of float atomics also on one stream -- batch statistics read from the workspace partials, the first
+    layer's weight gradient, the activations behind the first BatchNorm -- to 1e-5 of their range (another stream's partials
+    in the workspace would be off by O(1)).  With round 5's one scratch buffer per device the two streams raced on it
     (VERDICT r05 weak 14)."""
     import torch
     from synthsr_amd import ops
     shape, cin = (64, 64, 64), 2
     g = torch.Generator().manual_seed(21)
-    xs = [torch.rand(*shape, cin, generator=g).cuda() for _ in range(2)]
+    xs = [(torch.rand(*shape, cin, generator=g) + i).cuda() for i in range(2)]          # different inputs: different partials
+    x24 = [(torch.randn(*shape, 24, generator=g) * (1 + i)).cuda() for i in range(2)]
     douts = [torch.randn(*shape, 24, generator=g).cuda() for _ in range(2)]
+    ws_ = [torch.randn(3, 3, 3, 24, 24, generator=g).cuda() / 25 for _ in range(2)]
+    bias = torch.randn(24, generator=g).cuda()
     torch.cuda.synchronize()
 
-    def work(net, x, dout, reps):
+    def work(net, i, reps):
         out = None
         for _ in range(reps):
+            wp = ops.pack_conv_weights(ws_[i], shape, 0)
+            stats = torch.zeros(48, device='cuda')
+            ws64 = torch.zeros(48, dtype=torch.float64, device='cuda')
+            y = ops.conv3d_stats(x24[i], wp, bias, 24, stats, ws64)   # split kernel: statistics partials in the workspace
             net.training = True
-            low, bn = net.forward(x)                       # conv epilogues gather the BatchNorm statistics (workspace partials)
+            low, bn = net.forward(xs[i])
             dw = torch.zeros(3, 3, 3, cin, 24, device='cuda')
             db = torch.zeros(24, device='cuda')
-            ops.conv3d_wgrad(x, dout, dw, db)              # first layer (Cin = 2): partial rows in the workspace, ordered reduce
-            out = (low.clone(), net.bn_batch.clone(), dw, db)
+            ops.conv3d_wgrad(xs[i], douts[i], dw, db)      # first layer (Cin = 2): partial rows in the workspace, then a reduction
+            out = (y, net.saved['enc'][0][0].clone(), stats, net.bn_batch.clone(), dw, db, low.clone())
         return out
 
+    names = ('conv output', 'first conv of the network', 'epilogue statistics', 'batch statistics', 'dW first layer', 'dbias',
+             'last activation')
+    exact = 2                                                  # the first two are order-independent
+
+    def same(a, b, tag):
+        for k, (u, v) in enumerate(zip(a, b)):
+            if k < exact:
+                assert torch.equal(u, v), '%s: %s differs' % (tag, names[k])
+            else:
+                err = float((u.double() - v.double()).abs().max()) / max(float(v.double().abs().max()), 1e-30)
+                assert err < (1e-3 if k == 6 else 1e-5), '%s: %s off by %.2e of its range' % (tag, names[k], err)
+
     nets = [_net('f32', 24, 3, shape, cin, seed=s) for s in (3, 4)]
-    serial = [work(n, x, d, 1) for n, x, d in zip(nets, xs, douts)]
-    again = [work(n, x, d, 1) for n, x, d in zip(nets, xs, douts)]
+    serial = [work(n, i, 1) for i, n in enumerate(nets)]
+    again = [work(n, i, 1) for i, n in enumerate(nets)]
     torch.cuda.synchronize()
-    for a, b in zip(serial, again):                        # premise: these quantities are order-independent on one stream
-        for u, v in zip(a, b):
-            assert torch.equal(u, v)
+    for i in range(2):
+        same(again[i], serial[i], 'serial re-run %d' % i)
+    assert not torch.equal(serial[0][2], serial[1][2])         # the two streams' partials really differ
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     n_ctx = len(ops._ctxs)
     snets, results = [], [None, None]
-    for i, st in enumerate(streams):                       # the networks' buffers belong to their stream
+    for i, st in enumerate(streams):                           # the networks' buffers belong to their stream
         with torch.cuda.stream(st):
             snets.append(_net('f32', 24, 3, shape, cin, seed=(3, 4)[i]))
     torch.cuda.synchronize()
-    for rep in range(6):                                   # interleave: stream 0 and stream 1 both have work queued all the time
+    for rep in range(6):                                       # interleave: both streams have work queued all the time
         for i, st in enumerate(streams):
             with torch.cuda.stream(st):
-                results[i] = work(snets[i], xs[i], douts[i], 2)
+                results[i] = work(snets[i], i, 2)
     torch.cuda.synchronize()
-    assert len(ops._ctxs) == n_ctx + 2                     # one context (one workspace) per stream
+    assert len(ops._ctxs) == n_ctx + 2                         # one context (one workspace) per stream
     ws = [ops._ctxs[k][1].data_ptr() for k in ops._ctxs]
     assert len(set(ws)) == len(ws)
     for i in range(2):
-        for u, v, what in zip(results[i], serial[i], ('activation', 'batch statistics', 'dW first layer', 'dbias')):
-            assert torch.equal(u, v), 'stream %d: %s differs from the serial run' % (i, what)
+        same(results[i], serial[i], 'stream %d vs the serial run' % i)
 
 
 def test_conv_call_without_workspace_is_refused_not_silently_allocated():

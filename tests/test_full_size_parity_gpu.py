@@ -192,6 +192,7 @@ def _run(S, hyperfine, f64=False):
         # configs[3] as BASELINE.json names it: the same step in bf16 (bf16 activations / packed weights, fp32 accumulation,
         # fp32 BatchNorm statistics, fp32 master weights) against the SAME fp32 oracle result -- stated bf16 tolerances
         sd = net.state_dict()
+        net_prefix = net.prefix
         del net
         torch.cuda.empty_cache()
         nb = unet(24, bg.model_output_shape, 5, 3, 1, feat_mult=2, nb_conv_per_level=2, final_pred_activation='linear',
@@ -215,12 +216,39 @@ def _run(S, hyperfine, f64=False):
             cos[nm] = float(torch.dot(got, ref) / (got.norm() * ref.norm()).clamp_min(1e-30))
         rep['bf16_min_cos'] = min(cos.values())
         rep['bf16_min_cos_layer'] = min(cos, key=cos.get)
+        # (b) the oracle with the bf16 STORAGE roundings restated (oracle.unet_ref.round_bf16 wherever the bf16 network stores a
+        # tensor: tests/test_bf16_gpu.py::test_unet_bf16_step_vs_oracle) -- same pooling decisions up to rounding flips, so
+        # every gradient gets a PER-TENSOR bound (the bf16 leg asserted one global cosine)
+        Pq = {nm: v.detach().clone().requires_grad_(True) for nm, v in P.items()}
+        t0 = time.time()
+        sq = {}
+        prq = U.unet_forward(x, Pq, net_prefix, 5, 2, training=True, collect=sq, quant=U.round_bf16)
+        lq = U.regression_loss(prq, tgt, 'l1', residual=res)
+        lq.backward()
+        rep['t_bf16_oracle'] = time.time() - t0
+        eq = prq.detach() + (0 if res is None else res)
+        rep['bf16q_pred'] = float((pb.view(S, S, S, 1).cpu() - eq).abs().max()) / float(eq.abs().max())
+        rep['bf16q_loss'] = abs(lb.item() - float(lq)) / abs(float(lq))
+        worst_bn = 0.0
+        for bn in nb.bn_layers:
+            o, C = bn['soff'], bn['C']
+            for got, ref in ((nb.bn_batch[o:o + C], sq[bn['name']][0]), (nb.bn_batch[o + C:o + 2 * C], sq[bn['name']][1])):
+                worst_bn = max(worst_bn, float((got.cpu() - ref).abs().max() / ref.abs().max()))
+        rep['bf16q_bn'] = worst_bn
+        bq = {}
+        for nm, _, kind in nb.specs:
+            got = nb.view(nm, nb.grads).cpu().double().reshape(-1)
+            ref = Pq[nm].grad.double().reshape(-1)
+            bq[nm] = (float(torch.dot(got, ref) / (got.norm() * ref.norm()).clamp_min(1e-30)),
+                      float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-300)),
+                      abs(float(got.norm() / ref.norm().clamp_min(1e-300)) - 1.0), kind)
+        rep['bf16q'] = bq
     return rep, grads, t_gpu, t_cpu
 
 
 @pytest.mark.parametrize('S,hyperfine', [(160, False), (192, True)])
 def test_one_training_step_at_baseline_shape_vs_oracle(S, hyperfine):
-    rep, grads, t_gpu, t_cpu = _run(S, hyperfine, f64=not hyperfine)
+    rep, grads, t_gpu, t_cpu = _run(S, hyperfine, f64=True)
     worst = sorted(((e, nm) for nm, (e, _) in grads.items()), reverse=True)[:6]
     print('\n%d^3 %s: HIP step %.2fs (first call, incl. allocation), oracle step %.1fs; pred %.2e loss %.2e bn %.2e; worst '
           'gradients %s' % (S, 'configs[3]' if hyperfine else 'configs[1]', t_gpu, t_cpu, rep['pred'], rep['loss'],
@@ -240,6 +268,7 @@ def test_one_training_step_at_baseline_shape_vs_oracle(S, hyperfine):
         # rounds 1-3 reported for the encoder kernels were max-pool tie flips, not arithmetic.  Bounds: 4e-4 of range
         # absolute, and never further from float64 than 6x the fp32 host evaluation (+ 2e-5 of range)
         attr = rep.pop('attr')
+        anchor = {nm: v[1] for nm, v in attr.items()}
         lines = ['%-40s %-8s max/range: device %.3e  fp32 oracle %.3e  ratio %5.2f   rms/rms: device %.3e  fp32 oracle %.3e  ratio %5.2f'
                  % (nm, kind, d, o, d / max(o, 1e-30), dr, orr, dr / max(orr, 1e-30)) for nm, (d, o, kind, dr, orr) in attr.items()]
         print('float64 step %.1fs; prediction: device %.2e / oracle %.2e of range from float64; loss %.2e / %.2e'
@@ -251,7 +280,11 @@ def test_one_training_step_at_baseline_shape_vs_oracle(S, hyperfine):
                         'oracle: device | fp32 oracle (PyTorch CPU)\n# prediction %r loss %r\n' % (S, rep['pred_vs_f64'], rep['loss_vs_f64']))
                 f.write('\n'.join(lines) + '\n')
         for nm, (d, o, kind, dr, orr) in attr.items():
-            assert d <= 6.0 * o + 2e-5 and d <= 4e-4, 'gradient of %s: device %.3e of range from float64, fp32 oracle %.3e' % (nm, d, o)
+            assert d <= 6.0 * o + 2e-5, 'gradient of %s: device %.3e of range from float64, fp32 oracle %.3e' % (nm, d, o)
+            # absolute cap: every tensor at 160^3; at 192^3 (thick-slice Hyperfine inputs) the conv / head kernels -- the
+            # per-channel sums in front of a BatchNorm (its backward removes the mean of the signal: cancelling terms over 7 M
+            # voxels, tiny range) are held by the anchored rule alone there
+            assert d <= 4e-4 or (hyperfine and kind != 'kernel'), 'gradient of %s: device %.3e of range from float64' % (nm, d)
         assert rep['pred_vs_f64'][0] <= 4.0 * rep['pred_vs_f64'][1] + 1e-6 and rep['pred_vs_f64'][0] < 5e-5, rep['pred_vs_f64']
         assert rep['loss_vs_f64'][0] < 2e-6, rep['loss_vs_f64']
     assert rep['loss'] < 1e-4, rep
@@ -259,17 +292,36 @@ def test_one_training_step_at_baseline_shape_vs_oracle(S, hyperfine):
     assert rep['pred'] < 1e-3, rep
     if hyperfine:   # bf16 vs the fp32 oracle (stated bf16 tolerances; gradients: see tests/test_bf16_gpu.py on pooling flips)
         assert rep['bf16_loss'] < 1e-2 and rep['bf16_pred'] < 5e-2 and rep['bf16_bn'] < 3e-2 and rep['bf16_min_cos'] > 0.98, rep   # measured 0.991
+        # ... and against the oracle with the bf16 storage roundings restated, PER TENSOR (BF16Q_* below)
+        bq = rep.pop('bf16q')
+        lines = ['%-40s %-8s cos %.6f  max err / range %.3e  |norm ratio - 1| %.3e' % (nm, kind, c, e, r) for nm, (c, e, r, kind) in bq.items()]
+        print('bf16 step vs the bf16-storage oracle (%.1fs): prediction %.2e loss %.2e bn %.2e\n%s'
+              % (rep['t_bf16_oracle'], rep['bf16q_pred'], rep['bf16q_loss'], rep['bf16q_bn'], '\n'.join(lines)))
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, 'full_size_parity_%d_bf16_vs_storage_oracle.txt' % S), 'w') as f:
+                f.write('# one bf16 training step at %d^3 vs oracle.unet_ref with round_bf16 storage roundings: prediction %.3e loss '
+                        '%.3e batch statistics %.3e\n' % (S, rep['bf16q_pred'], rep['bf16q_loss'], rep['bf16q_bn']))
+                f.write('\n'.join(lines) + '\n')
+        assert rep['bf16q_loss'] < BF16Q_LOSS and rep['bf16q_pred'] < BF16Q_PRED and rep['bf16q_bn'] < BF16Q_BN, rep
+        for nm, (c, e, r, kind) in bq.items():
+            cmin, rmax = (BF16Q_COS_KERNEL, BF16Q_NORM_KERNEL) if kind == 'kernel' else (BF16Q_COS_SUM, BF16Q_NORM_SUM)
+            assert c > cmin and r < rmax, 'bf16 gradient of %s vs the bf16-storage oracle: cosine %.5f, norm off by %.3e' % (nm, c, r)
     for nm, (err, kind) in grads.items():
-        # device vs the fp32 oracle with the max-pool ties aligned (rounds 1-3 allowed 3e-3 / 3e-2 here: tie flips); measured
-        # worst 3e-4 at 160^3
-        if not hyperfine:
-            assert err < 1e-3, 'gradient of %s: %.3e of its range (worst: %s)' % (nm, err, worst)
-            continue
-        # 192^3 three-channel Hyperfine: no float64 run (memory / time), the round-3 bounds stand -- biases of the conv right
-        # before a BatchNorm (BN's backward removes the mean of the signal: the gradient is a sum of cancelling terms over 7 M
-        # voxels and its RANGE is tiny; measured 1.2e-2) and BatchNorm beta / gamma 3e-2, everything else 3e-3 (measured 2.1e-3)
-        bound = 3e-2 if (kind in ('beta', 'gamma') or nm.endswith('_1/bias')) else 3e-3
-        assert err < bound, 'gradient of %s: %.3e of its range (worst: %s)' % (nm, err, worst)
+        # device vs the fp32 oracle with the max-pool ties and L1 kinks aligned (rounds 1-3 allowed 3e-3 / 3e-2 here: tie flips);
+        # measured worst 3e-4 at 160^3.  At 192^3 the per-channel sums in front of a BatchNorm have almost no range of their own
+        # (cancelling terms over 7 M voxels): there the bound follows from the float64 anchor of the SAME tensor -- device and fp32
+        # oracle each within (6 o + 2e-5 | o) of float64, so at most 7 o + 2e-5 apart (round 5: flat 3e-3 / 3e-2, no anchor)
+        bound = 1e-3 if not hyperfine else max(1e-3, 7.0 * anchor[nm] + 2e-5)
+        assert err < bound, 'gradient of %s: %.3e of its range (bound %.1e; worst: %s)' % (nm, err, bound, worst)
+
+
+# bf16 step at 192^3 against the bf16-storage oracle, per tensor.  Measured (profiles/r06_full_size_parity_192_bf16_vs_storage_oracle.txt):
+# prediction 2.0e-2 of range (one flipped bf16 rounding = 2^-8), loss 2.0e-4, batch statistics 7.9e-4; conv / head kernels cosine
+# >= 0.99924 with norms within 1.5e-2; per-channel sums (biases, BatchNorm beta / gamma) cosine >= 0.9976 and norms within 1e-2
+# except the bias in front of the first BatchNorm (cancelling terms over 7 M voxels: 0.9817 / 0.124)
+BF16Q_LOSS, BF16Q_PRED, BF16Q_BN = 1e-3, 3e-2, 3e-3
+BF16Q_COS_KERNEL, BF16Q_NORM_KERNEL = 0.998, 3e-2
+BF16Q_COS_SUM, BF16Q_NORM_SUM = 0.97, 0.2
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
@@ -313,6 +365,25 @@ def test_critic_update_at_160_vs_oracle(dtype):
         dr_ref = float(U.critic_forward(real, Pd, net.name, n_levels))
         df_ref = float(U.critic_forward(fake, Pd, net.name, n_levels))
     nref, ref = float(nref.detach()), float(ref.detach())
+    anchor = None
+    if dtype == 'f32':
+        # float64 anchor (these bounds were fixed numbers): the same loss + double backward once more in
+        # float64; per tensor d = |device - float64|, o = |fp32 oracle - float64| relative to the tensor's range
+        t0 = time.time()
+        P64 = {k: v.detach().double().requires_grad_(True) for k, v in P.items()}
+        ref64, _ = U.critic_loss(real.double(), fake.double(), u, P64, net.name, n_levels, 10.0)
+        ref64.backward()
+        t_f64 = time.time() - t0
+        top = max(float(P64[nm].grad.abs().max()) for nm, _ in net.specs)
+        anchor = {}
+        for nm, _ in net.specs:
+            r64 = P64[nm].grad.reshape(-1)
+            rng = max(float(r64.abs().max()), 1e-3 * top, 1e-300)
+            ed = net.view(nm, net.grads).cpu().double().reshape(-1) - r64
+            eo = P[nm].grad.double().reshape(-1) - r64
+            anchor[nm] = (float(ed.abs().max()) / rng, float(eo.abs().max()) / rng,
+                          float(ed.pow(2).mean().sqrt()) / rng, float(eo.pow(2).mean().sqrt()) / rng)
+        del P64
     tol = 2e-4 if dtype == 'f32' else 3e-2
     dscale = max(1.0, abs(dr_ref), abs(df_ref))
     rep = dict(d_real=(d_real, dr_ref), d_fake=(d_fake, df_ref), norm=(norm, nref), loss=(loss, ref))
@@ -353,11 +424,26 @@ def test_critic_update_at_160_vs_oracle(dtype):
     assert abs(loss - ref) < tol * max(1.0, abs(ref)), rep
     assert abs(dn - dn_ref) < (2e-3 if dtype == 'f32' else 5e-2) * dn_ref, (dn, dn_ref)
     if dtype == 'f32':
-        # kernels (conv and dense): 1e-2 of the tensor's range -- sums over up to 4 M voxels of the three passes' nearly
-        # cancelling signals, float atomics (measured 7.3e-3 on conv_5; 2e-3 holds at the 16^3..32^3 sizes of
-        # test_critic_gpu.py) -- and a cosine > 0.9999 (measured 0.999997)
-        assert worst_max[0] < 1e-2 and worst_cos[0] > 0.9999, (worst_max, worst_cos)
-        assert worst_bias[0] < 5e-2, worst_bias      # biases: cancelling sums, see above
+        # every gradient anchored on float64 (the rule of tests/conftest.py): the device is never more than K times further from
+        # the float64 result than the fp32 host evaluation of the same graph, plus a floor of 2e-5 of range (4x for the
+        # per-channel sums).  Both distances are dominated by LeakyReLU kinks -- a pre-activation within rounding of zero takes
+        # slope 1 in one evaluation and 0.2 in another, the same discontinuity as a max-pool tie, and the critic has eight such
+        # layers over up to 4.1 M voxels --, i.e. by a handful of discrete events per tensor: the rms error (all entries) is
+        # held to K = 6, the single worst entry to K = 12.  Measured (profiles/r06_critic_parity_160_f32_vs_float64.txt): worst
+        # entry 0.64-5.9x the fp32 oracle's, 3.4e-4 ... 6.2e-3 of range for the conv tensors.  (Round 5 held kernels to a flat
+        # 1e-2 of range and biases to 5e-2 against the fp32 oracle.)
+        alines = ['%-32s max: device %.3e  fp32 oracle %.3e of range from float64  ratio %5.2f   rms: %.3e  %.3e  ratio %5.2f'
+                  % (nm, d, o, d / max(o, 1e-30), dr, orr, dr / max(orr, 1e-30)) for nm, (d, o, dr, orr) in anchor.items()]
+        print('float64 critic loss + double backward %.1fs\n%s' % (t_f64, '\n'.join(alines)))
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, 'critic_parity_160_f32_vs_float64.txt'), 'w') as f:
+                f.write('# critic update at 160^3: per-tensor gradient error / range against a float64 run of the oracle (max | rms)\n')
+                f.write('\n'.join(alines) + '\n')
+        for nm, (d, o, dr, orr) in anchor.items():
+            fl = 2e-5 * (1.0 if nm.endswith('/kernel') else 4.0)
+            assert dr <= 6.0 * orr + fl and d <= 12.0 * o + fl, \
+                'critic gradient of %s: device %.3e (rms %.3e) of range from float64, fp32 oracle %.3e (rms %.3e)' % (nm, d, dr, o, orr)
+        assert worst_cos[0] > 0.9999, worst_cos      # measured 0.999997
     else:   # bf16 conv stack: kernels cosine > 0.98, norm within 5 %; biases (cancelling sums) cosine > 0.97, norm within 15 %
         kc = min((c, n) for c, n in cos_all if not n.endswith('/bias'))
         kr = max((r, n) for r, n in rel_all if not n.endswith('/bias'))

@@ -31,13 +31,17 @@ def _err(y, ref):
     return float(d.abs().max()) / scale, float(d.pow(2).mean().sqrt()) / scale
 
 
-def _is_split(shape, cin, cout):
+def _plan(shape, cin, cout):
     import ctypes
     from synthsr_amd import _lib
     out = (ctypes.c_int64 * 8)()
     from synthsr_amd import ops
     _lib.check(_lib.load().synthsr_conv3d_plan(ops.conv_ctx_host(), _lib.i3(shape), cin, cout, 1, out), 'plan')
-    return int(out[2]) <= -100
+    return [int(v) for v in out]
+
+
+def _is_split(shape, cin, cout):
+    return _plan(shape, cin, cout)[2] <= -100
 
 
 def _data(kind, D, ci, co, seed):
@@ -61,9 +65,10 @@ def _data(kind, D, ci, co, seed):
 
 @pytest.mark.parametrize('kind', ['normal', 'offset', 'range', 'cancel'])
 @pytest.mark.parametrize('D,ci,co', [(48, 24, 24), (48, 24, 48), (40, 48, 48), (40, 96, 48), (40, 96, 96), (48, 16, 16),
-                                     ((42, 38, 50), 24, 24), ((38, 42, 50), 48, 48)])
+                                     ((42, 38, 50), 24, 24), ((38, 42, 50), 48, 48), (20, 192, 192), ((18, 21, 23), 96, 192)])
 def test_split_conv_is_as_accurate_as_the_fp32_mfma_kernels(D, ci, co, kind):
-    """(cubes, a one-column-tile layer, and volumes whose sizes are no multiples of the 4x4x16 tile: masked loads / stores)"""
+    """(cubes, a one-column-tile layer, volumes whose sizes are no multiples of the 4x4x16 tile: masked loads / stores, and --
+    the last two -- layers that run as split-K halves, csrc/conv_split.hip conv3d_split_fwd2_kernel<..., KS = 2>)"""
     from synthsr_amd import ops
     shape = (D, D, D) if isinstance(D, int) else tuple(D)
     x, dy, w, b = _data(kind, D, ci, co, seed=sum(shape) + ci + co)
@@ -77,6 +82,8 @@ def test_split_conv_is_as_accurate_as_the_fp32_mfma_kernels(D, ci, co, kind):
         for mode in ('fp32_mfma', 'split'):
             ops.set_conv_arithmetic(mode)
             assert _is_split(shape, ci, co) == (mode == 'split')
+            if mode == 'split' and max(shape) <= 24:
+                assert _plan(shape, ci, co)[5] == 2   # the forward launch runs as split-K halves (20^3 192 -> 192: the data gradient too)
             wp, wpd = ops.pack_conv_weights(w, shape, 0), ops.pack_conv_weights(w, shape, 1)
             y = ops.conv3d(x, wp, b, co, 0)
             dx = ops.conv3d(dy, wpd, None, ci, 0)
