@@ -268,6 +268,23 @@ __device__ __forceinline__ void syn_split3(float f0, float f1, uint32_t& p0, uin
 }
 #endif
 
+// Output-channel tiles (of 16) per co-chunk of a plain split conv (conv3d.hip plans and packs with it, conv_split.hip launches
+// with it).  Up to three tiles per workgroup (registers), whole co-chunks.  Round 6: a layer whose units (4x4x16 voxel tiles x
+// co-chunks of 48) fall between one and one and a half rounds of the 512 workgroup slots (40^3 with 96 output channels: 600)
+// takes co-chunks of 32 instead -- 900 shorter units in two rounds cost 2 x 2/3 of a unit-time where 600 cost two full ones
+// (4-wave kernel) or three half ones (8-wave kernel): -11 ... -18 % on the 40^3 layers, -0.36 ms per training step, same box
+// (profiles/r06_plan_40cubed_ab.txt).
+__host__ __device__ inline bool syn_split_replanned(int vox_tiles, int co_tiles, int mt) {
+  if (mt != 2 || co_tiles <= 3 || (co_tiles % 3) != 0 || (co_tiles % 2) != 0) return false;
+  const long long u3 = (long long)vox_tiles * (co_tiles / 3);
+  return u3 > 512 && u3 < 768;
+}
+__host__ __device__ inline int syn_split_plan_mt(int vox_tiles, int co_tiles, bool plain) {
+  const int mt = co_tiles <= 3 ? co_tiles : ((co_tiles % 3) == 0 ? 3 : ((co_tiles % 2) == 0 ? 2 : 1));
+  if (plain && mt == 3 && syn_split_replanned(vox_tiles, co_tiles, 2)) return 2;
+  return mt;
+}
+
 // K order of the split forward kernel (conv_split.hip): K slot 4 * step + g (g = lane >> 4) -> tap 0..26, or -1 for the one
 // spare slot (zero weights).  ds_read_b128 serves lanes {0-3, 12-15} of one 16-lane quarter together with lanes {4-11} of the
 // NEXT quarter (MI355X_MICROARCH.md, LDS): with the even x-voxels on the first set and the odd ones on the second, the two taps

@@ -3015,7 +3015,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
     // fp32 through three bf16 pieces per operand on the bf16 matrix cores (conv_split.hip): layers with enough 4x4x16 tiles
     const int64_t vox = (int64_t)s[0] * s[1] * s[2];
     const int ntiles = cdiv(Cout, 16);
-    const int mt = ntiles <= 3 ? ntiles : ((ntiles % 3) == 0 ? 3 : ((ntiles % 2) == 0 ? 2 : 1));
+    const int mt = syn_split_plan_mt(cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16), ntiles, plain);
     const int nchunks = cdiv(ntiles, mt);
     const int64_t wgs = (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) * nchunks;
     // (kind 0 = data gradient of a folded decoder conv: s is the low-resolution grid, the input lives on the 2x grid)

@@ -33,8 +33,11 @@ extern "C" int synthsr_split_timing_buffer(long long* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_tm), &p, sizeof(p)) == hipSuccess ? 0 : 1;
 }
 #define TM(i) do { if (g_tm && (blockIdx.x == 0 || blockIdx.x == 300) && blockIdx.y == 0 && tid == 0 && tix < 120) g_tm[((blockIdx.x ? 1 : 0) * 120 + tix) * 8 + (i)] = clock64(); } while (0)
+// fwd2: sequential stamps of thread 0 of workgroups (7, 0) and (20, 1): T2(k) writes slot n2++ = (k, clock)
+#define T2(k) do { if (g_tm && threadIdx.x == 0 && ((blockIdx.x == 7 && blockIdx.y == 0) || (blockIdx.x == 20 && blockIdx.y == 1)) && n2 < 400) { g_tm[(blockIdx.y * 400 + n2) * 2] = (k); g_tm[(blockIdx.y * 400 + n2) * 2 + 1] = clock64(); ++n2; } } while (0)
 #else
 #define TM(i)
+#define T2(k)
 #endif
 
 // Arithmetic "split9" (synthsr_conv_ctx.arithmetic = 2): all nine partial products a_i b_j instead of six -- an fp32 product is
@@ -723,6 +726,9 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_k
   };
 
   int buf = 0;
+  int n2 = 0;
+  (void)n2;
+  T2(0);
   if (walk.pos < walk.end) {
     halo_where(walk.pos, half, false);
     load_pieces(P0{}, P6{});
@@ -742,13 +748,16 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_k
     }
     wfirst = false;
   }
+  T2(1);
   for (int t = walk.pos; t < walk.end; t += walk.stride) {
 #pragma unroll
     for (int y = 0; y < TY; ++y)
 #pragma unroll
       for (int tl = 0; tl < NWT; ++tl) acc[y][tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int cc = half; cc < ncc; cc += KS) {   // (KS = 2: ncc is even, both halves run the same number of chunks)
+      T2(2);
       __syncthreads();  // image `buf` is complete; nobody reads the other one any more
+      T2(3);
       const bool last_cc = cc + KS >= ncc;
       const bool more = !last_cc || t + walk.stride < walk.end;
       halo_where(last_cc ? (more ? t + walk.stride : t) : t, last_cc ? half : cc + KS, !more);
@@ -873,6 +882,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_k
         }
       });
       __builtin_amdgcn_sched_barrier(0);
+      T2(4);
       buf ^= 1;
     }
     // ---- epilogue: lane (m, g): channels (chunk*MT + mt)*16 + 4g + i of voxel (z0 + wave, y0 + y, x0 + xv)
@@ -906,6 +916,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_k
     uint32_t yok = 0;
 #pragma unroll
     for (int y = 0; y < TYE; ++y) yok |= (zx_ok && (yh + y) < D1) ? (1u << y) : 0u;
+    T2(5);
     epi0(0, row0, yok);
 #pragma unroll
     for (int j = 0; j < NITEM; ++j) {
@@ -913,6 +924,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_k
       epi1(j);
       epi2(j);
     }
+    T2(6);
   }
   if constexpr (ST) {
     __syncthreads();
@@ -1631,8 +1643,12 @@ int launch_split_fwd2(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st
 // where the layer has between one and two rounds of its 512 workgroup slots AND several co-chunks (40^3, 96 output channels:
 // 600 units): there the 8-wave kernel (one workgroup per CU, weights through LDS) quantises better (-10 %); with fewer units
 // than slots (20^3, 192 output channels: 200) the 4-wave kernel wins again (0.126 vs 0.14 ms)
-inline bool split_uses_fwd3(int ntiles, int nchunks) {
+// Round 6: a layer that syn_split_plan_mt re-planned onto 32-channel co-chunks (40^3, 96 output channels: 900 units) stays on the
+// 4-wave kernel -- 0.200 / 0.193 ms against 0.234 / 0.218 for the 8-wave kernel on 600 units, same box
+// (profiles/r06_plan_40cubed_ab.txt)
+inline bool split_uses_fwd3(int ntiles, int nchunks, int mt = 3, int Cout = 0) {
   const int64_t units = (int64_t)ntiles * nchunks;
+  if (syn_split_replanned(ntiles, (Cout + 15) / 16, mt)) return false;
   return nchunks >= 2 && units >= 512 && units < 1024;
 }
 
@@ -1672,7 +1688,7 @@ int launch_split_fwd(const SplitFwdArgs& a, int gx, int nchunks, hipStream_t st)
     return SYNTHSR_EINVAL;
   }
   if constexpr (UPM == 0) {
-    if (t_nprod == 6 && split_uses_fwd3(a.ntiles, nchunks)) return launch_split_fwd3<MT, ST>(a, nchunks, st);
+    if (t_nprod == 6 && split_uses_fwd3(a.ntiles, nchunks, MT, a.Cout)) return launch_split_fwd3<MT, ST>(a, nchunks, st);
     if (t_nprod == 6) return launch_split_fwd2<MT, ST>(a, gx, nchunks, st);
   }
   return t_nprod == 9 ? launch_split_fwd_np<MT, ST, UPM, 9>(a, gx, nchunks, st) : launch_split_fwd_np<MT, ST, UPM, 6>(a, gx, nchunks, st);
@@ -2123,7 +2139,7 @@ extern "C" int synthsr_split_tile_schedule(int kernel, int ntiles, int ny, int b
 extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd_halves(const int s[3], int Cin, int nchunks, int stacked,
                                                                            int nprod) {
   const int ntiles = ((s[0] + TZ - 1) / TZ) * ((s[1] + TY - 1) / TY) * ((s[2] + TX - 1) / TX);
-  if (stacked || nprod != 6 || split_uses_fwd3(ntiles, nchunks)) return 0;
+  if (stacked || nprod != 6 || split_uses_fwd3(ntiles, nchunks, 3, 0)) return 0;
   return split_fwd2_uses_halves(split_grid_x(ntiles, nchunks), nchunks, Cin / 8) ? 1 : 0;
 }
 
@@ -2160,7 +2176,7 @@ extern "C" __attribute__((visibility("hidden"))) int syn_split_fwd(const float* 
     rc = mt == 1 ? launch_split_fwd<1, true>(a, gx, nchunks, st)
                  : (mt == 2 ? launch_split_fwd<2, true>(a, gx, nchunks, st) : launch_split_fwd<3, true>(a, gx, nchunks, st));
     if (rc != SYNTHSR_OK) return rc;
-    const int gcols = (!stacked && t_nprod == 6 && split_uses_fwd3(a.ntiles, nchunks)) ? split_upfwd_grid_x(a.ntiles, nchunks) : gx;  // workgroup columns that wrote partials
+    const int gcols = (!stacked && t_nprod == 6 && split_uses_fwd3(a.ntiles, nchunks, mt, Cout)) ? split_upfwd_grid_x(a.ntiles, nchunks) : gx;  // workgroup columns that wrote partials
     return synthsr_bn_stats_from_partials(partial, gcols, vox, Cout, stats, (synthsr_stream_t)st);
   }
   if (upm == 2)
