@@ -654,7 +654,12 @@ struct HeadBox {
   int res_off[4];  // residual channel added to intensity channel k (work_with_residual_channel)
 };
 
-template <typename T, int K>
+// CT = 24 (round 6): the 24-feature head of the benchmark network keeps the 72 BatchNorm / head coefficients of its dot product in
+// SCALAR registers (readfirstlane: the values are uniform) instead of reading them from LDS per voxel -- 72 broadcast ds_read_b32
+// per voxel and pass -- and requests the next 256-voxel slab before it computes on the current one: 0.184 -> 0.153 ms at 160^3
+// (2.1 -> 2.6 TB/s; profiles/r06_head_kernel_ab.txt; the VGPR form of the same idea needs 189 registers and is slower).  Same
+// products in the same order; the compiler's fma contraction may differ in the last bit.  CT = 0: any channel count, LDS.
+template <typename T, int K, int CT = 0>
 __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict__ x, int64_t nvox, int C,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ gamma,
@@ -681,6 +686,16 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict_
     for (int k = 0; k < K; ++k) weff[2 * C + k * C + c] = w[c * K + k];
   }
   __syncthreads();
+  constexpr int CR = (CT > 0 && K == 1) ? CT : 1;
+  float rsc[CR], rsh[CR], rw[CR];
+  if constexpr (CT > 0 && K == 1) {
+#pragma unroll
+    for (int c = 0; c < CR; ++c) {
+      rsc[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, weff[c])));       // scalar
+      rsh[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, weff[C + c])));   // registers
+      rw[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, weff[2 * C + c])));
+    }
+  }
   float lsum = 0.f;
   // second phase of a pass (ab): thread = (channel quad qa, voxel lane la); la walks the tile's voxels with stride LA
   __shared__ float gl[256];
@@ -702,7 +717,7 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict_
   float* tile = smem + (2 + K) * C;
   const int C4 = C / 4, CP = C + 4;
   // round 6: the slab of the NEXT pass is requested (registers) before this pass computes, so that the loads of a workgroup
-  // are in flight during its two compute phases instead of being waited for between three barriers (2.1 -> TB/s, see DESIGN)
+  // are in flight during its two compute phases instead of being waited for between three barriers
   constexpr int PF = 8;                 // float4 per thread of a prefetched slab: C <= 32
   const bool prefetch = C4 <= PF;
   float4 nxt[PF];
@@ -741,6 +756,18 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const T* __restrict_
 #pragma unroll
       for (int k = 0; k < K; ++k) acc[k] = 0.f;
       const float* xp = tile + threadIdx.x * CP;
+      if constexpr (CT > 0 && K == 1) {
+#pragma unroll
+        for (int c = 0; c < CR; c += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(xp + c);
+          const float n0 = a.x * rsc[c + 0] + rsh[c + 0], n1 = a.y * rsc[c + 1] + rsh[c + 1];
+          const float n2 = a.z * rsc[c + 2] + rsh[c + 2], n3 = a.w * rsc[c + 3] + rsh[c + 3];
+          acc[0] += rw[c + 0] * n0;
+          acc[0] += rw[c + 1] * n1;
+          acc[0] += rw[c + 2] * n2;
+          acc[0] += rw[c + 3] * n3;
+        }
+      } else
       for (int c = 0; c < C; c += 4) {
         const float4 a = *reinterpret_cast<const float4*>(xp + c);
         const float n0 = a.x * weff[c + 0] + weff[C + c + 0], n1 = a.y * weff[c + 1] + weff[C + c + 1];
@@ -1310,7 +1337,14 @@ int head_loss_fwd_t(const T* x, const int* shape, int C, const float* stats, con
   hipLaunchKernelGGL((head_loss_fwd_kernel<T, KK>), grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta, \
                      eps, w, b, residual, res_stride, target, pred, dpred, loss, inv_n, kind, box, ab)
   switch (K) {
-    case 1: SYN_HEAD_FWD(1); break;
+    case 1:
+      if (C == 24) {
+        hipLaunchKernelGGL((head_loss_fwd_kernel<T, 1, 24>), grid, dim3(256), smem, (hipStream_t)stream, x, nvox, C, stats, gamma, beta,
+                           eps, w, b, residual, res_stride, target, pred, dpred, loss, inv_n, kind, box, ab);
+        break;
+      }
+      SYN_HEAD_FWD(1);
+      break;
     case 2: SYN_HEAD_FWD(2); break;
     case 3: SYN_HEAD_FWD(3); break;
     default: SYN_HEAD_FWD(4); break;
