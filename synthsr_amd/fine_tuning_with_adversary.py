@@ -18,7 +18,7 @@ from . import host_math as hm
 from . import volumes
 from .brain_generator import BrainGenerator
 from .critic import Critic3D
-from .training import load_checkpoint, save_checkpoint
+from .training import load_checkpoint, save_checkpoint, settle_host_gc
 from .unet import unet as build_unet
 
 
@@ -261,6 +261,7 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
                                  loss_cropping, seg_reg, rng=rng, mask_lut=mask_lut, distributed=dist_on)
     width = len(str(epochs))
     log_d, log_g = np.array([]), np.array([])
+    gc_settled = False
     for epoch in range(epochs):
         t0 = time.time()
         avg_d = avg_g = 0.0
@@ -269,6 +270,9 @@ def training(labels_dir, images_dir, model_dir, prior_means, prior_stds, path_ge
             for _ in range(ratio):
                 avg_d += trainer.critic_step() / (steps_per_epoch * ratio)
             avg_g += trainer.generator_step() / steps_per_epoch
+            if not gc_settled:
+                settle_host_gc()
+                gc_settled = True
         if dist_on:                   # epoch averages over the ranks' samples (a Keras batch of `world` samples)
             import torch
             acc = torch.tensor([avg_d, avg_g], dtype=torch.float64, device=generator.device)

@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-settle-gc', action='store_true', help='A/B: leave the Python heap unfrozen (one update in ~12 then pays a full collection)')
     args = ap.parse_args()
     S, dtype = args.size, args.dtype
     critic = Critic3D([S, S, S, 1], seed=0, dtype=dtype)
@@ -42,6 +43,9 @@ def main():
     for _ in range(args.warmup):
         critic_update()
     torch.cuda.synchronize()
+    if not args.no_settle_gc:   # what fine_tuning_with_adversary.training() does after its first step (training.settle_host_gc)
+        from synthsr_amd.training import settle_host_gc
+        settle_host_gc()
     nprof = min(2, args.steps)
     ops.profile_start()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -101,7 +105,8 @@ def main():
            'value': round(1.0 / dt, 3), 'unit': 'updates/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
            'ms_per_step': round(dt * 1e3, 3),
            'step_ms': {'mean': round(float(step_ms.mean()), 3), 'median': round(float(np.median(step_ms)), 3),
-                       'min': round(float(step_ms.min()), 3), 'max': round(float(step_ms.max()), 3)},
+                       'min': round(float(step_ms.min()), 3), 'max': round(float(step_ms.max()), 3),
+                       'each': [round(float(v), 2) for v in step_ms]},
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
            'config': {'workload': 'configs[4]: one WGAN-GP critic update (-D(real) + D(fake) + 10 (1 - |grad D(x_hat)|)^2: 3 '
                                   'forward, 3 backward, penalty pass, Adam) at %d^3, %.1f M parameters (Dense %d x %d), %s'

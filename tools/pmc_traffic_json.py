@@ -37,9 +37,11 @@ out = {'_note': __doc__.split('bench.py reads')[1].strip().replace('\n', ' '),
 # (round 4: forward / data gradient of the Cout = 24 layers = conv3d_split_fwd2_kernel<2, ST, EPI, true>: EPI 1 / 4 forward,
 #  EPI 2 data gradient)
 for key, kerns, wide in (('conv3d_wgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_wgrad_kernel<24', 'conv3d_wgrad_p4_kernel'), True),
-                         ('conv3d_fwd 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd2_kernel<2, false, 1', 'conv3d_split_fwd_kernel<2, false',
-                                                                    'conv3d_fwd_p4_kernel'), True),
-                         ('conv3d_dgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd2_kernel<2, false, 2', 'conv3d_split_fwd_kernel<2, false',
+                         # (round 6: <MT, ST, EPI, STK, KS> -- the stacked (STK = true) kernels are the 160^3 ones; MT = 2 without STK is now
+                         #  the re-planned 40^3 layer)
+                         ('conv3d_fwd 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd2_kernel<2, true, 1, true', 'conv3d_split_fwd2_kernel<2, false, 1, true',
+                                                                    'conv3d_split_fwd_kernel<2, false', 'conv3d_fwd_p4_kernel'), True),
+                         ('conv3d_dgrad 160x160x160 Cin=24 Cout=24', ('conv3d_split_fwd2_kernel<2, false, 2, true', 'conv3d_split_fwd_kernel<2, false',
                                                                       'conv3d_fwd_p4_kernel'), True)):
     kern = next((k for pre in kerns for k in sorted(fetch) if k.startswith(pre) and k in write), None)
     if kern is None:
