@@ -1838,26 +1838,51 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
   // staging: x piece j -> halo voxel j / XQ, channels 4 (j % XQ) .. + 3 of the chunk; dz piece j -> voxel j / DQ, quad j % DQ
   // (LDS address of piece j, either image: 8 j -- a voxel's XQ resp. DQ pieces are 8 bytes apart and fill its XB resp. DROWB bytes)
   static_assert(XB == XQ * 8 && DROWB == DQ * 8, "pieces tile the voxel rows");
-  int xrel[NXL];
-  uint32_t xmask[NXL];
+  // XPLN (CIW = 16, round 6): piece i of a thread = halo PLANE i -- thread = (channel quad tid & 3, in-plane voxel tid >> 2 of the
+  // 6 x 18 = 108), so its six pieces differ by one plane stride and one mask bit: two registers instead of twelve address / mask
+  // registers (the 48-column kernel had 256 + 5 spilled); the same 16-byte pieces as before, 108 of 128 lanes active per load
+  // where the linear mapping had 2592 of 3072
+  constexpr bool XPLN = CIW == 16;
+  static_assert(!XPLN || (NXL == HZ && NTHR / XQ >= HY * HX), "one halo plane per staging piece");
+  int xrel[XPLN ? 1 : NXL];
+  uint32_t xmask[XPLN ? 1 : NXL];
+  const int xq = tid & 3, xr = tid >> 2;            // XPLN: channel quad, voxel inside a halo plane
+  const int xps = D1 * D2 * Cin * 4;                // XPLN: bytes from a halo plane to the next
+  if constexpr (XPLN) {
+    const int hy = xr / HX, hx = xr - hy * HX;
+    xrel[0] = (hy * D2 + hx) * Cin * 4 + xq * 16;
+    xmask[0] = xr < HY * HX ? ((1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+  } else {
 #pragma unroll
-  for (int i = 0; i < NXL; ++i) {
-    const int j = tid + NTHR * i;
-    const int v = j / XQ, h = j % XQ;
-    const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
-    xrel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4 + h * 16;
-    xmask[i] = j < NXP ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+    for (int i = 0; i < NXL; ++i) {
+      const int j = tid + NTHR * i;
+      const int v = j / XQ, h = j % XQ;
+      const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
+      xrel[i] = ((hz * D1 + hy) * D2 + hx) * Cin * 4 + h * 16;
+      xmask[i] = j < NXP ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
+    }
   }
-  int drel[NDL];
-  uint32_t dmask[NDL];  // bits (z | 4 + y | 8 + x) of the voxel inside the tile, against the tile's out-of-volume bits
+  // (XPLN, dz side: thread = (channel quad tid & 3 of four, voxel tid >> 2 of the first two z planes); piece i = channel quads
+  //  4 (i % 3) .. of z plane pair i / 3: again one address and one mask per thread)
+  constexpr bool DPLN = XPLN && COW == 48;
+  int drel[DPLN ? 1 : NDL];
+  uint32_t dmask[DPLN ? 1 : NDL];  // bits (z | 4 + y | 8 + x) of the voxel inside the tile, against the tile's out-of-volume bits
+  const int dps = 2 * D1 * D2 * Cout * 4;           // DPLN: bytes from z plane pair 0 to pair 1
+  if constexpr (DPLN) {
+    static_assert(!DPLN || NDL == 6, "two plane pairs x three quad groups");
+    const int vz = xr / (TY * TX), vy = (xr / TX) % TY, vxx = xr % TX;   // xr < 128: z planes 0, 1
+    dmask[0] = (1u << vz) | (1u << (4 + vy)) | (1u << (8 + vxx));         // (COW divides Cout: every column exists)
+    drel[0] = ((vz * D1 + vy) * D2 + vxx) * Cout * 4 + (oc * COW + xq * 4) * 4;
+  } else {
 #pragma unroll
-  for (int i = 0; i < NDL; ++i) {
-    const int j = tid + NTHR * i;
-    const int v = j / DQ, c4 = j - v * DQ;
-    const int vz = v / (TY * TX), vy = (v / TX) % TY, vxx = v % TX;
-    const int co = oc * COW + c4 * 4;
-    dmask[i] = co < Cout ? ((1u << vz) | (1u << (4 + vy)) | (1u << (8 + vxx))) : 0xFFFFFFFFu;
-    drel[i] = ((vz * D1 + vy) * D2 + vxx) * Cout * 4 + co * 4;
+    for (int i = 0; i < NDL; ++i) {
+      const int j = tid + NTHR * i;
+      const int v = j / DQ, c4 = j - v * DQ;
+      const int vz = v / (TY * TX), vy = (v / TX) % TY, vxx = v % TX;
+      const int co = oc * COW + c4 * 4;
+      dmask[i] = co < Cout ? ((1u << vz) | (1u << (4 + vy)) | (1u << (8 + vxx))) : 0xFFFFFFFFu;
+      drel[i] = ((vz * D1 + vy) * D2 + vxx) * Cout * 4 + co * 4;
+    }
   }
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
@@ -1875,9 +1900,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
 #pragma unroll
     for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
     const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * CIW) * 4;
+    int xps_t = xps;
+    uint32_t xm_t = xmask[0];
+    if constexpr (XPLN) {  // keep the six addresses / masks from being hoisted out of the tile loop into twelve registers again
+      asm volatile("" : "+s"(xps_t));
+      asm volatile("" : "+v"(xm_t));
+    }
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
-      const uint32_t vo = (xmask[i] & bad) ? OOB : (uint32_t)(xrel[i] + base);
+      uint32_t vo;
+      if constexpr (XPLN) vo = ((xm_t | (1u << i)) & bad) ? OOB : (uint32_t)(xrel[0] + i * xps_t + base);
+      else vo = (xmask[i] & bad) ? OOB : (uint32_t)(xrel[i] + base);
       xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
     }
     const int dbase = ((z0 * D1 + y0) * D2 + x0) * Cout * 4;
@@ -1888,10 +1921,23 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     for (int h = 0; h < TY; ++h) dbad |= (y0 + h >= D1) ? (1u << (4 + h)) : 0u;
 #pragma unroll
     for (int h = 0; h < TX; ++h) dbad |= (x0 + h >= D2) ? (1u << (8 + h)) : 0u;
+    int dps_t = dps;
+    uint32_t dm_t = dmask[0];
+    if constexpr (DPLN) {
+      asm volatile("" : "+s"(dps_t));
+      asm volatile("" : "+v"(dm_t));
+    }
 #pragma unroll
-    for (int i = 0; i < NDL; ++i)
-      dst[i] = __builtin_bit_cast(
-          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, (dmask[i] & dbad) ? (int)OOB : drel[i] + dbase, 0, 0));
+    for (int i = 0; i < NDL; ++i) {
+      int dvo;
+      if constexpr (DPLN) {
+        const uint32_t m = (dm_t & ~0xFu) | ((dm_t & 0xFu) << (2 * (i / 3)));
+        dvo = (m & dbad) ? (int)OOB : drel[0] + (i / 3) * dps_t + (i % 3) * 64 + dbase;
+      } else {
+        dvo = (dmask[i] & dbad) ? (int)OOB : drel[i] + dbase;
+      }
+      dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, dvo, 0, 0));
+    }
   };
   auto store_tile = [&](int buf) {  // four fp32 -> 3 x (four bf16 = 8 bytes)
     unsigned char* xd = lds + buf * C::BUFB;
@@ -1899,11 +1945,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
-      if (NXP % NTHR != 0 && i == NXL - 1 && tid + NTHR * i >= NXP) continue;
+      if constexpr (XPLN) {
+        if (xr >= HY * HX) continue;
+      } else {
+        if (NXP % NTHR != 0 && i == NXL - 1 && tid + NTHR * i >= NXP) continue;
+      }
       uint32_t p0, p1, p2, q0, q1, q2;
       syn_split3(xst[i][0], xst[i][1], p0, p1, p2);
       syn_split3(xst[i][2], xst[i][3], q0, q1, q2);
-      const int xj = tid + NTHR * i;
+      const int xj = XPLN ? (i * (HY * HX) + xr) * XQ + xq : tid + NTHR * i;
       const int xl = PL ? (xj % XQ) * QP + (xj / XQ) * 8 : xj * 8;
       *reinterpret_cast<u32x2*>(xd + xl) = (u32x2){p0, q0};
       *reinterpret_cast<u32x2*>(xd + WG_XPLANE + xl) = (u32x2){p1, q1};
@@ -1914,7 +1964,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wgrad_kernel(const SplitW
       uint32_t p0, p1, p2, q0, q1, q2;
       syn_split3(dst[i][0], dst[i][1], p0, p1, p2);
       syn_split3(dst[i][2], dst[i][3], q0, q1, q2);
-      const int dl = (tid + NTHR * i) * 8;
+      const int dl = DPLN ? ((xr + 128 * (i / 3)) * DQ + xq + 4 * (i % 3)) * 8 : (tid + NTHR * i) * 8;
       *reinterpret_cast<u32x2*>(dd + dl) = (u32x2){p0, q0};
       *reinterpret_cast<u32x2*>(dd + DPLANE + dl) = (u32x2){p1, q1};
       *reinterpret_cast<u32x2*>(dd + 2 * DPLANE + dl) = (u32x2){p2, q2};
