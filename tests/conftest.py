@@ -178,10 +178,18 @@ def align_pool_ties(dev_choices, oracle_inputs, max_ties=8, max_ulp=4.0, report=
     import torch
     eps = torch.finfo(torch.float32).eps
     nudges, n_ties = [], 0
-    for l, ((mask, _), t) in enumerate(zip(dev_choices, oracle_inputs)):
+    for l, ((mask, tdev), t) in enumerate(zip(dev_choices, oracle_inputs)):
         oshape = t.shape
         t = t.reshape(-1, *t.shape[-3:]) if t.dim() == 5 else t          # a batch [B, d0, ...] -> the stack [B d0, ...]
         w = _windows(t.float())
+        level_ulp = max_ulp
+        if tdev is not None and tuple(tdev.shape) == tuple(t.shape):
+            # (round 6) the two implementations' values of THIS tensor are both at hand: candidates closer than twice the distance
+            # between them cannot be ordered by either -- a few ulp in the network under test, more in a network downstream of
+            # its prediction (the frozen segmentation net inherits the prediction's 20-40 ulp); capped at 64 ulp
+            rms_t = max(float(w.pow(2).mean().sqrt()), 1e-30)
+            apart = float((tdev.detach().float().cpu() - t.float()).abs().max()) / (eps * rms_t)
+            level_ulp = min(64.0, max(max_ulp, 2.0 * apart))
         if report is not None:
             report['windows'] = report.get('windows', 0) + int(w.shape[0])
         idx_dev = _windows(mask.cpu()).float().argmax(1)
@@ -195,8 +203,8 @@ def align_pool_ties(dev_choices, oracle_inputs, max_ties=8, max_ulp=4.0, report=
         worst = float(((b - a) / ulp).max())
         if report is not None:
             report.setdefault('ulps', []).append(((b - a) / ulp).clone())
-        assert worst <= max_ulp, 'pooled level %d: device and oracle pick different maxima in %d windows whose candidates are up ' \
-            'to %.1f ulp apart: not a rounding tie' % (l, diff.numel(), worst)
+        assert worst <= level_ulp, 'pooled level %d: device and oracle pick different maxima in %d windows whose candidates are up ' \
+            'to %.1f ulp apart (allowed %.1f): not a rounding tie' % (l, diff.numel(), worst, level_ulp)
         nud = torch.zeros_like(w)
         nud[diff, idx_dev[diff]] = (b - a) + 8 * ulp
         nudges.append(_unwindows(nud, t.shape).reshape(oshape))
@@ -394,7 +402,7 @@ def single_shot_parity(run, oracle, compare, max_flips=8, loss_of=lambda net: ne
         ops.set_deterministic(prev)
     net = run()
     flips = 0
-    for l, ((m0, _), (m1, t1)) in enumerate(zip(det_pool, [c for n_ in pool_nets(net) for c in _pool_choices(n_)])):
+    for l, ((m0, t0), (m1, t1)) in enumerate(zip(det_pool, [c for n_ in pool_nets(net) for c in _pool_choices(n_)])):
         diff = (_windows(m0) != _windows(m1)).any(1)
         n = int(diff.sum())
         if n:
@@ -403,16 +411,34 @@ def single_shot_parity(run, oracle, compare, max_flips=8, loss_of=lambda net: ne
             a = (w * _windows(m0)[diff]).sum(1)
             b = (w * _windows(m1)[diff]).sum(1)
             # an ulp of the larger of (candidate, rms of the tensor): see align_pool_ties
-            ulp = torch.finfo(torch.float32).eps * torch.maximum(a.abs(), b.abs()).clamp_min(float(wall.float().pow(2).mean().sqrt()))
+            rms = float(wall.float().pow(2).mean().sqrt())
+            ulp = torch.finfo(torch.float32).eps * torch.maximum(a.abs(), b.abs()).clamp_min(rms)
             worst = float(((a - b).abs() / ulp).max())
-            assert worst <= 4.0, 'level %d: %d pooling windows changed their arg-max between the deterministic and the ' \
-                'atomics run, candidates up to %.1f ulp apart: not a rounding tie' % (l, n, worst)
+            # What counts as a tie BETWEEN THE TWO DEVICE RUNS: two candidates closer than twice the distance the pooled tensor
+            # itself moved from one run to the other cannot be ordered by either (each may have moved by that much).  The
+            # first network's tensors move by a few ulp (float atomics in its BatchNorm statistics: the flat 4 ulp of round 5);
+            # a DOWNSTREAM network (the frozen segmentation net reads the first one's prediction, which differs by up to ~36
+            # ulp between runs, KINK_ULP above) inherits its input's noise -- round 6's final suite flipped one window of that
+            # net whose candidates were 11.8 ulp apart.  Capped at 64 ulp: anything coarser is not rounding.
+            moved = float((t1.float() - t0.float()).abs().max()) / (torch.finfo(torch.float32).eps * max(rms, 1e-30))
+            tie = min(64.0, max(4.0, 2.0 * moved))
+            assert worst <= tie, 'level %d: %d pooling windows changed their arg-max between the deterministic and the ' \
+                'atomics run, candidates up to %.1f ulp apart while the tensor moved by %.1f ulp between the runs: not a ' \
+                'rounding tie' % (l, n, worst, moved)
             flips += n
     assert flips <= max_flips, '%d pooling windows flipped (> %d)' % (flips, max_flips)
     assert abs(float(loss_of(net)) - float(det_loss)) <= 2e-6 * max(1.0, abs(float(det_loss)))
     a_pr, a_dp = _kink_state(net)            # loss kinks: voxels where the two device runs' loss derivatives differ grossly
     kidx = _kink_disagreements(a_dp, det_kink[1])
-    if kidx.numel():
+    if flips and kidx.numel():
+        # a pooling window flipped between the runs: where it sits in a network DOWNSTREAM of the prediction (the frozen
+        # segmentation net) it re-routes d(loss)/d(pred) over its whole receptive field -- hundreds of voxels differ grossly
+        # between the two runs without any loss kink being involved, and the two effects cannot be told apart from the two
+        # device runs alone.  The atomics run is then judged against its OWN oracle only (below): aligned to its pooling masks,
+        # the oracle's d(loss)/d(pred) identifies its true kink ties (each <= KINK_ULP, at most max_flips) or fails.
+        print('single_shot_parity: %d pooling flip(s) between the device runs; d(loss)/d(pred) differs at %d voxels: kinks are '
+              'identified against the re-aligned oracle' % (flips, kidx.numel()))
+    elif kidx.numel():
         assert a_pr is not None and det_kink[0] is not None, 'the loss derivative of the two device runs differs grossly at %d ' \
             'voxels and the runs kept no prediction' % kidx.numel()
         worst = float(((a_pr[kidx] - det_kink[0][kidx]).abs() / _ulp_of(det_kink[0], kidx)).max())

@@ -362,7 +362,8 @@ def test_segmentation_loss_with_the_laplace_head_vs_autograd(T):
         assert abs(float(net.test_dice.item()) - float(dref)) < 2e-5
         # (every parameter gradient: the float64-anchored rule of conftest.single_shot_parity)
 
-    single_shot_parity(run, oracle, compare, loss_of=lambda n_: n_.test_loss, pool_nets=lambda n_: [n_, n_.test_segnet])
+    # (max_flips 32: see test_segmentation_regularised_loss_vs_autograd)
+    single_shot_parity(run, oracle, compare, loss_of=lambda n_: n_.test_loss, pool_nets=lambda n_: [n_, n_.test_segnet], max_flips=32)
     # two regression targets: refused like the reference's graph (the segmentation network takes ONE channel)
     from synthsr_amd.training import Trainer
     net4 = unet(24, list(shape) + [2], levels, 3, 4, feat_mult=2, nb_conv_per_level=2, batch_norm=-1, activation='elu',
@@ -471,9 +472,12 @@ def test_segmentation_regularised_loss_vs_autograd(T, fs_header, clip, crop, fro
         assert float((hb - ref[0][net.head['b']].grad).abs().max()) < 1e-5
 
     both = lambda net: [net, net.test_segnet]
-    single_shot_parity(make_run(w, False), make_oracle(False), compare_total, pool_nets=both)
+    # max_flips 32: with the segmentation network behind the prediction, d(loss)/d(pred) has more places where a rounding-sized
+    # change of the prediction shows grossly (the L1 kinks AND the frozen network's own pooling ties within its receptive field);
+    # a soak of the round-5 code (gpurun_out r06p: 6 runs) saw up to 14 such voxels of 16 k, each still <= KINK_ULP apart
+    single_shot_parity(make_run(w, False), make_oracle(False), compare_total, pool_nets=both, max_flips=32)
     # the Dice term alone (it is ~1 % of the total gradient here): weight 1
-    single_shot_parity(make_run(1.0, True), make_oracle(True), compare_dice, pool_nets=both)
+    single_shot_parity(make_run(1.0, True), make_oracle(True), compare_dice, pool_nets=both, max_flips=32)
 
 
 @pytest.mark.gpu
