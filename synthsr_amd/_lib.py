@@ -72,7 +72,8 @@ SIGNATURES = {
     'synthsr_conv3d_pack_ex': (c_int64, [_C, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_up_fwd': (c_int, [_C, _P, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, _S]),
     'synthsr_conv3d_up_dgrad': (c_int, [_C, _P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
-    'synthsr_conv3d_up_wgrad': (c_int, [_P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_conv3d_up_wgrad': (c_int, [_C, _P, _P, _P, POINTER(c_int), c_int, c_int, _S]),
+    'synthsr_conv3d_up_wgrad_runs_split': (c_int, [_C, POINTER(c_int), c_int, c_int]),
     'synthsr_conv3d_up_unpack': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad_bias': (c_int, [_C, _P, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),
     'synthsr_conv3d_wgrad_ex': (c_int, [_C, _P, _P, _P, POINTER(c_int), c_int, c_int, c_int, c_int, _S]),

@@ -279,9 +279,11 @@ __host__ __device__ inline bool syn_split_replanned(int vox_tiles, int co_tiles,
   const long long u3 = (long long)vox_tiles * (co_tiles / 3);
   return u3 > 512 && u3 < 768;
 }
-__host__ __device__ inline int syn_split_plan_mt(int vox_tiles, int co_tiles, bool plain) {
+// (`replan`: plain convs and, since the A/B of profiles/r06_folded_dgrad_replan_ab.txt, the data gradient of a folded decoder conv --
+// 40^3 96 <- 48: 0.326 -> 0.252 ms; not the folded forward pass, whose kernel takes one co-chunk)
+__host__ __device__ inline int syn_split_plan_mt(int vox_tiles, int co_tiles, bool replan) {
   const int mt = co_tiles <= 3 ? co_tiles : ((co_tiles % 3) == 0 ? 3 : ((co_tiles % 2) == 0 ? 2 : 1));
-  if (plain && mt == 3 && syn_split_replanned(vox_tiles, co_tiles, 2)) return 2;
+  if (replan && mt == 3 && syn_split_replanned(vox_tiles, co_tiles, 2)) return 2;
   return mt;
 }
 

@@ -2971,6 +2971,8 @@ static float* ctx_scratch(size_t bytes) {
 
 extern "C" int syn_split_wgrad(const float* in, const float* dout, float* dw, float* dbias, const int s[3], int cin_total,
                                int ci_off, int Cin, int Cout, int nprod, hipStream_t st);
+extern "C" int syn_split_upwgrad(const float* lo, const float* dout, float* dwc, const int s[3], int Cin, int Cout, int nprod,
+                                 hipStream_t st);
 extern "C" int syn_split_upfwd(const float* lo, const float* wp, const float* bias, const float* addend, float* out,
                                const int s[3], int Cin, int Cout, int mt, int act, int nprod, hipStream_t st);
 extern "C" int syn_split_fwd_halves(const int s[3], int Cin, int nchunks, int stacked, int nprod);
@@ -2984,6 +2986,14 @@ inline bool wgrad_takes_split(const int s[3], int Cin, int Cout) {
   const int64_t vox = (int64_t)s[0] * s[1] * s[2];
   return cfg().split && (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) >= PLAN_SPLIT_WGRAD_MIN_TILES && (Cin % 8) == 0 && (Cout % 24) == 0 &&
          vox * Cin * 4 < (1ll << 31) && vox * Cout * 4 < (1ll << 31);
+}
+
+// ... and the weight gradient of the up-sampled channel range of a folded decoder conv (conv_split.hip: syn_split_upwgrad: six
+// products, 16-channel input chunks, 24-column chunks)?  Asked by the dispatcher and by synthsr_conv3d_up_wgrad_runs_split
+inline bool up_wgrad_takes_split(const int s[3], int Cl, int Cout) {
+  const int64_t vox = (int64_t)s[0] * s[1] * s[2];
+  return cfg().split && cfg().nprod == 6 && (Cl % 16) == 0 && (Cout % 24) == 0 && vox * Cl * 4 < (1ll << 31) &&
+         8 * vox * Cout * 4 < (1ll << 31);
 }
 
 struct FwdPlan {
@@ -3015,7 +3025,7 @@ inline FwdPlan plan_fwd(const int s[3], int Cin, int Cout, int kind = 1) {
     // fp32 through three bf16 pieces per operand on the bf16 matrix cores (conv_split.hip): layers with enough 4x4x16 tiles
     const int64_t vox = (int64_t)s[0] * s[1] * s[2];
     const int ntiles = cdiv(Cout, 16);
-    const int mt = syn_split_plan_mt(cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16), ntiles, plain);
+    const int mt = syn_split_plan_mt(cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16), ntiles, kind != 2);
     const int nchunks = cdiv(ntiles, mt);
     const int64_t wgs = (int64_t)cdiv(s[0], 4) * cdiv(s[1], 4) * cdiv(s[2], 16) * nchunks;
     // (kind 0 = data gradient of a folded decoder conv: s is the low-resolution grid, the input lives on the 2x grid)
@@ -3714,6 +3724,11 @@ template <int NTAPS>
 int dispatch_wgrad(const float* in, const float* dout, float* dw, const int shape[3], int Cin, int Cout, hipStream_t st,
                    const WgExt& ext) {
   if constexpr (NTAPS == 8) {
+    // fp32 through three bf16 pieces per operand: the eight waves of a workgroup = the eight parities over one staged x halo
+    if (up_wgrad_takes_split(shape, Cin, Cout)) {
+      const int rc = syn_split_upwgrad(in, dout, dw, shape, Cin, Cout, cfg().nprod, st);
+      if (rc != SYNTHSR_EINVAL) return rc;
+    }
     const int64_t vox = (int64_t)shape[0] * shape[1] * shape[2];
     const int tiles0 = cdiv(shape[0], FT0), tiles1 = cdiv(shape[1], 4), tiles2 = cdiv(shape[2], FT2);
     const int ntiles = tiles0 * tiles1 * tiles2, ncc = Cin / 24;
@@ -3840,6 +3855,13 @@ int synthsr_conv3d_wgrad_runs_split(const synthsr_conv_ctx* ctx, const int shape
   if (!scope.ok) return SYNTHSR_EINVAL;
   if (!shape || Cin < 1 || Cout < 1 || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return SYNTHSR_EINVAL;
   return (Cin > 2 || Cout != 24) && wgrad_takes_split(shape, Cin, Cout) ? 1 : 0;
+}
+
+int synthsr_conv3d_up_wgrad_runs_split(const synthsr_conv_ctx* ctx, const int lo_shape[3], int Cl, int Cout) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
+  if (!lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1) return SYNTHSR_EINVAL;
+  return up_wgrad_takes_split(lo_shape, Cl, Cout) ? 1 : 0;
 }
 
 int synthsr_conv3d_pack_all(const float* params, float* packed, const int64_t* jobs_dev, int njobs,
@@ -4074,8 +4096,10 @@ int synthsr_conv3d_wgrad(const synthsr_conv_ctx* ctx, const float* in, const flo
   return synthsr_conv3d_wgrad_ex(ctx, in, dout, dw, shape, Cin, 0, Cin, Cout, stream);
 }
 
-int synthsr_conv3d_up_wgrad(const float* lo, const float* dout, float* dwc, const int lo_shape[3], int Cl, int Cout,
-                            synthsr_stream_t stream) {
+int synthsr_conv3d_up_wgrad(const synthsr_conv_ctx* ctx, const float* lo, const float* dout, float* dwc, const int lo_shape[3],
+                            int Cl, int Cout, synthsr_stream_t stream) {
+  const CtxScope scope(ctx);
+  if (!scope.ok) return SYNTHSR_EINVAL;
   if (!lo || !dout || !dwc || !lo_shape || Cl < 1 || Cout < 1 || lo_shape[0] < 1 || lo_shape[1] < 1 || lo_shape[2] < 1)
     return SYNTHSR_EINVAL;
   const WgExt ext{1, Cl, 0, (int64_t)27 * Cl * Cout, PLAN_DBG, nullptr};

@@ -39,6 +39,11 @@ extern "C" int synthsr_split_timing_buffer(long long* p) {
 #define TM(i)
 #define T2(k)
 #endif
+#ifdef SYN_SPLIT_TIMING  // per-WAVE stamps of workgroup (7, 0): slot (800 + (wave * 48 + n3) * 2 + i) of the int64 buffer
+#define T3(i) do { if (g_tm && lane == 0 && blockIdx.x == 7 && blockIdx.y == 0 && n3 < 48) g_tm[1600 + ((tid >> 6) * 48 + n3) * 2 + (i)] = clock64(); } while (0)
+#else
+#define T3(i)
+#endif
 
 // Arithmetic "split9" (synthsr_conv_ctx.arithmetic = 2): all nine partial products a_i b_j instead of six -- an fp32 product is
 // then reproduced EXACTLY (tests/test_split_arithmetic_cpu.py) at 1.5x the MFMAs; same packed weights, same kernels (template
@@ -2162,7 +2167,293 @@ int launch_split_wgrad(const SplitWgArgs& a, hipStream_t st) {
   return t_nprod == 9 ? launch_split_wgrad_np<COW, 9>(a, st) : launch_split_wgrad_np<COW, 6>(a, st);
 }
 
+// ---- weight gradient of the up-sampled channel range of a FOLDED decoder conv (round 6; unet.py; ext/neuron/models.py:426-444
+// UpSampling3D -> concatenate -> Conv3D) in split arithmetic:
+//   dwc[p][slot][ci][co] = sum over low-res voxels v of lo[v + slot - 1][ci] * dz[2 v + p][co],  slot in p + {0, 1}^3 per axis
+// (8 parities x 8 of the 27 slots; synthsr_conv3d_up_unpack folds them onto the 27 original taps).  Round 3 built this as one
+// workgroup per parity and lost (1.05 vs 0.72 ms at 80^3): a converted x halo then feeds 8 taps instead of 27.  Here the EIGHT
+// WAVES of a workgroup each own ONE PARITY over the SAME staged x halo (16 input channels, the plain kernel's 62 KB image), so a
+// converted halo feeds 64 (parity, tap) row tiles.  dz -- eight times the voxels of x -- goes through LDS in STAGES of one K step:
+// two low-res x-rows (y = 2 kj, 2 kj + 1) of a z plane of the tile for all eight parities = [piece 3][parity 8][32 voxels][24
+// channels] = 36 KB, double buffered; the hi-res rows are read as whole 3 KB lines.  A wave and stage: 8 row tiles (tap x 16
+// channels) x the five stacked column tiles of the 24-column kernel = 80 MFMAs; wave w also stages hi-res x-row w of the NEXT
+// stage (8 rows = 2 z parities x 2 low-res rows x 2 y parities; three 16-byte pieces per lane, requested one stage earlier):
+// each piece is split and stored into the other buffer between the MFMAs of a row tile, in the shadow of the wave's own matrix
+// instructions (a wave that converts next to ANOTHER wave's MFMA stream gets one vector instruction per ~27 cycles: measured,
+// profiles/r06_upwgrad_phase_timing.txt); one barrier per stage.  The x image is single-buffered: its next tile is
+// requested in the last stage of a tile and stored between two barriers at the tile boundary.  No cross-wave reduction at the
+// end -- every wave flushes its own parity.  Cout = 24 nco: the column chunk is blockIdx.y / ncc.
+struct SplitUpWgArgs {
+  const float* lo;    // x [D0][D1][D2][Cin] (the low-resolution tensor)
+  const float* dout;  // dz [2 D0][2 D1][2 D2][Cout]
+  float* dwc;         // [8][27][Cin][Cout], accumulated with atomics
+  int D0, D1, D2, Cin, Cout, ncc, nco, tiles1, tiles2, ntiles;
+  int64_t det_stride;
+};
+
+constexpr int UW_XB = 32, UW_XPLANE = HVOX * UW_XB;            // 16 channels x 2 bytes; one piece of the x halo image
+constexpr int UW_DROWB = 48, UW_PARB = 2 * TX * UW_DROWB;      // a voxel's 24 channels; one parity of a stage (2 x-rows)
+constexpr int UW_DPLANE = 8 * UW_PARB, UW_DBUF = 3 * UW_DPLANE;  // one piece of a stage image; a stage image
+constexpr int UW_DOFF = 3 * UW_XPLANE, UW_ZOFF = UW_DOFF + 2 * UW_DBUF, UW_LDS = UW_ZOFF + 64;
+constexpr int UW_NST = 2 * TZ;                                 // stages of a tile: (z plane, x-row pair)
+static_assert(UW_LDS <= 160 * 1024, "x halo image + two dz stage images fit the LDS");
+
+__global__ __launch_bounds__(512, 1) void conv3d_split_upwgrad_kernel(const SplitUpWgArgs a) {
+  constexpr int XQ = 4, DQ = 6, RT = 8, NDL = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int par = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's parity
+  const int pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
+  const int g = lane >> 4, li = lane & 15, lrow = li >> 2, lq = li & 3;
+  const int cc = blockIdx.y % a.ncc, oc = blockIdx.y / a.ncc;
+  const TileWalk walk = tile_walk(a.ntiles);
+  const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
+  const int D0 = a.D0, D1 = a.D1, D2 = a.D2, Cin = a.Cin, Cout = a.Cout;
+
+  // operand addresses (the K <-> voxel bijection of conv3d_split_wgrad_kernel: K index 8 g + j <-> voxel (row g >> 1,
+  // x = 8 (j >> 2) + 4 (g & 1) + (j & 3)) of the two x-rows of a K step); row tile q = tap (q >> 2, (q >> 1) & 1, q & 1) of the
+  // parity's 2x2x2 window, whose halo origin is the parity itself (slot = p + tap per axis), channel quad lq
+  const int vx = 4 * (g & 1) + lrow, vr = g >> 1;
+  uint32_t aaddr[RT];
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    const int hz = pz + (q >> 2), hy = py + ((q >> 1) & 1), hx = px + (q & 1);
+    aaddr[q] = (uint32_t)((((hz * HY + hy + vr) * HX) + hx + vx) * UW_XB + lq * 8);
+  }
+  const uint32_t bvox = (uint32_t)(UW_DOFF + par * UW_PARB + (vr * TX + vx) * UW_DROWB);
+  const uint32_t bbase = bvox + (uint32_t)(lq * 8);
+  // stacked column tiles U3 / U4: channels 16-23 (byte 32 of the row) of piece lq >> 1 resp. of piece 2 | the zeroed slack
+  const uint32_t u3off = bvox + (uint32_t)((lq >> 1) * UW_DPLANE + 32 + (lq & 1) * 8);
+  const uint32_t u4off = lq < 2 ? bvox + (uint32_t)(2 * UW_DPLANE + 32 + (lq & 1) * 8) : (uint32_t)UW_ZOFF;
+  const uint32_t u4hi = lq < 2 ? (uint32_t)(8 * UW_DROWB) : 0u;
+  if (tid < 2) *reinterpret_cast<uint64_t*>(lds + UW_ZOFF + tid * 8) = 0ull;
+
+  // staging of the x halo: thread = (channel quad tid & 3, in-plane halo voxel tid >> 2 of the 6 x 18), piece i = halo plane i
+  const int xq = tid & 3, xr = tid >> 2;
+  const int xps = D1 * D2 * Cin * 4;
+  const int xhy = xr / HX, xhx = xr - xhy * HX;
+  const int xrel = (xhy * D2 + xhx) * Cin * 4 + xq * 16;
+  const uint32_t xmask = xr < HY * HX ? ((1u << (6 + xhy)) | (1u << (12 + xhx))) : 0xFFFFFFFFu;
+  // staging of a dz stage: wave w = hi-res x-row (z parity w >> 2, low-res row (w >> 1) & 1, y parity w & 1) of the stage; piece k =
+  // 64-lane third k of the row's 192 16-byte pieces: hi-res x m / 6, channel quad m % 6 (m = 64 k + lane)
+  const int D1h = 2 * D1, D2h = 2 * D2;
+  const int dpz = par >> 2, dyl = (par >> 1) & 1, dpy = par & 1;
+  int drel[3], dxlo[3];
+  uint32_t dlds[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int m = k * 64 + lane, hx = m / DQ, dq = m - hx * DQ;
+    drel[k] = hx * Cout * 4 + (oc * 24 + dq * 4) * 4;
+    dxlo[k] = hx >> 1;
+    dlds[k] = (uint32_t)(UW_DOFF + (dpz * 4 + dpy * 2 + (hx & 1)) * UW_PARB + (dyl * TX + (hx >> 1)) * UW_DROWB + dq * 8);
+  }
+  const int dyp = D2h * Cout * 4;              // bytes from a hi-res row to the next
+  const int dwave = (dpz * D1h + 2 * dyl + dpy) * dyp;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lo), 0, (int)((int64_t)D0 * D1 * D2 * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.dout), 0, (int)((int64_t)8 * D0 * D1 * D2 * Cout * 4), 0x00020000);
+  f32x4 xst[HZ], dst[2][NDL];  // dz: two register sets (stage parity)
+  auto load_x = [&](int t) {
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    uint32_t bad = 0x80000000u;
+#pragma unroll
+    for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
+#pragma unroll
+    for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
+#pragma unroll
+    for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
+    const int base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 16) * 4;
+#pragma unroll
+    for (int i = 0; i < HZ; ++i) {
+      const uint32_t vo = ((xmask | (1u << i)) & bad) ? OOB : (uint32_t)(xrel + i * xps + base);
+      xst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, 0, 0));
+    }
+  };
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  auto store_x = [&]() {
+    if (xr >= HY * HX) return;
+#pragma unroll
+    for (int i = 0; i < HZ; ++i) {
+      uint32_t p0, p1, p2, q0, q1, q2;
+      syn_split3(xst[i][0], xst[i][1], p0, p1, p2);
+      syn_split3(xst[i][2], xst[i][3], q0, q1, q2);
+      const int xl = ((i * (HY * HX) + xr) * XQ + xq) * 8;
+      *reinterpret_cast<u32x2*>(lds + xl) = (u32x2){p0, q0};
+      *reinterpret_cast<u32x2*>(lds + UW_XPLANE + xl) = (u32x2){p1, q1};
+      *reinterpret_cast<u32x2*>(lds + 2 * UW_XPLANE + xl) = (u32x2){p2, q2};
+    }
+  };
+  auto load_dz = [&](int t, int st, int set) {  // stage st = (z plane st >> 1, x-row pair st & 1) of tile t
+    int z0, y0, x0;
+    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+    const int zp = st >> 1, yy = y0 + 2 * (st & 1) + dyl;
+    const bool okr = z0 + zp < D0 && yy < D1;
+    const int base = ((2 * (z0 + zp) * D1h + 2 * (y0 + 2 * (st & 1))) * D2h + 2 * x0) * Cout * 4 + dwave;
+#pragma unroll
+    for (int k = 0; k < NDL; ++k) {
+      const int vo = (okr && x0 + dxlo[k] < D2) ? base + drel[k] : (int)OOB;
+      dst[set][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, vo, 0, 0));
+    }
+  };
+  auto store_dz1 = [&](int set, int k, int buf) {  // piece k of register set `set` into stage image `buf`
+    uint32_t p0, p1, p2, q0, q1, q2;
+    syn_split3(dst[set][k][0], dst[set][k][1], p0, p1, p2);
+    syn_split3(dst[set][k][2], dst[set][k][3], q0, q1, q2);
+    unsigned char* d = lds + dlds[k] + buf * UW_DBUF;
+    *reinterpret_cast<u32x2*>(d) = (u32x2){p0, q0};
+    *reinterpret_cast<u32x2*>(d + UW_DPLANE) = (u32x2){p1, q1};
+    *reinterpret_cast<u32x2*>(d + 2 * UW_DPLANE) = (u32x2){p2, q2};
+  };
+
+  f32x4 acc[RT][2];
+#pragma unroll
+  for (int q = 0; q < RT; ++q) acc[q][0] = acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int n2 = 0, n3 = 0;
+  (void)n2;
+  (void)n3;
+  T2(0);
+  if (walk.pos < walk.end) {
+    load_x(walk.pos);
+    load_dz(walk.pos, 0, 0);
+    load_dz(walk.pos, 1, 1);
+    store_x();
+#pragma unroll
+    for (int k = 0; k < NDL; ++k) store_dz1(0, k, 0);
+  }
+  __syncthreads();
+  T2(1);
+  for (int t = walk.pos; t < walk.end; t += walk.stride) {
+    const bool more = t + walk.stride < walk.end;
+    sfor<0, UW_NST>([&](auto ST) {
+      constexpr int st = decltype(ST)::value, zp = st >> 1, kj = st & 1;
+      T2(2);
+      T3(0);
+      // requests: the stage after the next one into the register set this stage's image came from; the next tile's x halo
+      if constexpr (st + 2 < UW_NST) {
+        load_dz(t, st + 2, kj);
+      } else {
+        if (more) load_dz(t + walk.stride, st + 2 - UW_NST, kj);
+      }
+      if constexpr (st == UW_NST - 1) {
+        if (more) load_x(t + walk.stride);
+      }
+      const bool next = st + 1 < UW_NST || more;  // is there a next stage to convert (its pieces: register set kj ^ 1)
+      {
+        constexpr uint32_t ak = (uint32_t)((zp * HY * HX + kj * 2 * HX) * UW_XB), bk = (uint32_t)(kj * UW_DBUF);
+        u32x4 bfr[3][2], afr[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          bfr[p][0] = tr_read8(lds + bbase + bk + p * UW_DPLANE, lds + bbase + bk + p * UW_DPLANE + 8 * UW_DROWB);
+        bfr[0][1] = tr_read8(lds + u3off + bk, lds + u3off + bk + 8 * UW_DROWB);                   // U3
+        bfr[1][1] = tr_read8(lds + u4off + (lq < 2 ? bk : 0u), lds + u4off + (lq < 2 ? bk : 0u) + u4hi);  // U4
+        auto aload = [&](int q, int slot) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            afr[slot][p] = tr_read8(lds + aaddr[q] + ak + p * UW_XPLANE, lds + aaddr[q] + ak + p * UW_XPLANE + 8 * UW_XB);
+        };
+        aload(0, 0);
+        sfor<0, RT>([&](auto Q) {
+          constexpr int q = decltype(Q)::value;
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (q + 1 < RT) aload(q + 1, (q + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          // (x piece, column tile, accumulator) in the order of the stacked 24-column kernel: smallest terms first
+          auto mm = [&](int xa, int pb, int nb, int ac) {
+            acc[q][ac] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[q & 1][xa]),
+                                                                  __builtin_bit_cast(bf16x8, bfr[pb][nb]), acc[q][ac], 0, 0, 0);
+          };
+          mm(0, 2, 0, 0);  // x0 U2
+          mm(0, 1, 1, 1);  // x0 U4
+          mm(2, 0, 0, 0);  // x2 U0
+          mm(2, 0, 1, 1);  // x2 U3
+          mm(1, 1, 0, 0);  // x1 U1
+          mm(1, 0, 1, 1);  // x1 U3
+          mm(0, 1, 0, 0);  // x0 U1
+          mm(0, 0, 1, 1);  // x0 U3
+          mm(1, 0, 0, 0);  // x1 U0
+          mm(0, 0, 0, 0);  // x0 U0
+          // the next stage's pieces, one per row tile 2, 4, 6 (requested a stage ago), in the shadow of these MFMAs
+          if constexpr (q >= 2 && (q & 1) == 0) {
+            if (next) store_dz1(kj ^ 1, q / 2 - 1, kj ^ 1);
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      T2(3);
+      T3(1);
+      T2(4);
+#ifdef SYN_SPLIT_TIMING
+      ++n3;
+#endif
+      if constexpr (st == UW_NST - 1) {
+        __syncthreads();  // everyone is done with the tile's x image
+        if (more) store_x();
+      }
+      __syncthreads();  // the next stage's image is complete, this stage's is free
+      T2(5);
+    });
+  }
+  // ---- flush: this wave's parity; columns 16-23 = columns 0-7 + 8-15 of the stacked tile
+#pragma unroll
+  for (int q = 0; q < RT; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[q][1][i] += __shfl_down(acc[q][1][i], 8, 16);
+  float* dwp = a.dwc + (size_t)blockIdx.x * a.det_stride + (size_t)par * 27 * Cin * Cout;
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    const int slot = ((pz + (q >> 2)) * 3 + py + ((q >> 1) & 1)) * 3 + px + (q & 1);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int col = n * 16 + li;
+      if (col >= 24) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ci = cc * 16 + 4 * g + i;
+        atomicAdd(dwp + ((int64_t)slot * Cin + ci) * Cout + oc * 24 + col, acc[q][n][i]);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// weight gradient of the up-sampled channel range of a folded decoder conv (six products; SYNTHSR_EINVAL = shape not covered, the
+// caller takes the fp32-MFMA path); dwc [8][27][Cin][Cout] accumulated (the caller zeroes it)
+extern "C" __attribute__((visibility("hidden"))) int syn_split_upwgrad(const float* lo, const float* dout, float* dwc,
+                                                                        const int s[3], int Cin, int Cout, int nprod,
+                                                                        hipStream_t st) {
+  if (nprod != 6 || (Cin % 16) != 0 || (Cout % 24) != 0) return SYNTHSR_EINVAL;
+  const int64_t vox = (int64_t)s[0] * s[1] * s[2];
+  if (vox * Cin * 4 >= (1ll << 31) || 8 * vox * Cout * 4 >= (1ll << 31)) return SYNTHSR_EINVAL;
+  SplitUpWgArgs a;
+  a.lo = lo;
+  a.dout = dout;
+  a.dwc = dwc;
+  a.D0 = s[0]; a.D1 = s[1]; a.D2 = s[2];
+  a.Cin = Cin; a.Cout = Cout;
+  a.ncc = Cin / 16;
+  a.nco = Cout / 24;
+  a.tiles1 = (s[1] + TY - 1) / TY;
+  a.tiles2 = (s[2] + TX - 1) / TX;
+  a.ntiles = ((s[0] + TZ - 1) / TZ) * a.tiles1 * a.tiles2;
+  const int gy = a.ncc * a.nco;
+  const int gx = split_wgrad_grid_x(a.ntiles, gy);
+  static SynOncePerDevice attr_done;
+  if (auto once_ = attr_done.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_split_upwgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)UW_LDS);
+  }
+  DetRun det;
+  float* no_dbias = nullptr;
+  if (const int rc_ = syn_det_prepare(&det, &a.dwc, &no_dbias, (int64_t)8 * 27 * Cin * Cout, Cout, gx, st)) return rc_;
+  a.det_stride = det.stride;
+  hipLaunchKernelGGL(conv3d_split_upwgrad_kernel, dim3(gx, gy), dim3(512), (size_t)UW_LDS, st, a);
+  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  return syn_det_finish(&det, st);
+}
 
 // include/synthsr_hip_tuning.h: host restatement (the same function the kernels call) of the tile schedule, for tests
 extern "C" int synthsr_split_tile_schedule(int kernel, int ntiles, int ny, int block_x, int block_yz, int out[4]) {

@@ -95,10 +95,15 @@ def conv_runs_split(kind, shape, cin, cout):
     """whether a conv launch of this kind ('conv3d_fwd' | 'conv3d_dgrad' | 'conv3d_wgrad' | 'conv3d_up_fwd' | 'conv3d_up_dgrad',
     the names of the profile records) runs on the split kernels under the CURRENT arithmetic (mirrors the dispatcher: csrc/conv3d.hip plan_fwd /
     dispatch_wgrad); used by the benchmarks to price a kernel against the right peak"""
-    kinds = ('conv3d_fwd', 'conv3d_dgrad', 'conv3d_wgrad', 'conv3d_up_fwd', 'conv3d_up_dgrad')
-    if conv_arithmetic() == 'fp32_mfma' or kind not in kinds:   # (conv3d_up_wgrad: fp32 MFMA in every mode)
+    kinds = ('conv3d_fwd', 'conv3d_dgrad', 'conv3d_wgrad', 'conv3d_up_fwd', 'conv3d_up_dgrad', 'conv3d_up_wgrad')
+    if conv_arithmetic() == 'fp32_mfma' or kind not in kinds:
         return False
     d0, d1, d2 = [int(v) for v in shape[:3]]
+    if kind == 'conv3d_up_wgrad':   # (low-res shape, Cl, Cout): csrc/conv3d.hip up_wgrad_takes_split
+        rc = int(_L().synthsr_conv3d_up_wgrad_runs_split(conv_ctx_host(), _lib.i3((d0, d1, d2)), int(cin), int(cout)))
+        if rc < 0:
+            _lib.check(rc, 'conv3d_up_wgrad_runs_split')
+        return rc == 1
     if kind == 'conv3d_wgrad':   # the dispatcher's own condition (csrc/conv3d.hip: wgrad_takes_split)
         rc = int(_L().synthsr_conv3d_wgrad_runs_split(conv_ctx_host(), _lib.i3((d0, d1, d2)), int(cin), int(cout)))
         if rc < 0:
@@ -362,8 +367,8 @@ def conv3d_up_wgrad(lo, dout, dwc, dw, ci_off):
                                                 int(dout.shape[3]), _lib.stream()), 'conv3d_up_unpack')
         return dw
     with _Timed('conv3d_up_wgrad', s[:3], s[3], dout.shape[3]):
-        _check_wgrad(lambda: lib.synthsr_conv3d_up_wgrad(_lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]), int(s[3]),
-                                               int(dout.shape[3]), _lib.stream()), 'conv3d_up_wgrad')
+        _check_wgrad(lambda: lib.synthsr_conv3d_up_wgrad(conv_ctx(), _lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]),
+                                               int(s[3]), int(dout.shape[3]), _lib.stream()), 'conv3d_up_wgrad')
     _lib.check(lib.synthsr_conv3d_up_unpack(_lib.ptr(dwc), _lib.ptr(dw), int(dw.shape[3]), int(ci_off), int(s[3]),
                                             int(dout.shape[3]), _lib.stream()), 'conv3d_up_unpack')
     return dw
@@ -889,7 +894,7 @@ def conv3d_stride2_wgrad(x, dy, dw, dwc, dbias=None):
     lib = _L()
     Ci, Co = int(x.shape[3]), int(dy.shape[3])
     dwc.zero_()
-    _check_wgrad(lambda: lib.synthsr_conv3d_up_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dwc), _lib.i3(dy.shape[:3]), Co, Ci,
+    _check_wgrad(lambda: lib.synthsr_conv3d_up_wgrad(conv_ctx(), _lib.ptr(dy), _lib.ptr(x), _lib.ptr(dwc), _lib.i3(dy.shape[:3]), Co, Ci,
                                            _lib.stream()), 'conv3d_stride2_wgrad')
     _lib.check(lib.synthsr_conv3d_stride_unpack(_lib.ptr(dwc), _lib.ptr(dw), Ci, Co, _lib.stream()), 'stride_unpack')
     if dbias is not None:

@@ -290,7 +290,8 @@ def test_conv_arithmetic_switch_and_layer_plans():
     assert ops.conv_runs_split('conv3d_up_fwd', (80, 80, 80), 48, 24)     # folded decoder conv, up-sampled channels (low-res grid)
     assert ops.conv_runs_split('conv3d_up_dgrad', (80, 80, 80), 48, 24)
     assert not ops.conv_runs_split('conv3d_up_fwd', (20, 20, 20), 192, 96)
-    assert not ops.conv_runs_split('conv3d_up_wgrad', (80, 80, 80), 48, 24)   # fp32 MFMA in both modes
+    assert ops.conv_runs_split('conv3d_up_wgrad', (80, 80, 80), 48, 24)       # (round 6) eight parities over one staged x halo
+    assert not ops.conv_runs_split('conv3d_up_wgrad', (80, 80, 80), 40, 24)   # 16-channel input chunks
     prev = ops.set_conv_arithmetic('fp32_mfma')
     try:
         assert prev == 'split' and ops.conv_arithmetic() == 'fp32_mfma'

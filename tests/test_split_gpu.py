@@ -109,7 +109,7 @@ def test_split_conv_is_as_accurate_as_the_fp32_mfma_kernels(D, ci, co, kind):
 def test_split_folded_decoder_conv_vs_float64(D, cs, cl, co):
     """the up-sampled channel range of a folded decoder conv (8 parity 2x2x2 convs on the low-resolution tensor): forward and data
     gradient in split arithmetic against a float64 evaluation of conv3(UpSampling3D(2)(lo)) and its gradient, next to the fp32
-    MFMA kernels (the weight gradient of this part runs on fp32 MFMA in both modes)"""
+    MFMA kernels (the weight gradient of this part: test_split_folded_weight_gradient_vs_float64)"""
     from synthsr_amd import ops
     g = torch.Generator(device='cpu').manual_seed(D + cl)
     lo = torch.randn(D, D, D, cl, generator=g).cuda()
@@ -272,6 +272,56 @@ def test_network_step_agrees_between_the_two_arithmetics():
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
     assert cos > 1 - 1e-6, cos
     assert float((g0 - g1).abs().max()) < 2e-3 * float(g0.abs().max())   # max-pool ties may route a few gradients differently
+
+
+def _up_wgrad64(lo, dz):
+    """float64 weight gradient of conv3(UpSampling3D(2)(lo)) w.r.t. its [3,3,3,Cl,Cout] kernel"""
+    up = lo.double().cpu().repeat_interleave(2, 0).repeat_interleave(2, 1).repeat_interleave(2, 2)
+    return _wgrad64(up, dz)
+
+
+@pytest.mark.parametrize('lo_shape,cl,co', [
+    ((16, 16, 32), 48, 24), ((8, 8, 16), 96, 48), ((4, 4, 16), 16, 24), ((10, 10, 10), 32, 24), ((5, 7, 9), 16, 48),
+    ((18, 14, 34), 48, 24), ((20, 20, 20), 192, 96), ((12, 10, 18), 64, 72)])
+def test_split_folded_weight_gradient_vs_float64(lo_shape, cl, co):
+    """(round 6) the weight gradient of the up-sampled channel range of a folded decoder conv in split arithmetic
+    (csrc/conv_split.hip conv3d_split_upwgrad_kernel: the eight waves of a workgroup = the eight output parities over one staged
+    low-resolution halo; models.py:426-444) against a float64 evaluation of the weight gradient of conv3(UpSampling3D(2)(lo)),
+    next to the fp32 matrix instructions: few tiles, ragged volumes, several column chunks, TWO volumes accumulated into one dW as
+    a batch does; ordered sums and float atomics."""
+    from synthsr_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(sum(lo_shape) + 7 * cl + co)
+    hi = tuple(2 * v for v in lo_shape)
+    los = [torch.randn(*lo_shape, cl, generator=g) for _ in range(2)]
+    dzs = [torch.randn(*hi, co, generator=g) * s for s in (1.0, 1.7)]
+    cs = 8
+    ref = sum(_up_wgrad64(lo, dz) for lo, dz in zip(los, dzs))
+    los, dzs = [v.cuda() for v in los], [v.cuda() for v in dzs]
+    res = {}
+    prev = ops.conv_arithmetic()
+    try:
+        for mode in ('fp32_mfma', 'split'):
+            ops.set_conv_arithmetic(mode)
+            assert ops.conv_runs_split('conv3d_up_wgrad', lo_shape, cl, co) == (mode == 'split')
+            for det in (True, False):
+                prev_det = ops.set_deterministic(det)
+                try:
+                    dw = torch.zeros(3, 3, 3, cs + cl, co, device='cuda')
+                    dwc = torch.empty(8, 27, cl, co, device='cuda')
+                    for lo, dz in zip(los, dzs):
+                        ops.conv3d_up_wgrad(lo, dz, dwc, dw, cs)
+                    assert not det or ops.deterministic_status() == 1
+                finally:
+                    ops.set_deterministic(prev_det)
+                assert float(dw[:, :, :, :cs].abs().max()) == 0.0          # the skip channels' rows are not touched
+                res[mode, det] = _err(dw[:, :, :, cs:], ref)
+    finally:
+        ops.set_conv_arithmetic(prev)
+    for det in (True, False):
+        (nmax, nrms), (smax, srms) = res['fp32_mfma', det], res['split', det]
+        # the bounds of test_split_weight_gradient_small_and_ragged_layers_vs_float64 (sums of <= 2 x 8 x 9 216 products)
+        assert srms < 2e-6 and smax < 2e-5, (det, res)
+        assert srms <= 1.5 * nrms + 2e-8 and smax <= 2.5 * nmax + 2e-7, (det, res)
 
 
 @pytest.mark.parametrize('shape,ci,co', [
