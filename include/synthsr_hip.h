@@ -239,15 +239,16 @@ int synthsr_conv3d_up_fwd(const synthsr_conv_ctx* ctx, const float* lo, const fl
 /* dlo[lo_shape, Cl] = adjoint of upconv applied to dout [2*lo_shape, Cout]; wpacked8 from pack_ex(..., mode 1, up 1) */
 int synthsr_conv3d_up_dgrad(const synthsr_conv_ctx* ctx, const float* dout, const float* wpacked8, float* dlo,
                             const int lo_shape[3], int Cl, int Cout, synthsr_stream_t stream);
-/* per-parity weight gradients dwc[8][27][Cl][Cout] (zeroed by the caller) ...  (takes the context like every conv entry point of ABI 2 -- under split
+/* per-parity weight gradients dwc[8][27][Cl][Cout] (ACCUMULATED: zeros before the first use, see _up_unpack) ...  (takes the context like every conv entry point of ABI 2 -- under split
  * arithmetic with Cl % 16 == 0 and Cout % 24 == 0 it runs in split arithmetic, conv_split.hip conv3d_split_upwgrad_kernel) */
 int synthsr_conv3d_up_wgrad(const synthsr_conv_ctx* ctx, const float* lo, const float* dout, float* dwc, const int lo_shape[3],
                             int Cl, int Cout, synthsr_stream_t stream);
 /* 1 / 0: whether that launch runs on the split kernel under this context (the dispatcher's own condition) */
 int synthsr_conv3d_up_wgrad_runs_split(const synthsr_conv_ctx* ctx, const int lo_shape[3], int Cl, int Cout);
-/* ... folded back onto the original taps: dw[27][Cin_total][Cout] (+=) at channels [ci_off, ci_off+Cl) */
-int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_off, int Cl, int Cout,
-                             synthsr_stream_t stream);
+/* ... folded back onto the original taps: dw[27][Cin_total][Cout] (+=) at channels [ci_off, ci_off+Cl).  The partials are
+ * CONSUMED: on return (stream-ordered) every slot the weight-gradient kernels can write is zero again, so dwc needs the caller's
+ * zeros only before its first use (any prefix of a zeroed buffer may serve a smaller layer later) */
+int synthsr_conv3d_up_unpack(float* dwc, float* dw, int Cin_total, int ci_off, int Cl, int Cout, synthsr_stream_t stream);
 /* weight gradient of a layer part: in has Cin channels, dw rows are Cin_total wide, written at ci_off */
 /* as synthsr_conv3d_wgrad_ex, and dbias[Cout] += sum over voxels of dout (a constant-1 row of the same GEMM); NULL = skip */
 int synthsr_conv3d_wgrad_bias(const synthsr_conv_ctx* ctx, const float* in, const float* dout, float* dw, float* dbias,

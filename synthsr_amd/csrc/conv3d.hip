@@ -319,6 +319,10 @@ __global__ void pack_all_kernel(const float* __restrict__ params, float* __restr
 
 // dW of the up-sampled input channels from the 8 per-parity 27-slot gradients: every original tap t belongs to exactly
 // one slot per parity.  dw[27][Cin_total][Cout] (+= at channels [ci_off, ci_off+Cl)), dwc[8][27][Cl][Cout].
+// Thread = (slot triple s in {0,1,2}^3, ci, co): the taps of s per axis are {0} | {1} | {2} for s = 0 | 1 | 2 under parity
+// 0 | either | 1 ... i.e. tap t reads slot s(p, t); equivalently every (parity, slot) value is read by the taps that fold onto it.
+// Round 6: the partials are CONSUMED -- a second launch (same grid) writes zeros over the 8 x 8 slots the weight-gradient kernels
+// can have written, so a caller that zeroed dwc once never has to again (85 MB of memsets per training step at configs[1]).
 __global__ void up_unpack_kernel(const float* __restrict__ dwc, float* __restrict__ dw, int Cin_total, int ci_off, int Cl,
                                  int Cout, int64_t total) {
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
@@ -336,6 +340,17 @@ __global__ void up_unpack_kernel(const float* __restrict__ dwc, float* __restric
       acc += dwc[(((int64_t)p * 27 + (sz * 3 + sy) * 3 + sx) * Cl + ci) * Cout + co];
     }
     dw[((int64_t)t * Cin_total + ci_off + ci) * Cout + co] += acc;
+  }
+}
+// zeros over the slots p + {0, 1}^3 of every parity p (the only ones a folded weight-gradient kernel writes): 64 Cl Cout floats
+__global__ void up_clear_kernel(float* __restrict__ dwc, int Cl, int Cout, int64_t total64) {
+  const int64_t inner = (int64_t)Cl * Cout;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total64; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(idx / inner);  // (parity, tap of its window)
+    const int64_t rem = idx - (int64_t)q * inner;
+    const int p = q >> 3, t8 = q & 7;
+    const int slot = ((((p >> 2) & 1) + (t8 >> 2)) * 3 + ((p >> 1) & 1) + ((t8 >> 1) & 1)) * 3 + (p & 1) + (t8 & 1);
+    dwc[((int64_t)p * 27 + slot) * inner + rem] = 0.f;
   }
 }
 
@@ -3896,12 +3911,14 @@ int synthsr_conv3d_stride_unpack(const float* dwc, float* dw, int Ci, int Co, sy
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 
-int synthsr_conv3d_up_unpack(const float* dwc, float* dw, int Cin_total, int ci_off, int Cl, int Cout,
-                             synthsr_stream_t stream) {
+int synthsr_conv3d_up_unpack(float* dwc, float* dw, int Cin_total, int ci_off, int Cl, int Cout, synthsr_stream_t stream) {
   if (!dwc || !dw || Cl < 1 || Cout < 1 || ci_off < 0 || ci_off + Cl > Cin_total) return SYNTHSR_EINVAL;
   const int64_t total = (int64_t)27 * Cl * Cout;
   hipLaunchKernelGGL(up_unpack_kernel, dim3(syn_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dwc, dw, Cin_total,
                      ci_off, Cl, Cout, total);
+  if (hipGetLastError() != hipSuccess) return SYNTHSR_ELAUNCH;
+  const int64_t total64 = (int64_t)64 * Cl * Cout;  // the partials are consumed: dwc is all zeros again
+  hipLaunchKernelGGL(up_clear_kernel, dim3(syn_grid(total64, 256)), dim3(256), 0, (hipStream_t)stream, dwc, Cl, Cout, total64);
   return hipGetLastError() == hipSuccess ? SYNTHSR_OK : SYNTHSR_ELAUNCH;
 }
 

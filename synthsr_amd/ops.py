@@ -354,11 +354,14 @@ def conv3d_up_dgrad(dout, wpacked8, Cl, out=None):
     return out
 
 
-def conv3d_up_wgrad(lo, dout, dwc, dw, ci_off):
-    """weight gradient of the up-sampled channel range: dwc [8,27,Cl,Cout] scratch (zeroed here), dw (+=)"""
+def conv3d_up_wgrad(lo, dout, dwc, dw, ci_off, dwc_is_zero=False):
+    """weight gradient of the up-sampled channel range: dwc [8,27,Cl,Cout] scratch, dw (+=).  dwc is zeroed here unless the
+    caller vouches that it is all zeros (`dwc_is_zero`): the unpack kernel CONSUMES the partials and leaves zeros behind, so a
+    persistent scratch buffer needs the memset once, not once per call (UNet3D keeps that book)"""
     lib = _L()
     s = lo.shape
-    dwc.zero_()
+    if not dwc_is_zero:
+        dwc.zero_()
     if lo.dtype == torch.bfloat16:
         with _Timed('conv3d_bf16_up_wgrad', s[:3], s[3], dout.shape[3]):
             _check_wgrad(lambda: lib.synthsr_conv3d_bf16_up_wgrad(_lib.ptr(lo), _lib.ptr(dout), _lib.ptr(dwc), _lib.i3(s[:3]), int(s[3]),

@@ -841,11 +841,17 @@ class UNet3D:
                     dW = self.view(c0['w'], self.grads)
                     self._join()
                     dwc = self.buf('dwc', [8, 27, Cl, c0['cout']])
+                    # the unpack kernel leaves the partials it has folded at zero: the buffer is zeroed when it is (re)allocated
+                    # or outgrows what has been zeroed so far, not once per call (85 MB of memsets per step at configs[1])
+                    base = self._bufs['dwc']
+                    known = getattr(self, '_dwc_zeroed', (None, 0))
+                    dwc_is_zero = known[0] is base and known[1] >= dwc.numel()
+                    self._dwc_zeroed = (base, max(dwc.numel(), known[1] if known[0] is base else 0))
 
-                    def c0_wgrads(skip=skip, dz=dz, dW=dW, lo_bn=lo_bn, dwc=dwc, c0=c0, Cs=Cs):
+                    def c0_wgrads(skip=skip, dz=dz, dW=dW, lo_bn=lo_bn, dwc=dwc, c0=c0, Cs=Cs, dwc_is_zero=dwc_is_zero):
                         def one(skip_, dz_, lo_):
                             ops.conv3d_wgrad_part(skip_, dz_, dW, 0, dbias=self.view(c0['b'], self.grads))
-                            ops.conv3d_up_wgrad(lo_, dz_, dwc, dW, Cs)
+                            ops.conv3d_up_wgrad(lo_, dz_, dwc, dW, Cs, dwc_is_zero=dwc_is_zero)
                         self._pb(one, skip, dz, lo_bn)
                     self._fork(c0_wgrads, skip[..., 0].numel())
                 dskips[l] = self.buf('dskip%d' % l, self._bshape(l) + [Cs])
