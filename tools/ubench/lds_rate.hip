@@ -49,22 +49,31 @@ __global__ __launch_bounds__(512, 1) void probe(long long* out, int iters, int p
 int main() {
   long long* d;
   hipMalloc(&d, 16 * 8);
-  const int iters = 2000;
+  const int iters = 20000;
   for (int pat = 0; pat < 2; ++pat)
     for (int mode = 0; mode < 3; ++mode) {
       if (pat == 1 && mode == 2) continue;
       auto k = mode == 0 ? probe<0> : (mode == 1 ? probe<1> : probe<2>);
       hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(k, dim3(1), dim3(512), 160 * 1024, 0, d, iters, pat);
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      hipEventRecord(e0);
       hipLaunchKernelGGL(k, dim3(1), dim3(512), 160 * 1024, 0, d, iters, pat);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
       long long h[8];
       hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
       long long mx = 0;
       for (int w = 0; w < 8; ++w) mx = h[w] > mx ? h[w] : mx;
       const double bytes = 8.0 * iters * 8 * 64 * (mode == 2 ? 16 : 8);
-      printf("%-20s %-10s: %lld cycles for %d x 8 reads x 8 waves = %.1f bytes / cycle / CU, %.2f cycles per wave-instruction\n",
-             mode == 0 ? "ds_read_b64" : (mode == 1 ? "ds_read_b64_tr_b16" : "ds_read_b128"), pat ? "wgrad-tr" : "linear", mx, iters,
-             bytes / mx, (double)mx / (8.0 * iters * 8));
+      printf("%-20s %-10s: %lld ticks, %.3f ms (launch incl. fill of 160 KB) for %d x 8 reads x 8 waves = %.1f bytes / tick / CU, %.0f GB/s "
+             "of one CU = %.1f bytes / cycle at 2.4 GHz\n",
+             mode == 0 ? "ds_read_b64" : (mode == 1 ? "ds_read_b64_tr_b16" : "ds_read_b128"), pat ? "wgrad-tr" : "linear", mx, ms, iters,
+             bytes / mx, bytes / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / 2.4e9);
     }
   return 0;
 }
