@@ -378,8 +378,8 @@ int synthsr_conv3d_bf16_wgrad_part(const void* in, const void* dout, float* dw, 
  *            conv, synthsr_conv3d_bf16_fwd act 5); wpacked8 = the 8 parity sets (pack_ex mode 0), back to back;
  *  up_dgrad: dlo [lo_shape][Cl] = gradient w.r.t. lo of dout [2 lo_shape][Cout]; wpacked8 = pack_ex mode 1 sets; scratch:
  *            fp32 partial planes of the split-K path of small volumes (may be NULL);
- *  up_wgrad: dwc [8][27][Cl][Cout] fp32 (zeroed by the caller) += per-parity gradients in 27-slot form;
- *            synthsr_conv3d_up_unpack then folds them onto dw[27][Cin_total][Cout]. */
+ *  up_wgrad: dwc [8][27][Cl][Cout] fp32 (zeros before the first use) += per-parity gradients in 27-slot form;
+ *            synthsr_conv3d_up_unpack then folds them onto dw[27][Cin_total][Cout] and leaves dwc zeroed again. */
 int synthsr_conv3d_bf16_up_fwd(const void* lo, const void* wpacked8, void* out, const int lo_shape[3], int Cl, int Cout,
                                synthsr_stream_t stream);
 int synthsr_conv3d_bf16_up_dgrad(const void* dout, const void* wpacked8, void* dlo, const int lo_shape[3], int Cl, int Cout,
