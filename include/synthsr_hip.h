@@ -52,8 +52,9 @@ typedef void* synthsr_stream_t; /* hipStream_t */
  *     in the worst case, 2^-27 rms: within the rounding of an fp32 multiply-add.  Inputs, outputs, accumulation, BatchNorm
  *     statistics, gradients and weights stay fp32; against a float64 convolution the result is as accurate as the fp32-MFMA
  *     kernels' (tests/test_split_gpu.py).  Used where the layer has enough 4x4x16 tiles and channel counts that are multiples
- *     of 8 (csrc/conv_split.hip); the rest (first layer, the smallest deep layers, the folded convs' weight gradient) runs on
- *     the fp32 matrix instructions in every mode.
+ *     of 8 (csrc/conv_split.hip); the rest (first layer, forward / data gradient of the smallest deep layers) runs on the
+ *     fp32 matrix instructions in every mode.  The folded decoder convs' weight gradient runs in split arithmetic under this
+ *     value only (six products; under SPLIT9 and FP32_MFMA on the fp32 matrix instructions).
  *   SYNTHSR_ARITH_SPLIT9: the same kernels with ALL nine partial products a_i b_j (own packed weights: the three pieces of a
  *     Cout = 24 layer are not stacked): an fp32 product is reproduced exactly at 1.5x the matrix instructions.
  *   SYNTHSR_ARITH_FP32_MFMA: v_mfma_f32_4x4x1 / 16x16x4 kernels everywhere (csrc/conv3d.hip), the round-1/2 path.
