@@ -1377,9 +1377,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_fwd3_kernel(const SplitFw
 template <int MT, int NPAR, int NPROD = 6>
 __global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int NTHR = 512, RW = 2, NS = 2 * NPAR;  // rows per wave, K steps per chunk
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, g = lane >> 4, zw = wave & 3, yh = wave >> 2;
+  // Round 6 (second half): wave = (parity q of the group, part of the tile) instead of (z plane, y half) x all parities: a wave
+  // then streams ONLY its parity's weight fragments (the eight waves used to load the same 6 MT KB per K step each: 9 GB of L2
+  // reads per 80^3 launch) and multiplies them into NR = 2 NPAR voxel rows -- 6 NR MT MFMAs per 3 MT weight fragments instead of
+  // 12 MT.  Every accumulator receives the same products in the same order as before: bit-identical results.
+  constexpr int NTHR = 512, WPP = 8 / NPAR, NR = 16 / WPP, NH = NR / 4;  // waves per parity, x-rows per wave, halves of 4 rows
+  static_assert(NPAR == 2 || NPAR == 4, "two or four parities per workgroup");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4, q = wave % NPAR, part = wave / NPAR;
   const int pg = blockIdx.z;  // parity group: parities pg * NPAR + q
   const TileWalk walk = tile_walk(a.ntiles);
   const int tiles0 = a.ntiles / (a.tiles1 * a.tiles2);
@@ -1392,10 +1398,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitF
     koff[s] = (((t8 >> 2) * HY + ((t8 >> 1) & 1)) * HX + (t8 & 1)) * 16;
   }
   const int xv = syn_split_voxel(m);
-  // window origin of parity pg * NPAR + q: halo offset p per axis; the group part at run time, the rest at compile time
-  const int gpar = pg * NPAR;
-  const int lbase = ((zw * HY + RW * yh) * HX + xv) * 16 +
-                    ((((gpar >> 2) & 1) * HY + ((gpar >> 1) & 1)) * HX + (gpar & 1)) * 16;
+  // rows of this wave: r = part NR + j -> (z = r / 4, y = r % 4); window origin of its parity: halo offset p per axis
+  const int par = pg * NPAR + q, pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+  const int zw0 = part * NH;
+  const int lbase = ((zw0 * HY) * HX + xv) * 16 + ((pz * HY + py) * HX + px) * 16;
 
   constexpr int NP = HVOX * 2, NL = (NP + NTHR - 1) / NTHR;
   int prel[NL], plds[NL];
@@ -1444,16 +1450,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitF
     }
   };
 
-  // weights: 8 parity sets [piece 3][cc][step 2][mt][lane] back to back (one co-chunk: Cout <= 16 MT)
+  // weights: 8 parity sets [piece 3][cc][step 2][mt][lane] back to back (one co-chunk: Cout <= 16 MT); this wave's parity only
   const int64_t piece_stride = (int64_t)ncc * 2 * MT * 64, par_stride = 3 * piece_stride;
-  const u32x4* __restrict__ wbase = a.wp + (int64_t)gpar * par_stride + lane;
-  u32x4 wa[2][3][MT], xb[3][RW];
-  auto wload = [&](int cc, int q, int s, int slot) {
+  const u32x4* __restrict__ wbase = a.wp + (int64_t)par * par_stride + lane;
+  u32x4 wa[2][3][MT], xb[3][4];
+  auto wload = [&](int cc, int s, int slot) {
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        wa[slot][pc][mt] = wbase[(int64_t)q * par_stride + pc * piece_stride + ((cc * 2 + s) * MT + mt) * 64];
+      for (int mt = 0; mt < MT; ++mt) wa[slot][pc][mt] = wbase[pc * piece_stride + ((cc * 2 + s) * MT + mt) * 64];
   };
 
   const int64_t out_bytes = (int64_t)8 * D0 * D1 * D2 * Cout * 4;
@@ -1465,16 +1470,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitF
   if (walk.pos < walk.end) {
     load_halo(walk.pos, 0);
     store_halo(0);
-    wload(0, 0, 0, 0);
+    wload(0, 0, 0);
   }
   for (int t = walk.pos; t < walk.end; t += walk.stride) {
-    f32x4 acc[NPAR][RW][MT];
+    f32x4 acc[NR][MT];
 #pragma unroll
-    for (int q = 0; q < NPAR; ++q)
+    for (int y = 0; y < NR; ++y)
 #pragma unroll
-      for (int y = 0; y < RW; ++y)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[q][y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) acc[y][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int cc = 0; cc < ncc; ++cc) {
       __syncthreads();
       const bool more = cc + 1 < ncc || t + walk.stride < walk.end;
@@ -1482,66 +1485,66 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upfwd_kernel(const SplitF
       else if (t + walk.stride < walk.end) load_halo(t + walk.stride, 0);
       const unsigned char* img = lds + buf * BUF + lbase;
       const int cc_next = cc + 1 < ncc ? cc + 1 : 0;
-      sfor<0, NS>([&](auto N) {
-        constexpr int n = decltype(N)::value, q = n >> 1, s = n & 1, slot = n & 1;
-        constexpr int win = ((((q >> 2) & 1) * HY + ((q >> 1) & 1)) * HX + (q & 1)) * 16;  // parity q's part of the window origin
-        __builtin_amdgcn_sched_barrier(0);
+      sfor<0, 2>([&](auto S) {
+        constexpr int s = decltype(S)::value, slot = s;
+        sfor<0, NH>([&](auto H) {
+          constexpr int h = decltype(H)::value;
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+          for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-          for (int y = 0; y < RW; ++y)
-            xb[pc][y] = *reinterpret_cast<const u32x4*>(img + win + pc * PLANE + koff[s] + y * (HX * 16));
-        if constexpr (n + 1 < NS) wload(cc, (n + 1) >> 1, (n + 1) & 1, slot ^ 1);
-        else wload(cc_next, 0, 0, slot ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        sfor<0, NPROD>([&](auto CC) {
-          constexpr int c = decltype(CC)::value;
-          constexpr int qa = split_combo_a(c, NPROD), qb = split_combo_b(c, NPROD);
+            for (int y = 0; y < 4; ++y)
+              xb[pc][y] = *reinterpret_cast<const u32x4*>(img + pc * PLANE + koff[s] + (h * HY + y) * (HX * 16));
+          if constexpr (h == 0) {  // the next step's weights (other register set), one step ahead
+            if constexpr (s == 0) wload(cc, 1, 1);
+            else wload(cc_next, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          sfor<0, NPROD>([&](auto CC) {
+            constexpr int c = decltype(CC)::value;
+            constexpr int qa = split_combo_a(c, NPROD), qb = split_combo_b(c, NPROD);
 #pragma unroll
-          for (int y = 0; y < RW; ++y)
+            for (int y = 0; y < 4; ++y)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              acc[q][y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[slot][qa][mt]),
-                                                                      __builtin_bit_cast(bf16x8, xb[qb][y]), acc[q][y][mt], 0, 0, 0);
+              for (int mt = 0; mt < MT; ++mt)
+                acc[4 * h + y][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wa[slot][qa][mt]), __builtin_bit_cast(bf16x8, xb[qb][y]), acc[4 * h + y][mt], 0, 0, 0);
+          });
         });
       });
       __builtin_amdgcn_sched_barrier(0);
       if (more) store_halo(buf ^ 1);
       buf ^= 1;
     }
-    // ---- epilogue: lane (m, g): channels mt*16 + 4g + i of voxel 2 (z0 + zw, y0 + 2 yh + y, x0 + xv) + parity
+    // ---- epilogue: lane (m, g): channels mt*16 + 4g + i of voxel 2 (z0 + zw0 + r / 4, y0 + r % 4, x0 + xv) + parity
     int z0, y0, x0;
     tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
-    const int gz = z0 + zw, gx = x0 + xv, gy0 = y0 + RW * yh;
-    const bool zx_ok = gz < D0 && gx < D2;
+    const int gx = x0 + xv;
 #pragma unroll
-    for (int q = 0; q < NPAR; ++q) {
-      const int par = gpar + q, pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = mt * 16 + 4 * g;
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias && co < Cout) bias = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int co = mt * 16 + 4 * g;
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias && co < Cout) bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+      for (int r = 0; r < NR; ++r) {
+        const int gz = z0 + zw0 + (r >> 2), gy = y0 + (r & 3);
+        const bool vok = gz < D0 && gx < D2 && gy < D1 && co < Cout;
+        const uint32_t off = vok ? (uint32_t)(((2 * gz + pz) * (2 * D1) + (2 * gy + py)) * (2 * D2) + (2 * gx + px)) *
+                                       (uint32_t)(Cout * 4) + (uint32_t)(co * 4)
+                                 : OOB;
+        f32x4 v;
 #pragma unroll
-        for (int y = 0; y < RW; ++y) {
-          const bool vok = zx_ok && (gy0 + y) < D1 && co < Cout;
-          const uint32_t off = vok ? (uint32_t)(((2 * gz + pz) * (2 * D1) + (2 * (gy0 + y) + py)) * (2 * D2) + (2 * gx + px)) *
-                                         (uint32_t)(Cout * 4) + (uint32_t)(co * 4)
-                                   : OOB;
-          f32x4 v;
+        for (int i = 0; i < 4; ++i) v[i] = acc[r][mt][i] + bias[i];
+        if (a.addend) {
+          const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)off, 0, 0));
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = acc[q][y][mt][i] + bias[i];
-          if (a.addend) {
-            const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)off, 0, 0));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += b[i];
-          }
-          if (a.act == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)off, 0, 0);
+          for (int i = 0; i < 4; ++i) v[i] += b[i];
         }
+        if (a.act == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = elu_f(v[i]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)off, 0, 0);
       }
     }
   }
