@@ -202,18 +202,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
   // staging: 16-byte piece j = tid + 256 i of the 8-channel halo image -> halo voxel j >> 1, channels 4 (j & 1) .. + 3: the two
   // lanes of a voxel sit in ONE load instruction, which then touches 32 cache lines instead of 64 (the vector memory pipe's
   // tag rate, not bandwidth, is what these 96-byte-strided reads cost)
-  constexpr int NP = HVOX * 2, NL = (NP + 255) / 256;  // 1296 pieces, 6 per thread (the last one only for tid < 16)
+  // UPM (round 6): a parity's 2x2x2 window at origin o = 1 - p reads the halo coordinates o .. o + 4 (z, y) and o .. o + 16 (x)
+  // only -- 5 x 5 x 17 = 425 of the 648 voxels: the staged box is that sub-box (4 instead of 6 pieces per thread: a third less
+  // to load, split and store), placed at the origin of the chunk's parity; the rest of the image is never read
+  constexpr int SZ = UPM ? HZ - 1 : HZ, SY = UPM ? HY - 1 : HY, SX = UPM ? HX - 1 : HX;
+  constexpr int NP = SZ * SY * SX * 2, NL = (NP + 255) / 256;  // plain: 1296 pieces, 6 per thread (the last one only for tid < 16)
   int prel[NL], plds[NL];
   uint32_t pmask[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const int j = tid + 256 * i;
     const int v = j >> 1, h = j & 1;
-    const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
+    const int hz = v / (SY * SX), r = v - hz * (SY * SX), hy = r / SX, hx = r - hy * SX;
     prel[i] = ((UPS * hz * (UPS * D1) + UPS * hy) * (UPS * D2) + UPS * hx) * Cin * 4 + h * 16;
-    plds[i] = v * 16 + h * 8;
+    plds[i] = ((hz * HY + hy) * HX + hx) * 16 + h * 8;
     pmask[i] = j < NP ? ((1u << hz) | (1u << (6 + hy)) | (1u << (12 + hx))) : 0xFFFFFFFFu;
   }
+  int stg_off = 0;  // UPM: LDS offset of the sub-box of the image in flight (its parity's window origin)
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)(UPM ? 8 : 1) * D0 * D1 * D2 * Cin * 4), 0x00020000);
   f32x4 stg[NL];
@@ -228,9 +233,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
     for (int h = 0; h < HY; ++h) bad |= ((unsigned)(y0 - 1 + h) >= (unsigned)D1) ? (1u << (6 + h)) : 0u;
 #pragma unroll
     for (int h = 0; h < HX; ++h) bad |= ((unsigned)(x0 - 1 + h) >= (unsigned)D2) ? (1u << (12 + h)) : 0u;
-    const int base = UPM ? ((((2 * (z0 - 1) + ((par >> 2) & 1)) * (2 * D1) + (2 * (y0 - 1) + ((par >> 1) & 1))) * (2 * D2) +
-                             (2 * (x0 - 1) + (par & 1))) * Cin + cc * 8) * 4
-                         : ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
+    int base;
+    if constexpr (UPM) {
+      const int pz = (par >> 2) & 1, py = (par >> 1) & 1, px = par & 1, oz = 1 - pz, oy = 1 - py, ox = 1 - px;
+      base = (((2 * (z0 - 1 + oz) + pz) * (2 * D1) + (2 * (y0 - 1 + oy) + py)) * (2 * D2) + (2 * (x0 - 1 + ox) + px)) * Cin * 4 +
+             cc * 32;
+      stg_off = ((oz * HY + oy) * HX + ox) * 16;
+      // the sub-box's coordinate j is halo coordinate j + o: the out-of-range bits move down by the origin, field by field
+      bad = 0x80000000u | ((bad & 0x3Fu) >> oz) | ((((bad >> 6) & 0x3Fu) >> oy) << 6) | ((((bad >> 12) & 0x3FFFFu) >> ox) << 12);
+    } else {
+      base = ((((z0 - 1) * D1 + (y0 - 1)) * D2 + (x0 - 1)) * Cin + cc * 8) * 4;
+    }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const uint32_t vo = (pmask[i] & bad) ? OOB : (uint32_t)(prel[i] + base);
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_fwd_kernel(const SplitFwd
   };
   auto store_halo = [&](int buf) {  // four fp32 -> 3 x (four bf16 = 8 bytes)
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    unsigned char* dst = lds + buf * BUF;
+    unsigned char* dst = lds + buf * BUF + stg_off;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       if (i == NL - 1 && tid + 256 * i >= NP) continue;
