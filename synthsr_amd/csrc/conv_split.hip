@@ -684,19 +684,22 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_k
   using I4 = std::integral_constant<int, 4>;
 
   f32x4 acc[TY][NWT];
-  f32x4 ev, eb[2];
-  uint32_t eoff[2];
-  // epilogue item j = (mt, y) of the finished tile, in three segments; the addend of item j + 1 is requested before item j is
-  // worked on (two slots: its HBM latency hides behind an item's ELU / stores instead of being exposed eight times per tile)
+  // addend requests in flight ahead of the item being worked on: three (round 6: one left the HBM round trip of most of the eight
+  // items exposed; 160^3 data gradient 0.767 -> 0.751 ms, bit-identical, profiles/r06_epilogue_addend_prefetch_ab.txt; seven: no more)
+  constexpr int EA = EPI >= 2 ? 3 : 1, ENB = EA + 1;
+  f32x4 ev, eb[ENB];
+  uint32_t eoff[ENB];
+  // epilogue item j = (mt, y) of the finished tile, in three segments; the addends of items j + 1 .. j + EA are requested before
+  // item j is worked on (their HBM latency hides behind the items' ELU / stores instead of being exposed eight times per tile)
   auto epi0 = [&](int j, uint32_t row0, uint32_t yok) {
     const int mt = j / TYE, y = j % TYE;
     const int co = (chunk * MT + mt) * 16 + 4 * g;
 #if SYN_ABL & 32
     yok = 0;
 #endif
-    eoff[j & 1] = (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;   // (row0, yok: of the half's rows)
+    eoff[j % ENB] = (((yok >> y) & 1u) && co < Cout) ? row0 + (uint32_t)y * ystep + (uint32_t)(co * 4) : OOB;   // (row0, yok: of the half's rows)
     if constexpr (EPI >= 2)
-      eb[j & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)eoff[j & 1], 0, 0));
+      eb[j % ENB] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, (int)eoff[j % ENB], 0, 0));
   };
   auto epi1 = [&](int j) {
     const int mt = j / TYE, y = j % TYE;
@@ -717,11 +720,11 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_k
     for (int i = 0; i < 4; ++i) v[i] += bj[i];
     if constexpr (EPI == 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] *= elu_dy(eb[j & 1][i]);
+      for (int i = 0; i < 4; ++i) v[i] *= elu_dy(eb[j % ENB][i]);
     }
     if constexpr (EPI == 3 || EPI == 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += eb[j & 1][i];
+      for (int i = 0; i < 4; ++i) v[i] += eb[j % ENB][i];
     }
     if constexpr (EPI == 1 || EPI == 4) {
 #pragma unroll
@@ -730,10 +733,10 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_k
     ev = v;
   };
   auto epi2 = [&](int j) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), rout, (int)eoff[j & 1], 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), rout, (int)eoff[j % ENB], 0, 0);
     if constexpr (ST) {
       const int mt = j / TYE;
-      const float w = eoff[j & 1] != OOB ? 1.f : 0.f;
+      const float w = eoff[j % ENB] != OOB ? 1.f : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float r = w * ev[i];
@@ -935,10 +938,11 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3d_split_fwd2_k
 #pragma unroll
     for (int y = 0; y < TYE; ++y) yok |= (zx_ok && (yh + y) < D1) ? (1u << y) : 0u;
     T2(5);
-    epi0(0, row0, yok);
+#pragma unroll
+    for (int j = 0; j < EA && j < NITEM; ++j) epi0(j, row0, yok);
 #pragma unroll
     for (int j = 0; j < NITEM; ++j) {
-      if (j + 1 < NITEM) epi0(j + 1, row0, yok);
+      if (j + EA < NITEM) epi0(j + EA, row0, yok);
       epi1(j);
       epi2(j);
     }
