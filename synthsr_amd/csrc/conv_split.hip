@@ -2274,9 +2274,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upwgrad_kernel(const Spli
   const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.dout), 0, (int)((int64_t)8 * D0 * D1 * D2 * Cout * 4), 0x00020000);
   f32x4 xst[HZ], dst[2][NDL];  // dz: two register sets (stage parity)
-  auto load_x = [&](int t) {
-    int z0, y0, x0;
-    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+  // (tile origins are decoded ONCE per tile -- the divisions of tile_decode were a third of the kernel's scalar instructions
+  //  when every stage's request decoded its tile again)
+  auto load_x = [&](int z0, int y0, int x0) {
     uint32_t bad = 0x80000000u;
 #pragma unroll
     for (int h = 0; h < HZ; ++h) bad |= ((unsigned)(z0 - 1 + h) >= (unsigned)D0) ? (1u << h) : 0u;
@@ -2305,9 +2305,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upwgrad_kernel(const Spli
       *reinterpret_cast<u32x2*>(lds + 2 * UW_XPLANE + xl) = (u32x2){p2, q2};
     }
   };
-  auto load_dz = [&](int t, int st, int set) {  // stage st = (z plane st >> 1, x-row pair st & 1) of tile t
-    int z0, y0, x0;
-    tile_decode(t, tiles0, a.tiles1, a.tiles2, z0, y0, x0);
+  auto load_dz = [&](int z0, int y0, int x0, int st, int set) {  // stage st = (z plane st >> 1, x-row pair st & 1) of the tile at (z0, y0, x0)
     const int zp = st >> 1, yy = y0 + 2 * (st & 1) + dyl;
     const bool okr = z0 + zp < D0 && yy < D1;
     const int base = ((2 * (z0 + zp) * D1h + 2 * (y0 + 2 * (st & 1))) * D2h + 2 * x0) * Cout * 4 + dwave;
@@ -2335,10 +2333,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upwgrad_kernel(const Spli
   (void)n2;
   (void)n3;
   T2(0);
+  int cz = 0, cy = 0, cx = 0, nz = 0, ny = 0, nx = 0;  // origin of the current / the next tile
   if (walk.pos < walk.end) {
-    load_x(walk.pos);
-    load_dz(walk.pos, 0, 0);
-    load_dz(walk.pos, 1, 1);
+    tile_decode(walk.pos, tiles0, a.tiles1, a.tiles2, cz, cy, cx);
+    load_x(cz, cy, cx);
+    load_dz(cz, cy, cx, 0, 0);
+    load_dz(cz, cy, cx, 1, 1);
     store_x();
 #pragma unroll
     for (int k = 0; k < NDL; ++k) store_dz1(0, k, 0);
@@ -2347,18 +2347,19 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upwgrad_kernel(const Spli
   T2(1);
   for (int t = walk.pos; t < walk.end; t += walk.stride) {
     const bool more = t + walk.stride < walk.end;
+    if (more) tile_decode(t + walk.stride, tiles0, a.tiles1, a.tiles2, nz, ny, nx);
     sfor<0, UW_NST>([&](auto ST) {
       constexpr int st = decltype(ST)::value, zp = st >> 1, kj = st & 1;
       T2(2);
       T3(0);
       // requests: the stage after the next one into the register set this stage's image came from; the next tile's x halo
       if constexpr (st + 2 < UW_NST) {
-        load_dz(t, st + 2, kj);
+        load_dz(cz, cy, cx, st + 2, kj);
       } else {
-        if (more) load_dz(t + walk.stride, st + 2 - UW_NST, kj);
+        if (more) load_dz(nz, ny, nx, st + 2 - UW_NST, kj);
       }
       if constexpr (st == UW_NST - 1) {
-        if (more) load_x(t + walk.stride);
+        if (more) load_x(nz, ny, nx);
       }
       const bool next = st + 1 < UW_NST || more;  // is there a next stage to convert (its pieces: register set kj ^ 1)
       {
@@ -2415,6 +2416,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_upwgrad_kernel(const Spli
       __syncthreads();  // the next stage's image is complete, this stage's is free
       T2(5);
     });
+    cz = nz; cy = ny; cx = nx;
   }
   // ---- flush: this wave's parity; columns 16-23 = columns 0-7 + 8-15 of the stacked tile
 #pragma unroll
